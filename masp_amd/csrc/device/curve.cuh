@@ -1,0 +1,218 @@
+// BLS12-381 G1 / G2 group law for gfx950, written once over a field-ops policy (FpOps / Fp2Ops).
+//
+// Accumulators use extended-Jacobian "XYZZ" coordinates (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2):
+// mixed addition costs 8M + 2S and needs no inversion; infinity is ZZ = 0.  Every exceptional
+// case (P + P, P + (-P), infinity operands) is handled exactly, because proof bytes must be
+// bit-identical to the CPU prover for *any* CRS, including ones with repeated bases.
+// Replaces blst's point arithmetic used through `bls12_381::{G1Affine,G1Projective,G2...}`
+// (nam-blstrs / nam-blst, /root/reference/Cargo.lock:1385-1411).  Curve: y^2 = x^3 + 4 over Fp,
+// y^2 = x^3 + 4(1+u) over Fp2; a = 0 in both, which is all the formulas need.
+#pragma once
+#include "field.cuh"
+
+namespace masp {
+
+// Affine point.  Infinity is encoded as x = y = 0 (not on either curve), blst's convention.
+template <class O>
+struct Affine {
+    typename O::T x, y;
+};
+template <class O>
+struct Xyzz {
+    typename O::T X, Y, ZZ, ZZZ;
+};
+
+template <class O>
+MASP_HD bool aff_is_inf(const Affine<O>& p) {
+    return O::is_zero(p.x) && O::is_zero(p.y);
+}
+template <class O>
+MASP_HD Xyzz<O> xyzz_inf() {
+    Xyzz<O> r;
+    r.X = O::zero();
+    r.Y = O::zero();
+    r.ZZ = O::zero();
+    r.ZZZ = O::zero();
+    return r;
+}
+template <class O>
+MASP_HD bool xyzz_is_inf(const Xyzz<O>& p) {
+    return O::is_zero(p.ZZ);
+}
+template <class O>
+MASP_HD Xyzz<O> xyzz_from_affine(const Affine<O>& a) {
+    if (aff_is_inf(a)) return xyzz_inf<O>();
+    Xyzz<O> r;
+    r.X = a.x;
+    r.Y = a.y;
+    r.ZZ = O::one();
+    r.ZZZ = O::one();
+    return r;
+}
+template <class O>
+MASP_HD Xyzz<O> xyzz_neg(const Xyzz<O>& p) {
+    Xyzz<O> r = p;
+    r.Y = O::neg(p.Y);
+    return r;
+}
+
+// dbl-2008-s-1 for XYZZ
+template <class O>
+__host__ __device__ inline Xyzz<O> xyzz_dbl(const Xyzz<O>& p) {
+    if (xyzz_is_inf(p)) return p;
+    typedef typename O::T F;
+    F U = O::dbl(p.Y);
+    if (O::is_zero(U)) return xyzz_inf<O>();  // order-2 point: cannot occur on these curves, kept for exactness
+    F V = O::sqr(U);
+    F W = O::mul(U, V);
+    F S = O::mul(p.X, V);
+    F X2 = O::sqr(p.X);
+    F M = O::add(O::dbl(X2), X2);
+    Xyzz<O> r;
+    r.X = O::sub(O::sqr(M), O::dbl(S));
+    r.Y = O::sub(O::mul(M, O::sub(S, r.X)), O::mul(W, p.Y));
+    r.ZZ = O::mul(V, p.ZZ);
+    r.ZZZ = O::mul(W, p.ZZZ);
+    return r;
+}
+// doubling of an affine point (mdbl-2008-s-1)
+template <class O>
+__host__ __device__ inline Xyzz<O> xyzz_dbl_affine(const Affine<O>& p) {
+    if (aff_is_inf(p)) return xyzz_inf<O>();
+    typedef typename O::T F;
+    F U = O::dbl(p.y);
+    if (O::is_zero(U)) return xyzz_inf<O>();
+    F V = O::sqr(U);
+    F W = O::mul(U, V);
+    F S = O::mul(p.x, V);
+    F X2 = O::sqr(p.x);
+    F M = O::add(O::dbl(X2), X2);
+    Xyzz<O> r;
+    r.X = O::sub(O::sqr(M), O::dbl(S));
+    r.Y = O::sub(O::mul(M, O::sub(S, r.X)), O::mul(W, p.y));
+    r.ZZ = V;
+    r.ZZZ = W;
+    return r;
+}
+
+// acc += (negate ? -b : b), b affine (madd-2008-s)
+template <class O>
+__host__ __device__ inline void xyzz_madd(Xyzz<O>& acc, const Affine<O>& b, bool negate) {
+    typedef typename O::T F;
+    if (aff_is_inf(b)) return;
+    F by = negate ? O::neg(b.y) : b.y;
+    if (xyzz_is_inf(acc)) {
+        acc.X = b.x;
+        acc.Y = by;
+        acc.ZZ = O::one();
+        acc.ZZZ = O::one();
+        return;
+    }
+    F U2 = O::mul(b.x, acc.ZZ);
+    F S2 = O::mul(by, acc.ZZZ);
+    F P = O::sub(U2, acc.X);
+    F R = O::sub(S2, acc.Y);
+    if (O::is_zero(P)) {
+        if (O::is_zero(R)) {
+            Affine<O> t;
+            t.x = b.x;
+            t.y = by;
+            acc = xyzz_dbl_affine(t);
+        } else {
+            acc = xyzz_inf<O>();
+        }
+        return;
+    }
+    F PP = O::sqr(P);
+    F PPP = O::mul(P, PP);
+    F Q = O::mul(acc.X, PP);
+    F X3 = O::sub(O::sub(O::sqr(R), PPP), O::dbl(Q));
+    F Y3 = O::sub(O::mul(R, O::sub(Q, X3)), O::mul(acc.Y, PPP));
+    acc.X = X3;
+    acc.Y = Y3;
+    acc.ZZ = O::mul(acc.ZZ, PP);
+    acc.ZZZ = O::mul(acc.ZZZ, PPP);
+}
+
+// acc += b, both XYZZ (add-2008-s)
+template <class O>
+__host__ __device__ inline void xyzz_add(Xyzz<O>& acc, const Xyzz<O>& b) {
+    typedef typename O::T F;
+    if (xyzz_is_inf(b)) return;
+    if (xyzz_is_inf(acc)) {
+        acc = b;
+        return;
+    }
+    F U1 = O::mul(acc.X, b.ZZ);
+    F U2 = O::mul(b.X, acc.ZZ);
+    F S1 = O::mul(acc.Y, b.ZZZ);
+    F S2 = O::mul(b.Y, acc.ZZZ);
+    F P = O::sub(U2, U1);
+    F R = O::sub(S2, S1);
+    if (O::is_zero(P)) {
+        if (O::is_zero(R))
+            acc = xyzz_dbl(acc);
+        else
+            acc = xyzz_inf<O>();
+        return;
+    }
+    F PP = O::sqr(P);
+    F PPP = O::mul(P, PP);
+    F Q = O::mul(U1, PP);
+    F X3 = O::sub(O::sub(O::sqr(R), PPP), O::dbl(Q));
+    F Y3 = O::sub(O::mul(R, O::sub(Q, X3)), O::mul(S1, PPP));
+    acc.X = X3;
+    acc.Y = Y3;
+    acc.ZZ = O::mul(O::mul(acc.ZZ, b.ZZ), PP);
+    acc.ZZZ = O::mul(O::mul(acc.ZZZ, b.ZZZ), PPP);
+}
+
+// [k]p for a small public multiplier (double-and-add, MSB first)
+template <class O>
+__host__ __device__ inline Xyzz<O> xyzz_mul_u32(const Xyzz<O>& p, uint32_t k) {
+    Xyzz<O> r = xyzz_inf<O>();
+    for (int b = 31; b >= 0; --b) {
+        r = xyzz_dbl(r);
+        if ((k >> b) & 1) xyzz_add(r, p);
+    }
+    return r;
+}
+// [k]p for a 256-bit scalar given as 8 little-endian canonical limbs
+template <class O>
+__host__ __device__ inline Xyzz<O> xyzz_mul_scalar(const Xyzz<O>& p, const uint32_t* k) {
+    Xyzz<O> r = xyzz_inf<O>();
+    bool started = false;
+    for (int i = 7; i >= 0; --i)
+        for (int b = 31; b >= 0; --b) {
+            if (started) r = xyzz_dbl(r);
+            if ((k[i] >> b) & 1) {
+                xyzz_add(r, p);
+                started = true;
+            }
+        }
+    return r;
+}
+
+template <class O>
+__host__ __device__ inline Affine<O> xyzz_to_affine(const Xyzz<O>& p) {
+    Affine<O> r;
+    if (xyzz_is_inf(p)) {
+        r.x = O::zero();
+        r.y = O::zero();
+        return r;
+    }
+    // 1/ZZZ, then 1/ZZ = ZZZ^-2 * ZZ^2 ... cheaper: zi3 = 1/ZZZ ; zi2 = (zi3 * ZZ)^2  (since ZZ^3 = ZZZ^2 => ZZ/ZZZ = 1/Z)
+    typename O::T zi3 = O::inv(p.ZZZ);
+    typename O::T zi = O::mul(zi3, p.ZZ);
+    typename O::T zi2 = O::sqr(zi);
+    r.x = O::mul(p.X, zi2);
+    r.y = O::mul(p.Y, zi3);
+    return r;
+}
+
+typedef Affine<FpOps> G1Affine;
+typedef Affine<Fp2Ops> G2Affine;
+typedef Xyzz<FpOps> G1Xyzz;
+typedef Xyzz<Fp2Ops> G2Xyzz;
+
+}  // namespace masp

@@ -1,0 +1,272 @@
+// BLS12-381 prime-field arithmetic for gfx950: 32-bit limbs, Montgomery form, everything in VGPRs.
+//
+// Replaces, on the device, what the reference reaches through `bls12_381::Scalar` / blst field
+// types (nam-blstrs 0.7.1-nam.0 over nam-blst 0.3.15-nam.0, /root/reference/Cargo.lock:1385-1411;
+// SURVEY.md §2b).  Montgomery radix 2^(32N) is blst's own, so limb arrays are bit-compatible with
+// `blst_fp` / `blst_fr` memory.
+//
+// CDNA4 has no 64-bit integer multiplier in the vector ALU: a field product is built from
+// 32x32->64 multiply-adds (v_mad_u64_u32).  Functions are __host__ __device__ so that the very
+// same source is exercised on the CPU by tests/ (no GPU in the build container).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "consts.cuh"
+
+#define MASP_HD __host__ __device__ __forceinline__
+
+namespace masp {
+
+template <class C>
+struct Fe {
+    uint32_t v[C::N];
+};
+
+template <class C>
+MASP_HD Fe<C> fe_zero() {
+    Fe<C> r;
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) r.v[i] = 0;
+    return r;
+}
+template <class C>
+MASP_HD Fe<C> fe_one() {
+    Fe<C> r;
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) r.v[i] = C::R1[i];
+    return r;
+}
+template <class C>
+MASP_HD bool fe_is_zero(const Fe<C>& a) {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) acc |= a.v[i];
+    return acc == 0;
+}
+template <class C>
+MASP_HD bool fe_eq(const Fe<C>& a, const Fe<C>& b) {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) acc |= a.v[i] ^ b.v[i];
+    return acc == 0;
+}
+
+// r = a - p if a >= p else a   (a < 2p)
+template <class C>
+MASP_HD void fe_reduce_once(Fe<C>& a) {
+    uint32_t t[C::N];
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) {
+        uint64_t d = (uint64_t)a.v[i] - C::MOD[i] - borrow;
+        t[i] = (uint32_t)d;
+        borrow = (d >> 32) & 1;
+    }
+    if (!borrow) {
+#pragma unroll
+        for (int i = 0; i < C::N; ++i) a.v[i] = t[i];
+    }
+}
+template <class C>
+MASP_HD Fe<C> fe_add(const Fe<C>& a, const Fe<C>& b) {
+    Fe<C> r;
+    uint64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) {
+        uint64_t s = (uint64_t)a.v[i] + b.v[i] + carry;
+        r.v[i] = (uint32_t)s;
+        carry = s >> 32;
+    }
+    // both moduli leave a spare top bit, so a + b < 2p < 2^(32N): no carry out
+    fe_reduce_once(r);
+    return r;
+}
+template <class C>
+MASP_HD Fe<C> fe_sub(const Fe<C>& a, const Fe<C>& b) {
+    Fe<C> r;
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) {
+        uint64_t d = (uint64_t)a.v[i] - b.v[i] - borrow;
+        r.v[i] = (uint32_t)d;
+        borrow = (d >> 32) & 1;
+    }
+    uint32_t mask = (uint32_t)0 - (uint32_t)borrow;
+    uint64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) {
+        uint64_t s = (uint64_t)r.v[i] + (C::MOD[i] & mask) + carry;
+        r.v[i] = (uint32_t)s;
+        carry = s >> 32;
+    }
+    return r;
+}
+template <class C>
+MASP_HD Fe<C> fe_neg(const Fe<C>& a) {
+    return fe_sub(fe_zero<C>(), a);  // 0 - 0 = 0 stays canonical
+}
+template <class C>
+MASP_HD Fe<C> fe_dbl(const Fe<C>& a) {
+    return fe_add(a, a);
+}
+
+// Montgomery product a*b*R^-1 mod p, CIOS.  Because 2p - 1 < 2^(32N) the running value fits in
+// N+1 limbs (invariant t <= 2p - 1 after every outer iteration).
+template <class C>
+MASP_HD Fe<C> fe_mul(const Fe<C>& a, const Fe<C>& b) {
+    constexpr int N = C::N;
+    uint32_t t[N + 1];
+#pragma unroll
+    for (int i = 0; i <= N; ++i) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        uint32_t bi = b.v[i];
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            uint64_t x = (uint64_t)a.v[j] * bi + t[j] + c;
+            t[j] = (uint32_t)x;
+            c = x >> 32;
+        }
+        t[N] += (uint32_t)c;
+        uint32_t m = t[0] * C::INV;
+        c = ((uint64_t)m * C::MOD[0] + t[0]) >> 32;
+#pragma unroll
+        for (int j = 1; j < N; ++j) {
+            uint64_t x = (uint64_t)m * C::MOD[j] + t[j] + c;
+            t[j - 1] = (uint32_t)x;
+            c = x >> 32;
+        }
+        uint64_t x = (uint64_t)t[N] + c;
+        t[N - 1] = (uint32_t)x;
+        t[N] = (uint32_t)(x >> 32);
+    }
+    Fe<C> r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.v[i] = t[i];
+    // t[N] is 0 here: t <= 2p - 1 < 2^(32N)
+    fe_reduce_once(r);
+    return r;
+}
+template <class C>
+MASP_HD Fe<C> fe_sqr(const Fe<C>& a) {
+    return fe_mul(a, a);
+}
+
+// canonical integer limbs <-> Montgomery form
+template <class C>
+MASP_HD Fe<C> fe_to_mont(const Fe<C>& canonical) {
+    Fe<C> r2;
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) r2.v[i] = C::R2[i];
+    return fe_mul(canonical, r2);
+}
+template <class C>
+MASP_HD Fe<C> fe_from_mont(const Fe<C>& a) {
+    Fe<C> one;
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) one.v[i] = 0;
+    one.v[0] = 1;
+    return fe_mul(a, one);
+}
+// a (canonical) >= p ?
+template <class C>
+MASP_HD bool fe_canonical_ge_mod(const Fe<C>& a) {
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) {
+        uint64_t d = (uint64_t)a.v[i] - C::MOD[i] - borrow;
+        borrow = (d >> 32) & 1;
+    }
+    return !borrow;
+}
+
+// a^e for a public exponent given as N little-endian limbs (not unrolled: used off the hot path)
+template <class C>
+__host__ __device__ inline Fe<C> fe_pow(const Fe<C>& a, const uint32_t* e, int nlimbs) {
+    Fe<C> r = fe_one<C>();
+    bool started = false;
+    for (int i = nlimbs - 1; i >= 0; --i)
+        for (int b = 31; b >= 0; --b) {
+            if (started) r = fe_sqr(r);
+            if ((e[i] >> b) & 1) {
+                r = started ? fe_mul(r, a) : a;
+                started = true;
+            }
+        }
+    return r;
+}
+// Fermat inverse (inv(0) = 0)
+template <class C>
+__host__ __device__ inline Fe<C> fe_inv(const Fe<C>& a) {
+    uint32_t e[C::N];
+    for (int i = 0; i < C::N; ++i) e[i] = C::PM2[i];
+    return fe_pow(a, e, C::N);
+}
+// canonical value > (p-1)/2 ?  (zcash "lexicographically largest")
+template <class C>
+MASP_HD bool fe_canonical_gt_half(const Fe<C>& canon) {
+    // HALF - canon borrows  <=>  canon > HALF
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) {
+        uint64_t d = (uint64_t)C::HALF[i] - canon.v[i] - borrow;
+        borrow = (d >> 32) & 1;
+    }
+    return borrow != 0;
+}
+
+typedef Fe<FpCfg> Fp;
+typedef Fe<FrCfg> Fr;
+
+// ---- Fp2 = Fp[u]/(u^2 + 1) ---------------------------------------------------------------------
+struct Fp2 {
+    Fp c0, c1;
+};
+
+// A uniform static interface so the curve code is written once for G1 (Fp) and G2 (Fp2).
+struct FpOps {
+    typedef Fp T;
+    static MASP_HD T zero() { return fe_zero<FpCfg>(); }
+    static MASP_HD T one() { return fe_one<FpCfg>(); }
+    static MASP_HD T add(const T& a, const T& b) { return fe_add(a, b); }
+    static MASP_HD T sub(const T& a, const T& b) { return fe_sub(a, b); }
+    static MASP_HD T neg(const T& a) { return fe_neg(a); }
+    static MASP_HD T dbl(const T& a) { return fe_dbl(a); }
+    static MASP_HD T mul(const T& a, const T& b) { return fe_mul(a, b); }
+    static MASP_HD T sqr(const T& a) { return fe_sqr(a); }
+    static MASP_HD bool is_zero(const T& a) { return fe_is_zero(a); }
+    static MASP_HD bool eq(const T& a, const T& b) { return fe_eq(a, b); }
+    static __host__ __device__ inline T inv(const T& a) { return fe_inv(a); }
+};
+struct Fp2Ops {
+    typedef Fp2 T;
+    static MASP_HD T zero() { return {fe_zero<FpCfg>(), fe_zero<FpCfg>()}; }
+    static MASP_HD T one() { return {fe_one<FpCfg>(), fe_zero<FpCfg>()}; }
+    static MASP_HD T add(const T& a, const T& b) { return {fe_add(a.c0, b.c0), fe_add(a.c1, b.c1)}; }
+    static MASP_HD T sub(const T& a, const T& b) { return {fe_sub(a.c0, b.c0), fe_sub(a.c1, b.c1)}; }
+    static MASP_HD T neg(const T& a) { return {fe_neg(a.c0), fe_neg(a.c1)}; }
+    static MASP_HD T dbl(const T& a) { return {fe_dbl(a.c0), fe_dbl(a.c1)}; }
+    // Karatsuba: 3 base-field products
+    static __host__ __device__ inline T mul(const T& a, const T& b) {
+        Fp aa = fe_mul(a.c0, b.c0), bb = fe_mul(a.c1, b.c1);
+        Fp cc = fe_mul(fe_add(a.c0, a.c1), fe_add(b.c0, b.c1));
+        return {fe_sub(aa, bb), fe_sub(fe_sub(cc, aa), bb)};
+    }
+    // (a0 + a1)(a0 - a1) + 2 a0 a1 u : 2 base-field products
+    static __host__ __device__ inline T sqr(const T& a) {
+        Fp s = fe_add(a.c0, a.c1), d = fe_sub(a.c0, a.c1);
+        Fp m = fe_mul(a.c0, a.c1);
+        return {fe_mul(s, d), fe_dbl(m)};
+    }
+    static MASP_HD bool is_zero(const T& a) { return fe_is_zero(a.c0) && fe_is_zero(a.c1); }
+    static MASP_HD bool eq(const T& a, const T& b) { return fe_eq(a.c0, b.c0) && fe_eq(a.c1, b.c1); }
+    static __host__ __device__ inline T inv(const T& a) {
+        Fp n = fe_inv(fe_add(fe_sqr(a.c0), fe_sqr(a.c1)));
+        return {fe_mul(a.c0, n), fe_neg(fe_mul(a.c1, n))};
+    }
+};
+
+}  // namespace masp
