@@ -1,0 +1,114 @@
+/* masp_hip.h — C ABI of the MI355X-native Groth16 prover for the MASP Spend / Output / Convert circuits.
+ *
+ * The reference has no C ABI of its own for this path; these entry points sit exactly
+ * where masp_proofs calls into bellperson, i.e. what a Rust FFI layer in a fork of masp_proofs binds:
+ *
+ *   masp_hip_circuit_load   <- bellman::groth16::Parameters::<Bls12>::read(_, false)
+ *                              (/root/reference/masp_proofs/src/lib.rs:336-341) + the circuit's static
+ *                              shape that bellperson re-derives on every proof (DensityTracker, A.3 step 2)
+ *   masp_hip_prove          <- bellman::groth16::create_random_proof / create_proof
+ *                              (/root/reference/masp_proofs/src/sapling/prover.rs:117,202,252) followed by
+ *                              Proof::write (/root/reference/masp_proofs/src/prover.rs:190-193,218-221,245-248)
+ *   masp_hip_prove_batch    <- the serial per-description loops of SaplingBuilder::build
+ *                              (/root/reference/masp_primitives/src/transaction/components/sapling/builder.rs:935-1140)
+ *   masp_hip_msm_g1/_g2,
+ *   masp_hip_quotient_h     <- bellperson multiexp / EvaluationDomain (un-vendored);
+ *                              exposed so each kernel family can be checked and timed on its own.
+ *
+ * Conventions: C linkage, no exceptions across the boundary, integer return codes (0 = ok), the caller
+ * owns every buffer, outputs are written only on success, a context may be shared between threads
+ * (calls are serialised internally).  Field elements cross the boundary as 32-byte little-endian
+ * canonical integers (`Scalar::to_repr()`), points in the zcash encodings of the bellman wire format.
+ */
+#ifndef MASP_HIP_H
+#define MASP_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MASP_HIP_OK 0
+#define MASP_HIP_E_INVALID_ARG 1          /* NULL / out-of-range argument */
+#define MASP_HIP_E_PARAMS_FORMAT 2        /* undecodable Parameters bytes (the reference panics: lib.rs:337) */
+#define MASP_HIP_E_PARAMS_SHAPE 3         /* query lengths disagree with the circuit (SURVEY.md App. C invariants) */
+#define MASP_HIP_E_NO_DEVICE 4            /* no gfx950 device / HIP extension unusable — there is NO CPU fallback */
+#define MASP_HIP_E_HIP 5                  /* HIP runtime error (see masp_hip_last_error) */
+#define MASP_HIP_E_UNEXPECTED_IDENTITY 6  /* delta_g1 / delta_g2 is the identity (bellperson SynthesisError::UnexpectedIdentity) */
+#define MASP_HIP_E_NOT_LOADED 7           /* circuit slot empty */
+#define MASP_HIP_E_SCALAR_RANGE 8         /* a scalar >= r was supplied */
+
+#define MASP_HIP_MAX_CIRCUITS 8
+/* conventional slots for the three MASP circuits */
+#define MASP_HIP_SPEND 0
+#define MASP_HIP_OUTPUT 1
+#define MASP_HIP_CONVERT 2
+
+typedef struct masp_hip_ctx masp_hip_ctx;
+
+/* Static R1CS of one circuit as three CSR matrices over n_constraints rows.  Column v < n_inputs is
+ * Input(v) (Input(0) = ONE), otherwise Aux(v - n_inputs).  Terms are merged per variable and non-zero.
+ * coef: 32 bytes little-endian canonical per term.  (What `Circuit::synthesize` emits through
+ * `ConstraintSystem::enforce`, /root/reference/masp_proofs/src/circuit/sapling.rs:139-596, convert.rs:29-128.) */
+typedef struct {
+    uint32_t n_inputs, n_aux, n_constraints;
+    const uint32_t* a_rowptr; const uint32_t* a_col; const uint8_t* a_coef;
+    const uint32_t* b_rowptr; const uint32_t* b_col; const uint8_t* b_coef;
+    const uint32_t* c_rowptr; const uint32_t* c_col; const uint8_t* c_coef;
+} masp_hip_r1cs;
+
+/* One proving job (masp_hip_prove_batch). a/b/c may be NULL: they are then computed on the GPU from the
+ * circuit's static R1CS, so only the assignment crosses PCIe. */
+typedef struct {
+    uint32_t circuit;          /* slot */
+    const uint8_t* inputs;     /* n_inputs x 32 (inputs[0] = ONE) */
+    const uint8_t* aux;        /* n_aux x 32 */
+    const uint8_t* a;          /* (n_constraints + n_inputs) x 32, or NULL */
+    const uint8_t* b;
+    const uint8_t* c;
+    uint8_t r[32], s[32];      /* Groth16 blinding scalars (the reference draws them from OsRng) */
+} masp_hip_job;
+
+int masp_hip_ctx_create(int device, masp_hip_ctx** out);
+void masp_hip_ctx_destroy(masp_hip_ctx* ctx);
+const char* masp_hip_strerror(int code);
+/* last HIP runtime error text seen by this context ("" if none) */
+const char* masp_hip_last_error(const masp_hip_ctx* ctx);
+
+/* Parse `params` (bellman Parameters wire format; trailing bytes such as the MPC transcript are ignored),
+ * check the length invariants against `cs`, upload the CRS and build the window tables. */
+int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* params, size_t params_len, const masp_hip_r1cs* cs);
+
+/* One proof, blocking.  proof_out: 192 bytes = A (48, G1 compressed) | B (96, G2 compressed) | C (48). */
+int masp_hip_prove(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* inputs, const uint8_t* aux, const uint8_t* a,
+                   const uint8_t* b, const uint8_t* c, const uint8_t r[32], const uint8_t s[32], uint8_t proof_out[192]);
+/* n independent jobs, results in job order; proofs_out: n x 192 bytes. */
+int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, uint8_t* proofs_out);
+
+/* ---- building blocks (same kernels the prover uses) ---- */
+/* sum_i scalars[i] * bases[i]; bases uncompressed (96 / 192 B each), result uncompressed */
+int masp_hip_msm_g1(masp_hip_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[96]);
+int masp_hip_msm_g2(masp_hip_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[192]);
+/* h = ((A*B - C)/Z) coefficients from evaluation vectors a,b,c (nrows x 32 each, zero-padded to 2^logm);
+ * h_out: (2^logm - 1) x 32 */
+int masp_hip_quotient_h(masp_hip_ctx* ctx, const uint8_t* a, const uint8_t* b, const uint8_t* c, size_t nrows,
+                        uint32_t logm, uint8_t* h_out);
+/* in-place radix-2 NTT over Fr of 2^logm elements, natural order in and out */
+int masp_hip_ntt(masp_hip_ctx* ctx, uint8_t* data, uint32_t logm, int inverse);
+
+/* ---- measurement hooks (bench.py): device-resident workloads, HIP-event timing on the ctx stream ---- */
+/* Keeps `n` jobs' assignments resident in HBM; returns a handle (>= 0) or a negative error code. */
+int masp_hip_batch_upload(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs);
+/* Proves every resident job of `handle` once; proofs_out n x 192.  elapsed_ms (may be NULL) = HIP-event time
+ * from first kernel to last proof written, inputs already in HBM. */
+int masp_hip_batch_prove_resident(masp_hip_ctx* ctx, int handle, uint8_t* proofs_out, float* elapsed_ms);
+int masp_hip_batch_free(masp_hip_ctx* ctx, int handle);
+/* Runs the G1 MSM of query `which` (0 h, 1 l, 2 a, 3 b_g1) of circuit `slot` `iters` times on resident job
+ * `job` of `handle`; returns average kernel-sequence time per MSM in ms and the number of bases. */
+int masp_hip_bench_msm(masp_hip_ctx* ctx, int handle, size_t job, int which, int iters, float* avg_ms, uint32_t* n_bases);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

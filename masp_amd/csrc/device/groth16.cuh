@@ -1,0 +1,129 @@
+// Groth16-specific device kernels around the NTT and MSM engines: witness -> (a, b, c) evaluation
+// vectors from the static R1CS, query-scalar gathering by density, and the final proof assembly +
+// zcash encoding.  Restates, for the GPU, bellperson's `ProvingAssignment::enforce` evaluation and
+// `create_proof` tail (nam-bellperson 0.26.6-nam.1, un-vendored) and
+// `Proof::write` (/root/reference/masp_proofs/src/prover.rs:190-193).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "curve.cuh"
+#include "io.cuh"
+#include "ntt.cuh"
+
+namespace masp {
+
+// canonical -> Montgomery, n elements; flags any value >= r
+__global__ void k_fr_to_mont(const Fr* __restrict__ x, Fr* __restrict__ y, uint32_t n, int* __restrict__ range_err) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    Fr v = fr_load(x + k);
+    if (fe_canonical_ge_mod(v)) atomicOr(range_err, 1);
+    fr_store(y + k, fe_to_mont(v));
+}
+
+// One CSR row per lane: out[row] = sum_t coef[t] * w[col[t]]  (all Montgomery).  Rows
+// n_constraints .. n_constraints + n_inputs - 1 are bellperson's extra "Input(i) * 0 = 0" rows:
+// a = input value, b = c = 0 (which == 0 selects matrix A).
+__global__ void k_r1cs_eval(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, const Fr* __restrict__ coef,
+                            const Fr* __restrict__ w, uint32_t n_constraints, uint32_t n_inputs, int which, Fr* __restrict__ out) {
+    uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_constraints + n_inputs) return;
+    Fr acc = fe_zero<FrCfg>();
+    if (row < n_constraints) {
+        uint32_t lo = rowptr[row], hi = rowptr[row + 1];
+        for (uint32_t t = lo; t < hi; ++t) acc = fe_add(acc, fe_mul(fr_load(coef + t), fr_load(w + col[t])));
+    } else if (which == 0) {
+        acc = fr_load(w + (row - n_constraints));
+    }
+    fr_store(out + row, acc);
+}
+
+// dst[k] = src[idx[k]]  (32-byte scalars)
+__global__ void k_gather_scalars(const Fr* __restrict__ src, const uint32_t* __restrict__ idx, uint32_t n, Fr* __restrict__ dst) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    fr_store(dst + k, fr_load(src + idx[k]));
+}
+
+struct VkDevice {
+    G1Affine alpha_g1, beta_g1, delta_g1;
+    G2Affine beta_g2, delta_g2;
+};
+
+// Proof assembly:
+//   g_a = r*delta1 + alpha1 + A
+//   g_b = s*delta2 + beta2 + B2
+//   g_c = (r s)*delta1 + s*alpha1 + r*beta1 + s*A + r*B1 + H + L
+// One workgroup of 128 lanes: wave 0 lanes 0..5 run the six G1 scalar multiplications side by side
+// (same instruction stream, different data), wave 1 lane 0 the G2 one; then three lanes normalise
+// and encode.  rs: 8 limbs r | 8 limbs s (canonical).
+__global__ void __launch_bounds__(128) k_groth16_assemble(const VkDevice* __restrict__ vk, const G1Xyzz* __restrict__ msm_g1 /* H, L, A, B1 */,
+                                                          const G2Xyzz* __restrict__ msm_g2, const uint32_t* __restrict__ rs,
+                                                          uint8_t* __restrict__ proof) {
+    __shared__ G1Xyzz part[6];
+    __shared__ G2Xyzz part2;
+    const uint32_t tid = threadIdx.x;
+    Fr r, s;
+    for (int i = 0; i < 8; ++i) {
+        r.v[i] = rs[i];
+        s.v[i] = rs[8 + i];
+    }
+    if (tid < 6) {
+        Fr rs_prod = fe_mul(fe_to_mont(r), s);  // mont(r) * s = r*s mod q, canonical
+        G1Xyzz base;
+        Fr k;
+        switch (tid) {
+            case 0: base = xyzz_from_affine(vk->delta_g1); k = r; break;
+            case 1: base = xyzz_from_affine(vk->alpha_g1); k = s; break;
+            case 2: base = xyzz_from_affine(vk->beta_g1); k = r; break;
+            case 3: base = msm_g1[2]; k = s; break;
+            case 4: base = msm_g1[3]; k = r; break;
+            default: base = xyzz_from_affine(vk->delta_g1); k = rs_prod; break;
+        }
+        part[tid] = xyzz_mul_scalar(base, k.v);
+    }
+    if (tid == 64) part2 = xyzz_mul_scalar(xyzz_from_affine(vk->delta_g2), s.v);
+    __syncthreads();
+    if (tid == 0) {
+        G1Xyzz ga = part[0];
+        xyzz_madd(ga, vk->alpha_g1, false);
+        xyzz_add(ga, msm_g1[2]);
+        g1_write_compressed(xyzz_to_affine(ga), proof);
+    } else if (tid == 1) {
+        G1Xyzz gc = part[5];
+        xyzz_add(gc, part[1]);
+        xyzz_add(gc, part[2]);
+        xyzz_add(gc, part[3]);
+        xyzz_add(gc, part[4]);
+        xyzz_add(gc, msm_g1[0]);
+        xyzz_add(gc, msm_g1[1]);
+        g1_write_compressed(xyzz_to_affine(gc), proof + 144);
+    } else if (tid == 64) {
+        G2Xyzz gb = part2;
+        xyzz_madd(gb, vk->beta_g2, false);
+        xyzz_add(gb, *msm_g2);
+        g2_write_compressed(xyzz_to_affine(gb), proof + 48);
+    }
+}
+
+// single point XYZZ -> uncompressed bytes (building-block entry points)
+__global__ void k_g1_export(const G1Xyzz* __restrict__ p, uint8_t* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) g1_write_uncompressed(xyzz_to_affine(*p), out);
+}
+__global__ void k_g2_export(const G2Xyzz* __restrict__ p, uint8_t* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) g2_write_uncompressed(xyzz_to_affine(*p), out);
+}
+__global__ void k_g1_import_one(const uint8_t* __restrict__ raw, G1Affine* __restrict__ out, int* __restrict__ status) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int st = g1_read_uncompressed(raw, *out);
+        if (st) atomicOr(status, st);
+    }
+}
+__global__ void k_g2_import_one(const uint8_t* __restrict__ raw, G2Affine* __restrict__ out, int* __restrict__ status) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int st = g2_read_uncompressed(raw, *out);
+        if (st) atomicOr(status, st);
+    }
+}
+
+}  // namespace masp

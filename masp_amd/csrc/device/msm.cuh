@@ -1,0 +1,250 @@
+// Multi-scalar multiplication  sum_i k_i * P_i  over BLS12-381 G1 / G2 for gfx950.
+//
+// Replaces bellperson's `multiexp` (nam-bellperson 0.26.6-nam.1, un-vendored; the six G1 calls and
+// two G2 calls per proof listed in SURVEY.md A.3 step 4, reached from
+// /root/reference/masp_proofs/src/sapling/prover.rs:117,202,252) and the `<G1>_multiexp` kernels of
+// nam-ec-gpu-gen.  Not a port of either: the design spends HBM capacity (288 GB) to
+// remove ALU work, which is what bounds this path on CDNA4.
+//
+//   load time   T[j][i] = 2^(c*j) * P_i  for every window j (affine, Montgomery), so that all windows
+//               share ONE bucket set and no per-window Horner doublings exist at prove time.
+//   prove time  (1) digits   : signed c-bit digits of every scalar; zero scalars vanish, scalars equal
+//                              to 1 (≈70 % of a MASP witness) go to a "ones" list;
+//                              histogram of sub-bucket keys.
+//               (2) scan     : exclusive prefix sum of the histogram.
+//               (3) scatter  : counting sort of (table index, sign) by sub-bucket.
+//               (4) accumulate: one lane per sub-bucket, mixed XYZZ additions of gathered table rows.
+//               (5) reduce   : sub-buckets -> buckets -> sum_w w*B_w by chunked running sums;
+//                              the ones list by a plain tree; total = weighted + ones.
+// Group arithmetic is exact, so the result (after affine normalisation) is bit-identical to any
+// other evaluation order — which is what lets the sort be unstable and the atomics unordered.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "curve.cuh"
+#include "io.cuh"
+
+namespace masp {
+
+struct MsmGeom {
+    int c;        // window bits
+    int W;        // windows = ceil(256 / c)
+    int nb;       // buckets = 2^(c-1)  (|digit| in 1..2^(c-1))
+    int sl_log;   // log2 of sub-buckets per bucket
+    __host__ __device__ int nsub() const { return nb << sl_log; }
+};
+static inline MsmGeom msm_geom(int c, int sl_log) {
+    MsmGeom g;
+    g.c = c;
+    g.W = (256 + c - 1) / c;
+    g.nb = 1 << (c - 1);
+    g.sl_log = sl_log;
+    return g;
+}
+
+static constexpr uint32_t ENT_NONE = 0xffffffffu;
+
+// ---- load time ----------------------------------------------------------------------------------
+// raw uncompressed bytes -> T[0][i]; status word collects PT_* bits (infinity is legal in a generic
+// MSM and contributes nothing).
+template <class O, int BYTES>
+__global__ void k_msm_import(const uint8_t* __restrict__ raw, Affine<O>* __restrict__ tab, uint32_t n, int* __restrict__ status) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<O> p;
+    int st;
+    if constexpr (BYTES == 96)
+        st = g1_read_uncompressed(raw + (size_t)i * 96, p);
+    else
+        st = g2_read_uncompressed(raw + (size_t)i * 192, p);
+    if (st & ~PT_INFINITY) {
+        atomicOr(status, st);
+        p.x = O::zero();
+        p.y = O::zero();
+    } else if (st & PT_INFINITY) {
+        atomicOr(status, PT_INFINITY);
+    }
+    tab[i] = p;
+}
+// T[j][i] = 2^c * T[j-1][i]
+template <class O>
+__global__ void k_msm_precompute(Affine<O>* __restrict__ tab, uint32_t n, int c, int W) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<O> p = tab[i];
+    for (int j = 1; j < W; ++j) {
+        Xyzz<O> q = xyzz_dbl_affine(p);
+        for (int k = 1; k < c; ++k) q = xyzz_dbl(q);
+        p = xyzz_to_affine(q);
+        tab[(size_t)j * n + i] = p;
+    }
+}
+
+// ---- (1) digits ---------------------------------------------------------------------------------
+// scalars: n x 8 canonical little-endian limbs.  ent[j*n + i] = sub-bucket key | sign<<31, or ENT_NONE.
+__global__ void k_msm_digits(const uint32_t* __restrict__ scalars, uint32_t n, MsmGeom g, uint32_t* __restrict__ ent,
+                             uint32_t* __restrict__ hist, uint32_t* __restrict__ ones, uint32_t* __restrict__ n_ones) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* sw = scalars + (size_t)i * 8;
+    const uint4* sp = reinterpret_cast<const uint4*>(sw);
+    uint4 lo = sp[0], hi = sp[1];
+    uint32_t rest = lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w;
+    bool is_zero = (rest | lo.x) == 0;
+    bool is_one = rest == 0 && lo.x == 1;
+    if (is_one) {
+        uint32_t k = atomicAdd(n_ones, 1u);
+        ones[k] = i;
+    }
+    bool skip = is_zero || is_one;
+    uint32_t carry = 0;
+    const uint32_t mask = (1u << g.c) - 1u;
+    const uint32_t half = 1u << (g.c - 1);
+    const uint32_t slmask = (1u << g.sl_log) - 1u;
+    for (int j = 0; j < g.W; ++j) {
+        uint32_t e = ENT_NONE;
+        if (!skip) {
+            int bit = j * g.c;
+            int w = bit >> 5, off = bit & 31;
+            // (re-read from L1/L2 instead of indexing a register array dynamically)
+            uint64_t two = ((uint64_t)(w + 1 < 8 ? sw[w + 1] : 0u) << 32) | sw[w];
+            uint32_t v = (uint32_t)(two >> off) & mask;
+            v += carry;
+            uint32_t neg = 0;
+            if (v > half) {
+                v = (1u << g.c) - v;
+                neg = 1;
+                carry = 1;
+            } else {
+                carry = 0;
+            }
+            if (v != 0) {
+                uint32_t key = ((v - 1) << g.sl_log) | (i & slmask);
+                e = key | (neg << 31);
+                atomicAdd(&hist[key], 1u);
+            }
+        }
+        ent[(size_t)j * n + i] = e;
+    }
+}
+
+// ---- (2) exclusive scan, single workgroup ----------------------------------------------------------
+__global__ void k_scan_exclusive(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t base;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (uint32_t start = 0; start < n; start += blockDim.x) {
+        uint32_t idx = start + tid;
+        uint32_t v = idx < n ? in[idx] : 0;
+        uint32_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t y = __shfl_up(x, d, 64);
+            if ((int)lane >= d) x += y;
+        }
+        if (lane == 63) wsum[wid] = x;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t k = 0; k < wid; ++k) woff += wsum[k];
+        uint32_t b = base;
+        if (idx < n) out[idx] = b + woff + x - v;
+        __syncthreads();
+        if (tid == blockDim.x - 1) base = b + woff + x;
+        __syncthreads();
+    }
+}
+
+// ---- (3) scatter --------------------------------------------------------------------------------
+__global__ void k_msm_scatter(const uint32_t* __restrict__ ent, uint32_t total, uint32_t n, const uint32_t* __restrict__ start,
+                              uint32_t* __restrict__ fill, uint32_t* __restrict__ sorted) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    uint32_t e = ent[t];
+    if (e == ENT_NONE) return;
+    uint32_t key = e & 0x7fffffffu;
+    uint32_t pos = start[key] + atomicAdd(&fill[key], 1u);
+    // t = j*n + i is exactly the table row index
+    sorted[pos] = t | (e & 0x80000000u);
+}
+
+// ---- (4) accumulate -----------------------------------------------------------------------------
+template <class O>
+__global__ void __launch_bounds__(64)
+k_msm_accumulate(const Affine<O>* __restrict__ tab, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ start,
+                 const uint32_t* __restrict__ count, uint32_t nsub, Xyzz<O>* __restrict__ sub) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nsub) return;
+    uint32_t lo = start[b], cnt = count[b];
+    Xyzz<O> acc = xyzz_inf<O>();
+    for (uint32_t k = 0; k < cnt; ++k) {
+        uint32_t e = sorted[lo + k];
+        Affine<O> p = tab[e & 0x7fffffffu];
+        xyzz_madd(acc, p, (e >> 31) != 0);
+    }
+    sub[b] = acc;
+}
+
+// ---- (5) reductions -----------------------------------------------------------------------------
+// out[t] = sum of in[t*f .. min(n, t*f+f))
+template <class O>
+__global__ void __launch_bounds__(64) k_xyzz_reduce(const Xyzz<O>* __restrict__ in, uint32_t n, uint32_t f, Xyzz<O>* __restrict__ out) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t lo = t * f;
+    if (lo >= n) return;
+    uint32_t hi = lo + f < n ? lo + f : n;
+    Xyzz<O> acc = in[lo];
+    for (uint32_t k = lo + 1; k < hi; ++k) xyzz_add(acc, in[k]);
+    out[t] = acc;
+}
+// ones list: out[t] = sum of tab[ones[t*f ..]]  (window-0 table rows)
+template <class O>
+__global__ void __launch_bounds__(64) k_msm_ones(const Affine<O>* __restrict__ tab, const uint32_t* __restrict__ ones,
+                                                 const uint32_t* __restrict__ n_ones, uint32_t f, Xyzz<O>* __restrict__ out,
+                                                 uint32_t out_cap) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= out_cap) return;
+    uint32_t n = *n_ones;
+    uint32_t lo = t * f;
+    Xyzz<O> acc = xyzz_inf<O>();
+    if (lo < n) {
+        uint32_t hi = lo + f < n ? lo + f : n;
+        for (uint32_t k = lo; k < hi; ++k) xyzz_madd(acc, tab[ones[k]], false);
+    }
+    out[t] = acc;
+}
+// One level of the weighted sum  V(B, off) = sum_k (k + off) * B[k]:
+// chunk ch of `cs` elements yields S[ch] = sum_l B[ch*cs+l] and T[ch] = sum_l (l + off) * B[ch*cs+l];
+// then V(B, off) = sum_ch T[ch] + cs * V(S, 0).
+template <class O>
+__global__ void __launch_bounds__(64) k_msm_wsum_level(const Xyzz<O>* __restrict__ B, uint32_t m, uint32_t cs, uint32_t off,
+                                                       Xyzz<O>* __restrict__ S, Xyzz<O>* __restrict__ T) {
+    uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t lo = ch * cs;
+    if (lo >= m) return;
+    uint32_t hi = lo + cs < m ? lo + cs : m;
+    Xyzz<O> run = xyzz_inf<O>(), acc = xyzz_inf<O>();
+    // running sum from the top: after the loop  acc = sum_l (l - lo + off) * B[l],  run = sum_l B[l]
+    for (uint32_t l = hi; l-- > lo;) {
+        xyzz_add(run, B[l]);
+        if (l > lo || off) xyzz_add(acc, run);
+    }
+    S[ch] = run;
+    T[ch] = acc;
+}
+// V = T0 + cs*(T1 + cs*(T2 + ...)) + ones ;  tsum[l] holds the fully reduced T of level l.
+template <class O>
+__global__ void k_msm_combine(const Xyzz<O>* __restrict__ tsum, int levels, int cs_log, const Xyzz<O>* __restrict__ ones_sum,
+                              Xyzz<O>* __restrict__ out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    Xyzz<O> acc = xyzz_inf<O>();
+    for (int l = levels - 1; l >= 0; --l) {
+        for (int k = 0; k < cs_log; ++k) acc = xyzz_dbl(acc);
+        xyzz_add(acc, tsum[l]);
+    }
+    xyzz_add(acc, *ones_sum);
+    *out = acc;
+}
+
+}  // namespace masp

@@ -1,0 +1,144 @@
+// Radix-2 NTT over the BLS12-381 scalar field and the Groth16 quotient  h = (A*B - C)/Z  for gfx950.
+//
+// Replaces bellperson's `EvaluationDomain::{ifft, coset_fft, mul_assign, sub_assign,
+// divide_by_z_on_coset, icoset_fft}` sequence (nam-bellperson 0.26.6-nam.1, un-vendored; SURVEY.md A.3
+// step 3, reached from /root/reference/masp_proofs/src/sapling/prover.rs:117,202,252) and the
+// `<Fr>_radix_fft` kernel of nam-ec-gpu-gen.
+//
+// A transform of 2^logm points is: one bit-reversal pass (fused with whatever pointwise work
+// precedes it) and then ceil(logm / 10) LDS passes, each doing up to 10 butterfly stages on a
+// 1024-element (32 KiB) tile held in LDS.  The whole data set of a MASP circuit (<= 4 MiB) stays
+// in L2 / Infinity Cache between passes.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "field.cuh"
+
+namespace masp {
+
+static constexpr int NTT_LT = 10;  // log2 of the LDS tile
+
+__device__ __forceinline__ uint32_t bitrev(uint32_t k, uint32_t logm) { return __brev(k) >> (32 - logm); }
+
+__device__ __forceinline__ Fr fr_load(const Fr* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1];
+    Fr r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void fr_store(Fr* p, const Fr& r) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
+
+// table[k] = scale * base^k  (Montgomery in, Montgomery out; `plain` strips the Montgomery factor)
+__global__ void k_fr_powers(Fr* __restrict__ table, uint32_t n, Fr base, Fr scale, int plain) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t e[1] = {k};
+    Fr r = fe_mul(fe_pow(base, e, 1), scale);
+    if (plain) r = fe_from_mont(r);
+    fr_store(table + k, r);
+}
+
+// ---- bit-reversal passes with fused pointwise work ------------------------------------------------
+// y[rev(k)] = to_mont(x[k]) for k < nrows, 0 above   (x canonical little-endian limbs)
+__global__ void k_ntt_load_bitrev(const Fr* __restrict__ x, uint32_t nrows, Fr* __restrict__ y, uint32_t logm) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (1u << logm)) return;
+    Fr v = fe_zero<FrCfg>();
+    if (k < nrows) v = fe_to_mont(fr_load(x + k));
+    fr_store(y + bitrev(k, logm), v);
+}
+// same but the input is already in Montgomery form
+__global__ void k_ntt_copy_bitrev(const Fr* __restrict__ x, uint32_t nrows, Fr* __restrict__ y, uint32_t logm) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (1u << logm)) return;
+    Fr v = fe_zero<FrCfg>();
+    if (k < nrows) v = fr_load(x + k);
+    fr_store(y + bitrev(k, logm), v);
+}
+// y[rev(k)] = x[k] * scale[k]
+__global__ void k_ntt_scale_bitrev(const Fr* __restrict__ x, const Fr* __restrict__ scale, Fr* __restrict__ y, uint32_t logm) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (1u << logm)) return;
+    fr_store(y + bitrev(k, logm), fe_mul(fr_load(x + k), fr_load(scale + k)));
+}
+// y[rev(k)] = (a[k] * b[k] - c[k]) * zinv
+__global__ void k_ntt_abc_bitrev(const Fr* __restrict__ a, const Fr* __restrict__ b, const Fr* __restrict__ c, Fr zinv,
+                                 Fr* __restrict__ y, uint32_t logm) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (1u << logm)) return;
+    Fr v = fe_mul(fe_sub(fe_mul(fr_load(a + k), fr_load(b + k)), fr_load(c + k)), zinv);
+    fr_store(y + bitrev(k, logm), v);
+}
+// y[k] = x[k] * scale[k]  (no permutation; with a plain-form scale table this also leaves Montgomery form)
+__global__ void k_fr_scale(const Fr* __restrict__ x, const Fr* __restrict__ scale, Fr* __restrict__ y, uint32_t n) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    fr_store(y + k, fe_mul(fr_load(x + k), fr_load(scale + k)));
+}
+__global__ void k_fr_from_mont(const Fr* __restrict__ x, Fr* __restrict__ y, uint32_t n) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    fr_store(y + k, fe_from_mont(fr_load(x + k)));
+}
+
+// ---- LDS pass: stages [s0, s0 + nst) of a decimation-in-time transform on bit-reversed input -------
+// Index bits of an element: [0, s0) "lo" | [s0, s0+nst) "h" (the butterfly bits of this pass) | rest "top".
+// A tile holds every h for `cols` = 2^(LT - nst) consecutive columns, column = top * 2^s0 + lo.
+// tw[k] = w^k for k < m/2 (w = omega or omega^-1).
+__global__ void __launch_bounds__(256) k_ntt_pass(Fr* __restrict__ data, const Fr* __restrict__ tw, uint32_t logm, uint32_t s0,
+                                                  uint32_t nst) {
+    __shared__ uint4 tile[2 << NTT_LT];  // 2 x uint4 per element, split planes to keep ds_read_b128 conflict-light
+    const uint32_t lt = nst + (NTT_LT - nst < logm - nst ? NTT_LT - nst : logm - nst);  // log2 of this tile's size
+    const uint32_t cols_log = lt - nst;
+    const uint32_t cols = 1u << cols_log;
+    const uint32_t tsize = 1u << lt;
+    const uint32_t col0 = blockIdx.x << cols_log;
+    const uint32_t lomask = (1u << s0) - 1u;
+    // load
+    for (uint32_t L = threadIdx.x; L < tsize; L += blockDim.x) {
+        uint32_t h = L >> cols_log, col = col0 + (L & (cols - 1));
+        uint32_t idx = ((col >> s0) << (s0 + nst)) | (h << s0) | (col & lomask);
+        const uint4* q = reinterpret_cast<const uint4*>(data + idx);
+        tile[L] = q[0];
+        tile[tsize + L] = q[1];
+    }
+    __syncthreads();
+    for (uint32_t q = 0; q < nst; ++q) {
+        const uint32_t s = s0 + q;
+        for (uint32_t b = threadIdx.x; b < (tsize >> 1); b += blockDim.x) {
+            uint32_t cl = b & (cols - 1), hb = b >> cols_log;
+            uint32_t hj = hb & ((1u << q) - 1u), hg = hb >> q;
+            uint32_t L0 = (((hg << (q + 1)) | hj) << cols_log) | cl;
+            uint32_t L1 = L0 + (cols << q);
+            uint32_t col = col0 + cl;
+            uint32_t jglob = (hj << s0) | (col & lomask);
+            Fr w = fr_load(tw + ((size_t)jglob << (logm - s - 1)));
+            Fr u, v;
+            uint4 a0 = tile[L0], a1 = tile[tsize + L0], b0 = tile[L1], b1 = tile[tsize + L1];
+            u.v[0] = a0.x; u.v[1] = a0.y; u.v[2] = a0.z; u.v[3] = a0.w; u.v[4] = a1.x; u.v[5] = a1.y; u.v[6] = a1.z; u.v[7] = a1.w;
+            v.v[0] = b0.x; v.v[1] = b0.y; v.v[2] = b0.z; v.v[3] = b0.w; v.v[4] = b1.x; v.v[5] = b1.y; v.v[6] = b1.z; v.v[7] = b1.w;
+            v = fe_mul(v, w);
+            Fr x = fe_add(u, v), y = fe_sub(u, v);
+            tile[L0] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+            tile[tsize + L0] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+            tile[L1] = make_uint4(y.v[0], y.v[1], y.v[2], y.v[3]);
+            tile[tsize + L1] = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
+        }
+        __syncthreads();
+    }
+    for (uint32_t L = threadIdx.x; L < tsize; L += blockDim.x) {
+        uint32_t h = L >> cols_log, col = col0 + (L & (cols - 1));
+        uint32_t idx = ((col >> s0) << (s0 + nst)) | (h << s0) | (col & lomask);
+        uint4* q = reinterpret_cast<uint4*>(data + idx);
+        q[0] = tile[L];
+        q[1] = tile[tsize + L];
+    }
+}
+
+}  // namespace masp

@@ -1,0 +1,194 @@
+// Host-side driver of the MSM kernels (device/msm.cuh): owns the precomputed window tables of one
+// base set and a reusable workspace, and enqueues one MSM on a HIP stream without any host sync.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <vector>
+
+#include "device/msm.cuh"
+#include "util.h"
+
+namespace masp {
+
+// ---- base set: T[j][i] = 2^(c j) P_i -------------------------------------------------------------
+template <class O, int BYTES>
+struct MsmBases {
+    MsmGeom g{};
+    uint32_t n = 0;
+    Affine<O>* tab = nullptr;  // W * n rows
+    int import_status = 0;     // PT_* bits seen while decoding
+
+    ~MsmBases() { release(); }
+    void release() {
+        if (tab) hipFree(tab);
+        tab = nullptr;
+    }
+    static MsmGeom pick_geom(uint32_t n) {
+        // window width by problem size: bucket work (2^(c-1) * ~3 adds) must stay well under n * W adds
+        int c = n >= (1u << 15) ? 16 : n >= (1u << 12) ? 13 : n >= (1u << 8) ? 10 : 7;
+        int sl = c >= 16 ? 3 : c >= 13 ? 2 : 0;
+        const char* e = getenv("MASP_HIP_MSM_C");
+        if (e) c = atoi(e);
+        e = getenv("MASP_HIP_MSM_SL");
+        if (e) sl = atoi(e);
+        return msm_geom(c, sl);
+    }
+    // raw: device pointer to n uncompressed points (bellman wire format)
+    int load_device(const uint8_t* d_raw, uint32_t n_, hipStream_t s) {
+        release();
+        n = n_;
+        g = pick_geom(n);
+        if (n == 0) return MASP_HIP_OK;
+        HIP_TRY(hipMalloc(&tab, sizeof(Affine<O>) * (size_t)g.W * n));
+        int* d_status;
+        HIP_TRY(hipMalloc(&d_status, sizeof(int)));
+        HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(int), s));
+        dim3 grid((n + 63) / 64), block(64);
+        hipLaunchKernelGGL((k_msm_import<O, BYTES>), grid, block, 0, s, d_raw, tab, n, d_status);
+        hipLaunchKernelGGL((k_msm_precompute<O>), grid, block, 0, s, tab, n, g.c, g.W);
+        HIP_TRY(hipMemcpyAsync(&import_status, d_status, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        hipFree(d_status);
+        return MASP_HIP_OK;
+    }
+    int load_host(const uint8_t* raw, uint32_t n_, hipStream_t s) {
+        uint8_t* d_raw = nullptr;
+        if (n_) {
+            HIP_TRY(hipMalloc(&d_raw, (size_t)n_ * BYTES));
+            HIP_TRY(hipMemcpyAsync(d_raw, raw, (size_t)n_ * BYTES, hipMemcpyHostToDevice, s));
+        }
+        int rc = load_device(d_raw, n_, s);
+        if (d_raw) hipFree(d_raw);
+        return rc;
+    }
+};
+
+// ---- workspace ------------------------------------------------------------------------------------
+template <class O>
+struct MsmWorkspace {
+    static constexpr uint32_t CS_LOG = 5;   // running-sum chunk = 32 buckets
+    static constexpr uint32_t RF = 32;      // plain reduction fan-in
+    static constexpr uint32_t ONES_F = 32;  // ones-list: bases per lane in the first pass
+
+    size_t cap_ent = 0, cap_sub = 0, cap_n = 0, cap_nb = 0;
+    uint32_t *ent = nullptr, *sorted = nullptr, *hist = nullptr, *start = nullptr, *fill = nullptr;
+    uint32_t *ones = nullptr, *n_ones = nullptr;
+    Xyzz<O>*sub = nullptr, *bkt = nullptr, *S[2] = {nullptr, nullptr}, *T = nullptr, *R[2] = {nullptr, nullptr};
+    Xyzz<O>*tsum = nullptr, *ones_sum = nullptr;
+
+    ~MsmWorkspace() { release(); }
+    void release() {
+        void* ptrs[] = {ent, sorted, hist, start, fill, ones, n_ones, sub, bkt, S[0], S[1], T, R[0], R[1], tsum, ones_sum};
+        for (void* p : ptrs)
+            if (p) hipFree(p);
+        ent = sorted = hist = start = fill = ones = n_ones = nullptr;
+        sub = bkt = S[0] = S[1] = T = R[0] = R[1] = tsum = ones_sum = nullptr;
+        cap_ent = cap_sub = cap_n = cap_nb = 0;
+    }
+    int reserve(uint32_t n, const MsmGeom& g) {
+        size_t need_ent = (size_t)n * g.W, need_sub = (size_t)g.nsub();
+        if (need_ent <= cap_ent && need_sub <= cap_sub && n <= cap_n && (size_t)g.nb <= cap_nb) return MASP_HIP_OK;
+        need_ent = std::max(need_ent, cap_ent);
+        need_sub = std::max(need_sub, cap_sub);
+        size_t need_n = std::max<size_t>(n, cap_n), need_nb = std::max<size_t>(g.nb, cap_nb);
+        release();
+        cap_ent = need_ent;
+        cap_sub = need_sub;
+        cap_n = need_n;
+        cap_nb = need_nb;
+        n = (uint32_t)need_n;
+        size_t chunks = (cap_nb + (1u << CS_LOG) - 1) >> CS_LOG;
+        size_t rcap = std::max<size_t>(std::max<size_t>(chunks, (n + ONES_F - 1) / ONES_F), 1);
+        HIP_TRY(hipMalloc(&ent, 4 * std::max<size_t>(cap_ent, 1)));
+        HIP_TRY(hipMalloc(&sorted, 4 * std::max<size_t>(cap_ent, 1)));
+        HIP_TRY(hipMalloc(&hist, 4 * cap_sub));
+        HIP_TRY(hipMalloc(&start, 4 * cap_sub));
+        HIP_TRY(hipMalloc(&fill, 4 * cap_sub));
+        HIP_TRY(hipMalloc(&ones, 4 * std::max<size_t>(n, 1)));
+        HIP_TRY(hipMalloc(&n_ones, 4));
+        HIP_TRY(hipMalloc(&sub, sizeof(Xyzz<O>) * cap_sub));
+        HIP_TRY(hipMalloc(&bkt, sizeof(Xyzz<O>) * cap_nb));
+        HIP_TRY(hipMalloc(&S[0], sizeof(Xyzz<O>) * std::max(chunks, rcap)));
+        HIP_TRY(hipMalloc(&S[1], sizeof(Xyzz<O>) * std::max(chunks, rcap)));
+        HIP_TRY(hipMalloc(&T, sizeof(Xyzz<O>) * chunks));
+        HIP_TRY(hipMalloc(&R[0], sizeof(Xyzz<O>) * rcap));
+        HIP_TRY(hipMalloc(&R[1], sizeof(Xyzz<O>) * rcap));
+        HIP_TRY(hipMalloc(&tsum, sizeof(Xyzz<O>) * 32));
+        HIP_TRY(hipMalloc(&ones_sum, sizeof(Xyzz<O>)));
+        return MASP_HIP_OK;
+    }
+
+    // reduce `m` points at `src` to one at `dst` (src is clobbered only if it is one of R[]).
+    void reduce_to_one(hipStream_t s, const Xyzz<O>* src, uint32_t m, Xyzz<O>* dst) {
+        int flip = 0;
+        const Xyzz<O>* cur = src;
+        while (true) {
+            uint32_t outn = (m + RF - 1) / RF;
+            Xyzz<O>* out = outn == 1 ? dst : R[flip];
+            hipLaunchKernelGGL((k_xyzz_reduce<O>), dim3((outn + 63) / 64), dim3(64), 0, s, cur, m, RF, out);
+            if (outn == 1) break;
+            cur = out;
+            m = outn;
+            flip ^= 1;
+        }
+    }
+};
+
+// Enqueue sum_i scalars[i] * P_i on stream `s`.  d_scalars: n x 8 canonical LE limbs on the device.
+// d_out: one XYZZ point on the device.  No host synchronisation.
+template <class O, int BYTES>
+int msm_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, MsmWorkspace<O>& ws, const uint32_t* d_scalars, Xyzz<O>* d_out) {
+    const MsmGeom& g = B.g;
+    const uint32_t n = B.n;
+    if (n == 0) {
+        HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(Xyzz<O>), s));  // all-zero limbs = infinity (ZZ = 0)
+        return MASP_HIP_OK;
+    }
+    int rc = ws.reserve(n, g);
+    if (rc) return rc;
+    const uint32_t nsub = g.nsub();
+    const uint32_t total = n * g.W;
+    HIP_TRY(hipMemsetAsync(ws.hist, 0, 4 * (size_t)nsub, s));
+    HIP_TRY(hipMemsetAsync(ws.fill, 0, 4 * (size_t)nsub, s));
+    HIP_TRY(hipMemsetAsync(ws.n_ones, 0, 4, s));
+    hipLaunchKernelGGL(k_msm_digits, dim3((n + 255) / 256), dim3(256), 0, s, d_scalars, n, g, ws.ent, ws.hist, ws.ones, ws.n_ones);
+    hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, s, ws.hist, ws.start, nsub);
+    hipLaunchKernelGGL(k_msm_scatter, dim3((total + 255) / 256), dim3(256), 0, s, ws.ent, total, n, ws.start, ws.fill, ws.sorted);
+    hipLaunchKernelGGL((k_msm_accumulate<O>), dim3((nsub + 63) / 64), dim3(64), 0, s, B.tab, ws.sorted, ws.start, ws.hist, nsub, ws.sub);
+    // sub-buckets -> buckets
+    const Xyzz<O>* bk = ws.sub;
+    if (g.sl_log) {
+        hipLaunchKernelGGL((k_xyzz_reduce<O>), dim3((g.nb + 63) / 64), dim3(64), 0, s, ws.sub, nsub, 1u << g.sl_log, ws.bkt);
+        bk = ws.bkt;
+    }
+    // weighted sum by levels of chunked running sums
+    const uint32_t cs = 1u << ws.CS_LOG;
+    uint32_t m = g.nb, off = 1;
+    int level = 0, flip = 0;
+    do {
+        uint32_t chunks = (m + cs - 1) / cs;
+        hipLaunchKernelGGL((k_msm_wsum_level<O>), dim3((chunks + 63) / 64), dim3(64), 0, s, bk, m, cs, off, ws.S[flip], ws.T);
+        ws.reduce_to_one(s, ws.T, chunks, ws.tsum + level);
+        bk = ws.S[flip];
+        flip ^= 1;
+        m = chunks;
+        off = 0;
+        ++level;
+    } while (m > 1);
+    // ones list
+    uint32_t ones_out = (n + ws.ONES_F - 1) / ws.ONES_F;
+    hipLaunchKernelGGL((k_msm_ones<O>), dim3((ones_out + 63) / 64), dim3(64), 0, s, B.tab, ws.ones, ws.n_ones, ws.ONES_F, ws.R[0], ones_out);
+    if (ones_out == 1) {
+        HIP_TRY(hipMemcpyAsync(ws.ones_sum, ws.R[0], sizeof(Xyzz<O>), hipMemcpyDeviceToDevice, s));
+    } else {
+        // R[0] is the source; reduce_to_one writes intermediate results to R[flip] starting with R[0]
+        // -> stage through S[flip] (free by now) to keep source and destination distinct
+        HIP_TRY(hipMemcpyAsync(ws.S[flip], ws.R[0], sizeof(Xyzz<O>) * ones_out, hipMemcpyDeviceToDevice, s));
+        ws.reduce_to_one(s, ws.S[flip], ones_out, ws.ones_sum);
+    }
+    hipLaunchKernelGGL((k_msm_combine<O>), dim3(1), dim3(64), 0, s, ws.tsum, level, (int)ws.CS_LOG, ws.ones_sum, d_out);
+    return MASP_HIP_OK;
+}
+
+}  // namespace masp

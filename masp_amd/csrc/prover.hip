@@ -1,0 +1,784 @@
+// libmasp_hip: context, CRS loading, the per-proof kernel pipeline and the C ABI (include/masp_hip.h).
+//
+// Mirrors, on the GPU, what `create_random_proof(circuit, &Parameters, rng)` does after synthesis
+// (/root/reference/masp_proofs/src/sapling/prover.rs:117,202,252 -> nam-bellperson):
+//   witness -> a,b,c (static R1CS SpMV) -> quotient h (7 NTTs) -> MSMs H, L, A, B1 (G1), B2 (G2)
+//   -> assembly with r, s -> 192-byte proof.
+// There is deliberately NO CPU fallback: without a usable HIP device every entry point fails with
+// MASP_HIP_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "device/groth16.cuh"
+#include "device/ntt.cuh"
+#include "msm_engine.cuh"
+#include "util.h"
+
+using namespace masp;
+
+namespace {
+
+typedef MsmBases<FpOps, 96> BasesG1;
+typedef MsmBases<Fp2Ops, 192> BasesG2;
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    int reserve(size_t n) {
+        if (n <= cap) return MASP_HIP_OK;
+        release();
+        HIP_TRY(hipMalloc(&p, sizeof(T) * std::max<size_t>(n, 1)));
+        cap = n;
+        return MASP_HIP_OK;
+    }
+    int upload(const T* h, size_t n, hipStream_t s) {
+        int rc = reserve(n);
+        if (rc) return rc;
+        if (n) HIP_TRY(hipMemcpyAsync(p, h, sizeof(T) * n, hipMemcpyHostToDevice, s));
+        return MASP_HIP_OK;
+    }
+};
+
+// host-side Fr helpers (the device field code is __host__ __device__)
+static Fr fr_from_u64_mont(uint64_t x) {
+    Fr v = fe_zero<FrCfg>();
+    v.v[0] = (uint32_t)x;
+    v.v[1] = (uint32_t)(x >> 32);
+    return fe_to_mont(v);
+}
+static Fr fr_const(const uint32_t* limbs) {
+    Fr v;
+    for (int i = 0; i < 8; ++i) v.v[i] = limbs[i];
+    return v;
+}
+
+struct NttDomain {
+    uint32_t logm = 0;
+    size_t m = 0;
+    DevBuf<Fr> tw_fwd, tw_inv, coset_scale, h_scale;
+    Fr zinv;
+    int init(uint32_t logm_, hipStream_t s) {
+        logm = logm_;
+        m = (size_t)1 << logm;
+        Fr omega = fr_const(FrCfg::ROOT_OF_UNITY);
+        for (uint32_t i = logm; i < 32; ++i) omega = fe_sqr(omega);
+        Fr omega_inv = fe_inv(omega);
+        Fr minv = fe_inv(fr_from_u64_mont(m));
+        Fr g = fr_const(FrCfg::GEN), ginv = fr_const(FrCfg::GEN_INV);
+        uint32_t e[2] = {(uint32_t)m, (uint32_t)((uint64_t)m >> 32)};
+        zinv = fe_inv(fe_sub(fe_pow(g, e, 2), fe_one<FrCfg>()));
+        Fr one = fe_one<FrCfg>();
+        size_t half = std::max<size_t>(m / 2, 1);
+        int rc;
+        if ((rc = tw_fwd.reserve(half)) || (rc = tw_inv.reserve(half)) || (rc = coset_scale.reserve(m)) || (rc = h_scale.reserve(m))) return rc;
+        hipLaunchKernelGGL(k_fr_powers, dim3((half + 255) / 256), dim3(256), 0, s, tw_fwd.p, (uint32_t)half, omega, one, 0);
+        hipLaunchKernelGGL(k_fr_powers, dim3((half + 255) / 256), dim3(256), 0, s, tw_inv.p, (uint32_t)half, omega_inv, one, 0);
+        hipLaunchKernelGGL(k_fr_powers, dim3((m + 255) / 256), dim3(256), 0, s, coset_scale.p, (uint32_t)m, g, minv, 0);
+        hipLaunchKernelGGL(k_fr_powers, dim3((m + 255) / 256), dim3(256), 0, s, h_scale.p, (uint32_t)m, ginv, minv, 1);
+        HIP_TRY(hipStreamSynchronize(s));
+        return MASP_HIP_OK;
+    }
+    void passes(hipStream_t s, Fr* data, const Fr* tw) const {
+        uint32_t lt = std::min<uint32_t>(NTT_LT, logm);
+        uint32_t tiles = (uint32_t)(m >> lt);
+        for (uint32_t s0 = 0; s0 < logm;) {
+            uint32_t nst = std::min<uint32_t>(NTT_LT, logm - s0);
+            hipLaunchKernelGGL(k_ntt_pass, dim3(tiles), dim3(256), 0, s, data, tw, logm, s0, nst);
+            s0 += nst;
+        }
+    }
+};
+
+struct Circuit {
+    uint32_t n_inputs = 0, n_aux = 0, n_constraints = 0, nrows = 0, logm = 0;
+    size_t m = 0;
+    DevBuf<uint32_t> rowptr[3], col[3];
+    DevBuf<Fr> coef[3];
+    DevBuf<uint32_t> a_var, b_var;
+    uint32_t na = 0, nbq = 0;
+    DevBuf<VkDevice> vk;
+    BasesG1 h, l, a, b1;
+    BasesG2 b2;
+    NttDomain* dom = nullptr;
+};
+
+// per-proof scratch + a stream: several slots let independent proofs overlap on the device
+struct Slot {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    MsmWorkspace<FpOps> ws1;
+    MsmWorkspace<Fp2Ops> ws2;
+    DevBuf<Fr> w, wm, ev[3], x0[3], x1[3], h, sa, sb;
+    DevBuf<G1Xyzz> res1;
+    DevBuf<G2Xyzz> res2;
+    DevBuf<uint32_t> rs;
+    DevBuf<uint8_t> proof;
+    DevBuf<int> flags;
+    uint8_t* h_stage = nullptr;  // pinned staging for the assignment
+    size_t h_stage_cap = 0;
+    uint8_t* h_proof = nullptr;  // pinned
+    int* h_flags = nullptr;      // pinned
+    ~Slot() {
+        if (stream) hipStreamDestroy(stream);
+        if (done) hipEventDestroy(done);
+        if (h_stage) hipHostFree(h_stage);
+        if (h_proof) hipHostFree(h_proof);
+        if (h_flags) hipHostFree(h_flags);
+    }
+    int init() {
+        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        HIP_TRY(hipHostMalloc(&h_proof, 192));
+        HIP_TRY(hipHostMalloc(&h_flags, sizeof(int)));
+        int rc;
+        if ((rc = res1.reserve(4)) || (rc = res2.reserve(1)) || (rc = rs.reserve(16)) || (rc = proof.reserve(192)) || (rc = flags.reserve(1))) return rc;
+        return MASP_HIP_OK;
+    }
+    int stage_reserve(size_t bytes) {
+        if (bytes <= h_stage_cap) return MASP_HIP_OK;
+        if (h_stage) hipHostFree(h_stage);
+        h_stage = nullptr;
+        HIP_TRY(hipHostMalloc(&h_stage, bytes));
+        h_stage_cap = bytes;
+        return MASP_HIP_OK;
+    }
+};
+
+struct ResidentBatch {
+    size_t n = 0;
+    std::vector<uint32_t> circuit;
+    std::vector<size_t> w_off;  // element offsets into w
+    DevBuf<Fr> w;
+    DevBuf<uint32_t> rs;        // n x 16
+};
+
+}  // namespace
+
+struct masp_hip_ctx {
+    int device = 0;
+    std::mutex mu;
+    std::string err;
+    hipStream_t main_stream = nullptr;
+    std::unique_ptr<Circuit> circ[MASP_HIP_MAX_CIRCUITS];
+    std::map<uint32_t, std::unique_ptr<NttDomain>> domains;
+    std::vector<std::unique_ptr<Slot>> slots;
+    std::vector<std::unique_ptr<ResidentBatch>> batches;
+    // scratch for the building-block entry points
+    DevBuf<Fr> tmp_scalars;
+    DevBuf<uint8_t> tmp_out;
+    DevBuf<G1Xyzz> tmp_g1;
+    DevBuf<G2Xyzz> tmp_g2;
+};
+
+namespace {
+
+static int fail(masp_hip_ctx* ctx, int rc) {
+    if (rc == MASP_HIP_E_HIP) ctx->err = last_hip_error();
+    return rc;
+}
+
+static int get_domain(masp_hip_ctx* ctx, uint32_t logm, NttDomain** out) {
+    auto it = ctx->domains.find(logm);
+    if (it == ctx->domains.end()) {
+        std::unique_ptr<NttDomain> d(new NttDomain);
+        int rc = d->init(logm, ctx->main_stream);
+        if (rc) return rc;
+        it = ctx->domains.emplace(logm, std::move(d)).first;
+    }
+    *out = it->second.get();
+    return MASP_HIP_OK;
+}
+
+static uint32_t log2_ceil(uint32_t n) {
+    uint32_t k = 0;
+    while ((1ull << k) < n) ++k;
+    return k;
+}
+
+static int n_slots_default() {
+    const char* e = getenv("MASP_HIP_SLOTS");
+    int n = e ? atoi(e) : 4;
+    return std::max(1, std::min(n, 64));
+}
+
+static int ensure_slots(masp_hip_ctx* ctx, size_t want) {
+    while (ctx->slots.size() < want) {
+        std::unique_ptr<Slot> s(new Slot);
+        int rc = s->init();
+        if (rc) return rc;
+        ctx->slots.push_back(std::move(s));
+    }
+    return MASP_HIP_OK;
+}
+
+// Quotient on slot buffers: in[i] are Montgomery (mont_in) or canonical evaluation vectors of `nrows`
+// entries on the device; result: sl.h = canonical coefficients h[0..m-1) (+1 garbage-free extra entry).
+static int enqueue_quotient(Slot& sl, const NttDomain& D, const Fr* const in[3], uint32_t nrows, bool mont_in) {
+    hipStream_t s = sl.stream;
+    const uint32_t m = (uint32_t)D.m, logm = D.logm;
+    dim3 grid((m + 255) / 256), block(256);
+    int rc;
+    for (int i = 0; i < 3; ++i) {
+        if ((rc = sl.x0[i].reserve(m)) || (rc = sl.x1[i].reserve(m))) return rc;
+        if (mont_in)
+            hipLaunchKernelGGL(k_ntt_copy_bitrev, grid, block, 0, s, in[i], nrows, sl.x0[i].p, logm);
+        else
+            hipLaunchKernelGGL(k_ntt_load_bitrev, grid, block, 0, s, in[i], nrows, sl.x0[i].p, logm);
+        D.passes(s, sl.x0[i].p, D.tw_inv.p);                                                           // iNTT (unscaled)
+        hipLaunchKernelGGL(k_ntt_scale_bitrev, grid, block, 0, s, sl.x0[i].p, D.coset_scale.p, sl.x1[i].p, logm);  // * g^k / m
+        D.passes(s, sl.x1[i].p, D.tw_fwd.p);                                                           // coset NTT
+    }
+    hipLaunchKernelGGL(k_ntt_abc_bitrev, grid, block, 0, s, sl.x1[0].p, sl.x1[1].p, sl.x1[2].p, D.zinv, sl.x0[0].p, logm);
+    D.passes(s, sl.x0[0].p, D.tw_inv.p);
+    if ((rc = sl.h.reserve(m))) return rc;
+    hipLaunchKernelGGL(k_fr_scale, grid, block, 0, s, sl.x0[0].p, D.h_scale.p, sl.h.p, m);  // * g^-k / m, leaves Montgomery form
+    return MASP_HIP_OK;
+}
+
+// Enqueue one proof.  d_w: n_vars canonical scalars on the device (inputs then aux).  d_abc: canonical
+// evaluation vectors on the device or all NULL.  d_rs: 16 limbs.  d_proof: 192 bytes on the device.
+static int enqueue_proof(Slot& sl, Circuit& C, const Fr* d_w, const Fr* const d_abc[3], const uint32_t* d_rs, uint8_t* d_proof) {
+    hipStream_t s = sl.stream;
+    const uint32_t nv = C.n_inputs + C.n_aux;
+    int rc;
+    HIP_TRY(hipMemsetAsync(sl.flags.p, 0, sizeof(int), s));
+    if ((rc = sl.wm.reserve(nv))) return rc;
+    // range check (+ Montgomery copy used by the SpMV)
+    hipLaunchKernelGGL(k_fr_to_mont, dim3((nv + 255) / 256), dim3(256), 0, s, d_w, sl.wm.p, nv, sl.flags.p);
+    const Fr* in[3];
+    bool mont_in;
+    if (d_abc[0]) {
+        in[0] = d_abc[0];
+        in[1] = d_abc[1];
+        in[2] = d_abc[2];
+        mont_in = false;
+    } else {
+        for (int i = 0; i < 3; ++i) {
+            if ((rc = sl.ev[i].reserve(C.nrows))) return rc;
+            hipLaunchKernelGGL(k_r1cs_eval, dim3((C.nrows + 127) / 128), dim3(128), 0, s, C.rowptr[i].p, C.col[i].p, C.coef[i].p,
+                               sl.wm.p, C.n_constraints, C.n_inputs, i, sl.ev[i].p);
+            in[i] = sl.ev[i].p;
+        }
+        mont_in = true;
+    }
+    if ((rc = enqueue_quotient(sl, *C.dom, in, C.nrows, mont_in))) return rc;
+    // query scalars selected by density
+    if ((rc = sl.sa.reserve(C.na)) || (rc = sl.sb.reserve(C.nbq))) return rc;
+    if (C.na) hipLaunchKernelGGL(k_gather_scalars, dim3((C.na + 255) / 256), dim3(256), 0, s, d_w, C.a_var.p, C.na, sl.sa.p);
+    if (C.nbq) hipLaunchKernelGGL(k_gather_scalars, dim3((C.nbq + 255) / 256), dim3(256), 0, s, d_w, C.b_var.p, C.nbq, sl.sb.p);
+    if ((rc = msm_enqueue(s, C.h, sl.ws1, (const uint32_t*)sl.h.p, sl.res1.p + 0))) return rc;
+    if ((rc = msm_enqueue(s, C.l, sl.ws1, (const uint32_t*)(d_w + C.n_inputs), sl.res1.p + 1))) return rc;
+    if ((rc = msm_enqueue(s, C.a, sl.ws1, (const uint32_t*)sl.sa.p, sl.res1.p + 2))) return rc;
+    if ((rc = msm_enqueue(s, C.b1, sl.ws1, (const uint32_t*)sl.sb.p, sl.res1.p + 3))) return rc;
+    if ((rc = msm_enqueue(s, C.b2, sl.ws2, (const uint32_t*)sl.sb.p, sl.res2.p))) return rc;
+    hipLaunchKernelGGL(k_groth16_assemble, dim3(1), dim3(128), 0, s, C.vk.p, sl.res1.p, sl.res2.p, d_rs, d_proof);
+    return MASP_HIP_OK;
+}
+
+static bool rs_in_range(const uint8_t* x) {
+    Fr v = fe_load_le<FrCfg>(x);
+    return !fe_canonical_ge_mod(v);
+}
+
+struct ParamsLayout {
+    const uint8_t *alpha_g1, *beta_g1, *beta_g2, *gamma_g2, *delta_g1, *delta_g2;
+    const uint8_t *ic, *h, *l, *a, *b_g1, *b_g2;
+    uint32_t n_ic, n_h, n_l, n_a, n_b1, n_b2;
+};
+static bool read_u32be(const uint8_t*& p, const uint8_t* end, uint32_t& v) {
+    if (end - p < 4) return false;
+    v = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+    p += 4;
+    return true;
+}
+// bellman Parameters wire format; trailing bytes are ignored like lib.rs:343-347 does
+static bool parse_params(const uint8_t* buf, size_t len, ParamsLayout& L) {
+    const uint8_t *p = buf, *end = buf + len;
+    if (len < 864) return false;
+    L.alpha_g1 = p; p += 96;
+    L.beta_g1 = p;  p += 96;
+    L.beta_g2 = p;  p += 192;
+    L.gamma_g2 = p; p += 192;
+    L.delta_g1 = p; p += 96;
+    L.delta_g2 = p; p += 192;
+    struct { const uint8_t** ptr; uint32_t* n; size_t sz; } secs[6] = {
+        {&L.ic, &L.n_ic, 96}, {&L.h, &L.n_h, 96}, {&L.l, &L.n_l, 96}, {&L.a, &L.n_a, 96}, {&L.b_g1, &L.n_b1, 96}, {&L.b_g2, &L.n_b2, 192}};
+    for (auto& sec : secs) {
+        if (!read_u32be(p, end, *sec.n)) return false;
+        if ((size_t)(end - p) < (size_t)*sec.n * sec.sz) return false;
+        *sec.ptr = p;
+        p += (size_t)*sec.n * sec.sz;
+    }
+    return true;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* masp_hip_strerror(int code) {
+    switch (code) {
+        case MASP_HIP_OK: return "ok";
+        case MASP_HIP_E_INVALID_ARG: return "invalid argument";
+        case MASP_HIP_E_PARAMS_FORMAT: return "Parameters bytes are malformed";
+        case MASP_HIP_E_PARAMS_SHAPE: return "Parameters do not match the circuit shape";
+        case MASP_HIP_E_NO_DEVICE: return "no usable HIP device (there is no CPU fallback)";
+        case MASP_HIP_E_HIP: return "HIP runtime error";
+        case MASP_HIP_E_UNEXPECTED_IDENTITY: return "delta is the identity (UnexpectedIdentity)";
+        case MASP_HIP_E_NOT_LOADED: return "circuit slot is empty";
+        case MASP_HIP_E_SCALAR_RANGE: return "scalar is not a canonical field element";
+        default: return "unknown error";
+    }
+}
+
+const char* masp_hip_last_error(const masp_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+int masp_hip_ctx_create(int device, masp_hip_ctx** out) {
+    if (!out) return MASP_HIP_E_INVALID_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return MASP_HIP_E_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return MASP_HIP_E_NO_DEVICE;
+    std::unique_ptr<masp_hip_ctx> ctx(new masp_hip_ctx);
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->main_stream, hipStreamNonBlocking) != hipSuccess) return MASP_HIP_E_NO_DEVICE;
+    *out = ctx.release();
+    return MASP_HIP_OK;
+}
+
+void masp_hip_ctx_destroy(masp_hip_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipDeviceSynchronize();
+    ctx->batches.clear();
+    ctx->slots.clear();
+    for (auto& c : ctx->circ) c.reset();
+    ctx->domains.clear();
+    if (ctx->main_stream) hipStreamDestroy(ctx->main_stream);
+    delete ctx;
+}
+
+int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* params, size_t params_len, const masp_hip_r1cs* cs) {
+    if (!ctx || !params || !cs || slot >= MASP_HIP_MAX_CIRCUITS || cs->n_inputs == 0) return MASP_HIP_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    hipSetDevice(ctx->device);
+    hipStream_t s = ctx->main_stream;
+    ParamsLayout L;
+    if (!parse_params(params, params_len, L)) return MASP_HIP_E_PARAMS_FORMAT;
+    std::unique_ptr<Circuit> C(new Circuit);
+    C->n_inputs = cs->n_inputs;
+    C->n_aux = cs->n_aux;
+    C->n_constraints = cs->n_constraints;
+    C->nrows = cs->n_constraints + cs->n_inputs;
+    C->logm = log2_ceil(C->nrows);
+    C->m = (size_t)1 << C->logm;
+    // density lists from the static structure (bellperson DensityTracker)
+    const uint32_t nv = cs->n_inputs + cs->n_aux;
+    std::vector<uint8_t> a_dense(nv, 0), b_dense(nv, 0);
+    const uint32_t* rp[3] = {cs->a_rowptr, cs->b_rowptr, cs->c_rowptr};
+    const uint32_t* cl[3] = {cs->a_col, cs->b_col, cs->c_col};
+    const uint8_t* cf[3] = {cs->a_coef, cs->b_coef, cs->c_coef};
+    for (int mi = 0; mi < 3; ++mi) {
+        uint32_t nnz = rp[mi][cs->n_constraints];
+        for (uint32_t t = 0; t < nnz; ++t) {
+            if (cl[mi][t] >= nv) return MASP_HIP_E_INVALID_ARG;
+            if (mi == 0) a_dense[cl[mi][t]] = 1;
+            if (mi == 1) b_dense[cl[mi][t]] = 1;
+        }
+    }
+    std::vector<uint32_t> a_var, b_var;
+    for (uint32_t i = 0; i < cs->n_inputs; ++i) a_var.push_back(i);  // inputs are always dense for A
+    for (uint32_t v = cs->n_inputs; v < nv; ++v)
+        if (a_dense[v]) a_var.push_back(v);
+    for (uint32_t v = 0; v < nv; ++v)
+        if (b_dense[v]) b_var.push_back(v);
+    C->na = a_var.size();
+    C->nbq = b_var.size();
+    // length invariants
+    if (L.n_ic != cs->n_inputs || L.n_h < C->m - 1 || L.n_l != cs->n_aux || L.n_a != C->na || L.n_b1 != C->nbq || L.n_b2 != C->nbq)
+        return MASP_HIP_E_PARAMS_SHAPE;
+    int rc;
+    if ((rc = C->a_var.upload(a_var.data(), a_var.size(), s)) || (rc = C->b_var.upload(b_var.data(), b_var.size(), s))) return fail(ctx, rc);
+    // static R1CS -> device (coefficients to Montgomery form)
+    DevBuf<int> d_flag;
+    if ((rc = d_flag.reserve(1))) return fail(ctx, rc);
+    hipMemsetAsync(d_flag.p, 0, sizeof(int), s);
+    for (int mi = 0; mi < 3; ++mi) {
+        uint32_t nnz = rp[mi][cs->n_constraints];
+        DevBuf<Fr> raw;
+        if ((rc = C->rowptr[mi].upload(rp[mi], cs->n_constraints + 1, s)) || (rc = C->col[mi].upload(cl[mi], nnz, s)) ||
+            (rc = raw.upload((const Fr*)cf[mi], nnz, s)) || (rc = C->coef[mi].reserve(nnz)))
+            return fail(ctx, rc);
+        if (nnz) hipLaunchKernelGGL(k_fr_to_mont, dim3((nnz + 255) / 256), dim3(256), 0, s, raw.p, C->coef[mi].p, nnz, d_flag.p);
+        if (hipStreamSynchronize(s) != hipSuccess) return fail(ctx, MASP_HIP_E_HIP);
+    }
+    // verifying-key points used by the prover
+    if ((rc = C->vk.reserve(1))) return fail(ctx, rc);
+    {
+        DevBuf<uint8_t> raw;
+        if ((rc = raw.upload(params, 864, s))) return fail(ctx, rc);
+        DevBuf<int> st;
+        if ((rc = st.reserve(1))) return fail(ctx, rc);
+        hipMemsetAsync(st.p, 0, sizeof(int), s);
+        VkDevice* v = C->vk.p;
+        hipLaunchKernelGGL(k_g1_import_one, dim3(1), dim3(1), 0, s, raw.p + 0, &v->alpha_g1, st.p);
+        hipLaunchKernelGGL(k_g1_import_one, dim3(1), dim3(1), 0, s, raw.p + 96, &v->beta_g1, st.p);
+        hipLaunchKernelGGL(k_g2_import_one, dim3(1), dim3(1), 0, s, raw.p + 192, &v->beta_g2, st.p);
+        hipLaunchKernelGGL(k_g1_import_one, dim3(1), dim3(1), 0, s, raw.p + 576, &v->delta_g1, st.p);
+        hipLaunchKernelGGL(k_g2_import_one, dim3(1), dim3(1), 0, s, raw.p + 672, &v->delta_g2, st.p);
+        int hst = 0, hflag = 0;
+        if (hipMemcpyAsync(&hst, st.p, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipMemcpyAsync(&hflag, d_flag.p, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            last_hip_error() = "vk import failed";
+            return fail(ctx, MASP_HIP_E_HIP);
+        }
+        if (hflag) return MASP_HIP_E_SCALAR_RANGE;
+        if (hst & (PT_BAD_FLAGS | PT_NOT_CANONICAL)) return MASP_HIP_E_PARAMS_FORMAT;
+        // delta at infinity -> bellperson's UnexpectedIdentity; alpha/beta at infinity are merely degenerate
+        if ((params[576] & 0x40) || (params[672] & 0x40)) return MASP_HIP_E_UNEXPECTED_IDENTITY;
+    }
+    // query vectors + window tables
+    if ((rc = C->h.load_host(L.h, (uint32_t)(C->m - 1), s)) || (rc = C->l.load_host(L.l, L.n_l, s)) || (rc = C->a.load_host(L.a, L.n_a, s)) ||
+        (rc = C->b1.load_host(L.b_g1, L.n_b1, s)) || (rc = C->b2.load_host(L.b_g2, L.n_b2, s)))
+        return fail(ctx, rc);
+    int st = C->h.import_status | C->l.import_status | C->a.import_status | C->b1.import_status | C->b2.import_status;
+    if (st) return MASP_HIP_E_PARAMS_FORMAT;  // includes infinity inside a query vector, which bellman rejects
+    if ((rc = get_domain(ctx, C->logm, &C->dom))) return fail(ctx, rc);
+    ctx->circ[slot] = std::move(C);
+    return MASP_HIP_OK;
+}
+
+int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, uint8_t* proofs_out) {
+    if (!ctx || (n && (!jobs || !proofs_out))) return MASP_HIP_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    hipSetDevice(ctx->device);
+    for (size_t j = 0; j < n; ++j) {
+        const masp_hip_job& J = jobs[j];
+        if (J.circuit >= MASP_HIP_MAX_CIRCUITS || !J.inputs || !J.aux) return MASP_HIP_E_INVALID_ARG;
+        if (!ctx->circ[J.circuit]) return MASP_HIP_E_NOT_LOADED;
+        if ((J.a || J.b || J.c) && !(J.a && J.b && J.c)) return MASP_HIP_E_INVALID_ARG;
+        if (!rs_in_range(J.r) || !rs_in_range(J.s)) return MASP_HIP_E_SCALAR_RANGE;
+    }
+    size_t ns = std::min<size_t>(std::max<size_t>(n, 1), n_slots_default());
+    int rc = ensure_slots(ctx, ns);
+    if (rc) return fail(ctx, rc);
+    std::vector<long> owner(ns, -1);
+    int result = MASP_HIP_OK;
+    auto retire = [&](size_t si) {
+        Slot& sl = *ctx->slots[si];
+        if (owner[si] < 0) return;
+        if (hipEventSynchronize(sl.done) != hipSuccess) {
+            last_hip_error() = "event sync failed";
+            result = fail(ctx, MASP_HIP_E_HIP);
+        } else if (*sl.h_flags) {
+            result = MASP_HIP_E_SCALAR_RANGE;
+        } else if (result == MASP_HIP_OK) {
+            memcpy(proofs_out + 192 * (size_t)owner[si], sl.h_proof, 192);
+        }
+        owner[si] = -1;
+    };
+    for (size_t j = 0; j < n && result == MASP_HIP_OK; ++j) {
+        size_t si = j % ns;
+        retire(si);
+        if (result) break;
+        Slot& sl = *ctx->slots[si];
+        Circuit& C = *ctx->circ[jobs[j].circuit];
+        const masp_hip_job& J = jobs[j];
+        const size_t nv = (size_t)C.n_inputs + C.n_aux;
+        const bool has_abc = J.a != nullptr;
+        size_t stage_bytes = 32 * nv + (has_abc ? 3 * 32 * (size_t)C.nrows : 0) + 64;
+        if ((rc = sl.stage_reserve(stage_bytes)) || (rc = sl.w.reserve(nv + (has_abc ? 3 * (size_t)C.nrows : 0)))) {
+            result = fail(ctx, rc);
+            break;
+        }
+        uint8_t* hs = sl.h_stage;
+        memcpy(hs, J.inputs, 32 * (size_t)C.n_inputs);
+        memcpy(hs + 32 * (size_t)C.n_inputs, J.aux, 32 * (size_t)C.n_aux);
+        size_t off = 32 * nv;
+        if (has_abc) {
+            memcpy(hs + off, J.a, 32 * (size_t)C.nrows);
+            memcpy(hs + off + 32 * (size_t)C.nrows, J.b, 32 * (size_t)C.nrows);
+            memcpy(hs + off + 64 * (size_t)C.nrows, J.c, 32 * (size_t)C.nrows);
+            off += 96 * (size_t)C.nrows;
+        }
+        memcpy(hs + off, J.r, 32);
+        memcpy(hs + off + 32, J.s, 32);
+        hipStream_t s = sl.stream;
+        bool ok = hipMemcpyAsync(sl.w.p, hs, off, hipMemcpyHostToDevice, s) == hipSuccess &&
+                  hipMemcpyAsync(sl.rs.p, hs + off, 64, hipMemcpyHostToDevice, s) == hipSuccess;
+        if (!ok) {
+            last_hip_error() = "H2D copy failed";
+            result = fail(ctx, MASP_HIP_E_HIP);
+            break;
+        }
+        const Fr* abc[3] = {nullptr, nullptr, nullptr};
+        if (has_abc) {
+            abc[0] = sl.w.p + nv;
+            abc[1] = abc[0] + C.nrows;
+            abc[2] = abc[1] + C.nrows;
+        }
+        if ((rc = enqueue_proof(sl, C, sl.w.p, abc, sl.rs.p, sl.proof.p))) {
+            result = fail(ctx, rc);
+            break;
+        }
+        ok = hipMemcpyAsync(sl.h_proof, sl.proof.p, 192, hipMemcpyDeviceToHost, s) == hipSuccess &&
+             hipMemcpyAsync(sl.h_flags, sl.flags.p, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess &&
+             hipEventRecord(sl.done, s) == hipSuccess;
+        if (!ok) {
+            last_hip_error() = "D2H copy failed";
+            result = fail(ctx, MASP_HIP_E_HIP);
+            break;
+        }
+        owner[si] = (long)j;
+    }
+    for (size_t si = 0; si < ns; ++si) retire(si);
+    if (hipGetLastError() != hipSuccess && result == MASP_HIP_OK) {
+        last_hip_error() = "kernel launch failed";
+        result = fail(ctx, MASP_HIP_E_HIP);
+    }
+    return result;
+}
+
+int masp_hip_prove(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* inputs, const uint8_t* aux, const uint8_t* a, const uint8_t* b,
+                   const uint8_t* c, const uint8_t r[32], const uint8_t s[32], uint8_t proof_out[192]) {
+    if (!r || !s || !proof_out) return MASP_HIP_E_INVALID_ARG;
+    masp_hip_job J;
+    J.circuit = slot;
+    J.inputs = inputs;
+    J.aux = aux;
+    J.a = a;
+    J.b = b;
+    J.c = c;
+    memcpy(J.r, r, 32);
+    memcpy(J.s, s, 32);
+    uint8_t tmp[192];
+    int rc = masp_hip_prove_batch(ctx, 1, &J, tmp);
+    if (rc == MASP_HIP_OK) memcpy(proof_out, tmp, 192);
+    return rc;
+}
+
+}  // extern "C"
+
+// ---- building blocks ----------------------------------------------------------------------------
+template <class O, int BYTES, class X>
+static int msm_block(masp_hip_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t* out, DevBuf<X>& res) {
+    if (!ctx || !out || (n && (!bases || !scalars)) || n > (1u << 26)) return MASP_HIP_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    hipSetDevice(ctx->device);
+    hipStream_t s = ctx->main_stream;
+    for (size_t i = 0; i < n; ++i)
+        if (!rs_in_range(scalars + 32 * i)) return MASP_HIP_E_SCALAR_RANGE;
+    MsmBases<O, BYTES> B;
+    MsmWorkspace<O> ws;
+    int rc;
+    if ((rc = B.load_host(bases, (uint32_t)n, s))) return fail(ctx, rc);
+    if (B.import_status & (PT_BAD_FLAGS | PT_NOT_CANONICAL)) return MASP_HIP_E_PARAMS_FORMAT;
+    if ((rc = ctx->tmp_scalars.upload((const Fr*)scalars, n, s)) || (rc = res.reserve(1)) || (rc = ctx->tmp_out.reserve(BYTES))) return fail(ctx, rc);
+    if ((rc = msm_enqueue(s, B, ws, (const uint32_t*)ctx->tmp_scalars.p, res.p))) return fail(ctx, rc);
+    if constexpr (BYTES == 96)
+        hipLaunchKernelGGL(k_g1_export, dim3(1), dim3(1), 0, s, res.p, ctx->tmp_out.p);
+    else
+        hipLaunchKernelGGL(k_g2_export, dim3(1), dim3(1), 0, s, res.p, ctx->tmp_out.p);
+    uint8_t tmp[BYTES];
+    if (hipMemcpyAsync(tmp, ctx->tmp_out.p, BYTES, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        last_hip_error() = std::string("msm failed: ") + hipGetErrorString(hipGetLastError());
+        return fail(ctx, MASP_HIP_E_HIP);
+    }
+    memcpy(out, tmp, BYTES);
+    return MASP_HIP_OK;
+}
+extern "C" {
+
+int masp_hip_msm_g1(masp_hip_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[96]) {
+    return msm_block<FpOps, 96>(ctx, bases, scalars, n, out, ctx->tmp_g1);
+}
+int masp_hip_msm_g2(masp_hip_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[192]) {
+    return msm_block<Fp2Ops, 192>(ctx, bases, scalars, n, out, ctx->tmp_g2);
+}
+
+int masp_hip_quotient_h(masp_hip_ctx* ctx, const uint8_t* a, const uint8_t* b, const uint8_t* c, size_t nrows, uint32_t logm, uint8_t* h_out) {
+    if (!ctx || !a || !b || !c || !h_out || logm == 0 || logm > 20 || nrows > ((size_t)1 << logm)) return MASP_HIP_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    hipSetDevice(ctx->device);
+    int rc;
+    if ((rc = ensure_slots(ctx, 1))) return fail(ctx, rc);
+    Slot& sl = *ctx->slots[0];
+    NttDomain* D;
+    if ((rc = get_domain(ctx, logm, &D))) return fail(ctx, rc);
+    if ((rc = sl.w.reserve(3 * nrows))) return fail(ctx, rc);
+    hipStream_t s = sl.stream;
+    const uint8_t* src[3] = {a, b, c};
+    const Fr* in[3];
+    for (int i = 0; i < 3; ++i) {
+        if (hipMemcpyAsync(sl.w.p + i * nrows, src[i], 32 * nrows, hipMemcpyHostToDevice, s) != hipSuccess) return fail(ctx, MASP_HIP_E_HIP);
+        in[i] = sl.w.p + i * nrows;
+    }
+    if ((rc = enqueue_quotient(sl, *D, in, (uint32_t)nrows, false))) return fail(ctx, rc);
+    size_t m = (size_t)1 << logm;
+    if (hipMemcpyAsync(h_out, sl.h.p, 32 * (m - 1), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        last_hip_error() = std::string("quotient failed: ") + hipGetErrorString(hipGetLastError());
+        return fail(ctx, MASP_HIP_E_HIP);
+    }
+    return MASP_HIP_OK;
+}
+
+int masp_hip_ntt(masp_hip_ctx* ctx, uint8_t* data, uint32_t logm, int inverse) {
+    if (!ctx || !data || logm == 0 || logm > 20) return MASP_HIP_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    hipSetDevice(ctx->device);
+    int rc;
+    if ((rc = ensure_slots(ctx, 1))) return fail(ctx, rc);
+    Slot& sl = *ctx->slots[0];
+    NttDomain* D;
+    if ((rc = get_domain(ctx, logm, &D))) return fail(ctx, rc);
+    uint32_t m = 1u << logm;
+    if ((rc = sl.w.reserve(m)) || (rc = sl.x0[0].reserve(m)) || (rc = sl.x1[0].reserve(m))) return fail(ctx, rc);
+    hipStream_t s = sl.stream;
+    if (hipMemcpyAsync(sl.w.p, data, 32 * (size_t)m, hipMemcpyHostToDevice, s) != hipSuccess) return fail(ctx, MASP_HIP_E_HIP);
+    dim3 grid((m + 255) / 256), block(256);
+    hipLaunchKernelGGL(k_ntt_load_bitrev, grid, block, 0, s, sl.w.p, m, sl.x0[0].p, logm);
+    D->passes(s, sl.x0[0].p, inverse ? D->tw_inv.p : D->tw_fwd.p);
+    if (inverse) {
+        // 1/m scaling: coset_scale[0] = g^0 / m
+        Fr* minv_tab = sl.x1[0].p;
+        Fr minv = fe_inv(fr_from_u64_mont(m));
+        hipLaunchKernelGGL(k_fr_powers, grid, block, 0, s, minv_tab, m, fe_one<FrCfg>(), minv, 0);
+        hipLaunchKernelGGL(k_fr_scale, grid, block, 0, s, sl.x0[0].p, minv_tab, sl.x0[0].p, m);
+    }
+    hipLaunchKernelGGL(k_fr_from_mont, grid, block, 0, s, sl.x0[0].p, sl.w.p, m);
+    if (hipMemcpyAsync(data, sl.w.p, 32 * (size_t)m, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        last_hip_error() = std::string("ntt failed: ") + hipGetErrorString(hipGetLastError());
+        return fail(ctx, MASP_HIP_E_HIP);
+    }
+    return MASP_HIP_OK;
+}
+
+// ---- measurement hooks ----------------------------------------------------------------------------
+int masp_hip_batch_upload(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs) {
+    if (!ctx || !n || !jobs) return -MASP_HIP_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    hipSetDevice(ctx->device);
+    std::unique_ptr<ResidentBatch> B(new ResidentBatch);
+    B->n = n;
+    size_t total = 0;
+    for (size_t j = 0; j < n; ++j) {
+        if (jobs[j].circuit >= MASP_HIP_MAX_CIRCUITS || !ctx->circ[jobs[j].circuit]) return -MASP_HIP_E_NOT_LOADED;
+        if (!rs_in_range(jobs[j].r) || !rs_in_range(jobs[j].s)) return -MASP_HIP_E_SCALAR_RANGE;
+        Circuit& C = *ctx->circ[jobs[j].circuit];
+        B->circuit.push_back(jobs[j].circuit);
+        B->w_off.push_back(total);
+        total += (size_t)C.n_inputs + C.n_aux;
+    }
+    if (B->w.reserve(total) || B->rs.reserve(16 * n)) return -fail(ctx, MASP_HIP_E_HIP);
+    hipStream_t s = ctx->main_stream;
+    for (size_t j = 0; j < n; ++j) {
+        Circuit& C = *ctx->circ[jobs[j].circuit];
+        bool ok = hipMemcpyAsync(B->w.p + B->w_off[j], jobs[j].inputs, 32 * (size_t)C.n_inputs, hipMemcpyHostToDevice, s) == hipSuccess &&
+                  hipMemcpyAsync(B->w.p + B->w_off[j] + C.n_inputs, jobs[j].aux, 32 * (size_t)C.n_aux, hipMemcpyHostToDevice, s) == hipSuccess &&
+                  hipMemcpyAsync(B->rs.p + 16 * j, jobs[j].r, 32, hipMemcpyHostToDevice, s) == hipSuccess &&
+                  hipMemcpyAsync(B->rs.p + 16 * j + 8, jobs[j].s, 32, hipMemcpyHostToDevice, s) == hipSuccess;
+        if (!ok || hipStreamSynchronize(s) != hipSuccess) return -fail(ctx, MASP_HIP_E_HIP);
+    }
+    for (size_t k = 0; k < ctx->batches.size(); ++k)
+        if (!ctx->batches[k]) {
+            ctx->batches[k] = std::move(B);
+            return (int)k;
+        }
+    ctx->batches.push_back(std::move(B));
+    return (int)ctx->batches.size() - 1;
+}
+
+int masp_hip_batch_free(masp_hip_ctx* ctx, int handle) {
+    if (!ctx || handle < 0 || (size_t)handle >= ctx->batches.size()) return MASP_HIP_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    hipSetDevice(ctx->device);
+    ctx->batches[handle].reset();
+    return MASP_HIP_OK;
+}
+
+int masp_hip_batch_prove_resident(masp_hip_ctx* ctx, int handle, uint8_t* proofs_out, float* elapsed_ms) {
+    if (!ctx || handle < 0 || (size_t)handle >= ctx->batches.size() || !ctx->batches[handle] || !proofs_out) return MASP_HIP_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    hipSetDevice(ctx->device);
+    ResidentBatch& B = *ctx->batches[handle];
+    size_t ns = std::min<size_t>(B.n, n_slots_default());
+    int rc;
+    if ((rc = ensure_slots(ctx, ns))) return fail(ctx, rc);
+    DevBuf<uint8_t> d_proofs;
+    DevBuf<int> d_flags;
+    if ((rc = d_proofs.reserve(192 * B.n))) return fail(ctx, rc);
+    hipEvent_t ev_start, ev_stop;
+    HIP_TRY(hipEventCreate(&ev_start));
+    HIP_TRY(hipEventCreate(&ev_stop));
+    hipStream_t ms = ctx->main_stream;
+    HIP_TRY(hipEventRecord(ev_start, ms));
+    for (size_t si = 0; si < ns; ++si) HIP_TRY(hipStreamWaitEvent(ctx->slots[si]->stream, ev_start, 0));
+    const Fr* none[3] = {nullptr, nullptr, nullptr};
+    for (size_t j = 0; j < B.n; ++j) {
+        Slot& sl = *ctx->slots[j % ns];
+        Circuit& C = *ctx->circ[B.circuit[j]];
+        if ((rc = enqueue_proof(sl, C, B.w.p + B.w_off[j], none, B.rs.p + 16 * j, d_proofs.p + 192 * j))) return fail(ctx, rc);
+    }
+    for (size_t si = 0; si < ns; ++si) {
+        HIP_TRY(hipEventRecord(ctx->slots[si]->done, ctx->slots[si]->stream));
+        HIP_TRY(hipStreamWaitEvent(ms, ctx->slots[si]->done, 0));
+    }
+    HIP_TRY(hipEventRecord(ev_stop, ms));
+    HIP_TRY(hipMemcpyAsync(proofs_out, d_proofs.p, 192 * B.n, hipMemcpyDeviceToHost, ms));
+    HIP_TRY(hipStreamSynchronize(ms));
+    if (elapsed_ms) HIP_TRY(hipEventElapsedTime(elapsed_ms, ev_start, ev_stop));
+    hipEventDestroy(ev_start);
+    hipEventDestroy(ev_stop);
+    return MASP_HIP_OK;
+}
+
+int masp_hip_bench_msm(masp_hip_ctx* ctx, int handle, size_t job, int which, int iters, float* avg_ms, uint32_t* n_bases) {
+    if (!ctx || handle < 0 || (size_t)handle >= ctx->batches.size() || !ctx->batches[handle] || which < 0 || which > 3 || iters <= 0 || !avg_ms)
+        return MASP_HIP_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    hipSetDevice(ctx->device);
+    ResidentBatch& B = *ctx->batches[handle];
+    if (job >= B.n) return MASP_HIP_E_INVALID_ARG;
+    int rc;
+    if ((rc = ensure_slots(ctx, 1))) return fail(ctx, rc);
+    Slot& sl = *ctx->slots[0];
+    Circuit& C = *ctx->circ[B.circuit[job]];
+    const Fr* none[3] = {nullptr, nullptr, nullptr};
+    // one full proof first so that sl.h / sl.sa / sl.sb hold this job's real scalars
+    if ((rc = enqueue_proof(sl, C, B.w.p + B.w_off[job], none, B.rs.p + 16 * job, sl.proof.p))) return fail(ctx, rc);
+    HIP_TRY(hipStreamSynchronize(sl.stream));
+    const BasesG1* bases[4] = {&C.h, &C.l, &C.a, &C.b1};
+    const uint32_t* scal[4] = {(const uint32_t*)sl.h.p, (const uint32_t*)(B.w.p + B.w_off[job] + C.n_inputs), (const uint32_t*)sl.sa.p,
+                               (const uint32_t*)sl.sb.p};
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, sl.stream));
+    for (int it = 0; it < iters; ++it)
+        if ((rc = msm_enqueue(sl.stream, *bases[which], sl.ws1, scal[which], sl.res1.p + which))) return fail(ctx, rc);
+    HIP_TRY(hipEventRecord(e1, sl.stream));
+    HIP_TRY(hipStreamSynchronize(sl.stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = ms / iters;
+    if (n_bases) *n_bases = bases[which]->n;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return MASP_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,198 @@
+"""ctypes binding of libmasp_hip.so (C ABI: include/masp_hip.h)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+ERRORS = {1: "invalid argument", 2: "Parameters bytes are malformed", 3: "Parameters do not match the circuit shape",
+          4: "no usable HIP device (there is no CPU fallback)", 5: "HIP runtime error", 6: "UnexpectedIdentity",
+          7: "circuit slot is empty", 8: "scalar is not a canonical field element"}
+
+SPEND, OUTPUT, CONVERT = 0, 1, 2
+
+
+class MaspHipError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        super().__init__("masp_hip error %d: %s%s" % (code, ERRORS.get(code, "?"), (" — " + detail) if detail else ""))
+
+
+class JobStruct(C.Structure):
+    _fields_ = [("circuit", C.c_uint32), ("inputs", C.c_void_p), ("aux", C.c_void_p), ("a", C.c_void_p),
+                ("b", C.c_void_p), ("c", C.c_void_p), ("r", C.c_uint8 * 32), ("s", C.c_uint8 * 32)]
+
+
+def library_path():
+    return os.path.join(_HERE, "libmasp_hip.so")
+
+
+def load_library():
+    """Loads the HIP extension; raises if it has not been built (no fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError("libmasp_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or `make -C masp_amd/csrc` (hipcc, --offload-arch=gfx950)")
+    L = C.CDLL(path)
+    vp, sz, u32 = C.c_void_p, C.c_size_t, C.c_uint32
+    L.masp_hip_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.masp_hip_ctx_destroy.argtypes = [vp]
+    L.masp_hip_ctx_destroy.restype = None
+    L.masp_hip_strerror.restype = C.c_char_p
+    L.masp_hip_last_error.argtypes = [vp]
+    L.masp_hip_last_error.restype = C.c_char_p
+    L.masp_hip_circuit_load.argtypes = [vp, u32, vp, sz, vp]
+    L.masp_hip_prove.argtypes = [vp, u32, vp, vp, vp, vp, vp, C.c_char_p, C.c_char_p, vp]
+    L.masp_hip_prove_batch.argtypes = [vp, sz, vp, vp]
+    L.masp_hip_msm_g1.argtypes = [vp, vp, vp, sz, vp]
+    L.masp_hip_msm_g2.argtypes = [vp, vp, vp, sz, vp]
+    L.masp_hip_quotient_h.argtypes = [vp, vp, vp, vp, sz, u32, vp]
+    L.masp_hip_ntt.argtypes = [vp, vp, u32, C.c_int]
+    L.masp_hip_batch_upload.argtypes = [vp, sz, vp]
+    L.masp_hip_batch_prove_resident.argtypes = [vp, C.c_int, vp, C.POINTER(C.c_float)]
+    L.masp_hip_batch_free.argtypes = [vp, C.c_int]
+    L.masp_hip_bench_msm.argtypes = [vp, C.c_int, sz, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(u32)]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _u8(a, shape_last=None):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if shape_last is not None:
+        a = a.reshape(-1, shape_last)
+    return a
+
+
+def _scalar32(x):
+    if isinstance(x, int):
+        return x.to_bytes(32, "little")
+    b = bytes(x)
+    assert len(b) == 32
+    return b
+
+
+class Context:
+    """One GPU.  Thread-safe (calls serialise inside the library)."""
+
+    def __init__(self, device=0):
+        self._L = load_library()
+        h = C.c_void_p()
+        rc = self._L.masp_hip_ctx_create(int(device), C.byref(h))
+        if rc:
+            raise MaspHipError(rc)
+        self._h = h
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.masp_hip_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise MaspHipError(rc, self._L.masp_hip_last_error(self._h).decode(errors="replace"))
+
+    # ---- circuits / proofs ----
+    def load_circuit(self, slot, params, cs):
+        params = _u8(params)
+        self._check(self._L.masp_hip_circuit_load(self._h, slot, _p(params), params.size, cs.ref))
+
+    def _job(self, slot, inputs, aux, r, s, abc=None):
+        j = JobStruct()
+        j.circuit = slot
+        inputs, aux = _u8(inputs, 32), _u8(aux, 32)
+        keep = [inputs, aux]
+        j.inputs, j.aux = inputs.ctypes.data, aux.ctypes.data
+        if abc is not None:
+            a, b, c = (_u8(x, 32) for x in abc)
+            keep += [a, b, c]
+            j.a, j.b, j.c = a.ctypes.data, b.ctypes.data, c.ctypes.data
+        j.r[:] = _scalar32(r)
+        j.s[:] = _scalar32(s)
+        return j, keep
+
+    def prove(self, slot, inputs, aux, r, s, abc=None):
+        """-> 192-byte proof (A | B | C compressed)."""
+        return self.prove_batch([(slot, inputs, aux, r, s, abc)])[0]
+
+    def prove_batch(self, jobs):
+        """jobs: iterable of (slot, inputs, aux, r, s[, (a,b,c)]) -> list of 192-byte proofs, job order."""
+        jobs = list(jobs)
+        arr = (JobStruct * len(jobs))()
+        keep = []
+        for i, job in enumerate(jobs):
+            slot, inputs, aux, r, s = job[:5]
+            abc = job[5] if len(job) > 5 else None
+            arr[i], k = self._job(slot, inputs, aux, r, s, abc)
+            keep.append(k)
+        out = np.zeros((len(jobs), 192), dtype=np.uint8)
+        self._check(self._L.masp_hip_prove_batch(self._h, len(jobs), arr, _p(out)))
+        return [out[i].tobytes() for i in range(len(jobs))]
+
+    # ---- building blocks ----
+    def msm_g1(self, bases, scalars):
+        bases, scalars = _u8(bases, 96), _u8(scalars, 32)
+        out = np.zeros(96, dtype=np.uint8)
+        self._check(self._L.masp_hip_msm_g1(self._h, _p(bases), _p(scalars), scalars.shape[0], _p(out)))
+        return out.tobytes()
+
+    def msm_g2(self, bases, scalars):
+        bases, scalars = _u8(bases, 192), _u8(scalars, 32)
+        out = np.zeros(192, dtype=np.uint8)
+        self._check(self._L.masp_hip_msm_g2(self._h, _p(bases), _p(scalars), scalars.shape[0], _p(out)))
+        return out.tobytes()
+
+    def quotient_h(self, a, b, c, logm):
+        a, b, c = _u8(a, 32), _u8(b, 32), _u8(c, 32)
+        out = np.zeros(((1 << logm) - 1, 32), dtype=np.uint8)
+        self._check(self._L.masp_hip_quotient_h(self._h, _p(a), _p(b), _p(c), a.shape[0], logm, _p(out)))
+        return out
+
+    def ntt(self, data, logm, inverse=False):
+        d = _u8(data, 32).copy()
+        self._check(self._L.masp_hip_ntt(self._h, _p(d), logm, 1 if inverse else 0))
+        return d
+
+    # ---- measurement hooks ----
+    def batch_upload(self, jobs):
+        jobs = list(jobs)
+        arr = (JobStruct * len(jobs))()
+        keep = []
+        for i, (slot, inputs, aux, r, s) in enumerate(jobs):
+            arr[i], k = self._job(slot, inputs, aux, r, s)
+            keep.append(k)
+        h = self._L.masp_hip_batch_upload(self._h, len(jobs), arr)
+        if h < 0:
+            raise MaspHipError(-h, self._L.masp_hip_last_error(self._h).decode(errors="replace"))
+        return h, len(jobs)
+
+    def batch_prove_resident(self, handle, n):
+        out = np.zeros((n, 192), dtype=np.uint8)
+        ms = C.c_float(0)
+        self._check(self._L.masp_hip_batch_prove_resident(self._h, handle, _p(out), C.byref(ms)))
+        return [out[i].tobytes() for i in range(n)], ms.value
+
+    def batch_free(self, handle):
+        self._check(self._L.masp_hip_batch_free(self._h, handle))
+
+    def bench_msm(self, handle, job, which, iters):
+        ms, nb = C.c_float(0), C.c_uint32(0)
+        self._check(self._L.masp_hip_bench_msm(self._h, handle, job, which, iters, C.byref(ms), C.byref(nb)))
+        return ms.value, nb.value

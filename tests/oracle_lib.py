@@ -5,7 +5,11 @@ import subprocess
 
 import numpy as np
 
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 _SO = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
 
 
@@ -13,11 +17,7 @@ def build():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
 
 
-class R1csStruct(C.Structure):
-    _fields_ = [("n_inputs", C.c_uint32), ("n_aux", C.c_uint32), ("n_constraints", C.c_uint32),
-                ("a_rowptr", C.c_void_p), ("a_col", C.c_void_p), ("a_coef", C.c_void_p),
-                ("b_rowptr", C.c_void_p), ("b_col", C.c_void_p), ("b_coef", C.c_void_p),
-                ("c_rowptr", C.c_void_p), ("c_col", C.c_void_p), ("c_coef", C.c_void_p)]
+from masp_amd.r1cs import R1cs  # noqa: E402,F401  (plain container; identical layout to oracle_r1cs)
 
 
 _lib = None
@@ -55,30 +55,6 @@ def lib():
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
-
-
-class R1cs:
-    """CSR R1CS in numpy: *_rowptr u32[n_constraints+1], *_col u32[nnz], *_coef u8[nnz,32] (LE canonical)."""
-
-    def __init__(self, n_inputs, n_aux, n_constraints, mats):
-        self.n_inputs, self.n_aux, self.n_constraints = n_inputs, n_aux, n_constraints
-        self.mats = [(np.ascontiguousarray(rp, dtype=np.uint32), np.ascontiguousarray(col, dtype=np.uint32),
-                      np.ascontiguousarray(coef, dtype=np.uint8)) for rp, col, coef in mats]
-        s = R1csStruct()
-        s.n_inputs, s.n_aux, s.n_constraints = n_inputs, n_aux, n_constraints
-        for name, (rp, col, coef) in zip("abc", self.mats):
-            setattr(s, name + "_rowptr", rp.ctypes.data)
-            setattr(s, name + "_col", col.ctypes.data)
-            setattr(s, name + "_coef", coef.ctypes.data)
-        self.struct = s
-
-    @property
-    def nrows(self):
-        return self.n_constraints + self.n_inputs
-
-    @property
-    def ref(self):
-        return C.byref(self.struct)
 
 
 def fr_op(op, a, b=0):

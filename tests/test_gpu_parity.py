@@ -1,0 +1,190 @@
+"""GPU parity tests proper: every call goes through the C ABI (include/masp_hip.h) of libmasp_hip.so and is
+compared bit-for-bit with the oracle on the same seeded inputs.  Run with `-m gpu` on an MI355X."""
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import toy_r1cs
+from pyref import R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import masp_amd
+    c = masp_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _le(x):
+    return np.frombuffer((x % R).to_bytes(32, "little"), np.uint8)
+
+
+def _rand_scalars(rng, n, bool_share=0.0):
+    out = np.zeros((n, 32), np.uint8)
+    for i in range(n):
+        u = rng.random()
+        if u < bool_share:
+            v = rng.randint(0, 1)
+        else:
+            v = rng.randrange(R)
+        out[i] = _le(v)
+    return out
+
+
+@pytest.mark.parametrize("logm", [1, 4, 9, 10, 11, 13, 17])
+def test_ntt_matches_oracle(ctx, logm):
+    rng = np.random.default_rng(logm)
+    m = 1 << logm
+    data = rng.integers(0, 256, size=(m, 32), dtype=np.uint8)
+    data[:, 31] &= 0x3f  # < 2^254 < r
+    assert (ctx.ntt(data, logm) == O.ntt(data, logm)).all()
+    assert (ctx.ntt(data, logm, inverse=True) == O.ntt(data, logm, inverse=True)).all()
+    assert (ctx.ntt(ctx.ntt(data, logm), logm, inverse=True) == data).all()
+
+
+@pytest.mark.parametrize("seed,n_inputs,n_free,n_constraints", [(21, 2, 3, 11), (22, 4, 30, 500), (23, 8, 200, 5000)])
+def test_quotient_matches_oracle(ctx, seed, n_inputs, n_free, n_constraints):
+    cs, inputs, aux, _ = toy_r1cs.make(seed, n_inputs, n_free, n_constraints)
+    a, b, c, *_ = O.r1cs_eval(cs, inputs, aux)
+    assert (ctx.quotient_h(a, b, c, cs.logm) == O.quotient_h(a, b, c, cs.logm)).all()
+
+
+def test_quotient_full_size_domain(ctx):
+    # 2^17 like Spend: random (unsatisfied) evaluation vectors — bellperson's sequence is defined for those too
+    rng = np.random.default_rng(5)
+    n = 100645
+    vecs = []
+    for _ in range(3):
+        v = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+        v[:, 31] &= 0x3f
+        vecs.append(v)
+    assert (ctx.quotient_h(*vecs, 17) == O.quotient_h(*vecs, 17)).all()
+
+
+def _edge_scalars(n, rng):
+    sc = _rand_scalars(rng, n, 0.4)
+    edge = [0, 1, 2, R - 1, R - 2, (1 << 255) % R, 0xffff, 0x10000, 0x8000, 0x8001, (1 << 128) - 1, 1 << 240]
+    for i, e in enumerate(edge[:n]):
+        sc[i] = _le(e)
+    return sc
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 40, 300, 5000, 40000])
+def test_msm_g1_matches_oracle(ctx, n):
+    rng = random.Random(n + 1)
+    ks = _rand_scalars(rng, n)
+    bases = O.g1_mul_gen_many(ks) if n else np.zeros((0, 96), np.uint8)
+    sc = _edge_scalars(n, rng)
+    if n >= 40:
+        bases[5] = bases[4]           # repeated base (P + P inside a bucket)
+        sc[5] = sc[4]
+        bases[7, :] = 0
+        bases[7, 0] = 0x40            # base at infinity
+    assert ctx.msm_g1(bases, sc) == O.msm_g1(bases, sc)
+
+
+def test_msm_g1_all_equal_and_cancelling(ctx):
+    # every scalar identical -> one bucket takes everything; and P, -P pairs cancel to infinity
+    rng = random.Random(77)
+    n = 600
+    bases = O.g1_mul_gen_many(_rand_scalars(rng, n))
+    sc = np.tile(_le(0x1234567), (n, 1))
+    assert ctx.msm_g1(bases, sc) == O.msm_g1(bases, sc)
+    half = n // 2
+    ks = _rand_scalars(rng, half)
+    kneg = np.stack([_le(R - int.from_bytes(k.tobytes(), "little")) for k in ks])
+    b2 = O.g1_mul_gen_many(np.concatenate([ks, kneg]))
+    s2 = np.tile(_le(3), (n, 1))
+    assert ctx.msm_g1(b2, s2) == b"\x40" + bytes(95) == O.msm_g1(b2, s2)
+
+
+@pytest.mark.parametrize("n", [1, 33, 700, 9000])
+def test_msm_g2_matches_oracle(ctx, n):
+    rng = random.Random(n + 100)
+    bases = O.g2_mul_gen_many(_rand_scalars(rng, n))
+    sc = _edge_scalars(n, rng)
+    assert ctx.msm_g2(bases, sc) == O.msm_g2(bases, sc)
+
+
+@pytest.mark.parametrize("seed,n_inputs,n_free,n_constraints", [(31, 2, 4, 9), (32, 4, 20, 200), (33, 8, 300, 3000)])
+def test_proof_bytes_match_oracle_and_closed_form(ctx, seed, n_inputs, n_free, n_constraints):
+    cs, inputs, aux, vals = toy_r1cs.make(seed, n_inputs, n_free, n_constraints, bool_share=0.7)
+    tw = toy_r1cs.toxic(seed)
+    pbuf = O.generate_parameters(cs, tw)
+    ctx.load_circuit(3, pbuf, cs)
+    rng = random.Random(seed)
+    r, s = rng.randrange(R), rng.randrange(R)
+    expect = O.create_proof(O.Params(pbuf), cs, inputs, aux, r, s)
+    assert expect == O.closed_form_proof(cs, tw, inputs, aux, r, s)
+    got = ctx.prove(3, inputs, aux, r, s)               # a,b,c computed on the GPU from the static R1CS
+    assert got == expect
+    a, b, c, *_ = O.r1cs_eval(cs, inputs, aux)
+    assert ctx.prove(3, inputs, aux, r, s, (a, b, c)) == expect   # caller-supplied evaluation vectors
+    assert O.verify_proof(pbuf, got, vals[1:n_inputs]) == 1
+    # r = s = 0 (no blinding) and extreme blinding
+    for rr, ss in ((0, 0), (R - 1, 1)):
+        assert ctx.prove(3, inputs, aux, rr, ss) == O.create_proof(O.Params(pbuf), cs, inputs, aux, rr, ss)
+
+
+def test_unsatisfied_assignment_matches_oracle(ctx):
+    # the reference bench proves an unsatisfiable witness (benches/sapling.rs:41,69): bytes must still agree
+    cs, inputs, aux, vals = toy_r1cs.make(41, 3, 10, 120)
+    aux = aux.copy()
+    aux[-1, 0] ^= 1
+    pbuf = O.generate_parameters(cs, toy_r1cs.toxic(41))
+    ctx.load_circuit(4, pbuf, cs)
+    got = ctx.prove(4, inputs, aux, 11, 12)
+    assert got == O.create_proof(O.Params(pbuf), cs, inputs, aux, 11, 12)
+    assert O.verify_proof(pbuf, got, vals[1:3]) == 0
+
+
+def test_batch_mixed_circuits_in_job_order(ctx):
+    specs = [(51, 2, 5, 40), (52, 5, 9, 90)]
+    loaded = []
+    for slot, (seed, ni, nf, nc) in enumerate(specs):
+        cs, inputs, aux, vals = toy_r1cs.make(seed, ni, nf, nc)
+        pbuf = O.generate_parameters(cs, toy_r1cs.toxic(seed))
+        ctx.load_circuit(5 + slot, pbuf, cs)
+        loaded.append((cs, inputs, aux, O.Params(pbuf)))
+    jobs, expect = [], []
+    for j in range(9):
+        which = j % 2
+        cs, inputs, aux, params = loaded[which]
+        r, s = 1000 + j, 2000 + 7 * j
+        jobs.append((5 + which, inputs, aux, r, s))
+        expect.append(O.create_proof(params, cs, inputs, aux, r, s))
+    assert ctx.prove_batch(jobs) == expect
+    h, n = ctx.batch_upload(jobs)
+    got, ms = ctx.batch_prove_resident(h, n)
+    assert got == expect and ms > 0
+    ctx.batch_free(h)
+
+
+def test_error_paths(ctx):
+    import masp_amd
+    cs, inputs, aux, _ = toy_r1cs.make(61, 2, 4, 12)
+    pbuf = O.generate_parameters(cs, toy_r1cs.toxic(61))
+    with pytest.raises(masp_amd.MaspHipError) as e:
+        ctx.prove(7, inputs, aux, 1, 2)
+    assert e.value.code == 7                      # slot empty
+    with pytest.raises(masp_amd.MaspHipError) as e:
+        ctx.load_circuit(7, pbuf[:500], cs)
+    assert e.value.code == 2                      # truncated params
+    other, *_ = toy_r1cs.make(62, 2, 4, 30)
+    with pytest.raises(masp_amd.MaspHipError) as e:
+        ctx.load_circuit(7, pbuf, other)
+    assert e.value.code == 3                      # shape mismatch
+    ctx.load_circuit(7, pbuf, cs)
+    bad = aux.copy()
+    bad[0] = 0xff                                 # >= r
+    with pytest.raises(masp_amd.MaspHipError) as e:
+        ctx.prove(7, inputs, bad, 1, 2)
+    assert e.value.code == 8
+    with pytest.raises(masp_amd.MaspHipError) as e:
+        ctx.prove(7, inputs, aux, R, 2)
+    assert e.value.code == 8
