@@ -56,48 +56,51 @@ MASP_HD Xyzz<O> xyzz_neg(const Xyzz<O>& p) {
     return r;
 }
 
-// dbl-2008-s-1 for XYZZ
+// dbl-2008-s-1 for XYZZ.  Out of line on purpose (reached from the rare P == Q branch of the additions
+// and from serial tails); G1: ~45 KiB, G2: call-based, tiny — see MASP_NOINLINE in field.cuh.
 template <class O>
-__host__ __device__ inline Xyzz<O> xyzz_dbl(const Xyzz<O>& p) {
+MASP_NOINLINE Xyzz<O> xyzz_dbl(const Xyzz<O>& p) {
     if (xyzz_is_inf(p)) return p;
     typedef typename O::T F;
+    typedef typename O::Cold K;
     F U = O::dbl(p.Y);
     if (O::is_zero(U)) return xyzz_inf<O>();  // order-2 point: cannot occur on these curves, kept for exactness
-    F V = O::sqr(U);
-    F W = O::mul(U, V);
-    F S = O::mul(p.X, V);
-    F X2 = O::sqr(p.X);
+    F V = K::sqr(U);
+    F W = K::mul(U, V);
+    F S = K::mul(p.X, V);
+    F X2 = K::sqr(p.X);
     F M = O::add(O::dbl(X2), X2);
     Xyzz<O> r;
-    r.X = O::sub(O::sqr(M), O::dbl(S));
-    r.Y = O::sub(O::mul(M, O::sub(S, r.X)), O::mul(W, p.Y));
-    r.ZZ = O::mul(V, p.ZZ);
-    r.ZZZ = O::mul(W, p.ZZZ);
+    r.X = O::sub(K::sqr(M), O::dbl(S));
+    r.Y = O::sub(K::mul(M, O::sub(S, r.X)), K::mul(W, p.Y));
+    r.ZZ = K::mul(V, p.ZZ);
+    r.ZZZ = K::mul(W, p.ZZZ);
     return r;
 }
 // doubling of an affine point (mdbl-2008-s-1)
 template <class O>
-__host__ __device__ inline Xyzz<O> xyzz_dbl_affine(const Affine<O>& p) {
+MASP_NOINLINE Xyzz<O> xyzz_dbl_affine(const Affine<O>& p) {
     if (aff_is_inf(p)) return xyzz_inf<O>();
     typedef typename O::T F;
+    typedef typename O::Cold K;
     F U = O::dbl(p.y);
     if (O::is_zero(U)) return xyzz_inf<O>();
-    F V = O::sqr(U);
-    F W = O::mul(U, V);
-    F S = O::mul(p.x, V);
-    F X2 = O::sqr(p.x);
+    F V = K::sqr(U);
+    F W = K::mul(U, V);
+    F S = K::mul(p.x, V);
+    F X2 = K::sqr(p.x);
     F M = O::add(O::dbl(X2), X2);
     Xyzz<O> r;
-    r.X = O::sub(O::sqr(M), O::dbl(S));
-    r.Y = O::sub(O::mul(M, O::sub(S, r.X)), O::mul(W, p.y));
+    r.X = O::sub(K::sqr(M), O::dbl(S));
+    r.Y = O::sub(K::mul(M, O::sub(S, r.X)), K::mul(W, p.y));
     r.ZZ = V;
     r.ZZZ = W;
     return r;
 }
 
 // acc += (negate ? -b : b), b affine (madd-2008-s)
-template <class O>
-__host__ __device__ inline void xyzz_madd(Xyzz<O>& acc, const Affine<O>& b, bool negate) {
+template <class O, class M = O>
+MASP_HD void xyzz_madd(Xyzz<O>& acc, const Affine<O>& b, bool negate) {
     typedef typename O::T F;
     if (aff_is_inf(b)) return;
     F by = negate ? O::neg(b.y) : b.y;
@@ -108,8 +111,8 @@ __host__ __device__ inline void xyzz_madd(Xyzz<O>& acc, const Affine<O>& b, bool
         acc.ZZZ = O::one();
         return;
     }
-    F U2 = O::mul(b.x, acc.ZZ);
-    F S2 = O::mul(by, acc.ZZZ);
+    F U2 = M::mul(b.x, acc.ZZ);
+    F S2 = M::mul(by, acc.ZZZ);
     F P = O::sub(U2, acc.X);
     F R = O::sub(S2, acc.Y);
     if (O::is_zero(P)) {
@@ -123,30 +126,30 @@ __host__ __device__ inline void xyzz_madd(Xyzz<O>& acc, const Affine<O>& b, bool
         }
         return;
     }
-    F PP = O::sqr(P);
-    F PPP = O::mul(P, PP);
-    F Q = O::mul(acc.X, PP);
-    F X3 = O::sub(O::sub(O::sqr(R), PPP), O::dbl(Q));
-    F Y3 = O::sub(O::mul(R, O::sub(Q, X3)), O::mul(acc.Y, PPP));
+    F PP = M::sqr(P);
+    F PPP = M::mul(P, PP);
+    F Q = M::mul(acc.X, PP);
+    F X3 = O::sub(O::sub(M::sqr(R), PPP), O::dbl(Q));
+    F Y3 = O::sub(M::mul(R, O::sub(Q, X3)), M::mul(acc.Y, PPP));
     acc.X = X3;
     acc.Y = Y3;
-    acc.ZZ = O::mul(acc.ZZ, PP);
-    acc.ZZZ = O::mul(acc.ZZZ, PPP);
+    acc.ZZ = M::mul(acc.ZZ, PP);
+    acc.ZZZ = M::mul(acc.ZZZ, PPP);
 }
 
 // acc += b, both XYZZ (add-2008-s)
-template <class O>
-__host__ __device__ inline void xyzz_add(Xyzz<O>& acc, const Xyzz<O>& b) {
+template <class O, class M = O>
+MASP_HD void xyzz_add(Xyzz<O>& acc, const Xyzz<O>& b) {
     typedef typename O::T F;
     if (xyzz_is_inf(b)) return;
     if (xyzz_is_inf(acc)) {
         acc = b;
         return;
     }
-    F U1 = O::mul(acc.X, b.ZZ);
-    F U2 = O::mul(b.X, acc.ZZ);
-    F S1 = O::mul(acc.Y, b.ZZZ);
-    F S2 = O::mul(b.Y, acc.ZZZ);
+    F U1 = M::mul(acc.X, b.ZZ);
+    F U2 = M::mul(b.X, acc.ZZ);
+    F S1 = M::mul(acc.Y, b.ZZZ);
+    F S2 = M::mul(b.Y, acc.ZZZ);
     F P = O::sub(U2, U1);
     F R = O::sub(S2, S1);
     if (O::is_zero(P)) {
@@ -156,37 +159,36 @@ __host__ __device__ inline void xyzz_add(Xyzz<O>& acc, const Xyzz<O>& b) {
             acc = xyzz_inf<O>();
         return;
     }
-    F PP = O::sqr(P);
-    F PPP = O::mul(P, PP);
-    F Q = O::mul(U1, PP);
-    F X3 = O::sub(O::sub(O::sqr(R), PPP), O::dbl(Q));
-    F Y3 = O::sub(O::mul(R, O::sub(Q, X3)), O::mul(S1, PPP));
+    F PP = M::sqr(P);
+    F PPP = M::mul(P, PP);
+    F Q = M::mul(U1, PP);
+    F X3 = O::sub(O::sub(M::sqr(R), PPP), O::dbl(Q));
+    F Y3 = O::sub(M::mul(R, O::sub(Q, X3)), M::mul(S1, PPP));
     acc.X = X3;
     acc.Y = Y3;
-    acc.ZZ = O::mul(O::mul(acc.ZZ, b.ZZ), PP);
-    acc.ZZZ = O::mul(O::mul(acc.ZZZ, b.ZZZ), PPP);
+    acc.ZZ = M::mul(M::mul(acc.ZZ, b.ZZ), PP);
+    acc.ZZZ = M::mul(M::mul(acc.ZZZ, b.ZZZ), PPP);
 }
 
-// [k]p for a small public multiplier (double-and-add, MSB first)
+// out-of-line forms for cold kernels and serial tails (G1: ~70 / ~50 KiB, inside the branch range)
 template <class O>
-__host__ __device__ inline Xyzz<O> xyzz_mul_u32(const Xyzz<O>& p, uint32_t k) {
-    Xyzz<O> r = xyzz_inf<O>();
-    for (int b = 31; b >= 0; --b) {
-        r = xyzz_dbl(r);
-        if ((k >> b) & 1) xyzz_add(r, p);
-    }
-    return r;
+MASP_NOINLINE void xyzz_add_nc(Xyzz<O>& acc, const Xyzz<O>& b) {
+    xyzz_add<O, typename O::Cold>(acc, b);
+}
+template <class O>
+MASP_NOINLINE void xyzz_madd_nc(Xyzz<O>& acc, const Affine<O>& b, bool negate) {
+    xyzz_madd<O, typename O::Cold>(acc, b, negate);
 }
 // [k]p for a 256-bit scalar given as 8 little-endian canonical limbs
 template <class O>
-__host__ __device__ inline Xyzz<O> xyzz_mul_scalar(const Xyzz<O>& p, const uint32_t* k) {
+MASP_HD Xyzz<O> xyzz_mul_scalar(const Xyzz<O>& p, const uint32_t* k) {
     Xyzz<O> r = xyzz_inf<O>();
     bool started = false;
     for (int i = 7; i >= 0; --i)
         for (int b = 31; b >= 0; --b) {
             if (started) r = xyzz_dbl(r);
             if ((k[i] >> b) & 1) {
-                xyzz_add(r, p);
+                xyzz_add_nc(r, p);
                 started = true;
             }
         }
@@ -194,7 +196,7 @@ __host__ __device__ inline Xyzz<O> xyzz_mul_scalar(const Xyzz<O>& p, const uint3
 }
 
 template <class O>
-__host__ __device__ inline Affine<O> xyzz_to_affine(const Xyzz<O>& p) {
+MASP_HD Affine<O> xyzz_to_affine(const Xyzz<O>& p) {
     Affine<O> r;
     if (xyzz_is_inf(p)) {
         r.x = O::zero();
@@ -203,10 +205,10 @@ __host__ __device__ inline Affine<O> xyzz_to_affine(const Xyzz<O>& p) {
     }
     // 1/ZZZ, then 1/ZZ = ZZZ^-2 * ZZ^2 ... cheaper: zi3 = 1/ZZZ ; zi2 = (zi3 * ZZ)^2  (since ZZ^3 = ZZZ^2 => ZZ/ZZZ = 1/Z)
     typename O::T zi3 = O::inv(p.ZZZ);
-    typename O::T zi = O::mul(zi3, p.ZZ);
-    typename O::T zi2 = O::sqr(zi);
-    r.x = O::mul(p.X, zi2);
-    r.y = O::mul(p.Y, zi3);
+    typename O::T zi = O::Cold::mul(zi3, p.ZZ);
+    typename O::T zi2 = O::Cold::sqr(zi);
+    r.x = O::Cold::mul(p.X, zi2);
+    r.y = O::Cold::mul(p.Y, zi3);
     return r;
 }
 

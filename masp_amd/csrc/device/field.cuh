@@ -16,6 +16,11 @@
 #include "consts.cuh"
 
 #define MASP_HD __host__ __device__ __forceinline__
+// Out-of-line variant.  NOTE (ROCm 7.2 / LLVM 22, gfx950): a non-kernel device function larger than the
+// +-128 KiB SOPP branch range gets its long branches relaxed through `s_getpc_b64 s[30:31]`, which
+// clobbers the return address and hangs the wave.  Every out-of-line function below is therefore kept
+// far smaller than that (the 384-bit product is ~5 KiB), and everything big is inlined into kernels.
+#define MASP_NOINLINE __host__ __device__ __noinline__
 
 namespace masp {
 
@@ -154,6 +159,11 @@ template <class C>
 MASP_HD Fe<C> fe_sqr(const Fe<C>& a) {
     return fe_mul(a, a);
 }
+// out-of-line product: used where code size matters more than the call (G2, serial tails)
+template <class C>
+MASP_NOINLINE Fe<C> fe_mul_nc(const Fe<C>& a, const Fe<C>& b) {
+    return fe_mul(a, b);
+}
 
 // canonical integer limbs <-> Montgomery form
 template <class C>
@@ -185,14 +195,14 @@ MASP_HD bool fe_canonical_ge_mod(const Fe<C>& a) {
 
 // a^e for a public exponent given as N little-endian limbs (not unrolled: used off the hot path)
 template <class C>
-__host__ __device__ inline Fe<C> fe_pow(const Fe<C>& a, const uint32_t* e, int nlimbs) {
+MASP_NOINLINE Fe<C> fe_pow(const Fe<C>& a, const uint32_t* e, int nlimbs) {
     Fe<C> r = fe_one<C>();
     bool started = false;
     for (int i = nlimbs - 1; i >= 0; --i)
         for (int b = 31; b >= 0; --b) {
-            if (started) r = fe_sqr(r);
+            if (started) r = fe_mul_nc(r, r);
             if ((e[i] >> b) & 1) {
-                r = started ? fe_mul(r, a) : a;
+                r = started ? fe_mul_nc(r, a) : a;
                 started = true;
             }
         }
@@ -200,7 +210,7 @@ __host__ __device__ inline Fe<C> fe_pow(const Fe<C>& a, const uint32_t* e, int n
 }
 // Fermat inverse (inv(0) = 0)
 template <class C>
-__host__ __device__ inline Fe<C> fe_inv(const Fe<C>& a) {
+MASP_NOINLINE Fe<C> fe_inv(const Fe<C>& a) {
     uint32_t e[C::N];
     for (int i = 0; i < C::N; ++i) e[i] = C::PM2[i];
     return fe_pow(a, e, C::N);
@@ -227,8 +237,15 @@ struct Fp2 {
 };
 
 // A uniform static interface so the curve code is written once for G1 (Fp) and G2 (Fp2).
+// `Cold` names the multiplier policy to use in out-of-line / cold code: same field, products by call.
+struct FpMulCold {
+    typedef Fp T;
+    static MASP_HD T mul(const T& a, const T& b) { return fe_mul_nc(a, b); }
+    static MASP_HD T sqr(const T& a) { return fe_mul_nc(a, a); }
+};
 struct FpOps {
     typedef Fp T;
+    typedef FpMulCold Cold;
     static MASP_HD T zero() { return fe_zero<FpCfg>(); }
     static MASP_HD T one() { return fe_one<FpCfg>(); }
     static MASP_HD T add(const T& a, const T& b) { return fe_add(a, b); }
@@ -239,33 +256,34 @@ struct FpOps {
     static MASP_HD T sqr(const T& a) { return fe_sqr(a); }
     static MASP_HD bool is_zero(const T& a) { return fe_is_zero(a); }
     static MASP_HD bool eq(const T& a, const T& b) { return fe_eq(a, b); }
-    static __host__ __device__ inline T inv(const T& a) { return fe_inv(a); }
+    static MASP_HD T inv(const T& a) { return fe_inv(a); }
 };
 struct Fp2Ops {
     typedef Fp2 T;
+    typedef Fp2Ops Cold;  // already call-based
     static MASP_HD T zero() { return {fe_zero<FpCfg>(), fe_zero<FpCfg>()}; }
     static MASP_HD T one() { return {fe_one<FpCfg>(), fe_zero<FpCfg>()}; }
     static MASP_HD T add(const T& a, const T& b) { return {fe_add(a.c0, b.c0), fe_add(a.c1, b.c1)}; }
     static MASP_HD T sub(const T& a, const T& b) { return {fe_sub(a.c0, b.c0), fe_sub(a.c1, b.c1)}; }
     static MASP_HD T neg(const T& a) { return {fe_neg(a.c0), fe_neg(a.c1)}; }
     static MASP_HD T dbl(const T& a) { return {fe_dbl(a.c0), fe_dbl(a.c1)}; }
-    // Karatsuba: 3 base-field products
-    static __host__ __device__ inline T mul(const T& a, const T& b) {
-        Fp aa = fe_mul(a.c0, b.c0), bb = fe_mul(a.c1, b.c1);
-        Fp cc = fe_mul(fe_add(a.c0, a.c1), fe_add(b.c0, b.c1));
+    // Karatsuba: 3 base-field products (out-of-line: keeps every G2 function small, see MASP_NOINLINE)
+    static MASP_HD T mul(const T& a, const T& b) {
+        Fp aa = fe_mul_nc(a.c0, b.c0), bb = fe_mul_nc(a.c1, b.c1);
+        Fp cc = fe_mul_nc(fe_add(a.c0, a.c1), fe_add(b.c0, b.c1));
         return {fe_sub(aa, bb), fe_sub(fe_sub(cc, aa), bb)};
     }
     // (a0 + a1)(a0 - a1) + 2 a0 a1 u : 2 base-field products
-    static __host__ __device__ inline T sqr(const T& a) {
+    static MASP_HD T sqr(const T& a) {
         Fp s = fe_add(a.c0, a.c1), d = fe_sub(a.c0, a.c1);
-        Fp m = fe_mul(a.c0, a.c1);
-        return {fe_mul(s, d), fe_dbl(m)};
+        Fp m = fe_mul_nc(a.c0, a.c1);
+        return {fe_mul_nc(s, d), fe_dbl(m)};
     }
     static MASP_HD bool is_zero(const T& a) { return fe_is_zero(a.c0) && fe_is_zero(a.c1); }
     static MASP_HD bool eq(const T& a, const T& b) { return fe_eq(a.c0, b.c0) && fe_eq(a.c1, b.c1); }
-    static __host__ __device__ inline T inv(const T& a) {
-        Fp n = fe_inv(fe_add(fe_sqr(a.c0), fe_sqr(a.c1)));
-        return {fe_mul(a.c0, n), fe_neg(fe_mul(a.c1, n))};
+    static MASP_HD T inv(const T& a) {
+        Fp n = fe_inv(fe_add(fe_mul_nc(a.c0, a.c0), fe_mul_nc(a.c1, a.c1)));
+        return {fe_mul_nc(a.c0, n), fe_neg(fe_mul_nc(a.c1, n))};
     }
 };
 

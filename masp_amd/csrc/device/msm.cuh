@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(64) k_xyzz_reduce(const Xyzz<O>* __restrict__ 
     if (lo >= n) return;
     uint32_t hi = lo + f < n ? lo + f : n;
     Xyzz<O> acc = in[lo];
-    for (uint32_t k = lo + 1; k < hi; ++k) xyzz_add(acc, in[k]);
+    for (uint32_t k = lo + 1; k < hi; ++k) xyzz_add_nc(acc, in[k]);
     out[t] = acc;
 }
 // ones list: out[t] = sum of tab[ones[t*f ..]]  (window-0 table rows)
@@ -227,8 +227,8 @@ __global__ void __launch_bounds__(64) k_msm_wsum_level(const Xyzz<O>* __restrict
     Xyzz<O> run = xyzz_inf<O>(), acc = xyzz_inf<O>();
     // running sum from the top: after the loop  acc = sum_l (l - lo + off) * B[l],  run = sum_l B[l]
     for (uint32_t l = hi; l-- > lo;) {
-        xyzz_add(run, B[l]);
-        if (l > lo || off) xyzz_add(acc, run);
+        xyzz_add_nc(run, B[l]);
+        if (l > lo || off) xyzz_add_nc(acc, run);
     }
     S[ch] = run;
     T[ch] = acc;
@@ -241,9 +241,9 @@ __global__ void k_msm_combine(const Xyzz<O>* __restrict__ tsum, int levels, int 
     Xyzz<O> acc = xyzz_inf<O>();
     for (int l = levels - 1; l >= 0; --l) {
         for (int k = 0; k < cs_log; ++k) acc = xyzz_dbl(acc);
-        xyzz_add(acc, tsum[l]);
+        xyzz_add_nc(acc, tsum[l]);
     }
-    xyzz_add(acc, *ones_sum);
+    xyzz_add_nc(acc, *ones_sum);
     *out = acc;
 }
 
