@@ -86,6 +86,15 @@ int masp_hip_prove(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* inputs, cons
 /* n independent jobs, results in job order; proofs_out: n x 192 bytes. */
 int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, uint8_t* proofs_out);
 
+/* Groth16 parameters for `cs` from explicit toxic waste (tau | alpha | beta | gamma | delta, 5 x 32 bytes LE),
+ * written in the bellman Parameters wire format.  Mirrors bellperson `generate_random_parameters`, which the
+ * reference's benches call (/root/reference/masp_proofs/benches/sapling.rs:24-36); needed because the real
+ * MPC parameters cannot be downloaded here.  *out_len receives the size; if cap is too small nothing is
+ * written and MASP_HIP_E_INVALID_ARG is returned (upper bound: masp_hip_parameters_max_size). */
+int masp_hip_generate_parameters(masp_hip_ctx* ctx, const masp_hip_r1cs* cs, const uint8_t toxic[160], uint8_t* out, size_t cap,
+                                 size_t* out_len);
+size_t masp_hip_parameters_max_size(const masp_hip_r1cs* cs);
+
 /* ---- building blocks (same kernels the prover uses) ---- */
 /* sum_i scalars[i] * bases[i]; bases uncompressed (96 / 192 B each), result uncompressed */
 int masp_hip_msm_g1(masp_hip_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[96]);
@@ -107,6 +116,14 @@ int masp_hip_batch_free(masp_hip_ctx* ctx, int handle);
 /* Runs the G1 MSM of query `which` (0 h, 1 l, 2 a, 3 b_g1) of circuit `slot` `iters` times on resident job
  * `job` of `handle`; returns average kernel-sequence time per MSM in ms and the number of bases. */
 int masp_hip_bench_msm(masp_hip_ctx* ctx, int handle, size_t job, int which, int iters, float* avg_ms, uint32_t* n_bases);
+
+/* Live timing of the dominant kernel, k_msm_accumulate over G1 (bucket accumulation): when enabled, every launch
+ * is bracketed by HIP events on its own stream.  read: summed duration, launch count and the algorithmic bytes
+ * (n x (96 + 32) per G1 MSM of n points) of all launches since enable/reset. */
+int masp_hip_profile_enable(masp_hip_ctx* ctx, int on);
+int masp_hip_profile_read(masp_hip_ctx* ctx, double* total_ms, uint64_t* launches, uint64_t* alg_bytes);
+/* hipDeviceSynchronize on the context's device */
+int masp_hip_sync(masp_hip_ctx* ctx);
 
 #ifdef __cplusplus
 }

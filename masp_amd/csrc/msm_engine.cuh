@@ -135,10 +135,58 @@ struct MsmWorkspace {
     }
 };
 
+// Optional live timing of the dominant kernel (bucket accumulation) with HIP events on the launching stream.
+struct MsmProfile {
+    struct Rec {
+        hipEvent_t e0, e1;
+        uint64_t alg_bytes;
+    };
+    std::vector<Rec> recs;      // pending (recorded, not yet read)
+    std::vector<Rec> pool;      // reusable event pairs
+    double total_ms = 0;
+    uint64_t launches = 0, alg_bytes = 0;
+    ~MsmProfile() {
+        for (auto& r : recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+        for (auto& r : pool) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    }
+    Rec acquire() {
+        if (!pool.empty()) {
+            Rec r = pool.back();
+            pool.pop_back();
+            return r;
+        }
+        Rec r;
+        hipEventCreate(&r.e0);
+        hipEventCreate(&r.e1);
+        r.alg_bytes = 0;
+        return r;
+    }
+    // call after the stream has been synchronised
+    void collect() {
+        for (auto& r : recs) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+                total_ms += ms;
+                ++launches;
+                alg_bytes += r.alg_bytes;
+            }
+            pool.push_back(r);
+        }
+        recs.clear();
+    }
+    void reset() {
+        collect();
+        total_ms = 0;
+        launches = 0;
+        alg_bytes = 0;
+    }
+};
+
 // Enqueue sum_i scalars[i] * P_i on stream `s`.  d_scalars: n x 8 canonical LE limbs on the device.
 // d_out: one XYZZ point on the device.  No host synchronisation.
 template <class O, int BYTES>
-int msm_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, MsmWorkspace<O>& ws, const uint32_t* d_scalars, Xyzz<O>* d_out) {
+int msm_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, MsmWorkspace<O>& ws, const uint32_t* d_scalars, Xyzz<O>* d_out,
+                MsmProfile* prof = nullptr) {
     const MsmGeom& g = B.g;
     const uint32_t n = B.n;
     if (n == 0) {
@@ -155,7 +203,17 @@ int msm_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, MsmWorkspace<O>& ws,
     hipLaunchKernelGGL(k_msm_digits, dim3((n + 255) / 256), dim3(256), 0, s, d_scalars, n, g, ws.ent, ws.hist, ws.ones, ws.n_ones);
     hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, s, ws.hist, ws.start, nsub);
     hipLaunchKernelGGL(k_msm_scatter, dim3((total + 255) / 256), dim3(256), 0, s, ws.ent, total, n, ws.start, ws.fill, ws.sorted);
+    MsmProfile::Rec rec{};
+    if (prof) {
+        rec = prof->acquire();
+        rec.alg_bytes = (uint64_t)n * (BYTES + 32);  // n x (affine base + scalar)
+        hipEventRecord(rec.e0, s);
+    }
     hipLaunchKernelGGL((k_msm_accumulate<O>), dim3((nsub + 63) / 64), dim3(64), 0, s, B.tab, ws.sorted, ws.start, ws.hist, nsub, ws.sub);
+    if (prof) {
+        hipEventRecord(rec.e1, s);
+        prof->recs.push_back(rec);
+    }
     // sub-buckets -> buckets
     const Xyzz<O>* bk = ws.sub;
     if (g.sl_log) {

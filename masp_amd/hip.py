@@ -49,6 +49,9 @@ def load_library():
     L.masp_hip_circuit_load.argtypes = [vp, u32, vp, sz, vp]
     L.masp_hip_prove.argtypes = [vp, u32, vp, vp, vp, vp, vp, C.c_char_p, C.c_char_p, vp]
     L.masp_hip_prove_batch.argtypes = [vp, sz, vp, vp]
+    L.masp_hip_generate_parameters.argtypes = [vp, vp, C.c_char_p, vp, sz, C.POINTER(sz)]
+    L.masp_hip_parameters_max_size.argtypes = [vp]
+    L.masp_hip_parameters_max_size.restype = sz
     L.masp_hip_msm_g1.argtypes = [vp, vp, vp, sz, vp]
     L.masp_hip_msm_g2.argtypes = [vp, vp, vp, sz, vp]
     L.masp_hip_quotient_h.argtypes = [vp, vp, vp, vp, sz, u32, vp]
@@ -57,6 +60,9 @@ def load_library():
     L.masp_hip_batch_prove_resident.argtypes = [vp, C.c_int, vp, C.POINTER(C.c_float)]
     L.masp_hip_batch_free.argtypes = [vp, C.c_int]
     L.masp_hip_bench_msm.argtypes = [vp, C.c_int, sz, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(u32)]
+    L.masp_hip_profile_enable.argtypes = [vp, C.c_int]
+    L.masp_hip_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.masp_hip_sync.argtypes = [vp]
     _lib = L
     return L
 
@@ -146,6 +152,15 @@ class Context:
         self._check(self._L.masp_hip_prove_batch(self._h, len(jobs), arr, _p(out)))
         return [out[i].tobytes() for i in range(len(jobs))]
 
+    def generate_parameters(self, cs, toxic):
+        """toxic: (tau, alpha, beta, gamma, delta) ints -> Parameters bytes (bellman wire format), np.uint8."""
+        t = b"".join(_scalar32(x) for x in toxic)
+        cap = self._L.masp_hip_parameters_max_size(cs.ref)
+        out = np.zeros(cap, dtype=np.uint8)
+        n = C.c_size_t(0)
+        self._check(self._L.masp_hip_generate_parameters(self._h, cs.ref, t, _p(out), cap, C.byref(n)))
+        return out[:n.value].copy()
+
     # ---- building blocks ----
     def msm_g1(self, bases, scalars):
         bases, scalars = _u8(bases, 96), _u8(scalars, 32)
@@ -191,6 +206,18 @@ class Context:
 
     def batch_free(self, handle):
         self._check(self._L.masp_hip_batch_free(self._h, handle))
+
+    def profile_enable(self, on=True):
+        self._check(self._L.masp_hip_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        """-> (summed k_msm_accumulate<G1> ms, launches, algorithmic bytes)"""
+        t, l, b = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+        self._check(self._L.masp_hip_profile_read(self._h, C.byref(t), C.byref(l), C.byref(b)))
+        return t.value, l.value, b.value
+
+    def sync(self):
+        self._check(self._L.masp_hip_sync(self._h))
 
     def bench_msm(self, handle, job, which, iters):
         ms, nb = C.c_float(0), C.c_uint32(0)

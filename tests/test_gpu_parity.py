@@ -188,3 +188,26 @@ def test_error_paths(ctx):
     with pytest.raises(masp_amd.MaspHipError) as e:
         ctx.prove(7, inputs, aux, R, 2)
     assert e.value.code == 8
+
+
+@pytest.mark.parametrize("seed,n_inputs,n_free,n_constraints", [(71, 2, 4, 9), (72, 6, 50, 600)])
+def test_generate_parameters_matches_oracle(ctx, seed, n_inputs, n_free, n_constraints):
+    cs, inputs, aux, vals = toy_r1cs.make(seed, n_inputs, n_free, n_constraints)
+    tw = toy_r1cs.toxic(seed)
+    assert ctx.generate_parameters(cs, tw).tobytes() == O.generate_parameters(cs, tw).tobytes()
+
+
+def test_spend_shaped_full_size_proof(ctx):
+    """BASELINE.json configs[1] sizes: NTT 2^17, G1 MSMs 131071/100497/86931/62170, G2 MSM 62170."""
+    from masp_amd import synthetic
+    cs, inputs, aux = synthetic.shaped("spend", seed=3)
+    tw = synthetic.toxic_waste(9)
+    params = ctx.generate_parameters(cs, tw)
+    assert params.size == 48482520          # SURVEY.md App. C.3: params body bytes of the real Spend file
+    ctx.load_circuit(0, params, cs)
+    r, s = 0x1234567890abcdef, 0xfedcba0987654321
+    proof = ctx.prove(0, inputs, aux, r, s)
+    assert proof == O.closed_form_proof(cs, tw, inputs, aux, r, s)      # oracle 1: no NTT / MSM involved
+    pub = [int.from_bytes(inputs[i].tobytes(), "little") for i in range(1, cs.n_inputs)]
+    assert O.verify_proof(params[:868 + 96 * cs.n_inputs], proof, pub) == 1   # oracle 2: pairing check
+    assert proof == O.create_proof(O.Params(params), cs, inputs, aux, r, s)  # oracle 3: CPU restatement
