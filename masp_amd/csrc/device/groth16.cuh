@@ -50,14 +50,44 @@ struct VkDevice {
     G2Affine beta_g2, delta_g2;
 };
 
+// Fixed-base tables for the per-circuit points that get multiplied by r, s, rs in every proof:
+// tab[w*255 + d-1] = d * 2^(8w) * P in XYZZ form (no inversions to build), w < 32.  One lane per window,
+// blockIdx.x selects the point.
+template <class O>
+__global__ void __launch_bounds__(64) k_fixed_table_xyzz(const Affine<O>* __restrict__ pts, Xyzz<O>* __restrict__ tabs) {
+    const uint32_t w = threadIdx.x;
+    if (w >= 32) return;
+    Xyzz<O> base = xyzz_from_affine(pts[blockIdx.x]);
+    for (uint32_t k = 0; k < 8 * w; ++k) base = xyzz_dbl(base);
+    Xyzz<O>* tab = tabs + (size_t)blockIdx.x * 32 * 255 + w * 255;
+    Xyzz<O> cur = base;
+    for (uint32_t d = 1; d <= 255; ++d) {
+        tab[d - 1] = cur;
+        xyzz_add_nc(cur, base);
+    }
+}
+template <class O>
+__device__ __forceinline__ Xyzz<O> xyzz_fixed_mul(const Xyzz<O>* __restrict__ tab, const Fr& k) {
+    Xyzz<O> acc = xyzz_inf<O>();
+    for (int w = 0; w < 32; ++w) {
+        uint32_t d = (k.v[w >> 2] >> (8 * (w & 3))) & 0xffu;
+        if (d) xyzz_add_nc(acc, tab[w * 255 + d - 1]);
+    }
+    return acc;
+}
+
 // Proof assembly:
 //   g_a = r*delta1 + alpha1 + A
 //   g_b = s*delta2 + beta2 + B2
 //   g_c = (r s)*delta1 + s*alpha1 + r*beta1 + s*A + r*B1 + H + L
-// One workgroup of 128 lanes: wave 0 lanes 0..5 run the six G1 scalar multiplications side by side
-// (same instruction stream, different data), wave 1 lane 0 the G2 one; then three lanes normalise
-// and encode.  rs: 8 limbs r | 8 limbs s (canonical).
-__global__ void __launch_bounds__(128) k_groth16_assemble(const VkDevice* __restrict__ vk, const G1Xyzz* __restrict__ msm_g1 /* H, L, A, B1 */,
+// One workgroup of three waves so that the three differently-shaped jobs do not serialise inside a wave:
+//   wave 0, lanes 0..1 : the two variable-base multiplications  s*A, r*B1     (255 doublings each)
+//   wave 1, lane 0     : s*delta2 on G2 through its fixed-base table          (<= 32 additions)
+//   wave 2, lanes 0..3 : r*delta1, s*alpha1, r*beta1, (r s)*delta1 through fixed-base tables
+// then three lanes normalise and encode.  rs: 8 limbs r | 8 limbs s (canonical).
+// fb1: tables of delta1, alpha1, beta1 (in that order); fb2: table of delta2.
+__global__ void __launch_bounds__(192) k_groth16_assemble(const VkDevice* __restrict__ vk, const G1Xyzz* __restrict__ fb1,
+                                                          const G2Xyzz* __restrict__ fb2, const G1Xyzz* __restrict__ msm_g1 /* H, L, A, B1 */,
                                                           const G2Xyzz* __restrict__ msm_g2, const uint32_t* __restrict__ rs,
                                                           uint8_t* __restrict__ proof) {
     __shared__ G1Xyzz part[6];
@@ -68,28 +98,26 @@ __global__ void __launch_bounds__(128) k_groth16_assemble(const VkDevice* __rest
         r.v[i] = rs[i];
         s.v[i] = rs[8 + i];
     }
-    if (tid < 6) {
+    constexpr size_t TAB = 32 * 255;
+    if (tid < 2) {
+        part[3 + tid] = xyzz_mul_scalar(tid == 0 ? msm_g1[2] : msm_g1[3], tid == 0 ? s.v : r.v);  // s*A, r*B1
+    } else if (tid == 64) {
+        part2 = xyzz_fixed_mul<Fp2Ops>(fb2, s);
+    } else if (tid >= 128 && tid < 132) {
+        const uint32_t j = tid - 128;
         Fr rs_prod = fe_mul(fe_to_mont(r), s);  // mont(r) * s = r*s mod q, canonical
-        G1Xyzz base;
-        Fr k;
-        switch (tid) {
-            case 0: base = xyzz_from_affine(vk->delta_g1); k = r; break;
-            case 1: base = xyzz_from_affine(vk->alpha_g1); k = s; break;
-            case 2: base = xyzz_from_affine(vk->beta_g1); k = r; break;
-            case 3: base = msm_g1[2]; k = s; break;
-            case 4: base = msm_g1[3]; k = r; break;
-            default: base = xyzz_from_affine(vk->delta_g1); k = rs_prod; break;
-        }
-        part[tid] = xyzz_mul_scalar(base, k.v);
+        const G1Xyzz* tab = fb1 + (j == 1 ? TAB : j == 2 ? 2 * TAB : 0);
+        Fr k = j == 0 ? r : j == 1 ? s : j == 2 ? r : rs_prod;
+        G1Xyzz v = xyzz_fixed_mul<FpOps>(tab, k);
+        part[j == 3 ? 5 : j] = v;  // 0: r*delta1, 1: s*alpha1, 2: r*beta1, 5: (r s)*delta1
     }
-    if (tid == 64) part2 = xyzz_mul_scalar(xyzz_from_affine(vk->delta_g2), s.v);
     __syncthreads();
     if (tid == 0) {
         G1Xyzz ga = part[0];
         xyzz_madd_nc(ga, vk->alpha_g1, false);
         xyzz_add_nc(ga, msm_g1[2]);
         g1_write_compressed(xyzz_to_affine(ga), proof);
-    } else if (tid == 1) {
+    } else if (tid == 128) {
         G1Xyzz gc = part[5];
         xyzz_add_nc(gc, part[1]);
         xyzz_add_nc(gc, part[2]);

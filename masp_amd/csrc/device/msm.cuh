@@ -214,24 +214,56 @@ __global__ void __launch_bounds__(64) k_msm_ones(const Affine<O>* __restrict__ t
     }
     out[t] = acc;
 }
-// One level of the weighted sum  V(B, off) = sum_k (k + off) * B[k]:
-// chunk ch of `cs` elements yields S[ch] = sum_l B[ch*cs+l] and T[ch] = sum_l (l + off) * B[ch*cs+l];
-// then V(B, off) = sum_ch T[ch] + cs * V(S, 0).
+// One level of the weighted sum  V(B, off) = sum_k (k + off) * B[k], one workgroup per chunk of WSUM_CS
+// elements:  S[ch] = sum_l B[ch*cs + l],  T[ch] = sum_l (l + off) * B[ch*cs + l];  then
+// V(B, off) = sum_ch T[ch] + cs * V(S, 0).  Inside the workgroup the running sums are a log-depth suffix scan
+// followed by a tree reduction through LDS (16 dependent additions instead of 2*cs), because a single
+// dependent XYZZ addition costs tens of microseconds on one wave.
+static constexpr uint32_t WSUM_CS_LOG = 8;
+static constexpr uint32_t WSUM_CS = 1u << WSUM_CS_LOG;
 template <class O>
-__global__ void __launch_bounds__(64) k_msm_wsum_level(const Xyzz<O>* __restrict__ B, uint32_t m, uint32_t cs, uint32_t off,
-                                                       Xyzz<O>* __restrict__ S, Xyzz<O>* __restrict__ T) {
-    uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t lo = ch * cs;
-    if (lo >= m) return;
-    uint32_t hi = lo + cs < m ? lo + cs : m;
-    Xyzz<O> run = xyzz_inf<O>(), acc = xyzz_inf<O>();
-    // running sum from the top: after the loop  acc = sum_l (l - lo + off) * B[l],  run = sum_l B[l]
-    for (uint32_t l = hi; l-- > lo;) {
-        xyzz_add_nc(run, B[l]);
-        if (l > lo || off) xyzz_add_nc(acc, run);
+__global__ void __launch_bounds__(256) k_msm_wsum_level(const Xyzz<O>* __restrict__ B, uint32_t m, uint32_t off,
+                                                        Xyzz<O>* __restrict__ S, Xyzz<O>* __restrict__ T) {
+    extern __shared__ uint4 wsum_lds[];
+    Xyzz<O>* sh = reinterpret_cast<Xyzz<O>*>(wsum_lds);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t k = blockIdx.x * WSUM_CS + tid;
+    Xyzz<O> x = k < m ? B[k] : xyzz_inf<O>();
+    // inclusive suffix scan: x_i = sum_{j >= i} B_j over the chunk
+    for (uint32_t d = 1; d < WSUM_CS; d <<= 1) {
+        sh[tid] = x;
+        __syncthreads();
+        if (tid + d < WSUM_CS) xyzz_add_nc(x, sh[tid + d]);
+        __syncthreads();
     }
-    S[ch] = run;
-    T[ch] = acc;
+    // sum_l l * B_l = sum_{i >= 1} x_i ;  with off = 1 the i = 0 term joins in
+    Xyzz<O> y = (tid > 0 || off) ? x : xyzz_inf<O>();
+    for (uint32_t d = WSUM_CS >> 1; d >= 1; d >>= 1) {
+        sh[tid] = y;
+        __syncthreads();
+        if (tid < d) xyzz_add_nc(y, sh[tid + d]);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        S[blockIdx.x] = x;
+        T[blockIdx.x] = y;
+    }
+}
+// out[b] = sum of in[b*256 .. min(n, b*256+256)) by an LDS tree (8 dependent additions)
+template <class O>
+__global__ void __launch_bounds__(256) k_xyzz_reduce_block(const Xyzz<O>* __restrict__ in, uint32_t n, Xyzz<O>* __restrict__ out) {
+    extern __shared__ uint4 wsum_lds[];
+    Xyzz<O>* sh = reinterpret_cast<Xyzz<O>*>(wsum_lds);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t k = blockIdx.x * 256 + tid;
+    Xyzz<O> y = k < n ? in[k] : xyzz_inf<O>();
+    for (uint32_t d = 128; d >= 1; d >>= 1) {
+        sh[tid] = y;
+        __syncthreads();
+        if (tid < d) xyzz_add_nc(y, sh[tid + d]);
+        __syncthreads();
+    }
+    if (tid == 0) out[blockIdx.x] = y;
 }
 // V = T0 + cs*(T1 + cs*(T2 + ...)) + ones ;  tsum[l] holds the fully reduced T of level l.
 template <class O>

@@ -67,7 +67,7 @@ struct MsmBases {
 // ---- workspace ------------------------------------------------------------------------------------
 template <class O>
 struct MsmWorkspace {
-    static constexpr uint32_t CS_LOG = 5;   // running-sum chunk = 32 buckets
+    static constexpr uint32_t CS_LOG = WSUM_CS_LOG;   // weighted-sum chunk = one 256-lane workgroup
     static constexpr uint32_t RF = 32;      // plain reduction fan-in
     static constexpr uint32_t ONES_F = 32;  // ones-list: bases per lane in the first pass
 
@@ -120,13 +120,14 @@ struct MsmWorkspace {
     }
 
     // reduce `m` points at `src` to one at `dst` (src is clobbered only if it is one of R[]).
+    // Workgroup tree reductions (fan-in 256, 8 dependent additions per pass).
     void reduce_to_one(hipStream_t s, const Xyzz<O>* src, uint32_t m, Xyzz<O>* dst) {
         int flip = 0;
         const Xyzz<O>* cur = src;
         while (true) {
-            uint32_t outn = (m + RF - 1) / RF;
+            uint32_t outn = (m + 255) / 256;
             Xyzz<O>* out = outn == 1 ? dst : R[flip];
-            hipLaunchKernelGGL((k_xyzz_reduce<O>), dim3((outn + 63) / 64), dim3(64), 0, s, cur, m, RF, out);
+            hipLaunchKernelGGL((k_xyzz_reduce_block<O>), dim3(outn), dim3(256), 256 * sizeof(Xyzz<O>), s, cur, m, out);
             if (outn == 1) break;
             cur = out;
             m = outn;
@@ -195,6 +196,19 @@ int msm_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, MsmWorkspace<O>& ws,
     }
     int rc = ws.reserve(n, g);
     if (rc) return rc;
+    {
+        // the LDS tree kernels keep 256 XYZZ points per workgroup: 48 KiB (G1) / 96 KiB (G2) of the 160 KiB LDS
+        static bool lds_ok = [] {
+            int bytes = 256 * (int)sizeof(Xyzz<O>);
+            bool ok = hipFuncSetAttribute((const void*)k_msm_wsum_level<O>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+            ok = ok && hipFuncSetAttribute((const void*)k_xyzz_reduce_block<O>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+            return ok;
+        }();
+        if (!lds_ok) {
+            last_hip_error() = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
+            return MASP_HIP_E_HIP;
+        }
+    }
     const uint32_t nsub = g.nsub();
     const uint32_t total = n * g.W;
     HIP_TRY(hipMemsetAsync(ws.hist, 0, 4 * (size_t)nsub, s));
@@ -226,7 +240,7 @@ int msm_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, MsmWorkspace<O>& ws,
     int level = 0, flip = 0;
     do {
         uint32_t chunks = (m + cs - 1) / cs;
-        hipLaunchKernelGGL((k_msm_wsum_level<O>), dim3((chunks + 63) / 64), dim3(64), 0, s, bk, m, cs, off, ws.S[flip], ws.T);
+        hipLaunchKernelGGL((k_msm_wsum_level<O>), dim3(chunks), dim3(256), 256 * sizeof(Xyzz<O>), s, bk, m, off, ws.S[flip], ws.T);
         ws.reduce_to_one(s, ws.T, chunks, ws.tsum + level);
         bk = ws.S[flip];
         flip ^= 1;

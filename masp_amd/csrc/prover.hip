@@ -111,6 +111,8 @@ struct Circuit {
     DevBuf<uint32_t> a_var, b_var;
     uint32_t na = 0, nbq = 0;
     DevBuf<VkDevice> vk;
+    DevBuf<G1Xyzz> fb1;  // fixed-base tables of delta1, alpha1, beta1
+    DevBuf<G2Xyzz> fb2;  // fixed-base table of delta2
     BasesG1 h, l, a, b1;
     BasesG2 b2;
     NttDomain* dom = nullptr;
@@ -293,7 +295,7 @@ static int enqueue_proof(Slot& sl, Circuit& C, const Fr* d_w, const Fr* const d_
     if ((rc = msm_enqueue(s, C.a, sl.ws1, (const uint32_t*)sl.sa.p, sl.res1.p + 2, prof))) return rc;
     if ((rc = msm_enqueue(s, C.b1, sl.ws1, (const uint32_t*)sl.sb.p, sl.res1.p + 3, prof))) return rc;
     if ((rc = msm_enqueue(s, C.b2, sl.ws2, (const uint32_t*)sl.sb.p, sl.res2.p))) return rc;
-    hipLaunchKernelGGL(k_groth16_assemble, dim3(1), dim3(128), 0, s, C.vk.p, sl.res1.p, sl.res2.p, d_rs, d_proof);
+    hipLaunchKernelGGL(k_groth16_assemble, dim3(1), dim3(192), 0, s, C.vk.p, C.fb1.p, C.fb2.p, sl.res1.p, sl.res2.p, d_rs, d_proof);
     return MASP_HIP_OK;
 }
 
@@ -457,6 +459,20 @@ int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* param
         }
         if (hflag) return MASP_HIP_E_SCALAR_RANGE;
         if (hst & (PT_BAD_FLAGS | PT_NOT_CANONICAL)) return MASP_HIP_E_PARAMS_FORMAT;
+        // fixed-base tables for the points every proof multiplies by r, s, rs
+        DevBuf<G1Affine> p1;
+        DevBuf<G2Affine> p2;
+        if ((rc = p1.reserve(3)) || (rc = p2.reserve(1)) || (rc = C->fb1.reserve(3 * 32 * 255)) || (rc = C->fb2.reserve(32 * 255))) return fail(ctx, rc);
+        hipMemcpyAsync(p1.p + 0, &v->delta_g1, sizeof(G1Affine), hipMemcpyDeviceToDevice, s);
+        hipMemcpyAsync(p1.p + 1, &v->alpha_g1, sizeof(G1Affine), hipMemcpyDeviceToDevice, s);
+        hipMemcpyAsync(p1.p + 2, &v->beta_g1, sizeof(G1Affine), hipMemcpyDeviceToDevice, s);
+        hipMemcpyAsync(p2.p, &v->delta_g2, sizeof(G2Affine), hipMemcpyDeviceToDevice, s);
+        hipLaunchKernelGGL((k_fixed_table_xyzz<FpOps>), dim3(3), dim3(64), 0, s, p1.p, C->fb1.p);
+        hipLaunchKernelGGL((k_fixed_table_xyzz<Fp2Ops>), dim3(1), dim3(64), 0, s, p2.p, C->fb2.p);
+        if (hipStreamSynchronize(s) != hipSuccess) {
+            last_hip_error() = std::string("fixed-base tables failed: ") + hipGetErrorString(hipGetLastError());
+            return fail(ctx, MASP_HIP_E_HIP);
+        }
         // delta at infinity -> bellperson's UnexpectedIdentity; alpha/beta at infinity are merely degenerate
         if ((params[576] & 0x40) || (params[672] & 0x40)) return MASP_HIP_E_UNEXPECTED_IDENTITY;
     }
