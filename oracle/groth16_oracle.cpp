@@ -25,7 +25,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -56,20 +58,80 @@ static int nthreads() {
     unsigned n = std::thread::hardware_concurrency();
     return n ? (int)n : 1;
 }
-static void parallel_for(size_t n, const std::function<void(size_t, size_t, int)>& fn) {
-    int T = nthreads();
-    if ((size_t)T > n) T = n ? (int)n : 1;
-    if (T <= 1) {
-        fn(0, n, 0);
-        return;
+// Persistent worker pool (bellperson's CPU path runs on a global rayon pool; spawning threads per NTT
+// stage would dominate on many-core hosts).  grain = minimum items per task.
+class Pool {
+  public:
+    static Pool& get() {
+        static Pool* p = new Pool;  // leaked on purpose: workers block on its condition variable at exit
+        return *p;
     }
-    std::vector<std::thread> th;
-    size_t chunk = (n + T - 1) / T;
-    for (int t = 0; t < T; ++t) {
-        size_t lo = std::min(n, chunk * t), hi = std::min(n, lo + chunk);
-        th.emplace_back(fn, lo, hi, t);
+    void run(size_t n, size_t grain, const std::function<void(size_t, size_t, int)>& fn) {
+        int T = nthreads();
+        size_t maxT = grain ? (n + grain - 1) / grain : n;
+        if ((size_t)T > maxT) T = (int)std::max<size_t>(maxT, 1);
+        if (T <= 1 || n == 0) {
+            fn(0, n, 0);
+            return;
+        }
+        std::unique_lock<std::mutex> api(api_mu_);  // one parallel region at a time
+        ensure_workers(T - 1);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &fn;
+            n_ = n;
+            parts_ = T;
+            next_ = 1;  // part 0 runs on the caller
+            pending_ = T - 1;
+            ++gen_;
+        }
+        cv_.notify_all();
+        size_t chunk = (n + T - 1) / T;
+        fn(0, std::min(n, chunk), 0);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [&] { return pending_ == 0; });
+        fn_ = nullptr;
     }
-    for (auto& x : th) x.join();
+
+  private:
+    void ensure_workers(int want) {
+        while ((int)workers_.size() < want) {
+            int id = (int)workers_.size();
+            workers_.emplace_back([this, id] { loop(id); });
+            workers_.back().detach();
+        }
+    }
+    void loop(int) {
+        uint64_t seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return gen_ != seen && next_ < parts_; });
+            if (gen_ == seen) continue;
+            while (next_ < parts_) {
+                int part = next_++;
+                const std::function<void(size_t, size_t, int)>* fn = fn_;
+                size_t n = n_;
+                int T = parts_;
+                lk.unlock();
+                size_t chunk = (n + T - 1) / T;
+                size_t lo = std::min(n, chunk * part), hi = std::min(n, lo + chunk);
+                (*fn)(lo, hi, part);
+                lk.lock();
+                if (--pending_ == 0) done_cv_.notify_all();
+            }
+            seen = gen_;
+        }
+    }
+    std::mutex api_mu_, mu_;
+    std::condition_variable cv_, done_cv_;
+    std::vector<std::thread> workers_;
+    const std::function<void(size_t, size_t, int)>* fn_ = nullptr;
+    size_t n_ = 0;
+    int parts_ = 0, next_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+};
+static void parallel_for(size_t n, const std::function<void(size_t, size_t, int)>& fn, size_t grain = 1) {
+    Pool::get().run(n, grain, fn);
 }
 static double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -136,18 +198,24 @@ static void fft(std::vector<Fr>& a, const Fr& omega, uint32_t logn) {
         for (uint32_t i = s + 1; i < logn; ++i) w_m = w_m.sqr();  // omega^(n/(2m))
         // precompute the m twiddles of this stage once
         std::vector<Fr> tw(m);
-        tw[0] = Fr::one();
-        for (size_t j = 1; j < m; ++j) tw[j] = tw[j - 1] * w_m;
-        parallel_for(n / (2 * m), [&](size_t lo, size_t hi, int) {
-            for (size_t blk = lo; blk < hi; ++blk) {
-                size_t k = blk * 2 * m;
-                for (size_t j = 0; j < m; ++j) {
-                    Fr t = a[k + j + m] * tw[j];
-                    a[k + j + m] = a[k + j] - t;
-                    a[k + j] = a[k + j] + t;
-                }
+        parallel_for(m, [&](size_t lo, size_t hi, int) {
+            uint64_t e = lo;
+            Fr u = w_m.pow(&e, 1);
+            for (size_t j = lo; j < hi; ++j) {
+                tw[j] = u;
+                u = u * w_m;
             }
-        });
+        }, 4096);
+        // parallel over butterflies (n/2 of them) so that late stages with few blocks still spread out
+        parallel_for(n / 2, [&](size_t lo, size_t hi, int) {
+            for (size_t t = lo; t < hi; ++t) {
+                size_t blk = t / m, j = t % m;
+                size_t k = blk * 2 * m;
+                Fr x = a[k + j + m] * tw[j];
+                a[k + j + m] = a[k + j] - x;
+                a[k + j] = a[k + j] + x;
+            }
+        }, 2048);
         m *= 2;
     }
 }
@@ -159,7 +227,7 @@ static void distribute_powers(std::vector<Fr>& a, const Fr& g) {
             a[i] = a[i] * u;
             u = u * g;
         }
-    });
+    }, 2048);
 }
 struct Domain {
     uint32_t logm;
@@ -175,7 +243,7 @@ struct Domain {
         fft(a, omega_inv, logm);
         parallel_for(a.size(), [&](size_t lo, size_t hi, int) {
             for (size_t i = lo; i < hi; ++i) a[i] = a[i] * minv;
-        });
+        }, 2048);
     }
     void coset_fft(std::vector<Fr>& a) const {
         distribute_powers(a, Fr::from_u64(7));
@@ -203,55 +271,84 @@ static void quotient_h(std::vector<Fr>& a, std::vector<Fr>& b, std::vector<Fr>& 
     Fr zi = d.z_on_coset_inv();
     parallel_for(a.size(), [&](size_t lo, size_t hi, int) {
         for (size_t i = lo; i < hi; ++i) a[i] = (a[i] * b[i] - c[i]) * zi;
-    });
+    }, 2048);
     d.icoset_fft(a);
     a.pop_back();  // truncate to m-1
 }
 
 // ---- multiexp (bellperson multiexp.rs CPU path restated) ----------------------------------------
 // bases[i] pairs with scalars[i] (canonical 4x64 LE limbs).  Result independent of all choices.
+// One multiexp split into per-window tasks so that several multiexps can share the worker pool, as
+// bellperson runs its eight multiexp calls concurrently on the rayon pool.
+struct WindowTask {
+    std::function<void()> run;
+};
+template <class F>
+struct MultiexpJob {
+    const Affine<F>* bases;
+    const uint64_t (*scalars)[4];
+    size_t n;
+    uint32_t c = 0, nwin = 0;
+    std::vector<Jac<F>> wsum;
+    MultiexpJob(const Affine<F>* b, const uint64_t (*s)[4], size_t n_) : bases(b), scalars(s), n(n_) {
+        if (n == 0) return;
+        c = n < 32 ? 3 : (uint32_t)std::ceil(std::log((double)n));
+        nwin = (255 + c - 1) / c;
+        wsum.assign(nwin, Jac<F>::infinity());
+    }
+    void window(uint32_t w) {
+        uint32_t skip = w * c;
+        std::vector<Jac<F>> buckets((size_t(1) << c) - 1, Jac<F>::infinity());
+        Jac<F> acc = Jac<F>::infinity();
+        for (size_t i = 0; i < n; ++i) {
+            const uint64_t* e = scalars[i];
+            if ((e[0] | e[1] | e[2] | e[3]) == 0) continue;
+            if (e[0] == 1 && (e[1] | e[2] | e[3]) == 0) {
+                if (w == 0) acc = acc.add_affine(bases[i]);
+                continue;
+            }
+            uint32_t limb = skip / 64, off = skip % 64;
+            uint64_t d = e[limb] >> off;
+            if (off + c > 64 && limb + 1 < 4) d |= e[limb + 1] << (64 - off);
+            d &= (1ull << c) - 1;
+            if (d) buckets[d - 1] = buckets[d - 1].add_affine(bases[i]);
+        }
+        Jac<F> run = Jac<F>::infinity();
+        for (size_t k = buckets.size(); k-- > 0;) {
+            run = run.add(buckets[k]);
+            acc = acc.add(run);
+        }
+        wsum[w] = acc;
+    }
+    void tasks(std::vector<WindowTask>& out) {
+        for (uint32_t w = 0; w < nwin; ++w) out.push_back({[this, w] { window(w); }});
+    }
+    Jac<F> finish() const {
+        Jac<F> total = Jac<F>::infinity();
+        for (uint32_t w = nwin; w-- > 0;) {
+            for (uint32_t k = 0; k < c; ++k) total = total.dbl();
+            total = total.add(wsum[w]);
+        }
+        return total;
+    }
+};
+static void run_tasks(std::vector<WindowTask>& tasks) {
+    std::atomic<size_t> next(0);
+    parallel_for((size_t)nthreads(), [&](size_t, size_t, int) {
+        for (;;) {
+            size_t t = next.fetch_add(1);
+            if (t >= tasks.size()) break;
+            tasks[t].run();
+        }
+    });
+}
 template <class F>
 static Jac<F> multiexp(const Affine<F>* bases, const uint64_t (*scalars)[4], size_t n) {
-    if (n == 0) return Jac<F>::infinity();
-    uint32_t c = n < 32 ? 3 : (uint32_t)std::ceil(std::log((double)n));
-    uint32_t nwin = (255 + c - 1) / c;
-    std::vector<Jac<F>> wsum(nwin);
-    std::atomic<uint32_t> next(0);
-    auto worker = [&](size_t, size_t, int) {
-        for (;;) {
-            uint32_t w = next.fetch_add(1);
-            if (w >= nwin) break;
-            uint32_t skip = w * c;
-            std::vector<Jac<F>> buckets((size_t(1) << c) - 1, Jac<F>::infinity());
-            Jac<F> acc = Jac<F>::infinity();
-            for (size_t i = 0; i < n; ++i) {
-                const uint64_t* e = scalars[i];
-                if ((e[0] | e[1] | e[2] | e[3]) == 0) continue;
-                if (e[0] == 1 && (e[1] | e[2] | e[3]) == 0) {
-                    if (w == 0) acc = acc.add_affine(bases[i]);
-                    continue;
-                }
-                uint32_t limb = skip / 64, off = skip % 64;
-                uint64_t d = e[limb] >> off;
-                if (off + c > 64 && limb + 1 < 4) d |= e[limb + 1] << (64 - off);
-                d &= (1ull << c) - 1;
-                if (d) buckets[d - 1] = buckets[d - 1].add_affine(bases[i]);
-            }
-            Jac<F> run = Jac<F>::infinity();
-            for (size_t k = buckets.size(); k-- > 0;) {
-                run = run.add(buckets[k]);
-                acc = acc.add(run);
-            }
-            wsum[w] = acc;
-        }
-    };
-    parallel_for((size_t)nthreads(), worker);
-    Jac<F> total = Jac<F>::infinity();
-    for (uint32_t w = nwin; w-- > 0;) {
-        for (uint32_t k = 0; k < c; ++k) total = total.dbl();
-        total = total.add(wsum[w]);
-    }
-    return total;
+    MultiexpJob<F> job(bases, scalars, n);
+    std::vector<WindowTask> tasks;
+    job.tasks(tasks);
+    run_tasks(tasks);
+    return job.finish();
 }
 
 // ---- QAP evaluation at tau (bellperson generator.rs semantics) --------------------
@@ -604,9 +701,6 @@ static int create_proof(const Params& P, const R1csView& cs, const uint8_t* inpu
     canon(A.aux, eaux);
     canon(A.in, ein);
     typedef const uint64_t(*SP)[4];
-    G1 H = multiexp<Fp>(P.h.data(), (SP)eh.data(), m - 1);
-    G1 L = multiexp<Fp>(P.l.data(), (SP)eaux.data(), cs.n_aux);
-    G1 A_in = multiexp<Fp>(P.a.data(), (SP)ein.data(), cs.n_inputs);
     std::vector<std::array<uint64_t, 4>> ea, eb;
     for (uint32_t j = 0; j < cs.n_aux; ++j)
         if (A.a_aux_density[j]) ea.push_back(eaux[j]);
@@ -614,11 +708,25 @@ static int create_proof(const Params& P, const R1csView& cs, const uint8_t* inpu
         if (A.b_input_density[i]) eb.push_back(ein[i]);
     for (uint32_t j = 0; j < cs.n_aux; ++j)
         if (A.b_aux_density[j]) eb.push_back(eaux[j]);
-    G1 A_aux = multiexp<Fp>(P.a.data() + cs.n_inputs, (SP)ea.data(), ea.size());
+    MultiexpJob<Fp> jH(P.h.data(), (SP)eh.data(), m - 1), jL(P.l.data(), (SP)eaux.data(), cs.n_aux),
+        jAin(P.a.data(), (SP)ein.data(), cs.n_inputs), jAaux(P.a.data() + cs.n_inputs, (SP)ea.data(), ea.size()),
+        jB1(P.b_g1.data(), (SP)eb.data(), eb.size());
     // bellperson runs B_in and B_aux as two calls; a single call over the concatenation is the same sum
-    G1 B1 = multiexp<Fp>(P.b_g1.data(), (SP)eb.data(), eb.size());
+    MultiexpJob<Fp2> jB2(P.b_g2.data(), (SP)eb.data(), eb.size());
+    // all multiexps share the pool (bellperson: concurrent on rayon).  The G1 and G2 legs are still timed
+    // separately by running them back to back.
+    std::vector<WindowTask> t1, t2;
+    jH.tasks(t1);
+    jL.tasks(t1);
+    jAin.tasks(t1);
+    jAaux.tasks(t1);
+    jB1.tasks(t1);
+    jB2.tasks(t2);
+    run_tasks(t1);
+    G1 H = jH.finish(), L = jL.finish(), A_in = jAin.finish(), A_aux = jAaux.finish(), B1 = jB1.finish();
     double t3 = now_ms();
-    G2 B2 = multiexp<Fp2>(P.b_g2.data(), (SP)eb.data(), eb.size());
+    run_tasks(t2);
+    G2 B2 = jB2.finish();
     double t4 = now_ms();
 
     if (P.delta_g1.inf || P.delta_g2.inf) return -3;  // UnexpectedIdentity
