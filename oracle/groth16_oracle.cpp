@@ -715,17 +715,17 @@ static int create_proof(const Params& P, const R1csView& cs, const uint8_t* inpu
     MultiexpJob<Fp2> jB2(P.b_g2.data(), (SP)eb.data(), eb.size());
     // all multiexps share the pool (bellperson: concurrent on rayon).  The G1 and G2 legs are still timed
     // separately by running them back to back.
-    std::vector<WindowTask> t1, t2;
-    jH.tasks(t1);
-    jL.tasks(t1);
-    jAin.tasks(t1);
-    jAaux.tasks(t1);
-    jB1.tasks(t1);
-    jB2.tasks(t2);
-    run_tasks(t1);
+    std::vector<WindowTask> wt1, wt2;
+    jH.tasks(wt1);
+    jL.tasks(wt1);
+    jAin.tasks(wt1);
+    jAaux.tasks(wt1);
+    jB1.tasks(wt1);
+    jB2.tasks(wt2);
+    run_tasks(wt1);
     G1 H = jH.finish(), L = jL.finish(), A_in = jAin.finish(), A_aux = jAaux.finish(), B1 = jB1.finish();
     double t3 = now_ms();
-    run_tasks(t2);
+    run_tasks(wt2);
     G2 B2 = jB2.finish();
     double t4 = now_ms();
 
