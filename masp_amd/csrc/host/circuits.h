@@ -1,0 +1,446 @@
+// The MASP Spend / Output / Convert circuits and their Jubjub gadgets, statement for statement in the order of
+//   /root/reference/masp_proofs/src/circuit/ecc.rs        (fixed_base_multiplication :27-73, EdwardsPoint :75-476, MontgomeryPoint :478-606)
+//   /root/reference/masp_proofs/src/circuit/pedersen_hash.rs :19-103
+//   /root/reference/masp_proofs/src/circuit/sapling.rs    (expose_value_commitment :71-137, Spend :139-417, Output :419-596)
+//   /root/reference/masp_proofs/src/circuit/convert.rs    :29-128
+//   /root/reference/masp_proofs/src/constants.rs          (window tables :44-94, Montgomery tables :99-173)
+// The allocation / constraint order is the Rust statement order: the structure hashes pinned by the reference's
+// tests (sapling.rs:733,1026, convert.rs:221) are reproduced bit for bit (tests/test_circuits.py).
+#pragma once
+#include "cs.h"
+
+namespace masp_host {
+
+// ------------------------------------------------------------------------------------------- window tables
+typedef std::vector<std::vector<Coord>> FixedGenerator;
+// 3-bit windows [0, 1, ..., 7] * 8^k * G, 84 windows
+inline FixedGenerator generate_circuit_generator(JPoint gen) {
+    FixedGenerator windows;
+    for (int w = 0; w < 84; ++w) {
+        std::vector<Coord> coeffs = {{Fr::zero(), Fr::one()}};
+        JPoint g = gen;
+        for (int k = 0; k < 7; ++k) {
+            JAffine a = g.to_affine();
+            coeffs.push_back({a.u, a.v});
+            g = g.add(gen);
+        }
+        windows.push_back(coeffs);
+        gen = g;  // 8 * gen
+    }
+    return windows;
+}
+inline Coord to_montgomery_coords(const JPoint& p) {
+    JAffine g = p.to_affine();
+    if (g.v == Fr::one()) throw SynthesisError("point at infinity in a Pedersen table");
+    if (g.u.is_zero()) return {Fr::zero(), Fr::zero()};
+    Fr inv1, invx;
+    (Fr::one() - g.v).invert(inv1);
+    g.u.invert(invx);
+    Fr u = (Fr::one() + g.v) * inv1;
+    Fr v = u * invx;
+    return {u, v * montgomery_scale()};
+}
+struct CircuitTables {
+    FixedGenerator proof_generation_key, note_commitment_randomness, nullifier_position, value_commitment_randomness, spending_key;
+    std::vector<std::vector<std::vector<Coord>>> pedersen;  // [segment][window][4]
+};
+inline const CircuitTables& tables() {
+    static CircuitTables t = [] {
+        CircuitTables x;
+        const Generators& g = generators();
+        x.proof_generation_key = generate_circuit_generator(g.proof_generation_key);
+        x.note_commitment_randomness = generate_circuit_generator(g.note_commitment_randomness);
+        x.nullifier_position = generate_circuit_generator(g.nullifier_position);
+        x.value_commitment_randomness = generate_circuit_generator(g.value_commitment_randomness);
+        x.spending_key = generate_circuit_generator(g.spending_key);
+        for (int s = 0; s < 6; ++s) {
+            JPoint gen = g.pedersen[s];
+            std::vector<std::vector<Coord>> windows;
+            for (int w = 0; w < 63; ++w) {
+                std::vector<Coord> coeffs;
+                JPoint p = gen;
+                for (int k = 0; k < 4; ++k) {
+                    coeffs.push_back(to_montgomery_coords(p));
+                    p = p.add(gen);
+                }
+                windows.push_back(coeffs);
+                for (int k = 0; k < 4; ++k) gen = gen.dbl();
+            }
+            x.pedersen.push_back(windows);
+        }
+        return x;
+    }();
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------- Edwards gadget
+struct EdwardsPoint {
+    AllocatedNum u, v;
+
+    static EdwardsPoint interpret(CS& cs, const AllocatedNum& u, const AllocatedNum& v) {
+        AllocatedNum u2 = u.square(cs);
+        AllocatedNum v2 = v.square(cs);
+        AllocatedNum u2v2 = u2.mul(cs, v2);
+        // -u^2 + v^2 = 1 + d u^2 v^2
+        cs.enforce(LC().sub(u2.var).add(v2.var), LC(ONE), LC(ONE).add(u2v2.var, edwards_d()));
+        return {u, v};
+    }
+    static EdwardsPoint witness(CS& cs, const JPoint& p) {
+        JAffine a = cs.has_witness() ? p.to_affine() : JAffine{Fr::zero(), Fr::one()};
+        AllocatedNum u = AllocatedNum::alloc(cs, a.u);
+        AllocatedNum v = AllocatedNum::alloc(cs, a.v);
+        return interpret(cs, u, v);
+    }
+    EdwardsPoint dbl(CS& cs) const {
+        // T = (u + v)^2
+        Fr tv = (u.value + v.value).square();
+        AllocatedNum t = AllocatedNum::alloc(cs, tv);
+        cs.enforce(LC(u.var).add(v.var), LC(u.var).add(v.var), LC(t.var));
+        AllocatedNum a = u.mul(cs, v);
+        // C = d A^2
+        AllocatedNum c = AllocatedNum::alloc(cs, a.value.square() * edwards_d());
+        cs.enforce(LC().add(a.var, edwards_d()), LC(a.var), LC(c.var));
+        // u3 = 2A / (1 + C)
+        Fr inv = Fr::zero();
+        if (cs.has_witness() && !(Fr::one() + c.value).invert(inv)) throw SynthesisError("DivisionByZero");
+        AllocatedNum u3 = AllocatedNum::alloc(cs, a.value.dbl() * inv);
+        cs.enforce(LC(ONE).add(c.var), LC(u3.var), LC(a.var).add(a.var));
+        // v3 = (T - 2A) / (1 - C)
+        if (cs.has_witness() && !(Fr::one() - c.value).invert(inv)) throw SynthesisError("DivisionByZero");
+        AllocatedNum v3 = AllocatedNum::alloc(cs, (t.value - a.value.dbl()) * inv);
+        cs.enforce(LC(ONE).sub(c.var), LC(v3.var), LC(t.var).sub(a.var).sub(a.var));
+        return {u3, v3};
+    }
+    EdwardsPoint add(CS& cs, const EdwardsPoint& o) const {
+        // U = (u1 + v1)(u2 + v2)
+        AllocatedNum uu = AllocatedNum::alloc(cs, (u.value + v.value) * (o.u.value + o.v.value));
+        cs.enforce(LC(u.var).add(v.var), LC(o.u.var).add(o.v.var), LC(uu.var));
+        AllocatedNum a = o.v.mul(cs, u);  // A = v2 u1
+        AllocatedNum b = o.u.mul(cs, v);  // B = u2 v1
+        AllocatedNum c = AllocatedNum::alloc(cs, a.value * b.value * edwards_d());
+        cs.enforce(LC().add(a.var, edwards_d()), LC(b.var), LC(c.var));
+        Fr inv = Fr::zero();
+        if (cs.has_witness() && !(Fr::one() + c.value).invert(inv)) throw SynthesisError("DivisionByZero");
+        AllocatedNum u3 = AllocatedNum::alloc(cs, (a.value + b.value) * inv);
+        cs.enforce(LC(ONE).add(c.var), LC(u3.var), LC(a.var).add(b.var));
+        if (cs.has_witness() && !(Fr::one() - c.value).invert(inv)) throw SynthesisError("DivisionByZero");
+        AllocatedNum v3 = AllocatedNum::alloc(cs, (uu.value - a.value - b.value) * inv);
+        cs.enforce(LC(ONE).sub(c.var), LC(v3.var), LC(uu.var).sub(a.var).sub(b.var));
+        return {u3, v3};
+    }
+    void assert_not_small_order(CS& cs) const {
+        EdwardsPoint t = dbl(cs).dbl(cs).dbl(cs);
+        t.u.assert_nonzero(cs);
+    }
+    void inputize(CS& cs) const {
+        u.inputize(cs);
+        v.inputize(cs);
+    }
+    std::vector<Boolean> repr(CS& cs) const {
+        std::vector<Boolean> ub = u.to_bits_le_strict(cs);
+        std::vector<Boolean> vb = v.to_bits_le_strict(cs);
+        vb.push_back(ub[0]);
+        return vb;
+    }
+    // self if condition else the neutral element (0, 1)
+    EdwardsPoint conditionally_select(CS& cs, const Boolean& cond) const {
+        bool c = cond.value();
+        AllocatedNum up = AllocatedNum::alloc(cs, c ? u.value : Fr::zero());
+        cs.enforce(LC(u.var), cond.lc(Fr::one()), LC(up.var));
+        AllocatedNum vp = AllocatedNum::alloc(cs, c ? v.value : Fr::one());
+        cs.enforce(LC(v.var), cond.lc(Fr::one()), LC(vp.var).sub(cond.not_().lc(Fr::one())));
+        return {up, vp};
+    }
+    EdwardsPoint mul(CS& cs, const std::vector<Boolean>& by) const {
+        EdwardsPoint curbase = *this, result = *this;
+        for (size_t i = 0; i < by.size(); ++i) {
+            if (i > 0) curbase = curbase.dbl(cs);
+            EdwardsPoint thisbase = curbase.conditionally_select(cs, by[i]);
+            result = i == 0 ? thisbase : result.add(cs, thisbase);
+        }
+        return result;
+    }
+};
+
+inline EdwardsPoint fixed_base_multiplication(CS& cs, const FixedGenerator& base, const std::vector<Boolean>& by) {
+    EdwardsPoint result{};
+    size_t nchunks = (by.size() + 2) / 3;
+    for (size_t i = 0; i < nchunks && i < base.size(); ++i) {
+        Boolean chunk[3];
+        for (int k = 0; k < 3; ++k) chunk[k] = 3 * i + k < by.size() ? by[3 * i + k] : Boolean::constant(false);
+        auto uv = lookup3_xy(cs, chunk, base[i]);
+        EdwardsPoint p{uv.first, uv.second};
+        result = i == 0 ? p : result.add(cs, p);
+    }
+    return result;
+}
+
+// ------------------------------------------------------------------------------------------- Montgomery gadget
+struct MontgomeryPoint {
+    Num x, y;
+
+    EdwardsPoint into_edwards(CS& cs) const {
+        // u = scale * x / y
+        Fr inv = Fr::zero();
+        if (cs.has_witness() && !y.value.invert(inv)) throw SynthesisError("DivisionByZero");
+        AllocatedNum u = AllocatedNum::alloc(cs, x.value * montgomery_scale() * inv);
+        cs.enforce(y.lc(Fr::one()), LC(u.var), x.lc(montgomery_scale()));
+        // v = (x - 1) / (x + 1)
+        if (cs.has_witness() && !(x.value + Fr::one()).invert(inv)) throw SynthesisError("DivisionByZero");
+        AllocatedNum v = AllocatedNum::alloc(cs, (x.value - Fr::one()) * inv);
+        cs.enforce(x.lc(Fr::one()).add(ONE), LC(v.var), x.lc(Fr::one()).sub(ONE));
+        return {u, v};
+    }
+    // affine addition, undefined for equal x
+    MontgomeryPoint add(CS& cs, const MontgomeryPoint& o) const {
+        Fr inv = Fr::zero();
+        if (cs.has_witness() && !(o.x.value - x.value).invert(inv)) throw SynthesisError("DivisionByZero");
+        AllocatedNum lambda = AllocatedNum::alloc(cs, (o.y.value - y.value) * inv);
+        cs.enforce(o.x.lc(Fr::one()).sub(x.lc(Fr::one())), LC(lambda.var), o.y.lc(Fr::one()).sub(y.lc(Fr::one())));
+        // x'' = lambda^2 - A - x - x'
+        AllocatedNum xp = AllocatedNum::alloc(cs, lambda.value.square() - montgomery_a() - x.value - o.x.value);
+        cs.enforce(LC(lambda.var), LC(lambda.var), LC().add(ONE, montgomery_a()).add(x.lc(Fr::one())).add(o.x.lc(Fr::one())).add(xp.var));
+        // y'' = -(y + lambda (x'' - x))
+        AllocatedNum yp = AllocatedNum::alloc(cs, ((xp.value - x.value) * lambda.value + y.value).neg());
+        cs.enforce(x.lc(Fr::one()).sub(xp.var), LC(lambda.var), LC(yp.var).add(y.lc(Fr::one())));
+        return {Num::from(xp), Num::from(yp)};
+    }
+};
+
+inline EdwardsPoint pedersen_hash_gadget(CS& cs, const Personalization& pers, const std::vector<Boolean>& msg) {
+    std::vector<Boolean> bits;
+    for (bool b : pers.bits()) bits.push_back(Boolean::constant(b));
+    bits.insert(bits.end(), msg.begin(), msg.end());
+    const auto& gens = tables().pedersen;
+    bool have_result = false;
+    EdwardsPoint edwards_result{};
+    size_t pos = 0, seg = 0;
+    while (pos < bits.size()) {
+        bool have_seg = false;
+        MontgomeryPoint seg_result{};
+        const auto& windows = gens.at(seg);
+        for (size_t w = 0; w < windows.size() && pos < bits.size(); ++w) {
+            Boolean chunk[3];
+            chunk[0] = bits[pos++];
+            chunk[1] = pos < bits.size() ? bits[pos++] : Boolean::constant(false);
+            chunk[2] = pos < bits.size() ? bits[pos++] : Boolean::constant(false);
+            auto xy = lookup3_xy_with_conditional_negation(cs, chunk, windows[w]);
+            MontgomeryPoint tmp{xy.first, xy.second};
+            if (!have_seg) {
+                seg_result = tmp;
+                have_seg = true;
+            } else {
+                seg_result = tmp.add(cs, seg_result);
+            }
+        }
+        EdwardsPoint e = seg_result.into_edwards(cs);
+        if (have_result) {
+            edwards_result = e.add(cs, edwards_result);
+        } else {
+            edwards_result = e;
+            have_result = true;
+        }
+        ++seg;
+    }
+    return edwards_result;
+}
+
+// ------------------------------------------------------------------------------------------- witnesses
+struct ValueCommitmentW {
+    JPoint asset_generator;  // cofactor not cleared
+    uint64_t value;
+    uint8_t randomness[32];  // jubjub::Fr, little-endian canonical
+};
+struct MerklePathW {
+    std::vector<std::pair<Fr, bool>> auth_path;  // (sibling, current node is the right child), leaf level first
+};
+struct SpendW {
+    ValueCommitmentW vc;
+    JPoint ak;
+    uint8_t nsk[32];
+    JPoint g_d, pk_d;
+    uint8_t rcm[32];
+    uint8_t ar[32];
+    MerklePathW path;
+    Fr anchor;
+};
+struct OutputW {
+    ValueCommitmentW vc;
+    uint8_t asset_identifier[32];
+    JPoint g_d, pk_d;
+    uint8_t rcm[32];
+    uint8_t esk[32];
+};
+struct ConvertW {
+    ValueCommitmentW vc;
+    MerklePathW path;
+    Fr anchor;
+};
+
+// circuit/sapling.rs:71-137
+inline void expose_value_commitment(CS& cs, const ValueCommitmentW& vc, std::vector<Boolean>& asset_generator_bits,
+                                    std::vector<Boolean>& value_bits) {
+    EdwardsPoint asset_generator = EdwardsPoint::witness(cs, vc.asset_generator);
+    asset_generator_bits = asset_generator.repr(cs);
+    asset_generator = asset_generator.dbl(cs);
+    asset_generator = asset_generator.dbl(cs);
+    asset_generator = asset_generator.dbl(cs);
+    asset_generator.u.assert_nonzero(cs);
+    value_bits = u64_into_boolean_vec_le(cs, vc.value);
+    EdwardsPoint value = asset_generator.mul(cs, value_bits);
+    std::vector<Boolean> rcv = bits_into_boolean_vec_le(cs, vc.randomness, 252);
+    EdwardsPoint rcvp = fixed_base_multiplication(cs, tables().value_commitment_randomness, rcv);
+    EdwardsPoint cv = value.add(cs, rcvp);
+    cv.inputize(cs);
+}
+
+static const int TREE_DEPTH = 32;
+
+// shared by Spend and Convert: ascend the Merkle path from `cur`
+inline AllocatedNum merkle_ascend(CS& cs, AllocatedNum cur, const MerklePathW& path, std::vector<Boolean>* position_bits) {
+    for (int i = 0; i < TREE_DEPTH; ++i) {
+        bool right = cs.has_witness() ? path.auth_path.at(i).second : false;
+        Fr sibling = cs.has_witness() ? path.auth_path.at(i).first : Fr::zero();
+        Boolean cur_is_right = Boolean::from(AllocatedBit::alloc(cs, right));
+        if (position_bits) position_bits->push_back(cur_is_right);
+        AllocatedNum path_element = AllocatedNum::alloc(cs, sibling);
+        auto lr = AllocatedNum::conditionally_reverse(cs, cur, path_element, cur_is_right);
+        std::vector<Boolean> preimage = lr.first.to_bits_le(cs);
+        std::vector<Boolean> rb = lr.second.to_bits_le(cs);
+        preimage.insert(preimage.end(), rb.begin(), rb.end());
+        cur = pedersen_hash_gadget(cs, {false, (unsigned)i}, preimage).u;
+    }
+    return cur;
+}
+inline void conditional_anchor(CS& cs, const AllocatedNum& cur, const Num& value_num, const Fr& anchor) {
+    AllocatedNum rt = AllocatedNum::alloc(cs, anchor);
+    // (cur - rt) * value = 0
+    cs.enforce(LC(cur.var).sub(rt.var), value_num.lc(Fr::one()), LC());
+    rt.inputize(cs);
+}
+
+// circuit/sapling.rs:139-417
+inline void synthesize_spend(CS& cs, const SpendW& w) {
+    EdwardsPoint ak = EdwardsPoint::witness(cs, w.ak);
+    ak.assert_not_small_order(cs);
+    {
+        std::vector<Boolean> ar = bits_into_boolean_vec_le(cs, w.ar, 252);
+        EdwardsPoint arp = fixed_base_multiplication(cs, tables().spending_key, ar);
+        EdwardsPoint rk = ak.add(cs, arp);
+        rk.inputize(cs);
+    }
+    EdwardsPoint nk;
+    {
+        std::vector<Boolean> nsk = bits_into_boolean_vec_le(cs, w.nsk, 252);
+        nk = fixed_base_multiplication(cs, tables().proof_generation_key, nsk);
+    }
+    std::vector<Boolean> ivk_preimage = ak.repr(cs);
+    std::vector<Boolean> nf_preimage;
+    {
+        std::vector<Boolean> repr_nk = nk.repr(cs);
+        ivk_preimage.insert(ivk_preimage.end(), repr_nk.begin(), repr_nk.end());
+        nf_preimage = repr_nk;
+    }
+    std::vector<Boolean> ivk = blake2s_gadget(cs, ivk_preimage, "MASP_ivk");
+    ivk.resize(251);  // jubjub::Fr::CAPACITY
+    EdwardsPoint g_d = EdwardsPoint::witness(cs, w.g_d);
+    g_d.assert_not_small_order(cs);
+    EdwardsPoint pk_d = g_d.mul(cs, ivk);
+    std::vector<Boolean> note_contents;
+    Num value_num = Num::zero();
+    {
+        std::vector<Boolean> asset_generator_bits, value_bits;
+        expose_value_commitment(cs, w.vc, asset_generator_bits, value_bits);
+        Fr coeff = Fr::one();
+        for (auto& bit : value_bits) {
+            value_num = value_num.add_bool_with_coeff(bit, coeff);
+            coeff = coeff.dbl();
+        }
+        note_contents.insert(note_contents.end(), asset_generator_bits.begin(), asset_generator_bits.end());
+        note_contents.insert(note_contents.end(), value_bits.begin(), value_bits.end());
+    }
+    {
+        std::vector<Boolean> r = g_d.repr(cs);
+        note_contents.insert(note_contents.end(), r.begin(), r.end());
+        r = pk_d.repr(cs);
+        note_contents.insert(note_contents.end(), r.begin(), r.end());
+    }
+    EdwardsPoint cm = pedersen_hash_gadget(cs, {true, 0}, note_contents);
+    {
+        std::vector<Boolean> rcm = bits_into_boolean_vec_le(cs, w.rcm, 252);
+        EdwardsPoint rcmp = fixed_base_multiplication(cs, tables().note_commitment_randomness, rcm);
+        cm = cm.add(cs, rcmp);
+    }
+    std::vector<Boolean> position_bits;
+    AllocatedNum cur = merkle_ascend(cs, cm.u, w.path, &position_bits);
+    conditional_anchor(cs, cur, value_num, w.anchor);
+    EdwardsPoint rho = cm;
+    {
+        EdwardsPoint position = fixed_base_multiplication(cs, tables().nullifier_position, position_bits);
+        rho = rho.add(cs, position);
+    }
+    {
+        std::vector<Boolean> r = rho.repr(cs);
+        nf_preimage.insert(nf_preimage.end(), r.begin(), r.end());
+    }
+    std::vector<Boolean> nf = blake2s_gadget(cs, nf_preimage, "MASP__nf");
+    pack_into_inputs(cs, nf);
+}
+
+// circuit/sapling.rs:419-596
+inline void synthesize_output(CS& cs, const OutputW& w) {
+    std::vector<Boolean> note_contents;
+    std::vector<Boolean> asset_generator_preimage;
+    for (int i = 0; i < 256; ++i)
+        asset_generator_preimage.push_back(Boolean::from(AllocatedBit::alloc(cs, (w.asset_identifier[i / 8] >> (i % 8)) & 1)));
+    std::vector<Boolean> asset_generator_image = blake2s_gadget(cs, asset_generator_preimage, "MASP__v_");
+    std::vector<Boolean> asset_generator_bits, value_bits;
+    expose_value_commitment(cs, w.vc, asset_generator_bits, value_bits);
+    for (int i = 0; i < 256; ++i) Boolean::enforce_equal(cs, asset_generator_bits[i], asset_generator_image[i]);
+    note_contents.insert(note_contents.end(), asset_generator_bits.begin(), asset_generator_bits.end());
+    note_contents.insert(note_contents.end(), value_bits.begin(), value_bits.end());
+    {
+        EdwardsPoint g_d = EdwardsPoint::witness(cs, w.g_d);
+        g_d.assert_not_small_order(cs);
+        std::vector<Boolean> r = g_d.repr(cs);
+        note_contents.insert(note_contents.end(), r.begin(), r.end());
+        std::vector<Boolean> esk = bits_into_boolean_vec_le(cs, w.esk, 252);
+        EdwardsPoint epk = g_d.mul(cs, esk);
+        epk.inputize(cs);
+    }
+    {
+        JAffine pk = cs.has_witness() ? w.pk_d.to_affine() : JAffine{Fr::zero(), Fr::one()};
+        uint8_t vle[32];
+        pk.v.to_bytes(vle);
+        std::vector<Boolean> v_contents = bits_into_boolean_vec_le(cs, vle, 255);
+        Boolean sign_bit = Boolean::from(AllocatedBit::alloc(cs, pk.u.is_odd()));
+        note_contents.insert(note_contents.end(), v_contents.begin(), v_contents.end());
+        note_contents.push_back(sign_bit);
+    }
+    EdwardsPoint cm = pedersen_hash_gadget(cs, {true, 0}, note_contents);
+    {
+        std::vector<Boolean> rcm = bits_into_boolean_vec_le(cs, w.rcm, 252);
+        EdwardsPoint rcmp = fixed_base_multiplication(cs, tables().note_commitment_randomness, rcm);
+        cm = cm.add(cs, rcmp);
+    }
+    cm.u.inputize(cs);
+}
+
+// circuit/convert.rs:29-128
+inline void synthesize_convert(CS& cs, const ConvertW& w) {
+    Num value_num = Num::zero();
+    std::vector<Boolean> asset_generator_bits, value_bits;
+    expose_value_commitment(cs, w.vc, asset_generator_bits, value_bits);
+    {
+        Fr coeff = Fr::one();
+        for (auto& bit : value_bits) {
+            value_num = value_num.add_bool_with_coeff(bit, coeff);
+            coeff = coeff.dbl();
+        }
+    }
+    EdwardsPoint cm = pedersen_hash_gadget(cs, {true, 0}, asset_generator_bits);
+    AllocatedNum cur = merkle_ascend(cs, cm.u, w.path, nullptr);
+    conditional_anchor(cs, cur, value_num, w.anchor);
+}
+
+}  // namespace masp_host

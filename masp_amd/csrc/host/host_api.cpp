@@ -1,0 +1,241 @@
+// libmasp_host: C ABI over the host-side witness generator (circuits.h).  This is the part of
+// `SaplingProvingContext::{spend_proof, output_proof, convert_proof}` that precedes `create_random_proof`
+// (/root/reference/masp_proofs/src/sapling/prover.rs:51-113, :163-198, :214-248): native key / commitment /
+// nullifier derivation, then synthesis of the circuit into (input_assignment, aux_assignment).
+// It also exports the static R1CS of each circuit (what bellperson's KeypairAssembly collects) and the
+// native primitives, so that tests can pin them against the reference's vectors.
+#include <memory>
+
+#include "circuits.h"
+
+using namespace masp_host;
+
+namespace {
+struct CircuitHandle {
+    std::unique_ptr<CS> cs;
+};
+Var remap(Var v, uint32_t n_inputs) { return (v & AUX) ? n_inputs + (v & ~AUX) : v; }
+
+void write_assignment(const CS& cs, uint8_t* inputs, uint8_t* aux) {
+    for (size_t i = 0; i < cs.num_inputs(); ++i) cs.inputs()[i].to_bytes(inputs + 32 * i);
+    for (size_t j = 0; j < cs.num_aux(); ++j) cs.aux()[j].to_bytes(aux + 32 * j);
+}
+bool load_path(MerklePathW& p, const uint8_t* siblings, uint64_t position) {
+    for (int i = 0; i < TREE_DEPTH; ++i) {
+        Fr s;
+        if (!Fr::from_bytes(s, siblings + 32 * i)) return false;
+        p.auth_path.push_back({s, (bool)((position >> i) & 1)});
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" {
+
+enum { MASP_HOST_OK = 0, MASP_HOST_E_INVALID = 1, MASP_HOST_E_DIVERSIFIER = 2, MASP_HOST_E_SYNTHESIS = 3, MASP_HOST_E_UNSATISFIED = 4 };
+
+// ---- static circuits: kind 0 spend, 1 output, 2 convert --------------------------------------------
+void* masp_host_circuit_setup(int kind) {
+    try {
+        std::unique_ptr<CircuitHandle> h(new CircuitHandle);
+        h->cs.reset(new CS(true, false));
+        if (kind == 0) {
+            SpendW w{};
+            w.vc.asset_generator = JPoint::identity();
+            w.ak = w.g_d = w.pk_d = JPoint::identity();
+            synthesize_spend(*h->cs, w);
+        } else if (kind == 1) {
+            OutputW w{};
+            w.vc.asset_generator = JPoint::identity();
+            w.g_d = w.pk_d = JPoint::identity();
+            synthesize_output(*h->cs, w);
+        } else if (kind == 2) {
+            ConvertW w{};
+            w.vc.asset_generator = JPoint::identity();
+            synthesize_convert(*h->cs, w);
+        } else {
+            return nullptr;
+        }
+        return h.release();
+    } catch (...) {
+        return nullptr;
+    }
+}
+void masp_host_circuit_free(void* h) { delete (CircuitHandle*)h; }
+// out: n_inputs, n_aux, n_constraints, nnz(A), nnz(B), nnz(C)
+void masp_host_circuit_counts(void* hh, uint32_t* out) {
+    CS& cs = *((CircuitHandle*)hh)->cs;
+    out[0] = cs.num_inputs();
+    out[1] = cs.num_aux();
+    out[2] = cs.num_constraints();
+    for (int i = 0; i < 3; ++i) out[3 + i] = cs.matrix(i).col.size();
+}
+// columns: input i -> i, aux j -> n_inputs + j (the masp_hip_r1cs convention); coef 32 B LE canonical
+void masp_host_circuit_matrix(void* hh, int mi, uint32_t* rowptr, uint32_t* col, uint8_t* coef) {
+    CS& cs = *((CircuitHandle*)hh)->cs;
+    const CS::Matrix& M = cs.matrix(mi);
+    memcpy(rowptr, M.rowptr.data(), 4 * M.rowptr.size());
+    for (size_t t = 0; t < M.col.size(); ++t) {
+        col[t] = remap(M.col[t], (uint32_t)cs.num_inputs());
+        M.coef[t].to_bytes(coef + 32 * t);
+    }
+}
+void masp_host_circuit_hash(void* hh, char* out65) {
+    std::string s = ((CircuitHandle*)hh)->cs->hash();
+    memcpy(out65, s.c_str(), 65);
+}
+
+// ---- witness generation -----------------------------------------------------------------------------
+// check != 0: additionally record the constraints and fail with MASP_HOST_E_UNSATISFIED if any is violated.
+// rcm is the note commitment randomness `note.rcm()` (sapling.rs:856-863) as 32 bytes LE.
+int masp_host_spend_assignment(const uint8_t ak[32], const uint8_t nsk[32], const uint8_t diversifier[11], const uint8_t rcm[32],
+                               const uint8_t ar[32], const uint8_t asset_identifier[32], uint64_t value, const uint8_t anchor[32],
+                               const uint8_t* path_siblings /*32 x 32*/, uint64_t position, const uint8_t rcv[32], int check,
+                               uint8_t* inputs /*8 x 32*/, uint8_t* aux /*100497 x 32*/, uint8_t cv_out[32], uint8_t rk_out[32],
+                               uint8_t nf_out[32]) {
+    try {
+        SpendW w;
+        if (!asset_generator(w.vc.asset_generator, asset_identifier)) return MASP_HOST_E_INVALID;
+        w.vc.value = value;
+        memcpy(w.vc.randomness, rcv, 32);
+        if (!JPoint::from_bytes(w.ak, ak)) return MASP_HOST_E_INVALID;
+        memcpy(w.nsk, nsk, 32);
+        memcpy(w.rcm, rcm, 32);
+        memcpy(w.ar, ar, 32);
+        if (!Fr::from_bytes(w.anchor, anchor) || !load_path(w.path, path_siblings, position)) return MASP_HOST_E_INVALID;
+        // viewing key, payment address (prover.rs:78-84)
+        JPoint nk = generators().proof_generation_key.mul(nsk);
+        uint8_t ivk[32];
+        crh_ivk(ivk, w.ak, nk);
+        if (!group_hash(w.g_d, diversifier, 11, "MASP__gd")) return MASP_HOST_E_DIVERSIFIER;
+        w.pk_d = w.g_d.mul(ivk);
+        // outputs the caller needs next to the proof (prover.rs:87-98,151-156)
+        JPoint cv = value_commitment(w.vc.asset_generator, value, rcv);
+        JPoint rk = w.ak.add(generators().spending_key.mul(ar));
+        JPoint cm = note_commitment(w.vc.asset_generator, value, w.g_d, w.pk_d, rcm);
+        cv.to_bytes(cv_out);
+        rk.to_bytes(rk_out);
+        nullifier(nf_out, cm, position, nk);
+        CS cs(check != 0, true);
+        synthesize_spend(cs, w);
+        if (check && cs.first_unsatisfied() >= 0) return MASP_HOST_E_UNSATISFIED;
+        write_assignment(cs, inputs, aux);
+        return MASP_HOST_OK;
+    } catch (const SynthesisError&) {
+        return MASP_HOST_E_SYNTHESIS;
+    }
+}
+int masp_host_output_assignment(const uint8_t esk[32], const uint8_t diversifier[11], const uint8_t pk_d[32], const uint8_t rcm[32],
+                                const uint8_t asset_identifier[32], uint64_t value, const uint8_t rcv[32], int check,
+                                uint8_t* inputs /*6 x 32*/, uint8_t* aux /*30896 x 32*/, uint8_t cv_out[32]) {
+    try {
+        OutputW w;
+        if (!asset_generator(w.vc.asset_generator, asset_identifier)) return MASP_HOST_E_INVALID;
+        w.vc.value = value;
+        memcpy(w.vc.randomness, rcv, 32);
+        memcpy(w.asset_identifier, asset_identifier, 32);
+        if (!group_hash(w.g_d, diversifier, 11, "MASP__gd")) return MASP_HOST_E_DIVERSIFIER;
+        if (!JPoint::from_bytes(w.pk_d, pk_d)) return MASP_HOST_E_INVALID;
+        memcpy(w.rcm, rcm, 32);
+        memcpy(w.esk, esk, 32);
+        value_commitment(w.vc.asset_generator, value, rcv).to_bytes(cv_out);
+        CS cs(check != 0, true);
+        synthesize_output(cs, w);
+        if (check && cs.first_unsatisfied() >= 0) return MASP_HOST_E_UNSATISFIED;
+        write_assignment(cs, inputs, aux);
+        return MASP_HOST_OK;
+    } catch (const SynthesisError&) {
+        return MASP_HOST_E_SYNTHESIS;
+    }
+}
+// generator: the AllowedConversion's asset generator point (masp_primitives/src/convert.rs:23-29), 32 bytes
+int masp_host_convert_assignment(const uint8_t generator[32], uint64_t value, const uint8_t anchor[32], const uint8_t* path_siblings,
+                                 uint64_t position, const uint8_t rcv[32], int check, uint8_t* inputs /*4 x 32*/,
+                                 uint8_t* aux /*47322 x 32*/, uint8_t cv_out[32]) {
+    try {
+        ConvertW w;
+        if (!JPoint::from_bytes(w.vc.asset_generator, generator)) return MASP_HOST_E_INVALID;
+        w.vc.value = value;
+        memcpy(w.vc.randomness, rcv, 32);
+        if (!Fr::from_bytes(w.anchor, anchor) || !load_path(w.path, path_siblings, position)) return MASP_HOST_E_INVALID;
+        value_commitment(w.vc.asset_generator, value, rcv).to_bytes(cv_out);
+        CS cs(check != 0, true);
+        synthesize_convert(cs, w);
+        if (check && cs.first_unsatisfied() >= 0) return MASP_HOST_E_UNSATISFIED;
+        write_assignment(cs, inputs, aux);
+        return MASP_HOST_OK;
+    } catch (const SynthesisError&) {
+        return MASP_HOST_E_SYNTHESIS;
+    }
+}
+
+// ---- native primitives (pinned by the reference's vectors in tests/) ---------------------------------
+// which: 0 proof_generation_key 1 note_commitment_randomness 2 nullifier_position 3 value_commitment_randomness
+//        4 spending_key 5..10 pedersen[0..5]; out: u | v as 2 x 32 B LE
+void masp_host_generator(int which, uint8_t out64[64]) {
+    const Generators& g = generators();
+    const JPoint* p[11] = {&g.proof_generation_key, &g.note_commitment_randomness, &g.nullifier_position, &g.value_commitment_randomness,
+                           &g.spending_key, &g.pedersen[0], &g.pedersen[1], &g.pedersen[2], &g.pedersen[3], &g.pedersen[4], &g.pedersen[5]};
+    JAffine a = p[which]->to_affine();
+    a.u.to_bytes(out64);
+    a.v.to_bytes(out64 + 32);
+}
+// personalization: -1 NoteCommitment, otherwise MerkleTree(depth); bits: one byte per bit; out: u | v
+void masp_host_pedersen_hash(int personalization, const uint8_t* bits, size_t nbits, uint8_t out64[64]) {
+    std::vector<bool> b(nbits);
+    for (size_t i = 0; i < nbits; ++i) b[i] = bits[i] != 0;
+    Personalization p{personalization < 0, personalization < 0 ? 0u : (unsigned)personalization};
+    JAffine a = pedersen_hash(p, b).to_affine();
+    a.u.to_bytes(out64);
+    a.v.to_bytes(out64 + 32);
+}
+int masp_host_asset_identifier(const uint8_t* name, size_t len, uint8_t out32[32]) { return asset_identifier(out32, name, len) ? 0 : 1; }
+int masp_host_asset_generator(const uint8_t id[32], uint8_t out32[32]) {
+    JPoint p;
+    if (!asset_generator(p, id)) return 1;
+    p.to_bytes(out32);
+    return 0;
+}
+int masp_host_value_commitment(const uint8_t id[32], uint64_t value, const uint8_t rcv[32], uint8_t out32[32], uint8_t uv64[64]) {
+    JPoint g;
+    if (!asset_generator(g, id)) return 1;
+    JPoint cv = value_commitment(g, value, rcv);
+    cv.to_bytes(out32);
+    if (uv64) {
+        JAffine a = cv.to_affine();
+        a.u.to_bytes(uv64);
+        a.v.to_bytes(uv64 + 32);
+    }
+    return 0;
+}
+// note commitment u-coordinate (cmu) from (asset id, value, diversifier, pk_d, rcm)
+int masp_host_note_cmu(const uint8_t id[32], uint64_t value, const uint8_t diversifier[11], const uint8_t pk_d[32], const uint8_t rcm[32],
+                       uint8_t cmu32[32]) {
+    JPoint g, gd, pk;
+    if (!asset_generator(g, id) || !group_hash(gd, diversifier, 11, "MASP__gd") || !JPoint::from_bytes(pk, pk_d)) return 1;
+    note_commitment(g, value, gd, pk, rcm).to_affine().u.to_bytes(cmu32);
+    return 0;
+}
+int masp_host_merkle_hash(unsigned depth, const uint8_t lhs[32], const uint8_t rhs[32], uint8_t out32[32]) {
+    Fr l, r;
+    if (!Fr::from_bytes(l, lhs) || !Fr::from_bytes(r, rhs)) return 1;
+    merkle_hash(depth, l, r).to_bytes(out32);
+    return 0;
+}
+// [k]P for P given as 32 bytes; (point decode / scalar multiplication / encode round trip)
+int masp_host_jubjub_mul(const uint8_t p32[32], const uint8_t k32[32], uint8_t out32[32]) {
+    JPoint p;
+    if (!JPoint::from_bytes(p, p32)) return 1;
+    p.mul(k32).to_bytes(out32);
+    return 0;
+}
+// leaf of the convert tree: u of PedersenHash(NoteCommitment, repr(generator))  (convert.rs:39-64)
+int masp_host_convert_cmu(const uint8_t generator[32], uint8_t out32[32]) {
+    JPoint g;
+    if (!JPoint::from_bytes(g, generator)) return 1;
+    uint8_t b[32];
+    g.to_bytes(b);
+    pedersen_hash({true, 0}, bytes_to_bits_le(b, 32)).to_affine().u.to_bytes(out32);
+    return 0;
+}
+}  // extern "C"
