@@ -229,6 +229,28 @@ int masp_host_jubjub_mul(const uint8_t p32[32], const uint8_t k32[32], uint8_t o
     p.mul(k32).to_bytes(out32);
     return 0;
 }
+// p + q, or p - q when subtract != 0 (value-commitment bookkeeping of the proving context)
+int masp_host_jubjub_add(const uint8_t p32[32], const uint8_t q32[32], int subtract, uint8_t out32[32]) {
+    JPoint p, q;
+    if (!JPoint::from_bytes(p, p32) || !JPoint::from_bytes(q, q32)) return 1;
+    p.add(subtract ? q.neg() : q).to_bytes(out32);
+    return 0;
+}
+// leaf of the commitment tree for a spendable note: derives nk, ivk, g_d, pk_d exactly as spend_proof does and
+// returns cmu (what the wallet already knows as the note commitment); also pk_d for callers that want the address
+int masp_host_spend_leaf(const uint8_t ak[32], const uint8_t nsk[32], const uint8_t diversifier[11], const uint8_t rcm[32],
+                         const uint8_t id[32], uint64_t value, uint8_t cmu32[32], uint8_t pk_d32[32]) {
+    JPoint akp, g, gd;
+    if (!JPoint::from_bytes(akp, ak) || !asset_generator(g, id)) return MASP_HOST_E_INVALID;
+    if (!group_hash(gd, diversifier, 11, "MASP__gd")) return MASP_HOST_E_DIVERSIFIER;
+    JPoint nk = generators().proof_generation_key.mul(nsk);
+    uint8_t ivk[32];
+    crh_ivk(ivk, akp, nk);
+    JPoint pk = gd.mul(ivk);
+    note_commitment(g, value, gd, pk, rcm).to_affine().u.to_bytes(cmu32);
+    if (pk_d32) pk.to_bytes(pk_d32);
+    return MASP_HOST_OK;
+}
 // leaf of the convert tree: u of PedersenHash(NoteCommitment, repr(generator))  (convert.rs:39-64)
 int masp_host_convert_cmu(const uint8_t generator[32], uint8_t out32[32]) {
     JPoint g;

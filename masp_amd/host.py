@@ -1,0 +1,235 @@
+"""ctypes binding of libmasp_host.so: the host-side witness generator and native primitives
+(masp_amd/csrc/host).  CPU-only code; the Groth16 hot path itself lives in libmasp_hip.so."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .r1cs import R1cs
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+SPEND, OUTPUT, CONVERT = 0, 1, 2
+KINDS = {"spend": SPEND, "output": OUTPUT, "convert": CONVERT}
+JUBJUB_ORDER = 6554484396890773809930967563523245729705921265872317281365359162392183254199
+FR_MODULUS = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+TREE_DEPTH = 32
+ERRORS = {1: "invalid encoding", 2: "invalid diversifier", 3: "synthesis error", 4: "assignment does not satisfy the circuit"}
+
+
+class HostError(RuntimeError):
+    def __init__(self, code):
+        self.code = code
+        super().__init__("masp_host error %d: %s" % (code, ERRORS.get(code, "?")))
+
+
+def load_library():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "libmasp_host.so")
+        if not os.path.exists(path):
+            raise ImportError("libmasp_host.so is not built: run `make -C masp_amd/csrc`")
+        L = C.CDLL(path)
+        L.masp_host_circuit_setup.restype = C.c_void_p
+        L.masp_host_circuit_setup.argtypes = [C.c_int]
+        L.masp_host_circuit_free.argtypes = [C.c_void_p]
+        L.masp_host_circuit_counts.argtypes = [C.c_void_p, C.c_void_p]
+        L.masp_host_circuit_matrix.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.masp_host_circuit_hash.argtypes = [C.c_void_p, C.c_char_p]
+        cp, vp, u64 = C.c_char_p, C.c_void_p, C.c_uint64
+        L.masp_host_spend_assignment.argtypes = [cp, cp, cp, cp, cp, cp, u64, cp, vp, u64, cp, C.c_int, vp, vp, cp, cp, cp]
+        L.masp_host_output_assignment.argtypes = [cp, cp, cp, cp, cp, u64, cp, C.c_int, vp, vp, cp]
+        L.masp_host_convert_assignment.argtypes = [cp, u64, cp, vp, u64, cp, C.c_int, vp, vp, cp]
+        L.masp_host_generator.argtypes = [C.c_int, cp]
+        L.masp_host_pedersen_hash.argtypes = [C.c_int, vp, C.c_size_t, cp]
+        L.masp_host_asset_identifier.argtypes = [cp, C.c_size_t, cp]
+        L.masp_host_asset_generator.argtypes = [cp, cp]
+        L.masp_host_value_commitment.argtypes = [cp, u64, cp, cp, cp]
+        L.masp_host_note_cmu.argtypes = [cp, u64, cp, cp, cp, cp]
+        L.masp_host_merkle_hash.argtypes = [C.c_uint, cp, cp, cp]
+        L.masp_host_jubjub_mul.argtypes = [cp, cp, cp]
+        L.masp_host_convert_cmu.argtypes = [cp, cp]
+        L.masp_host_jubjub_add.argtypes = [cp, cp, C.c_int, cp]
+        L.masp_host_spend_leaf.argtypes = [cp, cp, cp, cp, cp, u64, cp, cp]
+        _lib = L
+    return _lib
+
+
+_circuits = {}
+
+
+def circuit(kind):
+    """Static R1CS of a MASP circuit ("spend" | "output" | "convert") and its TestConstraintSystem hash."""
+    if kind not in _circuits:
+        L = load_library()
+        h = L.masp_host_circuit_setup(KINDS[kind])
+        if not h:
+            raise RuntimeError("circuit setup failed")
+        cnt = (C.c_uint32 * 6)()
+        L.masp_host_circuit_counts(h, cnt)
+        n_in, n_aux, n_con = cnt[0], cnt[1], cnt[2]
+        mats = []
+        for mi in range(3):
+            nnz = cnt[3 + mi]
+            rp = np.zeros(n_con + 1, np.uint32)
+            col = np.zeros(nnz, np.uint32)
+            coef = np.zeros((nnz, 32), np.uint8)
+            L.masp_host_circuit_matrix(h, mi, rp.ctypes.data, col.ctypes.data, coef.ctypes.data)
+            mats.append((rp, col, coef))
+        buf = C.create_string_buffer(65)
+        L.masp_host_circuit_hash(h, buf)
+        L.masp_host_circuit_free(h)
+        _circuits[kind] = (R1cs(n_in, n_aux, n_con, mats), buf.value.decode())
+    return _circuits[kind]
+
+
+def _b(x, n=32):
+    if isinstance(x, int):
+        return x.to_bytes(n, "little")
+    x = bytes(x)
+    assert len(x) == n, (len(x), n)
+    return x
+
+
+def _path(siblings):
+    assert len(siblings) == TREE_DEPTH
+    return np.frombuffer(b"".join(_b(s) for s in siblings), dtype=np.uint8).copy()
+
+
+def _check(rc):
+    if rc:
+        raise HostError(rc)
+
+
+def spend_assignment(ak, nsk, diversifier, rcm, ar, asset_identifier, value, anchor, path_siblings, position, rcv, check=False):
+    """-> (inputs u8[8,32], aux u8[100497,32], cv, rk, nf)   — SaplingProvingContext::spend_proof up to the prover call."""
+    L = load_library()
+    cs, _ = circuit("spend")
+    inputs = np.zeros((cs.n_inputs, 32), np.uint8)
+    aux = np.zeros((cs.n_aux, 32), np.uint8)
+    cv, rk, nf = (C.create_string_buffer(32) for _ in range(3))
+    p = _path(path_siblings)
+    _check(L.masp_host_spend_assignment(_b(ak), _b(nsk), _b(diversifier, 11), _b(rcm), _b(ar), _b(asset_identifier), value, _b(anchor),
+                                        p.ctypes.data, position, _b(rcv), 1 if check else 0, inputs.ctypes.data, aux.ctypes.data, cv, rk, nf))
+    return inputs, aux, cv.raw, rk.raw, nf.raw
+
+
+def output_assignment(esk, diversifier, pk_d, rcm, asset_identifier, value, rcv, check=False):
+    L = load_library()
+    cs, _ = circuit("output")
+    inputs = np.zeros((cs.n_inputs, 32), np.uint8)
+    aux = np.zeros((cs.n_aux, 32), np.uint8)
+    cv = C.create_string_buffer(32)
+    _check(L.masp_host_output_assignment(_b(esk), _b(diversifier, 11), _b(pk_d), _b(rcm), _b(asset_identifier), value, _b(rcv),
+                                         1 if check else 0, inputs.ctypes.data, aux.ctypes.data, cv))
+    return inputs, aux, cv.raw
+
+
+def convert_assignment(generator, value, anchor, path_siblings, position, rcv, check=False):
+    L = load_library()
+    cs, _ = circuit("convert")
+    inputs = np.zeros((cs.n_inputs, 32), np.uint8)
+    aux = np.zeros((cs.n_aux, 32), np.uint8)
+    cv = C.create_string_buffer(32)
+    p = _path(path_siblings)
+    _check(L.masp_host_convert_assignment(_b(generator), value, _b(anchor), p.ctypes.data, position, _b(rcv), 1 if check else 0,
+                                          inputs.ctypes.data, aux.ctypes.data, cv))
+    return inputs, aux, cv.raw
+
+
+# ---- native primitives ----
+GENERATOR_NAMES = ["proof_generation_key_generator", "note_commitment_randomness_generator", "nullifier_position_generator",
+                   "value_commitment_randomness_generator", "spending_key_generator"]
+
+
+def generator_uv(which):
+    out = C.create_string_buffer(64)
+    load_library().masp_host_generator(which, out)
+    return int.from_bytes(out.raw[:32], "little"), int.from_bytes(out.raw[32:], "little")
+
+
+def point_bytes(u, v):
+    return (v | ((u & 1) << 255)).to_bytes(32, "little")
+
+
+def pedersen_hash(personalization, bits):
+    """personalization: -1 for NoteCommitment, else MerkleTree depth; bits: iterable of 0/1 -> (u, v)"""
+    b = np.array(list(bits), dtype=np.uint8)
+    out = C.create_string_buffer(64)
+    load_library().masp_host_pedersen_hash(personalization, b.ctypes.data, b.size, out)
+    return int.from_bytes(out.raw[:32], "little"), int.from_bytes(out.raw[32:], "little")
+
+
+def asset_identifier(name):
+    out = C.create_string_buffer(32)
+    if load_library().masp_host_asset_identifier(bytes(name), len(name), out):
+        raise ValueError("no valid asset identifier")
+    return out.raw
+
+
+def asset_generator(identifier):
+    out = C.create_string_buffer(32)
+    if load_library().masp_host_asset_generator(_b(identifier), out):
+        raise ValueError("invalid asset identifier")
+    return out.raw
+
+
+def value_commitment(identifier, value, rcv):
+    out, uv = C.create_string_buffer(32), C.create_string_buffer(64)
+    if load_library().masp_host_value_commitment(_b(identifier), value, _b(rcv), out, uv):
+        raise ValueError("invalid asset identifier")
+    return out.raw, int.from_bytes(uv.raw[:32], "little"), int.from_bytes(uv.raw[32:], "little")
+
+
+def note_cmu(identifier, value, diversifier, pk_d, rcm):
+    out = C.create_string_buffer(32)
+    if load_library().masp_host_note_cmu(_b(identifier), value, _b(diversifier, 11), _b(pk_d), _b(rcm), out):
+        raise ValueError("invalid note")
+    return out.raw
+
+
+def merkle_hash(depth, lhs, rhs):
+    out = C.create_string_buffer(32)
+    if load_library().masp_host_merkle_hash(depth, _b(lhs), _b(rhs), out):
+        raise ValueError("non-canonical node")
+    return out.raw
+
+
+def jubjub_mul(point, scalar):
+    out = C.create_string_buffer(32)
+    if load_library().masp_host_jubjub_mul(_b(point), _b(scalar), out):
+        raise ValueError("invalid point")
+    return out.raw
+
+
+def jubjub_add(p, q, subtract=False):
+    out = C.create_string_buffer(32)
+    if load_library().masp_host_jubjub_add(_b(p), _b(q), 1 if subtract else 0, out):
+        raise ValueError("invalid point")
+    return out.raw
+
+
+JUBJUB_IDENTITY = (1).to_bytes(32, "little")   # (u, v) = (0, 1)
+
+
+def convert_cmu(generator):
+    out = C.create_string_buffer(32)
+    if load_library().masp_host_convert_cmu(_b(generator), out):
+        raise ValueError("invalid point")
+    return out.raw
+
+
+def spend_leaf(ak, nsk, diversifier, rcm, asset_identifier, value):
+    """(cmu, pk_d) of the note a Spend proves knowledge of: nk = [nsk]G, ivk = CRH(ak, nk), pk_d = [ivk] g_d."""
+    cmu, pk_d = C.create_string_buffer(32), C.create_string_buffer(32)
+    _check(load_library().masp_host_spend_leaf(_b(ak), _b(nsk), _b(diversifier, 11), _b(rcm), _b(asset_identifier), value, cmu, pk_d))
+    return cmu.raw, pk_d.raw
+
+
+def merkle_root(leaf, path_siblings, position):
+    """Root of the depth-32 tree from a leaf, its siblings (leaf level first) and its position."""
+    cur = _b(leaf)
+    for i, sib in enumerate(path_siblings):
+        cur = merkle_hash(i, _b(sib), cur) if (position >> i) & 1 else merkle_hash(i, cur, _b(sib))
+    return cur

@@ -1,0 +1,157 @@
+"""Host-side mirror of the reference's proving API for the Groth16 hot path.
+
+    masp_proofs::prover::LocalTxProver                      /root/reference/masp_proofs/src/prover.rs:27-33,55-95,156-261
+    masp_proofs::sapling::prover::SaplingProvingContext     /root/reference/masp_proofs/src/sapling/prover.rs:26-275
+    masp_primitives::sapling::prover::TxProver (trait)      /root/reference/masp_primitives/src/sapling/prover.rs:17-83
+
+Same method names, argument meaning, return values and error behaviour; the difference is what happens inside
+`create_random_proof`: witness synthesis runs in libmasp_host.so (C++), and NTT / MSM / assembly run on the MI355X in
+libmasp_hip.so.  The reference is Rust; no Rust toolchain exists in the build image, so this layer is Python over the
+two C ABIs (INTEGRATION.md shows the Rust FFI binding a maintainer would write instead).
+
+Types cross this API in their canonical byte encodings: Jubjub scalars and bls12_381::Scalar as 32-byte little-endian
+(ints are accepted too), Jubjub points as their 32-byte `to_bytes()` encoding, AssetType as its 32-byte identifier,
+MerklePath as (siblings leaf-level-first, position).
+"""
+import os
+import secrets
+
+from . import host as H
+from .hip import CONVERT, OUTPUT, SPEND, Context
+
+GROTH_PROOF_SIZE = 192  # masp_primitives/src/transaction/components.rs:15
+FR = H.FR_MODULUS
+RJ = H.JUBJUB_ORDER
+
+
+class ProvingError(Exception):
+    """The reference's `Err(())`."""
+
+
+def _int(x):
+    return x if isinstance(x, int) else int.from_bytes(bytes(x), "little")
+
+
+class SaplingProvingContext:
+    """bsk / cv_sum bookkeeping of one transaction (sapling/prover.rs:26-47, :69-75, :154, :177-183, :205, :228-234, :272).
+
+    Independent of the proof bytes, so the proofs of one transaction may be produced in any order or in one batch."""
+
+    def __init__(self):
+        self.bsk = 0                                  # jubjub::Fr::zero()
+        self.cv_sum = H.JUBJUB_IDENTITY               # jubjub::ExtendedPoint::identity()
+
+    def _spend_like(self, rcv, cv):
+        self.bsk = (self.bsk + _int(rcv)) % RJ
+        self.cv_sum = H.jubjub_add(self.cv_sum, cv)
+
+    def _output(self, rcv, cv):
+        self.bsk = (self.bsk - _int(rcv)) % RJ        # "Outputs subtract from the total."
+        self.cv_sum = H.jubjub_add(self.cv_sum, cv, subtract=True)
+
+    def binding_sig(self, assets_and_values, sighash):
+        # RedJubjub over bsk / cv_sum (sapling/prover.rs:279-326): not part of the Groth16 hot path (SURVEY.md §8b
+        # "Not touched by the build"); the accumulated state is exposed for the caller's signer.
+        raise NotImplementedError("binding_sig is outside the Groth16 hot path; use ctx.bsk / ctx.cv_sum with the reference's RedJubjub")
+
+
+class LocalTxProver:
+    """An implementation of `TxProver` using the MI355X prover.  Holds the three circuits' parameters for its lifetime."""
+
+    def __init__(self, spend_params, output_params, convert_params, device=0, rng=None):
+        """= LocalTxProver::from_bytes (prover.rs:81-95): parameter *bytes* in the bellman wire format.
+        Malformed or mismatching parameters raise (the reference panics, lib.rs:290-293,337)."""
+        self._ctx = Context(device)
+        self._rng = rng or (lambda: secrets.randbelow(FR))          # r, s <- OsRng (sapling/prover.rs:66,174,225)
+        for slot, kind, params in ((SPEND, "spend", spend_params), (OUTPUT, "output", output_params), (CONVERT, "convert", convert_params)):
+            cs, _ = H.circuit(kind)
+            self._ctx.load_circuit(slot, params, cs)
+
+    @classmethod
+    def new(cls, spend_path, output_path, convert_path, **kw):
+        """= LocalTxProver::new (prover.rs:55-64): parameter files on disk."""
+        return cls(*(open(p, "rb").read() for p in (spend_path, output_path, convert_path)), **kw)
+
+    @classmethod
+    def with_default_location(cls, **kw):
+        """= LocalTxProver::with_default_location (prover.rs:120-136): ~/.masp-params/masp-{spend,output,convert}.params"""
+        d = os.path.join(os.path.expanduser("~"), ".masp-params")
+        paths = [os.path.join(d, "masp-%s.params" % k) for k in ("spend", "output", "convert")]
+        if not all(os.path.exists(p) for p in paths):
+            return None
+        return cls.new(*paths, **kw)
+
+    @classmethod
+    def with_synthetic_parameters(cls, seed=0, device=0, **kw):
+        """Parameters generated on the GPU from known toxic waste, as the reference's benches do with
+        `generate_random_parameters` (benches/sapling.rs:24-36): the MPC parameter files cannot be downloaded here."""
+        from .synthetic import toxic_waste
+        ctx = Context(device)
+        params = [ctx.generate_parameters(H.circuit(k)[0], toxic_waste(seed * 3 + i)) for i, k in enumerate(("spend", "output", "convert"))]
+        ctx.close()
+        p = cls(*params, device=device, **kw)
+        p.parameters = dict(zip(("spend", "output", "convert"), params))
+        return p
+
+    def close(self):
+        self._ctx.close()
+
+    def new_sapling_proving_context(self):
+        return SaplingProvingContext()
+
+    # ---- witness preparation (host) and proving (GPU) are split so that batches can be formed ----
+    def prepare_spend(self, proof_generation_key, diversifier, rcm, ar, asset_type, value, anchor, merkle_path, rcv):
+        ak, nsk = proof_generation_key
+        siblings, position = merkle_path
+        try:
+            inputs, aux, cv, rk, nf = H.spend_assignment(ak, nsk, diversifier, rcm, ar, asset_type, value, anchor, siblings, position, rcv)
+        except H.HostError as e:
+            raise ProvingError(str(e)) from None           # invalid diversifier -> Err(()) (sapling/prover.rs:84)
+        return dict(slot=SPEND, inputs=inputs, aux=aux, cv=cv, rk=rk, nf=nf, rcv=rcv)
+
+    def prepare_output(self, esk, payment_address, rcm, asset_type, value, rcv):
+        diversifier, pk_d = payment_address
+        try:
+            inputs, aux, cv = H.output_assignment(esk, diversifier, pk_d, rcm, asset_type, value, rcv)
+        except H.HostError as e:
+            raise ProvingError(str(e)) from None
+        return dict(slot=OUTPUT, inputs=inputs, aux=aux, cv=cv, rcv=rcv)
+
+    def prepare_convert(self, allowed_conversion, value, anchor, merkle_path, rcv):
+        siblings, position = merkle_path
+        try:
+            inputs, aux, cv = H.convert_assignment(allowed_conversion, value, anchor, siblings, position, rcv)
+        except H.HostError as e:
+            raise ProvingError(str(e)) from None
+        return dict(slot=CONVERT, inputs=inputs, aux=aux, cv=cv, rcv=rcv)
+
+    def prove_prepared(self, jobs, rs=None):
+        """jobs: outputs of prepare_*; rs: optional explicit [(r, s)] (deterministic replay) -> list of 192-byte proofs."""
+        if rs is None:
+            rs = [(self._rng(), self._rng()) for _ in jobs]
+        return self._ctx.prove_batch([(j["slot"], j["inputs"], j["aux"], r, s) for j, (r, s) in zip(jobs, rs)])
+
+    # ---- the TxProver methods ----
+    def spend_proof(self, ctx, proof_generation_key, diversifier, rseed, ar, asset_type, value, anchor, merkle_path, rcv, rs=None):
+        """-> (zkproof[192], cv, rk).  `rseed` is the note commitment randomness rcm = note.rcm() (Rseed::BeforeZip212 form)."""
+        job = self.prepare_spend(proof_generation_key, diversifier, rseed, ar, asset_type, value, anchor, merkle_path, rcv)
+        zkproof = self.prove_prepared([job], None if rs is None else [rs])[0]
+        ctx._spend_like(rcv, job["cv"])
+        return zkproof, job["cv"], job["rk"]
+
+    def output_proof(self, ctx, esk, payment_address, rcm, asset_type, value, rcv, rs=None):
+        """-> (zkproof[192], cv); infallible for valid inputs like the reference (it panics if proving fails)."""
+        job = self.prepare_output(esk, payment_address, rcm, asset_type, value, rcv)
+        zkproof = self.prove_prepared([job], None if rs is None else [rs])[0]
+        ctx._output(rcv, job["cv"])
+        return zkproof, job["cv"]
+
+    def convert_proof(self, ctx, allowed_conversion, value, anchor, merkle_path, rcv, rs=None):
+        """-> (zkproof[192], cv)"""
+        job = self.prepare_convert(allowed_conversion, value, anchor, merkle_path, rcv)
+        zkproof = self.prove_prepared([job], None if rs is None else [rs])[0]
+        ctx._spend_like(rcv, job["cv"])
+        return zkproof, job["cv"]
+
+    def binding_sig(self, ctx, assets_and_values, sighash):
+        return ctx.binding_sig(assets_and_values, sighash)

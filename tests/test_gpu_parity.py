@@ -211,3 +211,78 @@ def test_spend_shaped_full_size_proof(ctx):
     pub = [int.from_bytes(inputs[i].tobytes(), "little") for i in range(1, cs.n_inputs)]
     assert O.verify_proof(params[:868 + 96 * cs.n_inputs], proof, pub) == 1   # oracle 2: pairing check
     assert proof == O.create_proof(O.Params(params), cs, inputs, aux, r, s)  # oracle 3: CPU restatement
+
+
+def test_local_tx_prover_real_circuits_match_oracle_and_verify(ctx):
+    """LocalTxProver::{spend_proof, output_proof, convert_proof} on the REAL MASP circuits (structure hashes pinned by
+    tests/test_circuits.py): proof bytes equal the CPU restatement and the toxic-waste closed form, and pass the
+    pairing check with the public inputs the reference's verifier would build (sapling/prover.rs:121-145,256-263)."""
+    import random
+    from masp_amd import host as H
+    from masp_amd import prover as P
+    from masp_amd.synthetic import toxic_waste
+    from test_circuits import spend_instance
+    rng = random.Random(77)
+    lp = P.LocalTxProver.with_synthetic_parameters(seed=5)
+    pc = lp.new_sapling_proving_context()
+    # ---- Spend (config 2 of BASELINE.json)
+    inst, cmu, pk_d = spend_instance(300, value=42)
+    r, s = rng.randrange(H.FR_MODULUS), rng.randrange(H.FR_MODULUS)
+    zk, cv, rk = lp.spend_proof(pc, (inst["ak"], inst["nsk"]), inst["diversifier"], inst["rcm"], inst["ar"], inst["asset_identifier"],
+                                inst["value"], inst["anchor"], (inst["path_siblings"], inst["position"]), inst["rcv"], rs=(r, s))
+    assert len(zk) == P.GROTH_PROOF_SIZE
+    cs, _ = H.circuit("spend")
+    inputs, aux, cv2, rk2, nf = H.spend_assignment(check=False, **inst)
+    assert (cv, rk) == (cv2, rk2)
+    params = lp.parameters["spend"]
+    assert params.size == 48482520
+    assert zk == O.create_proof(O.Params(params), cs, inputs, aux, r, s)
+    assert zk == O.closed_form_proof(cs, toxic_waste(15), inputs, aux, r, s)
+    pub = [int.from_bytes(inputs[i].tobytes(), "little") for i in range(1, 8)]
+    assert O.verify_proof(params[:868 + 96 * 8], zk, pub) == 1
+    assert pc.bsk == inst["rcv"] % H.JUBJUB_ORDER and pc.cv_sum == cv
+    # ---- Output
+    ident = H.asset_identifier(b"benchmark")
+    while True:
+        d = bytes(rng.getrandbits(8) for _ in range(11))
+        try:
+            pk = H.jubjub_mul(H.point_bytes(*H.generator_uv(0)), rng.randrange(1, H.JUBJUB_ORDER))
+            args = dict(esk=rng.randrange(1, H.JUBJUB_ORDER), payment_address=(d, pk), rcm=rng.randrange(1, H.JUBJUB_ORDER),
+                        asset_type=ident, value=7, rcv=rng.randrange(1, H.JUBJUB_ORDER))
+            zk_o, cv_o = lp.output_proof(pc, rs=(r, s), **args)
+            break
+        except P.ProvingError:
+            continue
+    cs_o, _ = H.circuit("output")
+    i_o, a_o, _ = H.output_assignment(args["esk"], d, pk, args["rcm"], ident, 7, args["rcv"])
+    po = lp.parameters["output"]
+    assert po.size == 15032568 and zk_o == O.create_proof(O.Params(po), cs_o, i_o, a_o, r, s)
+    assert O.verify_proof(po[:868 + 96 * 6], zk_o, [int.from_bytes(i_o[i].tobytes(), "little") for i in range(1, 6)]) == 1
+    assert pc.bsk == (inst["rcv"] - args["rcv"]) % H.JUBJUB_ORDER and pc.cv_sum == H.jubjub_add(cv, cv_o, subtract=True)
+    # ---- Convert
+    gen = H.asset_generator(H.asset_identifier(b"asset 1"))
+    sib = [rng.randrange(H.FR_MODULUS) for _ in range(32)]
+    pos = rng.getrandbits(32)
+    anchor = H.merkle_root(H.convert_cmu(gen), sib, pos)
+    rcv = rng.randrange(1, H.JUBJUB_ORDER)
+    zk_c, cv_c = lp.convert_proof(pc, gen, 99, anchor, (sib, pos), rcv, rs=(r, s))
+    cs_c, _ = H.circuit("convert")
+    i_c, a_c, _ = H.convert_assignment(gen, 99, anchor, sib, pos, rcv)
+    pcv = lp.parameters["convert"]
+    assert pcv.size == 21204888 and zk_c == O.create_proof(O.Params(pcv), cs_c, i_c, a_c, r, s)
+    assert O.verify_proof(pcv[:868 + 96 * 4], zk_c, [int.from_bytes(i_c[i].tobytes(), "little") for i in range(1, 4)]) == 1
+    # invalid diversifier -> Err(())
+    bad = next(bytes([k]) * 11 for k in range(256) if _invalid_diversifier(bytes([k]) * 11, inst))
+    with pytest.raises(P.ProvingError):
+        lp.spend_proof(pc, (inst["ak"], inst["nsk"]), bad, inst["rcm"], inst["ar"], inst["asset_identifier"], 1, inst["anchor"],
+                       (inst["path_siblings"], inst["position"]), inst["rcv"])
+    lp.close()
+
+
+def _invalid_diversifier(d, inst):
+    from masp_amd import host as H
+    try:
+        H.spend_leaf(inst["ak"], inst["nsk"], d, inst["rcm"], inst["asset_identifier"], 1)
+        return False
+    except H.HostError:
+        return True
