@@ -36,6 +36,47 @@ def make_jobs(n_distinct, total, shaped):
     return jobs
 
 
+def real_instances(kind, n, rank):
+    """n independent, valid instances of the real MASP circuit `kind`, shaped like the reference's benches
+    (masp_proofs/benches/sapling.rs:39-69, benches/convert.rs:32-53) but with the anchor set to the computed root."""
+    import random
+    from masp_amd import host as H
+    cs, _ = H.circuit(kind)
+    out = []
+    for k in range(n):
+        rng = random.Random("masp-bench-%s-%d-%d" % (kind, rank, k))
+        sc = lambda: rng.randrange(1, H.JUBJUB_ORDER)
+        siblings = [rng.randrange(H.FR_MODULUS) for _ in range(32)]
+        pos = rng.getrandbits(32)
+        if kind == "spend":
+            ident = H.asset_identifier(b"benchmark")
+            ak = H.jubjub_mul(H.point_bytes(*H.generator_uv(4)), sc())
+            nsk, ar, rcm, rcv = sc(), sc(), sc(), sc()
+            while True:
+                d = bytes(rng.getrandbits(8) for _ in range(11))
+                try:
+                    cmu, _ = H.spend_leaf(ak, nsk, d, rcm, ident, 1)
+                    break
+                except H.HostError:
+                    continue
+            inputs, aux, *_ = H.spend_assignment(ak, nsk, d, rcm, ar, ident, 1, H.merkle_root(cmu, siblings, pos), siblings, pos, rcv)
+        elif kind == "output":
+            ident = H.asset_identifier(b"benchmark")
+            pk = H.jubjub_mul(H.point_bytes(*H.generator_uv(0)), sc())
+            while True:
+                d = bytes(rng.getrandbits(8) for _ in range(11))
+                try:
+                    inputs, aux, _ = H.output_assignment(sc(), d, pk, sc(), ident, 1, sc())
+                    break
+                except H.HostError:
+                    continue
+        else:
+            gen = H.asset_generator(H.asset_identifier(b"asset %d" % k))
+            inputs, aux, _ = H.convert_assignment(gen, 1 + rng.getrandbits(40), H.merkle_root(H.convert_cmu(gen), siblings, pos), siblings, pos, sc())
+        out.append((cs, inputs, aux))
+    return out
+
+
 def cpu_baseline(cs, params, inputs, aux, budget_s=20.0):
     """Oracle (C++ restatement of bellperson's CPU prover, oracle/) timed on the host cores: reported baseline only."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -53,7 +94,7 @@ def cpu_baseline(cs, params, inputs, aux, budget_s=20.0):
             break
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "proofs/s", "cores": O.lib().oracle_get_threads(), "kind": "port",
-            "sample": "%d %s-shaped proofs, same CRS and witness as the GPU run (oracle/groth16_oracle.cpp, all host cores)" % (n, WORKLOAD),
+            "sample": "%d %s proofs, same circuit, CRS and witness as the GPU run (oracle/groth16_oracle.cpp, all host cores)" % (n, WORKLOAD),
             "phase_ms_per_proof": {k: round(v / n, 2) for k, v in phases.items()}}
 
 
@@ -64,6 +105,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # let independent proofs' kernels overlap (ROCm default: 4)
+    os.environ.setdefault("MASP_HIP_SLOTS", "16")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -82,7 +125,12 @@ def main():
 
     ctx = masp_amd.Context(local_rank)
     n_distinct = 4
-    shaped = [synthetic.shaped(WORKLOAD, seed=rank * 1000 + k) for k in range(n_distinct)]
+    if os.environ.get("MASP_BENCH_SYNTHETIC_SHAPE"):
+        shaped = [synthetic.shaped(WORKLOAD, seed=rank * 1000 + k) for k in range(n_distinct)]
+        circuit_desc = "%s-SHAPED synthetic R1CS (masp_amd/synthetic.py)" % WORKLOAD
+    else:
+        shaped = real_instances(WORKLOAD, n_distinct, rank)
+        circuit_desc = "the real MASP %s circuit (structure hash pinned to the reference's KAT), witnesses from the C++ synthesizer" % WORKLOAD
     cs = shaped[0][0]
     params = ctx.generate_parameters(cs, synthetic.toxic_waste(1))   # same CRS on every rank
     ctx.load_circuit(0, params, cs)
@@ -109,20 +157,21 @@ def main():
     barrier()
     t0 = time.perf_counter()
     proofs, gpu_ms = ctx.batch_prove_resident(*timed)       # exactly K steps
+    from masp_amd import distributed as D
     if dist is not None:
         import torch
-        mine = torch.from_numpy(np.frombuffer(b"".join(proofs), dtype=np.uint8).copy()).cuda()
-        gathered = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
-        dist.gather(mine, gathered, dst=0)                   # RCCL over xGMI: N*K*192 bytes
+        dev = torch.device("cuda", local_rank)
+        all_proofs = D.gather_proofs(proofs, K * world, dist, dev)   # RCCL over xGMI: N*K*192 bytes to rank 0
+    else:
+        all_proofs = proofs
     barrier()
     elapsed = time.perf_counter() - t0
     acc_ms, launches, alg_bytes = ctx.profile_read()
     ctx.profile_enable(False)
     if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = D.max_over_ranks(elapsed, dist, dev)
+        if rank == 0:
+            assert len(all_proofs) == K * world
     if rank == 0:
         assert len(set(proofs)) == len(proofs) and all(len(p) == 192 for p in proofs)
         total = K * world
@@ -138,10 +187,10 @@ def main():
             "metric": "Spend proofs/sec", "value": total / elapsed, "unit": "proofs/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 limbs (384-bit Fp / 255-bit Fr modular integers)", "data": "synthetic",
-            "config": {"workload": "single %s proof per step (BASELINE.json configs[1]); %s-shaped synthetic R1CS + synthetic CRS "
-                                   "(sizes of SURVEY.md App. C.3: NTT 2^%d, G1 MSMs %d/%d/%d/%d, G2 MSM %d), witness resident in HBM, "
+            "config": {"workload": "single %s proof per step (BASELINE.json configs[1]); %s + synthetic CRS from known toxic waste "
+                                   "(NTT 2^%d, G1 MSMs %d/%d/%d/%d, G2 MSM %d), witness resident in HBM, "
                                    "steps pipelined over %s HIP streams"
-                                   % (WORKLOAD, WORKLOAD, cs.logm, (1 << cs.logm) - 1, cs.n_aux,
+                                   % (WORKLOAD, circuit_desc, cs.logm, (1 << cs.logm) - 1, cs.n_aux,
                                       synthetic.SHAPES[WORKLOAD][3] + cs.n_inputs, synthetic.SHAPES[WORKLOAD][4] + 1,
                                       synthetic.SHAPES[WORKLOAD][4] + 1, os.environ.get("MASP_HIP_SLOTS", "4")),
                        "proofs_per_gpu": K, "parallelism": "proofs sharded over %d GPU(s), RCCL gather of proofs" % world},

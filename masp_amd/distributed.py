@@ -1,0 +1,47 @@
+"""Multi-GPU sharding of independent proving jobs: one process per GPU, no data-path collective, one final gather
+of the 192-byte proofs to rank 0.  Works with any initialised torch.distributed backend
+("nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests)."""
+import numpy as np
+
+PROOF_BYTES = 192
+
+
+def shard(n_jobs, rank, world):
+    """Contiguous shard of job indices for `rank`; sizes differ by at most one."""
+    base, extra = divmod(n_jobs, world)
+    lo = rank * base + min(rank, extra)
+    return range(lo, lo + base + (1 if rank < extra else 0))
+
+
+def gather_proofs(local_proofs, n_jobs, dist=None, device=None):
+    """Every rank passes the proofs of its shard (job order); rank 0 gets all n_jobs proofs in job order, others None."""
+    import torch
+    if dist is None or dist.get_world_size() == 1:
+        return list(local_proofs)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    cap = (n_jobs + world - 1) // world               # gather needs equal sizes: pad to the largest shard
+    buf = np.zeros((cap, PROOF_BYTES), dtype=np.uint8)
+    for i, p in enumerate(local_proofs):
+        buf[i] = np.frombuffer(p, dtype=np.uint8)
+    mine = torch.from_numpy(buf)
+    if device is not None:
+        mine = mine.to(device)
+    out = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+    dist.gather(mine, out, dst=0)
+    if rank != 0:
+        return None
+    proofs = []
+    for r in range(world):
+        arr = out[r].cpu().numpy()
+        for i in range(len(shard(n_jobs, r, world))):
+            proofs.append(arr[i].tobytes())
+    return proofs
+
+
+def max_over_ranks(value, dist=None, device=None):
+    import torch
+    if dist is None or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

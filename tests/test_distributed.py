@@ -1,0 +1,63 @@
+"""The N > 1 path of bench.py / prove sharding, exercised with world_size 2 on CPU (gloo): job sharding, the final
+gather of 192-byte proofs to rank 0 in job order, and the max-over-ranks timing reduction."""
+import hashlib
+import os
+import socket
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _fake_proof(job):
+    return (hashlib.sha256(b"job%d" % job).digest() * 6)[:192]
+
+
+def _worker(rank, world, port, n_jobs, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from masp_amd import distributed as D
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = [_fake_proof(j) for j in D.shard(n_jobs, rank, world)]
+    allp = D.gather_proofs(mine, n_jobs, dist)
+    t = D.max_over_ranks(1.0 + rank, dist)
+    dist.barrier()
+    q.put((rank, allp, t))
+    dist.destroy_process_group()
+
+
+def test_shard_partitions_jobs():
+    from masp_amd import distributed as D
+    for n in (0, 1, 7, 256, 4096):
+        for world in (1, 2, 3, 8):
+            seen = [j for r in range(world) for j in D.shard(n, r, world)]
+            assert seen == list(range(n))
+            sizes = [len(D.shard(n, r, world)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize("n_jobs", [5, 8])
+def test_gather_world_size_2_gloo(n_jobs):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_jobs, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, allp, t = q.get(timeout=120)
+        res[rank] = (allp, t)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[1][0] is None
+    assert res[0][0] == [_fake_proof(j) for j in range(n_jobs)]
+    assert res[0][1] == res[1][1] == 2.0
