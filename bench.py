@@ -205,11 +205,15 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cs, params, shaped[0][1], shaped[0][2])
-        print(json.dumps(out), flush=True)
+    else:
+        out = None
+    ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    if out is not None:
+        sys.stderr.flush()
+        print(json.dumps(out), flush=True)      # the ONE JSON line, last thing on stdout
 
 
 if __name__ == "__main__":

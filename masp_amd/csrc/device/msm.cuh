@@ -8,14 +8,18 @@
 //
 //   load time   T[j][i] = 2^(c*j) * P_i  for every window j (affine, Montgomery), so that all windows
 //               share ONE bucket set and no per-window Horner doublings exist at prove time.
-//   prove time  (1) digits   : signed c-bit digits of every scalar; zero scalars vanish, scalars equal
-//                              to 1 (≈70 % of a MASP witness) go to a "ones" list;
-//                              histogram of sub-bucket keys.
+//   prove time  (1) digits   : signed c-bit digits of every scalar; zero scalars (38 % of a Spend witness) vanish,
+//                              scalars equal to 1 (33 %) go to a "ones" list; bucket histogram.
 //               (2) scan     : exclusive prefix sum of the histogram.
-//               (3) scatter  : counting sort of (table index, sign) by sub-bucket.
-//               (4) accumulate: one lane per sub-bucket, mixed XYZZ additions of gathered table rows.
-//               (5) reduce   : sub-buckets -> buckets -> sum_w w*B_w by chunked running sums;
-//                              the ones list by a plain tree; total = weighted + ones.
+//               (3) scatter  : counting sort of (table row, sign) by bucket.
+//               (4) accumulate: the SORTED list is cut into equal chunks, one lane per chunk, mixed XYZZ
+//                              additions of gathered table rows; a lane flushes a partial sum whenever its
+//                              chunk crosses a bucket boundary.  Every lane does the same number of
+//                              additions whatever the digit distribution (the 1-bucket of a MASP witness
+//                              holds ~33 000 points, a uniform bucket ~64).
+//               (5) gather   : one lane per bucket adds the few partials of its bucket; buckets spread over
+//                              many chunks are finished by one wave each (LDS tree).
+//               (6) reduce   : sum_w w*B_w by a log-depth LDS suffix scan + tree per 256 buckets.
 // Group arithmetic is exact, so the result (after affine normalisation) is bit-identical to any
 // other evaluation order — which is what lets the sort be unstable and the atomics unordered.
 #pragma once
@@ -30,15 +34,12 @@ struct MsmGeom {
     int c;        // window bits
     int W;        // windows = ceil(256 / c)
     int nb;       // buckets = 2^(c-1)  (|digit| in 1..2^(c-1))
-    int sl_log;   // log2 of sub-buckets per bucket
-    __host__ __device__ int nsub() const { return nb << sl_log; }
 };
-static inline MsmGeom msm_geom(int c, int sl_log) {
+static inline MsmGeom msm_geom(int c) {
     MsmGeom g;
     g.c = c;
     g.W = (256 + c - 1) / c;
     g.nb = 1 << (c - 1);
-    g.sl_log = sl_log;
     return g;
 }
 
@@ -81,7 +82,7 @@ __global__ void k_msm_precompute(Affine<O>* __restrict__ tab, uint32_t n, int c,
 }
 
 // ---- (1) digits ---------------------------------------------------------------------------------
-// scalars: n x 8 canonical little-endian limbs.  ent[j*n + i] = sub-bucket key | sign<<31, or ENT_NONE.
+// scalars: n x 8 canonical little-endian limbs.  ent[j*n + i] = bucket | sign<<31, or ENT_NONE.
 __global__ void k_msm_digits(const uint32_t* __restrict__ scalars, uint32_t n, MsmGeom g, uint32_t* __restrict__ ent,
                              uint32_t* __restrict__ hist, uint32_t* __restrict__ ones, uint32_t* __restrict__ n_ones) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -90,17 +91,12 @@ __global__ void k_msm_digits(const uint32_t* __restrict__ scalars, uint32_t n, M
     const uint4* sp = reinterpret_cast<const uint4*>(sw);
     uint4 lo = sp[0], hi = sp[1];
     uint32_t rest = lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w;
-    bool is_zero = (rest | lo.x) == 0;
     bool is_one = rest == 0 && lo.x == 1;
-    if (is_one) {
-        uint32_t k = atomicAdd(n_ones, 1u);
-        ones[k] = i;
-    }
-    bool skip = is_zero || is_one;
+    if (is_one) ones[atomicAdd(n_ones, 1u)] = i;  // ~1/3 of a MASP witness: summed by k_msm_ones, not bucketed
+    bool skip = is_one || (rest | lo.x) == 0;
     uint32_t carry = 0;
     const uint32_t mask = (1u << g.c) - 1u;
     const uint32_t half = 1u << (g.c - 1);
-    const uint32_t slmask = (1u << g.sl_log) - 1u;
     for (int j = 0; j < g.W; ++j) {
         uint32_t e = ENT_NONE;
         if (!skip) {
@@ -119,16 +115,15 @@ __global__ void k_msm_digits(const uint32_t* __restrict__ scalars, uint32_t n, M
                 carry = 0;
             }
             if (v != 0) {
-                uint32_t key = ((v - 1) << g.sl_log) | (i & slmask);
-                e = key | (neg << 31);
-                atomicAdd(&hist[key], 1u);
+                e = (v - 1) | (neg << 31);
+                atomicAdd(&hist[v - 1], 1u);
             }
         }
         ent[(size_t)j * n + i] = e;
     }
 }
 
-// ---- (2) exclusive scan, single workgroup ----------------------------------------------------------
+// ---- (2) exclusive scan, single workgroup; out has n + 1 entries (out[n] = total) -------------------
 __global__ void k_scan_exclusive(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n) {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t base;
@@ -154,6 +149,7 @@ __global__ void k_scan_exclusive(const uint32_t* __restrict__ in, uint32_t* __re
         if (tid == blockDim.x - 1) base = b + woff + x;
         __syncthreads();
     }
+    if (tid == 0) out[n] = base;  // grand total
 }
 
 // ---- (3) scatter --------------------------------------------------------------------------------
@@ -169,51 +165,116 @@ __global__ void k_msm_scatter(const uint32_t* __restrict__ ent, uint32_t total, 
     sorted[pos] = t | (e & 0x80000000u);
 }
 
-// ---- (4) accumulate -----------------------------------------------------------------------------
+// ---- (4) accumulate: equal chunks of the sorted list ------------------------------------------------
+// start[0..nb] from the scan (start[nb] = number of entries).  Lane `ch` owns entries [ch*K, ch*K + K) with
+// K = ceil(total / nchunks); the partial sum of its run inside bucket b goes to part[ch + b] — a slot no other
+// (chunk, bucket) pair can hit, because chunk and bucket indices both only grow along the list.
+__device__ __forceinline__ uint32_t msm_chunk_len(uint32_t total, uint32_t nchunks) {
+    uint32_t k = (total + nchunks - 1) / nchunks;
+    return k < 4 ? 4 : k;  // at least 4 additions per lane: fewer partials to gather
+}
 template <class O>
 __global__ void __launch_bounds__(64)
-k_msm_accumulate(const Affine<O>* __restrict__ tab, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ start,
-                 const uint32_t* __restrict__ count, uint32_t nsub, Xyzz<O>* __restrict__ sub) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nsub) return;
-    uint32_t lo = start[b], cnt = count[b];
-    Xyzz<O> acc = xyzz_inf<O>();
-    for (uint32_t k = 0; k < cnt; ++k) {
-        uint32_t e = sorted[lo + k];
-        Affine<O> p = tab[e & 0x7fffffffu];
-        xyzz_madd(acc, p, (e >> 31) != 0);
+k_msm_accumulate(const Affine<O>* __restrict__ tab, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ start, uint32_t nb,
+                 uint32_t nchunks, Xyzz<O>* __restrict__ part) {
+    const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= nchunks) return;
+    const uint32_t total = start[nb];
+    const uint32_t K = msm_chunk_len(total, nchunks);
+    const uint32_t lo = ch * K;
+    if (lo >= total) return;
+    const uint32_t hi = lo + K < total ? lo + K : total;
+    // bucket of the first entry: largest b with start[b] <= lo (and a non-empty run there)
+    uint32_t b = 0, span = nb;
+    while (span > 1) {
+        uint32_t half = span >> 1;
+        if (start[b + half] <= lo) b += half;
+        span -= half;
     }
-    sub[b] = acc;
+    uint32_t next = start[b + 1];
+    Xyzz<O> acc = xyzz_inf<O>();
+    for (uint32_t pos = lo; pos < hi; ++pos) {
+        if (pos >= next) {
+            part[ch + b] = acc;
+            acc = xyzz_inf<O>();
+            do {
+                ++b;
+                next = start[b + 1];
+            } while (pos >= next);
+        }
+        uint32_t e = sorted[pos];
+        xyzz_madd(acc, tab[e & 0x7fffffffu], (e >> 31) != 0);
+    }
+    part[ch + b] = acc;
 }
 
-// ---- (5) reductions -----------------------------------------------------------------------------
-// out[t] = sum of in[t*f .. min(n, t*f+f))
+// ---- (5) gather: bucket b = sum of its partials part[c + b], c over the chunks its entries touch ---------
+static constexpr uint32_t MSM_HEAVY_SPAN = 24;  // more partials than this -> finished by a whole wave
 template <class O>
-__global__ void __launch_bounds__(64) k_xyzz_reduce(const Xyzz<O>* __restrict__ in, uint32_t n, uint32_t f, Xyzz<O>* __restrict__ out) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t lo = t * f;
-    if (lo >= n) return;
-    uint32_t hi = lo + f < n ? lo + f : n;
-    Xyzz<O> acc = in[lo];
-    for (uint32_t k = lo + 1; k < hi; ++k) xyzz_add_nc(acc, in[k]);
-    out[t] = acc;
-}
-// ones list: out[t] = sum of tab[ones[t*f ..]]  (window-0 table rows)
-template <class O>
-__global__ void __launch_bounds__(64) k_msm_ones(const Affine<O>* __restrict__ tab, const uint32_t* __restrict__ ones,
-                                                 const uint32_t* __restrict__ n_ones, uint32_t f, Xyzz<O>* __restrict__ out,
-                                                 uint32_t out_cap) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= out_cap) return;
-    uint32_t n = *n_ones;
-    uint32_t lo = t * f;
+__global__ void __launch_bounds__(64)
+k_msm_bucket_gather(const Xyzz<O>* __restrict__ part, const uint32_t* __restrict__ start, uint32_t nb, uint32_t nchunks,
+                    Xyzz<O>* __restrict__ bkt, uint32_t* __restrict__ heavy, uint32_t* __restrict__ n_heavy) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const uint32_t s0 = start[b], s1 = start[b + 1];
     Xyzz<O> acc = xyzz_inf<O>();
-    if (lo < n) {
-        uint32_t hi = lo + f < n ? lo + f : n;
-        for (uint32_t k = lo; k < hi; ++k) xyzz_madd(acc, tab[ones[k]], false);
+    if (s1 > s0) {
+        const uint32_t K = msm_chunk_len(start[nb], nchunks);
+        const uint32_t c0 = s0 / K, c1 = (s1 - 1) / K;
+        if (c1 - c0 >= MSM_HEAVY_SPAN) {
+            heavy[atomicAdd(n_heavy, 1u)] = b;
+            return;  // written by k_msm_bucket_heavy
+        }
+        acc = part[c0 + b];
+        for (uint32_t c = c0 + 1; c <= c1; ++c) xyzz_add_nc(acc, part[c + b]);
     }
-    out[t] = acc;
+    bkt[b] = acc;
 }
+template <class O>
+__global__ void __launch_bounds__(64)
+k_msm_bucket_heavy(const Xyzz<O>* __restrict__ part, const uint32_t* __restrict__ start, uint32_t nb, uint32_t nchunks,
+                   Xyzz<O>* __restrict__ bkt, const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ n_heavy) {
+    extern __shared__ uint4 wsum_lds[];
+    Xyzz<O>* sh = reinterpret_cast<Xyzz<O>*>(wsum_lds);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t nh = *n_heavy;
+    const uint32_t K = msm_chunk_len(start[nb], nchunks);
+    for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
+        const uint32_t b = heavy[h];
+        const uint32_t c0 = start[b] / K, c1 = (start[b + 1] - 1) / K;
+        Xyzz<O> acc = xyzz_inf<O>();
+        for (uint32_t c = c0 + lane; c <= c1; c += 64) xyzz_add_nc(acc, part[c + b]);
+        for (uint32_t d = 32; d >= 1; d >>= 1) {
+            sh[lane] = acc;
+            __syncthreads();
+            if (lane < d) xyzz_add_nc(acc, sh[lane + d]);
+            __syncthreads();
+        }
+        if (lane == 0) bkt[b] = acc;
+    }
+}
+
+// ones list: 256 workgroups of one wave; lane g adds tab[ones[g]], tab[ones[g + 16384]], ... then an LDS tree
+template <class O>
+__global__ void __launch_bounds__(64)
+k_msm_ones(const Affine<O>* __restrict__ tab, const uint32_t* __restrict__ ones, const uint32_t* __restrict__ n_ones,
+           Xyzz<O>* __restrict__ out) {
+    extern __shared__ uint4 wsum_lds[];
+    Xyzz<O>* sh = reinterpret_cast<Xyzz<O>*>(wsum_lds);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n = *n_ones;
+    Xyzz<O> acc = xyzz_inf<O>();
+    for (uint32_t k = blockIdx.x * 64 + lane; k < n; k += gridDim.x * 64) xyzz_madd_nc(acc, tab[ones[k]], false);
+    for (uint32_t d = 32; d >= 1; d >>= 1) {
+        sh[lane] = acc;
+        __syncthreads();
+        if (lane < d) xyzz_add_nc(acc, sh[lane + d]);
+        __syncthreads();
+    }
+    if (lane == 0) out[blockIdx.x] = acc;
+}
+
+// ---- (6) reductions -----------------------------------------------------------------------------
 // One level of the weighted sum  V(B, off) = sum_k (k + off) * B[k], one workgroup per chunk of WSUM_CS
 // elements:  S[ch] = sum_l B[ch*cs + l],  T[ch] = sum_l (l + off) * B[ch*cs + l];  then
 // V(B, off) = sum_ch T[ch] + cs * V(S, 0).  Inside the workgroup the running sums are a log-depth suffix scan

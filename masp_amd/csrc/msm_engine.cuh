@@ -25,14 +25,11 @@ struct MsmBases {
         tab = nullptr;
     }
     static MsmGeom pick_geom(uint32_t n) {
-        // window width by problem size: bucket work (2^(c-1) * ~3 adds) must stay well under n * W adds
+        // window width by problem size: the bucket reduction (2^(c-1) buckets) must stay small next to n * W additions
         int c = n >= (1u << 15) ? 16 : n >= (1u << 12) ? 13 : n >= (1u << 8) ? 10 : 7;
-        int sl = c >= 16 ? 3 : c >= 13 ? 2 : 0;
         const char* e = getenv("MASP_HIP_MSM_C");
         if (e) c = atoi(e);
-        e = getenv("MASP_HIP_MSM_SL");
-        if (e) sl = atoi(e);
-        return msm_geom(c, sl);
+        return msm_geom(c);
     }
     // raw: device pointer to n uncompressed points (bellman wire format)
     int load_device(const uint8_t* d_raw, uint32_t n_, hipStream_t s) {
@@ -68,58 +65,62 @@ struct MsmBases {
 template <class O>
 struct MsmWorkspace {
     static constexpr uint32_t CS_LOG = WSUM_CS_LOG;   // weighted-sum chunk = one 256-lane workgroup
-    static constexpr uint32_t RF = 32;      // plain reduction fan-in
-    static constexpr uint32_t ONES_F = 32;  // ones-list: bases per lane in the first pass
+    static constexpr uint32_t NCHUNKS = 1u << 18;     // lanes of the accumulation kernel (1024 waves x 4 per SIMD)
+    static constexpr uint32_t HEAVY_BLOCKS = 256;
 
-    size_t cap_ent = 0, cap_sub = 0, cap_n = 0, cap_nb = 0;
+    size_t cap_ent = 0, cap_nb = 0;
     uint32_t *ent = nullptr, *sorted = nullptr, *hist = nullptr, *start = nullptr, *fill = nullptr;
-    uint32_t *ones = nullptr, *n_ones = nullptr;
-    Xyzz<O>*sub = nullptr, *bkt = nullptr, *S[2] = {nullptr, nullptr}, *T = nullptr, *R[2] = {nullptr, nullptr};
-    Xyzz<O>*tsum = nullptr, *ones_sum = nullptr;
+    uint32_t *heavy = nullptr, *n_heavy = nullptr, *ones = nullptr, *n_ones = nullptr;
+    size_t cap_n = 0;
+    Xyzz<O>*part = nullptr, *bkt = nullptr, *S[2] = {nullptr, nullptr}, *T = nullptr, *R[2] = {nullptr, nullptr};
+    Xyzz<O>*tsum = nullptr, *ones_part = nullptr, *ones_sum = nullptr;
 
     ~MsmWorkspace() { release(); }
     void release() {
-        void* ptrs[] = {ent, sorted, hist, start, fill, ones, n_ones, sub, bkt, S[0], S[1], T, R[0], R[1], tsum, ones_sum};
+        void* ptrs[] = {ent, sorted, hist, start, fill, heavy, n_heavy, ones, n_ones, part, bkt, S[0], S[1], T, R[0], R[1], tsum, ones_part, ones_sum};
         for (void* p : ptrs)
             if (p) hipFree(p);
-        ent = sorted = hist = start = fill = ones = n_ones = nullptr;
-        sub = bkt = S[0] = S[1] = T = R[0] = R[1] = tsum = ones_sum = nullptr;
-        cap_ent = cap_sub = cap_n = cap_nb = 0;
+        ent = sorted = hist = start = fill = heavy = n_heavy = ones = n_ones = nullptr;
+        part = bkt = S[0] = S[1] = T = R[0] = R[1] = tsum = ones_part = ones_sum = nullptr;
+        cap_ent = cap_nb = cap_n = 0;
+    }
+    static uint32_t nchunks_for(uint32_t n, const MsmGeom& g) {
+        uint64_t ent = (uint64_t)n * g.W;
+        return (uint32_t)std::min<uint64_t>(NCHUNKS, std::max<uint64_t>(ent, 1));
     }
     int reserve(uint32_t n, const MsmGeom& g) {
-        size_t need_ent = (size_t)n * g.W, need_sub = (size_t)g.nsub();
-        if (need_ent <= cap_ent && need_sub <= cap_sub && n <= cap_n && (size_t)g.nb <= cap_nb) return MASP_HIP_OK;
+        size_t need_ent = (size_t)n * g.W;
+        if (need_ent <= cap_ent && (size_t)g.nb <= cap_nb && n <= cap_n) return MASP_HIP_OK;
         need_ent = std::max(need_ent, cap_ent);
-        need_sub = std::max(need_sub, cap_sub);
-        size_t need_n = std::max<size_t>(n, cap_n), need_nb = std::max<size_t>(g.nb, cap_nb);
+        size_t need_nb = std::max<size_t>(g.nb, cap_nb), need_n = std::max<size_t>(n, cap_n);
         release();
         cap_ent = need_ent;
-        cap_sub = need_sub;
-        cap_n = need_n;
         cap_nb = need_nb;
-        n = (uint32_t)need_n;
+        cap_n = need_n;
         size_t chunks = (cap_nb + (1u << CS_LOG) - 1) >> CS_LOG;
-        size_t rcap = std::max<size_t>(std::max<size_t>(chunks, (n + ONES_F - 1) / ONES_F), 1);
         HIP_TRY(hipMalloc(&ent, 4 * std::max<size_t>(cap_ent, 1)));
         HIP_TRY(hipMalloc(&sorted, 4 * std::max<size_t>(cap_ent, 1)));
-        HIP_TRY(hipMalloc(&hist, 4 * cap_sub));
-        HIP_TRY(hipMalloc(&start, 4 * cap_sub));
-        HIP_TRY(hipMalloc(&fill, 4 * cap_sub));
-        HIP_TRY(hipMalloc(&ones, 4 * std::max<size_t>(n, 1)));
+        HIP_TRY(hipMalloc(&hist, 4 * cap_nb));
+        HIP_TRY(hipMalloc(&start, 4 * (cap_nb + 1)));
+        HIP_TRY(hipMalloc(&fill, 4 * cap_nb));
+        HIP_TRY(hipMalloc(&heavy, 4 * cap_nb));
+        HIP_TRY(hipMalloc(&n_heavy, 4));
+        HIP_TRY(hipMalloc(&ones, 4 * std::max<size_t>(cap_n, 1)));
         HIP_TRY(hipMalloc(&n_ones, 4));
-        HIP_TRY(hipMalloc(&sub, sizeof(Xyzz<O>) * cap_sub));
-        HIP_TRY(hipMalloc(&bkt, sizeof(Xyzz<O>) * cap_nb));
-        HIP_TRY(hipMalloc(&S[0], sizeof(Xyzz<O>) * std::max(chunks, rcap)));
-        HIP_TRY(hipMalloc(&S[1], sizeof(Xyzz<O>) * std::max(chunks, rcap)));
-        HIP_TRY(hipMalloc(&T, sizeof(Xyzz<O>) * chunks));
-        HIP_TRY(hipMalloc(&R[0], sizeof(Xyzz<O>) * rcap));
-        HIP_TRY(hipMalloc(&R[1], sizeof(Xyzz<O>) * rcap));
-        HIP_TRY(hipMalloc(&tsum, sizeof(Xyzz<O>) * 32));
+        HIP_TRY(hipMalloc(&ones_part, sizeof(Xyzz<O>) * 256));
         HIP_TRY(hipMalloc(&ones_sum, sizeof(Xyzz<O>)));
+        HIP_TRY(hipMalloc(&part, sizeof(Xyzz<O>) * ((size_t)NCHUNKS + cap_nb)));
+        HIP_TRY(hipMalloc(&bkt, sizeof(Xyzz<O>) * cap_nb));
+        HIP_TRY(hipMalloc(&S[0], sizeof(Xyzz<O>) * chunks));
+        HIP_TRY(hipMalloc(&S[1], sizeof(Xyzz<O>) * chunks));
+        HIP_TRY(hipMalloc(&T, sizeof(Xyzz<O>) * chunks));
+        HIP_TRY(hipMalloc(&R[0], sizeof(Xyzz<O>) * chunks));
+        HIP_TRY(hipMalloc(&R[1], sizeof(Xyzz<O>) * chunks));
+        HIP_TRY(hipMalloc(&tsum, sizeof(Xyzz<O>) * 32));
         return MASP_HIP_OK;
     }
 
-    // reduce `m` points at `src` to one at `dst` (src is clobbered only if it is one of R[]).
+    // reduce `m` points at `src` to one at `dst` (src must not be one of R[]).
     // Workgroup tree reductions (fan-in 256, 8 dependent additions per pass).
     void reduce_to_one(hipStream_t s, const Xyzz<O>* src, uint32_t m, Xyzz<O>* dst) {
         int flip = 0;
@@ -209,13 +210,15 @@ int msm_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, MsmWorkspace<O>& ws,
             return MASP_HIP_E_HIP;
         }
     }
-    const uint32_t nsub = g.nsub();
+    const uint32_t nb = g.nb;
     const uint32_t total = n * g.W;
-    HIP_TRY(hipMemsetAsync(ws.hist, 0, 4 * (size_t)nsub, s));
-    HIP_TRY(hipMemsetAsync(ws.fill, 0, 4 * (size_t)nsub, s));
+    const uint32_t nchunks = ws.nchunks_for(n, g);
+    HIP_TRY(hipMemsetAsync(ws.hist, 0, 4 * (size_t)nb, s));
+    HIP_TRY(hipMemsetAsync(ws.fill, 0, 4 * (size_t)nb, s));
+    HIP_TRY(hipMemsetAsync(ws.n_heavy, 0, 4, s));
     HIP_TRY(hipMemsetAsync(ws.n_ones, 0, 4, s));
     hipLaunchKernelGGL(k_msm_digits, dim3((n + 255) / 256), dim3(256), 0, s, d_scalars, n, g, ws.ent, ws.hist, ws.ones, ws.n_ones);
-    hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, s, ws.hist, ws.start, nsub);
+    hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, s, ws.hist, ws.start, nb);
     hipLaunchKernelGGL(k_msm_scatter, dim3((total + 255) / 256), dim3(256), 0, s, ws.ent, total, n, ws.start, ws.fill, ws.sorted);
     MsmProfile::Rec rec{};
     if (prof) {
@@ -223,20 +226,18 @@ int msm_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, MsmWorkspace<O>& ws,
         rec.alg_bytes = (uint64_t)n * (BYTES + 32);  // n x (affine base + scalar)
         hipEventRecord(rec.e0, s);
     }
-    hipLaunchKernelGGL((k_msm_accumulate<O>), dim3((nsub + 63) / 64), dim3(64), 0, s, B.tab, ws.sorted, ws.start, ws.hist, nsub, ws.sub);
+    hipLaunchKernelGGL((k_msm_accumulate<O>), dim3((nchunks + 63) / 64), dim3(64), 0, s, B.tab, ws.sorted, ws.start, nb, nchunks, ws.part);
     if (prof) {
         hipEventRecord(rec.e1, s);
         prof->recs.push_back(rec);
     }
-    // sub-buckets -> buckets
-    const Xyzz<O>* bk = ws.sub;
-    if (g.sl_log) {
-        hipLaunchKernelGGL((k_xyzz_reduce<O>), dim3((g.nb + 63) / 64), dim3(64), 0, s, ws.sub, nsub, 1u << g.sl_log, ws.bkt);
-        bk = ws.bkt;
-    }
-    // weighted sum by levels of chunked running sums
+    hipLaunchKernelGGL((k_msm_bucket_gather<O>), dim3((nb + 63) / 64), dim3(64), 0, s, ws.part, ws.start, nb, nchunks, ws.bkt, ws.heavy, ws.n_heavy);
+    hipLaunchKernelGGL((k_msm_bucket_heavy<O>), dim3(ws.HEAVY_BLOCKS), dim3(64), 64 * sizeof(Xyzz<O>), s, ws.part, ws.start, nb, nchunks, ws.bkt,
+                       ws.heavy, ws.n_heavy);
+    // weighted sum by levels of 256-bucket workgroups
+    const Xyzz<O>* bk = ws.bkt;
     const uint32_t cs = 1u << ws.CS_LOG;
-    uint32_t m = g.nb, off = 1;
+    uint32_t m = nb, off = 1;
     int level = 0, flip = 0;
     do {
         uint32_t chunks = (m + cs - 1) / cs;
@@ -248,17 +249,9 @@ int msm_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, MsmWorkspace<O>& ws,
         off = 0;
         ++level;
     } while (m > 1);
-    // ones list
-    uint32_t ones_out = (n + ws.ONES_F - 1) / ws.ONES_F;
-    hipLaunchKernelGGL((k_msm_ones<O>), dim3((ones_out + 63) / 64), dim3(64), 0, s, B.tab, ws.ones, ws.n_ones, ws.ONES_F, ws.R[0], ones_out);
-    if (ones_out == 1) {
-        HIP_TRY(hipMemcpyAsync(ws.ones_sum, ws.R[0], sizeof(Xyzz<O>), hipMemcpyDeviceToDevice, s));
-    } else {
-        // R[0] is the source; reduce_to_one writes intermediate results to R[flip] starting with R[0]
-        // -> stage through S[flip] (free by now) to keep source and destination distinct
-        HIP_TRY(hipMemcpyAsync(ws.S[flip], ws.R[0], sizeof(Xyzz<O>) * ones_out, hipMemcpyDeviceToDevice, s));
-        ws.reduce_to_one(s, ws.S[flip], ones_out, ws.ones_sum);
-    }
+    // ones list: 256 waves, then one workgroup tree
+    hipLaunchKernelGGL((k_msm_ones<O>), dim3(256), dim3(64), 64 * sizeof(Xyzz<O>), s, B.tab, ws.ones, ws.n_ones, ws.ones_part);
+    hipLaunchKernelGGL((k_xyzz_reduce_block<O>), dim3(1), dim3(256), 256 * sizeof(Xyzz<O>), s, ws.ones_part, 256u, ws.ones_sum);
     hipLaunchKernelGGL((k_msm_combine<O>), dim3(1), dim3(64), 0, s, ws.tsum, level, (int)ws.CS_LOG, ws.ones_sum, d_out);
     return MASP_HIP_OK;
 }
