@@ -106,7 +106,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # let independent proofs' kernels overlap (ROCm default: 4)
-    os.environ.setdefault("MASP_HIP_SLOTS", "16")
+    os.environ.setdefault("MASP_HIP_SLOTS", "3")
+    os.environ.setdefault("MASP_HIP_BATCH", "16")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -189,10 +190,10 @@ def main():
             "dtype": "u32 limbs (384-bit Fp / 255-bit Fr modular integers)", "data": "synthetic",
             "config": {"workload": "single %s proof per step (BASELINE.json configs[1]); %s + synthetic CRS from known toxic waste "
                                    "(NTT 2^%d, G1 MSMs %d/%d/%d/%d, G2 MSM %d), witness resident in HBM, "
-                                   "steps pipelined over %s HIP streams"
+                                   "batches of %s proofs per launch sequence on %s HIP streams"
                                    % (WORKLOAD, circuit_desc, cs.logm, (1 << cs.logm) - 1, cs.n_aux,
                                       synthetic.SHAPES[WORKLOAD][3] + cs.n_inputs, synthetic.SHAPES[WORKLOAD][4] + 1,
-                                      synthetic.SHAPES[WORKLOAD][4] + 1, os.environ.get("MASP_HIP_SLOTS", "4")),
+                                      synthetic.SHAPES[WORKLOAD][4] + 1, os.environ.get("MASP_HIP_BATCH"), os.environ.get("MASP_HIP_SLOTS")),
                        "proofs_per_gpu": K, "parallelism": "proofs sharded over %d GPU(s), RCCL gather of proofs" % world},
             "single_proof_latency_ms": latency_ms,
             "gpu_event_ms_per_step": gpu_ms / K,

@@ -13,9 +13,11 @@
 namespace masp {
 
 // canonical -> Montgomery, n elements; flags any value >= r
-__global__ void k_fr_to_mont(const Fr* __restrict__ x, Fr* __restrict__ y, uint32_t n, int* __restrict__ range_err) {
+__global__ void k_fr_to_mont(const Fr* __restrict__ x, size_t x_stride, Fr* __restrict__ y, uint32_t n, int* __restrict__ range_err) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
+    x += blockIdx.y * x_stride;
+    y += (size_t)blockIdx.y * n;
     Fr v = fr_load(x + k);
     if (fe_canonical_ge_mod(v)) atomicOr(range_err, 1);
     fr_store(y + k, fe_to_mont(v));
@@ -25,9 +27,12 @@ __global__ void k_fr_to_mont(const Fr* __restrict__ x, Fr* __restrict__ y, uint3
 // n_constraints .. n_constraints + n_inputs - 1 are bellperson's extra "Input(i) * 0 = 0" rows:
 // a = input value, b = c = 0 (which == 0 selects matrix A).
 __global__ void k_r1cs_eval(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, const Fr* __restrict__ coef,
-                            const Fr* __restrict__ w, uint32_t n_constraints, uint32_t n_inputs, int which, Fr* __restrict__ out) {
+                            const Fr* __restrict__ w, uint32_t n_vars, uint32_t n_constraints, uint32_t n_inputs, int which,
+                            Fr* __restrict__ out) {
     uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_constraints + n_inputs) return;
+    w += (size_t)blockIdx.y * n_vars;
+    out += (size_t)blockIdx.y * (n_constraints + n_inputs);
     Fr acc = fe_zero<FrCfg>();
     if (row < n_constraints) {
         uint32_t lo = rowptr[row], hi = rowptr[row + 1];
@@ -39,9 +44,12 @@ __global__ void k_r1cs_eval(const uint32_t* __restrict__ rowptr, const uint32_t*
 }
 
 // dst[k] = src[idx[k]]  (32-byte scalars)
-__global__ void k_gather_scalars(const Fr* __restrict__ src, const uint32_t* __restrict__ idx, uint32_t n, Fr* __restrict__ dst) {
+__global__ void k_gather_scalars(const Fr* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ idx, uint32_t n,
+                                 Fr* __restrict__ dst) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
+    src += blockIdx.y * src_stride;
+    dst += (size_t)blockIdx.y * n;
     fr_store(dst + k, fr_load(src + idx[k]));
 }
 
@@ -88,11 +96,15 @@ __device__ __forceinline__ Xyzz<O> xyzz_fixed_mul(const Xyzz<O>* __restrict__ ta
 // fb1: tables of delta1, alpha1, beta1 (in that order); fb2: table of delta2.
 __global__ void __launch_bounds__(192) k_groth16_assemble(const VkDevice* __restrict__ vk, const G1Xyzz* __restrict__ fb1,
                                                           const G2Xyzz* __restrict__ fb2, const G1Xyzz* __restrict__ msm_g1 /* H, L, A, B1 */,
-                                                          const G2Xyzz* __restrict__ msm_g2, const uint32_t* __restrict__ rs,
+                                                          const G2Xyzz* __restrict__ msm_g2, const uint32_t* __restrict__ rs, size_t rs_stride,
                                                           uint8_t* __restrict__ proof) {
     __shared__ G1Xyzz part[6];
     __shared__ G2Xyzz part2;
     const uint32_t tid = threadIdx.x;
+    msm_g1 += (size_t)blockIdx.x * 4;  // one workgroup per proof of the batch
+    msm_g2 += blockIdx.x;
+    rs += (size_t)blockIdx.x * rs_stride;
+    proof += (size_t)blockIdx.x * 192;
     Fr r, s;
     for (int i = 0; i < 8; ++i) {
         r.v[i] = rs[i];

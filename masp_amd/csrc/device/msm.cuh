@@ -45,6 +45,11 @@ static inline MsmGeom msm_geom(int c) {
 
 static constexpr uint32_t ENT_NONE = 0xffffffffu;
 
+// Every prove-time kernel below is launched with gridDim.y = number of proofs in the batch: proof p works on
+// `ptr + p * stride` of each per-proof array (the window tables are shared).  One launch per stage for the whole
+// batch keeps the latency-bound reduction stages wide enough to fill the chip.
+#define MSM_P (blockIdx.y)
+
 // ---- load time ----------------------------------------------------------------------------------
 // raw uncompressed bytes -> T[0][i]; status word collects PT_* bits (infinity is legal in a generic
 // MSM and contributes nothing).
@@ -83,10 +88,16 @@ __global__ void k_msm_precompute(Affine<O>* __restrict__ tab, uint32_t n, int c,
 
 // ---- (1) digits ---------------------------------------------------------------------------------
 // scalars: n x 8 canonical little-endian limbs.  ent[j*n + i] = bucket | sign<<31, or ENT_NONE.
-__global__ void k_msm_digits(const uint32_t* __restrict__ scalars, uint32_t n, MsmGeom g, uint32_t* __restrict__ ent,
-                             uint32_t* __restrict__ hist, uint32_t* __restrict__ ones, uint32_t* __restrict__ n_ones) {
+__global__ void k_msm_digits(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32_t n, MsmGeom g,
+                             uint32_t* __restrict__ ent, uint32_t* __restrict__ hist, uint32_t* __restrict__ ones,
+                             uint32_t* __restrict__ n_ones) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    scalars += MSM_P * scalar_stride;
+    ent += (size_t)MSM_P * n * g.W;
+    hist += (size_t)MSM_P * g.nb;
+    ones += (size_t)MSM_P * n;
+    n_ones += MSM_P;
     const uint32_t* sw = scalars + (size_t)i * 8;
     const uint4* sp = reinterpret_cast<const uint4*>(sw);
     uint4 lo = sp[0], hi = sp[1];
@@ -127,6 +138,8 @@ __global__ void k_msm_digits(const uint32_t* __restrict__ scalars, uint32_t n, M
 __global__ void k_scan_exclusive(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n) {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t base;
+    in += (size_t)MSM_P * n;
+    out += (size_t)MSM_P * (n + 1);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (tid == 0) base = 0;
     __syncthreads();
@@ -153,10 +166,14 @@ __global__ void k_scan_exclusive(const uint32_t* __restrict__ in, uint32_t* __re
 }
 
 // ---- (3) scatter --------------------------------------------------------------------------------
-__global__ void k_msm_scatter(const uint32_t* __restrict__ ent, uint32_t total, uint32_t n, const uint32_t* __restrict__ start,
+__global__ void k_msm_scatter(const uint32_t* __restrict__ ent, uint32_t total, uint32_t nb, const uint32_t* __restrict__ start,
                               uint32_t* __restrict__ fill, uint32_t* __restrict__ sorted) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
+    ent += (size_t)MSM_P * total;
+    sorted += (size_t)MSM_P * total;
+    start += (size_t)MSM_P * (nb + 1);
+    fill += (size_t)MSM_P * nb;
     uint32_t e = ent[t];
     if (e == ENT_NONE) return;
     uint32_t key = e & 0x7fffffffu;
@@ -175,10 +192,13 @@ __device__ __forceinline__ uint32_t msm_chunk_len(uint32_t total, uint32_t nchun
 }
 template <class O>
 __global__ void __launch_bounds__(64)
-k_msm_accumulate(const Affine<O>* __restrict__ tab, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ start, uint32_t nb,
-                 uint32_t nchunks, Xyzz<O>* __restrict__ part) {
+k_msm_accumulate(const Affine<O>* __restrict__ tab, const uint32_t* __restrict__ sorted, size_t ent_stride,
+                 const uint32_t* __restrict__ start, uint32_t nb, uint32_t nchunks, Xyzz<O>* __restrict__ part) {
     const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= nchunks) return;
+    sorted += MSM_P * ent_stride;
+    start += (size_t)MSM_P * (nb + 1);
+    part += (size_t)MSM_P * ((size_t)nchunks + nb);
     const uint32_t total = start[nb];
     const uint32_t K = msm_chunk_len(total, nchunks);
     const uint32_t lo = ch * K;
@@ -216,6 +236,11 @@ k_msm_bucket_gather(const Xyzz<O>* __restrict__ part, const uint32_t* __restrict
                     Xyzz<O>* __restrict__ bkt, uint32_t* __restrict__ heavy, uint32_t* __restrict__ n_heavy) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
+    part += (size_t)MSM_P * ((size_t)nchunks + nb);
+    start += (size_t)MSM_P * (nb + 1);
+    bkt += (size_t)MSM_P * nb;
+    heavy += (size_t)MSM_P * nb;
+    n_heavy += MSM_P;
     const uint32_t s0 = start[b], s1 = start[b + 1];
     Xyzz<O> acc = xyzz_inf<O>();
     if (s1 > s0) {
@@ -237,6 +262,11 @@ k_msm_bucket_heavy(const Xyzz<O>* __restrict__ part, const uint32_t* __restrict_
     extern __shared__ uint4 wsum_lds[];
     Xyzz<O>* sh = reinterpret_cast<Xyzz<O>*>(wsum_lds);
     const uint32_t lane = threadIdx.x;
+    part += (size_t)MSM_P * ((size_t)nchunks + nb);
+    start += (size_t)MSM_P * (nb + 1);
+    bkt += (size_t)MSM_P * nb;
+    heavy += (size_t)MSM_P * nb;
+    n_heavy += MSM_P;
     const uint32_t nh = *n_heavy;
     const uint32_t K = msm_chunk_len(start[nb], nchunks);
     for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
@@ -257,12 +287,14 @@ k_msm_bucket_heavy(const Xyzz<O>* __restrict__ part, const uint32_t* __restrict_
 // ones list: 256 workgroups of one wave; lane g adds tab[ones[g]], tab[ones[g + 16384]], ... then an LDS tree
 template <class O>
 __global__ void __launch_bounds__(64)
-k_msm_ones(const Affine<O>* __restrict__ tab, const uint32_t* __restrict__ ones, const uint32_t* __restrict__ n_ones,
+k_msm_ones(const Affine<O>* __restrict__ tab, const uint32_t* __restrict__ ones, size_t ones_stride, const uint32_t* __restrict__ n_ones,
            Xyzz<O>* __restrict__ out) {
     extern __shared__ uint4 wsum_lds[];
     Xyzz<O>* sh = reinterpret_cast<Xyzz<O>*>(wsum_lds);
     const uint32_t lane = threadIdx.x;
-    const uint32_t n = *n_ones;
+    ones += MSM_P * ones_stride;
+    out += (size_t)MSM_P * gridDim.x;
+    const uint32_t n = n_ones[MSM_P];
     Xyzz<O> acc = xyzz_inf<O>();
     for (uint32_t k = blockIdx.x * 64 + lane; k < n; k += gridDim.x * 64) xyzz_madd_nc(acc, tab[ones[k]], false);
     for (uint32_t d = 32; d >= 1; d >>= 1) {
@@ -283,11 +315,14 @@ k_msm_ones(const Affine<O>* __restrict__ tab, const uint32_t* __restrict__ ones,
 static constexpr uint32_t WSUM_CS_LOG = 8;
 static constexpr uint32_t WSUM_CS = 1u << WSUM_CS_LOG;
 template <class O>
-__global__ void __launch_bounds__(256) k_msm_wsum_level(const Xyzz<O>* __restrict__ B, uint32_t m, uint32_t off,
-                                                        Xyzz<O>* __restrict__ S, Xyzz<O>* __restrict__ T) {
+__global__ void __launch_bounds__(256) k_msm_wsum_level(const Xyzz<O>* __restrict__ B, size_t b_stride, uint32_t m, uint32_t off,
+                                                        Xyzz<O>* __restrict__ S, Xyzz<O>* __restrict__ T, size_t st_stride) {
     extern __shared__ uint4 wsum_lds[];
     Xyzz<O>* sh = reinterpret_cast<Xyzz<O>*>(wsum_lds);
     const uint32_t tid = threadIdx.x;
+    B += MSM_P * b_stride;
+    S += MSM_P * st_stride;
+    T += MSM_P * st_stride;
     const uint32_t k = blockIdx.x * WSUM_CS + tid;
     Xyzz<O> x = k < m ? B[k] : xyzz_inf<O>();
     // inclusive suffix scan: x_i = sum_{j >= i} B_j over the chunk
@@ -312,10 +347,13 @@ __global__ void __launch_bounds__(256) k_msm_wsum_level(const Xyzz<O>* __restric
 }
 // out[b] = sum of in[b*256 .. min(n, b*256+256)) by an LDS tree (8 dependent additions)
 template <class O>
-__global__ void __launch_bounds__(256) k_xyzz_reduce_block(const Xyzz<O>* __restrict__ in, uint32_t n, Xyzz<O>* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_xyzz_reduce_block(const Xyzz<O>* __restrict__ in, size_t in_stride, uint32_t n,
+                                                           Xyzz<O>* __restrict__ out, size_t out_stride) {
     extern __shared__ uint4 wsum_lds[];
     Xyzz<O>* sh = reinterpret_cast<Xyzz<O>*>(wsum_lds);
     const uint32_t tid = threadIdx.x;
+    in += MSM_P * in_stride;
+    out += MSM_P * out_stride;
     const uint32_t k = blockIdx.x * 256 + tid;
     Xyzz<O> y = k < n ? in[k] : xyzz_inf<O>();
     for (uint32_t d = 128; d >= 1; d >>= 1) {
@@ -329,8 +367,11 @@ __global__ void __launch_bounds__(256) k_xyzz_reduce_block(const Xyzz<O>* __rest
 // V = T0 + cs*(T1 + cs*(T2 + ...)) + ones ;  tsum[l] holds the fully reduced T of level l.
 template <class O>
 __global__ void k_msm_combine(const Xyzz<O>* __restrict__ tsum, int levels, int cs_log, const Xyzz<O>* __restrict__ ones_sum,
-                              Xyzz<O>* __restrict__ out) {
+                              Xyzz<O>* __restrict__ out, size_t out_stride) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    tsum += (size_t)MSM_P * 32;
+    ones_sum += MSM_P;
+    out += MSM_P * out_stride;
     Xyzz<O> acc = xyzz_inf<O>();
     for (int l = levels - 1; l >= 0; --l) {
         for (int k = 0; k < cs_log; ++k) acc = xyzz_dbl(acc);

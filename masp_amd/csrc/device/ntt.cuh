@@ -44,19 +44,26 @@ __global__ void k_fr_powers(Fr* __restrict__ table, uint32_t n, Fr base, Fr scal
     fr_store(table + k, r);
 }
 
+// Prove-time kernels take gridDim.y = proofs in the batch; proof p uses `ptr + p * stride` (strides in elements).
+#define NTT_P (blockIdx.y)
+
 // ---- bit-reversal passes with fused pointwise work ------------------------------------------------
 // y[rev(k)] = to_mont(x[k]) for k < nrows, 0 above   (x canonical little-endian limbs)
-__global__ void k_ntt_load_bitrev(const Fr* __restrict__ x, uint32_t nrows, Fr* __restrict__ y, uint32_t logm) {
+__global__ void k_ntt_load_bitrev(const Fr* __restrict__ x, size_t x_stride, uint32_t nrows, Fr* __restrict__ y, uint32_t logm) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= (1u << logm)) return;
+    x += NTT_P * x_stride;
+    y += (size_t)NTT_P << logm;
     Fr v = fe_zero<FrCfg>();
     if (k < nrows) v = fe_to_mont(fr_load(x + k));
     fr_store(y + bitrev(k, logm), v);
 }
 // same but the input is already in Montgomery form
-__global__ void k_ntt_copy_bitrev(const Fr* __restrict__ x, uint32_t nrows, Fr* __restrict__ y, uint32_t logm) {
+__global__ void k_ntt_copy_bitrev(const Fr* __restrict__ x, size_t x_stride, uint32_t nrows, Fr* __restrict__ y, uint32_t logm) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= (1u << logm)) return;
+    x += NTT_P * x_stride;
+    y += (size_t)NTT_P << logm;
     Fr v = fe_zero<FrCfg>();
     if (k < nrows) v = fr_load(x + k);
     fr_store(y + bitrev(k, logm), v);
@@ -65,6 +72,8 @@ __global__ void k_ntt_copy_bitrev(const Fr* __restrict__ x, uint32_t nrows, Fr* 
 __global__ void k_ntt_scale_bitrev(const Fr* __restrict__ x, const Fr* __restrict__ scale, Fr* __restrict__ y, uint32_t logm) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= (1u << logm)) return;
+    x += (size_t)NTT_P << logm;
+    y += (size_t)NTT_P << logm;
     fr_store(y + bitrev(k, logm), fe_mul(fr_load(x + k), fr_load(scale + k)));
 }
 // y[rev(k)] = (a[k] * b[k] - c[k]) * zinv
@@ -72,6 +81,10 @@ __global__ void k_ntt_abc_bitrev(const Fr* __restrict__ a, const Fr* __restrict_
                                  Fr* __restrict__ y, uint32_t logm) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= (1u << logm)) return;
+    a += (size_t)NTT_P << logm;
+    b += (size_t)NTT_P << logm;
+    c += (size_t)NTT_P << logm;
+    y += (size_t)NTT_P << logm;
     Fr v = fe_mul(fe_sub(fe_mul(fr_load(a + k), fr_load(b + k)), fr_load(c + k)), zinv);
     fr_store(y + bitrev(k, logm), v);
 }
@@ -79,6 +92,8 @@ __global__ void k_ntt_abc_bitrev(const Fr* __restrict__ a, const Fr* __restrict_
 __global__ void k_fr_scale(const Fr* __restrict__ x, const Fr* __restrict__ scale, Fr* __restrict__ y, uint32_t n) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
+    x += (size_t)NTT_P * n;
+    y += (size_t)NTT_P * n;
     fr_store(y + k, fe_mul(fr_load(x + k), fr_load(scale + k)));
 }
 __global__ void k_fr_from_mont(const Fr* __restrict__ x, Fr* __restrict__ y, uint32_t n) {
@@ -100,6 +115,7 @@ __global__ void __launch_bounds__(256) k_ntt_pass(Fr* __restrict__ data, const F
     const uint32_t tsize = 1u << lt;
     const uint32_t col0 = blockIdx.x << cols_log;
     const uint32_t lomask = (1u << s0) - 1u;
+    data += (size_t)NTT_P << logm;
     // load
     for (uint32_t L = threadIdx.x; L < tsize; L += blockDim.x) {
         uint32_t h = L >> cols_log, col = col0 + (L & (cols - 1));

@@ -68,7 +68,7 @@ struct MsmWorkspace {
     static constexpr uint32_t NCHUNKS = 1u << 18;     // lanes of the accumulation kernel (1024 waves x 4 per SIMD)
     static constexpr uint32_t HEAVY_BLOCKS = 256;
 
-    size_t cap_ent = 0, cap_nb = 0;
+    size_t cap_ent = 0, cap_nb = 0, cap_np = 0;
     uint32_t *ent = nullptr, *sorted = nullptr, *hist = nullptr, *start = nullptr, *fill = nullptr;
     uint32_t *heavy = nullptr, *n_heavy = nullptr, *ones = nullptr, *n_ones = nullptr;
     size_t cap_n = 0;
@@ -82,55 +82,62 @@ struct MsmWorkspace {
             if (p) hipFree(p);
         ent = sorted = hist = start = fill = heavy = n_heavy = ones = n_ones = nullptr;
         part = bkt = S[0] = S[1] = T = R[0] = R[1] = tsum = ones_part = ones_sum = nullptr;
-        cap_ent = cap_nb = cap_n = 0;
+        cap_ent = cap_nb = cap_n = cap_np = 0;
     }
     static uint32_t nchunks_for(uint32_t n, const MsmGeom& g) {
         uint64_t ent = (uint64_t)n * g.W;
         return (uint32_t)std::min<uint64_t>(NCHUNKS, std::max<uint64_t>(ent, 1));
     }
-    int reserve(uint32_t n, const MsmGeom& g) {
+    // room for `np` proofs of an n-point MSM with geometry g (every per-proof array is np-fold)
+    int reserve(uint32_t n, const MsmGeom& g, uint32_t np) {
         size_t need_ent = (size_t)n * g.W;
-        if (need_ent <= cap_ent && (size_t)g.nb <= cap_nb && n <= cap_n) return MASP_HIP_OK;
+        if (need_ent <= cap_ent && (size_t)g.nb <= cap_nb && n <= cap_n && np <= cap_np) return MASP_HIP_OK;
         need_ent = std::max(need_ent, cap_ent);
-        size_t need_nb = std::max<size_t>(g.nb, cap_nb), need_n = std::max<size_t>(n, cap_n);
+        size_t need_nb = std::max<size_t>(g.nb, cap_nb), need_n = std::max<size_t>(n, cap_n), need_np = std::max<size_t>(np, cap_np);
         release();
         cap_ent = need_ent;
         cap_nb = need_nb;
         cap_n = need_n;
+        cap_np = need_np;
+        const size_t P = cap_np;
         size_t chunks = (cap_nb + (1u << CS_LOG) - 1) >> CS_LOG;
-        HIP_TRY(hipMalloc(&ent, 4 * std::max<size_t>(cap_ent, 1)));
-        HIP_TRY(hipMalloc(&sorted, 4 * std::max<size_t>(cap_ent, 1)));
-        HIP_TRY(hipMalloc(&hist, 4 * cap_nb));
-        HIP_TRY(hipMalloc(&start, 4 * (cap_nb + 1)));
-        HIP_TRY(hipMalloc(&fill, 4 * cap_nb));
-        HIP_TRY(hipMalloc(&heavy, 4 * cap_nb));
-        HIP_TRY(hipMalloc(&n_heavy, 4));
-        HIP_TRY(hipMalloc(&ones, 4 * std::max<size_t>(cap_n, 1)));
-        HIP_TRY(hipMalloc(&n_ones, 4));
-        HIP_TRY(hipMalloc(&ones_part, sizeof(Xyzz<O>) * 256));
-        HIP_TRY(hipMalloc(&ones_sum, sizeof(Xyzz<O>)));
-        HIP_TRY(hipMalloc(&part, sizeof(Xyzz<O>) * ((size_t)NCHUNKS + cap_nb)));
-        HIP_TRY(hipMalloc(&bkt, sizeof(Xyzz<O>) * cap_nb));
-        HIP_TRY(hipMalloc(&S[0], sizeof(Xyzz<O>) * chunks));
-        HIP_TRY(hipMalloc(&S[1], sizeof(Xyzz<O>) * chunks));
-        HIP_TRY(hipMalloc(&T, sizeof(Xyzz<O>) * chunks));
-        HIP_TRY(hipMalloc(&R[0], sizeof(Xyzz<O>) * chunks));
-        HIP_TRY(hipMalloc(&R[1], sizeof(Xyzz<O>) * chunks));
-        HIP_TRY(hipMalloc(&tsum, sizeof(Xyzz<O>) * 32));
+        HIP_TRY(hipMalloc(&ent, P * 4 * std::max<size_t>(cap_ent, 1)));
+        HIP_TRY(hipMalloc(&sorted, P * 4 * std::max<size_t>(cap_ent, 1)));
+        HIP_TRY(hipMalloc(&hist, P * 4 * cap_nb));
+        HIP_TRY(hipMalloc(&start, P * 4 * (cap_nb + 1)));
+        HIP_TRY(hipMalloc(&fill, P * 4 * cap_nb));
+        HIP_TRY(hipMalloc(&heavy, P * 4 * cap_nb));
+        HIP_TRY(hipMalloc(&n_heavy, P * 4));
+        HIP_TRY(hipMalloc(&ones, P * 4 * std::max<size_t>(cap_n, 1)));
+        HIP_TRY(hipMalloc(&n_ones, P * 4));
+        HIP_TRY(hipMalloc(&ones_part, P * sizeof(Xyzz<O>) * 256));
+        HIP_TRY(hipMalloc(&ones_sum, P * sizeof(Xyzz<O>)));
+        HIP_TRY(hipMalloc(&part, P * sizeof(Xyzz<O>) * ((size_t)NCHUNKS + cap_nb)));
+        HIP_TRY(hipMalloc(&bkt, P * sizeof(Xyzz<O>) * cap_nb));
+        HIP_TRY(hipMalloc(&S[0], P * sizeof(Xyzz<O>) * chunks));
+        HIP_TRY(hipMalloc(&S[1], P * sizeof(Xyzz<O>) * chunks));
+        HIP_TRY(hipMalloc(&T, P * sizeof(Xyzz<O>) * chunks));
+        HIP_TRY(hipMalloc(&R[0], P * sizeof(Xyzz<O>) * chunks));
+        HIP_TRY(hipMalloc(&R[1], P * sizeof(Xyzz<O>) * chunks));
+        HIP_TRY(hipMalloc(&tsum, P * sizeof(Xyzz<O>) * 32));
         return MASP_HIP_OK;
     }
 
-    // reduce `m` points at `src` to one at `dst` (src must not be one of R[]).
+    // per proof: reduce the `m` points at `src + p*src_stride` to one at `dst + p*dst_stride` (src must not be R[]).
     // Workgroup tree reductions (fan-in 256, 8 dependent additions per pass).
-    void reduce_to_one(hipStream_t s, const Xyzz<O>* src, uint32_t m, Xyzz<O>* dst) {
+    void reduce_to_one(hipStream_t s, uint32_t np, const Xyzz<O>* src, size_t src_stride, uint32_t m, Xyzz<O>* dst, size_t dst_stride,
+                       size_t r_stride) {
         int flip = 0;
         const Xyzz<O>* cur = src;
+        size_t cur_stride = src_stride;
         while (true) {
             uint32_t outn = (m + 255) / 256;
             Xyzz<O>* out = outn == 1 ? dst : R[flip];
-            hipLaunchKernelGGL((k_xyzz_reduce_block<O>), dim3(outn), dim3(256), 256 * sizeof(Xyzz<O>), s, cur, m, out);
+            size_t out_stride = outn == 1 ? dst_stride : r_stride;
+            hipLaunchKernelGGL((k_xyzz_reduce_block<O>), dim3(outn, np), dim3(256), 256 * sizeof(Xyzz<O>), s, cur, cur_stride, m, out, out_stride);
             if (outn == 1) break;
             cur = out;
+            cur_stride = out_stride;
             m = outn;
             flip ^= 1;
         }
@@ -184,18 +191,20 @@ struct MsmProfile {
     }
 };
 
-// Enqueue sum_i scalars[i] * P_i on stream `s`.  d_scalars: n x 8 canonical LE limbs on the device.
-// d_out: one XYZZ point on the device.  No host synchronisation.
+// Enqueue, for each of `np` proofs p, sum_i scalars_p[i] * P_i on stream `s` — one launch per stage for the whole batch.
+// scalars_p = d_scalars + p * scalar_stride (u32 units), n x 8 canonical LE limbs each; result p at d_out + p * out_stride.
+// No host synchronisation.
 template <class O, int BYTES>
-int msm_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, MsmWorkspace<O>& ws, const uint32_t* d_scalars, Xyzz<O>* d_out,
-                MsmProfile* prof = nullptr) {
+int msm_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, MsmWorkspace<O>& ws, const uint32_t* d_scalars, size_t scalar_stride,
+                Xyzz<O>* d_out, size_t out_stride, uint32_t np, MsmProfile* prof = nullptr) {
     const MsmGeom& g = B.g;
     const uint32_t n = B.n;
+    if (np == 0) return MASP_HIP_OK;
     if (n == 0) {
-        HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(Xyzz<O>), s));  // all-zero limbs = infinity (ZZ = 0)
+        for (uint32_t p = 0; p < np; ++p) HIP_TRY(hipMemsetAsync(d_out + p * out_stride, 0, sizeof(Xyzz<O>), s));  // infinity (ZZ = 0)
         return MASP_HIP_OK;
     }
-    int rc = ws.reserve(n, g);
+    int rc = ws.reserve(n, g, np);
     if (rc) return rc;
     {
         // the LDS tree kernels keep 256 XYZZ points per workgroup: 48 KiB (G1) / 96 KiB (G2) of the 160 KiB LDS
@@ -213,46 +222,56 @@ int msm_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, MsmWorkspace<O>& ws,
     const uint32_t nb = g.nb;
     const uint32_t total = n * g.W;
     const uint32_t nchunks = ws.nchunks_for(n, g);
-    HIP_TRY(hipMemsetAsync(ws.hist, 0, 4 * (size_t)nb, s));
-    HIP_TRY(hipMemsetAsync(ws.fill, 0, 4 * (size_t)nb, s));
-    HIP_TRY(hipMemsetAsync(ws.n_heavy, 0, 4, s));
-    HIP_TRY(hipMemsetAsync(ws.n_ones, 0, 4, s));
-    hipLaunchKernelGGL(k_msm_digits, dim3((n + 255) / 256), dim3(256), 0, s, d_scalars, n, g, ws.ent, ws.hist, ws.ones, ws.n_ones);
-    hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, s, ws.hist, ws.start, nb);
-    hipLaunchKernelGGL(k_msm_scatter, dim3((total + 255) / 256), dim3(256), 0, s, ws.ent, total, n, ws.start, ws.fill, ws.sorted);
+    const size_t part_stride = (size_t)nchunks + nb;
+    (void)part_stride;
+    HIP_TRY(hipMemsetAsync(ws.hist, 0, 4 * (size_t)nb * np, s));
+    HIP_TRY(hipMemsetAsync(ws.fill, 0, 4 * (size_t)nb * np, s));
+    HIP_TRY(hipMemsetAsync(ws.n_heavy, 0, 4 * np, s));
+    HIP_TRY(hipMemsetAsync(ws.n_ones, 0, 4 * np, s));
+    hipLaunchKernelGGL(k_msm_digits, dim3((n + 255) / 256, np), dim3(256), 0, s, d_scalars, scalar_stride, n, g, ws.ent, ws.hist, ws.ones,
+                       ws.n_ones);
+    hipLaunchKernelGGL(k_scan_exclusive, dim3(1, np), dim3(1024), 0, s, ws.hist, ws.start, nb);
+    hipLaunchKernelGGL(k_msm_scatter, dim3((total + 255) / 256, np), dim3(256), 0, s, ws.ent, total, nb, ws.start, ws.fill, ws.sorted);
     MsmProfile::Rec rec{};
     if (prof) {
         rec = prof->acquire();
-        rec.alg_bytes = (uint64_t)n * (BYTES + 32);  // n x (affine base + scalar)
+        rec.alg_bytes = (uint64_t)np * n * (BYTES + 32);  // n x (affine base + scalar) per proof
         hipEventRecord(rec.e0, s);
     }
-    hipLaunchKernelGGL((k_msm_accumulate<O>), dim3((nchunks + 63) / 64), dim3(64), 0, s, B.tab, ws.sorted, ws.start, nb, nchunks, ws.part);
+    hipLaunchKernelGGL((k_msm_accumulate<O>), dim3((nchunks + 63) / 64, np), dim3(64), 0, s, B.tab, ws.sorted, (size_t)total, ws.start, nb,
+                       nchunks, ws.part);
     if (prof) {
         hipEventRecord(rec.e1, s);
         prof->recs.push_back(rec);
     }
-    hipLaunchKernelGGL((k_msm_bucket_gather<O>), dim3((nb + 63) / 64), dim3(64), 0, s, ws.part, ws.start, nb, nchunks, ws.bkt, ws.heavy, ws.n_heavy);
-    hipLaunchKernelGGL((k_msm_bucket_heavy<O>), dim3(ws.HEAVY_BLOCKS), dim3(64), 64 * sizeof(Xyzz<O>), s, ws.part, ws.start, nb, nchunks, ws.bkt,
-                       ws.heavy, ws.n_heavy);
+    hipLaunchKernelGGL((k_msm_bucket_gather<O>), dim3((nb + 63) / 64, np), dim3(64), 0, s, ws.part, ws.start, nb, nchunks, ws.bkt, ws.heavy,
+                       ws.n_heavy);
+    hipLaunchKernelGGL((k_msm_bucket_heavy<O>), dim3(ws.HEAVY_BLOCKS, np), dim3(64), 64 * sizeof(Xyzz<O>), s, ws.part, ws.start, nb, nchunks,
+                       ws.bkt, ws.heavy, ws.n_heavy);
     // weighted sum by levels of 256-bucket workgroups
-    const Xyzz<O>* bk = ws.bkt;
     const uint32_t cs = 1u << ws.CS_LOG;
+    const size_t st_stride = (nb + cs - 1) / cs;  // level-0 chunk count bounds every later level
+    const Xyzz<O>* bk = ws.bkt;
+    size_t bk_stride = nb;
     uint32_t m = nb, off = 1;
     int level = 0, flip = 0;
     do {
         uint32_t chunks = (m + cs - 1) / cs;
-        hipLaunchKernelGGL((k_msm_wsum_level<O>), dim3(chunks), dim3(256), 256 * sizeof(Xyzz<O>), s, bk, m, off, ws.S[flip], ws.T);
-        ws.reduce_to_one(s, ws.T, chunks, ws.tsum + level);
+        hipLaunchKernelGGL((k_msm_wsum_level<O>), dim3(chunks, np), dim3(256), 256 * sizeof(Xyzz<O>), s, bk, bk_stride, m, off, ws.S[flip],
+                           ws.T, st_stride);
+        ws.reduce_to_one(s, np, ws.T, st_stride, chunks, ws.tsum + level, 32, st_stride);
         bk = ws.S[flip];
+        bk_stride = st_stride;
         flip ^= 1;
         m = chunks;
         off = 0;
         ++level;
     } while (m > 1);
-    // ones list: 256 waves, then one workgroup tree
-    hipLaunchKernelGGL((k_msm_ones<O>), dim3(256), dim3(64), 64 * sizeof(Xyzz<O>), s, B.tab, ws.ones, ws.n_ones, ws.ones_part);
-    hipLaunchKernelGGL((k_xyzz_reduce_block<O>), dim3(1), dim3(256), 256 * sizeof(Xyzz<O>), s, ws.ones_part, 256u, ws.ones_sum);
-    hipLaunchKernelGGL((k_msm_combine<O>), dim3(1), dim3(64), 0, s, ws.tsum, level, (int)ws.CS_LOG, ws.ones_sum, d_out);
+    // ones list: 256 waves per proof, then one workgroup tree
+    hipLaunchKernelGGL((k_msm_ones<O>), dim3(256, np), dim3(64), 64 * sizeof(Xyzz<O>), s, B.tab, ws.ones, (size_t)n, ws.n_ones, ws.ones_part);
+    hipLaunchKernelGGL((k_xyzz_reduce_block<O>), dim3(1, np), dim3(256), 256 * sizeof(Xyzz<O>), s, ws.ones_part, (size_t)256, 256u, ws.ones_sum,
+                       (size_t)1);
+    hipLaunchKernelGGL((k_msm_combine<O>), dim3(1, np), dim3(64), 0, s, ws.tsum, level, (int)ws.CS_LOG, ws.ones_sum, d_out, out_stride);
     return MASP_HIP_OK;
 }
 

@@ -92,12 +92,13 @@ struct NttDomain {
         HIP_TRY(hipStreamSynchronize(s));
         return MASP_HIP_OK;
     }
-    void passes(hipStream_t s, Fr* data, const Fr* tw) const {
+    // np transforms at data + p * m
+    void passes(hipStream_t s, Fr* data, const Fr* tw, uint32_t np = 1) const {
         uint32_t lt = std::min<uint32_t>(NTT_LT, logm);
         uint32_t tiles = (uint32_t)(m >> lt);
         for (uint32_t s0 = 0; s0 < logm;) {
             uint32_t nst = std::min<uint32_t>(NTT_LT, logm - s0);
-            hipLaunchKernelGGL(k_ntt_pass, dim3(tiles), dim3(256), 0, s, data, tw, logm, s0, nst);
+            hipLaunchKernelGGL(k_ntt_pass, dim3(tiles, np), dim3(256), 0, s, data, tw, logm, s0, nst);
             s0 += nst;
         }
     }
@@ -118,13 +119,14 @@ struct Circuit {
     NttDomain* dom = nullptr;
 };
 
-// per-proof scratch + a stream: several slots let independent proofs overlap on the device
+// scratch for one batch of up to `batch_cap()` proofs of the same circuit + a stream.  Every stage is ONE launch for the
+// whole batch (gridDim.y = proofs); a few slots let the stages of different batches overlap on the device.
 struct Slot {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     MsmWorkspace<FpOps> ws1;
     MsmWorkspace<Fp2Ops> ws2;
-    DevBuf<Fr> w, wm, ev[3], x0[3], x1[3], h, sa, sb;
+    DevBuf<Fr> w, abc, wm, ev[3], x0[3], x1[3], h, sa, sb;
     DevBuf<G1Xyzz> res1;
     DevBuf<G2Xyzz> res2;
     DevBuf<uint32_t> rs;
@@ -134,7 +136,8 @@ struct Slot {
     bool profiling = false;
     uint8_t* h_stage = nullptr;  // pinned staging for the assignment
     size_t h_stage_cap = 0;
-    uint8_t* h_proof = nullptr;  // pinned
+    uint8_t* h_proof = nullptr;  // pinned, batch_cap x 192
+    size_t h_proof_cap = 0;
     int* h_flags = nullptr;      // pinned
     ~Slot() {
         if (stream) hipStreamDestroy(stream);
@@ -146,10 +149,20 @@ struct Slot {
     int init() {
         HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
-        HIP_TRY(hipHostMalloc(&h_proof, 192));
         HIP_TRY(hipHostMalloc(&h_flags, sizeof(int)));
         int rc;
-        if ((rc = res1.reserve(4)) || (rc = res2.reserve(1)) || (rc = rs.reserve(16)) || (rc = proof.reserve(192)) || (rc = flags.reserve(1))) return rc;
+        if ((rc = flags.reserve(1))) return rc;
+        return reserve_batch(1);
+    }
+    int reserve_batch(size_t np) {
+        int rc;
+        if ((rc = res1.reserve(4 * np)) || (rc = res2.reserve(np)) || (rc = rs.reserve(16 * np)) || (rc = proof.reserve(192 * np))) return rc;
+        if (np > h_proof_cap) {
+            if (h_proof) hipHostFree(h_proof);
+            h_proof = nullptr;
+            HIP_TRY(hipHostMalloc(&h_proof, 192 * np));
+            h_proof_cap = np;
+        }
         return MASP_HIP_OK;
     }
     int stage_reserve(size_t bytes) {
@@ -219,8 +232,14 @@ static uint32_t log2_ceil(uint32_t n) {
 
 static int n_slots_default() {
     const char* e = getenv("MASP_HIP_SLOTS");
-    int n = e ? atoi(e) : 4;
+    int n = e ? atoi(e) : 2;
     return std::max(1, std::min(n, 64));
+}
+// proofs per batched launch sequence
+static size_t batch_cap() {
+    const char* e = getenv("MASP_HIP_BATCH");
+    int n = e ? atoi(e) : 16;
+    return (size_t)std::max(1, std::min(n, 256));
 }
 
 static int ensure_slots(masp_hip_ctx* ctx, size_t want) {
@@ -234,40 +253,43 @@ static int ensure_slots(masp_hip_ctx* ctx, size_t want) {
     return MASP_HIP_OK;
 }
 
-// Quotient on slot buffers: in[i] are Montgomery (mont_in) or canonical evaluation vectors of `nrows`
-// entries on the device; result: sl.h = canonical coefficients h[0..m-1) (+1 garbage-free extra entry).
-static int enqueue_quotient(Slot& sl, const NttDomain& D, const Fr* const in[3], uint32_t nrows, bool mont_in) {
+// Quotient for np proofs on slot buffers: in[i] + p * in_stride are Montgomery (mont_in) or canonical evaluation
+// vectors of `nrows` entries on the device; result: sl.h + p * m = canonical coefficients h[0..m-1).
+static int enqueue_quotient(Slot& sl, const NttDomain& D, const Fr* const in[3], size_t in_stride, uint32_t nrows, bool mont_in, uint32_t np) {
     hipStream_t s = sl.stream;
     const uint32_t m = (uint32_t)D.m, logm = D.logm;
-    dim3 grid((m + 255) / 256), block(256);
+    dim3 grid((m + 255) / 256, np), block(256);
     int rc;
     for (int i = 0; i < 3; ++i) {
-        if ((rc = sl.x0[i].reserve(m)) || (rc = sl.x1[i].reserve(m))) return rc;
+        if ((rc = sl.x0[i].reserve((size_t)m * np)) || (rc = sl.x1[i].reserve((size_t)m * np))) return rc;
         if (mont_in)
-            hipLaunchKernelGGL(k_ntt_copy_bitrev, grid, block, 0, s, in[i], nrows, sl.x0[i].p, logm);
+            hipLaunchKernelGGL(k_ntt_copy_bitrev, grid, block, 0, s, in[i], in_stride, nrows, sl.x0[i].p, logm);
         else
-            hipLaunchKernelGGL(k_ntt_load_bitrev, grid, block, 0, s, in[i], nrows, sl.x0[i].p, logm);
-        D.passes(s, sl.x0[i].p, D.tw_inv.p);                                                           // iNTT (unscaled)
+            hipLaunchKernelGGL(k_ntt_load_bitrev, grid, block, 0, s, in[i], in_stride, nrows, sl.x0[i].p, logm);
+        D.passes(s, sl.x0[i].p, D.tw_inv.p, np);                                                       // iNTT (unscaled)
         hipLaunchKernelGGL(k_ntt_scale_bitrev, grid, block, 0, s, sl.x0[i].p, D.coset_scale.p, sl.x1[i].p, logm);  // * g^k / m
-        D.passes(s, sl.x1[i].p, D.tw_fwd.p);                                                           // coset NTT
+        D.passes(s, sl.x1[i].p, D.tw_fwd.p, np);                                                       // coset NTT
     }
     hipLaunchKernelGGL(k_ntt_abc_bitrev, grid, block, 0, s, sl.x1[0].p, sl.x1[1].p, sl.x1[2].p, D.zinv, sl.x0[0].p, logm);
-    D.passes(s, sl.x0[0].p, D.tw_inv.p);
-    if ((rc = sl.h.reserve(m))) return rc;
+    D.passes(s, sl.x0[0].p, D.tw_inv.p, np);
+    if ((rc = sl.h.reserve((size_t)m * np))) return rc;
     hipLaunchKernelGGL(k_fr_scale, grid, block, 0, s, sl.x0[0].p, D.h_scale.p, sl.h.p, m);  // * g^-k / m, leaves Montgomery form
     return MASP_HIP_OK;
 }
 
-// Enqueue one proof.  d_w: n_vars canonical scalars on the device (inputs then aux).  d_abc: canonical
-// evaluation vectors on the device or all NULL.  d_rs: 16 limbs.  d_proof: 192 bytes on the device.
-static int enqueue_proof(Slot& sl, Circuit& C, const Fr* d_w, const Fr* const d_abc[3], const uint32_t* d_rs, uint8_t* d_proof) {
+// Enqueue np proofs of circuit C as one batch.  d_w + p * w_stride: n_vars canonical scalars on the device (inputs then
+// aux).  d_abc[i] + p * nrows: canonical evaluation vectors on the device, or all NULL.  d_rs + p * 16: r | s limbs.
+// d_proof + p * 192: output.
+static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size_t w_stride, const Fr* const d_abc[3], const uint32_t* d_rs,
+                          uint8_t* d_proof) {
     hipStream_t s = sl.stream;
     const uint32_t nv = C.n_inputs + C.n_aux;
     int rc;
+    if ((rc = sl.reserve_batch(np))) return rc;
     HIP_TRY(hipMemsetAsync(sl.flags.p, 0, sizeof(int), s));
-    if ((rc = sl.wm.reserve(nv))) return rc;
+    if ((rc = sl.wm.reserve((size_t)nv * np))) return rc;
     // range check (+ Montgomery copy used by the SpMV)
-    hipLaunchKernelGGL(k_fr_to_mont, dim3((nv + 255) / 256), dim3(256), 0, s, d_w, sl.wm.p, nv, sl.flags.p);
+    hipLaunchKernelGGL(k_fr_to_mont, dim3((nv + 255) / 256, np), dim3(256), 0, s, d_w, w_stride, sl.wm.p, nv, sl.flags.p);
     const Fr* in[3];
     bool mont_in;
     if (d_abc[0]) {
@@ -277,25 +299,26 @@ static int enqueue_proof(Slot& sl, Circuit& C, const Fr* d_w, const Fr* const d_
         mont_in = false;
     } else {
         for (int i = 0; i < 3; ++i) {
-            if ((rc = sl.ev[i].reserve(C.nrows))) return rc;
-            hipLaunchKernelGGL(k_r1cs_eval, dim3((C.nrows + 127) / 128), dim3(128), 0, s, C.rowptr[i].p, C.col[i].p, C.coef[i].p,
-                               sl.wm.p, C.n_constraints, C.n_inputs, i, sl.ev[i].p);
+            if ((rc = sl.ev[i].reserve((size_t)C.nrows * np))) return rc;
+            hipLaunchKernelGGL(k_r1cs_eval, dim3((C.nrows + 127) / 128, np), dim3(128), 0, s, C.rowptr[i].p, C.col[i].p, C.coef[i].p, sl.wm.p,
+                               nv, C.n_constraints, C.n_inputs, i, sl.ev[i].p);
             in[i] = sl.ev[i].p;
         }
         mont_in = true;
     }
-    if ((rc = enqueue_quotient(sl, *C.dom, in, C.nrows, mont_in))) return rc;
+    if ((rc = enqueue_quotient(sl, *C.dom, in, C.nrows, C.nrows, mont_in, np))) return rc;
     // query scalars selected by density
-    if ((rc = sl.sa.reserve(C.na)) || (rc = sl.sb.reserve(C.nbq))) return rc;
-    if (C.na) hipLaunchKernelGGL(k_gather_scalars, dim3((C.na + 255) / 256), dim3(256), 0, s, d_w, C.a_var.p, C.na, sl.sa.p);
-    if (C.nbq) hipLaunchKernelGGL(k_gather_scalars, dim3((C.nbq + 255) / 256), dim3(256), 0, s, d_w, C.b_var.p, C.nbq, sl.sb.p);
+    if ((rc = sl.sa.reserve((size_t)C.na * np)) || (rc = sl.sb.reserve((size_t)C.nbq * np))) return rc;
+    if (C.na) hipLaunchKernelGGL(k_gather_scalars, dim3((C.na + 255) / 256, np), dim3(256), 0, s, d_w, w_stride, C.a_var.p, C.na, sl.sa.p);
+    if (C.nbq) hipLaunchKernelGGL(k_gather_scalars, dim3((C.nbq + 255) / 256, np), dim3(256), 0, s, d_w, w_stride, C.b_var.p, C.nbq, sl.sb.p);
     MsmProfile* prof = sl.profiling ? &sl.prof : nullptr;
-    if ((rc = msm_enqueue(s, C.h, sl.ws1, (const uint32_t*)sl.h.p, sl.res1.p + 0, prof))) return rc;
-    if ((rc = msm_enqueue(s, C.l, sl.ws1, (const uint32_t*)(d_w + C.n_inputs), sl.res1.p + 1, prof))) return rc;
-    if ((rc = msm_enqueue(s, C.a, sl.ws1, (const uint32_t*)sl.sa.p, sl.res1.p + 2, prof))) return rc;
-    if ((rc = msm_enqueue(s, C.b1, sl.ws1, (const uint32_t*)sl.sb.p, sl.res1.p + 3, prof))) return rc;
-    if ((rc = msm_enqueue(s, C.b2, sl.ws2, (const uint32_t*)sl.sb.p, sl.res2.p))) return rc;
-    hipLaunchKernelGGL(k_groth16_assemble, dim3(1), dim3(192), 0, s, C.vk.p, C.fb1.p, C.fb2.p, sl.res1.p, sl.res2.p, d_rs, d_proof);
+    const size_t m8 = C.m * 8;
+    if ((rc = msm_enqueue(s, C.h, sl.ws1, (const uint32_t*)sl.h.p, m8, sl.res1.p + 0, 4, np, prof))) return rc;
+    if ((rc = msm_enqueue(s, C.l, sl.ws1, (const uint32_t*)(d_w + C.n_inputs), w_stride * 8, sl.res1.p + 1, 4, np, prof))) return rc;
+    if ((rc = msm_enqueue(s, C.a, sl.ws1, (const uint32_t*)sl.sa.p, (size_t)C.na * 8, sl.res1.p + 2, 4, np, prof))) return rc;
+    if ((rc = msm_enqueue(s, C.b1, sl.ws1, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res1.p + 3, 4, np, prof))) return rc;
+    if ((rc = msm_enqueue(s, C.b2, sl.ws2, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res2.p, 1, np))) return rc;
+    hipLaunchKernelGGL(k_groth16_assemble, dim3(np), dim3(192), 0, s, C.vk.p, C.fb1.p, C.fb2.p, sl.res1.p, sl.res2.p, d_rs, (size_t)16, d_proof);
     return MASP_HIP_OK;
 }
 
@@ -434,7 +457,7 @@ int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* param
         if ((rc = C->rowptr[mi].upload(rp[mi], cs->n_constraints + 1, s)) || (rc = C->col[mi].upload(cl[mi], nnz, s)) ||
             (rc = raw.upload((const Fr*)cf[mi], nnz, s)) || (rc = C->coef[mi].reserve(nnz)))
             return fail(ctx, rc);
-        if (nnz) hipLaunchKernelGGL(k_fr_to_mont, dim3((nnz + 255) / 256), dim3(256), 0, s, raw.p, C->coef[mi].p, nnz, d_flag.p);
+        if (nnz) hipLaunchKernelGGL(k_fr_to_mont, dim3((nnz + 255) / 256), dim3(256), 0, s, raw.p, (size_t)0, C->coef[mi].p, nnz, d_flag.p);
         if (hipStreamSynchronize(s) != hipSuccess) return fail(ctx, MASP_HIP_E_HIP);
     }
     // verifying-key points used by the prover
@@ -498,7 +521,19 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
         if ((J.a || J.b || J.c) && !(J.a && J.b && J.c)) return MASP_HIP_E_INVALID_ARG;
         if (!rs_in_range(J.r) || !rs_in_range(J.s)) return MASP_HIP_E_SCALAR_RANGE;
     }
-    size_t ns = std::min<size_t>(std::max<size_t>(n, 1), n_slots_default());
+    // consecutive jobs of the same circuit (and the same a/b/c mode) form batches of up to batch_cap() proofs
+    struct Group {
+        size_t first, count;
+    };
+    std::vector<Group> groups;
+    const size_t cap = batch_cap();
+    for (size_t j = 0; j < n;) {
+        size_t k = j + 1;
+        while (k < n && k - j < cap && jobs[k].circuit == jobs[j].circuit && (jobs[k].a != nullptr) == (jobs[j].a != nullptr)) ++k;
+        groups.push_back({j, k - j});
+        j = k;
+    }
+    size_t ns = std::min<size_t>(std::max<size_t>(groups.size(), 1), n_slots_default());
     int rc = ensure_slots(ctx, ns);
     if (rc) return fail(ctx, rc);
     std::vector<long> owner(ns, -1);
@@ -506,69 +541,69 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
     auto retire = [&](size_t si) {
         Slot& sl = *ctx->slots[si];
         if (owner[si] < 0) return;
+        const Group& G = groups[owner[si]];
         if (hipEventSynchronize(sl.done) != hipSuccess) {
             last_hip_error() = "event sync failed";
             result = fail(ctx, MASP_HIP_E_HIP);
         } else if (*sl.h_flags) {
             result = MASP_HIP_E_SCALAR_RANGE;
         } else if (result == MASP_HIP_OK) {
-            memcpy(proofs_out + 192 * (size_t)owner[si], sl.h_proof, 192);
+            memcpy(proofs_out + 192 * G.first, sl.h_proof, 192 * G.count);
         }
         owner[si] = -1;
     };
-    for (size_t j = 0; j < n && result == MASP_HIP_OK; ++j) {
-        size_t si = j % ns;
+    for (size_t gi = 0; gi < groups.size() && result == MASP_HIP_OK; ++gi) {
+        size_t si = gi % ns;
         retire(si);
         if (result) break;
+        const Group& G = groups[gi];
         Slot& sl = *ctx->slots[si];
-        Circuit& C = *ctx->circ[jobs[j].circuit];
-        const masp_hip_job& J = jobs[j];
-        const size_t nv = (size_t)C.n_inputs + C.n_aux;
-        const bool has_abc = J.a != nullptr;
-        size_t stage_bytes = 32 * nv + (has_abc ? 3 * 32 * (size_t)C.nrows : 0) + 64;
-        if ((rc = sl.stage_reserve(stage_bytes)) || (rc = sl.w.reserve(nv + (has_abc ? 3 * (size_t)C.nrows : 0)))) {
+        Circuit& C = *ctx->circ[jobs[G.first].circuit];
+        const size_t nv = (size_t)C.n_inputs + C.n_aux, np = G.count;
+        const bool has_abc = jobs[G.first].a != nullptr;
+        // staging layout: [np][nv] witness | (a | b | c each [np][nrows]) | [np][16] r,s limbs
+        const size_t w_bytes = 32 * nv * np, abc_bytes = has_abc ? 3 * 32 * (size_t)C.nrows * np : 0, rs_bytes = 64 * np;
+        if ((rc = sl.stage_reserve(w_bytes + abc_bytes + rs_bytes)) || (rc = sl.w.reserve(nv * np)) ||
+            (rc = sl.abc.reserve(has_abc ? 3 * (size_t)C.nrows * np : 1)) || (rc = sl.reserve_batch(np))) {
             result = fail(ctx, rc);
             break;
         }
         uint8_t* hs = sl.h_stage;
-        memcpy(hs, J.inputs, 32 * (size_t)C.n_inputs);
-        memcpy(hs + 32 * (size_t)C.n_inputs, J.aux, 32 * (size_t)C.n_aux);
-        size_t off = 32 * nv;
-        if (has_abc) {
-            memcpy(hs + off, J.a, 32 * (size_t)C.nrows);
-            memcpy(hs + off + 32 * (size_t)C.nrows, J.b, 32 * (size_t)C.nrows);
-            memcpy(hs + off + 64 * (size_t)C.nrows, J.c, 32 * (size_t)C.nrows);
-            off += 96 * (size_t)C.nrows;
+        for (size_t p = 0; p < np; ++p) {
+            const masp_hip_job& J = jobs[G.first + p];
+            memcpy(hs + 32 * nv * p, J.inputs, 32 * (size_t)C.n_inputs);
+            memcpy(hs + 32 * nv * p + 32 * (size_t)C.n_inputs, J.aux, 32 * (size_t)C.n_aux);
+            if (has_abc) {
+                const uint8_t* src[3] = {J.a, J.b, J.c};
+                for (int i = 0; i < 3; ++i) memcpy(hs + w_bytes + 32 * (size_t)C.nrows * (np * i + p), src[i], 32 * (size_t)C.nrows);
+            }
+            memcpy(hs + w_bytes + abc_bytes + 64 * p, J.r, 32);
+            memcpy(hs + w_bytes + abc_bytes + 64 * p + 32, J.s, 32);
         }
-        memcpy(hs + off, J.r, 32);
-        memcpy(hs + off + 32, J.s, 32);
         hipStream_t s = sl.stream;
-        bool ok = hipMemcpyAsync(sl.w.p, hs, off, hipMemcpyHostToDevice, s) == hipSuccess &&
-                  hipMemcpyAsync(sl.rs.p, hs + off, 64, hipMemcpyHostToDevice, s) == hipSuccess;
+        bool ok = hipMemcpyAsync(sl.w.p, hs, w_bytes, hipMemcpyHostToDevice, s) == hipSuccess &&
+                  (!has_abc || hipMemcpyAsync(sl.abc.p, hs + w_bytes, abc_bytes, hipMemcpyHostToDevice, s) == hipSuccess) &&
+                  hipMemcpyAsync(sl.rs.p, hs + w_bytes + abc_bytes, rs_bytes, hipMemcpyHostToDevice, s) == hipSuccess;
         if (!ok) {
             last_hip_error() = "H2D copy failed";
             result = fail(ctx, MASP_HIP_E_HIP);
             break;
         }
         const Fr* abc[3] = {nullptr, nullptr, nullptr};
-        if (has_abc) {
-            abc[0] = sl.w.p + nv;
-            abc[1] = abc[0] + C.nrows;
-            abc[2] = abc[1] + C.nrows;
-        }
-        if ((rc = enqueue_proof(sl, C, sl.w.p, abc, sl.rs.p, sl.proof.p))) {
+        if (has_abc)
+            for (int i = 0; i < 3; ++i) abc[i] = sl.abc.p + (size_t)C.nrows * np * i;
+        if ((rc = enqueue_proofs(sl, C, (uint32_t)np, sl.w.p, nv, abc, sl.rs.p, sl.proof.p))) {
             result = fail(ctx, rc);
             break;
         }
-        ok = hipMemcpyAsync(sl.h_proof, sl.proof.p, 192, hipMemcpyDeviceToHost, s) == hipSuccess &&
-             hipMemcpyAsync(sl.h_flags, sl.flags.p, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess &&
-             hipEventRecord(sl.done, s) == hipSuccess;
+        ok = hipMemcpyAsync(sl.h_proof, sl.proof.p, 192 * np, hipMemcpyDeviceToHost, s) == hipSuccess &&
+             hipMemcpyAsync(sl.h_flags, sl.flags.p, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess && hipEventRecord(sl.done, s) == hipSuccess;
         if (!ok) {
             last_hip_error() = "D2H copy failed";
             result = fail(ctx, MASP_HIP_E_HIP);
             break;
         }
-        owner[si] = (long)j;
+        owner[si] = (long)gi;
     }
     for (size_t si = 0; si < ns; ++si) retire(si);
     if (hipGetLastError() != hipSuccess && result == MASP_HIP_OK) {
@@ -613,7 +648,7 @@ static int msm_block(masp_hip_ctx* ctx, const uint8_t* bases, const uint8_t* sca
     if ((rc = B.load_host(bases, (uint32_t)n, s))) return fail(ctx, rc);
     if (B.import_status & (PT_BAD_FLAGS | PT_NOT_CANONICAL)) return MASP_HIP_E_PARAMS_FORMAT;
     if ((rc = ctx->tmp_scalars.upload((const Fr*)scalars, n, s)) || (rc = res.reserve(1)) || (rc = ctx->tmp_out.reserve(BYTES))) return fail(ctx, rc);
-    if ((rc = msm_enqueue(s, B, ws, (const uint32_t*)ctx->tmp_scalars.p, res.p))) return fail(ctx, rc);
+    if ((rc = msm_enqueue(s, B, ws, (const uint32_t*)ctx->tmp_scalars.p, 0, res.p, 1, 1))) return fail(ctx, rc);
     if constexpr (BYTES == 96)
         hipLaunchKernelGGL(k_g1_export, dim3(1), dim3(1), 0, s, res.p, ctx->tmp_out.p);
     else
@@ -652,7 +687,7 @@ int masp_hip_quotient_h(masp_hip_ctx* ctx, const uint8_t* a, const uint8_t* b, c
         if (hipMemcpyAsync(sl.w.p + i * nrows, src[i], 32 * nrows, hipMemcpyHostToDevice, s) != hipSuccess) return fail(ctx, MASP_HIP_E_HIP);
         in[i] = sl.w.p + i * nrows;
     }
-    if ((rc = enqueue_quotient(sl, *D, in, (uint32_t)nrows, false))) return fail(ctx, rc);
+    if ((rc = enqueue_quotient(sl, *D, in, 0, (uint32_t)nrows, false, 1))) return fail(ctx, rc);
     size_t m = (size_t)1 << logm;
     if (hipMemcpyAsync(h_out, sl.h.p, 32 * (m - 1), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
         last_hip_error() = std::string("quotient failed: ") + hipGetErrorString(hipGetLastError());
@@ -675,7 +710,7 @@ int masp_hip_ntt(masp_hip_ctx* ctx, uint8_t* data, uint32_t logm, int inverse) {
     hipStream_t s = sl.stream;
     if (hipMemcpyAsync(sl.w.p, data, 32 * (size_t)m, hipMemcpyHostToDevice, s) != hipSuccess) return fail(ctx, MASP_HIP_E_HIP);
     dim3 grid((m + 255) / 256), block(256);
-    hipLaunchKernelGGL(k_ntt_load_bitrev, grid, block, 0, s, sl.w.p, m, sl.x0[0].p, logm);
+    hipLaunchKernelGGL(k_ntt_load_bitrev, grid, block, 0, s, sl.w.p, (size_t)0, m, sl.x0[0].p, logm);
     D->passes(s, sl.x0[0].p, inverse ? D->tw_inv.p : D->tw_fwd.p);
     if (inverse) {
         // 1/m scaling: coset_scale[0] = g^0 / m
@@ -772,7 +807,7 @@ int masp_hip_generate_parameters(masp_hip_ctx* ctx, const masp_hip_r1cs* cs, con
         if ((rc = d_colptr.upload(colptr.data(), nv + 1, s)) || (rc = d_rowidx.upload(rowidx.data(), nnz, s)) ||
             (rc = d_raw.upload(coefs.data(), nnz, s)) || (rc = d_coef.reserve(nnz)) || (rc = qt[mi].reserve(nv)))
             return fail(ctx, rc);
-        if (nnz) hipLaunchKernelGGL(k_fr_to_mont, dim3((nnz + 255) / 256), dim3(256), 0, s, d_raw.p, d_coef.p, nnz, d_flag.p);
+        if (nnz) hipLaunchKernelGGL(k_fr_to_mont, dim3((nnz + 255) / 256), dim3(256), 0, s, d_raw.p, (size_t)0, d_coef.p, nnz, d_flag.p);
         hipLaunchKernelGGL(k_setup_qap, dim3((nv + 127) / 128), dim3(128), 0, s, d_colptr.p, d_rowidx.p, d_coef.p, lag.p, nv, n_in, nc,
                            mi == 0 ? 1 : 0, qt[mi].p);
         if (hipStreamSynchronize(s) != hipSuccess) {
@@ -912,11 +947,22 @@ int masp_hip_batch_prove_resident(masp_hip_ctx* ctx, int handle, uint8_t* proofs
     std::lock_guard<std::mutex> lock(ctx->mu);
     hipSetDevice(ctx->device);
     ResidentBatch& B = *ctx->batches[handle];
-    size_t ns = std::min<size_t>(B.n, n_slots_default());
+    // groups of consecutive same-circuit jobs (their assignments are contiguous: stride = n_vars)
+    struct Group {
+        size_t first, count;
+    };
+    std::vector<Group> groups;
+    const size_t cap = batch_cap();
+    for (size_t j = 0; j < B.n;) {
+        size_t k = j + 1;
+        while (k < B.n && k - j < cap && B.circuit[k] == B.circuit[j]) ++k;
+        groups.push_back({j, k - j});
+        j = k;
+    }
+    size_t ns = std::min<size_t>(groups.size(), n_slots_default());
     int rc;
     if ((rc = ensure_slots(ctx, ns))) return fail(ctx, rc);
     DevBuf<uint8_t> d_proofs;
-    DevBuf<int> d_flags;
     if ((rc = d_proofs.reserve(192 * B.n))) return fail(ctx, rc);
     hipEvent_t ev_start, ev_stop;
     HIP_TRY(hipEventCreate(&ev_start));
@@ -925,10 +971,13 @@ int masp_hip_batch_prove_resident(masp_hip_ctx* ctx, int handle, uint8_t* proofs
     HIP_TRY(hipEventRecord(ev_start, ms));
     for (size_t si = 0; si < ns; ++si) HIP_TRY(hipStreamWaitEvent(ctx->slots[si]->stream, ev_start, 0));
     const Fr* none[3] = {nullptr, nullptr, nullptr};
-    for (size_t j = 0; j < B.n; ++j) {
-        Slot& sl = *ctx->slots[j % ns];
-        Circuit& C = *ctx->circ[B.circuit[j]];
-        if ((rc = enqueue_proof(sl, C, B.w.p + B.w_off[j], none, B.rs.p + 16 * j, d_proofs.p + 192 * j))) return fail(ctx, rc);
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        const Group& G = groups[gi];
+        Slot& sl = *ctx->slots[gi % ns];
+        Circuit& C = *ctx->circ[B.circuit[G.first]];
+        if ((rc = enqueue_proofs(sl, C, (uint32_t)G.count, B.w.p + B.w_off[G.first], (size_t)C.n_inputs + C.n_aux, none, B.rs.p + 16 * G.first,
+                                 d_proofs.p + 192 * G.first)))
+            return fail(ctx, rc);
     }
     for (size_t si = 0; si < ns; ++si) {
         HIP_TRY(hipEventRecord(ctx->slots[si]->done, ctx->slots[si]->stream));
@@ -940,7 +989,13 @@ int masp_hip_batch_prove_resident(masp_hip_ctx* ctx, int handle, uint8_t* proofs
     if (elapsed_ms) HIP_TRY(hipEventElapsedTime(elapsed_ms, ev_start, ev_stop));
     hipEventDestroy(ev_start);
     hipEventDestroy(ev_stop);
-    return MASP_HIP_OK;
+    int flags = 0;
+    for (size_t si = 0; si < ns; ++si) {
+        int f = 0;
+        HIP_TRY(hipMemcpy(&f, ctx->slots[si]->flags.p, sizeof(int), hipMemcpyDeviceToHost));
+        flags |= f;
+    }
+    return flags ? MASP_HIP_E_SCALAR_RANGE : MASP_HIP_OK;
 }
 
 int masp_hip_profile_enable(masp_hip_ctx* ctx, int on) {
@@ -994,7 +1049,7 @@ int masp_hip_bench_msm(masp_hip_ctx* ctx, int handle, size_t job, int which, int
     Circuit& C = *ctx->circ[B.circuit[job]];
     const Fr* none[3] = {nullptr, nullptr, nullptr};
     // one full proof first so that sl.h / sl.sa / sl.sb hold this job's real scalars
-    if ((rc = enqueue_proof(sl, C, B.w.p + B.w_off[job], none, B.rs.p + 16 * job, sl.proof.p))) return fail(ctx, rc);
+    if ((rc = enqueue_proofs(sl, C, 1, B.w.p + B.w_off[job], 0, none, B.rs.p + 16 * job, sl.proof.p))) return fail(ctx, rc);
     HIP_TRY(hipStreamSynchronize(sl.stream));
     const BasesG1* bases[4] = {&C.h, &C.l, &C.a, &C.b1};
     const uint32_t* scal[4] = {(const uint32_t*)sl.h.p, (const uint32_t*)(B.w.p + B.w_off[job] + C.n_inputs), (const uint32_t*)sl.sa.p,
@@ -1004,7 +1059,7 @@ int masp_hip_bench_msm(masp_hip_ctx* ctx, int handle, size_t job, int which, int
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, sl.stream));
     for (int it = 0; it < iters; ++it)
-        if ((rc = msm_enqueue(sl.stream, *bases[which], sl.ws1, scal[which], sl.res1.p + which))) return fail(ctx, rc);
+        if ((rc = msm_enqueue(sl.stream, *bases[which], sl.ws1, scal[which], 0, sl.res1.p + which, 4, 1))) return fail(ctx, rc);
     HIP_TRY(hipEventRecord(e1, sl.stream));
     HIP_TRY(hipStreamSynchronize(sl.stream));
     float ms = 0;
