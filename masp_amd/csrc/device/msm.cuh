@@ -307,15 +307,19 @@ k_msm_ones(const Affine<O>* __restrict__ tab, const uint32_t* __restrict__ ones,
 }
 
 // ---- (6) reductions -----------------------------------------------------------------------------
-// One level of the weighted sum  V(B, off) = sum_k (k + off) * B[k], one workgroup per chunk of WSUM_CS
-// elements:  S[ch] = sum_l B[ch*cs + l],  T[ch] = sum_l (l + off) * B[ch*cs + l];  then
-// V(B, off) = sum_ch T[ch] + cs * V(S, 0).  Inside the workgroup the running sums are a log-depth suffix scan
-// followed by a tree reduction through LDS (16 dependent additions instead of 2*cs), because a single
-// dependent XYZZ addition costs tens of microseconds on one wave.
-static constexpr uint32_t WSUM_CS_LOG = 8;
+// One level of the weighted sum  V(B, off) = sum_k (k + off) * B[k].  A workgroup of WSUM_L lanes owns a chunk of
+// WSUM_CS = WSUM_G * WSUM_L elements and produces  S[ch] = sum_l B[ch*cs + l],  T[ch] = sum_l (l + off) * B[ch*cs + l];
+// then V(B, off) = sum_ch T[ch] + cs * V(S, 0).
+//   phase 1  every lane runs the classic running sum over its own WSUM_G consecutive elements (2G - 1 additions);
+//   phase 2  the per-lane sums are combined with a log-depth suffix scan and one tree through LDS.
+// ~4.5 additions per bucket in total (a pure log-depth scan costs 16) at a depth of 33 dependent additions:
+// with a batch of proofs in flight the chip is throughput-bound here, so work counts, not just depth.
+static constexpr uint32_t WSUM_G_LOG = 3, WSUM_L_LOG = 7;
+static constexpr uint32_t WSUM_G = 1u << WSUM_G_LOG, WSUM_L = 1u << WSUM_L_LOG;
+static constexpr uint32_t WSUM_CS_LOG = WSUM_G_LOG + WSUM_L_LOG;
 static constexpr uint32_t WSUM_CS = 1u << WSUM_CS_LOG;
 template <class O>
-__global__ void __launch_bounds__(256) k_msm_wsum_level(const Xyzz<O>* __restrict__ B, size_t b_stride, uint32_t m, uint32_t off,
+__global__ void __launch_bounds__(128) k_msm_wsum_level(const Xyzz<O>* __restrict__ B, size_t b_stride, uint32_t m, uint32_t off,
                                                         Xyzz<O>* __restrict__ S, Xyzz<O>* __restrict__ T, size_t st_stride) {
     extern __shared__ uint4 wsum_lds[];
     Xyzz<O>* sh = reinterpret_cast<Xyzz<O>*>(wsum_lds);
@@ -323,18 +327,25 @@ __global__ void __launch_bounds__(256) k_msm_wsum_level(const Xyzz<O>* __restric
     B += MSM_P * b_stride;
     S += MSM_P * st_stride;
     T += MSM_P * st_stride;
-    const uint32_t k = blockIdx.x * WSUM_CS + tid;
-    Xyzz<O> x = k < m ? B[k] : xyzz_inf<O>();
-    // inclusive suffix scan: x_i = sum_{j >= i} B_j over the chunk
-    for (uint32_t d = 1; d < WSUM_CS; d <<= 1) {
+    // phase 1: lane-local running sum, top element first:  run = sum B_l,  acc = sum (l + off) B_l  (l local)
+    const uint32_t base = blockIdx.x * WSUM_CS + tid * WSUM_G;
+    Xyzz<O> run = xyzz_inf<O>(), acc = xyzz_inf<O>();
+    for (uint32_t l = WSUM_G; l-- > 0;) {
+        if (base + l < m) xyzz_add_nc(run, B[base + l]);
+        if (l > 0 || off) xyzz_add_nc(acc, run);
+    }
+    // phase 2: lanes.  sum_lane (lane * G) * run_lane = G * sum_{i >= 1} x_i  with x = inclusive suffix scan of run
+    Xyzz<O> x = run;
+    for (uint32_t d = 1; d < WSUM_L; d <<= 1) {
         sh[tid] = x;
         __syncthreads();
-        if (tid + d < WSUM_CS) xyzz_add_nc(x, sh[tid + d]);
+        if (tid + d < WSUM_L) xyzz_add_nc(x, sh[tid + d]);
         __syncthreads();
     }
-    // sum_l l * B_l = sum_{i >= 1} x_i ;  with off = 1 the i = 0 term joins in
-    Xyzz<O> y = (tid > 0 || off) ? x : xyzz_inf<O>();
-    for (uint32_t d = WSUM_CS >> 1; d >= 1; d >>= 1) {
+    Xyzz<O> y = tid > 0 ? x : xyzz_inf<O>();
+    for (uint32_t k = 0; k < WSUM_G_LOG; ++k) y = xyzz_dbl(y);
+    xyzz_add_nc(y, acc);
+    for (uint32_t d = WSUM_L >> 1; d >= 1; d >>= 1) {
         sh[tid] = y;
         __syncthreads();
         if (tid < d) xyzz_add_nc(y, sh[tid + d]);

@@ -64,7 +64,7 @@ struct MsmBases {
 // ---- workspace ------------------------------------------------------------------------------------
 template <class O>
 struct MsmWorkspace {
-    static constexpr uint32_t CS_LOG = WSUM_CS_LOG;   // weighted-sum chunk = one 256-lane workgroup
+    static constexpr uint32_t CS_LOG = WSUM_CS_LOG;   // weighted-sum chunk = WSUM_G x WSUM_L buckets per workgroup
     static constexpr uint32_t NCHUNKS = 1u << 18;     // lanes of the accumulation kernel (1024 waves x 4 per SIMD)
     static constexpr uint32_t HEAVY_BLOCKS = 256;
 
@@ -257,8 +257,8 @@ int msm_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, MsmWorkspace<O>& ws,
     int level = 0, flip = 0;
     do {
         uint32_t chunks = (m + cs - 1) / cs;
-        hipLaunchKernelGGL((k_msm_wsum_level<O>), dim3(chunks, np), dim3(256), 256 * sizeof(Xyzz<O>), s, bk, bk_stride, m, off, ws.S[flip],
-                           ws.T, st_stride);
+        hipLaunchKernelGGL((k_msm_wsum_level<O>), dim3(chunks, np), dim3(WSUM_L), WSUM_L * sizeof(Xyzz<O>), s, bk, bk_stride, m, off,
+                           ws.S[flip], ws.T, st_stride);
         ws.reduce_to_one(s, np, ws.T, st_stride, chunks, ws.tsum + level, 32, st_stride);
         bk = ws.S[flip];
         bk_stride = st_stride;
