@@ -84,9 +84,14 @@ struct MsmWorkspace {
         part = bkt = S[0] = S[1] = T = R[0] = R[1] = tsum = ones_part = ones_sum = nullptr;
         cap_ent = cap_nb = cap_n = cap_np = 0;
     }
-    static uint32_t nchunks_for(uint32_t n, const MsmGeom& g) {
+    // lanes of the accumulation kernel per proof: ~2^18 across the whole batch.  Fewer, longer chunks mean fewer
+    // partial sums to write and to gather (each extra partial costs a full XYZZ addition later).
+    static uint32_t nchunks_for(uint32_t n, const MsmGeom& g, uint32_t np) {
         uint64_t ent = (uint64_t)n * g.W;
-        return (uint32_t)std::min<uint64_t>(NCHUNKS, std::max<uint64_t>(ent, 1));
+        uint64_t lanes = std::max<uint64_t>(NCHUNKS / std::max<uint32_t>(np, 1), 1u << 13);
+        const char* e = getenv("MASP_HIP_MSM_CHUNKS");
+        if (e) lanes = std::max(1, atoi(e));
+        return (uint32_t)std::min<uint64_t>(std::min<uint64_t>(lanes, NCHUNKS), std::max<uint64_t>(ent, 1));
     }
     // room for `np` proofs of an n-point MSM with geometry g (every per-proof array is np-fold)
     int reserve(uint32_t n, const MsmGeom& g, uint32_t np) {
@@ -221,7 +226,7 @@ int msm_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, MsmWorkspace<O>& ws,
     }
     const uint32_t nb = g.nb;
     const uint32_t total = n * g.W;
-    const uint32_t nchunks = ws.nchunks_for(n, g);
+    const uint32_t nchunks = ws.nchunks_for(n, g, np);
     const size_t part_stride = (size_t)nchunks + nb;
     (void)part_stride;
     HIP_TRY(hipMemsetAsync(ws.hist, 0, 4 * (size_t)nb * np, s));
