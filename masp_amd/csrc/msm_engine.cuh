@@ -68,7 +68,7 @@ struct MsmWorkspace {
     static constexpr uint32_t NCHUNKS = 1u << 18;     // lanes of the accumulation kernel (1024 waves x 4 per SIMD)
     static constexpr uint32_t HEAVY_BLOCKS = 256;
 
-    size_t cap_ent = 0, cap_nb = 0, cap_np = 0;
+    size_t cap_ent = 0, cap_nb = 0, cap_np = 0, cap_chunks = 0;
     uint32_t *ent = nullptr, *sorted = nullptr, *hist = nullptr, *start = nullptr, *fill = nullptr;
     uint32_t *heavy = nullptr, *n_heavy = nullptr, *ones = nullptr, *n_ones = nullptr;
     size_t cap_n = 0;
@@ -82,7 +82,7 @@ struct MsmWorkspace {
             if (p) hipFree(p);
         ent = sorted = hist = start = fill = heavy = n_heavy = ones = n_ones = nullptr;
         part = bkt = S[0] = S[1] = T = R[0] = R[1] = tsum = ones_part = ones_sum = nullptr;
-        cap_ent = cap_nb = cap_n = cap_np = 0;
+        cap_ent = cap_nb = cap_n = cap_np = cap_chunks = 0;
     }
     // lanes of the accumulation kernel per proof: ~2^18 across the whole batch.  Fewer, longer chunks mean fewer
     // partial sums to write and to gather (each extra partial costs a full XYZZ addition later).
@@ -95,15 +95,17 @@ struct MsmWorkspace {
     }
     // room for `np` proofs of an n-point MSM with geometry g (every per-proof array is np-fold)
     int reserve(uint32_t n, const MsmGeom& g, uint32_t np) {
-        size_t need_ent = (size_t)n * g.W;
-        if (need_ent <= cap_ent && (size_t)g.nb <= cap_nb && n <= cap_n && np <= cap_np) return MASP_HIP_OK;
+        size_t need_ent = (size_t)n * g.W, need_chunks = nchunks_for(n, g, np);
+        if (need_ent <= cap_ent && (size_t)g.nb <= cap_nb && n <= cap_n && np <= cap_np && need_chunks <= cap_chunks) return MASP_HIP_OK;
         need_ent = std::max(need_ent, cap_ent);
+        need_chunks = std::max(need_chunks, cap_chunks);
         size_t need_nb = std::max<size_t>(g.nb, cap_nb), need_n = std::max<size_t>(n, cap_n), need_np = std::max<size_t>(np, cap_np);
         release();
         cap_ent = need_ent;
         cap_nb = need_nb;
         cap_n = need_n;
         cap_np = need_np;
+        cap_chunks = need_chunks;
         const size_t P = cap_np;
         size_t chunks = (cap_nb + (1u << CS_LOG) - 1) >> CS_LOG;
         HIP_TRY(hipMalloc(&ent, P * 4 * std::max<size_t>(cap_ent, 1)));
@@ -117,7 +119,7 @@ struct MsmWorkspace {
         HIP_TRY(hipMalloc(&n_ones, P * 4));
         HIP_TRY(hipMalloc(&ones_part, P * sizeof(Xyzz<O>) * 256));
         HIP_TRY(hipMalloc(&ones_sum, P * sizeof(Xyzz<O>)));
-        HIP_TRY(hipMalloc(&part, P * sizeof(Xyzz<O>) * ((size_t)NCHUNKS + cap_nb)));
+        HIP_TRY(hipMalloc(&part, P * sizeof(Xyzz<O>) * (cap_chunks + cap_nb)));
         HIP_TRY(hipMalloc(&bkt, P * sizeof(Xyzz<O>) * cap_nb));
         HIP_TRY(hipMalloc(&S[0], P * sizeof(Xyzz<O>) * chunks));
         HIP_TRY(hipMalloc(&S[1], P * sizeof(Xyzz<O>) * chunks));
