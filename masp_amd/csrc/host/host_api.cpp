@@ -7,8 +7,36 @@
 #include <memory>
 
 #include "circuits.h"
+#include "pairing.h"
 
 using namespace masp_host;
+
+namespace masp_host {
+namespace bls {
+#include "pairing_consts.inc"
+const PairingK& pairing_k() {
+    static PairingK k = [] {
+        PairingK c;
+        Fp12 w = {Fp6::zero(), Fp6::one()};  // w
+        Fp12 w2 = w * w, w3 = w2 * w;
+        c.w2i = w2.inv();
+        c.w3i = w3.inv();
+        c.hard.assign(HARD_EXP_LIMBS, HARD_EXP_LIMBS + sizeof(HARD_EXP_LIMBS) / 8);
+        return c;
+    }();
+    return k;
+}
+}  // namespace bls
+}  // namespace masp_host
+
+namespace {
+// PreparedVerifyingKey (lib.rs:391-393): the Miller value of (alpha, beta) is computed once
+struct PreparedVk {
+    bls::Fp12 alpha_beta;
+    bls::G2A gamma, delta;
+    std::vector<bls::G1A> ic;
+};
+}  // namespace
 
 namespace {
 struct CircuitHandle {
@@ -169,6 +197,44 @@ int masp_host_convert_assignment(const uint8_t generator[32], uint64_t value, co
     }
 }
 
+// ---- Groth16 self-verification (sapling/prover.rs:148,266) ---------------------------------------------
+// params: the Parameters bytes (only the verifying-key prefix is read).  Returns a handle or NULL.
+void* masp_host_vk_prepare(const uint8_t* params, size_t len) {
+    if (len < 868) return nullptr;
+    std::unique_ptr<PreparedVk> vk(new PreparedVk);
+    bls::G1A alpha, delta1;
+    bls::G2A beta;
+    if (!bls::g1_uncompressed(alpha, params) || !bls::g2_uncompressed(beta, params + 192) || !bls::g2_uncompressed(vk->gamma, params + 384) ||
+        !bls::g1_uncompressed(delta1, params + 576) || !bls::g2_uncompressed(vk->delta, params + 672))
+        return nullptr;
+    uint32_t n = ((uint32_t)params[864] << 24) | (params[865] << 16) | (params[866] << 8) | params[867];
+    if ((size_t)n * 96 + 868 > len || n == 0) return nullptr;
+    vk->ic.resize(n);
+    for (uint32_t i = 0; i < n; ++i)
+        if (!bls::g1_uncompressed(vk->ic[i], params + 868 + 96 * (size_t)i)) return nullptr;
+    vk->alpha_beta = bls::miller(alpha, beta);
+    return vk.release();
+}
+void masp_host_vk_free(void* h) { delete (PreparedVk*)h; }
+// public_inputs: n_public x 32 B LE, excluding ONE.  1 = valid, 0 = invalid, < 0 = malformed
+int masp_host_vk_verify(const void* h, const uint8_t proof[192], const uint8_t* public_inputs, uint32_t n_public) {
+    const PreparedVk& vk = *(const PreparedVk*)h;
+    if ((size_t)n_public + 1 != vk.ic.size()) return -1;
+    bls::G1A a, c;
+    bls::G2A b;
+    if (!bls::g1_compressed(a, proof) || !bls::g2_compressed(b, proof + 48) || !bls::g1_compressed(c, proof + 144)) return -2;
+    bls::G1J acc = bls::G1J::from(vk.ic[0]);
+    for (uint32_t i = 0; i < n_public; ++i) {
+        Fr chk;
+        if (!Fr::from_bytes(chk, public_inputs + 32 * i)) return -3;
+        acc = acc.add(bls::G1J::from(vk.ic[i + 1]).mul_le(public_inputs + 32 * i));
+    }
+    // e(A, B) == e(alpha, beta) e(acc, gamma) e(C, delta)   <=>   ML(A,B) / (ML(alpha,beta) ML(acc,gamma) ML(C,delta)) -> 1
+    bls::Fp12 lhs = bls::miller(a, b);
+    bls::Fp12 rhs = vk.alpha_beta * bls::miller(acc.affine(), vk.gamma) * bls::miller(c, vk.delta);
+    return bls::final_exp(lhs * rhs.inv()) == bls::Fp12::one() ? 1 : 0;
+}
+
 // ---- native primitives (pinned by the reference's vectors in tests/) ---------------------------------
 // which: 0 proof_generation_key 1 note_commitment_randomness 2 nullifier_position 3 value_commitment_randomness
 //        4 spending_key 5..10 pedersen[0..5]; out: u | v as 2 x 32 B LE
@@ -227,6 +293,15 @@ int masp_host_jubjub_mul(const uint8_t p32[32], const uint8_t k32[32], uint8_t o
     JPoint p;
     if (!JPoint::from_bytes(p, p32)) return 1;
     p.mul(k32).to_bytes(out32);
+    return 0;
+}
+// affine coordinates (u | v, 2 x 32 B LE) of an encoded point
+int masp_host_point_uv(const uint8_t p32[32], uint8_t out64[64]) {
+    JPoint p;
+    if (!JPoint::from_bytes(p, p32)) return 1;
+    JAffine a = p.to_affine();
+    a.u.to_bytes(out64);
+    a.v.to_bytes(out64 + 32);
     return 0;
 }
 // p + q, or p - q when subtract != 0 (value-commitment bookkeeping of the proving context)

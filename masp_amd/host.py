@@ -50,6 +50,11 @@ def load_library():
         L.masp_host_merkle_hash.argtypes = [C.c_uint, cp, cp, cp]
         L.masp_host_jubjub_mul.argtypes = [cp, cp, cp]
         L.masp_host_convert_cmu.argtypes = [cp, cp]
+        L.masp_host_vk_prepare.restype = vp
+        L.masp_host_vk_prepare.argtypes = [vp, C.c_size_t]
+        L.masp_host_vk_free.argtypes = [vp]
+        L.masp_host_vk_verify.argtypes = [vp, cp, cp, C.c_uint32]
+        L.masp_host_point_uv.argtypes = [cp, cp]
         L.masp_host_jubjub_add.argtypes = [cp, cp, C.c_int, cp]
         L.masp_host_spend_leaf.argtypes = [cp, cp, cp, cp, cp, u64, cp, cp]
         _lib = L
@@ -138,6 +143,32 @@ def convert_assignment(generator, value, anchor, path_siblings, position, rcv, c
     return inputs, aux, cv.raw
 
 
+class PreparedVerifyingKey:
+    """= bellman `prepare_verifying_key(&params.vk)` (lib.rs:391-393) + `verify_proof` (sapling/prover.rs:148,266)."""
+
+    def __init__(self, params):
+        buf = np.ascontiguousarray(params, dtype=np.uint8)
+        n_ic = int.from_bytes(buf[864:868].tobytes(), "big")
+        self._buf = buf[:868 + 96 * n_ic].copy()
+        self._L = load_library()
+        self._h = self._L.masp_host_vk_prepare(self._buf.ctypes.data, self._buf.size)
+        if not self._h:
+            raise ValueError("malformed verifying key")
+
+    def verify(self, proof, public_inputs):
+        """public_inputs: ints or 32-byte LE values, excluding ONE -> True / False"""
+        pi = b"".join(_b(x) for x in public_inputs)
+        rc = self._L.masp_host_vk_verify(self._h, bytes(proof), pi, len(public_inputs))
+        if rc < 0:
+            return False
+        return rc == 1
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.masp_host_vk_free(self._h)
+            self._h = None
+
+
 # ---- native primitives ----
 GENERATOR_NAMES = ["proof_generation_key_generator", "note_commitment_randomness_generator", "nullifier_position_generator",
                    "value_commitment_randomness_generator", "spending_key_generator"]
@@ -201,6 +232,19 @@ def jubjub_mul(point, scalar):
     if load_library().masp_host_jubjub_mul(_b(point), _b(scalar), out):
         raise ValueError("invalid point")
     return out.raw
+
+
+def point_uv(point):
+    out = C.create_string_buffer(64)
+    if load_library().masp_host_point_uv(_b(point), out):
+        raise ValueError("invalid point")
+    return int.from_bytes(out.raw[:32], "little"), int.from_bytes(out.raw[32:], "little")
+
+
+def multipack(data):
+    """bellman multipack::compute_multipacking(bytes_to_bits_le(data)): 254-bit little-endian chunks (sapling/prover.rs:138-139)"""
+    bits = [(data[i // 8] >> (i % 8)) & 1 for i in range(8 * len(data))]
+    return [sum(b << k for k, b in enumerate(bits[o:o + 254])) for o in range(0, len(bits), 254)]
 
 
 def jubjub_add(p, q, subtract=False):

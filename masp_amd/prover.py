@@ -58,11 +58,15 @@ class SaplingProvingContext:
 class LocalTxProver:
     """An implementation of `TxProver` using the MI355X prover.  Holds the three circuits' parameters for its lifetime."""
 
-    def __init__(self, spend_params, output_params, convert_params, device=0, rng=None):
+    def __init__(self, spend_params, output_params, convert_params, device=0, rng=None, self_verify=True):
         """= LocalTxProver::from_bytes (prover.rs:81-95): parameter *bytes* in the bellman wire format.
         Malformed or mismatching parameters raise (the reference panics, lib.rs:290-293,337)."""
         self._ctx = Context(device)
         self._rng = rng or (lambda: secrets.randbelow(FR))          # r, s <- OsRng (sapling/prover.rs:66,174,225)
+        self._self_verify = self_verify
+        # spend_vk / convert_vk: PreparedVerifyingKey (prover.rs:27-33, lib.rs:391-393); Output proofs are not self-checked
+        self.spend_vk = H.PreparedVerifyingKey(spend_params)
+        self.convert_vk = H.PreparedVerifyingKey(convert_params)
         for slot, kind, params in ((SPEND, "spend", spend_params), (OUTPUT, "output", output_params), (CONVERT, "convert", convert_params)):
             cs, _ = H.circuit(kind)
             self._ctx.load_circuit(slot, params, cs)
@@ -136,6 +140,11 @@ class LocalTxProver:
         """-> (zkproof[192], cv, rk).  `rseed` is the note commitment randomness rcm = note.rcm() (Rseed::BeforeZip212 form)."""
         job = self.prepare_spend(proof_generation_key, diversifier, rseed, ar, asset_type, value, anchor, merkle_path, rcv)
         zkproof = self.prove_prepared([job], None if rs is None else [rs])[0]
+        if self._self_verify:
+            # public input built from the natively computed rk, cv, anchor and nullifier (sapling/prover.rs:121-145)
+            public_input = list(H.point_uv(job["rk"])) + list(H.point_uv(job["cv"])) + [_int(anchor)] + H.multipack(job["nf"])
+            if not self.spend_vk.verify(zkproof, public_input):
+                raise ProvingError("spend proof failed self-verification")      # .map_err(|_| ())? at :148
         ctx._spend_like(rcv, job["cv"])
         return zkproof, job["cv"], job["rk"]
 
@@ -150,6 +159,10 @@ class LocalTxProver:
         """-> (zkproof[192], cv)"""
         job = self.prepare_convert(allowed_conversion, value, anchor, merkle_path, rcv)
         zkproof = self.prove_prepared([job], None if rs is None else [rs])[0]
+        if self._self_verify:
+            public_input = list(H.point_uv(job["cv"])) + [_int(anchor)]            # sapling/prover.rs:256-263
+            if not self.convert_vk.verify(zkproof, public_input):
+                raise ProvingError("convert proof failed self-verification")    # :266
         ctx._spend_like(rcv, job["cv"])
         return zkproof, job["cv"]
 

@@ -171,3 +171,21 @@ def test_output_and_convert_witnesses_satisfy_their_circuits():
     assert H.point_bytes(pub[1], pub[2]) == cv and pub[3] == int.from_bytes(anchor, "little")
     with pytest.raises(H.HostError):
         H.convert_assignment(gen, 7, (int.from_bytes(anchor, "little") + 1) % R, siblings, pos, 5, check=True)
+
+
+def test_host_verifier_agrees_with_oracle_pairing_check():
+    """product-side verify_proof (masp_amd/csrc/host/pairing.h) vs the oracle's independent pairing on oracle-made proofs"""
+    import toy_r1cs
+    cs, inputs, aux, vals = toy_r1cs.make(3, 8, 40, 300)
+    pbuf = O.generate_parameters(cs, toy_r1cs.toxic(3))
+    P = O.Params(pbuf)
+    vk = H.PreparedVerifyingKey(pbuf)
+    proof = O.create_proof(P, cs, inputs, aux, 5, 6)
+    other = O.create_proof(P, cs, inputs, aux, 5, 7)
+    pub = vals[1:8]
+    cases = [(proof, pub), (other, pub), (proof[:144] + other[144:], pub), (proof, [pub[0] + 1] + pub[1:]),
+             (bytes([proof[0] ^ 0x20]) + proof[1:], pub)]
+    for pr, pi in cases:
+        assert vk.verify(pr, pi) == (O.verify_proof(pbuf, pr, pi) == 1)
+    assert vk.verify(proof, pub) and not vk.verify(proof, pub[:-1])
+    assert not vk.verify(bytes(192), pub)          # not even valid encodings

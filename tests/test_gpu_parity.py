@@ -271,6 +271,10 @@ def test_local_tx_prover_real_circuits_match_oracle_and_verify(ctx):
     pcv = lp.parameters["convert"]
     assert pcv.size == 21204888 and zk_c == O.create_proof(O.Params(pcv), cs_c, i_c, a_c, r, s)
     assert O.verify_proof(pcv[:868 + 96 * 4], zk_c, [int.from_bytes(i_c[i].tobytes(), "little") for i in range(1, 4)]) == 1
+    # an unsatisfiable statement (wrong anchor, value != 0) still "proves" but fails the self-check -> Err(())
+    with pytest.raises(P.ProvingError):
+        lp.spend_proof(pc, (inst["ak"], inst["nsk"]), inst["diversifier"], inst["rcm"], inst["ar"], inst["asset_identifier"], inst["value"],
+                       (int.from_bytes(inst["anchor"], "little") + 1) % H.FR_MODULUS, (inst["path_siblings"], inst["position"]), inst["rcv"])
     # invalid diversifier -> Err(())
     bad = next(bytes([k]) * 11 for k in range(256) if _invalid_diversifier(bytes([k]) * 11, inst))
     with pytest.raises(P.ProvingError):
