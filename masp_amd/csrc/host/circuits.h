@@ -82,7 +82,7 @@ struct EdwardsPoint {
         AllocatedNum v2 = v.square(cs);
         AllocatedNum u2v2 = u2.mul(cs, v2);
         // -u^2 + v^2 = 1 + d u^2 v^2
-        cs.enforce(LC().sub(u2.var).add(v2.var), LC(ONE), LC(ONE).add(u2v2.var, edwards_d()));
+        MASP_ENFORCE(cs, LC().sub(u2.var).add(v2.var), LC(ONE), LC(ONE).add(u2v2.var, edwards_d()));
         return {u, v};
     }
     static EdwardsPoint witness(CS& cs, const JPoint& p) {
@@ -95,37 +95,37 @@ struct EdwardsPoint {
         // T = (u + v)^2
         Fr tv = (u.value + v.value).square();
         AllocatedNum t = AllocatedNum::alloc(cs, tv);
-        cs.enforce(LC(u.var).add(v.var), LC(u.var).add(v.var), LC(t.var));
+        MASP_ENFORCE(cs, LC(u.var).add(v.var), LC(u.var).add(v.var), LC(t.var));
         AllocatedNum a = u.mul(cs, v);
         // C = d A^2
         AllocatedNum c = AllocatedNum::alloc(cs, a.value.square() * edwards_d());
-        cs.enforce(LC().add(a.var, edwards_d()), LC(a.var), LC(c.var));
+        MASP_ENFORCE(cs, LC().add(a.var, edwards_d()), LC(a.var), LC(c.var));
         // u3 = 2A / (1 + C)
         Fr inv = Fr::zero();
         if (cs.has_witness() && !(Fr::one() + c.value).invert(inv)) throw SynthesisError("DivisionByZero");
         AllocatedNum u3 = AllocatedNum::alloc(cs, a.value.dbl() * inv);
-        cs.enforce(LC(ONE).add(c.var), LC(u3.var), LC(a.var).add(a.var));
+        MASP_ENFORCE(cs, LC(ONE).add(c.var), LC(u3.var), LC(a.var).add(a.var));
         // v3 = (T - 2A) / (1 - C)
         if (cs.has_witness() && !(Fr::one() - c.value).invert(inv)) throw SynthesisError("DivisionByZero");
         AllocatedNum v3 = AllocatedNum::alloc(cs, (t.value - a.value.dbl()) * inv);
-        cs.enforce(LC(ONE).sub(c.var), LC(v3.var), LC(t.var).sub(a.var).sub(a.var));
+        MASP_ENFORCE(cs, LC(ONE).sub(c.var), LC(v3.var), LC(t.var).sub(a.var).sub(a.var));
         return {u3, v3};
     }
     EdwardsPoint add(CS& cs, const EdwardsPoint& o) const {
         // U = (u1 + v1)(u2 + v2)
         AllocatedNum uu = AllocatedNum::alloc(cs, (u.value + v.value) * (o.u.value + o.v.value));
-        cs.enforce(LC(u.var).add(v.var), LC(o.u.var).add(o.v.var), LC(uu.var));
+        MASP_ENFORCE(cs, LC(u.var).add(v.var), LC(o.u.var).add(o.v.var), LC(uu.var));
         AllocatedNum a = o.v.mul(cs, u);  // A = v2 u1
         AllocatedNum b = o.u.mul(cs, v);  // B = u2 v1
         AllocatedNum c = AllocatedNum::alloc(cs, a.value * b.value * edwards_d());
-        cs.enforce(LC().add(a.var, edwards_d()), LC(b.var), LC(c.var));
+        MASP_ENFORCE(cs, LC().add(a.var, edwards_d()), LC(b.var), LC(c.var));
         Fr inv = Fr::zero();
         if (cs.has_witness() && !(Fr::one() + c.value).invert(inv)) throw SynthesisError("DivisionByZero");
         AllocatedNum u3 = AllocatedNum::alloc(cs, (a.value + b.value) * inv);
-        cs.enforce(LC(ONE).add(c.var), LC(u3.var), LC(a.var).add(b.var));
+        MASP_ENFORCE(cs, LC(ONE).add(c.var), LC(u3.var), LC(a.var).add(b.var));
         if (cs.has_witness() && !(Fr::one() - c.value).invert(inv)) throw SynthesisError("DivisionByZero");
         AllocatedNum v3 = AllocatedNum::alloc(cs, (uu.value - a.value - b.value) * inv);
-        cs.enforce(LC(ONE).sub(c.var), LC(v3.var), LC(uu.var).sub(a.var).sub(b.var));
+        MASP_ENFORCE(cs, LC(ONE).sub(c.var), LC(v3.var), LC(uu.var).sub(a.var).sub(b.var));
         return {u3, v3};
     }
     void assert_not_small_order(CS& cs) const {
@@ -146,9 +146,9 @@ struct EdwardsPoint {
     EdwardsPoint conditionally_select(CS& cs, const Boolean& cond) const {
         bool c = cond.value();
         AllocatedNum up = AllocatedNum::alloc(cs, c ? u.value : Fr::zero());
-        cs.enforce(LC(u.var), cond.lc(Fr::one()), LC(up.var));
+        MASP_ENFORCE(cs, LC(u.var), cond.lc(Fr::one()), LC(up.var));
         AllocatedNum vp = AllocatedNum::alloc(cs, c ? v.value : Fr::one());
-        cs.enforce(LC(v.var), cond.lc(Fr::one()), LC(vp.var).sub(cond.not_().lc(Fr::one())));
+        MASP_ENFORCE(cs, LC(v.var), cond.lc(Fr::one()), LC(vp.var).sub(cond.not_().lc(Fr::one())));
         return {up, vp};
     }
     EdwardsPoint mul(CS& cs, const std::vector<Boolean>& by) const {
@@ -184,11 +184,11 @@ struct MontgomeryPoint {
         Fr inv = Fr::zero();
         if (cs.has_witness() && !y.value.invert(inv)) throw SynthesisError("DivisionByZero");
         AllocatedNum u = AllocatedNum::alloc(cs, x.value * montgomery_scale() * inv);
-        cs.enforce(y.lc(Fr::one()), LC(u.var), x.lc(montgomery_scale()));
+        MASP_ENFORCE(cs, y.lc(Fr::one()), LC(u.var), x.lc(montgomery_scale()));
         // v = (x - 1) / (x + 1)
         if (cs.has_witness() && !(x.value + Fr::one()).invert(inv)) throw SynthesisError("DivisionByZero");
         AllocatedNum v = AllocatedNum::alloc(cs, (x.value - Fr::one()) * inv);
-        cs.enforce(x.lc(Fr::one()).add(ONE), LC(v.var), x.lc(Fr::one()).sub(ONE));
+        MASP_ENFORCE(cs, x.lc(Fr::one()).add(ONE), LC(v.var), x.lc(Fr::one()).sub(ONE));
         return {u, v};
     }
     // affine addition, undefined for equal x
@@ -196,13 +196,13 @@ struct MontgomeryPoint {
         Fr inv = Fr::zero();
         if (cs.has_witness() && !(o.x.value - x.value).invert(inv)) throw SynthesisError("DivisionByZero");
         AllocatedNum lambda = AllocatedNum::alloc(cs, (o.y.value - y.value) * inv);
-        cs.enforce(o.x.lc(Fr::one()).sub(x.lc(Fr::one())), LC(lambda.var), o.y.lc(Fr::one()).sub(y.lc(Fr::one())));
+        MASP_ENFORCE(cs, o.x.lc(Fr::one()).sub(x.lc(Fr::one())), LC(lambda.var), o.y.lc(Fr::one()).sub(y.lc(Fr::one())));
         // x'' = lambda^2 - A - x - x'
         AllocatedNum xp = AllocatedNum::alloc(cs, lambda.value.square() - montgomery_a() - x.value - o.x.value);
-        cs.enforce(LC(lambda.var), LC(lambda.var), LC().add(ONE, montgomery_a()).add(x.lc(Fr::one())).add(o.x.lc(Fr::one())).add(xp.var));
+        MASP_ENFORCE(cs, LC(lambda.var), LC(lambda.var), LC().add(ONE, montgomery_a()).add(x.lc(Fr::one())).add(o.x.lc(Fr::one())).add(xp.var));
         // y'' = -(y + lambda (x'' - x))
         AllocatedNum yp = AllocatedNum::alloc(cs, ((xp.value - x.value) * lambda.value + y.value).neg());
-        cs.enforce(x.lc(Fr::one()).sub(xp.var), LC(lambda.var), LC(yp.var).add(y.lc(Fr::one())));
+        MASP_ENFORCE(cs, x.lc(Fr::one()).sub(xp.var), LC(lambda.var), LC(yp.var).add(y.lc(Fr::one())));
         return {Num::from(xp), Num::from(yp)};
     }
 };
@@ -315,7 +315,7 @@ inline AllocatedNum merkle_ascend(CS& cs, AllocatedNum cur, const MerklePathW& p
 inline void conditional_anchor(CS& cs, const AllocatedNum& cur, const Num& value_num, const Fr& anchor) {
     AllocatedNum rt = AllocatedNum::alloc(cs, anchor);
     // (cur - rt) * value = 0
-    cs.enforce(LC(cur.var).sub(rt.var), value_num.lc(Fr::one()), LC());
+    MASP_ENFORCE(cs, LC(cur.var).sub(rt.var), value_num.lc(Fr::one()), LC());
     rt.inputize(cs);
 }
 

@@ -29,6 +29,15 @@ typedef uint32_t Var;  // input i -> i ; aux j -> AUX | j
 static const Var AUX = 0x80000000u;
 static const Var ONE = 0;
 
+// In proving mode nothing records constraints, so the three linear combinations are never even built.
+#define MASP_ENFORCE(CS_, A_, B_, C_)              \
+    do {                                           \
+        if ((CS_).recording())                     \
+            (CS_).enforce((A_), (B_), (C_));       \
+        else                                       \
+            (CS_).count_constraint();              \
+    } while (0)
+
 struct LC {
     std::vector<std::pair<Var, Fr>> t;
     LC() {}
@@ -70,6 +79,7 @@ class CS {
         inputs_.push_back(value);
         return (Var)(inputs_.size() - 1);
     }
+    void count_constraint() { ++n_constraints_; }
     void enforce(const LC& a, const LC& b, const LC& c) {
         ++n_constraints_;
         if (!record_) return;
@@ -182,38 +192,38 @@ struct AllocatedBit {
     static AllocatedBit alloc(CS& cs, bool value) {
         Var v = cs.alloc(value ? Fr::one() : Fr::zero());
         // (1 - a) * a = 0
-        cs.enforce(LC(ONE).sub(v), LC(v), LC());
+        MASP_ENFORCE(cs, LC(ONE).sub(v), LC(v), LC());
         return {v, value};
     }
     // a may be true only if must_be_false is false:  (1 - must_be_false - a) * a = 0
     static AllocatedBit alloc_conditionally(CS& cs, bool value, const AllocatedBit& must_be_false) {
         Var v = cs.alloc(value ? Fr::one() : Fr::zero());
-        cs.enforce(LC(ONE).sub(must_be_false.var).sub(v), LC(v), LC());
+        MASP_ENFORCE(cs, LC(ONE).sub(must_be_false.var).sub(v), LC(v), LC());
         return {v, value};
     }
     static AllocatedBit xor_(CS& cs, const AllocatedBit& a, const AllocatedBit& b) {
         bool r = a.value ^ b.value;
         Var v = cs.alloc(r ? Fr::one() : Fr::zero());
         // (a + a) * b = a + b - c
-        cs.enforce(LC(a.var).add(a.var), LC(b.var), LC(a.var).add(b.var).sub(v));
+        MASP_ENFORCE(cs, LC(a.var).add(a.var), LC(b.var), LC(a.var).add(b.var).sub(v));
         return {v, r};
     }
     static AllocatedBit and_(CS& cs, const AllocatedBit& a, const AllocatedBit& b) {
         bool r = a.value && b.value;
         Var v = cs.alloc(r ? Fr::one() : Fr::zero());
-        cs.enforce(LC(a.var), LC(b.var), LC(v));
+        MASP_ENFORCE(cs, LC(a.var), LC(b.var), LC(v));
         return {v, r};
     }
     static AllocatedBit and_not(CS& cs, const AllocatedBit& a, const AllocatedBit& b) {
         bool r = a.value && !b.value;
         Var v = cs.alloc(r ? Fr::one() : Fr::zero());
-        cs.enforce(LC(a.var), LC(ONE).sub(b.var), LC(v));
+        MASP_ENFORCE(cs, LC(a.var), LC(ONE).sub(b.var), LC(v));
         return {v, r};
     }
     static AllocatedBit nor(CS& cs, const AllocatedBit& a, const AllocatedBit& b) {
         bool r = !a.value && !b.value;
         Var v = cs.alloc(r ? Fr::one() : Fr::zero());
-        cs.enforce(LC(ONE).sub(a.var), LC(ONE).sub(b.var), LC(v));
+        MASP_ENFORCE(cs, LC(ONE).sub(a.var), LC(ONE).sub(b.var), LC(v));
         return {v, r};
     }
 };
@@ -272,12 +282,12 @@ struct Boolean {
             const Boolean& k = a.kind == CONST ? a : b;
             const Boolean& o = a.kind == CONST ? b : a;
             if (k.c)
-                cs.enforce(LC(), LC(), LC(ONE).sub(o.lc(Fr::one())));
+                MASP_ENFORCE(cs, LC(), LC(), LC(ONE).sub(o.lc(Fr::one())));
             else
-                cs.enforce(LC(), LC(), o.lc(Fr::one()));
+                MASP_ENFORCE(cs, LC(), LC(), o.lc(Fr::one()));
             return;
         }
-        cs.enforce(LC(), LC(), a.lc(Fr::one()).sub(b.lc(Fr::one())));
+        MASP_ENFORCE(cs, LC(), LC(), a.lc(Fr::one()).sub(b.lc(Fr::one())));
     }
 };
 
@@ -302,31 +312,31 @@ struct AllocatedNum {
     static AllocatedNum alloc(CS& cs, const Fr& value) { return {cs.alloc(value), value}; }
     void inputize(CS& cs) const {
         Var in = cs.alloc_input(value);
-        cs.enforce(LC(in), LC(ONE), LC(var));
+        MASP_ENFORCE(cs, LC(in), LC(ONE), LC(var));
     }
     AllocatedNum mul(CS& cs, const AllocatedNum& o) const {
         AllocatedNum r = alloc(cs, value * o.value);
-        cs.enforce(LC(var), LC(o.var), LC(r.var));
+        MASP_ENFORCE(cs, LC(var), LC(o.var), LC(r.var));
         return r;
     }
     AllocatedNum square(CS& cs) const {
         AllocatedNum r = alloc(cs, value.square());
-        cs.enforce(LC(var), LC(var), LC(r.var));
+        MASP_ENFORCE(cs, LC(var), LC(var), LC(r.var));
         return r;
     }
     void assert_nonzero(CS& cs) const {
         Fr inv = Fr::zero();
         if (cs.has_witness() && !value.invert(inv)) throw SynthesisError("DivisionByZero");
         Var v = cs.alloc(inv);
-        cs.enforce(LC(var), LC(v), LC(ONE));
+        MASP_ENFORCE(cs, LC(var), LC(v), LC(ONE));
     }
     // (c, d) = condition ? (b, a) : (a, b)
     static std::pair<AllocatedNum, AllocatedNum> conditionally_reverse(CS& cs, const AllocatedNum& a, const AllocatedNum& b,
                                                                        const Boolean& cond) {
         AllocatedNum c = alloc(cs, cond.value() ? b.value : a.value);
-        cs.enforce(LC(a.var).sub(b.var), cond.lc(Fr::one()), LC(a.var).sub(c.var));
+        MASP_ENFORCE(cs, LC(a.var).sub(b.var), cond.lc(Fr::one()), LC(a.var).sub(c.var));
         AllocatedNum d = alloc(cs, cond.value() ? a.value : b.value);
-        cs.enforce(LC(b.var).sub(a.var), cond.lc(Fr::one()), LC(b.var).sub(d.var));
+        MASP_ENFORCE(cs, LC(b.var).sub(a.var), cond.lc(Fr::one()), LC(b.var).sub(d.var));
         return {c, d};
     }
     // 255 plain bits + one unpacking constraint (no range check)
@@ -341,7 +351,7 @@ struct AllocatedNum {
             coeff = coeff.dbl();
         }
         lc.sub(var);
-        cs.enforce(LC(), LC(), lc);
+        MASP_ENFORCE(cs, LC(), LC(), lc);
         return bits;
     }
     // bits proven to be the canonical representation (<= r - 1): SURVEY.md Appendix B `to_bits_le_strict`
@@ -382,7 +392,7 @@ struct AllocatedNum {
             coeff = coeff.dbl();
         }
         lc.sub(var);
-        cs.enforce(LC(), LC(), lc);
+        MASP_ENFORCE(cs, LC(), LC(), lc);
         std::vector<Boolean> out;
         for (size_t k = result.size(); k-- > 0;) out.push_back(Boolean::from(result[k]));
         return out;
@@ -435,7 +445,7 @@ inline std::pair<AllocatedNum, AllocatedNum> lookup3_xy(CS& cs, const Boolean bi
         a.add(ONE, c[1]).add(bits[1].lc(c[3])).add(bits[2].lc(c[5])).add(precomp.lc(c[7]));
         LC cc(res[k]->var);
         cc.add(ONE, c[0].neg()).sub(bits[1].lc(c[2])).sub(bits[2].lc(c[4])).sub(precomp.lc(c[6]));
-        cs.enforce(a, bits[0].lc(Fr::one()), cc);
+        MASP_ENFORCE(cs, a, bits[0].lc(Fr::one()), cc);
     }
     return {rx, ry};
 }
@@ -464,7 +474,7 @@ inline std::pair<Num, Num> lookup3_xy_with_conditional_negation(CS& cs, const Bo
     a.add(ylc);
     LC c = ylc;
     c.sub(y.var);
-    cs.enforce(a, bits[2].lc(Fr::one()), c);
+    MASP_ENFORCE(cs, a, bits[2].lc(Fr::one()), c);
     return {x, Num::from(y)};
 }
 
@@ -475,7 +485,7 @@ struct MultiEq {
     LC lhs, rhs;
     explicit MultiEq(CS& c) : cs(c) {}
     void accumulate() {
-        cs.enforce(lhs, LC(ONE), rhs);
+        MASP_ENFORCE(cs, lhs, LC(ONE), rhs);
         lhs = LC();
         rhs = LC();
         bits_used = 0;
@@ -638,7 +648,7 @@ inline void pack_into_inputs(CS& cs, const std::vector<Boolean>& bits) {
             coeff = coeff.dbl();
         }
         Var in = cs.alloc_input(num.value);
-        cs.enforce(num.lc(Fr::one()), LC(ONE), LC(in));
+        MASP_ENFORCE(cs, num.lc(Fr::one()), LC(ONE), LC(in));
     }
 }
 

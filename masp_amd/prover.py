@@ -129,6 +129,40 @@ class LocalTxProver:
             raise ProvingError(str(e)) from None
         return dict(slot=CONVERT, inputs=inputs, aux=aux, cv=cv, rcv=rcv)
 
+    def prove_batch(self, ctx, descriptions, threads=None, rs=None):
+        """Batched form of the serial per-description loops of `SaplingBuilder::build`
+        (/root/reference/masp_primitives/src/transaction/components/sapling/builder.rs:935-1140):
+        descriptions = [("spend", kwargs) | ("output", kwargs) | ("convert", kwargs)] with the keyword arguments of
+        prepare_spend / prepare_output / prepare_convert.  Witness synthesis runs on `threads` host threads (the C++
+        synthesizer releases the GIL), all proofs go to the GPU as one batch, Spend / Convert proofs are self-verified,
+        and the context accumulates in description order, so bsk / cv_sum end up exactly as in the serial loops.
+        -> list of (zkproof, cv[, rk])"""
+        from concurrent.futures import ThreadPoolExecutor
+        prep = {"spend": self.prepare_spend, "output": self.prepare_output, "convert": self.prepare_convert}
+        with ThreadPoolExecutor(max_workers=threads or min(32, (os.cpu_count() or 1))) as ex:
+            jobs = list(ex.map(lambda d: prep[d[0]](**d[1]), descriptions))
+            proofs = self.prove_prepared(jobs, rs)
+            if self._self_verify:
+                def check(args):
+                    (kind, kw), job, zk = args
+                    if kind == "spend":
+                        pi = list(H.point_uv(job["rk"])) + list(H.point_uv(job["cv"])) + [_int(kw["anchor"])] + H.multipack(job["nf"])
+                        return self.spend_vk.verify(zk, pi)
+                    if kind == "convert":
+                        return self.convert_vk.verify(zk, list(H.point_uv(job["cv"])) + [_int(kw["anchor"])])
+                    return True
+                if not all(ex.map(check, zip(descriptions, jobs, proofs))):
+                    raise ProvingError("a proof failed self-verification")
+        out = []
+        for (kind, kw), job, zk in zip(descriptions, jobs, proofs):
+            if kind == "output":
+                ctx._output(kw["rcv"], job["cv"])
+                out.append((zk, job["cv"]))
+            else:
+                ctx._spend_like(kw["rcv"], job["cv"])
+                out.append((zk, job["cv"], job["rk"]) if kind == "spend" else (zk, job["cv"]))
+        return out
+
     def prove_prepared(self, jobs, rs=None):
         """jobs: outputs of prepare_*; rs: optional explicit [(r, s)] (deterministic replay) -> list of 192-byte proofs."""
         if rs is None:

@@ -290,3 +290,36 @@ def _invalid_diversifier(d, inst):
         return False
     except H.HostError:
         return True
+
+
+def test_local_tx_prover_batch_equals_serial(ctx):
+    """prove_batch (threaded synthesis + one GPU batch) == the serial TxProver calls, including the context state."""
+    import random
+    from masp_amd import host as H
+    from masp_amd import prover as P
+    from test_circuits import spend_instance
+    rng = random.Random(5)
+    lp = P.LocalTxProver.with_synthetic_parameters(seed=6)
+    descs, rs = [], []
+    for k in range(3):
+        inst, _, _ = spend_instance(400 + k, value=10 + k)
+        descs.append(("spend", dict(proof_generation_key=(inst["ak"], inst["nsk"]), diversifier=inst["diversifier"], rcm=inst["rcm"],
+                                    ar=inst["ar"], asset_type=inst["asset_identifier"], value=inst["value"], anchor=inst["anchor"],
+                                    merkle_path=(inst["path_siblings"], inst["position"]), rcv=inst["rcv"])))
+    gen = H.asset_generator(H.asset_identifier(b"asset 2"))
+    sib = [rng.randrange(H.FR_MODULUS) for _ in range(32)]
+    anchor = H.merkle_root(H.convert_cmu(gen), sib, 77)
+    descs.insert(1, ("convert", dict(allowed_conversion=gen, value=5, anchor=anchor, merkle_path=(sib, 77), rcv=rng.randrange(1, H.JUBJUB_ORDER))))
+    rs = [(rng.randrange(H.FR_MODULUS), rng.randrange(H.FR_MODULUS)) for _ in descs]
+    c1 = lp.new_sapling_proving_context()
+    batch = lp.prove_batch(c1, descs, rs=rs)
+    c2 = lp.new_sapling_proving_context()
+    serial = []
+    for (kind, kw), r in zip(descs, rs):
+        if kind == "spend":
+            serial.append(lp.spend_proof(c2, kw["proof_generation_key"], kw["diversifier"], kw["rcm"], kw["ar"], kw["asset_type"], kw["value"],
+                                         kw["anchor"], kw["merkle_path"], kw["rcv"], rs=r))
+        else:
+            serial.append(lp.convert_proof(c2, kw["allowed_conversion"], kw["value"], kw["anchor"], kw["merkle_path"], kw["rcv"], rs=r))
+    assert batch == serial and (c1.bsk, c1.cv_sum) == (c2.bsk, c2.cv_sum)
+    lp.close()
