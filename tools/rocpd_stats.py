@@ -20,6 +20,12 @@ def main(path):
     for name, n, tot, avg, mn, mx in rows:
         short = re.sub(r"\(.*", "", name)[:70]
         print("%-70s %8d %12.1f %12.2f %10.2f %10.2f %6.2f" % (short, n, tot / 1e3, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * tot / total))
+    # the dominant kernel by batch size (grid.y = proofs per launch): bench.py's live roofline leg times only the launches
+    # of its timed region, i.e. the rows with the full batch size
+    q2 = ("select d.grid_size_y, count(*), avg(d.end - d.start) from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s "
+          "on d.kernel_id = s.id where s.%s like '%%k_msm_accumulate<masp::FpOps>%%' group by d.grid_size_y order by 1" % name_col)
+    print("# k_msm_accumulate<G1> by proofs per launch (grid.y): " +
+          ", ".join("P=%d: %d launches, avg %.2f us" % (gy, n, avg / 1e3) for gy, n, avg in cur.execute(q2)))
     t0, t1 = cur.execute("select min(start), max(end) from rocpd_kernel_dispatch").fetchone()
     print("# span of all dispatches: %.3f ms; summed kernel time: %.3f ms" % ((t1 - t0) / 1e6, total / 1e6))
 
