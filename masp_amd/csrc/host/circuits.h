@@ -73,6 +73,14 @@ inline const CircuitTables& tables() {
     return t;
 }
 
+// 1/(1 + c) and 1/(1 - c) from a single inversion
+inline void inv_pair(const Fr& c, Fr& inv_plus, Fr& inv_minus) {
+    Fr p = Fr::one() + c, m = Fr::one() - c, i;
+    if (!(p * m).invert(i)) throw SynthesisError("DivisionByZero");
+    inv_plus = i * m;
+    inv_minus = i * p;
+}
+
 // ------------------------------------------------------------------------------------------- Edwards gadget
 struct EdwardsPoint {
     AllocatedNum u, v;
@@ -100,14 +108,12 @@ struct EdwardsPoint {
         // C = d A^2
         AllocatedNum c = AllocatedNum::alloc(cs, a.value.square() * edwards_d());
         MASP_ENFORCE(cs, LC().add(a.var, edwards_d()), LC(a.var), LC(c.var));
-        // u3 = 2A / (1 + C)
-        Fr inv = Fr::zero();
-        if (cs.has_witness() && !(Fr::one() + c.value).invert(inv)) throw SynthesisError("DivisionByZero");
-        AllocatedNum u3 = AllocatedNum::alloc(cs, a.value.dbl() * inv);
+        // u3 = 2A / (1 + C),  v3 = (T - 2A) / (1 - C): both inverses from one inversion of (1 + C)(1 - C)
+        Fr ip = Fr::zero(), im = Fr::zero();
+        if (cs.has_witness()) inv_pair(c.value, ip, im);
+        AllocatedNum u3 = AllocatedNum::alloc(cs, a.value.dbl() * ip);
         MASP_ENFORCE(cs, LC(ONE).add(c.var), LC(u3.var), LC(a.var).add(a.var));
-        // v3 = (T - 2A) / (1 - C)
-        if (cs.has_witness() && !(Fr::one() - c.value).invert(inv)) throw SynthesisError("DivisionByZero");
-        AllocatedNum v3 = AllocatedNum::alloc(cs, (t.value - a.value.dbl()) * inv);
+        AllocatedNum v3 = AllocatedNum::alloc(cs, (t.value - a.value.dbl()) * im);
         MASP_ENFORCE(cs, LC(ONE).sub(c.var), LC(v3.var), LC(t.var).sub(a.var).sub(a.var));
         return {u3, v3};
     }
@@ -119,12 +125,11 @@ struct EdwardsPoint {
         AllocatedNum b = o.u.mul(cs, v);  // B = u2 v1
         AllocatedNum c = AllocatedNum::alloc(cs, a.value * b.value * edwards_d());
         MASP_ENFORCE(cs, LC().add(a.var, edwards_d()), LC(b.var), LC(c.var));
-        Fr inv = Fr::zero();
-        if (cs.has_witness() && !(Fr::one() + c.value).invert(inv)) throw SynthesisError("DivisionByZero");
-        AllocatedNum u3 = AllocatedNum::alloc(cs, (a.value + b.value) * inv);
+        Fr ip = Fr::zero(), im = Fr::zero();
+        if (cs.has_witness()) inv_pair(c.value, ip, im);
+        AllocatedNum u3 = AllocatedNum::alloc(cs, (a.value + b.value) * ip);
         MASP_ENFORCE(cs, LC(ONE).add(c.var), LC(u3.var), LC(a.var).add(b.var));
-        if (cs.has_witness() && !(Fr::one() - c.value).invert(inv)) throw SynthesisError("DivisionByZero");
-        AllocatedNum v3 = AllocatedNum::alloc(cs, (uu.value - a.value - b.value) * inv);
+        AllocatedNum v3 = AllocatedNum::alloc(cs, (uu.value - a.value - b.value) * im);
         MASP_ENFORCE(cs, LC(ONE).sub(c.var), LC(v3.var), LC(uu.var).sub(a.var).sub(b.var));
         return {u3, v3};
     }
