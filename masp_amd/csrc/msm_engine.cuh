@@ -24,18 +24,20 @@ struct MsmBases {
         if (tab) hipFree(tab);
         tab = nullptr;
     }
-    static MsmGeom pick_geom(uint32_t n) {
-        // window width by problem size: the bucket reduction (2^(c-1) buckets) must stay small next to n * W additions
-        int c = n >= (1u << 15) ? 16 : n >= (1u << 12) ? 13 : n >= (1u << 8) ? 10 : 7;
+    // Window width by the number of scalars expected to be neither 0 nor 1 (`n_eff`; the caller knows the witness
+    // statistics of its circuit, a generic caller passes n): per non-trivial scalar the accumulation costs W = 256/c
+    // mixed additions, per bucket the gather + weighted sum cost ~5.5 full additions.
+    static MsmGeom pick_geom(uint32_t n_eff) {
+        int c = n_eff >= (1u << 16) ? 16 : n_eff >= (1u << 12) ? 13 : n_eff >= (1u << 8) ? 10 : 7;
         const char* e = getenv("MASP_HIP_MSM_C");
         if (e) c = atoi(e);
         return msm_geom(c);
     }
     // raw: device pointer to n uncompressed points (bellman wire format)
-    int load_device(const uint8_t* d_raw, uint32_t n_, hipStream_t s) {
+    int load_device(const uint8_t* d_raw, uint32_t n_, hipStream_t s, uint32_t n_eff = 0xffffffffu) {
         release();
         n = n_;
-        g = pick_geom(n);
+        g = pick_geom(std::min(n_eff, n_));
         if (n == 0) return MASP_HIP_OK;
         HIP_TRY(hipMalloc(&tab, sizeof(Affine<O>) * (size_t)g.W * n));
         int* d_status;
@@ -49,13 +51,13 @@ struct MsmBases {
         hipFree(d_status);
         return MASP_HIP_OK;
     }
-    int load_host(const uint8_t* raw, uint32_t n_, hipStream_t s) {
+    int load_host(const uint8_t* raw, uint32_t n_, hipStream_t s, uint32_t n_eff = 0xffffffffu) {
         uint8_t* d_raw = nullptr;
         if (n_) {
             HIP_TRY(hipMalloc(&d_raw, (size_t)n_ * BYTES));
             HIP_TRY(hipMemcpyAsync(d_raw, raw, (size_t)n_ * BYTES, hipMemcpyHostToDevice, s));
         }
-        int rc = load_device(d_raw, n_, s);
+        int rc = load_device(d_raw, n_, s, n_eff);
         if (d_raw) hipFree(d_raw);
         return rc;
     }

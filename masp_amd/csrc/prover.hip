@@ -500,8 +500,14 @@ int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* param
         if ((params[576] & 0x40) || (params[672] & 0x40)) return MASP_HIP_E_UNEXPECTED_IDENTITY;
     }
     // query vectors + window tables
-    if ((rc = C->h.load_host(L.h, (uint32_t)(C->m - 1), s)) || (rc = C->l.load_host(L.l, L.n_l, s)) || (rc = C->a.load_host(L.a, L.n_a, s)) ||
-        (rc = C->b1.load_host(L.b_g1, L.n_b1, s)) || (rc = C->b2.load_host(L.b_g2, L.n_b2, s)))
+    // h scalars are uniform in Fr; the witness queries are mostly 0 / 1 (70 % of a Spend witness is
+    // boolean-constrained), so their effective size for window selection is a fraction of their length
+    const char* fe = getenv("MASP_HIP_WITNESS_NONTRIVIAL_PERCENT");
+    const uint32_t pct = fe ? (uint32_t)atoi(fe) : 100;  // measured: narrower windows for the witness queries do not pay (their tails overlap anyway)
+    auto eff = [&](uint32_t n) { return (uint32_t)((uint64_t)n * pct / 100); };
+    if ((rc = C->h.load_host(L.h, (uint32_t)(C->m - 1), s)) || (rc = C->l.load_host(L.l, L.n_l, s, eff(L.n_l))) ||
+        (rc = C->a.load_host(L.a, L.n_a, s, eff(L.n_a))) || (rc = C->b1.load_host(L.b_g1, L.n_b1, s, eff(L.n_b1))) ||
+        (rc = C->b2.load_host(L.b_g2, L.n_b2, s, eff(L.n_b2))))
         return fail(ctx, rc);
     int st = C->h.import_status | C->l.import_status | C->a.import_status | C->b1.import_status | C->b2.import_status;
     if (st) return MASP_HIP_E_PARAMS_FORMAT;  // includes infinity inside a query vector, which bellman rejects
