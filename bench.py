@@ -24,15 +24,17 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 WORKLOAD = os.environ.get("MASP_BENCH_CIRCUIT", "spend")
 
 
-def make_jobs(n_distinct, total, shaped):
-    """`total` jobs cycling over `n_distinct` independent witnesses, each with its own (r, s)."""
+def make_jobs(n_distinct, total, instances):
+    """`total` jobs, job j of circuit slot j mod len(instances), cycling over `n_distinct` independent witnesses per
+    circuit, each job with its own (r, s)."""
     import random
     rng = random.Random(0x5962be3d)  # the reference bench's XorShift seed bytes, benches/sapling.rs:19-22
     R = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
     jobs = []
     for j in range(total):
-        _, inputs, aux = shaped[j % n_distinct]
-        jobs.append((0, inputs, aux, rng.randrange(R), rng.randrange(R)))
+        slot = j % len(instances)
+        _, inputs, aux = instances[slot][(j // len(instances)) % n_distinct]
+        jobs.append((slot, inputs, aux, rng.randrange(R), rng.randrange(R)))
     return jobs
 
 
@@ -126,22 +128,27 @@ def main():
 
     ctx = masp_amd.Context(local_rank)
     n_distinct = 4
+    kinds = ["spend", "output", "convert"] if WORKLOAD == "mixed" else [WORKLOAD]   # mixed = BASELINE.json configs[4] job mix
     if os.environ.get("MASP_BENCH_SYNTHETIC_SHAPE"):
-        shaped = [synthetic.shaped(WORKLOAD, seed=rank * 1000 + k) for k in range(n_distinct)]
+        instances = [[synthetic.shaped(k, seed=rank * 1000 + i) for i in range(n_distinct)] for k in kinds]
         circuit_desc = "%s-SHAPED synthetic R1CS (masp_amd/synthetic.py)" % WORKLOAD
     else:
-        shaped = real_instances(WORKLOAD, n_distinct, rank)
-        circuit_desc = "the real MASP %s circuit (structure hash pinned to the reference's KAT), witnesses from the C++ synthesizer" % WORKLOAD
+        instances = [real_instances(k, n_distinct, rank) for k in kinds]
+        circuit_desc = "the real MASP %s circuit(s) (structure hashes pinned to the reference's KATs), witnesses from the C++ synthesizer" % "/".join(kinds)
+    shaped = instances[0]
     cs = shaped[0][0]
-    params = ctx.generate_parameters(cs, synthetic.toxic_waste(1))   # same CRS on every rank
-    ctx.load_circuit(0, params, cs)
+    params = None
+    for slot, inst in enumerate(instances):
+        p_ = ctx.generate_parameters(inst[0][0], synthetic.toxic_waste(1 + slot))   # same CRS on every rank
+        ctx.load_circuit(slot, p_, inst[0][0])
+        params = params if params is not None else p_
     K, W = args.steps, args.warmup
-    warm = ctx.batch_upload(make_jobs(n_distinct, max(W, 1), shaped))
-    timed = ctx.batch_upload(make_jobs(n_distinct, K, shaped))
+    warm = ctx.batch_upload(make_jobs(n_distinct, max(W, 1), instances))
+    timed = ctx.batch_upload(make_jobs(n_distinct, K, instances))
     if W > 0:
         ctx.batch_prove_resident(*warm)
     # single-proof latency (not the headline value)
-    one = ctx.batch_upload(make_jobs(n_distinct, 1, shaped))
+    one = ctx.batch_upload(make_jobs(n_distinct, 1, instances))
     t0 = time.perf_counter()
     ctx.batch_prove_resident(*one)
     latency_ms = (time.perf_counter() - t0) * 1e3
@@ -185,15 +192,15 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "Spend proofs/sec", "value": total / elapsed, "unit": "proofs/s", "n_gpus": world, "steps": K, "warmup": W,
+            "metric": "Spend proofs/sec" if WORKLOAD == "spend" else "%s proofs/sec" % WORKLOAD, "value": total / elapsed, "unit": "proofs/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 limbs (384-bit Fp / 255-bit Fr modular integers)", "data": "synthetic",
             "config": {"workload": "single %s proof per step (BASELINE.json configs[1]); %s + synthetic CRS from known toxic waste "
                                    "(NTT 2^%d, G1 MSMs %d/%d/%d/%d, G2 MSM %d), witness resident in HBM, "
                                    "batches of %s proofs per launch sequence on %s HIP streams"
                                    % (WORKLOAD, circuit_desc, cs.logm, (1 << cs.logm) - 1, cs.n_aux,
-                                      synthetic.SHAPES[WORKLOAD][3] + cs.n_inputs, synthetic.SHAPES[WORKLOAD][4] + 1,
-                                      synthetic.SHAPES[WORKLOAD][4] + 1, os.environ.get("MASP_HIP_BATCH"), os.environ.get("MASP_HIP_SLOTS")),
+                                      synthetic.SHAPES[kinds[0]][3] + cs.n_inputs, synthetic.SHAPES[kinds[0]][4] + 1,
+                                      synthetic.SHAPES[kinds[0]][4] + 1, os.environ.get("MASP_HIP_BATCH"), os.environ.get("MASP_HIP_SLOTS")),
                        "proofs_per_gpu": K, "parallelism": "proofs sharded over %d GPU(s), RCCL gather of proofs" % world},
             "single_proof_latency_ms": latency_ms,
             "gpu_event_ms_per_step": gpu_ms / K,

@@ -177,8 +177,9 @@ struct Slot {
 
 struct ResidentBatch {
     size_t n = 0;
-    std::vector<uint32_t> circuit;
-    std::vector<size_t> w_off;  // element offsets into w
+    std::vector<uint32_t> circuit;  // in STORAGE order: jobs are stored grouped by circuit so that batches are strided
+    std::vector<size_t> order;      // storage position -> caller's job index
+    std::vector<size_t> w_off;      // element offsets into w
     DevBuf<Fr> w;
     DevBuf<uint32_t> rs;        // n x 16
 };
@@ -527,17 +528,22 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
         if ((J.a || J.b || J.c) && !(J.a && J.b && J.c)) return MASP_HIP_E_INVALID_ARG;
         if (!rs_in_range(J.r) || !rs_in_range(J.s)) return MASP_HIP_E_SCALAR_RANGE;
     }
-    // consecutive jobs of the same circuit (and the same a/b/c mode) form batches of up to batch_cap() proofs
+    // jobs are bucketed by (circuit, a/b/c mode) — whatever their order in the list — and every bucket is cut into
+    // batches of up to batch_cap() proofs; results go back to the jobs' own positions
     struct Group {
-        size_t first, count;
+        std::vector<size_t> idx;
     };
     std::vector<Group> groups;
     const size_t cap = batch_cap();
-    for (size_t j = 0; j < n;) {
-        size_t k = j + 1;
-        while (k < n && k - j < cap && jobs[k].circuit == jobs[j].circuit && (jobs[k].a != nullptr) == (jobs[j].a != nullptr)) ++k;
-        groups.push_back({j, k - j});
-        j = k;
+    {
+        std::map<std::pair<uint32_t, bool>, std::vector<size_t>> by_kind;
+        for (size_t j = 0; j < n; ++j) by_kind[{jobs[j].circuit, jobs[j].a != nullptr}].push_back(j);
+        for (auto& kv : by_kind)
+            for (size_t o = 0; o < kv.second.size(); o += cap) {
+                Group g;
+                g.idx.assign(kv.second.begin() + o, kv.second.begin() + std::min(kv.second.size(), o + cap));
+                groups.push_back(std::move(g));
+            }
     }
     size_t ns = std::min<size_t>(std::max<size_t>(groups.size(), 1), n_slots_default());
     int rc = ensure_slots(ctx, ns);
@@ -554,7 +560,7 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
         } else if (*sl.h_flags) {
             result = MASP_HIP_E_SCALAR_RANGE;
         } else if (result == MASP_HIP_OK) {
-            memcpy(proofs_out + 192 * G.first, sl.h_proof, 192 * G.count);
+            for (size_t p = 0; p < G.idx.size(); ++p) memcpy(proofs_out + 192 * G.idx[p], sl.h_proof + 192 * p, 192);
         }
         owner[si] = -1;
     };
@@ -564,9 +570,9 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
         if (result) break;
         const Group& G = groups[gi];
         Slot& sl = *ctx->slots[si];
-        Circuit& C = *ctx->circ[jobs[G.first].circuit];
-        const size_t nv = (size_t)C.n_inputs + C.n_aux, np = G.count;
-        const bool has_abc = jobs[G.first].a != nullptr;
+        Circuit& C = *ctx->circ[jobs[G.idx[0]].circuit];
+        const size_t nv = (size_t)C.n_inputs + C.n_aux, np = G.idx.size();
+        const bool has_abc = jobs[G.idx[0]].a != nullptr;
         // staging layout: [np][nv] witness | (a | b | c each [np][nrows]) | [np][16] r,s limbs
         const size_t w_bytes = 32 * nv * np, abc_bytes = has_abc ? 3 * 32 * (size_t)C.nrows * np : 0, rs_bytes = 64 * np;
         if ((rc = sl.stage_reserve(w_bytes + abc_bytes + rs_bytes)) || (rc = sl.w.reserve(nv * np)) ||
@@ -576,7 +582,7 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
         }
         uint8_t* hs = sl.h_stage;
         for (size_t p = 0; p < np; ++p) {
-            const masp_hip_job& J = jobs[G.first + p];
+            const masp_hip_job& J = jobs[G.idx[p]];
             memcpy(hs + 32 * nv * p, J.inputs, 32 * (size_t)C.n_inputs);
             memcpy(hs + 32 * nv * p + 32 * (size_t)C.n_inputs, J.aux, 32 * (size_t)C.n_aux);
             if (has_abc) {
@@ -916,19 +922,25 @@ int masp_hip_batch_upload(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs)
     for (size_t j = 0; j < n; ++j) {
         if (jobs[j].circuit >= MASP_HIP_MAX_CIRCUITS || !ctx->circ[jobs[j].circuit]) return -MASP_HIP_E_NOT_LOADED;
         if (!rs_in_range(jobs[j].r) || !rs_in_range(jobs[j].s)) return -MASP_HIP_E_SCALAR_RANGE;
-        Circuit& C = *ctx->circ[jobs[j].circuit];
-        B->circuit.push_back(jobs[j].circuit);
-        B->w_off.push_back(total);
-        total += (size_t)C.n_inputs + C.n_aux;
     }
+    for (uint32_t c = 0; c < MASP_HIP_MAX_CIRCUITS; ++c)
+        for (size_t j = 0; j < n; ++j)
+            if (jobs[j].circuit == c) {
+                Circuit& C = *ctx->circ[c];
+                B->circuit.push_back(c);
+                B->order.push_back(j);
+                B->w_off.push_back(total);
+                total += (size_t)C.n_inputs + C.n_aux;
+            }
     if (B->w.reserve(total) || B->rs.reserve(16 * n)) return -fail(ctx, MASP_HIP_E_HIP);
     hipStream_t s = ctx->main_stream;
-    for (size_t j = 0; j < n; ++j) {
-        Circuit& C = *ctx->circ[jobs[j].circuit];
-        bool ok = hipMemcpyAsync(B->w.p + B->w_off[j], jobs[j].inputs, 32 * (size_t)C.n_inputs, hipMemcpyHostToDevice, s) == hipSuccess &&
-                  hipMemcpyAsync(B->w.p + B->w_off[j] + C.n_inputs, jobs[j].aux, 32 * (size_t)C.n_aux, hipMemcpyHostToDevice, s) == hipSuccess &&
-                  hipMemcpyAsync(B->rs.p + 16 * j, jobs[j].r, 32, hipMemcpyHostToDevice, s) == hipSuccess &&
-                  hipMemcpyAsync(B->rs.p + 16 * j + 8, jobs[j].s, 32, hipMemcpyHostToDevice, s) == hipSuccess;
+    for (size_t k = 0; k < n; ++k) {
+        const masp_hip_job& J = jobs[B->order[k]];
+        Circuit& C = *ctx->circ[J.circuit];
+        bool ok = hipMemcpyAsync(B->w.p + B->w_off[k], J.inputs, 32 * (size_t)C.n_inputs, hipMemcpyHostToDevice, s) == hipSuccess &&
+                  hipMemcpyAsync(B->w.p + B->w_off[k] + C.n_inputs, J.aux, 32 * (size_t)C.n_aux, hipMemcpyHostToDevice, s) == hipSuccess &&
+                  hipMemcpyAsync(B->rs.p + 16 * k, J.r, 32, hipMemcpyHostToDevice, s) == hipSuccess &&
+                  hipMemcpyAsync(B->rs.p + 16 * k + 8, J.s, 32, hipMemcpyHostToDevice, s) == hipSuccess;
         if (!ok || hipStreamSynchronize(s) != hipSuccess) return -fail(ctx, MASP_HIP_E_HIP);
     }
     for (size_t k = 0; k < ctx->batches.size(); ++k)
@@ -990,8 +1002,10 @@ int masp_hip_batch_prove_resident(masp_hip_ctx* ctx, int handle, uint8_t* proofs
         HIP_TRY(hipStreamWaitEvent(ms, ctx->slots[si]->done, 0));
     }
     HIP_TRY(hipEventRecord(ev_stop, ms));
-    HIP_TRY(hipMemcpyAsync(proofs_out, d_proofs.p, 192 * B.n, hipMemcpyDeviceToHost, ms));
+    std::vector<uint8_t> stored(192 * B.n);
+    HIP_TRY(hipMemcpyAsync(stored.data(), d_proofs.p, 192 * B.n, hipMemcpyDeviceToHost, ms));
     HIP_TRY(hipStreamSynchronize(ms));
+    for (size_t k = 0; k < B.n; ++k) memcpy(proofs_out + 192 * B.order[k], stored.data() + 192 * k, 192);
     if (elapsed_ms) HIP_TRY(hipEventElapsedTime(elapsed_ms, ev_start, ev_stop));
     hipEventDestroy(ev_start);
     hipEventDestroy(ev_stop);
@@ -1049,6 +1063,11 @@ int masp_hip_bench_msm(masp_hip_ctx* ctx, int handle, size_t job, int which, int
     hipSetDevice(ctx->device);
     ResidentBatch& B = *ctx->batches[handle];
     if (job >= B.n) return MASP_HIP_E_INVALID_ARG;
+    for (size_t k = 0; k < B.n; ++k)
+        if (B.order[k] == job) {
+            job = k;
+            break;
+        }
     int rc;
     if ((rc = ensure_slots(ctx, 1))) return fail(ctx, rc);
     Slot& sl = *ctx->slots[0];
