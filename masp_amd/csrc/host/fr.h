@@ -7,9 +7,9 @@
 #include <cstring>
 #include <string>
 
-namespace masp_host {
+#include "mont.h"
 
-typedef unsigned __int128 u128;
+namespace masp_host {
 
 struct Fr {
     uint64_t l[4];
@@ -69,34 +69,7 @@ struct Fr {
         }
         return borrow;
     }
-    static void mont_mul(uint64_t* out, const uint64_t* a, const uint64_t* b) {
-        const uint64_t* p = modulus();
-        const uint64_t inv = k().inv;
-        uint64_t t[6] = {0, 0, 0, 0, 0, 0};
-        for (int i = 0; i < 4; ++i) {
-            u128 carry = 0;
-            for (int j = 0; j < 4; ++j) {
-                u128 x = (u128)a[j] * b[i] + t[j] + carry;
-                t[j] = (uint64_t)x;
-                carry = x >> 64;
-            }
-            u128 x = (u128)t[4] + carry;
-            t[4] = (uint64_t)x;
-            t[5] = (uint64_t)(x >> 64);
-            uint64_t m = t[0] * inv;
-            carry = ((u128)m * p[0] + t[0]) >> 64;
-            for (int j = 1; j < 4; ++j) {
-                u128 y = (u128)m * p[j] + t[j] + carry;
-                t[j - 1] = (uint64_t)y;
-                carry = y >> 64;
-            }
-            x = (u128)t[4] + carry;
-            t[3] = (uint64_t)x;
-            t[4] = t[5] + (uint64_t)(x >> 64);
-        }
-        if (t[4] || ge(t, p)) sub_raw(t, t, p);
-        memcpy(out, t, 32);
-    }
+    static void mont_mul(uint64_t* out, const uint64_t* a, const uint64_t* b) { mont_mul_n<4>(out, a, b, modulus(), k().inv); }
 
     static Fr zero() { return Fr{{0, 0, 0, 0}}; }
     static Fr one() {
@@ -148,50 +121,11 @@ struct Fr {
             }
         return r;
     }
-    // returns false for zero (no inverse).  Binary extended Euclid on the raw limbs (witness synthesis performs
-    // ~8 000 inversions per Spend; a Fermat power made them 85 % of the synthesis time).
+    // returns false for zero (no inverse).  Batched-divstep inversion on the raw limbs (mont.h).
     bool invert(Fr& out) const {
-        if (is_zero()) return false;
-        const uint64_t* p = modulus();
-        uint64_t u[4], v[4], x1[4] = {1, 0, 0, 0}, x2[4] = {0, 0, 0, 0};
-        memcpy(u, l, 32);  // the Montgomery representative a*R: its plain inverse is a^-1 * R^-1
-        memcpy(v, p, 32);
-        auto is_one = [](const uint64_t* a) { return a[0] == 1 && (a[1] | a[2] | a[3]) == 0; };
-        auto shr1 = [](uint64_t* a, uint64_t top) {
-            a[0] = (a[0] >> 1) | (a[1] << 63);
-            a[1] = (a[1] >> 1) | (a[2] << 63);
-            a[2] = (a[2] >> 1) | (a[3] << 63);
-            a[3] = (a[3] >> 1) | (top << 63);
-        };
-        auto halve_mod = [&](uint64_t* x) {  // x / 2 mod p
-            if (x[0] & 1) {
-                uint64_t c = add_raw(x, x, p);
-                shr1(x, c);
-            } else {
-                shr1(x, 0);
-            }
-        };
-        auto sub_mod = [&](uint64_t* x, const uint64_t* y) {
-            if (sub_raw(x, x, y)) add_raw(x, x, p);
-        };
-        while (!is_one(u) && !is_one(v)) {
-            while (!(u[0] & 1)) {
-                shr1(u, 0);
-                halve_mod(x1);
-            }
-            while (!(v[0] & 1)) {
-                shr1(v, 0);
-                halve_mod(x2);
-            }
-            if (ge(u, v)) {
-                sub_raw(u, u, v);
-                sub_mod(x1, x2);
-            } else {
-                sub_raw(v, v, u);
-                sub_mod(x2, x1);
-            }
-        }
-        const uint64_t* r = is_one(u) ? x1 : x2;  // (a R)^-1 mod p
+        static const ModInv<4> inv(modulus());
+        uint64_t r[4];  // (a R)^-1 mod p from the Montgomery representative a R
+        if (!inv.invert(r, l)) return false;
         // to Montgomery form of a^-1:  (aR)^-1 * R^2 = a^-1 R : two Montgomery products by R^2
         uint64_t t[4];
         mont_mul(t, r, k().r2);

@@ -13,15 +13,26 @@ using namespace masp_host;
 
 namespace masp_host {
 namespace bls {
-#include "pairing_consts.inc"
 const PairingK& pairing_k() {
     static PairingK k = [] {
         PairingK c;
-        Fp12 w = {Fp6::zero(), Fp6::one()};  // w
-        Fp12 w2 = w * w, w3 = w2 * w;
-        c.w2i = w2.inv();
-        c.w3i = w3.inv();
-        c.hard.assign(HARD_EXP_LIMBS, HARD_EXP_LIMBS + sizeof(HARD_EXP_LIMBS) / 8);
+        // (p - 1) / 6
+        uint64_t e[6], one_[6] = {1, 0, 0, 0, 0, 0};
+        Fp::subr(e, Fp::P(), one_);
+        uint64_t rem = 0;
+        for (int i = 5; i >= 0; --i) {
+            u128 cur = ((u128)rem << 64) | e[i];
+            e[i] = (uint64_t)(cur / 6);
+            rem = (uint64_t)(cur % 6);
+        }
+        Fp2 xi = {Fp::one(), Fp::one()}, g = Fp2::one();
+        for (int i = 5; i >= 0; --i)
+            for (int b = 63; b >= 0; --b) {
+                g = g.sq();
+                if ((e[i] >> b) & 1) g = g * xi;
+            }
+        c.gamma[0] = Fp2::one();
+        for (int i = 1; i < 6; ++i) c.gamma[i] = c.gamma[i - 1] * g;
         return c;
     }();
     return k;
@@ -30,11 +41,36 @@ const PairingK& pairing_k() {
 }  // namespace masp_host
 
 namespace {
-// PreparedVerifyingKey (lib.rs:391-393): the Miller value of (alpha, beta) is computed once
+// PreparedVerifyingKey (lib.rs:391-393): the Miller value of (alpha, beta) is computed once; each IC point carries a
+// table of d * 16^w * IC (d = 1..15, w = 0..63) so that the public-input combination costs 64 additions per input.
 struct PreparedVk {
     bls::Fp12 alpha_beta;
     bls::G2A gamma, delta;
     std::vector<bls::G1A> ic;
+    std::vector<std::vector<bls::G1J>> ic_tab;  // [input][w * 15 + d - 1]
+    void build_tables() {
+        ic_tab.resize(ic.size());
+        for (size_t i = 1; i < ic.size(); ++i) {
+            auto& t = ic_tab[i];
+            t.resize(64 * 15);
+            bls::G1J base = bls::G1J::from(ic[i]);
+            for (int w = 0; w < 64; ++w) {
+                t[w * 15] = base;
+                for (int d = 2; d <= 15; ++d) t[w * 15 + d - 1] = t[w * 15 + d - 2].add(base);
+                base = t[w * 15 + 7].dbl();  // 16 * base
+            }
+        }
+    }
+    // IC_i * k for a 32-byte little-endian scalar
+    bls::G1J ic_mul(size_t i, const uint8_t* k32) const {
+        bls::G1J r = bls::G1J::inf();
+        const auto& t = ic_tab[i];
+        for (int w = 0; w < 64; ++w) {
+            int d = (k32[w >> 1] >> ((w & 1) * 4)) & 15;
+            if (d) r = r.add(t[w * 15 + d - 1]);
+        }
+        return r;
+    }
 };
 }  // namespace
 
@@ -213,6 +249,7 @@ void* masp_host_vk_prepare(const uint8_t* params, size_t len) {
     for (uint32_t i = 0; i < n; ++i)
         if (!bls::g1_uncompressed(vk->ic[i], params + 868 + 96 * (size_t)i)) return nullptr;
     vk->alpha_beta = bls::miller(alpha, beta);
+    vk->build_tables();
     return vk.release();
 }
 void masp_host_vk_free(void* h) { delete (PreparedVk*)h; }
@@ -227,12 +264,74 @@ int masp_host_vk_verify(const void* h, const uint8_t proof[192], const uint8_t* 
     for (uint32_t i = 0; i < n_public; ++i) {
         Fr chk;
         if (!Fr::from_bytes(chk, public_inputs + 32 * i)) return -3;
-        acc = acc.add(bls::G1J::from(vk.ic[i + 1]).mul_le(public_inputs + 32 * i));
+        acc = acc.add(vk.ic_mul(i + 1, public_inputs + 32 * i));
     }
-    // e(A, B) == e(alpha, beta) e(acc, gamma) e(C, delta)   <=>   ML(A,B) / (ML(alpha,beta) ML(acc,gamma) ML(C,delta)) -> 1
-    bls::Fp12 lhs = bls::miller(a, b);
-    bls::Fp12 rhs = vk.alpha_beta * bls::miller(acc.affine(), vk.gamma) * bls::miller(c, vk.delta);
-    return bls::final_exp(lhs * rhs.inv()) == bls::Fp12::one() ? 1 : 0;
+    // e(A, B) == e(alpha, beta) e(acc, gamma) e(C, delta)   <=>   ML(A,B) ML(-acc,gamma) ML(-C,delta) / ML(alpha,beta) -> 1
+    // (conj = inverse once final-exponentiated)
+    bls::G1A nacc = acc.affine(), nc = c;
+    nacc.y = nacc.y.neg();
+    nc.y = nc.y.neg();
+    std::vector<bls::MillerPair> pairs;
+    if (!a.inf && !b.inf) pairs.emplace_back(a, b);
+    if (!nacc.inf) pairs.emplace_back(nacc, vk.gamma);
+    if (!nc.inf) pairs.emplace_back(nc, vk.delta);
+    bls::Fp12 f = bls::multi_miller(pairs) * vk.alpha_beta.conj();
+    return bls::final_exp(f) == bls::Fp12::one() ? 1 : 0;
+}
+// Batched form (bellman `verify_proofs_batch`, reached from /root/reference/masp_proofs/src/sapling/verifier/batch.rs:24-31):
+// with random z_i,  prod_i e(z_i A_i, B_i) == e(alpha,beta)^(sum z_i) e(sum_i z_i acc_i, gamma) e(sum_i z_i C_i, delta).
+// proofs: n x 192 B; public_inputs: n x n_public x 32 B; z: n x 16 B of caller-supplied randomness (128-bit coefficients).
+// 1 = all valid, 0 = at least one invalid (the caller re-checks one by one to find it), < 0 = malformed.
+int masp_host_vk_verify_batch(const void* h, size_t n, const uint8_t* proofs, const uint8_t* public_inputs, uint32_t n_public,
+                              const uint8_t* z) {
+    const PreparedVk& vk = *(const PreparedVk*)h;
+    if ((size_t)n_public + 1 != vk.ic.size()) return -1;
+    if (n == 0) return 1;
+    std::vector<bls::MillerPair> pairs;
+    pairs.reserve(n + 2);
+    std::vector<Fr> coef(n_public + 1, Fr::zero());  // sum_i z_i * input_ij  (j = 0: the constant ONE)
+    bls::G1J csum = bls::G1J::inf();
+    for (size_t i = 0; i < n; ++i) {
+        const uint8_t* pr = proofs + 192 * i;
+        bls::G1A a, c;
+        bls::G2A b;
+        if (!bls::g1_compressed(a, pr) || !bls::g2_compressed(b, pr + 48) || !bls::g1_compressed(c, pr + 144)) return -2;
+        uint8_t zi[32] = {0};
+        memcpy(zi, z + 16 * i, 16);
+        zi[0] |= 1;  // never zero
+        Fr zf;
+        Fr::from_bytes(zf, zi);
+        coef[0] = coef[0] + zf;
+        for (uint32_t j = 0; j < n_public; ++j) {
+            Fr in;
+            if (!Fr::from_bytes(in, public_inputs + 32 * ((size_t)i * n_public + j))) return -3;
+            coef[j + 1] = coef[j + 1] + zf * in;
+        }
+        bls::G1A za = bls::G1J::from(a).mul_le(zi, 128).affine();
+        csum = csum.add(bls::G1J::from(c).mul_le(zi, 128));
+        if (!za.inf && !b.inf) pairs.emplace_back(za, b);
+    }
+    uint8_t k32[32];
+    coef[0].to_bytes(k32);
+    bls::G1J acc = bls::G1J::from(vk.ic[0]).mul_le(k32, 256);
+    for (uint32_t j = 0; j < n_public; ++j) {
+        uint8_t kj[32];
+        coef[j + 1].to_bytes(kj);
+        acc = acc.add(vk.ic_mul(j + 1, kj));
+    }
+    bls::G1A nacc = acc.affine(), nc = csum.affine();
+    nacc.y = nacc.y.neg();
+    nc.y = nc.y.neg();
+    if (!nacc.inf) pairs.emplace_back(nacc, vk.gamma);
+    if (!nc.inf) pairs.emplace_back(nc, vk.delta);
+    // alpha_beta^(sum z)
+    bls::Fp12 ab = bls::Fp12::one();
+    for (int bit = 255; bit >= 0; --bit) {
+        ab = ab.sq();
+        if ((k32[bit >> 3] >> (bit & 7)) & 1) ab = ab * vk.alpha_beta;
+    }
+    bls::Fp12 f = bls::multi_miller(pairs) * ab.conj();
+    return bls::final_exp(f) == bls::Fp12::one() ? 1 : 0;
 }
 
 // ---- native primitives (pinned by the reference's vectors in tests/) ---------------------------------

@@ -2,19 +2,21 @@
 //   `verify_proof(verifying_key, &proof, &public_input)` at /root/reference/masp_proofs/src/sapling/prover.rs:148,266
 //   with `PreparedVerifyingKey` built at /root/reference/masp_proofs/src/lib.rs:391-393
 // (nam-bellperson / pairing 0.23 / blst, un-vendored).  SURVEY.md §8 row a12: "CPU, ~ms; stays on host".
-// BLS12-381 base field in 6 x 64-bit limbs, the Fp2/Fp6/Fp12 tower, zcash point decoding, an ate Miller loop over
-// E(Fp12) and the final exponentiation  f^((p^12-1)/r)  split as  (p^6-1)(p^2+1) * (p^4-p^2+1)/r  with the first two
-// factors done by conjugation / Frobenius-free inversion and squaring tricks kept deliberately simple.
-// Product code (libmasp_host); independent of oracle/.
+// BLS12-381 base field in 6 x 64-bit limbs, the Fp2/Fp6/Fp12 tower, zcash point decoding, a multi-pair ate Miller loop
+// (G2 in homogeneous projective coordinates on the twist, sparse line evaluations, one shared squaring chain) and the
+// final exponentiation  f^(3 (p^12-1)/r)  =  easy part (p^6-1)(p^2+1) by conjugation / inversion / Frobenius, hard part
+//   3 (p^4-p^2+1)/r = (x-1)^2 (x+p) (x^2+p^2-1) + 3      (x = -0xd201000000010000; identity checked in tools/)
+// as five exponentiations by |x|.  The factor 3 is coprime to r, so "== 1" is unchanged.
+// Product code (libmasp_host); independent of oracle/ (whose own slow pairing is what the tests compare against).
 #pragma once
 #include <cstdint>
 #include <cstring>
 #include <vector>
 
+#include "mont.h"
+
 namespace masp_host {
 namespace bls {
-
-typedef unsigned __int128 u128;
 
 struct Fp {
     uint64_t l[6];
@@ -67,34 +69,7 @@ struct Fp {
         }();
         return c;
     }
-    static void mm(uint64_t* out, const uint64_t* a, const uint64_t* b) {
-        const uint64_t* p = P();
-        const uint64_t inv = k().inv;
-        uint64_t t[8] = {0};
-        for (int i = 0; i < 6; ++i) {
-            u128 c = 0;
-            for (int j = 0; j < 6; ++j) {
-                u128 x = (u128)a[j] * b[i] + t[j] + c;
-                t[j] = (uint64_t)x;
-                c = x >> 64;
-            }
-            u128 x = (u128)t[6] + c;
-            t[6] = (uint64_t)x;
-            t[7] = (uint64_t)(x >> 64);
-            uint64_t m = t[0] * inv;
-            c = ((u128)m * p[0] + t[0]) >> 64;
-            for (int j = 1; j < 6; ++j) {
-                u128 y = (u128)m * p[j] + t[j] + c;
-                t[j - 1] = (uint64_t)y;
-                c = y >> 64;
-            }
-            x = (u128)t[6] + c;
-            t[5] = (uint64_t)x;
-            t[6] = t[7] + (uint64_t)(x >> 64);
-        }
-        if (t[6] || ge(t, p)) subr(t, t, p);
-        memcpy(out, t, 48);
-    }
+    static void mm(uint64_t* out, const uint64_t* a, const uint64_t* b) { mont_mul_n<6>(out, a, b, P(), k().inv); }
     static Fp zero() {
         Fp r;
         memset(r.l, 0, 48);
@@ -142,10 +117,14 @@ struct Fp {
             }
         return r;
     }
-    Fp inv() const {
-        uint64_t e[6], two[6] = {2, 0, 0, 0, 0, 0};
-        subr(e, P(), two);
-        return pow(e, 6);
+    Fp inv() const {  // 0 -> 0, like a Fermat power
+        static const ModInv<6> mi(P());
+        uint64_t r[6], t[6];
+        if (!mi.invert(r, l)) return zero();
+        Fp o;
+        mm(t, r, k().r2);  // (aR)^-1 R^2 R^-1 = a^-1
+        mm(o.l, t, k().r2);
+        return o;
     }
     // big-endian 48 bytes, canonical
     static bool from_be(Fp& out, const uint8_t* b) {
@@ -239,9 +218,15 @@ struct Fp6 {
     Fp6 operator+(const Fp6& o) const { return {a + o.a, b + o.b, c + o.c}; }
     Fp6 operator-(const Fp6& o) const { return {a - o.a, b - o.b, c - o.c}; }
     Fp6 neg() const { return {a.neg(), b.neg(), c.neg()}; }
-    Fp6 operator*(const Fp6& o) const {
-        return {a * o.a + (b * o.c + c * o.b).xi(), a * o.b + b * o.a + (c * o.c).xi(), a * o.c + b * o.b + c * o.a};
+    Fp6 operator*(const Fp6& o) const {  // Karatsuba: 6 Fp2 products
+        Fp2 v0 = a * o.a, v1 = b * o.b, v2 = c * o.c;
+        return {v0 + ((b + c) * (o.b + o.c) - v1 - v2).xi(), (a + b) * (o.a + o.b) - v0 - v1 + v2.xi(), (a + c) * (o.a + o.c) - v0 - v2 + v1};
     }
+    Fp6 mul_01(const Fp2& x0, const Fp2& x1) const {  // * (x0 + x1 v)
+        Fp2 v0 = a * x0, v1 = b * x1;
+        return {v0 + (c * x1).xi(), (a + b) * (x0 + x1) - v0 - v1, v1 + c * x0};
+    }
+    Fp6 mul_1(const Fp2& x1) const { return {(c * x1).xi(), a * x1, b * x1}; }  // * (x1 v)
     Fp6 mulv() const { return {c.xi(), a, b}; }
     Fp6 inv() const {
         Fp2 t0 = a.sq() - (b * c).xi(), t1 = c.sq().xi() - a * b, t2 = b.sq() - a * c;
@@ -257,7 +242,15 @@ struct Fp12 {
         Fp6 t0 = a * o.a, t1 = b * o.b;
         return {t0 + t1.mulv(), (a + b) * (o.a + o.b) - t0 - t1};
     }
-    Fp12 sq() const { return *this * *this; }
+    Fp12 sq() const {  // (a + b w)^2 = (a^2 + b^2 v) + 2ab w  with two Fp6 products
+        Fp6 ab = a * b;
+        return {(a + b) * (a + b.mulv()) - ab - ab.mulv(), ab + ab};
+    }
+    // * (c0 + c1 v + c2 v w): the shape of a line evaluation
+    Fp12 mul_line(const Fp2& c0, const Fp2& c1, const Fp2& c2) const {
+        Fp6 t0 = a.mul_01(c0, c1), t1 = b.mul_1(c2);
+        return {t0 + t1.mulv(), (a + b).mul_01(c0, c1 + c2) - t0 - t1};
+    }
     Fp12 operator-(const Fp12& o) const { return {a - o.a, b - o.b}; }
     Fp12 operator+(const Fp12& o) const { return {a + o.a, b + o.b}; }
     Fp12 conj() const { return {a, b.neg()}; }  // = x^(p^6)
@@ -321,9 +314,9 @@ struct G1J {
         Fp X3 = r.sq() - J - V.dbl();
         return {X3, r * (V - X3) - (s1 * J).dbl(), ((Z + o.Z).sq() - z1 - z2) * H};
     }
-    G1J mul_le(const uint8_t* k32) const {
+    G1J mul_le(const uint8_t* k32, int bits = 256) const {
         G1J r = inf();
-        for (int i = 255; i >= 0; --i) {
+        for (int i = bits - 1; i >= 0; --i) {
             r = r.dbl();
             if ((k32[i / 8] >> (i % 8)) & 1) r = r.add(*this);
         }
@@ -389,62 +382,102 @@ inline bool g2_compressed(G2A& p, const uint8_t* in) {
     return true;
 }
 
-// Miller loop f_{|x|,Q}(P) with Q untwisted into E(Fp12): (x', y') -> (x'/w^2, y'/w^3); x = -0xd201000000010000.
+// ---- pairing ---------------------------------------------------------------------------------------------
 struct PairingK {
-    Fp12 w2i, w3i;
-    std::vector<uint64_t> hard;  // (p^4 - p^2 + 1) / r
+    Fp2 gamma[6];  // gamma[i] = xi^(i (p-1)/6): (c w^i)^p = conj(c) gamma[i] w^i
 };
 const PairingK& pairing_k();  // host_api.cpp
 
-inline Fp12 miller(const G1A& P, const G2A& Q) {
-    if (P.inf || Q.inf) return Fp12::one();
-    const PairingK& k = pairing_k();
-    Fp12 xq = Fp12::from_fp2(Q.x) * k.w2i, yq = Fp12::from_fp2(Q.y) * k.w3i;
-    Fp12 xp = Fp12::from_fp(P.x), yp = Fp12::from_fp(P.y);
-    Fp12 xt = xq, yt = yq, f = Fp12::one();
+inline Fp2 fp2_conj(const Fp2& x) { return {x.a, x.b.neg()}; }
+inline Fp2 fp2_scale(const Fp2& x, const Fp& k) { return {x.a * k, x.b * k}; }
+// x -> x^p.  Coefficient of w^i: a.a w^0, b.a w^1, a.b w^2, b.b w^3, a.c w^4, b.c w^5
+inline Fp12 frobenius(const Fp12& f) {
+    const Fp2* g = pairing_k().gamma;
+    return {{fp2_conj(f.a.a), fp2_conj(f.a.b) * g[2], fp2_conj(f.a.c) * g[4]},
+            {fp2_conj(f.b.a) * g[1], fp2_conj(f.b.b) * g[3], fp2_conj(f.b.c) * g[5]}};
+}
+
+// G2 point in homogeneous projective coordinates on the twist  y^2 = x^3 + 4 xi
+struct G2P {
+    Fp2 X, Y, Z;
+};
+// One pair of the Miller loop.  A line through points of the twist, untwisted by (x', y') -> (x'/w^2, y'/w^3) and
+// evaluated at P = (xp, yp), is  yp - (lam xp)/w + (lam x' - y')/w^3 ; multiplied by w^3 and by an Fp2 scale factor
+// (both die in the final exponentiation) it is  c0 + c1 v + c2 v w  with the coefficients below.
+struct MillerPair {
+    Fp xp, yp;
+    Fp2 xq, yq;
+    G2P T;
+    MillerPair(const G1A& P, const G2A& Q) : xp(P.x), yp(P.y), xq(Q.x), yq(Q.y), T{Q.x, Q.y, Fp2::one()} {}
+    // T <- 2T ; f <- f * l_{T,T}(P)
+    void dbl_step(Fp12& f) {
+        Fp2 Y2 = T.Y.sq(), Z2 = T.Z.sq(), X2 = T.X.sq();
+        Fp2 bz = Z2.xi();  // b' Z^2 / 4
+        bz = bz + bz;
+        bz = bz + bz;                   // b' Z^2
+        Fp2 E = bz + bz + bz;           // 3 b' Z^2
+        Fp2 YZ2 = T.Y * T.Z;
+        YZ2 = YZ2 + YZ2;                // 2 Y Z
+        Fp2 X23 = X2 + X2 + X2;         // 3 X^2
+        f = f.mul_line(Y2 - E, fp2_scale(X23, xp).neg(), fp2_scale(YZ2, yp));
+        Fp2 E3 = E + E + E, XY = T.X * T.Y;
+        Fp2 EY = E * Y2, E2 = E.sq();
+        Fp2 EY2 = EY + EY, EY6 = EY2 + EY2 + EY2;
+        T.X = (XY + XY) * (Y2 - E3);
+        T.Y = Y2.sq() + EY6 - (E2 + E2 + E2);
+        Fp2 Y2Z = Y2 * YZ2;             // 2 Y^3 Z
+        Y2Z = Y2Z + Y2Z;
+        T.Z = Y2Z + Y2Z;                // 8 Y^3 Z
+    }
+    // T <- T + Q ; f <- f * l_{T,Q}(P)
+    void add_step(Fp12& f) {
+        Fp2 N = T.Y - yq * T.Z, D = T.X - xq * T.Z;
+        f = f.mul_line(N * xq - D * yq, fp2_scale(N, xp).neg(), fp2_scale(D, yp));
+        Fp2 D2 = D.sq(), D3 = D2 * D, xqZ = xq * T.Z;
+        Fp2 A = N.sq() * T.Z - D2 * (T.X + xqZ);
+        Fp2 Y3 = N * (xqZ * D2 - A) - yq * T.Z * D3;
+        T.X = A * D;
+        T.Y = Y3;
+        T.Z = T.Z * D3;
+    }
+};
+// prod_k f_{|x|,Q_k}(P_k), conjugated for x < 0 (equal to the inverse once final-exponentiated); pairs with a point at
+// infinity contribute 1
+inline Fp12 multi_miller(std::vector<MillerPair>& pairs) {
+    Fp12 f = Fp12::one();
     const uint64_t xabs = 0xd201000000010000ull;
     for (int b = 62; b >= 0; --b) {
-        f = f.sq();
-        Fp12 x2 = xt.sq();
-        Fp12 lam = (x2 + x2 + x2) * (yt + yt).inv();
-        f = f * ((yp - yt) - lam * (xp - xt));
-        Fp12 x3 = lam.sq() - xt - xt;
-        yt = lam * (xt - x3) - yt;
-        xt = x3;
-        if ((xabs >> b) & 1) {
-            Fp12 l2 = (yq - yt) * (xq - xt).inv();
-            f = f * ((yp - yt) - l2 * (xp - xt));
-            Fp12 x4 = l2.sq() - xt - xq;
-            yt = l2 * (xt - x4) - yt;
-            xt = x4;
-        }
+        if (b != 62) f = f.sq();
+        for (auto& pr : pairs) pr.dbl_step(f);
+        if ((xabs >> b) & 1)
+            for (auto& pr : pairs) pr.add_step(f);
     }
-    return f.conj();  // x < 0: f^-1 up to factors killed by the final exponentiation (conj = inverse on the cyclotomic subgroup)
+    return f.conj();
 }
-// f^((p^12 - 1)/r):  easy part f^(p^6 - 1) = conj(f)/f, then ^(p^2 + 1) by a plain power, then the hard exponent
+inline Fp12 miller(const G1A& P, const G2A& Q) {
+    std::vector<MillerPair> v;
+    if (!P.inf && !Q.inf) v.emplace_back(P, Q);
+    return multi_miller(v);
+}
+// f^x on the cyclotomic subgroup (inverse = conjugate there)
+inline Fp12 pow_x(const Fp12& f) {
+    const uint64_t xabs = 0xd201000000010000ull;
+    Fp12 r = f;
+    for (int b = 62; b >= 0; --b) {
+        r = r.sq();
+        if ((xabs >> b) & 1) r = r * f;
+    }
+    return r.conj();
+}
+// f^(3 (p^12 - 1)/r)
 inline Fp12 final_exp(const Fp12& f) {
-    const PairingK& k = pairing_k();
-    Fp12 t = f.conj() * f.inv();  // f^(p^6 - 1)
-    // t^(p^2 + 1): p^2 + 1 as an exponent (762 bits)
-    static const std::vector<uint64_t> p2p1 = [] {
-        // (p * p + 1) in 64-bit limbs by schoolbook on the modulus
-        const uint64_t* p = Fp::P();
-        std::vector<uint64_t> r(12, 0);
-        for (int i = 0; i < 6; ++i) {
-            u128 c = 0;
-            for (int j = 0; j < 6; ++j) {
-                u128 x = (u128)p[i] * p[j] + r[i + j] + c;
-                r[i + j] = (uint64_t)x;
-                c = x >> 64;
-            }
-            r[i + 6] += (uint64_t)c;
-        }
-        for (int i = 0; i < 12; ++i)
-            if (++r[i]) break;
-        return r;
-    }();
-    t = t.pow(p2p1);
-    return t.pow(k.hard);
+    Fp12 t = f.conj() * f.inv();            // ^(p^6 - 1)
+    t = frobenius(frobenius(t)) * t;        // ^(p^2 + 1): t is now in the cyclotomic subgroup
+    Fp12 a = pow_x(t) * t.conj();           // ^(x - 1)
+    Fp12 b = pow_x(a) * a.conj();           // ^(x - 1)^2
+    Fp12 c = pow_x(b) * frobenius(b);       // ^(x + p)
+    Fp12 d = pow_x(pow_x(c)) * frobenius(frobenius(c)) * c.conj();  // ^(x^2 + p^2 - 1)
+    return d * t.sq() * t;                  // + 3
 }
 
 }  // namespace bls

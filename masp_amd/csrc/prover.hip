@@ -11,7 +11,10 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -186,9 +189,15 @@ struct ResidentBatch {
 
 }  // namespace
 
+// Locking: `mu` is held SHARED by masp_hip_prove_batch (any number of host threads prove concurrently, each batch on
+// its own slot = stream + scratch) and EXCLUSIVE by everything that changes circuits or uses the shared scratch.  The
+// slot pool has its own small lock (`slot_mu`); `err` is written under it.
 struct masp_hip_ctx {
     int device = 0;
-    std::mutex mu;
+    std::shared_mutex mu;
+    std::mutex slot_mu;
+    std::condition_variable slot_cv;
+    std::vector<char> slot_busy;
     std::string err;
     hipStream_t main_stream = nullptr;
     std::unique_ptr<Circuit> circ[MASP_HIP_MAX_CIRCUITS];
@@ -244,14 +253,64 @@ static size_t batch_cap() {
 }
 
 static int ensure_slots(masp_hip_ctx* ctx, size_t want) {
+    std::lock_guard<std::mutex> g(ctx->slot_mu);
     while (ctx->slots.size() < want) {
         std::unique_ptr<Slot> s(new Slot);
         int rc = s->init();
         if (rc) return rc;
         ctx->slots.push_back(std::move(s));
+        ctx->slot_busy.push_back(0);
     }
     for (auto& sl : ctx->slots) sl->profiling = ctx->profiling;
     return MASP_HIP_OK;
+}
+// Slot pool for concurrent provers.  try: a free slot, or a new one while fewer than n_slots_default() exist.
+// Returns MASP_HIP_OK and *si, or -1 if every slot is busy, or an error code.
+static int slot_try_acquire(masp_hip_ctx* ctx, size_t* si) {
+    std::lock_guard<std::mutex> g(ctx->slot_mu);
+    for (size_t i = 0; i < ctx->slots.size(); ++i)
+        if (!ctx->slot_busy[i]) {
+            ctx->slot_busy[i] = 1;
+            *si = i;
+            return MASP_HIP_OK;
+        }
+    if (ctx->slots.size() >= (size_t)n_slots_default()) return -1;
+    std::unique_ptr<Slot> s(new Slot);
+    int rc = s->init();
+    if (rc) return rc;
+    s->profiling = ctx->profiling;
+    ctx->slots.push_back(std::move(s));
+    ctx->slot_busy.push_back(1);
+    *si = ctx->slots.size() - 1;
+    return MASP_HIP_OK;
+}
+static size_t slot_acquire_blocking(masp_hip_ctx* ctx) {
+    std::unique_lock<std::mutex> g(ctx->slot_mu);
+    size_t found = 0;
+    ctx->slot_cv.wait(g, [&] {
+        for (size_t i = 0; i < ctx->slots.size(); ++i)
+            if (!ctx->slot_busy[i]) {
+                found = i;
+                return true;
+            }
+        return false;
+    });
+    ctx->slot_busy[found] = 1;
+    return found;
+}
+static void slot_release(masp_hip_ctx* ctx, size_t si) {
+    {
+        std::lock_guard<std::mutex> g(ctx->slot_mu);
+        ctx->slot_busy[si] = 0;
+    }
+    ctx->slot_cv.notify_one();
+}
+static int fail_shared(masp_hip_ctx* ctx, int rc) {
+    if (rc == MASP_HIP_E_HIP) {
+        std::lock_guard<std::mutex> g(ctx->slot_mu);
+        ctx->err = last_hip_error();
+    }
+    return rc;
 }
 
 // Quotient for np proofs on slot buffers: in[i] + p * in_stride are Montgomery (mont_in) or canonical evaluation
@@ -409,7 +468,7 @@ void masp_hip_ctx_destroy(masp_hip_ctx* ctx) {
 
 int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* params, size_t params_len, const masp_hip_r1cs* cs) {
     if (!ctx || !params || !cs || slot >= MASP_HIP_MAX_CIRCUITS || cs->n_inputs == 0) return MASP_HIP_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::unique_lock<std::shared_mutex> lock(ctx->mu);
     hipSetDevice(ctx->device);
     hipStream_t s = ctx->main_stream;
     ParamsLayout L;
@@ -519,7 +578,7 @@ int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* param
 
 int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, uint8_t* proofs_out) {
     if (!ctx || (n && (!jobs || !proofs_out))) return MASP_HIP_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::shared_lock<std::shared_mutex> lock(ctx->mu);  // concurrent with other provers, exclusive with circuit loads
     hipSetDevice(ctx->device);
     for (size_t j = 0; j < n; ++j) {
         const masp_hip_job& J = jobs[j];
@@ -545,29 +604,40 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
                 groups.push_back(std::move(g));
             }
     }
-    size_t ns = std::min<size_t>(std::max<size_t>(groups.size(), 1), n_slots_default());
-    int rc = ensure_slots(ctx, ns);
-    if (rc) return fail(ctx, rc);
-    std::vector<long> owner(ns, -1);
-    int result = MASP_HIP_OK;
-    auto retire = [&](size_t si) {
-        Slot& sl = *ctx->slots[si];
-        if (owner[si] < 0) return;
-        const Group& G = groups[owner[si]];
+    // Each batch runs on a slot taken from the context's pool; this call keeps up to all of them in flight, and calls
+    // from other host threads interleave with it slot by slot.
+    struct Owned {
+        size_t si, gi;
+    };
+    std::deque<Owned> owned;
+    int result = MASP_HIP_OK, rc;
+    auto retire_oldest = [&]() -> size_t {  // waits for the oldest batch in flight; the slot stays ours
+        Owned o = owned.front();
+        owned.pop_front();
+        Slot& sl = *ctx->slots[o.si];
+        const Group& G = groups[o.gi];
         if (hipEventSynchronize(sl.done) != hipSuccess) {
             last_hip_error() = "event sync failed";
-            result = fail(ctx, MASP_HIP_E_HIP);
+            result = fail_shared(ctx, MASP_HIP_E_HIP);
         } else if (*sl.h_flags) {
             result = MASP_HIP_E_SCALAR_RANGE;
         } else if (result == MASP_HIP_OK) {
             for (size_t p = 0; p < G.idx.size(); ++p) memcpy(proofs_out + 192 * G.idx[p], sl.h_proof + 192 * p, 192);
         }
-        owner[si] = -1;
+        return o.si;
     };
     for (size_t gi = 0; gi < groups.size() && result == MASP_HIP_OK; ++gi) {
-        size_t si = gi % ns;
-        retire(si);
-        if (result) break;
+        size_t si = 0;
+        rc = slot_try_acquire(ctx, &si);
+        if (rc > 0) {
+            result = fail_shared(ctx, rc);
+            break;
+        }
+        if (rc < 0) si = owned.empty() ? slot_acquire_blocking(ctx) : retire_oldest();
+        if (result) {
+            slot_release(ctx, si);
+            break;
+        }
         const Group& G = groups[gi];
         Slot& sl = *ctx->slots[si];
         Circuit& C = *ctx->circ[jobs[G.idx[0]].circuit];
@@ -575,52 +645,64 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
         const bool has_abc = jobs[G.idx[0]].a != nullptr;
         // staging layout: [np][nv] witness | (a | b | c each [np][nrows]) | [np][16] r,s limbs
         const size_t w_bytes = 32 * nv * np, abc_bytes = has_abc ? 3 * 32 * (size_t)C.nrows * np : 0, rs_bytes = 64 * np;
+        bool ok = true;
         if ((rc = sl.stage_reserve(w_bytes + abc_bytes + rs_bytes)) || (rc = sl.w.reserve(nv * np)) ||
             (rc = sl.abc.reserve(has_abc ? 3 * (size_t)C.nrows * np : 1)) || (rc = sl.reserve_batch(np))) {
-            result = fail(ctx, rc);
-            break;
+            result = fail_shared(ctx, rc);
+            ok = false;
         }
-        uint8_t* hs = sl.h_stage;
-        for (size_t p = 0; p < np; ++p) {
-            const masp_hip_job& J = jobs[G.idx[p]];
-            memcpy(hs + 32 * nv * p, J.inputs, 32 * (size_t)C.n_inputs);
-            memcpy(hs + 32 * nv * p + 32 * (size_t)C.n_inputs, J.aux, 32 * (size_t)C.n_aux);
-            if (has_abc) {
-                const uint8_t* src[3] = {J.a, J.b, J.c};
-                for (int i = 0; i < 3; ++i) memcpy(hs + w_bytes + 32 * (size_t)C.nrows * (np * i + p), src[i], 32 * (size_t)C.nrows);
+        if (ok) {
+            uint8_t* hs = sl.h_stage;
+            for (size_t p = 0; p < np; ++p) {
+                const masp_hip_job& J = jobs[G.idx[p]];
+                memcpy(hs + 32 * nv * p, J.inputs, 32 * (size_t)C.n_inputs);
+                memcpy(hs + 32 * nv * p + 32 * (size_t)C.n_inputs, J.aux, 32 * (size_t)C.n_aux);
+                if (has_abc) {
+                    const uint8_t* src[3] = {J.a, J.b, J.c};
+                    for (int i = 0; i < 3; ++i) memcpy(hs + w_bytes + 32 * (size_t)C.nrows * (np * i + p), src[i], 32 * (size_t)C.nrows);
+                }
+                memcpy(hs + w_bytes + abc_bytes + 64 * p, J.r, 32);
+                memcpy(hs + w_bytes + abc_bytes + 64 * p + 32, J.s, 32);
             }
-            memcpy(hs + w_bytes + abc_bytes + 64 * p, J.r, 32);
-            memcpy(hs + w_bytes + abc_bytes + 64 * p + 32, J.s, 32);
+            hipStream_t s = sl.stream;
+            ok = hipMemcpyAsync(sl.w.p, hs, w_bytes, hipMemcpyHostToDevice, s) == hipSuccess &&
+                 (!has_abc || hipMemcpyAsync(sl.abc.p, hs + w_bytes, abc_bytes, hipMemcpyHostToDevice, s) == hipSuccess) &&
+                 hipMemcpyAsync(sl.rs.p, hs + w_bytes + abc_bytes, rs_bytes, hipMemcpyHostToDevice, s) == hipSuccess;
+            if (!ok) {
+                last_hip_error() = "H2D copy failed";
+                result = fail_shared(ctx, MASP_HIP_E_HIP);
+            }
         }
-        hipStream_t s = sl.stream;
-        bool ok = hipMemcpyAsync(sl.w.p, hs, w_bytes, hipMemcpyHostToDevice, s) == hipSuccess &&
-                  (!has_abc || hipMemcpyAsync(sl.abc.p, hs + w_bytes, abc_bytes, hipMemcpyHostToDevice, s) == hipSuccess) &&
-                  hipMemcpyAsync(sl.rs.p, hs + w_bytes + abc_bytes, rs_bytes, hipMemcpyHostToDevice, s) == hipSuccess;
+        if (ok) {
+            const Fr* abc[3] = {nullptr, nullptr, nullptr};
+            if (has_abc)
+                for (int i = 0; i < 3; ++i) abc[i] = sl.abc.p + (size_t)C.nrows * np * i;
+            if ((rc = enqueue_proofs(sl, C, (uint32_t)np, sl.w.p, nv, abc, sl.rs.p, sl.proof.p))) {
+                result = fail_shared(ctx, rc);
+                ok = false;
+            }
+        }
+        if (ok) {
+            hipStream_t s = sl.stream;
+            ok = hipMemcpyAsync(sl.h_proof, sl.proof.p, 192 * np, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                 hipMemcpyAsync(sl.h_flags, sl.flags.p, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess &&
+                 hipEventRecord(sl.done, s) == hipSuccess;
+            if (!ok) {
+                last_hip_error() = "D2H copy failed";
+                result = fail_shared(ctx, MASP_HIP_E_HIP);
+            }
+        }
         if (!ok) {
-            last_hip_error() = "H2D copy failed";
-            result = fail(ctx, MASP_HIP_E_HIP);
+            hipStreamSynchronize(sl.stream);
+            slot_release(ctx, si);
             break;
         }
-        const Fr* abc[3] = {nullptr, nullptr, nullptr};
-        if (has_abc)
-            for (int i = 0; i < 3; ++i) abc[i] = sl.abc.p + (size_t)C.nrows * np * i;
-        if ((rc = enqueue_proofs(sl, C, (uint32_t)np, sl.w.p, nv, abc, sl.rs.p, sl.proof.p))) {
-            result = fail(ctx, rc);
-            break;
-        }
-        ok = hipMemcpyAsync(sl.h_proof, sl.proof.p, 192 * np, hipMemcpyDeviceToHost, s) == hipSuccess &&
-             hipMemcpyAsync(sl.h_flags, sl.flags.p, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess && hipEventRecord(sl.done, s) == hipSuccess;
-        if (!ok) {
-            last_hip_error() = "D2H copy failed";
-            result = fail(ctx, MASP_HIP_E_HIP);
-            break;
-        }
-        owner[si] = (long)gi;
+        owned.push_back({si, gi});
     }
-    for (size_t si = 0; si < ns; ++si) retire(si);
+    while (!owned.empty()) slot_release(ctx, retire_oldest());
     if (hipGetLastError() != hipSuccess && result == MASP_HIP_OK) {
         last_hip_error() = "kernel launch failed";
-        result = fail(ctx, MASP_HIP_E_HIP);
+        result = fail_shared(ctx, MASP_HIP_E_HIP);
     }
     return result;
 }
@@ -649,7 +731,7 @@ int masp_hip_prove(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* inputs, cons
 template <class O, int BYTES, class X>
 static int msm_block(masp_hip_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t* out, DevBuf<X>& res) {
     if (!ctx || !out || (n && (!bases || !scalars)) || n > (1u << 26)) return MASP_HIP_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::unique_lock<std::shared_mutex> lock(ctx->mu);
     hipSetDevice(ctx->device);
     hipStream_t s = ctx->main_stream;
     for (size_t i = 0; i < n; ++i)
@@ -684,7 +766,7 @@ int masp_hip_msm_g2(masp_hip_ctx* ctx, const uint8_t* bases, const uint8_t* scal
 
 int masp_hip_quotient_h(masp_hip_ctx* ctx, const uint8_t* a, const uint8_t* b, const uint8_t* c, size_t nrows, uint32_t logm, uint8_t* h_out) {
     if (!ctx || !a || !b || !c || !h_out || logm == 0 || logm > 20 || nrows > ((size_t)1 << logm)) return MASP_HIP_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::unique_lock<std::shared_mutex> lock(ctx->mu);
     hipSetDevice(ctx->device);
     int rc;
     if ((rc = ensure_slots(ctx, 1))) return fail(ctx, rc);
@@ -710,7 +792,7 @@ int masp_hip_quotient_h(masp_hip_ctx* ctx, const uint8_t* a, const uint8_t* b, c
 
 int masp_hip_ntt(masp_hip_ctx* ctx, uint8_t* data, uint32_t logm, int inverse) {
     if (!ctx || !data || logm == 0 || logm > 20) return MASP_HIP_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::unique_lock<std::shared_mutex> lock(ctx->mu);
     hipSetDevice(ctx->device);
     int rc;
     if ((rc = ensure_slots(ctx, 1))) return fail(ctx, rc);
@@ -750,7 +832,7 @@ size_t masp_hip_parameters_max_size(const masp_hip_r1cs* cs) {
 int masp_hip_generate_parameters(masp_hip_ctx* ctx, const masp_hip_r1cs* cs, const uint8_t toxic[160], uint8_t* out, size_t cap,
                                  size_t* out_len) {
     if (!ctx || !cs || !toxic || !out_len || cs->n_inputs == 0) return MASP_HIP_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::unique_lock<std::shared_mutex> lock(ctx->mu);
     hipSetDevice(ctx->device);
     hipStream_t s = ctx->main_stream;
     Fr tw[5];
@@ -914,7 +996,7 @@ int masp_hip_generate_parameters(masp_hip_ctx* ctx, const masp_hip_r1cs* cs, con
 // ---- measurement hooks ----------------------------------------------------------------------------
 int masp_hip_batch_upload(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs) {
     if (!ctx || !n || !jobs) return -MASP_HIP_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::unique_lock<std::shared_mutex> lock(ctx->mu);
     hipSetDevice(ctx->device);
     std::unique_ptr<ResidentBatch> B(new ResidentBatch);
     B->n = n;
@@ -954,7 +1036,7 @@ int masp_hip_batch_upload(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs)
 
 int masp_hip_batch_free(masp_hip_ctx* ctx, int handle) {
     if (!ctx || handle < 0 || (size_t)handle >= ctx->batches.size()) return MASP_HIP_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::unique_lock<std::shared_mutex> lock(ctx->mu);
     hipSetDevice(ctx->device);
     ctx->batches[handle].reset();
     return MASP_HIP_OK;
@@ -962,7 +1044,7 @@ int masp_hip_batch_free(masp_hip_ctx* ctx, int handle) {
 
 int masp_hip_batch_prove_resident(masp_hip_ctx* ctx, int handle, uint8_t* proofs_out, float* elapsed_ms) {
     if (!ctx || handle < 0 || (size_t)handle >= ctx->batches.size() || !ctx->batches[handle] || !proofs_out) return MASP_HIP_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::unique_lock<std::shared_mutex> lock(ctx->mu);
     hipSetDevice(ctx->device);
     ResidentBatch& B = *ctx->batches[handle];
     // groups of consecutive same-circuit jobs (their assignments are contiguous: stride = n_vars)
@@ -1020,7 +1102,7 @@ int masp_hip_batch_prove_resident(masp_hip_ctx* ctx, int handle, uint8_t* proofs
 
 int masp_hip_profile_enable(masp_hip_ctx* ctx, int on) {
     if (!ctx) return MASP_HIP_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::unique_lock<std::shared_mutex> lock(ctx->mu);
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
     ctx->profiling = on != 0;
@@ -1033,7 +1115,7 @@ int masp_hip_profile_enable(masp_hip_ctx* ctx, int on) {
 
 int masp_hip_profile_read(masp_hip_ctx* ctx, double* total_ms, uint64_t* launches, uint64_t* alg_bytes) {
     if (!ctx) return MASP_HIP_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::unique_lock<std::shared_mutex> lock(ctx->mu);
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
     double t = 0;
@@ -1059,7 +1141,7 @@ int masp_hip_sync(masp_hip_ctx* ctx) {
 int masp_hip_bench_msm(masp_hip_ctx* ctx, int handle, size_t job, int which, int iters, float* avg_ms, uint32_t* n_bases) {
     if (!ctx || handle < 0 || (size_t)handle >= ctx->batches.size() || !ctx->batches[handle] || which < 0 || which > 3 || iters <= 0 || !avg_ms)
         return MASP_HIP_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::unique_lock<std::shared_mutex> lock(ctx->mu);
     hipSetDevice(ctx->device);
     ResidentBatch& B = *ctx->batches[handle];
     if (job >= B.n) return MASP_HIP_E_INVALID_ARG;

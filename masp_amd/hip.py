@@ -74,6 +74,8 @@ def _p(a):
 def _u8(a, shape_last=None):
     if a is None:
         return None
+    if isinstance(a, (bytes, bytearray, memoryview)):
+        a = np.frombuffer(a, dtype=np.uint8)
     a = np.ascontiguousarray(a, dtype=np.uint8)
     if shape_last is not None:
         a = a.reshape(-1, shape_last)

@@ -54,11 +54,31 @@ def load_library():
         L.masp_host_vk_prepare.argtypes = [vp, C.c_size_t]
         L.masp_host_vk_free.argtypes = [vp]
         L.masp_host_vk_verify.argtypes = [vp, cp, cp, C.c_uint32]
+        L.masp_host_vk_verify_batch.argtypes = [vp, C.c_size_t, cp, cp, C.c_uint32, cp]
         L.masp_host_point_uv.argtypes = [cp, cp]
         L.masp_host_jubjub_add.argtypes = [cp, cp, C.c_int, cp]
         L.masp_host_spend_leaf.argtypes = [cp, cp, cp, cp, cp, u64, cp, cp]
         _lib = L
     return _lib
+
+
+def effective_cpus():
+    """Host threads worth starting: the scheduler affinity, capped by a cgroup CPU quota when one is set (a container
+    that sees 256 logical CPUs may be entitled to 16 of them; oversubscribing it only adds contention)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 _circuits = {}
@@ -147,7 +167,7 @@ class PreparedVerifyingKey:
     """= bellman `prepare_verifying_key(&params.vk)` (lib.rs:391-393) + `verify_proof` (sapling/prover.rs:148,266)."""
 
     def __init__(self, params):
-        buf = np.ascontiguousarray(params, dtype=np.uint8)
+        buf = np.frombuffer(params, dtype=np.uint8) if isinstance(params, (bytes, bytearray, memoryview)) else np.ascontiguousarray(params, dtype=np.uint8)
         n_ic = int.from_bytes(buf[864:868].tobytes(), "big")
         self._buf = buf[:868 + 96 * n_ic].copy()
         self._L = load_library()
@@ -162,6 +182,22 @@ class PreparedVerifyingKey:
         if rc < 0:
             return False
         return rc == 1
+
+    def verify_batch(self, proofs, public_inputs, randomness=None):
+        """= bellman `verify_proofs_batch` (sapling/verifier/batch.rs:24-31): one random linear combination, n + 2 Miller
+        loops and a single final exponentiation for n proofs.  public_inputs: one list per proof.  True iff all verify
+        (up to 2^-128); False says at least one is invalid, not which."""
+        import secrets
+        n = len(proofs)
+        if n == 0:
+            return True
+        k = len(public_inputs[0])
+        if any(len(pi) != k for pi in public_inputs) or len(public_inputs) != n:
+            return False
+        pi = b"".join(_b(x) for row in public_inputs for x in row)
+        z = randomness if randomness is not None else secrets.token_bytes(16 * n)
+        assert len(z) == 16 * n
+        return self._L.masp_host_vk_verify_batch(self._h, n, b"".join(bytes(p) for p in proofs), pi, k, z) == 1
 
     def __del__(self):
         if getattr(self, "_h", None):

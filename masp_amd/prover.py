@@ -17,6 +17,7 @@ import os
 import secrets
 
 from . import host as H
+from . import params as P
 from .hip import CONVERT, OUTPUT, SPEND, Context
 
 GROTH_PROOF_SIZE = 192  # masp_primitives/src/transaction/components.rs:15
@@ -58,9 +59,12 @@ class SaplingProvingContext:
 class LocalTxProver:
     """An implementation of `TxProver` using the MI355X prover.  Holds the three circuits' parameters for its lifetime."""
 
-    def __init__(self, spend_params, output_params, convert_params, device=0, rng=None, self_verify=True):
-        """= LocalTxProver::from_bytes (prover.rs:81-95): parameter *bytes* in the bellman wire format.
-        Malformed or mismatching parameters raise (the reference panics, lib.rs:290-293,337)."""
+    def __init__(self, spend_params, output_params, convert_params, device=0, rng=None, self_verify=True, expected=P.EXPECTED):
+        """= LocalTxProver::from_bytes (prover.rs:81-95): parameter *bytes* in the bellman wire format, digests checked
+        as `parse_parameters` does (lib.rs:333-388).  Malformed or mismatching parameters raise `params.ParameterError` /
+        `hip.HipError` (the reference panics, lib.rs:290-293,337,359-362).  `expected=None`: parameters that are not the
+        MPC files (benches, tests)."""
+        spend_params, output_params, convert_params = P.parse_parameters(spend_params, output_params, convert_params, expected=expected)
         self._ctx = Context(device)
         self._rng = rng or (lambda: secrets.randbelow(FR))          # r, s <- OsRng (sapling/prover.rs:66,174,225)
         self._self_verify = self_verify
@@ -71,16 +75,25 @@ class LocalTxProver:
             cs, _ = H.circuit(kind)
             self._ctx.load_circuit(slot, params, cs)
 
+    from_bytes = classmethod(lambda cls, spend, output, convert, **kw: cls(spend, output, convert, **kw))
+
     @classmethod
     def new(cls, spend_path, output_path, convert_path, **kw):
-        """= LocalTxProver::new (prover.rs:55-64): parameter files on disk."""
+        """= LocalTxProver::new (prover.rs:55-64) = load_parameters (lib.rs:278-328): parameter files on disk, sizes
+        checked before anything is read."""
+        expected = kw.get("expected", P.EXPECTED)
+        if expected is not None:
+            for kind, path in zip(P.KINDS, (spend_path, output_path, convert_path)):
+                P.verify_file_size(path, expected[kind].bytes, "masp " + kind)
         return cls(*(open(p, "rb").read() for p in (spend_path, output_path, convert_path)), **kw)
 
     @classmethod
     def with_default_location(cls, **kw):
         """= LocalTxProver::with_default_location (prover.rs:120-136): ~/.masp-params/masp-{spend,output,convert}.params"""
-        d = os.path.join(os.path.expanduser("~"), ".masp-params")
-        paths = [os.path.join(d, "masp-%s.params" % k) for k in ("spend", "output", "convert")]
+        d = P.default_params_folder()
+        if d is None or not os.path.isdir(d):
+            return None
+        paths = [os.path.join(d, n) for n in (P.MASP_SPEND_NAME, P.MASP_OUTPUT_NAME, P.MASP_CONVERT_NAME)]
         if not all(os.path.exists(p) for p in paths):
             return None
         return cls.new(*paths, **kw)
@@ -93,7 +106,7 @@ class LocalTxProver:
         ctx = Context(device)
         params = [ctx.generate_parameters(H.circuit(k)[0], toxic_waste(seed * 3 + i)) for i, k in enumerate(("spend", "output", "convert"))]
         ctx.close()
-        p = cls(*params, device=device, **kw)
+        p = cls(*params, device=device, expected=None, **kw)
         p.parameters = dict(zip(("spend", "output", "convert"), params))
         return p
 
@@ -129,30 +142,58 @@ class LocalTxProver:
             raise ProvingError(str(e)) from None
         return dict(slot=CONVERT, inputs=inputs, aux=aux, cv=cv, rcv=rcv)
 
-    def prove_batch(self, ctx, descriptions, threads=None, rs=None):
+    def prove_batch(self, ctx, descriptions, threads=None, rs=None, chunk=None, progress=None):
         """Batched form of the serial per-description loops of `SaplingBuilder::build`
         (/root/reference/masp_primitives/src/transaction/components/sapling/builder.rs:935-1140):
         descriptions = [("spend", kwargs) | ("output", kwargs) | ("convert", kwargs)] with the keyword arguments of
-        prepare_spend / prepare_output / prepare_convert.  Witness synthesis runs on `threads` host threads (the C++
-        synthesizer releases the GIL), all proofs go to the GPU as one batch, Spend / Convert proofs are self-verified,
-        and the context accumulates in description order, so bsk / cv_sum end up exactly as in the serial loops.
+        prepare_spend / prepare_output / prepare_convert.
+
+        Three stages run as a pipeline over chunks of `chunk` descriptions (default: the GPU batch size):
+        witness synthesis on `threads` host threads (the C++ synthesizer releases the GIL), proving on the GPU (each
+        chunk in flight owns one slot of the native context, which is re-entrant), and self-verification of the Spend /
+        Convert proofs of a finished chunk as one `verify_proofs_batch`-style check per circuit (a failing batch is
+        re-checked proof by proof, so the outcome is that of the per-proof checks at sapling/prover.rs:148,266).
+        The context accumulates in description order afterwards, so bsk / cv_sum end up exactly as in the serial loops.
+        `progress(done, total)` mirrors the builder's `Progress` notifications (builder.rs:946-952 etc.).
         -> list of (zkproof, cv[, rk])"""
         from concurrent.futures import ThreadPoolExecutor
+        n = len(descriptions)
+        if rs is None:
+            rs = [(self._rng(), self._rng()) for _ in range(n)]
+        threads = threads or H.effective_cpus()
+        chunk = chunk or int(os.environ.get("MASP_HIP_BATCH", "16"))
+        in_flight = max(1, int(os.environ.get("MASP_HIP_SLOTS", "2"))) + 1
         prep = {"spend": self.prepare_spend, "output": self.prepare_output, "convert": self.prepare_convert}
-        with ThreadPoolExecutor(max_workers=threads or min(32, (os.cpu_count() or 1))) as ex:
-            jobs = list(ex.map(lambda d: prep[d[0]](**d[1]), descriptions))
-            proofs = self.prove_prepared(jobs, rs)
-            if self._self_verify:
-                def check(args):
-                    (kind, kw), job, zk = args
-                    if kind == "spend":
-                        pi = list(H.point_uv(job["rk"])) + list(H.point_uv(job["cv"])) + [_int(kw["anchor"])] + H.multipack(job["nf"])
-                        return self.spend_vk.verify(zk, pi)
-                    if kind == "convert":
-                        return self.convert_vk.verify(zk, list(H.point_uv(job["cv"])) + [_int(kw["anchor"])])
-                    return True
-                if not all(ex.map(check, zip(descriptions, jobs, proofs))):
-                    raise ProvingError("a proof failed self-verification")
+        done = [0]
+
+        def public_input(kind, kw, job):
+            if kind == "spend":       # sapling/prover.rs:121-145
+                return list(H.point_uv(job["rk"])) + list(H.point_uv(job["cv"])) + [_int(kw["anchor"])] + H.multipack(job["nf"])
+            return list(H.point_uv(job["cv"])) + [_int(kw["anchor"])]          # convert: sapling/prover.rs:256-263
+
+        with ThreadPoolExecutor(max_workers=threads) as synth, ThreadPoolExecutor(max_workers=in_flight) as gpu:
+            futures = [synth.submit(prep[kind], **kw) for kind, kw in descriptions]
+
+            def run_chunk(lo):
+                hi = min(n, lo + chunk)
+                jobs = [f.result() for f in futures[lo:hi]]
+                proofs = self.prove_prepared(jobs, rs[lo:hi])
+                if self._self_verify:
+                    for kind, vk in (("spend", self.spend_vk), ("convert", self.convert_vk)):
+                        sel = [i for i in range(hi - lo) if descriptions[lo + i][0] == kind]
+                        if not sel:
+                            continue
+                        pis = [public_input(kind, descriptions[lo + i][1], jobs[i]) for i in sel]
+                        if not vk.verify_batch([proofs[i] for i in sel], pis):
+                            bad = [lo + i for i, pi in zip(sel, pis) if not vk.verify(proofs[i], pi)]
+                            raise ProvingError("proof(s) %s failed self-verification" % bad)
+                done[0] += hi - lo
+                if progress is not None:
+                    progress(done[0], n)
+                return jobs, proofs
+            results = list(gpu.map(run_chunk, range(0, n, chunk)))
+        jobs = [j for js, _ in results for j in js]
+        proofs = [p for _, ps in results for p in ps]
         out = []
         for (kind, kw), job, zk in zip(descriptions, jobs, proofs):
             if kind == "output":

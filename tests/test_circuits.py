@@ -189,3 +189,23 @@ def test_host_verifier_agrees_with_oracle_pairing_check():
         assert vk.verify(pr, pi) == (O.verify_proof(pbuf, pr, pi) == 1)
     assert vk.verify(proof, pub) and not vk.verify(proof, pub[:-1])
     assert not vk.verify(bytes(192), pub)          # not even valid encodings
+
+
+def test_host_batch_verifier():
+    """`verify_proofs_batch` semantics (sapling/verifier/batch.rs:24-31): a batch passes iff every member verifies"""
+    import toy_r1cs
+    cs, inputs, aux, vals = toy_r1cs.make(4, 8, 40, 300)
+    pbuf = O.generate_parameters(cs, toy_r1cs.toxic(4))
+    P = O.Params(pbuf)
+    vk = H.PreparedVerifyingKey(pbuf)
+    pub = vals[1:8]
+    proofs = [O.create_proof(P, cs, inputs, aux, 10 + i, 20 + i) for i in range(5)]
+    assert all(vk.verify(p, pub) for p in proofs)
+    assert vk.verify_batch(proofs, [pub] * 5)
+    assert vk.verify_batch(proofs[:1], [pub]) and vk.verify_batch([], [])
+    assert vk.verify_batch(proofs, [pub] * 5, randomness=bytes(80))            # coefficients are forced non-zero
+    bad_c = proofs[2][:144] + proofs[3][144:]                                  # C of another proof
+    assert not vk.verify_batch(proofs[:2] + [bad_c] + proofs[3:], [pub] * 5)
+    assert not vk.verify_batch(proofs, [pub] * 4 + [[pub[0] + 1] + pub[1:]])   # one wrong public input
+    assert not vk.verify_batch(proofs, [pub] * 4 + [pub[:-1]])                 # ragged
+    assert not vk.verify_batch([bytes(192)], [pub])

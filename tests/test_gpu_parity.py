@@ -292,6 +292,23 @@ def _invalid_diversifier(d, inst):
         return True
 
 
+def test_concurrent_provers_share_one_context(ctx):
+    """SURVEY.md §8(b) threading: one prover shared by several host threads — the native context is re-entrant, every
+    caller gets its own proofs back, bit-identical to the oracle's."""
+    from concurrent.futures import ThreadPoolExecutor
+    cs, inputs, aux, vals = toy_r1cs.make(61, 3, 12, 150)
+    pbuf = O.generate_parameters(cs, toy_r1cs.toxic(61))
+    ctx.load_circuit(7, pbuf, cs)
+    params = O.Params(pbuf)
+
+    def caller(t):
+        jobs = [(7, inputs, aux, 100 * t + j + 1, 7000 + 100 * t + j) for j in range(1 + (t * 5) % 13)]
+        return ctx.prove_batch(jobs), [O.create_proof(params, cs, inputs, aux, r, s) for (_, _, _, r, s) in jobs]
+    with ThreadPoolExecutor(8) as ex:
+        for got, expect in ex.map(caller, range(24)):
+            assert got == expect
+
+
 def test_local_tx_prover_batch_equals_serial(ctx):
     """prove_batch (threaded synthesis + one GPU batch) == the serial TxProver calls, including the context state."""
     import random
@@ -312,7 +329,9 @@ def test_local_tx_prover_batch_equals_serial(ctx):
     descs.insert(1, ("convert", dict(allowed_conversion=gen, value=5, anchor=anchor, merkle_path=(sib, 77), rcv=rng.randrange(1, H.JUBJUB_ORDER))))
     rs = [(rng.randrange(H.FR_MODULUS), rng.randrange(H.FR_MODULUS)) for _ in descs]
     c1 = lp.new_sapling_proving_context()
-    batch = lp.prove_batch(c1, descs, rs=rs)
+    seen = []
+    batch = lp.prove_batch(c1, descs, rs=rs, chunk=3, progress=lambda done, total: seen.append((done, total)))
+    assert sorted(seen) == [(1, 4), (4, 4)] or sorted(seen) == [(3, 4), (4, 4)]
     c2 = lp.new_sapling_proving_context()
     serial = []
     for (kind, kw), r in zip(descs, rs):

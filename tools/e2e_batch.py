@@ -1,0 +1,80 @@
+"""End-to-end `LocalTxProver.prove_batch` over N real Spend descriptions (BASELINE.json configs[3]: batch of 256 Spends on
+one GPU): host synthesis (C++ threads) -> GPU batch -> host self-verification, each stage timed.  Unlike bench.py (inputs
+resident in HBM), this includes witness generation, the H2D copies and the pairing checks.
+
+    python tools/e2e_batch.py [N=256] [threads=os.cpu_count()]
+"""
+import os
+import random
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("MASP_HIP_SLOTS", "4")
+os.environ.setdefault("MASP_HIP_BATCH", "32")
+
+from masp_amd import host as H                     # noqa: E402
+from masp_amd.prover import LocalTxProver, _int    # noqa: E402
+
+R = H.FR_MODULUS
+
+
+def spend_description(seed):
+    rng = random.Random(seed)
+    ident = H.asset_identifier(b"benchmark")
+    rs = lambda: rng.randrange(H.JUBJUB_ORDER)     # noqa: E731
+    ak = H.jubjub_mul(H.point_bytes(*H.generator_uv(4)), rs())
+    nsk, ar, rcm, rcv = rs(), rs(), rs(), rs()
+    siblings = [rng.randrange(R) for _ in range(32)]
+    pos = rng.getrandbits(32)
+    while True:
+        d = bytes(rng.getrandbits(8) for _ in range(11))
+        try:
+            cmu, _ = H.spend_leaf(ak, nsk, d, rcm, ident, 1)
+            break
+        except H.HostError:
+            pass
+    anchor = H.merkle_root(cmu, siblings, pos)
+    return ("spend", dict(proof_generation_key=(ak, nsk), diversifier=d, rcm=rcm, ar=ar, asset_type=ident, value=1, anchor=anchor,
+                          merkle_path=(siblings, pos), rcv=rcv))
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    threads = int(sys.argv[2]) if len(sys.argv) > 2 else H.effective_cpus()
+    t = time.time()
+    prover = LocalTxProver.with_synthetic_parameters(seed=7)
+    print("parameters generated + loaded: %.1f s" % (time.time() - t))
+    with ThreadPoolExecutor(threads) as ex:
+        descs = list(ex.map(spend_description, range(n)))
+        # warm-up (workspace allocation, first-launch costs)
+        prover.prove_batch(prover.new_sapling_proving_context(), descs[:min(n, 64)], threads=threads)
+        t0 = time.time()
+        jobs = list(ex.map(lambda d: prover.prepare_spend(**d[1]), descs))
+        t1 = time.time()
+        proofs = prover.prove_prepared(jobs)
+        t2 = time.time()
+
+        def check(args):
+            (kind, kw), job, zk = args
+            pi = list(H.point_uv(job["rk"])) + list(H.point_uv(job["cv"])) + [_int(kw["anchor"])] + H.multipack(job["nf"])
+            return prover.spend_vk.verify(zk, pi)
+        ok = all(ex.map(check, zip(descs, jobs, proofs)))
+        t3 = time.time()
+    assert ok
+    ctx = prover.new_sapling_proving_context()
+    t4 = time.time()
+    out = prover.prove_batch(ctx, descs, threads=threads)
+    t5 = time.time()
+    assert len(out) == n
+    print("N = %d Spend descriptions, %d host threads" % (n, threads))
+    print("  synthesis  %8.1f ms  (%.2f ms/proof wall, %.1f proofs/s)" % ((t1 - t0) * 1e3, (t1 - t0) * 1e3 / n, n / (t1 - t0)))
+    print("  GPU batch  %8.1f ms  (%.2f ms/proof, %.1f proofs/s; includes H2D of witnesses, D2H of proofs)" % ((t2 - t1) * 1e3, (t2 - t1) * 1e3 / n, n / (t2 - t1)))
+    print("  verify     %8.1f ms  (%.2f ms/proof wall)" % ((t3 - t2) * 1e3, (t3 - t2) * 1e3 / n))
+    print("  prove_batch end to end %8.1f ms = %.1f proofs/s" % ((t5 - t4) * 1e3, n / (t5 - t4)))
+
+
+if __name__ == "__main__":
+    main()
