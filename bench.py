@@ -83,6 +83,8 @@ def cpu_baseline(cs, params, inputs, aux, budget_s=20.0):
     """Oracle (C++ restatement of bellperson's CPU prover, oracle/) timed on the host cores: reported baseline only."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
+    from masp_amd.host import effective_cpus
+    O.lib().oracle_set_threads(effective_cpus())     # the cores this process may actually use (cgroup quota), not nproc
     P = O.Params(params)
     n, t0 = 0, time.perf_counter()
     phases = {}
@@ -103,8 +105,8 @@ def cpu_baseline(cs, params, inputs, aux, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=32, help="timed steps; one step = one GPU batch of MASP_HIP_BATCH (32) proofs")
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # let independent proofs' kernels overlap (ROCm default: 4)
@@ -142,9 +144,10 @@ def main():
         p_ = ctx.generate_parameters(inst[0][0], synthetic.toxic_waste(1 + slot))   # same CRS on every rank
         ctx.load_circuit(slot, p_, inst[0][0])
         params = params if params is not None else p_
-    K, W = args.steps, args.warmup
-    warm = ctx.batch_upload(make_jobs(n_distinct, max(W, 1), instances))
-    timed = ctx.batch_upload(make_jobs(n_distinct, K, instances))
+    # one step = one pass of the hot path over one batch: B proofs enqueued as a single launch sequence on one stream
+    K, W, B = args.steps, args.warmup, int(os.environ["MASP_HIP_BATCH"])
+    warm = ctx.batch_upload(make_jobs(n_distinct, max(W, 1) * B, instances))
+    timed = ctx.batch_upload(make_jobs(n_distinct, K * B, instances))
     if W > 0:
         ctx.batch_prove_resident(*warm)
     # single-proof latency (not the headline value)
@@ -169,7 +172,7 @@ def main():
     if dist is not None:
         import torch
         dev = torch.device("cuda", local_rank)
-        all_proofs = D.gather_proofs(proofs, K * world, dist, dev)   # RCCL over xGMI: N*K*192 bytes to rank 0
+        all_proofs = D.gather_proofs(proofs, K * B * world, dist, dev)   # RCCL over xGMI: N*K*B*192 bytes to rank 0
     else:
         all_proofs = proofs
     barrier()
@@ -179,10 +182,10 @@ def main():
     if dist is not None:
         elapsed = D.max_over_ranks(elapsed, dist, dev)
         if rank == 0:
-            assert len(all_proofs) == K * world
+            assert len(all_proofs) == K * B * world
     if rank == 0:
         assert len(set(proofs)) == len(proofs) and all(len(p) == 192 for p in proofs)
-        total = K * world
+        total = K * B * world
         achieved = alg_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -195,14 +198,15 @@ def main():
             "metric": "Spend proofs/sec" if WORKLOAD == "spend" else "%s proofs/sec" % WORKLOAD, "value": total / elapsed, "unit": "proofs/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 limbs (384-bit Fp / 255-bit Fr modular integers)", "data": "synthetic",
-            "config": {"workload": "single %s proof per step (BASELINE.json configs[1]); %s + synthetic CRS from known toxic waste "
+            "config": {"workload": "%s proofs (BASELINE.json configs[1] instances), one step = one batch of %d independent proofs; %s + synthetic CRS from known toxic waste "
                                    "(NTT 2^%d, G1 MSMs %d/%d/%d/%d, G2 MSM %d), witness resident in HBM, "
                                    "batches of %s proofs per launch sequence on %s HIP streams"
-                                   % (WORKLOAD, circuit_desc, cs.logm, (1 << cs.logm) - 1, cs.n_aux,
+                                   % (WORKLOAD, B, circuit_desc, cs.logm, (1 << cs.logm) - 1, cs.n_aux,
                                       synthetic.SHAPES[kinds[0]][3] + cs.n_inputs, synthetic.SHAPES[kinds[0]][4] + 1,
                                       synthetic.SHAPES[kinds[0]][4] + 1, os.environ.get("MASP_HIP_BATCH"), os.environ.get("MASP_HIP_SLOTS")),
-                       "proofs_per_gpu": K, "parallelism": "proofs sharded over %d GPU(s), RCCL gather of proofs" % world},
+                       "proofs_per_step": B, "proofs_per_gpu": K * B, "parallelism": "proofs sharded over %d GPU(s), RCCL gather of proofs" % world},
             "single_proof_latency_ms": latency_ms,
+            "ms_per_proof": elapsed * 1e3 / (K * B),
             "gpu_event_ms_per_step": gpu_ms / K,
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate<G1> (bucket accumulation of the 4 G1 MSMs)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

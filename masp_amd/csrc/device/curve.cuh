@@ -56,10 +56,11 @@ MASP_HD Xyzz<O> xyzz_neg(const Xyzz<O>& p) {
     return r;
 }
 
-// dbl-2008-s-1 for XYZZ.  Out of line on purpose (reached from the rare P == Q branch of the additions
-// and from serial tails); G1: ~45 KiB, G2: call-based, tiny — see MASP_NOINLINE in field.cuh.
+// dbl-2008-s-1 for XYZZ.  Reached from the rare P == Q branch of the additions and from serial tails: its products go
+// through the Cold multiplier policy (register-argument calls, field.cuh), so inlining it costs ~1.5 KiB per site while
+// the point itself never leaves the VGPRs.
 template <class O>
-MASP_NOINLINE Xyzz<O> xyzz_dbl(const Xyzz<O>& p) {
+MASP_HD Xyzz<O> xyzz_dbl(const Xyzz<O>& p) {
     if (xyzz_is_inf(p)) return p;
     typedef typename O::T F;
     typedef typename O::Cold K;
@@ -79,7 +80,7 @@ MASP_NOINLINE Xyzz<O> xyzz_dbl(const Xyzz<O>& p) {
 }
 // doubling of an affine point (mdbl-2008-s-1)
 template <class O>
-MASP_NOINLINE Xyzz<O> xyzz_dbl_affine(const Affine<O>& p) {
+MASP_HD Xyzz<O> xyzz_dbl_affine(const Affine<O>& p) {
     if (aff_is_inf(p)) return xyzz_inf<O>();
     typedef typename O::T F;
     typedef typename O::Cold K;
@@ -170,13 +171,14 @@ MASP_HD void xyzz_add(Xyzz<O>& acc, const Xyzz<O>& b) {
     acc.ZZZ = M::mul(M::mul(acc.ZZZ, b.ZZZ), PPP);
 }
 
-// out-of-line forms for cold kernels and serial tails (G1: ~70 / ~50 KiB, inside the branch range)
+// forms for cold kernels and serial tails: the group law inline (additions / subtractions, ~4 KiB), every field product
+// a call with register arguments — small code, points stay in VGPRs
 template <class O>
-MASP_NOINLINE void xyzz_add_nc(Xyzz<O>& acc, const Xyzz<O>& b) {
+MASP_HD void xyzz_add_nc(Xyzz<O>& acc, const Xyzz<O>& b) {
     xyzz_add<O, typename O::Cold>(acc, b);
 }
 template <class O>
-MASP_NOINLINE void xyzz_madd_nc(Xyzz<O>& acc, const Affine<O>& b, bool negate) {
+MASP_HD void xyzz_madd_nc(Xyzz<O>& acc, const Affine<O>& b, bool negate) {
     xyzz_madd<O, typename O::Cold>(acc, b, negate);
 }
 // [k]p for a 256-bit scalar given as 8 little-endian canonical limbs

@@ -253,10 +253,52 @@ template <class C>
 MASP_HD Fe<C> fe_sqr(const Fe<C>& a) {
     return fe_mul(a, a);
 }
-// out-of-line product: used where code size matters more than the call (G2, serial tails)
+// Out-of-line product: used where code size matters more than the call (G2, cold kernels, serial tails).
+// On the device the 384-bit operands travel in VGPRs: as six 4-dword vectors they are register arguments of the AMDGPU
+// calling convention (an aggregate passed by reference would be spilled to scratch by the caller and re-loaded with flat
+// loads by the callee: ~36 dwords of scratch traffic and a full memory round trip per product).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct FpRegs {
+    u32x4 q0, q1, q2;
+};
+__device__ __noinline__ FpRegs fp_mul_call(u32x4 a0, u32x4 a1, u32x4 a2, u32x4 b0, u32x4 b1, u32x4 b2) {
+    Fe<FpCfg> a, b;
+    a.v[0] = a0.x; a.v[1] = a0.y; a.v[2] = a0.z; a.v[3] = a0.w;
+    a.v[4] = a1.x; a.v[5] = a1.y; a.v[6] = a1.z; a.v[7] = a1.w;
+    a.v[8] = a2.x; a.v[9] = a2.y; a.v[10] = a2.z; a.v[11] = a2.w;
+    b.v[0] = b0.x; b.v[1] = b0.y; b.v[2] = b0.z; b.v[3] = b0.w;
+    b.v[4] = b1.x; b.v[5] = b1.y; b.v[6] = b1.z; b.v[7] = b1.w;
+    b.v[8] = b2.x; b.v[9] = b2.y; b.v[10] = b2.z; b.v[11] = b2.w;
+    Fe<FpCfg> r = fe_mul(a, b);
+    FpRegs o;
+    o.q0 = u32x4{r.v[0], r.v[1], r.v[2], r.v[3]};
+    o.q1 = u32x4{r.v[4], r.v[5], r.v[6], r.v[7]};
+    o.q2 = u32x4{r.v[8], r.v[9], r.v[10], r.v[11]};
+    return o;
+}
+// by-reference form for the other field (Fr: only in set-up code and the final assembly)
 template <class C>
-MASP_NOINLINE Fe<C> fe_mul_nc(const Fe<C>& a, const Fe<C>& b) {
+__device__ __noinline__ Fe<C> fe_mul_ref(const Fe<C>& a, const Fe<C>& b) {
     return fe_mul(a, b);
+}
+template <class C>
+MASP_HD Fe<C> fe_mul_nc(const Fe<C>& a, const Fe<C>& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (C::N == 12) {
+        FpRegs o = fp_mul_call(u32x4{a.v[0], a.v[1], a.v[2], a.v[3]}, u32x4{a.v[4], a.v[5], a.v[6], a.v[7]},
+                               u32x4{a.v[8], a.v[9], a.v[10], a.v[11]}, u32x4{b.v[0], b.v[1], b.v[2], b.v[3]},
+                               u32x4{b.v[4], b.v[5], b.v[6], b.v[7]}, u32x4{b.v[8], b.v[9], b.v[10], b.v[11]});
+        Fe<C> r;
+        r.v[0] = o.q0.x; r.v[1] = o.q0.y; r.v[2] = o.q0.z; r.v[3] = o.q0.w;
+        r.v[4] = o.q1.x; r.v[5] = o.q1.y; r.v[6] = o.q1.z; r.v[7] = o.q1.w;
+        r.v[8] = o.q2.x; r.v[9] = o.q2.y; r.v[10] = o.q2.z; r.v[11] = o.q2.w;
+        return r;
+    } else {
+        return fe_mul_ref(a, b);
+    }
+#else
+    return fe_mul(a, b);
+#endif
 }
 
 // canonical integer limbs <-> Montgomery form

@@ -1,19 +1,21 @@
 #!/usr/bin/env python3
 """Kernel statistics (the `--stats` view) out of a rocprofv3 rocpd SQLite database.
-usage: rocpd_stats.py results.db [> profiles/summary.txt]"""
+usage: rocpd_stats.py results.db [grid_y] [> profiles/summary.txt]
+grid_y: only dispatches with that gridDim.y (= proofs per launch), which isolates the full batches of the timed region."""
 import re
 import sqlite3
 import sys
 
 
-def main(path):
+def main(path, gy=None):
     db = sqlite3.connect(path)
     cur = db.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(rocpd_kernel_dispatch)")]
     sym_cols = [r[1] for r in cur.execute("pragma table_info(rocpd_info_kernel_symbol)")]
     name_col = "display_name" if "display_name" in sym_cols else "kernel_name"
     q = ("select s.%s, count(*), sum(d.end - d.start), avg(d.end - d.start), min(d.end - d.start), max(d.end - d.start) "
-         "from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id group by s.%s order by 3 desc" % (name_col, name_col))
+         "from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id %s group by s.%s order by 3 desc"
+         % (name_col, ("where d.grid_size_y = %d" % gy) if gy else "", name_col))
     rows = list(cur.execute(q))
     total = sum(r[2] for r in rows) or 1
     print("%-70s %8s %12s %12s %10s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "%"))
@@ -31,4 +33,4 @@ def main(path):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else None)
