@@ -8,10 +8,10 @@
 //
 //   load time   T[j][i] = 2^(c*j) * P_i  for every window j (affine, Montgomery), so that all windows
 //               share ONE bucket set and no per-window Horner doublings exist at prove time.
-//   prove time  (1) digits   : signed c-bit digits of every scalar; zero scalars (38 % of a Spend witness) vanish,
-//                              scalars equal to 1 (33 %) go to a "ones" list; bucket histogram.
-//               (2) scan     : exclusive prefix sum of the histogram.
-//               (3) scatter  : counting sort of (table row, sign) by bucket.
+//   prove time  (1) hist     : signed c-bit digits of every scalar, counted per bucket in LDS (zero scalars, 38 % of a
+//                              Spend witness, vanish; scalars equal to 1, 33 %, are one entry of bucket 0).
+//               (2) offsets  : prefix sums over buckets and scalar ranges.
+//               (3) scatter  : counting sort of (table row, sign) by bucket, positions from LDS counters.
 //               (4) accumulate: the SORTED list is cut into equal chunks, one lane per chunk, mixed XYZZ
 //                              additions of gathered table rows; a lane flushes a partial sum whenever its
 //                              chunk crosses a bucket boundary.  Every lane does the same number of
@@ -86,66 +86,93 @@ __global__ void k_msm_precompute(Affine<O>* __restrict__ tab, uint32_t n, int c,
     }
 }
 
-// ---- (1) digits ---------------------------------------------------------------------------------
-// scalars: n x 8 canonical little-endian limbs.  ent[j*n + i] = bucket | sign<<31, or ENT_NONE.
-__global__ void k_msm_digits(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32_t n, MsmGeom g,
-                             uint32_t* __restrict__ ent, uint32_t* __restrict__ hist, uint32_t* __restrict__ ones,
-                             uint32_t* __restrict__ n_ones) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    scalars += MSM_P * scalar_stride;
-    ent += (size_t)MSM_P * n * g.W;
-    hist += (size_t)MSM_P * g.nb;
-    ones += (size_t)MSM_P * n;
-    n_ones += MSM_P;
-    const uint32_t* sw = scalars + (size_t)i * 8;
+// ---- (1)-(3) counting sort of the signed digits by bucket, without global atomics -------------------------
+// The scalars of one proof are cut into `ng` contiguous ranges, one workgroup each.  A workgroup keeps the whole bucket
+// histogram (2^(c-1) counters, 128 KiB for c = 16) in LDS:
+//   k_msm_hist     counts the digits of its range into LDS and stores the histogram            hist_wg[p][wg][b]
+//   k_msm_offsets  turns them into  rel[p][wg][b] = entries of bucket b in earlier ranges  and  start[p][b]
+//   k_msm_scatter  reloads  start[b] + rel[wg][b]  into LDS, recomputes the digits of the same range and places every
+//                  entry with one LDS atomic.
+// Scalars equal to 1 (a third of a MASP witness: booleans) all land in bucket 0 of window 0; a wave counts / places them
+// with one ballot instead of 64 colliding atomics.  Zero scalars (38 %) produce nothing.
+// scalars: n x 8 canonical little-endian limbs.  sorted entry = table row (j*n + i) | sign << 31.
+struct MsmDigitIter {
+    const uint32_t* sw;
+    uint32_t carry, mask, half;
+    int c;
+    __device__ __forceinline__ MsmDigitIter(const uint32_t* sw_, int c_) : sw(sw_), carry(0), mask((1u << c_) - 1u), half(1u << (c_ - 1)), c(c_) {}
+    // digit of window j (call with j = 0, 1, 2, ... in order); false if it is zero
+    __device__ __forceinline__ bool next(int j, uint32_t& bucket, uint32_t& neg) {
+        int bit = j * c;
+        int w = bit >> 5, off = bit & 31;
+        // (re-read from L1/L2 instead of indexing a register array dynamically)
+        uint64_t two = ((uint64_t)(w + 1 < 8 ? sw[w + 1] : 0u) << 32) | sw[w];
+        uint32_t v = ((uint32_t)(two >> off) & mask) + carry;
+        neg = 0;
+        carry = 0;
+        if (v > half) {
+            v = (1u << c) - v;
+            neg = 1;
+            carry = 1;
+        }
+        bucket = v - 1;
+        return v != 0;
+    }
+};
+// 0: zero, 1: one, 2: anything else
+__device__ __forceinline__ int msm_scalar_class(const uint32_t* sw) {
     const uint4* sp = reinterpret_cast<const uint4*>(sw);
     uint4 lo = sp[0], hi = sp[1];
     uint32_t rest = lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w;
-    bool is_one = rest == 0 && lo.x == 1;
-    if (is_one) ones[atomicAdd(n_ones, 1u)] = i;  // ~1/3 of a MASP witness: summed by k_msm_ones, not bucketed
-    bool skip = is_one || (rest | lo.x) == 0;
-    uint32_t carry = 0;
-    const uint32_t mask = (1u << g.c) - 1u;
-    const uint32_t half = 1u << (g.c - 1);
-    for (int j = 0; j < g.W; ++j) {
-        uint32_t e = ENT_NONE;
-        if (!skip) {
-            int bit = j * g.c;
-            int w = bit >> 5, off = bit & 31;
-            // (re-read from L1/L2 instead of indexing a register array dynamically)
-            uint64_t two = ((uint64_t)(w + 1 < 8 ? sw[w + 1] : 0u) << 32) | sw[w];
-            uint32_t v = (uint32_t)(two >> off) & mask;
-            v += carry;
-            uint32_t neg = 0;
-            if (v > half) {
-                v = (1u << g.c) - v;
-                neg = 1;
-                carry = 1;
-            } else {
-                carry = 0;
-            }
-            if (v != 0) {
-                e = (v - 1) | (neg << 31);
-                atomicAdd(&hist[v - 1], 1u);
+    if (rest == 0 && lo.x <= 1) return (int)lo.x;
+    return 2;
+}
+static constexpr uint32_t MSM_SORT_THREADS = 1024;
+__global__ void __launch_bounds__(1024)
+k_msm_hist(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32_t n, MsmGeom g, uint32_t ng, uint32_t* __restrict__ hist_wg) {
+    extern __shared__ uint32_t msm_lds[];
+    const uint32_t tid = threadIdx.x, wg = blockIdx.x, nb = (uint32_t)g.nb;
+    scalars += MSM_P * scalar_stride;
+    hist_wg += ((size_t)MSM_P * ng + wg) * nb;
+    for (uint32_t b = tid; b < nb; b += MSM_SORT_THREADS) msm_lds[b] = 0;
+    __syncthreads();
+    const uint32_t per = (n + ng - 1) / ng, lo = wg * per, hi = lo + per < n ? lo + per : n;
+    for (uint32_t base = lo; base < hi; base += MSM_SORT_THREADS) {
+        const uint32_t i = base + tid;
+        const uint32_t* sw = scalars + (size_t)i * 8;
+        const int cls = i < hi ? msm_scalar_class(sw) : 0;
+        const uint64_t ones = __ballot(cls == 1);
+        if (cls == 1) {
+            if ((uint32_t)__ffsll((unsigned long long)ones) - 1u == (tid & 63u)) atomicAdd(&msm_lds[0], (uint32_t)__popcll(ones));
+        } else if (cls == 2) {
+            MsmDigitIter it(sw, g.c);
+            for (int j = 0; j < g.W; ++j) {
+                uint32_t bucket, neg;
+                if (it.next(j, bucket, neg)) atomicAdd(&msm_lds[bucket], 1u);
             }
         }
-        ent[(size_t)j * n + i] = e;
     }
+    __syncthreads();
+    for (uint32_t b = tid; b < nb; b += MSM_SORT_THREADS) hist_wg[b] = msm_lds[b];
 }
-
-// ---- (2) exclusive scan, single workgroup; out has n + 1 entries (out[n] = total) -------------------
-__global__ void k_scan_exclusive(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n) {
+// one workgroup per proof: hist_wg[wg][b] -> rel[wg][b] (in place), start[0..nb] (start[nb] = number of entries)
+__global__ void __launch_bounds__(1024) k_msm_offsets(uint32_t* __restrict__ hist_wg, uint32_t ng, uint32_t nb, uint32_t* __restrict__ start) {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t base;
-    in += (size_t)MSM_P * n;
-    out += (size_t)MSM_P * (n + 1);
+    hist_wg += (size_t)MSM_P * ng * nb;
+    start += (size_t)MSM_P * (nb + 1);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (tid == 0) base = 0;
     __syncthreads();
-    for (uint32_t start = 0; start < n; start += blockDim.x) {
-        uint32_t idx = start + tid;
-        uint32_t v = idx < n ? in[idx] : 0;
+    for (uint32_t b0 = 0; b0 < nb; b0 += blockDim.x) {
+        const uint32_t b = b0 + tid;
+        uint32_t v = 0;
+        if (b < nb)
+            for (uint32_t w = 0; w < ng; ++w) {
+                uint32_t h = hist_wg[(size_t)w * nb + b];
+                hist_wg[(size_t)w * nb + b] = v;
+                v += h;
+            }
         uint32_t x = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -156,30 +183,46 @@ __global__ void k_scan_exclusive(const uint32_t* __restrict__ in, uint32_t* __re
         __syncthreads();
         uint32_t woff = 0;
         for (uint32_t k = 0; k < wid; ++k) woff += wsum[k];
-        uint32_t b = base;
-        if (idx < n) out[idx] = b + woff + x - v;
+        const uint32_t bs = base;
+        if (b < nb) start[b] = bs + woff + x - v;
         __syncthreads();
-        if (tid == blockDim.x - 1) base = b + woff + x;
+        if (tid == blockDim.x - 1) base = bs + woff + x;
         __syncthreads();
     }
-    if (tid == 0) out[n] = base;  // grand total
+    if (tid == 0) start[nb] = base;
 }
-
-// ---- (3) scatter --------------------------------------------------------------------------------
-__global__ void k_msm_scatter(const uint32_t* __restrict__ ent, uint32_t total, uint32_t nb, const uint32_t* __restrict__ start,
-                              uint32_t* __restrict__ fill, uint32_t* __restrict__ sorted) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    ent += (size_t)MSM_P * total;
-    sorted += (size_t)MSM_P * total;
+__global__ void __launch_bounds__(1024)
+k_msm_scatter(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32_t n, MsmGeom g, uint32_t ng, const uint32_t* __restrict__ rel,
+              const uint32_t* __restrict__ start, uint32_t* __restrict__ sorted) {
+    extern __shared__ uint32_t msm_lds[];
+    const uint32_t tid = threadIdx.x, wg = blockIdx.x, nb = (uint32_t)g.nb;
+    scalars += MSM_P * scalar_stride;
+    rel += ((size_t)MSM_P * ng + wg) * nb;
     start += (size_t)MSM_P * (nb + 1);
-    fill += (size_t)MSM_P * nb;
-    uint32_t e = ent[t];
-    if (e == ENT_NONE) return;
-    uint32_t key = e & 0x7fffffffu;
-    uint32_t pos = start[key] + atomicAdd(&fill[key], 1u);
-    // t = j*n + i is exactly the table row index
-    sorted[pos] = t | (e & 0x80000000u);
+    sorted += (size_t)MSM_P * n * g.W;
+    for (uint32_t b = tid; b < nb; b += MSM_SORT_THREADS) msm_lds[b] = start[b] + rel[b];
+    __syncthreads();
+    const uint32_t per = (n + ng - 1) / ng, lo = wg * per, hi = lo + per < n ? lo + per : n;
+    for (uint32_t base = lo; base < hi; base += MSM_SORT_THREADS) {
+        const uint32_t i = base + tid;
+        const uint32_t* sw = scalars + (size_t)i * 8;
+        const int cls = i < hi ? msm_scalar_class(sw) : 0;
+        const uint64_t ones = __ballot(cls == 1);
+        if (ones) {
+            const int leader = __ffsll((unsigned long long)ones) - 1;
+            uint32_t first = 0;
+            if ((int)(tid & 63u) == leader) first = atomicAdd(&msm_lds[0], (uint32_t)__popcll(ones));
+            first = __shfl(first, leader, 64);
+            if (cls == 1) sorted[first + (uint32_t)__popcll(ones & ((1ull << (tid & 63u)) - 1ull))] = i;  // window 0: row i, positive
+        }
+        if (cls == 2) {
+            MsmDigitIter it(sw, g.c);
+            for (int j = 0; j < g.W; ++j) {
+                uint32_t bucket, neg;
+                if (it.next(j, bucket, neg)) sorted[atomicAdd(&msm_lds[bucket], 1u)] = ((uint32_t)j * n + i) | (neg << 31);
+            }
+        }
+    }
 }
 
 // ---- (4) accumulate: equal chunks of the sorted list ------------------------------------------------
@@ -284,28 +327,6 @@ k_msm_bucket_heavy(const Xyzz<O>* __restrict__ part, const uint32_t* __restrict_
     }
 }
 
-// ones list: 256 workgroups of one wave; lane g adds tab[ones[g]], tab[ones[g + 16384]], ... then an LDS tree
-template <class O>
-__global__ void __launch_bounds__(64)
-k_msm_ones(const Affine<O>* __restrict__ tab, const uint32_t* __restrict__ ones, size_t ones_stride, const uint32_t* __restrict__ n_ones,
-           Xyzz<O>* __restrict__ out) {
-    extern __shared__ uint4 wsum_lds[];
-    Xyzz<O>* sh = reinterpret_cast<Xyzz<O>*>(wsum_lds);
-    const uint32_t lane = threadIdx.x;
-    ones += MSM_P * ones_stride;
-    out += (size_t)MSM_P * gridDim.x;
-    const uint32_t n = n_ones[MSM_P];
-    Xyzz<O> acc = xyzz_inf<O>();
-    for (uint32_t k = blockIdx.x * 64 + lane; k < n; k += gridDim.x * 64) xyzz_madd_nc(acc, tab[ones[k]], false);
-    for (uint32_t d = 32; d >= 1; d >>= 1) {
-        sh[lane] = acc;
-        __syncthreads();
-        if (lane < d) xyzz_add_nc(acc, sh[lane + d]);
-        __syncthreads();
-    }
-    if (lane == 0) out[blockIdx.x] = acc;
-}
-
 // ---- (6) reductions -----------------------------------------------------------------------------
 // One level of the weighted sum  V(B, off) = sum_k (k + off) * B[k].  A workgroup of WSUM_L lanes owns a chunk of
 // WSUM_CS = WSUM_G * WSUM_L elements and produces  S[ch] = sum_l B[ch*cs + l],  T[ch] = sum_l (l + off) * B[ch*cs + l];
@@ -375,20 +396,17 @@ __global__ void __launch_bounds__(256) k_xyzz_reduce_block(const Xyzz<O>* __rest
     }
     if (tid == 0) out[blockIdx.x] = y;
 }
-// V = T0 + cs*(T1 + cs*(T2 + ...)) + ones ;  tsum[l] holds the fully reduced T of level l.
+// V = T0 + cs*(T1 + cs*(T2 + ...)) ;  tsum[l] holds the fully reduced T of level l.
 template <class O>
-__global__ void k_msm_combine(const Xyzz<O>* __restrict__ tsum, int levels, int cs_log, const Xyzz<O>* __restrict__ ones_sum,
-                              Xyzz<O>* __restrict__ out, size_t out_stride) {
+__global__ void k_msm_combine(const Xyzz<O>* __restrict__ tsum, int levels, int cs_log, Xyzz<O>* __restrict__ out, size_t out_stride) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     tsum += (size_t)MSM_P * 32;
-    ones_sum += MSM_P;
     out += MSM_P * out_stride;
     Xyzz<O> acc = xyzz_inf<O>();
     for (int l = levels - 1; l >= 0; --l) {
         for (int k = 0; k < cs_log; ++k) acc = xyzz_dbl(acc);
         xyzz_add_nc(acc, tsum[l]);
     }
-    xyzz_add_nc(acc, *ones_sum);
     *out = acc;
 }
 

@@ -63,28 +63,67 @@ struct MsmBases {
     }
 };
 
-// ---- workspace ------------------------------------------------------------------------------------
+// ---- sort buffers (curve-independent): one counting sort can feed several MSMs over the same scalars ---------
+struct MsmSortBuf {
+    size_t cap_ent = 0, cap_nb = 0, cap_np = 0, cap_ng = 0;
+    uint32_t *sorted = nullptr, *hist_wg = nullptr, *start = nullptr;
+    // what the last msm_sort_enqueue produced (consumed by msm_reduce_enqueue)
+    uint32_t n = 0, np = 0;
+    MsmGeom g{};
+
+    ~MsmSortBuf() { release(); }
+    void release() {
+        void* ptrs[] = {sorted, hist_wg, start};
+        for (void* p : ptrs)
+            if (p) hipFree(p);
+        sorted = hist_wg = start = nullptr;
+        cap_ent = cap_nb = cap_np = cap_ng = 0;
+    }
+    // scalar ranges (= sorting workgroups) per proof: enough to occupy the chip across the batch, not more
+    static uint32_t ranges_for(uint32_t n, uint32_t np) {
+        uint32_t ng = std::max(1u, 512u / std::max(np, 1u));
+        ng = std::min(ng, 64u);
+        return std::max(1u, std::min(ng, (n + 1023) / 1024));
+    }
+    int reserve(uint32_t n_, const MsmGeom& g_, uint32_t np_) {
+        size_t need_ent = (size_t)n_ * g_.W, need_ng = ranges_for(n_, np_);
+        if (need_ent <= cap_ent && (size_t)g_.nb <= cap_nb && np_ <= cap_np && need_ng <= cap_ng) return MASP_HIP_OK;
+        need_ent = std::max(need_ent, cap_ent);
+        size_t need_nb = std::max<size_t>(g_.nb, cap_nb), need_np = std::max<size_t>(np_, cap_np);
+        need_ng = std::max(need_ng, cap_ng);
+        release();
+        cap_ent = need_ent;
+        cap_nb = need_nb;
+        cap_np = need_np;
+        cap_ng = need_ng;
+        HIP_TRY(hipMalloc(&sorted, cap_np * 4 * std::max<size_t>(cap_ent, 1)));
+        HIP_TRY(hipMalloc(&hist_wg, cap_np * 4 * cap_ng * cap_nb));
+        HIP_TRY(hipMalloc(&start, cap_np * 4 * (cap_nb + 1)));
+        return MASP_HIP_OK;
+    }
+};
+
+// ---- workspace of the group arithmetic ---------------------------------------------------------------
 template <class O>
 struct MsmWorkspace {
     static constexpr uint32_t CS_LOG = WSUM_CS_LOG;   // weighted-sum chunk = WSUM_G x WSUM_L buckets per workgroup
     static constexpr uint32_t NCHUNKS = 1u << 18;     // lanes of the accumulation kernel (1024 waves x 4 per SIMD)
     static constexpr uint32_t HEAVY_BLOCKS = 256;
 
-    size_t cap_ent = 0, cap_nb = 0, cap_np = 0, cap_chunks = 0;
-    uint32_t *ent = nullptr, *sorted = nullptr, *hist = nullptr, *start = nullptr, *fill = nullptr;
-    uint32_t *heavy = nullptr, *n_heavy = nullptr, *ones = nullptr, *n_ones = nullptr;
-    size_t cap_n = 0;
+    MsmSortBuf sort;  // used unless the caller shares another workspace's sort
+    size_t cap_nb = 0, cap_np = 0, cap_chunks = 0;
+    uint32_t *heavy = nullptr, *n_heavy = nullptr;
     Xyzz<O>*part = nullptr, *bkt = nullptr, *S[2] = {nullptr, nullptr}, *T = nullptr, *R[2] = {nullptr, nullptr};
-    Xyzz<O>*tsum = nullptr, *ones_part = nullptr, *ones_sum = nullptr;
+    Xyzz<O>* tsum = nullptr;
 
     ~MsmWorkspace() { release(); }
     void release() {
-        void* ptrs[] = {ent, sorted, hist, start, fill, heavy, n_heavy, ones, n_ones, part, bkt, S[0], S[1], T, R[0], R[1], tsum, ones_part, ones_sum};
+        void* ptrs[] = {heavy, n_heavy, part, bkt, S[0], S[1], T, R[0], R[1], tsum};
         for (void* p : ptrs)
             if (p) hipFree(p);
-        ent = sorted = hist = start = fill = heavy = n_heavy = ones = n_ones = nullptr;
-        part = bkt = S[0] = S[1] = T = R[0] = R[1] = tsum = ones_part = ones_sum = nullptr;
-        cap_ent = cap_nb = cap_n = cap_np = cap_chunks = 0;
+        heavy = n_heavy = nullptr;
+        part = bkt = S[0] = S[1] = T = R[0] = R[1] = tsum = nullptr;
+        cap_nb = cap_np = cap_chunks = 0;
     }
     // lanes of the accumulation kernel per proof: ~2^18 across the whole batch.  Fewer, longer chunks mean fewer
     // partial sums to write and to gather (each extra partial costs a full XYZZ addition later).
@@ -97,30 +136,18 @@ struct MsmWorkspace {
     }
     // room for `np` proofs of an n-point MSM with geometry g (every per-proof array is np-fold)
     int reserve(uint32_t n, const MsmGeom& g, uint32_t np) {
-        size_t need_ent = (size_t)n * g.W, need_chunks = nchunks_for(n, g, np);
-        if (need_ent <= cap_ent && (size_t)g.nb <= cap_nb && n <= cap_n && np <= cap_np && need_chunks <= cap_chunks) return MASP_HIP_OK;
-        need_ent = std::max(need_ent, cap_ent);
+        size_t need_chunks = nchunks_for(n, g, np);
+        if ((size_t)g.nb <= cap_nb && np <= cap_np && need_chunks <= cap_chunks) return MASP_HIP_OK;
         need_chunks = std::max(need_chunks, cap_chunks);
-        size_t need_nb = std::max<size_t>(g.nb, cap_nb), need_n = std::max<size_t>(n, cap_n), need_np = std::max<size_t>(np, cap_np);
+        size_t need_nb = std::max<size_t>(g.nb, cap_nb), need_np = std::max<size_t>(np, cap_np);
         release();
-        cap_ent = need_ent;
         cap_nb = need_nb;
-        cap_n = need_n;
         cap_np = need_np;
         cap_chunks = need_chunks;
         const size_t P = cap_np;
         size_t chunks = (cap_nb + (1u << CS_LOG) - 1) >> CS_LOG;
-        HIP_TRY(hipMalloc(&ent, P * 4 * std::max<size_t>(cap_ent, 1)));
-        HIP_TRY(hipMalloc(&sorted, P * 4 * std::max<size_t>(cap_ent, 1)));
-        HIP_TRY(hipMalloc(&hist, P * 4 * cap_nb));
-        HIP_TRY(hipMalloc(&start, P * 4 * (cap_nb + 1)));
-        HIP_TRY(hipMalloc(&fill, P * 4 * cap_nb));
         HIP_TRY(hipMalloc(&heavy, P * 4 * cap_nb));
         HIP_TRY(hipMalloc(&n_heavy, P * 4));
-        HIP_TRY(hipMalloc(&ones, P * 4 * std::max<size_t>(cap_n, 1)));
-        HIP_TRY(hipMalloc(&n_ones, P * 4));
-        HIP_TRY(hipMalloc(&ones_part, P * sizeof(Xyzz<O>) * 256));
-        HIP_TRY(hipMalloc(&ones_sum, P * sizeof(Xyzz<O>)));
         HIP_TRY(hipMalloc(&part, P * sizeof(Xyzz<O>) * (cap_chunks + cap_nb)));
         HIP_TRY(hipMalloc(&bkt, P * sizeof(Xyzz<O>) * cap_nb));
         HIP_TRY(hipMalloc(&S[0], P * sizeof(Xyzz<O>) * chunks));
@@ -200,23 +227,51 @@ struct MsmProfile {
     }
 };
 
-// Enqueue, for each of `np` proofs p, sum_i scalars_p[i] * P_i on stream `s` — one launch per stage for the whole batch.
-// scalars_p = d_scalars + p * scalar_stride (u32 units), n x 8 canonical LE limbs each; result p at d_out + p * out_stride.
-// No host synchronisation.
+// Counting sort of the signed window digits of `np` scalar vectors (n scalars each) by bucket, on stream `s`.
+// scalars_p = d_scalars + p * scalar_stride (u32 units), n x 8 canonical LE limbs each.  No host synchronisation.
+static inline int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb, const uint32_t* d_scalars, size_t scalar_stride,
+                                   uint32_t np) {
+    if (g.c < 2 || g.c > 16) {
+        last_hip_error() = "MSM window width must be 2..16 bits (the bucket histogram lives in LDS)";
+        return MASP_HIP_E_INVALID_ARG;
+    }
+    int rc = sb.reserve(n, g, np);
+    if (rc) return rc;
+    sb.n = n;
+    sb.np = np;
+    sb.g = g;
+    static bool lds_ok = [] {
+        int bytes = 4 << 15;
+        return hipFuncSetAttribute((const void*)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+               hipFuncSetAttribute((const void*)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+    }();
+    if (!lds_ok) {
+        last_hip_error() = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
+        return MASP_HIP_E_HIP;
+    }
+    const uint32_t ng = MsmSortBuf::ranges_for(n, np), nb = g.nb;
+    hipLaunchKernelGGL(k_msm_hist, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg);
+    hipLaunchKernelGGL(k_msm_offsets, dim3(1, np), dim3(1024), 0, s, sb.hist_wg, ng, nb, sb.start);
+    hipLaunchKernelGGL(k_msm_scatter, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg, sb.start,
+                       sb.sorted);
+    return MASP_HIP_OK;
+}
+
+// Bucket accumulation + reduction of the MSM whose digits were sorted into `sb` (same n, geometry and batch size):
+// result p at d_out + p * out_stride.  No host synchronisation.
 template <class O, int BYTES>
-int msm_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, MsmWorkspace<O>& ws, const uint32_t* d_scalars, size_t scalar_stride,
-                Xyzz<O>* d_out, size_t out_stride, uint32_t np, MsmProfile* prof = nullptr) {
+int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSortBuf& sb, MsmWorkspace<O>& ws, Xyzz<O>* d_out, size_t out_stride,
+                       MsmProfile* prof = nullptr) {
     const MsmGeom& g = B.g;
-    const uint32_t n = B.n;
-    if (np == 0) return MASP_HIP_OK;
-    if (n == 0) {
-        for (uint32_t p = 0; p < np; ++p) HIP_TRY(hipMemsetAsync(d_out + p * out_stride, 0, sizeof(Xyzz<O>), s));  // infinity (ZZ = 0)
-        return MASP_HIP_OK;
+    const uint32_t n = B.n, np = sb.np;
+    if (sb.n != n || sb.g.c != g.c) {
+        last_hip_error() = "msm_reduce_enqueue: sort does not match the base set";
+        return MASP_HIP_E_INVALID_ARG;
     }
     int rc = ws.reserve(n, g, np);
     if (rc) return rc;
     {
-        // the LDS tree kernels keep 256 XYZZ points per workgroup: 48 KiB (G1) / 96 KiB (G2) of the 160 KiB LDS
+        // the LDS tree kernels keep up to 256 XYZZ points per workgroup: 48 KiB (G1) / 96 KiB (G2) of the 160 KiB LDS
         static bool lds_ok = [] {
             int bytes = 256 * (int)sizeof(Xyzz<O>);
             bool ok = hipFuncSetAttribute((const void*)k_msm_wsum_level<O>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
@@ -231,33 +286,24 @@ int msm_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, MsmWorkspace<O>& ws,
     const uint32_t nb = g.nb;
     const uint32_t total = n * g.W;
     const uint32_t nchunks = ws.nchunks_for(n, g, np);
-    const size_t part_stride = (size_t)nchunks + nb;
-    (void)part_stride;
-    HIP_TRY(hipMemsetAsync(ws.hist, 0, 4 * (size_t)nb * np, s));
-    HIP_TRY(hipMemsetAsync(ws.fill, 0, 4 * (size_t)nb * np, s));
     HIP_TRY(hipMemsetAsync(ws.n_heavy, 0, 4 * np, s));
-    HIP_TRY(hipMemsetAsync(ws.n_ones, 0, 4 * np, s));
-    hipLaunchKernelGGL(k_msm_digits, dim3((n + 255) / 256, np), dim3(256), 0, s, d_scalars, scalar_stride, n, g, ws.ent, ws.hist, ws.ones,
-                       ws.n_ones);
-    hipLaunchKernelGGL(k_scan_exclusive, dim3(1, np), dim3(1024), 0, s, ws.hist, ws.start, nb);
-    hipLaunchKernelGGL(k_msm_scatter, dim3((total + 255) / 256, np), dim3(256), 0, s, ws.ent, total, nb, ws.start, ws.fill, ws.sorted);
     MsmProfile::Rec rec{};
     if (prof) {
         rec = prof->acquire();
         rec.alg_bytes = (uint64_t)np * n * (BYTES + 32);  // n x (affine base + scalar) per proof
         hipEventRecord(rec.e0, s);
     }
-    hipLaunchKernelGGL((k_msm_accumulate<O>), dim3((nchunks + 63) / 64, np), dim3(64), 0, s, B.tab, ws.sorted, (size_t)total, ws.start, nb,
+    hipLaunchKernelGGL((k_msm_accumulate<O>), dim3((nchunks + 63) / 64, np), dim3(64), 0, s, B.tab, sb.sorted, (size_t)total, sb.start, nb,
                        nchunks, ws.part);
     if (prof) {
         hipEventRecord(rec.e1, s);
         prof->recs.push_back(rec);
     }
-    hipLaunchKernelGGL((k_msm_bucket_gather<O>), dim3((nb + 63) / 64, np), dim3(64), 0, s, ws.part, ws.start, nb, nchunks, ws.bkt, ws.heavy,
+    hipLaunchKernelGGL((k_msm_bucket_gather<O>), dim3((nb + 63) / 64, np), dim3(64), 0, s, ws.part, sb.start, nb, nchunks, ws.bkt, ws.heavy,
                        ws.n_heavy);
-    hipLaunchKernelGGL((k_msm_bucket_heavy<O>), dim3(ws.HEAVY_BLOCKS, np), dim3(64), 64 * sizeof(Xyzz<O>), s, ws.part, ws.start, nb, nchunks,
+    hipLaunchKernelGGL((k_msm_bucket_heavy<O>), dim3(ws.HEAVY_BLOCKS, np), dim3(64), 64 * sizeof(Xyzz<O>), s, ws.part, sb.start, nb, nchunks,
                        ws.bkt, ws.heavy, ws.n_heavy);
-    // weighted sum by levels of 256-bucket workgroups
+    // weighted sum by levels of WSUM_CS-bucket workgroups
     const uint32_t cs = 1u << ws.CS_LOG;
     const size_t st_stride = (nb + cs - 1) / cs;  // level-0 chunk count bounds every later level
     const Xyzz<O>* bk = ws.bkt;
@@ -276,12 +322,24 @@ int msm_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, MsmWorkspace<O>& ws,
         off = 0;
         ++level;
     } while (m > 1);
-    // ones list: 256 waves per proof, then one workgroup tree
-    hipLaunchKernelGGL((k_msm_ones<O>), dim3(256, np), dim3(64), 64 * sizeof(Xyzz<O>), s, B.tab, ws.ones, (size_t)n, ws.n_ones, ws.ones_part);
-    hipLaunchKernelGGL((k_xyzz_reduce_block<O>), dim3(1, np), dim3(256), 256 * sizeof(Xyzz<O>), s, ws.ones_part, (size_t)256, 256u, ws.ones_sum,
-                       (size_t)1);
-    hipLaunchKernelGGL((k_msm_combine<O>), dim3(1, np), dim3(64), 0, s, ws.tsum, level, (int)ws.CS_LOG, ws.ones_sum, d_out, out_stride);
+    hipLaunchKernelGGL((k_msm_combine<O>), dim3(1, np), dim3(64), 0, s, ws.tsum, level, (int)ws.CS_LOG, d_out, out_stride);
     return MASP_HIP_OK;
+}
+
+// Enqueue, for each of `np` proofs p, sum_i scalars_p[i] * P_i on stream `s` — one launch per stage for the whole batch.
+// scalars_p = d_scalars + p * scalar_stride (u32 units), n x 8 canonical LE limbs each; result p at d_out + p * out_stride.
+// No host synchronisation.
+template <class O, int BYTES>
+int msm_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, MsmWorkspace<O>& ws, const uint32_t* d_scalars, size_t scalar_stride,
+                Xyzz<O>* d_out, size_t out_stride, uint32_t np, MsmProfile* prof = nullptr) {
+    if (np == 0) return MASP_HIP_OK;
+    if (B.n == 0) {
+        for (uint32_t p = 0; p < np; ++p) HIP_TRY(hipMemsetAsync(d_out + p * out_stride, 0, sizeof(Xyzz<O>), s));  // infinity (ZZ = 0)
+        return MASP_HIP_OK;
+    }
+    int rc = msm_sort_enqueue(s, B.n, B.g, ws.sort, d_scalars, scalar_stride, np);
+    if (rc) return rc;
+    return msm_reduce_enqueue(s, B, ws.sort, ws, d_out, out_stride, prof);
 }
 
 }  // namespace masp

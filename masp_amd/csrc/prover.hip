@@ -377,7 +377,12 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
     if ((rc = msm_enqueue(s, C.l, sl.ws1, (const uint32_t*)(d_w + C.n_inputs), w_stride * 8, sl.res1.p + 1, 4, np, prof))) return rc;
     if ((rc = msm_enqueue(s, C.a, sl.ws1, (const uint32_t*)sl.sa.p, (size_t)C.na * 8, sl.res1.p + 2, 4, np, prof))) return rc;
     if ((rc = msm_enqueue(s, C.b1, sl.ws1, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res1.p + 3, 4, np, prof))) return rc;
-    if ((rc = msm_enqueue(s, C.b2, sl.ws2, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res2.p, 1, np))) return rc;
+    // B2 runs over the same scalars as B1: when both base sets use the same window width the sort is shared
+    if (C.nbq && C.b2.n == C.b1.n && C.b2.g.c == C.b1.g.c) {
+        if ((rc = msm_reduce_enqueue(s, C.b2, sl.ws1.sort, sl.ws2, sl.res2.p, 1))) return rc;
+    } else if ((rc = msm_enqueue(s, C.b2, sl.ws2, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res2.p, 1, np))) {
+        return rc;
+    }
     hipLaunchKernelGGL(k_groth16_assemble, dim3(np), dim3(192), 0, s, C.vk.p, C.fb1.p, C.fb2.p, sl.res1.p, sl.res2.p, d_rs, (size_t)16, d_proof);
     return MASP_HIP_OK;
 }
