@@ -26,15 +26,18 @@ __global__ void k_fr_to_mont(const Fr* __restrict__ x, size_t x_stride, Fr* __re
 // One CSR row per lane: out[row] = sum_t coef[t] * w[col[t]]  (all Montgomery).  Rows
 // n_constraints .. n_constraints + n_inputs - 1 are bellperson's extra "Input(i) * 0 = 0" rows:
 // a = input value, b = c = 0 (which == 0 selects matrix A).
-__global__ void k_r1cs_eval(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, const Fr* __restrict__ coef,
-                            const Fr* __restrict__ w, uint32_t n_vars, uint32_t n_constraints, uint32_t n_inputs, int which,
-                            Fr* __restrict__ out) {
+// Row lengths of the MASP circuits range from 1 to several hundred terms (bit packings): `order` lists the constraint
+// rows by decreasing length, so the 64 rows of a wave take about equally long.
+__global__ void k_r1cs_eval(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ order, const uint32_t* __restrict__ col,
+                            const Fr* __restrict__ coef, const Fr* __restrict__ w, uint32_t n_vars, uint32_t n_constraints, uint32_t n_inputs,
+                            int which, Fr* __restrict__ out) {
     uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_constraints + n_inputs) return;
     w += (size_t)blockIdx.y * n_vars;
     out += (size_t)blockIdx.y * (n_constraints + n_inputs);
     Fr acc = fe_zero<FrCfg>();
     if (row < n_constraints) {
+        row = order[row];
         uint32_t lo = rowptr[row], hi = rowptr[row + 1];
         for (uint32_t t = lo; t < hi; ++t) acc = fe_add(acc, fe_mul(fr_load(coef + t), fr_load(w + col[t])));
     } else if (which == 0) {

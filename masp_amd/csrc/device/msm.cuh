@@ -335,7 +335,10 @@ k_msm_bucket_heavy(const Xyzz<O>* __restrict__ part, const uint32_t* __restrict_
 //   phase 2  the per-lane sums are combined with a log-depth suffix scan and one tree through LDS.
 // ~4.5 additions per bucket in total (a pure log-depth scan costs 16) at a depth of 33 dependent additions:
 // with a batch of proofs in flight the chip is throughput-bound here, so work counts, not just depth.
-static constexpr uint32_t WSUM_G_LOG = 3, WSUM_L_LOG = 7;
+#ifndef MASP_WSUM_G_LOG
+#define MASP_WSUM_G_LOG 4
+#endif
+static constexpr uint32_t WSUM_G_LOG = MASP_WSUM_G_LOG, WSUM_L_LOG = 7;
 static constexpr uint32_t WSUM_G = 1u << WSUM_G_LOG, WSUM_L = 1u << WSUM_L_LOG;
 static constexpr uint32_t WSUM_CS_LOG = WSUM_G_LOG + WSUM_L_LOG;
 static constexpr uint32_t WSUM_CS = 1u << WSUM_CS_LOG;

@@ -26,7 +26,8 @@ class JobStruct(C.Structure):
 
 
 def library_path():
-    return os.path.join(_HERE, "libmasp_hip.so")
+    # MASP_HIP_LIBRARY: an alternative build of the same library (A/B measurements of compile-time parameters)
+    return os.environ.get("MASP_HIP_LIBRARY") or os.path.join(_HERE, "libmasp_hip.so")
 
 
 def load_library():
