@@ -28,16 +28,16 @@ struct MsmBases {
     // statistics of its circuit, a generic caller passes n): per non-trivial scalar the accumulation costs W = 256/c
     // mixed additions, per bucket the gather + weighted sum cost ~5.5 full additions.
     static MsmGeom pick_geom(uint32_t n_eff) {
-        int c = n_eff >= (1u << 16) ? 16 : n_eff >= (1u << 12) ? 13 : n_eff >= (1u << 8) ? 10 : 7;
+        int c = n_eff >= (1u << 16) ? 16 : n_eff >= (1u << 12) ? 12 : n_eff >= (1u << 8) ? 10 : 7;
         const char* e = getenv("MASP_HIP_MSM_C");
         if (e) c = atoi(e);
         return msm_geom(c);
     }
     // raw: device pointer to n uncompressed points (bellman wire format)
-    int load_device(const uint8_t* d_raw, uint32_t n_, hipStream_t s, uint32_t n_eff = 0xffffffffu) {
+    int load_device(const uint8_t* d_raw, uint32_t n_, hipStream_t s, uint32_t n_eff = 0xffffffffu, int force_c = 0) {
         release();
         n = n_;
-        g = pick_geom(std::min(n_eff, n_));
+        g = force_c ? msm_geom(force_c) : pick_geom(std::min(n_eff, n_));
         if (n == 0) return MASP_HIP_OK;
         HIP_TRY(hipMalloc(&tab, sizeof(Affine<O>) * (size_t)g.W * n));
         int* d_status;
@@ -51,13 +51,13 @@ struct MsmBases {
         hipFree(d_status);
         return MASP_HIP_OK;
     }
-    int load_host(const uint8_t* raw, uint32_t n_, hipStream_t s, uint32_t n_eff = 0xffffffffu) {
+    int load_host(const uint8_t* raw, uint32_t n_, hipStream_t s, uint32_t n_eff = 0xffffffffu, int force_c = 0) {
         uint8_t* d_raw = nullptr;
         if (n_) {
             HIP_TRY(hipMalloc(&d_raw, (size_t)n_ * BYTES));
             HIP_TRY(hipMemcpyAsync(d_raw, raw, (size_t)n_ * BYTES, hipMemcpyHostToDevice, s));
         }
-        int rc = load_device(d_raw, n_, s, n_eff);
+        int rc = load_device(d_raw, n_, s, n_eff, force_c);
         if (d_raw) hipFree(d_raw);
         return rc;
     }

@@ -244,13 +244,13 @@ static uint32_t log2_ceil(uint32_t n) {
 
 static int n_slots_default() {
     const char* e = getenv("MASP_HIP_SLOTS");
-    int n = e ? atoi(e) : 2;
+    int n = e ? atoi(e) : 4;
     return std::max(1, std::min(n, 64));
 }
 // proofs per batched launch sequence
 static size_t batch_cap() {
     const char* e = getenv("MASP_HIP_BATCH");
-    int n = e ? atoi(e) : 16;
+    int n = e ? atoi(e) : 32;
     return (size_t)std::max(1, std::min(n, 256));
 }
 
@@ -577,9 +577,14 @@ int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* param
     const char* fe = getenv("MASP_HIP_WITNESS_NONTRIVIAL_PERCENT");
     const uint32_t pct = fe ? (uint32_t)atoi(fe) : 30;  // ~30 % of a MASP witness is neither 0 nor 1; measured +3..5 % throughput vs 100
     auto eff = [&](uint32_t n) { return (uint32_t)((uint64_t)n * pct / 100); };
-    if ((rc = C->h.load_host(L.h, (uint32_t)(C->m - 1), s)) || (rc = C->l.load_host(L.l, L.n_l, s, eff(L.n_l))) ||
-        (rc = C->a.load_host(L.a, L.n_a, s, eff(L.n_a))) || (rc = C->b1.load_host(L.b_g1, L.n_b1, s, eff(L.n_b1))) ||
-        (rc = C->b2.load_host(L.b_g2, L.n_b2, s, eff(L.n_b2))))
+    auto envc = [](const char* name) {  // experiment knobs: window width of one query family
+        const char* e = getenv(name);
+        return e ? atoi(e) : 0;
+    };
+    const int c_la = envc("MASP_HIP_MSM_C_LA"), c_b = envc("MASP_HIP_MSM_C_B");
+    if ((rc = C->h.load_host(L.h, (uint32_t)(C->m - 1), s)) || (rc = C->l.load_host(L.l, L.n_l, s, eff(L.n_l), c_la)) ||
+        (rc = C->a.load_host(L.a, L.n_a, s, eff(L.n_a), c_la)) || (rc = C->b1.load_host(L.b_g1, L.n_b1, s, eff(L.n_b1), c_b)) ||
+        (rc = C->b2.load_host(L.b_g2, L.n_b2, s, eff(L.n_b2), c_b)))
         return fail(ctx, rc);
     int st = C->h.import_status | C->l.import_status | C->a.import_status | C->b1.import_status | C->b2.import_status;
     if (st) return MASP_HIP_E_PARAMS_FORMAT;  // includes infinity inside a query vector, which bellman rejects

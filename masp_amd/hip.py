@@ -39,6 +39,9 @@ def load_library():
     if not os.path.exists(path):
         raise ImportError("libmasp_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "or `make -C masp_amd/csrc` (hipcc, --offload-arch=gfx950)")
+    # batches in flight on different HIP streams only overlap if the runtime gives them their own hardware queues
+    # (ROCm's default is 4); read once, when the HIP runtime initialises
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     L = C.CDLL(path)
     vp, sz, u32 = C.c_void_p, C.c_size_t, C.c_uint32
     L.masp_hip_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
