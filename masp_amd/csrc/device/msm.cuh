@@ -298,13 +298,25 @@ k_msm_bucket_gather(const Xyzz<O>* __restrict__ part, const uint32_t* __restrict
     }
     bkt[b] = acc;
 }
+// value of lane (lane + d) of the wave, limb by limb (a point is 36 / 96 dwords: noise next to one group addition)
 template <class O>
-__global__ void __launch_bounds__(64)
+__device__ __forceinline__ Xyzz<O> xyzz_shfl_down(const Xyzz<O>& p, int d) {
+    Xyzz<O> r;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&p);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+    for (uint32_t i = 0; i < sizeof(Xyzz<O>) / 4; ++i) dst[i] = (uint32_t)__shfl_down((int)src[i], d, 64);
+    return r;
+}
+// A heavy bucket (the unit scalars of a witness put ~33 000 entries into bucket 0) is finished by one workgroup of four
+// waves: strided serial sums, a shuffle tree inside each wave, four values through LDS.
+static constexpr uint32_t MSM_HEAVY_THREADS = 256;
+template <class O>
+__global__ void __launch_bounds__(256)
 k_msm_bucket_heavy(const Xyzz<O>* __restrict__ part, const uint32_t* __restrict__ start, uint32_t nb, uint32_t nchunks,
                    Xyzz<O>* __restrict__ bkt, const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ n_heavy) {
-    extern __shared__ uint4 wsum_lds[];
-    Xyzz<O>* sh = reinterpret_cast<Xyzz<O>*>(wsum_lds);
-    const uint32_t lane = threadIdx.x;
+    __shared__ Xyzz<O> sh[MSM_HEAVY_THREADS / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     part += (size_t)MSM_P * ((size_t)nchunks + nb);
     start += (size_t)MSM_P * (nb + 1);
     bkt += (size_t)MSM_P * nb;
@@ -316,14 +328,18 @@ k_msm_bucket_heavy(const Xyzz<O>* __restrict__ part, const uint32_t* __restrict_
         const uint32_t b = heavy[h];
         const uint32_t c0 = start[b] / K, c1 = (start[b + 1] - 1) / K;
         Xyzz<O> acc = xyzz_inf<O>();
-        for (uint32_t c = c0 + lane; c <= c1; c += 64) xyzz_add_nc(acc, part[c + b]);
-        for (uint32_t d = 32; d >= 1; d >>= 1) {
-            sh[lane] = acc;
-            __syncthreads();
-            if (lane < d) xyzz_add_nc(acc, sh[lane + d]);
-            __syncthreads();
+        for (uint32_t c = c0 + tid; c <= c1; c += MSM_HEAVY_THREADS) xyzz_add_nc(acc, part[c + b]);
+        for (int d = 32; d >= 1; d >>= 1) {
+            Xyzz<O> other = xyzz_shfl_down(acc, d);
+            if ((int)lane < d) xyzz_add_nc(acc, other);
         }
-        if (lane == 0) bkt[b] = acc;
+        if (lane == 0) sh[wid] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            for (uint32_t w = 1; w < MSM_HEAVY_THREADS / 64; ++w) xyzz_add_nc(acc, sh[w]);
+            bkt[b] = acc;
+        }
+        __syncthreads();
     }
 }
 
@@ -335,47 +351,47 @@ k_msm_bucket_heavy(const Xyzz<O>* __restrict__ part, const uint32_t* __restrict_
 //   phase 2  the per-lane sums are combined with a log-depth suffix scan and one tree through LDS.
 // ~4.5 additions per bucket in total (a pure log-depth scan costs 16) at a depth of 33 dependent additions:
 // with a batch of proofs in flight the chip is throughput-bound here, so work counts, not just depth.
-#ifndef MASP_WSUM_G_LOG
-#define MASP_WSUM_G_LOG 4
-#endif
-static constexpr uint32_t WSUM_G_LOG = MASP_WSUM_G_LOG, WSUM_L_LOG = 7;
-static constexpr uint32_t WSUM_G = 1u << WSUM_G_LOG, WSUM_L = 1u << WSUM_L_LOG;
-static constexpr uint32_t WSUM_CS_LOG = WSUM_G_LOG + WSUM_L_LOG;
-static constexpr uint32_t WSUM_CS = 1u << WSUM_CS_LOG;
-template <class O>
+// G = 2^G_LOG is chosen by the host: 16 for batches (least work per bucket: ~2.9 additions), 4 for a lone proof
+// (shortest dependent chain).
+static constexpr uint32_t WSUM_L_LOG = 7, WSUM_L = 1u << WSUM_L_LOG;
+static constexpr uint32_t WSUM_G_LOG_MIN = 2;
+template <class O, uint32_t G_LOG>
 __global__ void __launch_bounds__(128) k_msm_wsum_level(const Xyzz<O>* __restrict__ B, size_t b_stride, uint32_t m, uint32_t off,
                                                         Xyzz<O>* __restrict__ S, Xyzz<O>* __restrict__ T, size_t st_stride) {
-    extern __shared__ uint4 wsum_lds[];
-    Xyzz<O>* sh = reinterpret_cast<Xyzz<O>*>(wsum_lds);
-    const uint32_t tid = threadIdx.x;
+    constexpr uint32_t G = 1u << G_LOG, CS = G * WSUM_L;
+    __shared__ Xyzz<O> sh[2];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     B += MSM_P * b_stride;
     S += MSM_P * st_stride;
     T += MSM_P * st_stride;
     // phase 1: lane-local running sum, top element first:  run = sum B_l,  acc = sum (l + off) B_l  (l local)
-    const uint32_t base = blockIdx.x * WSUM_CS + tid * WSUM_G;
+    const uint32_t base = blockIdx.x * CS + tid * G;
     Xyzz<O> run = xyzz_inf<O>(), acc = xyzz_inf<O>();
-    for (uint32_t l = WSUM_G; l-- > 0;) {
+    for (uint32_t l = G; l-- > 0;) {
         if (base + l < m) xyzz_add_nc(run, B[base + l]);
         if (l > 0 || off) xyzz_add_nc(acc, run);
     }
-    // phase 2: lanes.  sum_lane (lane * G) * run_lane = G * sum_{i >= 1} x_i  with x = inclusive suffix scan of run
+    // phase 2: lanes.  sum_lane (lane * G) * run_lane = G * sum_{i >= 1} x_i  with x = inclusive suffix scan of run over
+    // the 128 lanes: a shuffle scan inside each wave, then wave 0 adds the total of wave 1
     Xyzz<O> x = run;
-    for (uint32_t d = 1; d < WSUM_L; d <<= 1) {
-        sh[tid] = x;
-        __syncthreads();
-        if (tid + d < WSUM_L) xyzz_add_nc(x, sh[tid + d]);
-        __syncthreads();
+    for (int d = 1; d < 64; d <<= 1) {
+        Xyzz<O> other = xyzz_shfl_down(x, d);
+        if ((int)lane + d < 64) xyzz_add_nc(x, other);
     }
+    if (wid == 1 && lane == 0) sh[0] = x;
+    __syncthreads();
+    if (wid == 0) xyzz_add_nc(x, sh[0]);
     Xyzz<O> y = tid > 0 ? x : xyzz_inf<O>();
-    for (uint32_t k = 0; k < WSUM_G_LOG; ++k) y = xyzz_dbl(y);
+    for (uint32_t k = 0; k < G_LOG; ++k) y = xyzz_dbl(y);
     xyzz_add_nc(y, acc);
-    for (uint32_t d = WSUM_L >> 1; d >= 1; d >>= 1) {
-        sh[tid] = y;
-        __syncthreads();
-        if (tid < d) xyzz_add_nc(y, sh[tid + d]);
-        __syncthreads();
+    for (int d = 32; d >= 1; d >>= 1) {
+        Xyzz<O> other = xyzz_shfl_down(y, d);
+        if ((int)lane < d) xyzz_add_nc(y, other);
     }
+    if (wid == 1 && lane == 0) sh[1] = y;
+    __syncthreads();
     if (tid == 0) {
+        xyzz_add_nc(y, sh[1]);
         S[blockIdx.x] = x;
         T[blockIdx.x] = y;
     }

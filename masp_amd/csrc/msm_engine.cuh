@@ -106,9 +106,8 @@ struct MsmSortBuf {
 // ---- workspace of the group arithmetic ---------------------------------------------------------------
 template <class O>
 struct MsmWorkspace {
-    static constexpr uint32_t CS_LOG = WSUM_CS_LOG;   // weighted-sum chunk = WSUM_G x WSUM_L buckets per workgroup
+    static constexpr uint32_t CS_LOG = WSUM_G_LOG_MIN + WSUM_L_LOG;   // smallest weighted-sum chunk (buckets per workgroup): sizes S / T
     static constexpr uint32_t NCHUNKS = 1u << 18;     // lanes of the accumulation kernel (1024 waves x 4 per SIMD)
-    static constexpr uint32_t HEAVY_BLOCKS = 256;
 
     MsmSortBuf sort;  // used unless the caller shares another workspace's sort
     size_t cap_nb = 0, cap_np = 0, cap_chunks = 0;
@@ -271,12 +270,10 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
     int rc = ws.reserve(n, g, np);
     if (rc) return rc;
     {
-        // the LDS tree kernels keep up to 256 XYZZ points per workgroup: 48 KiB (G1) / 96 KiB (G2) of the 160 KiB LDS
+        // the LDS tree kernel keeps 256 XYZZ points per workgroup: 48 KiB (G1) / 96 KiB (G2) of the 160 KiB LDS
         static bool lds_ok = [] {
             int bytes = 256 * (int)sizeof(Xyzz<O>);
-            bool ok = hipFuncSetAttribute((const void*)k_msm_wsum_level<O>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
-            ok = ok && hipFuncSetAttribute((const void*)k_xyzz_reduce_block<O>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
-            return ok;
+            return hipFuncSetAttribute((const void*)k_xyzz_reduce_block<O>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
         }();
         if (!lds_ok) {
             last_hip_error() = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
@@ -301,10 +298,13 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
     }
     hipLaunchKernelGGL((k_msm_bucket_gather<O>), dim3((nb + 63) / 64, np), dim3(64), 0, s, ws.part, sb.start, nb, nchunks, ws.bkt, ws.heavy,
                        ws.n_heavy);
-    hipLaunchKernelGGL((k_msm_bucket_heavy<O>), dim3(ws.HEAVY_BLOCKS, np), dim3(64), 64 * sizeof(Xyzz<O>), s, ws.part, sb.start, nb, nchunks,
-                       ws.bkt, ws.heavy, ws.n_heavy);
-    // weighted sum by levels of WSUM_CS-bucket workgroups
-    const uint32_t cs = 1u << ws.CS_LOG;
+    // (with a lone proof the chunks are short and most buckets of a narrow-window MSM count as heavy: give them the chip)
+    const uint32_t heavy_blocks = std::min<uint32_t>(std::max<uint32_t>(4096u / np, 16u), nb);
+    hipLaunchKernelGGL((k_msm_bucket_heavy<O>), dim3(heavy_blocks, np), dim3(MSM_HEAVY_THREADS), 0, s, ws.part, sb.start, nb, nchunks, ws.bkt,
+                       ws.heavy, ws.n_heavy);
+    // weighted sum by levels of (G x 128)-bucket workgroups; G = 16 buckets per lane in a batch, 4 for a lone proof
+    const uint32_t g_log = np >= 8 ? 4 : WSUM_G_LOG_MIN;
+    const uint32_t cs = 1u << (g_log + WSUM_L_LOG);
     const size_t st_stride = (nb + cs - 1) / cs;  // level-0 chunk count bounds every later level
     const Xyzz<O>* bk = ws.bkt;
     size_t bk_stride = nb;
@@ -312,8 +312,11 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
     int level = 0, flip = 0;
     do {
         uint32_t chunks = (m + cs - 1) / cs;
-        hipLaunchKernelGGL((k_msm_wsum_level<O>), dim3(chunks, np), dim3(WSUM_L), WSUM_L * sizeof(Xyzz<O>), s, bk, bk_stride, m, off,
-                           ws.S[flip], ws.T, st_stride);
+        if (g_log == 4)
+            hipLaunchKernelGGL((k_msm_wsum_level<O, 4>), dim3(chunks, np), dim3(WSUM_L), 0, s, bk, bk_stride, m, off, ws.S[flip], ws.T, st_stride);
+        else
+            hipLaunchKernelGGL((k_msm_wsum_level<O, WSUM_G_LOG_MIN>), dim3(chunks, np), dim3(WSUM_L), 0, s, bk, bk_stride, m, off, ws.S[flip],
+                               ws.T, st_stride);
         ws.reduce_to_one(s, np, ws.T, st_stride, chunks, ws.tsum + level, 32, st_stride);
         bk = ws.S[flip];
         bk_stride = st_stride;
@@ -322,7 +325,7 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
         off = 0;
         ++level;
     } while (m > 1);
-    hipLaunchKernelGGL((k_msm_combine<O>), dim3(1, np), dim3(64), 0, s, ws.tsum, level, (int)ws.CS_LOG, d_out, out_stride);
+    hipLaunchKernelGGL((k_msm_combine<O>), dim3(1, np), dim3(64), 0, s, ws.tsum, level, (int)(g_log + WSUM_L_LOG), d_out, out_stride);
     return MASP_HIP_OK;
 }
 
