@@ -224,6 +224,13 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    # RCCL writes its version banner (NCCL_DEBUG=VERSION) through C stdio, which is flushed at exit when stdout is a file:
+    # push it out now so that the JSON line really is the last thing on stdout
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     if out is not None:
         sys.stderr.flush()
         print(json.dumps(out), flush=True)      # the ONE JSON line, last thing on stdout

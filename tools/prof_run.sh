@@ -4,7 +4,7 @@ tag=$1; shift
 export TMPDIR=/tmp
 out=$PWD/gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
-(cd /tmp && env "$@" rocprofv3 --kernel-trace -d $out -o run -- python $OLDPWD/bench.py --steps ${PROF_STEPS:-16} --warmup 2 --no-cpu-baseline > $out/bench.log 2>&1)
+(cd /tmp && env "$@" rocprofv3 --kernel-trace -d $out -o run -- python $OLDPWD/bench.py ${PROF_ARGS:---no-cpu-baseline} > $out/bench.log 2>&1)
 db=$(find $out -name "*.db" | head -1)
 python tools/rocpd_stats.py $db > $out/all.txt
 python tools/rocpd_stats.py $db ${PROF_GY:-64} > $out/batch.txt
