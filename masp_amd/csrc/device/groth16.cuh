@@ -92,7 +92,9 @@ __device__ __forceinline__ Xyzz<O> xyzz_fixed_mul(const Xyzz<O>* __restrict__ ta
 //   g_b = s*delta2 + beta2 + B2
 //   g_c = (r s)*delta1 + s*alpha1 + r*beta1 + s*A + r*B1 + H + L
 // One workgroup of three waves so that the three differently-shaped jobs do not serialise inside a wave:
-//   wave 0, lanes 0..1 : the two variable-base multiplications  s*A, r*B1     (255 doublings each)
+//   wave 0             : the two variable-base multiplications  s*A, r*B1: lanes 0..31 build the tables d*A, d*B1
+//                        (d < 16) in LDS, then lanes 0..1 run 4-bit fixed windows (252 doublings + <= 64 additions each;
+//                        exact for any curve point: no endomorphism, the CRS is read unchecked like the reference's)
 //   wave 1, lane 0     : s*delta2 on G2 through its fixed-base table          (<= 32 additions)
 //   wave 2, lanes 0..3 : r*delta1, s*alpha1, r*beta1, (r s)*delta1 through fixed-base tables
 // then three lanes normalise and encode.  rs: 8 limbs r | 8 limbs s (canonical).
@@ -103,6 +105,7 @@ __global__ void __launch_bounds__(192) k_groth16_assemble(const VkDevice* __rest
                                                           uint8_t* __restrict__ proof) {
     __shared__ G1Xyzz part[6];
     __shared__ G2Xyzz part2;
+    __shared__ G1Xyzz wtab[2][16];
     const uint32_t tid = threadIdx.x;
     msm_g1 += (size_t)blockIdx.x * 4;  // one workgroup per proof of the batch
     msm_g2 += blockIdx.x;
@@ -114,8 +117,32 @@ __global__ void __launch_bounds__(192) k_groth16_assemble(const VkDevice* __rest
         s.v[i] = rs[8 + i];
     }
     constexpr size_t TAB = 32 * 255;
-    if (tid < 2) {
-        part[3 + tid] = xyzz_mul_scalar(tid == 0 ? msm_g1[2] : msm_g1[3], tid == 0 ? s.v : r.v);  // s*A, r*B1
+    if (tid < 64) {
+        if (tid < 32) {  // wtab[j][d] = d * P_j by double-and-add over the 4 bits of d
+            const uint32_t j = tid >> 4, d = tid & 15;
+            const G1Xyzz P = msm_g1[2 + j];
+            G1Xyzz t = xyzz_inf<FpOps>();
+            for (int b = 3; b >= 0; --b) {
+                t = xyzz_dbl(t);
+                if ((d >> b) & 1) xyzz_add_nc(t, P);
+            }
+            wtab[j][d] = t;
+        }
+        // same wave writes and reads the table: LDS is in order per wave, only the compiler must not reorder
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (tid < 2) {
+            const uint32_t* k = tid == 0 ? s.v : r.v;  // s*A, r*B1
+            G1Xyzz acc = xyzz_inf<FpOps>();
+            for (int w = 63; w >= 0; --w) {
+                if (w != 63)
+                    for (int q = 0; q < 4; ++q) acc = xyzz_dbl(acc);
+                const uint32_t d = (k[w >> 3] >> (4 * (w & 7))) & 15u;
+                if (d) xyzz_add_nc(acc, wtab[tid][d]);
+            }
+            part[3 + tid] = acc;
+        }
     } else if (tid == 64) {
         part2 = xyzz_fixed_mul<Fp2Ops>(fb2, s);
     } else if (tid >= 128 && tid < 132) {

@@ -272,11 +272,12 @@ k_msm_accumulate(const Affine<O>* __restrict__ tab, const uint32_t* __restrict__
 }
 
 // ---- (5) gather: bucket b = sum of its partials part[c + b], c over the chunks its entries touch ---------
-static constexpr uint32_t MSM_HEAVY_SPAN = 24;  // more partials than this -> finished by a whole wave
+// heavy_span: a bucket with at least this many partials is left to k_msm_bucket_heavy (24 in a batch, where work
+// counts; 12 for a lone proof, where the longest serial chain counts too — but a wave per bucket costs 64 lanes)
 template <class O>
 __global__ void __launch_bounds__(64)
 k_msm_bucket_gather(const Xyzz<O>* __restrict__ part, const uint32_t* __restrict__ start, uint32_t nb, uint32_t nchunks,
-                    Xyzz<O>* __restrict__ bkt, uint32_t* __restrict__ heavy, uint32_t* __restrict__ n_heavy) {
+                    Xyzz<O>* __restrict__ bkt, uint32_t* __restrict__ heavy, uint32_t* __restrict__ n_heavy, uint32_t heavy_span) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     part += (size_t)MSM_P * ((size_t)nchunks + nb);
@@ -289,7 +290,7 @@ k_msm_bucket_gather(const Xyzz<O>* __restrict__ part, const uint32_t* __restrict
     if (s1 > s0) {
         const uint32_t K = msm_chunk_len(start[nb], nchunks);
         const uint32_t c0 = s0 / K, c1 = (s1 - 1) / K;
-        if (c1 - c0 >= MSM_HEAVY_SPAN) {
+        if (c1 - c0 >= heavy_span) {
             heavy[atomicAdd(n_heavy, 1u)] = b;
             return;  // written by k_msm_bucket_heavy
         }
@@ -308,14 +309,15 @@ __device__ __forceinline__ Xyzz<O> xyzz_shfl_down(const Xyzz<O>& p, int d) {
     for (uint32_t i = 0; i < sizeof(Xyzz<O>) / 4; ++i) dst[i] = (uint32_t)__shfl_down((int)src[i], d, 64);
     return r;
 }
-// A heavy bucket (the unit scalars of a witness put ~33 000 entries into bucket 0) is finished by one workgroup of four
-// waves: strided serial sums, a shuffle tree inside each wave, four values through LDS.
-static constexpr uint32_t MSM_HEAVY_THREADS = 256;
-template <class O>
-__global__ void __launch_bounds__(256)
+// A heavy bucket (the unit scalars of a witness put ~33 000 entries into bucket 0) is finished by one workgroup of
+// THREADS / 64 waves: strided serial sums, a shuffle tree inside each wave, the waves' values through LDS.
+// (THREADS = 256 measured faster than a single wave in both regimes: one bucket of ~650 partials per proof in a batch,
+// thousands of buckets with ~80 partials each for a lone proof.)
+template <class O, uint32_t THREADS>
+__global__ void __launch_bounds__(THREADS)
 k_msm_bucket_heavy(const Xyzz<O>* __restrict__ part, const uint32_t* __restrict__ start, uint32_t nb, uint32_t nchunks,
                    Xyzz<O>* __restrict__ bkt, const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ n_heavy) {
-    __shared__ Xyzz<O> sh[MSM_HEAVY_THREADS / 64];
+    __shared__ Xyzz<O> sh[THREADS / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     part += (size_t)MSM_P * ((size_t)nchunks + nb);
     start += (size_t)MSM_P * (nb + 1);
@@ -328,18 +330,21 @@ k_msm_bucket_heavy(const Xyzz<O>* __restrict__ part, const uint32_t* __restrict_
         const uint32_t b = heavy[h];
         const uint32_t c0 = start[b] / K, c1 = (start[b + 1] - 1) / K;
         Xyzz<O> acc = xyzz_inf<O>();
-        for (uint32_t c = c0 + tid; c <= c1; c += MSM_HEAVY_THREADS) xyzz_add_nc(acc, part[c + b]);
+        for (uint32_t c = c0 + tid; c <= c1; c += THREADS) xyzz_add_nc(acc, part[c + b]);
+        const uint32_t span = c1 - c0 + 1;  // lanes >= span hold infinity: skip the tree levels that only move infinities
         for (int d = 32; d >= 1; d >>= 1) {
+            if ((uint32_t)d >= span) continue;
             Xyzz<O> other = xyzz_shfl_down(acc, d);
             if ((int)lane < d) xyzz_add_nc(acc, other);
         }
-        if (lane == 0) sh[wid] = acc;
-        __syncthreads();
-        if (tid == 0) {
-            for (uint32_t w = 1; w < MSM_HEAVY_THREADS / 64; ++w) xyzz_add_nc(acc, sh[w]);
-            bkt[b] = acc;
+        if constexpr (THREADS > 64) {
+            if (lane == 0) sh[wid] = acc;
+            __syncthreads();
+            if (tid == 0)
+                for (uint32_t w = 1; w < THREADS / 64; ++w) xyzz_add_nc(acc, sh[w]);
         }
-        __syncthreads();
+        if (tid == 0) bkt[b] = acc;
+        if constexpr (THREADS > 64) __syncthreads();
     }
 }
 

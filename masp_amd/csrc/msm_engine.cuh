@@ -296,14 +296,15 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
         hipEventRecord(rec.e1, s);
         prof->recs.push_back(rec);
     }
+    const bool lone = np < 8;  // latency regime: short chains matter more than total work
     hipLaunchKernelGGL((k_msm_bucket_gather<O>), dim3((nb + 63) / 64, np), dim3(64), 0, s, ws.part, sb.start, nb, nchunks, ws.bkt, ws.heavy,
-                       ws.n_heavy);
+                       ws.n_heavy, lone ? 12u : 24u);
     // (with a lone proof the chunks are short and most buckets of a narrow-window MSM count as heavy: give them the chip)
     const uint32_t heavy_blocks = std::min<uint32_t>(std::max<uint32_t>(4096u / np, 16u), nb);
-    hipLaunchKernelGGL((k_msm_bucket_heavy<O>), dim3(heavy_blocks, np), dim3(MSM_HEAVY_THREADS), 0, s, ws.part, sb.start, nb, nchunks, ws.bkt,
-                       ws.heavy, ws.n_heavy);
+    hipLaunchKernelGGL((k_msm_bucket_heavy<O, 256>), dim3(heavy_blocks, np), dim3(256), 0, s, ws.part, sb.start, nb, nchunks, ws.bkt, ws.heavy,
+                       ws.n_heavy);
     // weighted sum by levels of (G x 128)-bucket workgroups; G = 16 buckets per lane in a batch, 4 for a lone proof
-    const uint32_t g_log = np >= 8 ? 4 : WSUM_G_LOG_MIN;
+    const uint32_t g_log = lone ? WSUM_G_LOG_MIN : 4;
     const uint32_t cs = 1u << (g_log + WSUM_L_LOG);
     const size_t st_stride = (nb + cs - 1) / cs;  // level-0 chunk count bounds every later level
     const Xyzz<O>* bk = ws.bkt;

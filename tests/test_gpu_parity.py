@@ -111,6 +111,24 @@ def test_msm_g2_matches_oracle(ctx, n):
     assert ctx.msm_g2(bases, sc) == O.msm_g2(bases, sc)
 
 
+@pytest.mark.parametrize("group,n,bool_share", [("g1", 131071, 0.0), ("g1", 100497, 0.7), ("g2", 62170, 0.8)])
+def test_msm_full_size_by_discrete_log_checksum(ctx, group, n, bool_share):
+    """BASELINE sizes (Spend: H 131 071 uniform scalars on 16-bit windows; L / B2 with the witness' 0/1 share on 12-bit
+    windows) checked through a size-independent identity instead of a CPU MSM: with bases P_i = k_i G,
+    sum_i s_i P_i = (sum_i s_i k_i mod r) G."""
+    rng = random.Random(n)
+    ks = _rand_scalars(rng, n)
+    sc = _edge_scalars(n, rng) if bool_share == 0.0 else _rand_scalars(rng, n, bool_share)
+    k_int = [int.from_bytes(k.tobytes(), "little") for k in ks]
+    s_int = [int.from_bytes(x.tobytes(), "little") for x in sc]
+    total = sum(a * b for a, b in zip(k_int, s_int)) % R
+    expect_scalar = np.frombuffer(_le(total), np.uint8).reshape(1, 32)
+    if group == "g1":
+        assert ctx.msm_g1(O.g1_mul_gen_many(ks), sc) == O.g1_mul_gen_many(expect_scalar)[0].tobytes()
+    else:
+        assert ctx.msm_g2(O.g2_mul_gen_many(ks), sc) == O.g2_mul_gen_many(expect_scalar)[0].tobytes()
+
+
 @pytest.mark.parametrize("seed,n_inputs,n_free,n_constraints", [(31, 2, 4, 9), (32, 4, 20, 200), (33, 8, 300, 3000)])
 def test_proof_bytes_match_oracle_and_closed_form(ctx, seed, n_inputs, n_free, n_constraints):
     cs, inputs, aux, vals = toy_r1cs.make(seed, n_inputs, n_free, n_constraints, bool_share=0.7)
