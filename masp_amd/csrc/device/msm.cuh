@@ -43,7 +43,6 @@ static inline MsmGeom msm_geom(int c) {
     return g;
 }
 
-static constexpr uint32_t ENT_NONE = 0xffffffffu;
 
 // Every prove-time kernel below is launched with gridDim.y = number of proofs in the batch: proof p works on
 // `ptr + p * stride` of each per-proof array (the window tables are shared).  One launch per stage for the whole

@@ -310,6 +310,41 @@ def _invalid_diversifier(d, inst):
         return True
 
 
+def test_local_tx_prover_from_parameter_files(ctx, tmp_path):
+    """LocalTxProver::new = load_parameters (lib.rs:278-328): files with an MPC-transcript tail after the Parameters body,
+    sizes checked first, BLAKE2b-512 over body + transcript; the loaded prover yields the same proof bytes."""
+    import hashlib
+    from masp_amd import host as H
+    from masp_amd import params as PP
+    from masp_amd import prover as P
+    from test_circuits import spend_instance
+    lp0 = P.LocalTxProver.with_synthetic_parameters(seed=9)
+    blobs, paths, exp = {}, [], {}
+    for i, kind in enumerate(PP.KINDS):
+        blobs[kind] = lp0.parameters[kind].tobytes() + b"transcript of contribution %d" % i * 1000
+        path = tmp_path / PP.EXPECTED[kind].name
+        path.write_bytes(blobs[kind])
+        paths.append(str(path))
+        exp[kind] = PP.Expected(PP.EXPECTED[kind].name, hashlib.blake2b(blobs[kind], digest_size=64).hexdigest(), len(blobs[kind]))
+    inst, _, _ = spend_instance(500, value=3)
+    args = ((inst["ak"], inst["nsk"]), inst["diversifier"], inst["rcm"], inst["ar"], inst["asset_identifier"], inst["value"], inst["anchor"],
+            (inst["path_siblings"], inst["position"]), inst["rcv"])
+    want = lp0.spend_proof(lp0.new_sapling_proving_context(), *args, rs=(11, 12))
+    lp0.close()
+    lp = P.LocalTxProver.new(*paths, expected=exp)
+    assert lp.spend_proof(lp.new_sapling_proving_context(), *args, rs=(11, 12)) == want
+    lp.close()
+    with pytest.raises(PP.ParameterError):                 # the real MPC digests cannot match synthetic files
+        P.LocalTxProver.new(*paths)
+    bad = dict(exp, output=PP.Expected(exp["output"].name, "00" * 64, exp["output"].bytes))
+    with pytest.raises(PP.ParameterError, match="failed validation"):
+        P.LocalTxProver.new(*paths, expected=bad)
+    (tmp_path / exp["convert"].name).write_bytes(blobs["convert"][:-1])
+    with pytest.raises(PP.ParameterError, match="bytes"):
+        P.LocalTxProver.new(*paths, expected=exp)
+    assert P.LocalTxProver.from_bytes(blobs["spend"], blobs["output"], blobs["convert"], expected=None) is not None
+
+
 def test_concurrent_provers_share_one_context(ctx):
     """SURVEY.md §8(b) threading: one prover shared by several host threads — the native context is re-entrant, every
     caller gets its own proofs back, bit-identical to the oracle's."""
