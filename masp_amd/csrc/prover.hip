@@ -131,6 +131,12 @@ struct Slot {
     hipEvent_t done = nullptr;
     MsmWorkspace<FpOps> ws1;
     MsmWorkspace<Fp2Ops> ws2;
+    // lone-proof mode (a batch too small to fill the chip): the five MSMs run side by side on their own streams, each
+    // with its own workspace, next to the quotient pipeline on the main stream
+    static constexpr int N_AUX = 4;
+    hipStream_t aux[N_AUX] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_sort_b = nullptr, ev_join[N_AUX] = {nullptr, nullptr, nullptr, nullptr};
+    MsmWorkspace<FpOps> ws_l, ws_a, ws_b;
     DevBuf<Fr> w, abc, wm, ev[3], x0[3], x1[3], h, sa, sb;
     DevBuf<G1Xyzz> res1;
     DevBuf<G2Xyzz> res2;
@@ -147,6 +153,12 @@ struct Slot {
     ~Slot() {
         if (stream) hipStreamDestroy(stream);
         if (done) hipEventDestroy(done);
+        for (int i = 0; i < N_AUX; ++i) {
+            if (aux[i]) hipStreamDestroy(aux[i]);
+            if (ev_join[i]) hipEventDestroy(ev_join[i]);
+        }
+        if (ev_fork) hipEventDestroy(ev_fork);
+        if (ev_sort_b) hipEventDestroy(ev_sort_b);
         if (h_stage) hipHostFree(h_stage);
         if (h_proof) hipHostFree(h_proof);
         if (h_flags) hipHostFree(h_flags);
@@ -154,6 +166,12 @@ struct Slot {
     int init() {
         HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_sort_b, hipEventDisableTiming));
+        for (int i = 0; i < N_AUX; ++i) {
+            HIP_TRY(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
+        }
         HIP_TRY(hipHostMalloc(&h_flags, sizeof(int)));
         int rc;
         if ((rc = flags.reserve(1))) return rc;
@@ -368,22 +386,51 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
         }
         mont_in = true;
     }
-    if ((rc = enqueue_quotient(sl, *C.dom, in, C.nrows, C.nrows, mont_in, np))) return rc;
-    // query scalars selected by density
     if ((rc = sl.sa.reserve((size_t)C.na * np)) || (rc = sl.sb.reserve((size_t)C.nbq * np))) return rc;
-    if (C.na) hipLaunchKernelGGL(k_gather_scalars, dim3((C.na + 255) / 256, np), dim3(256), 0, s, d_w, w_stride, C.a_var.p, C.na, sl.sa.p);
-    if (C.nbq) hipLaunchKernelGGL(k_gather_scalars, dim3((C.nbq + 255) / 256, np), dim3(256), 0, s, d_w, w_stride, C.b_var.p, C.nbq, sl.sb.p);
     MsmProfile* prof = sl.profiling ? &sl.prof : nullptr;
     const size_t m8 = C.m * 8;
-    if ((rc = msm_enqueue(s, C.h, sl.ws1, (const uint32_t*)sl.h.p, m8, sl.res1.p + 0, 4, np, prof))) return rc;
-    if ((rc = msm_enqueue(s, C.l, sl.ws1, (const uint32_t*)(d_w + C.n_inputs), w_stride * 8, sl.res1.p + 1, 4, np, prof))) return rc;
-    if ((rc = msm_enqueue(s, C.a, sl.ws1, (const uint32_t*)sl.sa.p, (size_t)C.na * 8, sl.res1.p + 2, 4, np, prof))) return rc;
-    if ((rc = msm_enqueue(s, C.b1, sl.ws1, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res1.p + 3, 4, np, prof))) return rc;
-    // B2 runs over the same scalars as B1: when both base sets use the same window width the sort is shared
-    if (C.nbq && C.b2.n == C.b1.n && C.b2.g.c == C.b1.g.c) {
-        if ((rc = msm_reduce_enqueue(s, C.b2, sl.ws1.sort, sl.ws2, sl.res2.p, 1))) return rc;
-    } else if ((rc = msm_enqueue(s, C.b2, sl.ws2, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res2.p, 1, np))) {
-        return rc;
+    const bool share_b = C.nbq && C.b2.n == C.b1.n && C.b2.g.c == C.b1.g.c;  // B2 runs over the same scalars as B1
+    if (np < 8) {
+        // lone-proof mode: L, A, B1 and B2 only need the assignment, so they start at once on their own streams while
+        // the main stream runs SpMV -> quotient -> H; everything joins before the assembly
+        HIP_TRY(hipEventRecord(sl.ev_fork, s));
+        for (int i = 0; i < Slot::N_AUX; ++i) HIP_TRY(hipStreamWaitEvent(sl.aux[i], sl.ev_fork, 0));
+        if ((rc = msm_enqueue(sl.aux[0], C.l, sl.ws_l, (const uint32_t*)(d_w + C.n_inputs), w_stride * 8, sl.res1.p + 1, 4, np))) return rc;
+        if (C.na) hipLaunchKernelGGL(k_gather_scalars, dim3((C.na + 255) / 256, np), dim3(256), 0, sl.aux[1], d_w, w_stride, C.a_var.p, C.na, sl.sa.p);
+        if ((rc = msm_enqueue(sl.aux[1], C.a, sl.ws_a, (const uint32_t*)sl.sa.p, (size_t)C.na * 8, sl.res1.p + 2, 4, np))) return rc;
+        if (C.nbq) hipLaunchKernelGGL(k_gather_scalars, dim3((C.nbq + 255) / 256, np), dim3(256), 0, sl.aux[2], d_w, w_stride, C.b_var.p, C.nbq, sl.sb.p);
+        if (share_b) {
+            if ((rc = msm_sort_enqueue(sl.aux[2], C.b1.n, C.b1.g, sl.ws_b.sort, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, np))) return rc;
+            HIP_TRY(hipEventRecord(sl.ev_sort_b, sl.aux[2]));
+            HIP_TRY(hipStreamWaitEvent(sl.aux[3], sl.ev_sort_b, 0));
+            if ((rc = msm_reduce_enqueue(sl.aux[2], C.b1, sl.ws_b.sort, sl.ws_b, sl.res1.p + 3, 4))) return rc;
+            if ((rc = msm_reduce_enqueue(sl.aux[3], C.b2, sl.ws_b.sort, sl.ws2, sl.res2.p, 1))) return rc;
+        } else {
+            if ((rc = msm_enqueue(sl.aux[2], C.b1, sl.ws_b, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res1.p + 3, 4, np))) return rc;
+            HIP_TRY(hipEventRecord(sl.ev_sort_b, sl.aux[2]));  // orders the read of sb after its gather
+            HIP_TRY(hipStreamWaitEvent(sl.aux[3], sl.ev_sort_b, 0));
+            if ((rc = msm_enqueue(sl.aux[3], C.b2, sl.ws2, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res2.p, 1, np))) return rc;
+        }
+        if ((rc = enqueue_quotient(sl, *C.dom, in, C.nrows, C.nrows, mont_in, np))) return rc;
+        if ((rc = msm_enqueue(s, C.h, sl.ws1, (const uint32_t*)sl.h.p, m8, sl.res1.p + 0, 4, np, prof))) return rc;
+        for (int i = 0; i < Slot::N_AUX; ++i) {
+            HIP_TRY(hipEventRecord(sl.ev_join[i], sl.aux[i]));
+            HIP_TRY(hipStreamWaitEvent(s, sl.ev_join[i], 0));
+        }
+    } else {
+        if ((rc = enqueue_quotient(sl, *C.dom, in, C.nrows, C.nrows, mont_in, np))) return rc;
+        // query scalars selected by density
+        if (C.na) hipLaunchKernelGGL(k_gather_scalars, dim3((C.na + 255) / 256, np), dim3(256), 0, s, d_w, w_stride, C.a_var.p, C.na, sl.sa.p);
+        if (C.nbq) hipLaunchKernelGGL(k_gather_scalars, dim3((C.nbq + 255) / 256, np), dim3(256), 0, s, d_w, w_stride, C.b_var.p, C.nbq, sl.sb.p);
+        if ((rc = msm_enqueue(s, C.h, sl.ws1, (const uint32_t*)sl.h.p, m8, sl.res1.p + 0, 4, np, prof))) return rc;
+        if ((rc = msm_enqueue(s, C.l, sl.ws1, (const uint32_t*)(d_w + C.n_inputs), w_stride * 8, sl.res1.p + 1, 4, np, prof))) return rc;
+        if ((rc = msm_enqueue(s, C.a, sl.ws1, (const uint32_t*)sl.sa.p, (size_t)C.na * 8, sl.res1.p + 2, 4, np, prof))) return rc;
+        if ((rc = msm_enqueue(s, C.b1, sl.ws1, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res1.p + 3, 4, np, prof))) return rc;
+        if (share_b) {
+            if ((rc = msm_reduce_enqueue(s, C.b2, sl.ws1.sort, sl.ws2, sl.res2.p, 1))) return rc;
+        } else if ((rc = msm_enqueue(s, C.b2, sl.ws2, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res2.p, 1, np))) {
+            return rc;
+        }
     }
     hipLaunchKernelGGL(k_groth16_assemble, dim3(np), dim3(192), 0, s, C.vk.p, C.fb1.p, C.fb2.p, sl.res1.p, sl.res2.p, d_rs, (size_t)16, d_proof);
     return MASP_HIP_OK;
@@ -710,6 +757,7 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
             }
         }
         if (!ok) {
+            for (int i = 0; i < Slot::N_AUX; ++i) hipStreamSynchronize(sl.aux[i]);
             hipStreamSynchronize(sl.stream);
             slot_release(ctx, si);
             break;
