@@ -297,12 +297,24 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
         prof->recs.push_back(rec);
     }
     const bool lone = np < 8;  // latency regime: short chains matter more than total work
+    static const uint32_t lone_span = [] {
+        const char* e = getenv("MASP_HIP_LONE_SPAN");
+        return e ? (uint32_t)atoi(e) : 12u;
+    }();
     hipLaunchKernelGGL((k_msm_bucket_gather<O>), dim3((nb + 63) / 64, np), dim3(64), 0, s, ws.part, sb.start, nb, nchunks, ws.bkt, ws.heavy,
-                       ws.n_heavy, lone ? 12u : 24u);
+                       ws.n_heavy, lone ? lone_span : 24u);
     // (with a lone proof the chunks are short and most buckets of a narrow-window MSM count as heavy: give them the chip)
     const uint32_t heavy_blocks = std::min<uint32_t>(std::max<uint32_t>(4096u / np, 16u), nb);
-    hipLaunchKernelGGL((k_msm_bucket_heavy<O, 256>), dim3(heavy_blocks, np), dim3(256), 0, s, ws.part, sb.start, nb, nchunks, ws.bkt, ws.heavy,
-                       ws.n_heavy);
+    static const int lone_threads = [] {
+        const char* e = getenv("MASP_HIP_LONE_HEAVY_THREADS");
+        return e ? atoi(e) : 256;
+    }();
+    if (lone && lone_threads == 64)
+        hipLaunchKernelGGL((k_msm_bucket_heavy<O, 64>), dim3(heavy_blocks, np), dim3(64), 0, s, ws.part, sb.start, nb, nchunks, ws.bkt, ws.heavy,
+                           ws.n_heavy);
+    else
+        hipLaunchKernelGGL((k_msm_bucket_heavy<O, 256>), dim3(heavy_blocks, np), dim3(256), 0, s, ws.part, sb.start, nb, nchunks, ws.bkt,
+                           ws.heavy, ws.n_heavy);
     // weighted sum by levels of (G x 128)-bucket workgroups; G = 16 buckets per lane in a batch, 4 for a lone proof
     const uint32_t g_log = lone ? WSUM_G_LOG_MIN : 4;
     const uint32_t cs = 1u << (g_log + WSUM_L_LOG);
