@@ -123,6 +123,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch
         import torch.distributed as dist
+        local_rank %= max(1, torch.cuda.device_count())      # a launcher may expose one device per rank (HIP_VISIBLE_DEVICES)
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     import masp_amd
