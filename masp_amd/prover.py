@@ -50,10 +50,26 @@ class SaplingProvingContext:
         self.bsk = (self.bsk - _int(rcv)) % RJ        # "Outputs subtract from the total."
         self.cv_sum = H.jubjub_add(self.cv_sum, cv, subtract=True)
 
-    def binding_sig(self, assets_and_values, sighash):
-        # RedJubjub over bsk / cv_sum (sapling/prover.rs:279-326): not part of the Groth16 hot path (SURVEY.md §8b
-        # "Not touched by the build"); the accumulated state is exposed for the caller's signer.
-        raise NotImplementedError("binding_sig is outside the Groth16 hot path; use ctx.bsk / ctx.cv_sum with the reference's RedJubjub")
+    def binding_sig(self, assets_and_values, sighash, rng=None):
+        """= SaplingProvingContext::binding_sig (sapling/prover.rs:279-326).  assets_and_values: iterable of
+        (asset identifier[32], value balance as a signed 128-bit int) — the components of the reference's `I128Sum`.
+        -> 64-byte RedJubjub signature over bvk || sighash, or ProvingError (`Err(())`) if the value balances do not
+        match the accumulated commitments or a balance is i128::MIN."""
+        from . import redjubjub as RJS
+        g_rcv = H.point_bytes(*H.generator_uv(3))            # value_commitment_randomness_generator()
+        bvk = RJS.public_key(self.bsk, g_rcv)
+        final_bvk = self.cv_sum
+        for asset, value in assets_and_values:
+            if not -(1 << 127) < value < (1 << 127):         # checked_abs fails for i128::MIN (sapling/mod.rs:14-20)
+                raise ProvingError("bad value balance")
+            # value_commitment_generator = the asset generator with its cofactor cleared (asset_type.rs), times |value|
+            vb = H.jubjub_mul(H.jubjub_mul(H.asset_generator(asset), 8), abs(value))
+            final_bvk = H.jubjub_add(final_bvk, vb, subtract=value >= 0)
+        if bvk != final_bvk:
+            raise ProvingError("value balance does not match the accumulated value commitments")
+        msg = bvk + bytes(sighash)
+        assert len(msg) == 64
+        return RJS.sign(self.bsk, msg, g_rcv, **({"rng": rng} if rng else {}))
 
 
 class LocalTxProver:
