@@ -122,6 +122,13 @@ int masp_hip_bench_msm(masp_hip_ctx* ctx, int handle, size_t job, int which, int
  * (n x (96 + 32) per G1 MSM of n points) of all launches since enable/reset. */
 int masp_hip_profile_enable(masp_hip_ctx* ctx, int on);
 int masp_hip_profile_read(masp_hip_ctx* ctx, double* total_ms, uint64_t* launches, uint64_t* alg_bytes);
+/* Page-locked host memory for assignments.  masp_hip_prove_batch recognises `aux` pointers that lie in page-locked
+ * memory (from here or from the caller's own hipHostMalloc / hipHostRegister) and copies them to the device directly;
+ * anything else goes through the library's own pinned staging buffer first (one extra host copy of ~3 MB per Spend).
+ * The reference keeps the assignment in ordinary Vec<Scalar>s inside bellperson's ProvingAssignment; a binding that
+ * synthesizes into a buffer obtained here saves that copy.  NULL on failure. */
+void* masp_hip_host_alloc(masp_hip_ctx* ctx, size_t bytes);
+void masp_hip_host_free(masp_hip_ctx* ctx, void* ptr);
 /* hipDeviceSynchronize on the context's device */
 int masp_hip_sync(masp_hip_ctx* ctx);
 

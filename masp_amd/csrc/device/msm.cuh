@@ -228,12 +228,15 @@ k_msm_scatter(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32
 // start[0..nb] from the scan (start[nb] = number of entries).  Lane `ch` owns entries [ch*K, ch*K + K) with
 // K = ceil(total / nchunks); the partial sum of its run inside bucket b goes to part[ch + b] — a slot no other
 // (chunk, bucket) pair can hit, because chunk and bucket indices both only grow along the list.
+#ifndef MASP_ACC_MIN_WAVES
+#define MASP_ACC_MIN_WAVES 1  // (2 was measured: the G2 kernel then spills 1 590 registers and the batch runs 11 % slower)
+#endif
 __device__ __forceinline__ uint32_t msm_chunk_len(uint32_t total, uint32_t nchunks) {
     uint32_t k = (total + nchunks - 1) / nchunks;
     return k < 4 ? 4 : k;  // at least 4 additions per lane: fewer partials to gather
 }
 template <class O>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, MASP_ACC_MIN_WAVES)
 k_msm_accumulate(const Affine<O>* __restrict__ tab, const uint32_t* __restrict__ sorted, size_t ent_stride,
                  const uint32_t* __restrict__ start, uint32_t nb, uint32_t nchunks, Xyzz<O>* __restrict__ part) {
     const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;

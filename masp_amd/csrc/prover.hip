@@ -717,10 +717,19 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
         }
         if (ok) {
             uint8_t* hs = sl.h_stage;
+            // aux vectors that already sit in page-locked memory go to the device straight from there
+            std::vector<char> direct(np, 0);
+            bool any_staged = false;
+            for (size_t p = 0; p < np; ++p) {
+                hipPointerAttribute_t attr;
+                direct[p] = hipPointerGetAttributes(&attr, jobs[G.idx[p]].aux) == hipSuccess && attr.type == hipMemoryTypeHost;
+                any_staged = any_staged || !direct[p];
+            }
+            (void)hipGetLastError();  // an unregistered pointer makes hipPointerGetAttributes report an error: expected
             for (size_t p = 0; p < np; ++p) {
                 const masp_hip_job& J = jobs[G.idx[p]];
                 memcpy(hs + 32 * nv * p, J.inputs, 32 * (size_t)C.n_inputs);
-                memcpy(hs + 32 * nv * p + 32 * (size_t)C.n_inputs, J.aux, 32 * (size_t)C.n_aux);
+                if (!direct[p]) memcpy(hs + 32 * nv * p + 32 * (size_t)C.n_inputs, J.aux, 32 * (size_t)C.n_aux);
                 if (has_abc) {
                     const uint8_t* src[3] = {J.a, J.b, J.c};
                     for (int i = 0; i < 3; ++i) memcpy(hs + w_bytes + 32 * (size_t)C.nrows * (np * i + p), src[i], 32 * (size_t)C.nrows);
@@ -729,8 +738,17 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
                 memcpy(hs + w_bytes + abc_bytes + 64 * p + 32, J.s, 32);
             }
             hipStream_t s = sl.stream;
-            ok = hipMemcpyAsync(sl.w.p, hs, w_bytes, hipMemcpyHostToDevice, s) == hipSuccess &&
-                 (!has_abc || hipMemcpyAsync(sl.abc.p, hs + w_bytes, abc_bytes, hipMemcpyHostToDevice, s) == hipSuccess) &&
+            if (any_staged) {
+                ok = hipMemcpyAsync(sl.w.p, hs, w_bytes, hipMemcpyHostToDevice, s) == hipSuccess;
+            } else {
+                for (size_t p = 0; p < np && ok; ++p)  // only the public inputs of each proof come from staging
+                    ok = hipMemcpyAsync(sl.w.p + nv * p, hs + 32 * nv * p, 32 * (size_t)C.n_inputs, hipMemcpyHostToDevice, s) == hipSuccess;
+            }
+            for (size_t p = 0; p < np && ok; ++p)
+                if (direct[p])
+                    ok = hipMemcpyAsync(sl.w.p + nv * p + C.n_inputs, jobs[G.idx[p]].aux, 32 * (size_t)C.n_aux, hipMemcpyHostToDevice, s) ==
+                         hipSuccess;
+            ok = ok && (!has_abc || hipMemcpyAsync(sl.abc.p, hs + w_bytes, abc_bytes, hipMemcpyHostToDevice, s) == hipSuccess) &&
                  hipMemcpyAsync(sl.rs.p, hs + w_bytes + abc_bytes, rs_bytes, hipMemcpyHostToDevice, s) == hipSuccess;
             if (!ok) {
                 last_hip_error() = "H2D copy failed";
@@ -1195,6 +1213,22 @@ int masp_hip_profile_read(masp_hip_ctx* ctx, double* total_ms, uint64_t* launche
     if (launches) *launches = l;
     if (alg_bytes) *alg_bytes = b;
     return MASP_HIP_OK;
+}
+
+void* masp_hip_host_alloc(masp_hip_ctx* ctx, size_t bytes) {
+    if (!ctx || !bytes) return nullptr;
+    hipSetDevice(ctx->device);
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+void masp_hip_host_free(masp_hip_ctx* ctx, void* ptr) {
+    if (!ctx || !ptr) return;
+    hipSetDevice(ctx->device);
+    hipHostFree(ptr);
 }
 
 int masp_hip_sync(masp_hip_ctx* ctx) {

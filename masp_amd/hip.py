@@ -67,6 +67,10 @@ def load_library():
     L.masp_hip_profile_enable.argtypes = [vp, C.c_int]
     L.masp_hip_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.masp_hip_sync.argtypes = [vp]
+    L.masp_hip_host_alloc.argtypes = [vp, sz]
+    L.masp_hip_host_alloc.restype = vp
+    L.masp_hip_host_free.argtypes = [vp, vp]
+    L.masp_hip_host_free.restype = None
     _lib = L
     return L
 
@@ -105,9 +109,13 @@ class Context:
             raise MaspHipError(rc)
         self._h = h
         self._keep = []
+        self._pinned = {}
 
     def close(self):
         if getattr(self, "_h", None):
+            for p in list(getattr(self, "_pinned", {}).values()):
+                self._L.masp_hip_host_free(self._h, p)
+            self._pinned = {}
             self._L.masp_hip_ctx_destroy(self._h)
             self._h = None
 
@@ -120,6 +128,22 @@ class Context:
     def _check(self, rc):
         if rc:
             raise MaspHipError(rc, self._L.masp_hip_last_error(self._h).decode(errors="replace"))
+
+    # ---- page-locked host buffers (assignments written here reach the device without a staging copy) ----
+    def host_alloc(self, rows, cols=32):
+        """-> np.uint8 array [rows, cols] over memory from masp_hip_host_alloc; release with host_free(array)."""
+        p = self._L.masp_hip_host_alloc(self._h, rows * cols)
+        if not p:
+            raise MemoryError("masp_hip_host_alloc(%d bytes) failed" % (rows * cols))
+        buf = (C.c_uint8 * (rows * cols)).from_address(p)
+        a = np.frombuffer(buf, dtype=np.uint8).reshape(rows, cols)
+        self._pinned[a.ctypes.data] = p
+        return a
+
+    def host_free(self, a):
+        p = self._pinned.pop(a.ctypes.data, None)
+        if p and getattr(self, "_h", None):
+            self._L.masp_hip_host_free(self._h, p)
 
     # ---- circuits / proofs ----
     def load_circuit(self, slot, params, cs):

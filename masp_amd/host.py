@@ -127,12 +127,21 @@ def _check(rc):
         raise HostError(rc)
 
 
-def spend_assignment(ak, nsk, diversifier, rcm, ar, asset_identifier, value, anchor, path_siblings, position, rcv, check=False):
+def _aux_buffer(cs, aux_out):
+    """The aux assignment is written into `aux_out` when given (e.g. page-locked memory from hip.Context.host_alloc)."""
+    if aux_out is None:
+        return np.zeros((cs.n_aux, 32), np.uint8)
+    assert aux_out.dtype == np.uint8 and aux_out.shape == (cs.n_aux, 32) and aux_out.flags["C_CONTIGUOUS"]
+    return aux_out
+
+
+def spend_assignment(ak, nsk, diversifier, rcm, ar, asset_identifier, value, anchor, path_siblings, position, rcv, check=False,
+                     aux_out=None):
     """-> (inputs u8[8,32], aux u8[100497,32], cv, rk, nf)   — SaplingProvingContext::spend_proof up to the prover call."""
     L = load_library()
     cs, _ = circuit("spend")
     inputs = np.zeros((cs.n_inputs, 32), np.uint8)
-    aux = np.zeros((cs.n_aux, 32), np.uint8)
+    aux = _aux_buffer(cs, aux_out)
     cv, rk, nf = (C.create_string_buffer(32) for _ in range(3))
     p = _path(path_siblings)
     _check(L.masp_host_spend_assignment(_b(ak), _b(nsk), _b(diversifier, 11), _b(rcm), _b(ar), _b(asset_identifier), value, _b(anchor),
@@ -140,22 +149,22 @@ def spend_assignment(ak, nsk, diversifier, rcm, ar, asset_identifier, value, anc
     return inputs, aux, cv.raw, rk.raw, nf.raw
 
 
-def output_assignment(esk, diversifier, pk_d, rcm, asset_identifier, value, rcv, check=False):
+def output_assignment(esk, diversifier, pk_d, rcm, asset_identifier, value, rcv, check=False, aux_out=None):
     L = load_library()
     cs, _ = circuit("output")
     inputs = np.zeros((cs.n_inputs, 32), np.uint8)
-    aux = np.zeros((cs.n_aux, 32), np.uint8)
+    aux = _aux_buffer(cs, aux_out)
     cv = C.create_string_buffer(32)
     _check(L.masp_host_output_assignment(_b(esk), _b(diversifier, 11), _b(pk_d), _b(rcm), _b(asset_identifier), value, _b(rcv),
                                          1 if check else 0, inputs.ctypes.data, aux.ctypes.data, cv))
     return inputs, aux, cv.raw
 
 
-def convert_assignment(generator, value, anchor, path_siblings, position, rcv, check=False):
+def convert_assignment(generator, value, anchor, path_siblings, position, rcv, check=False, aux_out=None):
     L = load_library()
     cs, _ = circuit("convert")
     inputs = np.zeros((cs.n_inputs, 32), np.uint8)
-    aux = np.zeros((cs.n_aux, 32), np.uint8)
+    aux = _aux_buffer(cs, aux_out)
     cv = C.create_string_buffer(32)
     p = _path(path_siblings)
     _check(L.masp_host_convert_assignment(_b(generator), value, _b(anchor), p.ctypes.data, position, _b(rcv), 1 if check else 0,

@@ -15,6 +15,7 @@ MerklePath as (siblings leaf-level-first, position).
 """
 import os
 import secrets
+import threading
 
 from . import host as H
 from . import params as P
@@ -82,6 +83,8 @@ class LocalTxProver:
         MPC files (benches, tests)."""
         spend_params, output_params, convert_params = P.parse_parameters(spend_params, output_params, convert_params, expected=expected)
         self._ctx = Context(device)
+        self._pool = {SPEND: [], OUTPUT: [], CONVERT: []}           # recycled page-locked aux buffers per circuit
+        self._pool_lock = threading.Lock()
         self._rng = rng or (lambda: secrets.randbelow(FR))          # r, s <- OsRng (sapling/prover.rs:66,174,225)
         self._self_verify = self_verify
         # spend_vk / convert_vk: PreparedVerifyingKey (prover.rs:27-33, lib.rs:391-393); Output proofs are not self-checked
@@ -132,31 +135,54 @@ class LocalTxProver:
     def new_sapling_proving_context(self):
         return SaplingProvingContext()
 
+    # ---- page-locked aux buffers: the synthesizer writes where the DMA engine reads (no staging copy of ~3 MB / Spend) ----
+    def _aux_take(self, slot):
+        with self._pool_lock:
+            if self._pool[slot]:
+                return self._pool[slot].pop()
+        n_aux = H.circuit(("spend", "output", "convert")[slot])[0].n_aux
+        return self._ctx.host_alloc(n_aux, 32)
+
+    def _aux_give(self, jobs):
+        """Return the aux buffers of finished jobs to the pool (the job dicts must not be proved again afterwards)."""
+        with self._pool_lock:
+            for j in jobs:
+                buf = j.pop("_pinned", None)
+                if buf is not None:
+                    self._pool[j["slot"]].append(buf)
+
     # ---- witness preparation (host) and proving (GPU) are split so that batches can be formed ----
     def prepare_spend(self, proof_generation_key, diversifier, rcm, ar, asset_type, value, anchor, merkle_path, rcv):
         ak, nsk = proof_generation_key
         siblings, position = merkle_path
+        buf = self._aux_take(SPEND)
         try:
-            inputs, aux, cv, rk, nf = H.spend_assignment(ak, nsk, diversifier, rcm, ar, asset_type, value, anchor, siblings, position, rcv)
+            inputs, aux, cv, rk, nf = H.spend_assignment(ak, nsk, diversifier, rcm, ar, asset_type, value, anchor, siblings, position, rcv,
+                                                         aux_out=buf)
         except H.HostError as e:
+            self._aux_give([dict(slot=SPEND, _pinned=buf)])
             raise ProvingError(str(e)) from None           # invalid diversifier -> Err(()) (sapling/prover.rs:84)
-        return dict(slot=SPEND, inputs=inputs, aux=aux, cv=cv, rk=rk, nf=nf, rcv=rcv)
+        return dict(slot=SPEND, inputs=inputs, aux=aux, cv=cv, rk=rk, nf=nf, rcv=rcv, _pinned=buf)
 
     def prepare_output(self, esk, payment_address, rcm, asset_type, value, rcv):
         diversifier, pk_d = payment_address
+        buf = self._aux_take(OUTPUT)
         try:
-            inputs, aux, cv = H.output_assignment(esk, diversifier, pk_d, rcm, asset_type, value, rcv)
+            inputs, aux, cv = H.output_assignment(esk, diversifier, pk_d, rcm, asset_type, value, rcv, aux_out=buf)
         except H.HostError as e:
+            self._aux_give([dict(slot=OUTPUT, _pinned=buf)])
             raise ProvingError(str(e)) from None
-        return dict(slot=OUTPUT, inputs=inputs, aux=aux, cv=cv, rcv=rcv)
+        return dict(slot=OUTPUT, inputs=inputs, aux=aux, cv=cv, rcv=rcv, _pinned=buf)
 
     def prepare_convert(self, allowed_conversion, value, anchor, merkle_path, rcv):
         siblings, position = merkle_path
+        buf = self._aux_take(CONVERT)
         try:
-            inputs, aux, cv = H.convert_assignment(allowed_conversion, value, anchor, siblings, position, rcv)
+            inputs, aux, cv = H.convert_assignment(allowed_conversion, value, anchor, siblings, position, rcv, aux_out=buf)
         except H.HostError as e:
+            self._aux_give([dict(slot=CONVERT, _pinned=buf)])
             raise ProvingError(str(e)) from None
-        return dict(slot=CONVERT, inputs=inputs, aux=aux, cv=cv, rcv=rcv)
+        return dict(slot=CONVERT, inputs=inputs, aux=aux, cv=cv, rcv=rcv, _pinned=buf)
 
     def prove_batch(self, ctx, descriptions, threads=None, rs=None, chunk=None, progress=None):
         """Batched form of the serial per-description loops of `SaplingBuilder::build`
@@ -187,8 +213,15 @@ class LocalTxProver:
                 return list(H.point_uv(job["rk"])) + list(H.point_uv(job["cv"])) + [_int(kw["anchor"])] + H.multipack(job["nf"])
             return list(H.point_uv(job["cv"])) + [_int(kw["anchor"])]          # convert: sapling/prover.rs:256-263
 
+        # synthesis may run ahead of the GPU only so far: every job in flight owns a page-locked aux buffer (3.2 MB / Spend)
+        ahead = threading.Semaphore((in_flight + 2) * chunk + threads)
+
+        def synthesize(kind, kw):
+            ahead.acquire()
+            return prep[kind](**kw)
+
         with ThreadPoolExecutor(max_workers=threads) as synth, ThreadPoolExecutor(max_workers=in_flight) as gpu:
-            futures = [synth.submit(prep[kind], **kw) for kind, kw in descriptions]
+            futures = [synth.submit(synthesize, kind, kw) for kind, kw in descriptions]
 
             def run_chunk(lo):
                 hi = min(n, lo + chunk)
@@ -203,6 +236,9 @@ class LocalTxProver:
                         if not vk.verify_batch([proofs[i] for i in sel], pis):
                             bad = [lo + i for i, pi in zip(sel, pis) if not vk.verify(proofs[i], pi)]
                             raise ProvingError("proof(s) %s failed self-verification" % bad)
+                self._aux_give(jobs)                       # proved and checked: the aux buffers go back to the pool
+                for _ in range(hi - lo):
+                    ahead.release()
                 done[0] += hi - lo
                 if progress is not None:
                     progress(done[0], n)
@@ -231,6 +267,7 @@ class LocalTxProver:
         """-> (zkproof[192], cv, rk).  `rseed` is the note commitment randomness rcm = note.rcm() (Rseed::BeforeZip212 form)."""
         job = self.prepare_spend(proof_generation_key, diversifier, rseed, ar, asset_type, value, anchor, merkle_path, rcv)
         zkproof = self.prove_prepared([job], None if rs is None else [rs])[0]
+        self._aux_give([job])
         if self._self_verify:
             # public input built from the natively computed rk, cv, anchor and nullifier (sapling/prover.rs:121-145)
             public_input = list(H.point_uv(job["rk"])) + list(H.point_uv(job["cv"])) + [_int(anchor)] + H.multipack(job["nf"])
@@ -243,6 +280,7 @@ class LocalTxProver:
         """-> (zkproof[192], cv); infallible for valid inputs like the reference (it panics if proving fails)."""
         job = self.prepare_output(esk, payment_address, rcm, asset_type, value, rcv)
         zkproof = self.prove_prepared([job], None if rs is None else [rs])[0]
+        self._aux_give([job])
         ctx._output(rcv, job["cv"])
         return zkproof, job["cv"]
 
@@ -250,6 +288,7 @@ class LocalTxProver:
         """-> (zkproof[192], cv)"""
         job = self.prepare_convert(allowed_conversion, value, anchor, merkle_path, rcv)
         zkproof = self.prove_prepared([job], None if rs is None else [rs])[0]
+        self._aux_give([job])
         if self._self_verify:
             public_input = list(H.point_uv(job["cv"])) + [_int(anchor)]            # sapling/prover.rs:256-263
             if not self.convert_vk.verify(zkproof, public_input):

@@ -51,8 +51,9 @@ def main():
         descs = list(ex.map(spend_description, range(n)))
         # warm-up (workspace allocation, first-launch costs)
         prover.prove_batch(prover.new_sapling_proving_context(), descs[:min(n, 64)], threads=threads)
+        stage_n = min(n, 256)                     # the staged measurement holds every aux buffer at once: bound it
         t0 = time.time()
-        jobs = list(ex.map(lambda d: prover.prepare_spend(**d[1]), descs))
+        jobs = list(ex.map(lambda d: prover.prepare_spend(**d[1]), descs[:stage_n]))
         t1 = time.time()
         proofs = prover.prove_prepared(jobs)
         t2 = time.time()
@@ -63,16 +64,17 @@ def main():
             return prover.spend_vk.verify(zk, pi)
         ok = all(ex.map(check, zip(descs, jobs, proofs)))
         t3 = time.time()
+        prover._aux_give(jobs)
     assert ok
     ctx = prover.new_sapling_proving_context()
     t4 = time.time()
     out = prover.prove_batch(ctx, descs, threads=threads)
     t5 = time.time()
     assert len(out) == n
-    print("N = %d Spend descriptions, %d host threads" % (n, threads))
-    print("  synthesis  %8.1f ms  (%.2f ms/proof wall, %.1f proofs/s)" % ((t1 - t0) * 1e3, (t1 - t0) * 1e3 / n, n / (t1 - t0)))
-    print("  GPU batch  %8.1f ms  (%.2f ms/proof, %.1f proofs/s; includes H2D of witnesses, D2H of proofs)" % ((t2 - t1) * 1e3, (t2 - t1) * 1e3 / n, n / (t2 - t1)))
-    print("  verify     %8.1f ms  (%.2f ms/proof wall)" % ((t3 - t2) * 1e3, (t3 - t2) * 1e3 / n))
+    print("N = %d Spend descriptions, %d host threads; stage by stage on the first %d:" % (n, threads, stage_n))
+    print("  synthesis  %8.1f ms  (%.2f ms/proof wall, %.1f proofs/s)" % ((t1 - t0) * 1e3, (t1 - t0) * 1e3 / stage_n, stage_n / (t1 - t0)))
+    print("  GPU batch  %8.1f ms  (%.2f ms/proof, %.1f proofs/s; includes H2D of witnesses, D2H of proofs)" % ((t2 - t1) * 1e3, (t2 - t1) * 1e3 / stage_n, stage_n / (t2 - t1)))
+    print("  verify     %8.1f ms  (%.2f ms/proof wall)" % ((t3 - t2) * 1e3, (t3 - t2) * 1e3 / stage_n))
     print("  prove_batch end to end %8.1f ms = %.1f proofs/s" % ((t5 - t4) * 1e3, n / (t5 - t4)))
 
 
