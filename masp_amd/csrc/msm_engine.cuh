@@ -315,7 +315,9 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
     else
         hipLaunchKernelGGL((k_msm_bucket_heavy<O, 256>), dim3(heavy_blocks, np), dim3(256), 0, s, ws.part, sb.start, nb, nchunks, ws.bkt,
                            ws.heavy, ws.n_heavy);
-    // weighted sum by levels of (G x 128)-bucket workgroups; G = 16 buckets per lane in a batch, 4 for a lone proof
+    // weighted sum by levels of (G x 128)-bucket workgroups; G = 16 buckets per lane in a batch (least work per bucket:
+    // the latency of the launches with few buckets hides behind the other batches in flight; choosing G = 4 for those
+    // was measured 2 % slower), 4 for a lone proof (shortest dependent chain)
     const uint32_t g_log = lone ? WSUM_G_LOG_MIN : 4;
     const uint32_t cs = 1u << (g_log + WSUM_L_LOG);
     const size_t st_stride = (nb + cs - 1) / cs;  // level-0 chunk count bounds every later level
