@@ -1,0 +1,31 @@
+#!/bin/bash
+# Where do the wave cycles of the dominant kernel go?  One rocprofv3 --pmc pass of SQ counters (8 slots) with the kernel
+# running alone (one slot), summarised per launch of k_msm_accumulate<G1> into profiles/pmc_sq_accumulate.json.
+export TMPDIR=/tmp
+root=$PWD
+out=$root/gpurun_out/pmc_sq
+rm -rf $out; mkdir -p $out
+ctrs="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_WAVES"
+(cd /tmp && MASP_HIP_SLOTS=1 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out -o run -- python $root/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $out/run.log 2>&1)
+python - <<PY
+import csv, glob, json, collections
+f = glob.glob("$out/**/*counter_collection.csv", recursive=True)[0]
+rows = [r for r in csv.DictReader(open(f)) if "k_msm_accumulate<masp::FpOps>" in r["Kernel_Name"]]
+full = max(int(r["Grid_Size"]) for r in rows)
+acc = collections.defaultdict(list)
+for r in rows:
+    if int(r["Grid_Size"]) == full:
+        acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+avg = {k: sum(v) / len(v) for k, v in acc.items()}
+wave_cycles = avg.get("SQ_ACTIVE_INST_ANY", 0) + avg.get("SQ_WAIT_ANY", 0) + avg.get("SQ_WAIT_INST_ANY", 0)
+out = {"kernel": "k_msm_accumulate<G1>, one batch in flight (MASP_HIP_SLOTS=1), averages per launch of the full batch",
+       "command": "tools/pmc_sq.sh", "launches_sampled": len(next(iter(acc.values()))), "counters": avg,
+       "derived": {"wave_quad_cycles (ACTIVE_INST_ANY + WAIT_ANY + WAIT_INST_ANY, MI355X_MICROARCH.md)": wave_cycles,
+                   "share issuing VALU": avg.get("SQ_ACTIVE_INST_VALU", 0) / wave_cycles if wave_cycles else None,
+                   "share waiting on memory / barriers (WAIT_ANY)": avg.get("SQ_WAIT_ANY", 0) / wave_cycles if wave_cycles else None,
+                   "share stalled at issue (WAIT_INST_ANY)": avg.get("SQ_WAIT_INST_ANY", 0) / wave_cycles if wave_cycles else None,
+                   "VALU instructions per wave": avg.get("SQ_INSTS_VALU", 0) / avg["SQ_WAVES"] if avg.get("SQ_WAVES") else None}}
+json.dump(out, open("$root/profiles/pmc_sq_accumulate.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
+PY
+cp $root/profiles/pmc_sq_accumulate.json $root/gpurun_out/pmc_sq_accumulate.json
