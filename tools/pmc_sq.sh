@@ -28,4 +28,4 @@ out = {"kernel": "k_msm_accumulate<G1>, one batch in flight (MASP_HIP_SLOTS=1), 
 json.dump(out, open("$root/profiles/pmc_sq_accumulate.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
-cp $root/profiles/pmc_sq_accumulate.json $root/gpurun_out/pmc_sq_accumulate.json
+cp $root/profiles/pmc_sq_accumulate.json $root/gpurun_out/pmc_sq_accumulate.json   # gpurun only merges gpurun_out/ back: copy it into profiles/ afterwards
