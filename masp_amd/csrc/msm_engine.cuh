@@ -129,6 +129,9 @@ struct MsmWorkspace {
     static uint32_t nchunks_for(uint32_t n, const MsmGeom& g, uint32_t np) {
         uint64_t ent = (uint64_t)n * g.W;
         uint64_t lanes = std::max<uint64_t>(NCHUNKS / std::max<uint32_t>(np, 1), 1u << 13);
+        // lone proof: about eight chunks per bucket, so that a bucket's partials are few enough for one gather lane
+        // (otherwise every bucket of a 12-bit-window MSM becomes a "heavy" bucket with a workgroup of its own)
+        if (np < 8) lanes = std::min<uint64_t>(lanes, std::max<uint64_t>(8ull * g.nb, 1u << 13));
         const char* e = getenv("MASP_HIP_MSM_CHUNKS");
         if (e) lanes = std::max(1, atoi(e));
         return (uint32_t)std::min<uint64_t>(std::min<uint64_t>(lanes, NCHUNKS), std::max<uint64_t>(ent, 1));
