@@ -87,14 +87,79 @@ __device__ __forceinline__ Xyzz<O> xyzz_fixed_mul(const Xyzz<O>* __restrict__ ta
     return acc;
 }
 
+// ---- four lanes, one point ------------------------------------------------------------------------------
+// The only long serial chain of a proof is the pair of variable-base multiplications of the assembly (252 doublings
+// each).  A lone wave spends ~2.4 us per dependent 384-bit product, so the chain is cut by giving every point operation to
+// FOUR adjacent lanes: all four hold the same point, each computes a different product of the same dependency level
+// (one call site, different operands per lane), and the results are exchanged with width-4 shuffles.  A doubling is 3
+// levels instead of 9 products, an addition 4 instead of 14.  `lig` = lane in group (0..3).
+__device__ __forceinline__ Fp coop_pick(uint32_t lig, const Fp& a0, const Fp& a1, const Fp& a2, const Fp& a3) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) r.v[i] = lig == 0 ? a0.v[i] : lig == 1 ? a1.v[i] : lig == 2 ? a2.v[i] : a3.v[i];
+    return r;
+}
+__device__ __forceinline__ Fp coop_from(const Fp& v, int src) {  // the value lane `src` of this 4-lane group holds
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) r.v[i] = (uint32_t)__shfl((int)v.v[i], src, 4);
+    return r;
+}
+// dbl-2008-s-1, same case analysis as xyzz_dbl
+__device__ __forceinline__ G1Xyzz xyzz_dbl_coop(const G1Xyzz& p, uint32_t lig) {
+    if (xyzz_is_inf(p)) return p;
+    Fp U = fe_dbl(p.Y);
+    if (fe_is_zero(U)) return xyzz_inf<FpOps>();
+    Fp t = fe_mul_nc(coop_pick(lig, U, p.X, U, U), coop_pick(lig, U, p.X, U, U));  // V = U^2 | X^2
+    const Fp V = coop_from(t, 0), X2 = coop_from(t, 1);
+    const Fp M = fe_add(fe_dbl(X2), X2);
+    t = fe_mul_nc(coop_pick(lig, U, p.X, M, V), coop_pick(lig, V, V, M, p.ZZ));      // W = U V | S = X V | M^2 | ZZ' = V ZZ
+    const Fp W = coop_from(t, 0), S = coop_from(t, 1), MM = coop_from(t, 2);
+    G1Xyzz r;
+    r.ZZ = coop_from(t, 3);
+    r.X = fe_sub(MM, fe_dbl(S));
+    t = fe_mul_nc(coop_pick(lig, W, M, W, W), coop_pick(lig, p.Y, fe_sub(S, r.X), p.ZZZ, W));  // W Y | M (S - X') | ZZZ' = W ZZZ
+    r.Y = fe_sub(coop_from(t, 1), coop_from(t, 0));
+    r.ZZZ = coop_from(t, 2);
+    return r;
+}
+// add-2008-s, same case analysis as xyzz_add (the rare P == +-Q cases are computed redundantly by the four lanes)
+__device__ __forceinline__ void xyzz_add_coop(G1Xyzz& acc, const G1Xyzz& b, uint32_t lig) {
+    if (xyzz_is_inf(b)) return;
+    if (xyzz_is_inf(acc)) {
+        acc = b;
+        return;
+    }
+    Fp t = fe_mul_nc(coop_pick(lig, acc.X, b.X, acc.Y, b.Y), coop_pick(lig, b.ZZ, acc.ZZ, b.ZZZ, acc.ZZZ));
+    const Fp U1 = coop_from(t, 0), U2 = coop_from(t, 1), S1 = coop_from(t, 2), S2 = coop_from(t, 3);
+    const Fp P = fe_sub(U2, U1), R = fe_sub(S2, S1);
+    if (fe_is_zero(P)) {
+        if (fe_is_zero(R))
+            acc = xyzz_dbl(acc);
+        else
+            acc = xyzz_inf<FpOps>();
+        return;
+    }
+    t = fe_mul_nc(coop_pick(lig, P, R, acc.ZZ, acc.ZZZ), coop_pick(lig, P, R, b.ZZ, b.ZZZ));  // PP | R^2 | ZZ1 ZZ2 | ZZZ1 ZZZ2
+    const Fp PP = coop_from(t, 0), RR = coop_from(t, 1), Z12 = coop_from(t, 2), Z123 = coop_from(t, 3);
+    t = fe_mul_nc(coop_pick(lig, P, U1, Z12, P), PP);                                       // PPP | Q | ZZ3
+    const Fp PPP = coop_from(t, 0), Q = coop_from(t, 1);
+    acc.ZZ = coop_from(t, 2);
+    acc.X = fe_sub(fe_sub(RR, PPP), fe_dbl(Q));
+    t = fe_mul_nc(coop_pick(lig, S1, R, Z123, S1), coop_pick(lig, PPP, fe_sub(Q, acc.X), PPP, PPP));  // S1 PPP | R (Q - X3) | ZZZ3
+    acc.Y = fe_sub(coop_from(t, 1), coop_from(t, 0));
+    acc.ZZZ = coop_from(t, 2);
+}
+
 // Proof assembly:
 //   g_a = r*delta1 + alpha1 + A
 //   g_b = s*delta2 + beta2 + B2
 //   g_c = (r s)*delta1 + s*alpha1 + r*beta1 + s*A + r*B1 + H + L
 // One workgroup of three waves so that the three differently-shaped jobs do not serialise inside a wave:
 //   wave 0             : the two variable-base multiplications  s*A, r*B1: lanes 0..31 build the tables d*A, d*B1
-//                        (d < 16) in LDS, then lanes 0..1 run 4-bit fixed windows (252 doublings + <= 64 additions each;
-//                        exact for any curve point: no endomorphism, the CRS is read unchecked like the reference's)
+//                        (d < 16) in LDS, then lanes 0..7 run 4-bit fixed windows (252 doublings + <= 64 additions each,
+//                        four lanes per point; exact for any curve point: no endomorphism, the CRS is read unchecked like
+//                        the reference's)
 //   wave 1, lane 0     : s*delta2 on G2 through its fixed-base table          (<= 32 additions)
 //   wave 2, lanes 0..3 : r*delta1, s*alpha1, r*beta1, (r s)*delta1 through fixed-base tables
 // then three lanes normalise and encode.  rs: 8 limbs r | 8 limbs s (canonical).
@@ -132,16 +197,17 @@ __global__ void __launch_bounds__(192) k_groth16_assemble(const VkDevice* __rest
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (tid < 2) {
-            const uint32_t* k = tid == 0 ? s.v : r.v;  // s*A, r*B1
+        if (tid < 8) {  // lanes 0..3: s*A, lanes 4..7: r*B1 — four lanes per point (see xyzz_dbl_coop)
+            const uint32_t grp = tid >> 2, lig = tid & 3;
+            const uint32_t* k = grp == 0 ? s.v : r.v;
             G1Xyzz acc = xyzz_inf<FpOps>();
             for (int w = 63; w >= 0; --w) {
                 if (w != 63)
-                    for (int q = 0; q < 4; ++q) acc = xyzz_dbl(acc);
+                    for (int q = 0; q < 4; ++q) acc = xyzz_dbl_coop(acc, lig);
                 const uint32_t d = (k[w >> 3] >> (4 * (w & 7))) & 15u;
-                if (d) xyzz_add_nc(acc, wtab[tid][d]);
+                if (d) xyzz_add_coop(acc, wtab[grp][d], lig);
             }
-            part[3 + tid] = acc;
+            if (lig == 0) part[3 + grp] = acc;
         }
     } else if (tid == 64) {
         part2 = xyzz_fixed_mul<Fp2Ops>(fb2, s);
