@@ -149,6 +149,20 @@ def test_proof_bytes_match_oracle_and_closed_form(ctx, seed, n_inputs, n_free, n
         assert ctx.prove(3, inputs, aux, rr, ss) == O.create_proof(O.Params(pbuf), cs, inputs, aux, rr, ss)
 
 
+def test_caller_supplied_abc_evaluations(ctx):
+    """masp_hip_prove with a, b, c given (a caller whose constraint system evaluated the rows itself, SURVEY.md §8b
+    "a,b,c or NULL") == the same proof with the rows evaluated on the GPU from the static R1CS; mixed in one batch too."""
+    cs, inputs, aux, vals = toy_r1cs.make(35, 5, 40, 700)
+    pbuf = O.generate_parameters(cs, toy_r1cs.toxic(35))
+    ctx.load_circuit(3, pbuf, cs)
+    a, b, c, *_ = O.r1cs_eval(cs, inputs, aux)
+    want = O.create_proof(O.Params(pbuf), cs, inputs, aux, 21, 22)
+    assert ctx.prove(3, inputs, aux, 21, 22, abc=(a, b, c)) == want == ctx.prove(3, inputs, aux, 21, 22)
+    jobs = [(3, inputs, aux, 21, 22, (a, b, c)), (3, inputs, aux, 21, 22), (3, inputs, aux, 23, 24, (a, b, c))]
+    got = ctx.prove_batch(jobs)
+    assert got[0] == got[1] == want and got[2] == O.create_proof(O.Params(pbuf), cs, inputs, aux, 23, 24)
+
+
 def test_unsatisfied_assignment_matches_oracle(ctx):
     # the reference bench proves an unsatisfiable witness (benches/sapling.rs:41,69): bytes must still agree
     cs, inputs, aux, vals = toy_r1cs.make(41, 3, 10, 120)
