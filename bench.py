@@ -237,6 +237,8 @@ def main():
         pass
     if out is not None:
         sys.stderr.flush()
+        if world > 1:
+            time.sleep(1.0)                     # the other ranks share this stdout: let their flushes land first
         print(json.dumps(out), flush=True)      # the ONE JSON line, last thing on stdout
 
 
