@@ -105,13 +105,13 @@ def cpu_baseline(cs, params, inputs, aux, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32, help="timed steps; one step = one GPU batch of MASP_HIP_BATCH (64) proofs")
+    ap.add_argument("--steps", type=int, default=32, help="timed steps; one step = one GPU batch of MASP_HIP_BATCH (96) proofs")
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # let independent proofs' kernels overlap (ROCm default: 4)
     os.environ.setdefault("MASP_HIP_SLOTS", "4")
-    os.environ.setdefault("MASP_HIP_BATCH", "64")
+    os.environ.setdefault("MASP_HIP_BATCH", "96")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

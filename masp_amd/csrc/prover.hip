@@ -268,7 +268,7 @@ static int n_slots_default() {
 // proofs per batched launch sequence
 static size_t batch_cap() {
     const char* e = getenv("MASP_HIP_BATCH");
-    int n = e ? atoi(e) : 32;
+    int n = e ? atoi(e) : 64;
     return (size_t)std::max(1, std::min(n, 256));
 }
 

@@ -203,7 +203,7 @@ class LocalTxProver:
         if rs is None:
             rs = [(self._rng(), self._rng()) for _ in range(n)]
         threads = threads or H.effective_cpus()
-        chunk = chunk or int(os.environ.get("MASP_HIP_BATCH", "32"))
+        chunk = chunk or int(os.environ.get("MASP_HIP_BATCH", "64"))
         in_flight = max(1, int(os.environ.get("MASP_HIP_SLOTS", "4"))) + 1
         prep = {"spend": self.prepare_spend, "output": self.prepare_output, "convert": self.prepare_convert}
         done = [0]

@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 os.environ.setdefault("MASP_HIP_SLOTS", "4")
-os.environ.setdefault("MASP_HIP_BATCH", "64")
+os.environ.setdefault("MASP_HIP_BATCH", "96")
 
 from masp_amd import host as H                     # noqa: E402
 from masp_amd.prover import LocalTxProver, _int    # noqa: E402

@@ -12,7 +12,7 @@ done
 python - <<PY
 import csv, glob, json, os
 res = {}
-batch = int(os.environ.get("MASP_HIP_BATCH", "64"))
+batch = int(os.environ.get("MASP_HIP_BATCH", "96"))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob("$out/%s/**/*counter_collection.csv" % c, recursive=True)[0]
     rows = [r for r in csv.DictReader(open(f)) if "k_msm_accumulate<masp::FpOps>" in r["Kernel_Name"] and r["Counter_Name"] == c]

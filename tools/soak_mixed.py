@@ -12,7 +12,7 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-os.environ.setdefault("MASP_HIP_BATCH", "64")
+os.environ.setdefault("MASP_HIP_BATCH", "96")
 
 import e2e_batch as E                                   # noqa: E402
 from masp_amd import host as H                         # noqa: E402
