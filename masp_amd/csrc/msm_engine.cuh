@@ -300,27 +300,15 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
         prof->recs.push_back(rec);
     }
     const bool lone = np < 8;  // latency regime: short chains matter more than total work
-    static const uint32_t lone_span = [] {
-        const char* e = getenv("MASP_HIP_LONE_SPAN");
-        return e ? (uint32_t)atoi(e) : 12u;
-    }();
     hipLaunchKernelGGL((k_msm_bucket_gather<O>), dim3((nb + 63) / 64, np), dim3(64), 0, s, ws.part, sb.start, nb, nchunks, ws.bkt, ws.heavy,
-                       ws.n_heavy, lone ? lone_span : 24u);
+                       ws.n_heavy, lone ? 12u : 24u);
     // (with a lone proof the chunks are short and most buckets of a narrow-window MSM count as heavy: give them the chip)
     // Usually ONE workgroup per proof has work here (bucket 0).  Workgroups go to the 8 XCDs round-robin by linear id
     // x + gridDim.x * y, so with gridDim.x a multiple of 8 every proof's working workgroup (x = 0) would land on the same
     // XCD (measured: 9.9 ms instead of 4.1 ms for the G2 launch of a 64-proof batch): keep gridDim.x odd.
     const uint32_t heavy_blocks = std::min<uint32_t>(std::max<uint32_t>(4096u / np, 16u), nb) | 1u;
-    static const int lone_threads = [] {
-        const char* e = getenv("MASP_HIP_LONE_HEAVY_THREADS");
-        return e ? atoi(e) : 256;
-    }();
-    if (lone && lone_threads == 64)
-        hipLaunchKernelGGL((k_msm_bucket_heavy<O, 64>), dim3(heavy_blocks, np), dim3(64), 0, s, ws.part, sb.start, nb, nchunks, ws.bkt, ws.heavy,
-                           ws.n_heavy);
-    else
-        hipLaunchKernelGGL((k_msm_bucket_heavy<O, 256>), dim3(heavy_blocks, np), dim3(256), 0, s, ws.part, sb.start, nb, nchunks, ws.bkt,
-                           ws.heavy, ws.n_heavy);
+    hipLaunchKernelGGL((k_msm_bucket_heavy<O, 256>), dim3(heavy_blocks, np), dim3(256), 0, s, ws.part, sb.start, nb, nchunks, ws.bkt, ws.heavy,
+                       ws.n_heavy);
     // weighted sum by levels of (G x 128)-bucket workgroups; G = 16 buckets per lane in a batch (least work per bucket:
     // the latency of the launches with few buckets hides behind the other batches in flight; choosing G = 4 for those
     // was measured 2 % slower), 4 for a lone proof (shortest dependent chain)
