@@ -202,14 +202,14 @@ def main():
         out = {
             "metric": "Spend proofs/sec" if WORKLOAD == "spend" else "%s proofs/sec" % WORKLOAD, "value": total / elapsed, "unit": "proofs/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32 limbs (384-bit Fp / 255-bit Fr modular integers)", "data": "synthetic",
+            "dtype": "u32", "data": "synthetic",
             "config": {"workload": "%s proofs (BASELINE.json configs[1] instances), one step = one batch of %d independent proofs; %s + synthetic CRS from known toxic waste "
                                    "(NTT 2^%d, G1 MSMs %d/%d/%d/%d, G2 MSM %d), witness resident in HBM, "
                                    "batches of %s proofs per launch sequence on %s HIP streams"
                                    % (WORKLOAD, B, circuit_desc, cs.logm, (1 << cs.logm) - 1, cs.n_aux,
                                       synthetic.SHAPES[kinds[0]][3] + cs.n_inputs, synthetic.SHAPES[kinds[0]][4] + 1,
                                       synthetic.SHAPES[kinds[0]][4] + 1, os.environ.get("MASP_HIP_BATCH"), os.environ.get("MASP_HIP_SLOTS")),
-                       "proofs_per_step": B, "proofs_per_gpu": K * B, "parallelism": "proofs sharded over %d GPU(s), RCCL gather of proofs" % world},
+                       "proofs_per_step": B, "proofs_per_gpu": K * B, "arithmetic": "384-bit Fp / 255-bit Fr modular integers in 32-bit limbs (v_mad_u64_u32)", "parallelism": "proofs sharded over %d GPU(s), RCCL gather of proofs" % world},
             "single_proof_latency_ms": latency_ms,
             "ms_per_proof": elapsed * 1e3 / (K * B),
             "gpu_event_ms_per_step": gpu_ms / K,
