@@ -129,6 +129,30 @@ def test_msm_full_size_by_discrete_log_checksum(ctx, group, n, bool_share):
         assert ctx.msm_g2(O.g2_mul_gen_many(ks), sc) == O.g2_mul_gen_many(expect_scalar)[0].tobytes()
 
 
+@pytest.mark.parametrize("pattern", ["one_value", "all_ones", "all_r_minus_1", "two_values_and_zeros"])
+def test_msm_skewed_digit_distributions(ctx, pattern):
+    """Digit distributions that put everything into a handful of buckets (the balanced chunking, the heavy-bucket path
+    and the signed-digit carries at 70 000 points on 16-bit windows), checked by the discrete-log identity."""
+    rng = random.Random({"one_value": 1, "all_ones": 2, "all_r_minus_1": 3, "two_values_and_zeros": 4}[pattern])
+    n = 70000
+    ks = _rand_scalars(rng, n)
+    v = rng.randrange(R)
+    if pattern == "one_value":
+        s_int = [v] * n
+    elif pattern == "all_ones":
+        s_int = [1] * n
+    elif pattern == "all_r_minus_1":
+        s_int = [R - 1] * n
+    else:
+        w = (1 << 255) % R
+        s_int = [(v, w, 0, 0)[rng.randrange(4)] for _ in range(n)]
+    sc = np.stack([_le(x) for x in s_int])
+    k_int = [int.from_bytes(k.tobytes(), "little") for k in ks]
+    total = sum(a * b for a, b in zip(k_int, s_int)) % R
+    expect = O.g1_mul_gen_many(np.frombuffer(_le(total), np.uint8).reshape(1, 32))[0].tobytes()
+    assert ctx.msm_g1(O.g1_mul_gen_many(ks), sc) == expect
+
+
 @pytest.mark.parametrize("seed,n_inputs,n_free,n_constraints", [(31, 2, 4, 9), (32, 4, 20, 200), (33, 8, 300, 3000)])
 def test_proof_bytes_match_oracle_and_closed_form(ctx, seed, n_inputs, n_free, n_constraints):
     cs, inputs, aux, vals = toy_r1cs.make(seed, n_inputs, n_free, n_constraints, bool_share=0.7)
