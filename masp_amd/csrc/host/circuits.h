@@ -185,21 +185,32 @@ struct MontgomeryPoint {
     Num x, y;
 
     EdwardsPoint into_edwards(CS& cs) const {
-        // u = scale * x / y
-        Fr inv = Fr::zero();
-        if (cs.has_witness() && !y.value.invert(inv)) throw SynthesisError("DivisionByZero");
-        AllocatedNum u = AllocatedNum::alloc(cs, x.value * montgomery_scale() * inv);
+        // u = scale * x / y ; v = (x - 1) / (x + 1): both inverses from one inversion of y (x + 1)
+        Fr inv_y = Fr::zero(), inv_x1 = Fr::zero();
+        if (cs.has_witness()) {
+            const Fr x1 = x.value + Fr::one();
+            Fr t;
+            if (!(y.value * x1).invert(t)) throw SynthesisError("DivisionByZero");
+            inv_y = t * x1;
+            inv_x1 = t * y.value;
+        }
+        AllocatedNum u = AllocatedNum::alloc(cs, x.value * montgomery_scale() * inv_y);
         MASP_ENFORCE(cs, y.lc(Fr::one()), LC(u.var), x.lc(montgomery_scale()));
-        // v = (x - 1) / (x + 1)
-        if (cs.has_witness() && !(x.value + Fr::one()).invert(inv)) throw SynthesisError("DivisionByZero");
-        AllocatedNum v = AllocatedNum::alloc(cs, (x.value - Fr::one()) * inv);
+        AllocatedNum v = AllocatedNum::alloc(cs, (x.value - Fr::one()) * inv_x1);
         MASP_ENFORCE(cs, x.lc(Fr::one()).add(ONE), LC(v.var), x.lc(Fr::one()).sub(ONE));
         return {u, v};
     }
-    // affine addition, undefined for equal x
-    MontgomeryPoint add(CS& cs, const MontgomeryPoint& o) const {
+    // affine addition, undefined for equal x.  `inv_hint`: 1 / (o.x - x) if the caller already knows it (the Pedersen
+    // gadget batches the inversions of a whole segment, see pedersen_segment_hints); checked with one product.
+    MontgomeryPoint add(CS& cs, const MontgomeryPoint& o, const Fr* inv_hint = nullptr) const {
         Fr inv = Fr::zero();
-        if (cs.has_witness() && !(o.x.value - x.value).invert(inv)) throw SynthesisError("DivisionByZero");
+        if (cs.has_witness()) {
+            const Fr d = o.x.value - x.value;
+            if (inv_hint && *inv_hint * d == Fr::one())
+                inv = *inv_hint;
+            else if (!d.invert(inv))
+                throw SynthesisError("DivisionByZero");
+        }
         AllocatedNum lambda = AllocatedNum::alloc(cs, (o.y.value - y.value) * inv);
         MASP_ENFORCE(cs, o.x.lc(Fr::one()).sub(x.lc(Fr::one())), LC(lambda.var), o.y.lc(Fr::one()).sub(y.lc(Fr::one())));
         // x'' = lambda^2 - A - x - x'
@@ -211,6 +222,48 @@ struct MontgomeryPoint {
         return {Num::from(xp), Num::from(yp)};
     }
 };
+
+// The ~5 700 affine Montgomery additions of a Spend (one field inversion each for the slope, which the circuit
+// allocates: circuit/ecc.rs `MontgomeryPoint::add`) dominate witness synthesis.  For one segment of the Pedersen hash the
+// summands are table entries selected by the message bits, so the whole chain can first be run in projective
+// coordinates (no inversion), after which every denominator is known and ONE inversion serves the segment:
+//   acc = (X : Y : Z), next summand (x, y):  1 / (acc.x - x) = Z / (X - x Z).
+// pts[k] = value of the k-th lookup of the segment; hints[k] (k >= 1) = 1 / (sum_{j<k} pts[j]).x - pts[k].x).
+// On any degenerate input (a zero denominator) no hints are produced and the gadget inverts one by one as before.
+inline void pedersen_segment_hints(const std::vector<Coord>& pts, std::vector<Fr>& hints) {
+    hints.clear();
+    const size_t n = pts.size();
+    if (n < 2) return;
+    std::vector<Fr> e(n), z(n), pre(n);
+    Fr X = pts[0].first, Y = pts[0].second, Z = Fr::one();
+    const Fr A = montgomery_a();
+    for (size_t k = 1; k < n; ++k) {
+        const Fr &x2 = pts[k].first, &y2 = pts[k].second;
+        const Fr x2z = x2 * Z;
+        e[k] = X - x2z;
+        z[k] = Z;
+        if (e[k].is_zero()) return;
+        // acc += (x2, y2): lambda = u / v
+        const Fr u = y2 * Z - Y, v = x2z - X;
+        const Fr v2 = v.square(), v3 = v2 * v;
+        const Fr x3n = u.square() * Z - (A * Z + X + x2z) * v2;  // x3 = x3n / (v^2 Z)
+        const Fr y3n = u * (X * v2 - x3n) - Y * v3;              // y3 = y3n / (v^3 Z)
+        X = x3n * v;
+        Y = y3n;
+        Z = v3 * Z;
+    }
+    // batch inversion of e[1..n)
+    pre[1] = e[1];
+    for (size_t k = 2; k < n; ++k) pre[k] = pre[k - 1] * e[k];
+    Fr inv;
+    if (!pre[n - 1].invert(inv)) return;
+    hints.assign(n, Fr::zero());
+    for (size_t k = n - 1; k >= 1; --k) {
+        const Fr ek_inv = k > 1 ? inv * pre[k - 1] : inv;
+        inv = inv * e[k];
+        hints[k] = z[k] * ek_inv;
+    }
+}
 
 inline EdwardsPoint pedersen_hash_gadget(CS& cs, const Personalization& pers, const std::vector<Boolean>& msg) {
     std::vector<Boolean> bits;
@@ -224,6 +277,18 @@ inline EdwardsPoint pedersen_hash_gadget(CS& cs, const Personalization& pers, co
         bool have_seg = false;
         MontgomeryPoint seg_result{};
         const auto& windows = gens.at(seg);
+        std::vector<Fr> hints;
+        if (cs.has_witness()) {  // the segment's summands, straight from the tables
+            std::vector<Coord> pts;
+            for (size_t w = 0, q = pos; w < windows.size() && q < bits.size(); ++w) {
+                const bool b0 = bits[q++].value(), b1 = q < bits.size() ? bits[q++].value() : false,
+                           b2 = q < bits.size() ? bits[q++].value() : false;
+                Coord c = windows[w][(b0 ? 1 : 0) + (b1 ? 2 : 0)];
+                if (b2) c.second = c.second.neg();
+                pts.push_back(c);
+            }
+            pedersen_segment_hints(pts, hints);
+        }
         for (size_t w = 0; w < windows.size() && pos < bits.size(); ++w) {
             Boolean chunk[3];
             chunk[0] = bits[pos++];
@@ -235,7 +300,7 @@ inline EdwardsPoint pedersen_hash_gadget(CS& cs, const Personalization& pers, co
                 seg_result = tmp;
                 have_seg = true;
             } else {
-                seg_result = tmp.add(cs, seg_result);
+                seg_result = tmp.add(cs, seg_result, w < hints.size() ? &hints[w] : nullptr);
             }
         }
         EdwardsPoint e = seg_result.into_edwards(cs);

@@ -429,6 +429,12 @@ inline std::pair<AllocatedNum, AllocatedNum> lookup3_xy(CS& cs, const Boolean bi
     int i = (bits[0].value() ? 1 : 0) + (bits[1].value() ? 2 : 0) + (bits[2].value() ? 4 : 0);
     AllocatedNum rx = AllocatedNum::alloc(cs, coords[i].first);
     AllocatedNum ry = AllocatedNum::alloc(cs, coords[i].second);
+    Boolean precomp = Boolean::and_(cs, bits[1], bits[2]);
+    if (!cs.recording()) {  // proving mode: the table coefficients and the two rows are only needed for the structure
+        cs.count_constraint();
+        cs.count_constraint();
+        return {rx, ry};
+    }
     std::vector<Fr> xs, ys, xc, yc;
     for (auto& c : coords) {
         xs.push_back(c.first);
@@ -436,7 +442,6 @@ inline std::pair<AllocatedNum, AllocatedNum> lookup3_xy(CS& cs, const Boolean bi
     }
     synth(3, xs, xc);
     synth(3, ys, yc);
-    Boolean precomp = Boolean::and_(cs, bits[1], bits[2]);
     const std::vector<Fr>* co[2] = {&xc, &yc};
     const AllocatedNum* res[2] = {&rx, &ry};
     for (int k = 0; k < 2; ++k) {
@@ -455,6 +460,11 @@ inline std::pair<Num, Num> lookup3_xy_with_conditional_negation(CS& cs, const Bo
     Fr yv = coords[i].second;
     if (bits[2].value()) yv = yv.neg();
     AllocatedNum y = AllocatedNum::alloc(cs, yv);
+    Boolean precomp = Boolean::and_(cs, bits[0], bits[1]);
+    if (!cs.recording()) {  // proving mode: x is the table entry itself (the linear combination below evaluates to it)
+        cs.count_constraint();
+        return {Num{coords[i].first, LC()}, Num::from(y)};
+    }
     std::vector<Fr> xs, ys, xc, yc;
     for (auto& c : coords) {
         xs.push_back(c.first);
@@ -462,7 +472,6 @@ inline std::pair<Num, Num> lookup3_xy_with_conditional_negation(CS& cs, const Bo
     }
     synth(2, xs, xc);
     synth(2, ys, yc);
-    Boolean precomp = Boolean::and_(cs, bits[0], bits[1]);
     Num x = Num::zero()
                 .add_bool_with_coeff(Boolean::constant(true), xc[0])
                 .add_bool_with_coeff(bits[0], xc[1])

@@ -82,7 +82,20 @@ Var remap(Var v, uint32_t n_inputs) { return (v & AUX) ? n_inputs + (v & ~AUX) :
 
 void write_assignment(const CS& cs, uint8_t* inputs, uint8_t* aux) {
     for (size_t i = 0; i < cs.num_inputs(); ++i) cs.inputs()[i].to_bytes(inputs + 32 * i);
-    for (size_t j = 0; j < cs.num_aux(); ++j) cs.aux()[j].to_bytes(aux + 32 * j);
+    // 70 % of a MASP witness is 0 or 1 (booleans): no Montgomery conversion needed for those
+    const Fr one = Fr::one();
+    for (size_t j = 0; j < cs.num_aux(); ++j) {
+        const Fr& v = cs.aux()[j];
+        uint8_t* o = aux + 32 * j;
+        if (v.is_zero()) {
+            memset(o, 0, 32);
+        } else if (v == one) {
+            memset(o, 0, 32);
+            o[0] = 1;
+        } else {
+            v.to_bytes(o);
+        }
+    }
 }
 bool load_path(MerklePathW& p, const uint8_t* siblings, uint64_t position) {
     for (int i = 0; i < TREE_DEPTH; ++i) {

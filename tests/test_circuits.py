@@ -173,6 +173,33 @@ def test_output_and_convert_witnesses_satisfy_their_circuits():
         H.convert_assignment(gen, 7, (int.from_bytes(anchor, "little") + 1) % R, siblings, pos, 5, check=True)
 
 
+def test_proving_mode_assignment_equals_recording_mode():
+    """The synthesizer takes shortcuts when nothing records constraints (table coefficients skipped, one inversion per
+    Pedersen segment, 0 / 1 written without a Montgomery conversion): the assignment must be the same bytes."""
+    inst, _, _ = spend_instance(110, value=77)
+    fast, slow = H.spend_assignment(check=False, **inst), H.spend_assignment(check=True, **inst)
+    assert (fast[0] == slow[0]).all() and (fast[1] == slow[1]).all() and fast[2:] == slow[2:]
+    rng = random.Random(9)
+    ident = H.asset_identifier(b"benchmark")
+    pk = H.jubjub_mul(H.point_bytes(*H.generator_uv(0)), _rand_scalar(rng))
+    while True:
+        d = bytes(rng.getrandbits(8) for _ in range(11))
+        try:
+            args = (_rand_scalar(rng), d, pk, _rand_scalar(rng), ident, 5, _rand_scalar(rng))
+            fo = H.output_assignment(*args, check=False)
+            break
+        except H.HostError:
+            continue
+    so = H.output_assignment(*args, check=True)
+    assert (fo[0] == so[0]).all() and (fo[1] == so[1]).all() and fo[2] == so[2]
+    gen = H.asset_generator(H.asset_identifier(b"asset 3"))
+    sib = [rng.randrange(R) for _ in range(32)]
+    anchor = H.merkle_root(H.convert_cmu(gen), sib, 5)
+    fc = H.convert_assignment(gen, 9, anchor, sib, 5, 11, check=False)
+    sc = H.convert_assignment(gen, 9, anchor, sib, 5, 11, check=True)
+    assert (fc[0] == sc[0]).all() and (fc[1] == sc[1]).all() and fc[2] == sc[2]
+
+
 def test_host_verifier_agrees_with_oracle_pairing_check():
     """product-side verify_proof (masp_amd/csrc/host/pairing.h) vs the oracle's independent pairing on oracle-made proofs"""
     import toy_r1cs
