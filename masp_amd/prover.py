@@ -216,8 +216,12 @@ class LocalTxProver:
         # synthesis may run ahead of the GPU only so far: every job in flight owns a page-locked aux buffer (3.2 MB / Spend)
         ahead = threading.Semaphore((in_flight + 2) * chunk + threads)
 
+        abort = threading.Event()              # set when a chunk fails: queued synthesis tasks then return at once
+
         def synthesize(kind, kw):
             ahead.acquire()
+            if abort.is_set():
+                return None
             return prep[kind](**kw)
 
         with ThreadPoolExecutor(max_workers=threads) as synth, ThreadPoolExecutor(max_workers=in_flight) as gpu:
@@ -243,7 +247,13 @@ class LocalTxProver:
                 if progress is not None:
                     progress(done[0], n)
                 return jobs, proofs
-            results = list(gpu.map(run_chunk, range(0, n, chunk)))
+            try:
+                results = list(gpu.map(run_chunk, range(0, n, chunk)))
+            except BaseException:
+                abort.set()                        # (an invalid diversifier, a failed self-check, a device error ...)
+                for _ in range(n):
+                    ahead.release()
+                raise
         jobs = [j for js, _ in results for j in js]
         proofs = [p for _, ps in results for p in ps]
         out = []

@@ -432,4 +432,11 @@ def test_local_tx_prover_batch_equals_serial(ctx):
         else:
             serial.append(lp.convert_proof(c2, kw["allowed_conversion"], kw["value"], kw["anchor"], kw["merkle_path"], kw["rcv"], rs=r))
     assert batch == serial and (c1.bsk, c1.cv_sum) == (c2.bsk, c2.cv_sum)
+    # one bad description (invalid diversifier) fails the whole call with Err(()) — and does not leave the pipeline hanging
+    inst = spend_instance(400, value=10)[0]
+    bad_d = next(bytes([k]) * 11 for k in range(256) if _invalid_diversifier(bytes([k]) * 11, inst))
+    bad = ("spend", dict(descs[0][1], diversifier=bad_d))
+    with pytest.raises(P.ProvingError):
+        lp.prove_batch(lp.new_sapling_proving_context(), descs * 8 + [bad] + descs * 8, chunk=4, threads=4)
+    assert lp.prove_batch(lp.new_sapling_proving_context(), descs, rs=rs) == serial        # and the prover is still usable
     lp.close()
