@@ -50,7 +50,8 @@ def main():
     with ThreadPoolExecutor(threads) as ex:
         descs = list(ex.map(spend_description, range(n)))
         # warm-up (workspace allocation, first-launch costs)
-        prover.prove_batch(prover.new_sapling_proving_context(), descs[:min(n, 64)], threads=threads)
+        # (five full batches: every slot's workspace gets its final size before anything is timed)
+        prover.prove_batch(prover.new_sapling_proving_context(), descs[:min(n, 5 * int(os.environ["MASP_HIP_BATCH"]))], threads=threads)
         stage_n = min(n, 256)                     # the staged measurement holds every aux buffer at once: bound it
         t0 = time.time()
         jobs = list(ex.map(lambda d: prover.prepare_spend(**d[1]), descs[:stage_n]))

@@ -51,7 +51,7 @@ def main():
     t = time.time()
     descs = [make[i % 3](i) for i in range(n)]
     print("%d descriptions built in %.1f s" % (n, time.time() - t))
-    prover.prove_batch(prover.new_sapling_proving_context(), descs[:96])      # warm-up
+    prover.prove_batch(prover.new_sapling_proving_context(), descs[:min(n, 15 * 96)])      # warm-up: every slot, every circuit, full batches
     ctx = prover.new_sapling_proving_context()
     seen = []
     t0 = time.time()
