@@ -629,7 +629,10 @@ int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* param
         return e ? atoi(e) : 0;
     };
     const int c_la = envc("MASP_HIP_MSM_C_LA"), c_b = envc("MASP_HIP_MSM_C_B");
-    if ((rc = C->h.load_host(L.h, (uint32_t)(C->m - 1), s)) || (rc = C->l.load_host(L.l, L.n_l, s, eff(L.n_l), c_la)) ||
+    // h has uniform scalars: 16-bit windows from 48 k points (Spend 131 071, Convert 65 535), 15 bits below (Output 32 767)
+    const uint32_t n_h = (uint32_t)(C->m - 1);
+    const int c_h = envc("MASP_HIP_MSM_C_H") ? envc("MASP_HIP_MSM_C_H") : n_h >= 49152 ? 16 : n_h >= 16384 ? 15 : 0;
+    if ((rc = C->h.load_host(L.h, (uint32_t)(C->m - 1), s, 0xffffffffu, c_h)) || (rc = C->l.load_host(L.l, L.n_l, s, eff(L.n_l), c_la)) ||
         (rc = C->a.load_host(L.a, L.n_a, s, eff(L.n_a), c_la)) || (rc = C->b1.load_host(L.b_g1, L.n_b1, s, eff(L.n_b1), c_b)) ||
         (rc = C->b2.load_host(L.b_g2, L.n_b2, s, eff(L.n_b2), c_b)))
         return fail(ctx, rc);
