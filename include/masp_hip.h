@@ -16,8 +16,11 @@
  *                              exposed so each kernel family can be checked and timed on its own.
  *
  * Conventions: C linkage, no exceptions across the boundary, integer return codes (0 = ok), the caller
- * owns every buffer, outputs are written only on success, a context may be shared between threads
- * (calls are serialised internally).  Field elements cross the boundary as 32-byte little-endian
+ * owns every buffer, outputs are written only on success.  A context may be shared between threads:
+ * masp_hip_prove / masp_hip_prove_batch are re-entrant (concurrent callers each get batches on their own
+ * stream + scratch from the context's pool, so their proofs overlap on the device); circuit loads and the
+ * building-block / measurement entry points take the context exclusively.
+ * Field elements cross the boundary as 32-byte little-endian
  * canonical integers (`Scalar::to_repr()`), points in the zcash encodings of the bellman wire format.
  */
 #ifndef MASP_HIP_H
