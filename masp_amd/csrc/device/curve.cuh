@@ -197,7 +197,8 @@ MASP_HD Xyzz<O> xyzz_mul_scalar(const Xyzz<O>& p, const uint32_t* k) {
     return r;
 }
 
-template <class O>
+// LONE: called by a single lane on a serial tail (see FpOps::inv_lone)
+template <class O, bool LONE = false>
 MASP_HD Affine<O> xyzz_to_affine(const Xyzz<O>& p) {
     Affine<O> r;
     if (xyzz_is_inf(p)) {
@@ -206,7 +207,7 @@ MASP_HD Affine<O> xyzz_to_affine(const Xyzz<O>& p) {
         return r;
     }
     // 1/ZZZ, then 1/ZZ = ZZZ^-2 * ZZ^2 ... cheaper: zi3 = 1/ZZZ ; zi2 = (zi3 * ZZ)^2  (since ZZ^3 = ZZZ^2 => ZZ/ZZZ = 1/Z)
-    typename O::T zi3 = O::inv(p.ZZZ);
+    typename O::T zi3 = LONE ? O::inv_lone(p.ZZZ) : O::inv(p.ZZZ);
     typename O::T zi = O::Cold::mul(zi3, p.ZZ);
     typename O::T zi2 = O::Cold::sqr(zi);
     r.x = O::Cold::mul(p.X, zi2);

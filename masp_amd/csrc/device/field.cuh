@@ -344,12 +344,196 @@ MASP_NOINLINE Fe<C> fe_pow(const Fe<C>& a, const uint32_t* e, int nlimbs) {
         }
     return r;
 }
-// Fermat inverse (inv(0) = 0)
+// Inverse (inv(0) = 0) by batched division steps (Bernstein-Yang "safegcd", variable time): 62 steps are decided on the
+// low words and applied to the full-width values as one 2x2 integer matrix, ~10 rounds for 384 bits.  ~12x fewer
+// instructions than the Fermat power (381 squarings + ~190 products) it replaces — it sits on the serial tail of every
+// proof (three affine conversions in the assembly) and in the window-table precomputation at load time.
+// Values are L signed limbs of 62 bits; 64 x 64 -> 128-bit products (`__int128` works in device code).
 template <class C>
-MASP_NOINLINE Fe<C> fe_inv(const Fe<C>& a) {
+struct FeDivsteps {
+    static constexpr int L = (32 * C::N + 61) / 62 + (((32 * C::N + 61) / 62) * 62 - 32 * C::N < 2 ? 1 : 0);  // room for a sign
+    static constexpr uint64_t M62 = ~0ull >> 2;
+    typedef __int128 i128;
+
+    static MASP_HD void to62(int64_t* o, const uint32_t* a) {
+        for (int i = 0; i < L; ++i) {
+            uint64_t v = 0;
+            for (int b = 0; b < 62; b += 1) {
+                int bit = 62 * i + b;
+                if (bit >= 32 * C::N) break;
+                v |= (uint64_t)((a[bit >> 5] >> (bit & 31)) & 1u) << b;
+            }
+            o[i] = (int64_t)v;
+        }
+    }
+    static MASP_HD void from62(uint32_t* o, const int64_t* a) {
+        for (int w = 0; w < C::N; ++w) o[w] = 0;
+        for (int i = 0; i < L; ++i)
+            for (int b = 0; b < 62; ++b) {
+                int bit = 62 * i + b;
+                if (bit >= 32 * C::N) break;
+                o[bit >> 5] |= (uint32_t)(((uint64_t)a[i] >> b) & 1u) << (bit & 31);
+            }
+    }
+    static MASP_HD int ctz64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __ffsll((unsigned long long)x) - 1;
+#else
+        return __builtin_ctzll(x);
+#endif
+    }
+    // up to 62 division steps on the low words; eta = -delta.  2^62 (f', g') = [[u v] [q r]] (f, g)
+    static MASP_HD int64_t divsteps(int64_t eta, uint64_t f, uint64_t g, int64_t* t) {
+        uint64_t u = 1, v = 0, q = 0, r = 1;
+        int i = 62;
+        for (;;) {
+            int zeros = ctz64(g | (~0ull << i));
+            g >>= zeros;
+            u <<= zeros;
+            v <<= zeros;
+            eta -= zeros;
+            i -= zeros;
+            if (i == 0) break;
+            if (eta < 0) {
+                uint64_t tmp;
+                eta = -eta;
+                tmp = f; f = g; g = (uint64_t)0 - tmp;
+                tmp = u; u = q; q = (uint64_t)0 - tmp;
+                tmp = v; v = r; r = (uint64_t)0 - tmp;
+            }
+            // cancel the low bits of g with a multiple of f (up to 4 at once): w = -g / f mod 2^k
+            int limit = ((int)eta + 1) > i ? i : ((int)eta + 1);
+            uint64_t m = (~0ull >> (64 - limit)) & 15u;
+            uint64_t w = f + (((f + 1) & 4) << 1);  // f^-1 mod 16
+            w = ((uint64_t)0 - w * g) & m;
+            g += f * w;
+            q += u * w;
+            r += v * w;
+        }
+        t[0] = (int64_t)u;
+        t[1] = (int64_t)v;
+        t[2] = (int64_t)q;
+        t[3] = (int64_t)r;
+        return eta;
+    }
+    static MASP_HD void update_fg(int64_t* f, int64_t* g, const int64_t* t) {
+        const int64_t u = t[0], v = t[1], q = t[2], r = t[3];
+        i128 cf = (i128)u * f[0] + (i128)v * g[0];
+        i128 cg = (i128)q * f[0] + (i128)r * g[0];
+        cf >>= 62;
+        cg >>= 62;
+        for (int i = 1; i < L; ++i) {
+            cf += (i128)u * f[i] + (i128)v * g[i];
+            cg += (i128)q * f[i] + (i128)r * g[i];
+            f[i - 1] = (int64_t)((uint64_t)cf & M62);
+            g[i - 1] = (int64_t)((uint64_t)cg & M62);
+            cf >>= 62;
+            cg >>= 62;
+        }
+        f[L - 1] = (int64_t)cf;
+        g[L - 1] = (int64_t)cg;
+    }
+    // (d, e) <- t (d, e) / 2^62 mod p, both kept in (-2p, p)
+    static MASP_HD void update_de(int64_t* d, int64_t* e, const int64_t* t, const int64_t* p62, uint64_t p_inv62) {
+        const int64_t u = t[0], v = t[1], q = t[2], r = t[3];
+        const int64_t sd = d[L - 1] >> 63, se = e[L - 1] >> 63;
+        int64_t md = (u & sd) + (v & se), me = (q & sd) + (r & se);
+        i128 cd = (i128)u * d[0] + (i128)v * e[0];
+        i128 ce = (i128)q * d[0] + (i128)r * e[0];
+        md -= (int64_t)((p_inv62 * (uint64_t)cd + (uint64_t)md) & M62);
+        me -= (int64_t)((p_inv62 * (uint64_t)ce + (uint64_t)me) & M62);
+        cd += (i128)p62[0] * md;
+        ce += (i128)p62[0] * me;
+        cd >>= 62;
+        ce >>= 62;
+        for (int i = 1; i < L; ++i) {
+            cd += (i128)u * d[i] + (i128)v * e[i] + (i128)p62[i] * md;
+            ce += (i128)q * d[i] + (i128)r * e[i] + (i128)p62[i] * me;
+            d[i - 1] = (int64_t)((uint64_t)cd & M62);
+            e[i - 1] = (int64_t)((uint64_t)ce & M62);
+            cd >>= 62;
+            ce >>= 62;
+        }
+        d[L - 1] = (int64_t)cd;
+        e[L - 1] = (int64_t)ce;
+    }
+    static MASP_HD void carry(int64_t* r) {
+        for (int i = 0; i < L - 1; ++i) {
+            r[i + 1] += r[i] >> 62;
+            r[i] &= (int64_t)M62;
+        }
+    }
+    // plain residues: out = x^-1 mod p (0 for x = 0)
+    static MASP_HD void invert(uint32_t* out, const uint32_t* x) {
+        int64_t f[L], g[L], d[L], e[L], p62[L];
+        to62(p62, C::MOD);
+        to62(g, x);
+        uint64_t nz = 0;
+        for (int i = 0; i < L; ++i) {
+            f[i] = p62[i];
+            d[i] = e[i] = 0;
+            nz |= (uint64_t)g[i];
+        }
+        if (!nz) {
+            for (int w = 0; w < C::N; ++w) out[w] = 0;
+            return;
+        }
+        e[0] = 1;
+        uint64_t pinv = 1;  // p^-1 mod 2^64 by Newton, then mod 2^62
+        const uint64_t p0 = (uint64_t)C::MOD[0] | ((uint64_t)C::MOD[1] << 32);
+        for (int i = 0; i < 6; ++i) pinv *= 2 - p0 * pinv;
+        pinv &= M62;
+        int64_t eta = -1;
+        for (int round = 0; round < 64; ++round) {  // 12 rounds cover the 735-step bound for 384 bits
+            int64_t t[4];
+            eta = divsteps(eta, (uint64_t)f[0], (uint64_t)g[0], t);
+            update_de(d, e, t, p62, pinv);
+            update_fg(f, g, t);
+            int64_t any = 0;
+            for (int i = 0; i < L; ++i) any |= g[i];
+            if (any == 0) break;
+        }
+        // f = +-1 ; x^-1 = d * f, brought into [0, p)
+        const bool negate = f[L - 1] < 0;
+        carry(d);
+        if (d[L - 1] < 0) {
+            for (int i = 0; i < L; ++i) d[i] += p62[i];
+            carry(d);
+        }
+        if (negate) {
+            for (int i = 0; i < L; ++i) d[i] = -d[i];
+            carry(d);
+        }
+        for (int guard = 0; guard < 4 && d[L - 1] < 0; ++guard) {
+            for (int i = 0; i < L; ++i) d[i] += p62[i];
+            carry(d);
+        }
+        for (int guard = 0; guard < 4; ++guard) {  // subtract p while d >= p
+            int64_t s[L];
+            for (int i = 0; i < L; ++i) s[i] = d[i] - p62[i];
+            carry(s);
+            if (s[L - 1] < 0) break;
+            for (int i = 0; i < L; ++i) d[i] = s[i];
+        }
+        from62(out, d);
+    }
+};
+// Fermat inverse (inv(0) = 0): 381 squarings + ~190 products.  More instructions than the divsteps, but a straight
+// chain of products — on a lone lane (the assembly's three affine conversions) it is the faster of the two (1.4 ms
+// against 2.3 ms), while in bulk (table precomputation, every lane busy) the divsteps win 3-4x.
+template <class C>
+MASP_NOINLINE Fe<C> fe_inv_fermat(const Fe<C>& a) {
     uint32_t e[C::N];
     for (int i = 0; i < C::N; ++i) e[i] = C::PM2[i];
     return fe_pow(a, e, C::N);
+}
+template <class C>
+MASP_NOINLINE Fe<C> fe_inv(const Fe<C>& a) {
+    Fe<C> r, r2;
+    FeDivsteps<C>::invert(r.v, a.v);  // (a R)^-1 from the Montgomery representative
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) r2.v[i] = C::R2[i];
+    return fe_mul_nc(fe_mul_nc(r, r2), r2);  // (aR)^-1 R^2 R^-1 = a^-1, once more: a^-1 R
 }
 // canonical value > (p-1)/2 ?  (zcash "lexicographically largest")
 template <class C>
@@ -393,6 +577,7 @@ struct FpOps {
     static MASP_HD bool is_zero(const T& a) { return fe_is_zero(a); }
     static MASP_HD bool eq(const T& a, const T& b) { return fe_eq(a, b); }
     static MASP_HD T inv(const T& a) { return fe_inv(a); }
+    static MASP_HD T inv_lone(const T& a) { return fe_inv_fermat(a); }  // for single-lane serial tails
 };
 struct Fp2Ops {
     typedef Fp2 T;
@@ -419,6 +604,10 @@ struct Fp2Ops {
     static MASP_HD bool eq(const T& a, const T& b) { return fe_eq(a.c0, b.c0) && fe_eq(a.c1, b.c1); }
     static MASP_HD T inv(const T& a) {
         Fp n = fe_inv(fe_add(fe_mul_nc(a.c0, a.c0), fe_mul_nc(a.c1, a.c1)));
+        return {fe_mul_nc(a.c0, n), fe_neg(fe_mul_nc(a.c1, n))};
+    }
+    static MASP_HD T inv_lone(const T& a) {
+        Fp n = fe_inv_fermat(fe_add(fe_mul_nc(a.c0, a.c0), fe_mul_nc(a.c1, a.c1)));
         return {fe_mul_nc(a.c0, n), fe_neg(fe_mul_nc(a.c1, n))};
     }
 };

@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(192) k_groth16_assemble(const VkDevice* __rest
         G1Xyzz ga = part[0];
         xyzz_madd_nc(ga, vk->alpha_g1, false);
         xyzz_add_nc(ga, msm_g1[2]);
-        g1_write_compressed(xyzz_to_affine(ga), proof);
+        g1_write_compressed(xyzz_to_affine<FpOps, true>(ga), proof);
     } else if (tid == 128) {
         G1Xyzz gc = part[5];
         xyzz_add_nc(gc, part[1]);
@@ -233,12 +233,12 @@ __global__ void __launch_bounds__(192) k_groth16_assemble(const VkDevice* __rest
         xyzz_add_nc(gc, part[4]);
         xyzz_add_nc(gc, msm_g1[0]);
         xyzz_add_nc(gc, msm_g1[1]);
-        g1_write_compressed(xyzz_to_affine(gc), proof + 144);
+        g1_write_compressed(xyzz_to_affine<FpOps, true>(gc), proof + 144);
     } else if (tid == 64) {
         G2Xyzz gb = part2;
         xyzz_madd_nc(gb, vk->beta_g2, false);
         xyzz_add_nc(gb, *msm_g2);
-        g2_write_compressed(xyzz_to_affine(gb), proof + 48);
+        g2_write_compressed(xyzz_to_affine<Fp2Ops, true>(gb), proof + 48);
     }
 }
 
