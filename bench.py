@@ -38,6 +38,9 @@ def make_jobs(n_distinct, total, instances):
     return jobs
 
 
+SYNTHESIS_MS = {}    # per circuit: wall time of building one instance (witness preparation + C++ synthesis), one host thread
+
+
 def real_instances(kind, n, rank):
     """n independent, valid instances of the real MASP circuit `kind`, shaped like the reference's benches
     (masp_proofs/benches/sapling.rs:39-69, benches/convert.rs:32-53) but with the anchor set to the computed root."""
@@ -46,6 +49,7 @@ def real_instances(kind, n, rank):
     cs, _ = H.circuit(kind)
     out = []
     for k in range(n):
+        t_syn = time.perf_counter()
         rng = random.Random("masp-bench-%s-%d-%d" % (kind, rank, k))
         sc = lambda: rng.randrange(1, H.JUBJUB_ORDER)
         siblings = [rng.randrange(H.FR_MODULUS) for _ in range(32)]
@@ -76,6 +80,7 @@ def real_instances(kind, n, rank):
             gen = H.asset_generator(H.asset_identifier(b"asset %d" % k))
             inputs, aux, _ = H.convert_assignment(gen, 1 + rng.getrandbits(40), H.merkle_root(H.convert_cmu(gen), siblings, pos), siblings, pos, sc())
         out.append((cs, inputs, aux))
+        SYNTHESIS_MS.setdefault(kind, []).append((time.perf_counter() - t_syn) * 1e3)
     return out
 
 
@@ -211,6 +216,8 @@ def main():
                                       synthetic.SHAPES[kinds[0]][4] + 1, os.environ.get("MASP_HIP_BATCH"), os.environ.get("MASP_HIP_SLOTS")),
                        "proofs_per_step": B, "proofs_per_gpu": K * B, "arithmetic": "384-bit Fp / 255-bit Fr modular integers in 32-bit limbs (v_mad_u64_u32)", "parallelism": "proofs sharded over %d GPU(s), RCCL gather of proofs" % world},
             "single_proof_latency_ms": latency_ms,
+            # not part of `value` (assignments are resident when the timed region starts): one host thread, libmasp_host
+            "host_synthesis_ms_per_proof": {k: round(min(v), 2) for k, v in SYNTHESIS_MS.items()},
             "ms_per_proof": elapsed * 1e3 / (K * B),
             "gpu_event_ms_per_step": gpu_ms / K,
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate<G1> (bucket accumulation of the 4 G1 MSMs)",
