@@ -125,33 +125,32 @@ struct Mont {
     }
     Mont dbl() const { return *this + *this; }
 
-    // CIOS Montgomery product (a*b*R^-1 mod p).
+    // CIOS Montgomery product (a*b*R^-1 mod p), product and reduction interleaved in one pass per limb of b; valid
+    // because both moduli leave the top bit of their top limb clear, so the running value never needs an extra limb.
     static void mont_mul(uint64_t* out, const uint64_t* a, const uint64_t* b) {
         const MontCtx<N>& c = ctx();
-        uint64_t t[N + 2];
-        for (int i = 0; i < N + 2; ++i) t[i] = 0;
+        const uint64_t* p = c.p;
+        const uint64_t inv = c.inv;
+        uint64_t t[N];
+#pragma GCC unroll 8
+        for (int j = 0; j < N; ++j) t[j] = 0;
+#pragma GCC unroll 8
         for (int i = 0; i < N; ++i) {
-            u128 carry = 0;
-            for (int j = 0; j < N; ++j) {
-                u128 x = (u128)a[j] * b[i] + t[j] + carry;
-                t[j] = (uint64_t)x;
-                carry = x >> 64;
-            }
-            u128 x = (u128)t[N] + carry;
-            t[N] = (uint64_t)x;
-            t[N + 1] = (uint64_t)(x >> 64);
-            uint64_t m = t[0] * c.inv;
-            carry = ((u128)m * c.p[0] + t[0]) >> 64;
+            u128 x = (u128)a[0] * b[i] + t[0];
+            uint64_t hi = (uint64_t)(x >> 64);
+            const uint64_t m = (uint64_t)x * inv;
+            uint64_t red = (uint64_t)(((u128)m * p[0] + (uint64_t)x) >> 64);
+#pragma GCC unroll 8
             for (int j = 1; j < N; ++j) {
-                u128 y = (u128)m * c.p[j] + t[j] + carry;
+                x = (u128)a[j] * b[i] + t[j] + hi;
+                hi = (uint64_t)(x >> 64);
+                const u128 y = (u128)m * p[j] + (uint64_t)x + red;
                 t[j - 1] = (uint64_t)y;
-                carry = y >> 64;
+                red = (uint64_t)(y >> 64);
             }
-            x = (u128)t[N] + carry;
-            t[N - 1] = (uint64_t)x;
-            t[N] = t[N + 1] + (uint64_t)(x >> 64);
+            t[N - 1] = red + hi;
         }
-        if (t[N] || cmp_limbs<N>(t, c.p) >= 0) sub_limbs<N>(t, t, c.p);
+        if (cmp_limbs<N>(t, p) >= 0) sub_limbs<N>(t, t, p);
         for (int i = 0; i < N; ++i) out[i] = t[i];
     }
     Mont operator*(const Mont& o) const {
