@@ -74,9 +74,19 @@ typedef struct {
 } masp_hip_job;
 
 int masp_hip_ctx_create(int device, masp_hip_ctx** out);
+/* One prover over several GPUs of a node (SURVEY.md §8b "devices, n_dev"): the serial per-description loops of
+ * SaplingBuilder::build (/root/reference/masp_primitives/src/transaction/components/sapling/builder.rs:935-1140) become one
+ * masp_hip_prove_batch call whose jobs are dealt to the devices in full batches, one host thread per device inside
+ * the library — a Rust caller reaches all GPUs without any Python / torch.distributed.  masp_hip_circuit_load
+ * replicates the CRS on every device (side by side).  A device may be listed more than once (two contexts on one
+ * GPU).  The building-block and measurement entry points of such a context run on devices[0]. */
+int masp_hip_ctx_create_multi(const int* devices, int n_devices, masp_hip_ctx** out);
+/* number of device contexts behind `ctx` (1 for masp_hip_ctx_create) */
+int masp_hip_ctx_device_count(const masp_hip_ctx* ctx);
 void masp_hip_ctx_destroy(masp_hip_ctx* ctx);
 const char* masp_hip_strerror(int code);
-/* last HIP runtime error text seen by this context ("" if none) */
+/* last HIP runtime error text seen by this context ("" if none); the pointer belongs to the calling thread and stays
+ * valid until the same thread calls this function again */
 const char* masp_hip_last_error(const masp_hip_ctx* ctx);
 
 /* Parse `params` (bellman Parameters wire format; trailing bytes such as the MPC transcript are ignored),
@@ -102,6 +112,11 @@ size_t masp_hip_parameters_max_size(const masp_hip_r1cs* cs);
 /* sum_i scalars[i] * bases[i]; bases uncompressed (96 / 192 B each), result uncompressed */
 int masp_hip_msm_g1(masp_hip_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[96]);
 int masp_hip_msm_g2(masp_hip_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[192]);
+/* np MSMs over ONE set of n G1 bases, launched the way a batch of proofs launches them (one kernel sequence,
+ * gridDim.y = np): scalars np x n x 32, out np x 96.  window_bits: 0 = chosen from n, else 2..16 (the prover uses 16 for
+ * the h query and 12 for the witness queries).  Exists so that the batched code path can be checked on its own. */
+int masp_hip_msm_g1_multi(masp_hip_ctx* ctx, const uint8_t* bases, size_t n, const uint8_t* scalars, size_t np, int window_bits,
+                          uint8_t* out);
 /* h = ((A*B - C)/Z) coefficients from evaluation vectors a,b,c (nrows x 32 each, zero-padded to 2^logm);
  * h_out: (2^logm - 1) x 32 */
 int masp_hip_quotient_h(masp_hip_ctx* ctx, const uint8_t* a, const uint8_t* b, const uint8_t* c, size_t nrows,
@@ -115,6 +130,11 @@ int masp_hip_batch_upload(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs)
 /* Proves every resident job of `handle` once; proofs_out n x 192.  elapsed_ms (may be NULL) = HIP-event time
  * from first kernel to last proof written, inputs already in HBM. */
 int masp_hip_batch_prove_resident(masp_hip_ctx* ctx, int handle, uint8_t* proofs_out, float* elapsed_ms);
+/* The same, `steps` times over: step k proves every resident job with the blinding scalars rs[(k * n + job) * 64 ...]
+ * (r | s, 32 + 32 bytes; NULL = the uploaded ones), all steps enqueued back to back without host synchronisation — one
+ * step = one pass of the hot path over one batch of n jobs.  proofs_out: steps x n x 192 bytes. */
+int masp_hip_batch_prove_resident_steps(masp_hip_ctx* ctx, int handle, size_t steps, const uint8_t* rs, uint8_t* proofs_out,
+                                        float* elapsed_ms);
 int masp_hip_batch_free(masp_hip_ctx* ctx, int handle);
 /* Runs the G1 MSM of query `which` (0 h, 1 l, 2 a, 3 b_g1) of circuit `slot` `iters` times on resident job
  * `job` of `handle`; returns average kernel-sequence time per MSM in ms and the number of bases. */

@@ -97,6 +97,18 @@ void write_assignment(const CS& cs, uint8_t* inputs, uint8_t* aux) {
         }
     }
 }
+// jubjub::Fr is a canonical value by construction in the reference; here scalars arrive as raw bytes.  The circuits witness
+// only their low 252 bits while the native cv / rk / cm use all 256, so an unreduced scalar would give a silently
+// invalid proof: reject anything >= the Jubjub subgroup order (0x0e7db4ea6533afa906673b0101343b00a6682093ccc81082d0970e5ed6f72cb7).
+bool jubjub_scalar_canonical(const uint8_t s[32]) {
+    static const uint8_t ORDER_LE[32] = {0xb7, 0x2c, 0xf7, 0xd6, 0x5e, 0x0e, 0x97, 0xd0, 0x82, 0x10, 0xc8, 0xcc, 0x93, 0x20, 0x68, 0xa6,
+                                         0x00, 0x3b, 0x34, 0x01, 0x01, 0x3b, 0x67, 0x06, 0xa9, 0xaf, 0x33, 0x65, 0xea, 0xb4, 0x7d, 0x0e};
+    for (int i = 31; i >= 0; --i) {
+        if (s[i] < ORDER_LE[i]) return true;
+        if (s[i] > ORDER_LE[i]) return false;
+    }
+    return false;  // equal to the order
+}
 bool load_path(MerklePathW& p, const uint8_t* siblings, uint64_t position) {
     for (int i = 0; i < TREE_DEPTH; ++i) {
         Fr s;
@@ -172,6 +184,8 @@ int masp_host_spend_assignment(const uint8_t ak[32], const uint8_t nsk[32], cons
                                uint8_t nf_out[32]) {
     try {
         SpendW w;
+        if (!jubjub_scalar_canonical(nsk) || !jubjub_scalar_canonical(rcm) || !jubjub_scalar_canonical(ar) || !jubjub_scalar_canonical(rcv))
+            return MASP_HOST_E_INVALID;
         if (!asset_generator(w.vc.asset_generator, asset_identifier)) return MASP_HOST_E_INVALID;
         w.vc.value = value;
         memcpy(w.vc.randomness, rcv, 32);
@@ -207,6 +221,7 @@ int masp_host_output_assignment(const uint8_t esk[32], const uint8_t diversifier
                                 uint8_t* inputs /*6 x 32*/, uint8_t* aux /*30896 x 32*/, uint8_t cv_out[32]) {
     try {
         OutputW w;
+        if (!jubjub_scalar_canonical(esk) || !jubjub_scalar_canonical(rcm) || !jubjub_scalar_canonical(rcv)) return MASP_HOST_E_INVALID;
         if (!asset_generator(w.vc.asset_generator, asset_identifier)) return MASP_HOST_E_INVALID;
         w.vc.value = value;
         memcpy(w.vc.randomness, rcv, 32);
@@ -231,6 +246,7 @@ int masp_host_convert_assignment(const uint8_t generator[32], uint64_t value, co
                                  uint8_t* aux /*47322 x 32*/, uint8_t cv_out[32]) {
     try {
         ConvertW w;
+        if (!jubjub_scalar_canonical(rcv)) return MASP_HOST_E_INVALID;
         if (!JPoint::from_bytes(w.vc.asset_generator, generator)) return MASP_HOST_E_INVALID;
         w.vc.value = value;
         memcpy(w.vc.randomness, rcv, 32);
@@ -436,6 +452,34 @@ int masp_host_spend_leaf(const uint8_t ak[32], const uint8_t nsk[32], const uint
     JPoint pk = gd.mul(ivk);
     note_commitment(g, value, gd, pk, rcm).to_affine().u.to_bytes(cmu32);
     if (pk_d32) pk.to_bytes(pk_d32);
+    return MASP_HOST_OK;
+}
+// AllowedConversion::from(I128Sum) (masp_primitives/src/convert.rs:86-118): generator = sum_i sign(v_i) * [|v_i| as u64] G_i with
+// G_i the asset generator of identifier i, cofactor NOT cleared.  values: n x 16 bytes, little-endian two's-complement
+// i128.  `abs as u64` keeps the low 64 bits, as the reference's cast does; i128::MIN has no absolute value (the reference
+// panics "invalid conversion"): MASP_HOST_E_INVALID.
+int masp_host_allowed_conversion(size_t n, const uint8_t* identifiers /* n x 32 */, const uint8_t* values /* n x 16 */, uint8_t generator_out[32]) {
+    JPoint acc = JPoint::identity();
+    for (size_t i = 0; i < n; ++i) {
+        JPoint g;
+        if (!asset_generator(g, identifiers + 32 * i)) return MASP_HOST_E_INVALID;
+        const uint8_t* v = values + 16 * i;
+        uint64_t lo = 0, hi = 0;
+        for (int b = 0; b < 8; ++b) {
+            lo |= (uint64_t)v[b] << (8 * b);
+            hi |= (uint64_t)v[8 + b] << (8 * b);
+        }
+        const bool negative = (hi >> 63) != 0;
+        if (negative) {
+            if (hi == (1ull << 63) && lo == 0) return MASP_HOST_E_INVALID;  // i128::MIN
+            lo = ~lo + 1;                                                     // low 64 bits of -value
+        }
+        uint8_t k[32] = {0};
+        for (int b = 0; b < 8; ++b) k[b] = (uint8_t)(lo >> (8 * b));
+        JPoint t = g.mul(k);
+        acc = acc.add(negative ? t.neg() : t);
+    }
+    acc.to_bytes(generator_out);
     return MASP_HOST_OK;
 }
 // leaf of the convert tree: u of PedersenHash(NoteCommitment, repr(generator))  (convert.rs:39-64)

@@ -132,8 +132,11 @@ struct MsmWorkspace {
         // lone proof: about eight chunks per bucket, so that a bucket's partials are few enough for one gather lane
         // (otherwise every bucket of a 12-bit-window MSM becomes a "heavy" bucket with a workgroup of its own)
         if (np < 8) lanes = std::min<uint64_t>(lanes, std::max<uint64_t>(8ull * g.nb, 1u << 13));
-        const char* e = getenv("MASP_HIP_MSM_CHUNKS");
-        if (e) lanes = std::max(1, atoi(e));
+        static const int forced = [] {  // experiment knob, read once per process
+            const char* e = getenv("MASP_HIP_MSM_CHUNKS");
+            return e ? std::max(1, atoi(e)) : 0;
+        }();
+        if (forced) lanes = (uint64_t)forced;
         return (uint32_t)std::min<uint64_t>(std::min<uint64_t>(lanes, NCHUNKS), std::max<uint64_t>(ent, 1));
     }
     // room for `np` proofs of an n-point MSM with geometry g (every per-proof array is np-fold)

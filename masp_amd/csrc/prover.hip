@@ -17,6 +17,7 @@
 #include <mutex>
 #include <shared_mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "device/groth16.cuh"
@@ -124,7 +125,7 @@ struct Circuit {
     NttDomain* dom = nullptr;
 };
 
-// scratch for one batch of up to `batch_cap()` proofs of the same circuit + a stream.  Every stage is ONE launch for the
+// scratch for one batch of up to `ctx->batch_cap` proofs of the same circuit + a stream.  Every stage is ONE launch for the
 // whole batch (gridDim.y = proofs); a few slots let the stages of different batches overlap on the device.
 struct Slot {
     hipStream_t stream = nullptr;
@@ -211,11 +212,17 @@ struct ResidentBatch {
 
 // Locking: `mu` is held SHARED by masp_hip_prove_batch (any number of host threads prove concurrently, each batch on
 // its own slot = stream + scratch) and EXCLUSIVE by everything that changes circuits or uses the shared scratch.  The
-// slot pool has its own small lock (`slot_mu`); `err` is written under it.
+// slot pool has its own small lock (`slot_mu`); `err` is read and written under it.  `slots` / `slot_busy` are reserved
+// to MAX_SLOTS at creation and never reallocate, so a prover thread may keep indexing them while another one adds a slot.
 struct masp_hip_ctx {
+    static constexpr size_t MAX_SLOTS = 64;
     int device = 0;
+    // multi-device front (masp_hip_ctx_create_multi): one full context per device; this object only shards and forwards
+    std::vector<masp_hip_ctx*> children;
+    int n_slots = 4;       // MASP_HIP_SLOTS, read once at creation
+    size_t batch_cap = 64; // MASP_HIP_BATCH, read once at creation
     std::shared_mutex mu;
-    std::mutex slot_mu;
+    mutable std::mutex slot_mu;
     std::condition_variable slot_cv;
     std::vector<char> slot_busy;
     std::string err;
@@ -238,7 +245,10 @@ struct masp_hip_ctx {
 namespace {
 
 static int fail(masp_hip_ctx* ctx, int rc) {
-    if (rc == MASP_HIP_E_HIP) ctx->err = last_hip_error();
+    if (rc == MASP_HIP_E_HIP) {
+        std::lock_guard<std::mutex> g(ctx->slot_mu);
+        ctx->err = last_hip_error();
+    }
     return rc;
 }
 
@@ -260,20 +270,35 @@ static uint32_t log2_ceil(uint32_t n) {
     return k;
 }
 
-static int n_slots_default() {
+// environment knobs, read once when a context is created
+static int env_slots() {
     const char* e = getenv("MASP_HIP_SLOTS");
     int n = e ? atoi(e) : 4;
-    return std::max(1, std::min(n, 64));
+    return std::max(1, std::min(n, (int)masp_hip_ctx::MAX_SLOTS));
 }
-// proofs per batched launch sequence
-static size_t batch_cap() {
+// proofs per batched launch sequence (upper bound: a list of n same-circuit jobs is cut into ceil(n / cap) equal groups)
+static size_t env_batch_cap() {
     const char* e = getenv("MASP_HIP_BATCH");
     int n = e ? atoi(e) : 64;
     return (size_t)std::max(1, std::min(n, 256));
 }
+// [0, n) cut into ceil(n / cap) groups whose sizes differ by at most one: (first, count) pairs
+static std::vector<std::pair<size_t, size_t>> even_groups(size_t n, size_t cap) {
+    std::vector<std::pair<size_t, size_t>> out;
+    if (!n) return out;
+    const size_t g = (n + cap - 1) / cap, base = n / g, extra = n % g;
+    size_t lo = 0;
+    for (size_t i = 0; i < g; ++i) {
+        size_t cnt = base + (i < extra ? 1 : 0);
+        out.push_back({lo, cnt});
+        lo += cnt;
+    }
+    return out;
+}
 
 static int ensure_slots(masp_hip_ctx* ctx, size_t want) {
     std::lock_guard<std::mutex> g(ctx->slot_mu);
+    want = std::min(want, masp_hip_ctx::MAX_SLOTS);
     while (ctx->slots.size() < want) {
         std::unique_ptr<Slot> s(new Slot);
         int rc = s->init();
@@ -284,7 +309,7 @@ static int ensure_slots(masp_hip_ctx* ctx, size_t want) {
     for (auto& sl : ctx->slots) sl->profiling = ctx->profiling;
     return MASP_HIP_OK;
 }
-// Slot pool for concurrent provers.  try: a free slot, or a new one while fewer than n_slots_default() exist.
+// Slot pool for concurrent provers.  try: a free slot, or a new one while fewer than ctx->n_slots exist.
 // Returns MASP_HIP_OK and *si, or -1 if every slot is busy, or an error code.
 static int slot_try_acquire(masp_hip_ctx* ctx, size_t* si) {
     std::lock_guard<std::mutex> g(ctx->slot_mu);
@@ -294,7 +319,7 @@ static int slot_try_acquire(masp_hip_ctx* ctx, size_t* si) {
             *si = i;
             return MASP_HIP_OK;
         }
-    if (ctx->slots.size() >= (size_t)n_slots_default()) return -1;
+    if (ctx->slots.size() >= (size_t)ctx->n_slots) return -1;
     std::unique_ptr<Slot> s(new Slot);
     int rc = s->init();
     if (rc) return rc;
@@ -366,8 +391,15 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
     const uint32_t nv = C.n_inputs + C.n_aux;
     int rc;
     if ((rc = sl.reserve_batch(np))) return rc;
-    HIP_TRY(hipMemsetAsync(sl.flags.p, 0, sizeof(int), s));
+    // (sl.flags accumulates: the caller clears it before the first batch it will read the flag for)
     if ((rc = sl.wm.reserve((size_t)nv * np))) return rc;
+    const bool lone = np < 8;
+    if (lone) {
+        // lone-proof mode: L, A, B1 and B2 only read the assignment (already on the device when this stream gets here), so
+        // their streams fork NOW, before the range check and the SpMV are queued on the main stream
+        HIP_TRY(hipEventRecord(sl.ev_fork, s));
+        for (int i = 0; i < Slot::N_AUX; ++i) HIP_TRY(hipStreamWaitEvent(sl.aux[i], sl.ev_fork, 0));
+    }
     // range check (+ Montgomery copy used by the SpMV)
     hipLaunchKernelGGL(k_fr_to_mont, dim3((nv + 255) / 256, np), dim3(256), 0, s, d_w, w_stride, sl.wm.p, nv, sl.flags.p);
     const Fr* in[3];
@@ -390,11 +422,9 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
     MsmProfile* prof = sl.profiling ? &sl.prof : nullptr;
     const size_t m8 = C.m * 8;
     const bool share_b = C.nbq && C.b2.n == C.b1.n && C.b2.g.c == C.b1.g.c;  // B2 runs over the same scalars as B1
-    if (np < 8) {
-        // lone-proof mode: L, A, B1 and B2 only need the assignment, so they start at once on their own streams while
-        // the main stream runs SpMV -> quotient -> H; everything joins before the assembly
-        HIP_TRY(hipEventRecord(sl.ev_fork, s));
-        for (int i = 0; i < Slot::N_AUX; ++i) HIP_TRY(hipStreamWaitEvent(sl.aux[i], sl.ev_fork, 0));
+    if (lone) {
+        // the four witness MSMs run on their own streams (forked above) while the main stream runs SpMV -> quotient -> H;
+        // everything joins before the assembly
         if ((rc = msm_enqueue(sl.aux[0], C.l, sl.ws_l, (const uint32_t*)(d_w + C.n_inputs), w_stride * 8, sl.res1.p + 1, 4, np))) return rc;
         if (C.na) hipLaunchKernelGGL(k_gather_scalars, dim3((C.na + 255) / 256, np), dim3(256), 0, sl.aux[1], d_w, w_stride, C.a_var.p, C.na, sl.sa.p);
         if ((rc = msm_enqueue(sl.aux[1], C.a, sl.ws_a, (const uint32_t*)sl.sa.p, (size_t)C.na * 8, sl.res1.p + 2, 4, np))) return rc;
@@ -493,7 +523,22 @@ const char* masp_hip_strerror(int code) {
     }
 }
 
-const char* masp_hip_last_error(const masp_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : ""; }
+// The text is copied under the lock into a buffer of the calling thread: concurrent provers that fail at the same time
+// each read a consistent message, and the pointer stays valid until this thread asks again.
+const char* masp_hip_last_error(const masp_hip_ctx* ctx) {
+    static thread_local std::string copy;
+    if (!ctx) return "";
+    if (!ctx->children.empty()) {
+        for (const masp_hip_ctx* ch : ctx->children) {
+            const char* e = masp_hip_last_error(ch);
+            if (e[0]) return e;
+        }
+        return "";
+    }
+    std::lock_guard<std::mutex> g(ctx->slot_mu);
+    copy = ctx->err;
+    return copy.c_str();
+}
 
 int masp_hip_ctx_create(int device, masp_hip_ctx** out) {
     if (!out) return MASP_HIP_E_INVALID_ARG;
@@ -503,13 +548,43 @@ int masp_hip_ctx_create(int device, masp_hip_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) return MASP_HIP_E_NO_DEVICE;
     std::unique_ptr<masp_hip_ctx> ctx(new masp_hip_ctx);
     ctx->device = device;
+    ctx->n_slots = env_slots();
+    ctx->batch_cap = env_batch_cap();
+    ctx->slots.reserve(masp_hip_ctx::MAX_SLOTS);      // never reallocates: see the locking note on masp_hip_ctx
+    ctx->slot_busy.reserve(masp_hip_ctx::MAX_SLOTS);
     if (hipStreamCreateWithFlags(&ctx->main_stream, hipStreamNonBlocking) != hipSuccess) return MASP_HIP_E_NO_DEVICE;
     *out = ctx.release();
     return MASP_HIP_OK;
 }
 
+int masp_hip_ctx_create_multi(const int* devices, int n_devices, masp_hip_ctx** out) {
+    if (!out || !devices || n_devices <= 0 || n_devices > 64) return MASP_HIP_E_INVALID_ARG;
+    *out = nullptr;
+    std::unique_ptr<masp_hip_ctx> front(new masp_hip_ctx);
+    front->device = devices[0];
+    front->batch_cap = env_batch_cap();
+    for (int i = 0; i < n_devices; ++i) {
+        masp_hip_ctx* ch = nullptr;
+        int rc = masp_hip_ctx_create(devices[i], &ch);
+        if (rc) {
+            for (masp_hip_ctx* c : front->children) masp_hip_ctx_destroy(c);
+            return rc;
+        }
+        front->children.push_back(ch);
+    }
+    *out = front.release();
+    return MASP_HIP_OK;
+}
+
+int masp_hip_ctx_device_count(const masp_hip_ctx* ctx) { return !ctx ? 0 : ctx->children.empty() ? 1 : (int)ctx->children.size(); }
+
 void masp_hip_ctx_destroy(masp_hip_ctx* ctx) {
     if (!ctx) return;
+    if (!ctx->children.empty()) {
+        for (masp_hip_ctx* c : ctx->children) masp_hip_ctx_destroy(c);
+        delete ctx;
+        return;
+    }
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
     ctx->batches.clear();
@@ -522,6 +597,16 @@ void masp_hip_ctx_destroy(masp_hip_ctx* ctx) {
 
 int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* params, size_t params_len, const masp_hip_r1cs* cs) {
     if (!ctx || !params || !cs || slot >= MASP_HIP_MAX_CIRCUITS || cs->n_inputs == 0) return MASP_HIP_E_INVALID_ARG;
+    if (!ctx->children.empty()) {  // the CRS is replicated: every device builds its own window tables, side by side
+        std::vector<int> rcs(ctx->children.size(), MASP_HIP_OK);
+        std::vector<std::thread> th;
+        for (size_t d = 0; d < ctx->children.size(); ++d)
+            th.emplace_back([&, d] { rcs[d] = masp_hip_circuit_load(ctx->children[d], slot, params, params_len, cs); });
+        for (auto& t : th) t.join();
+        for (int rc : rcs)
+            if (rc) return rc;
+        return MASP_HIP_OK;
+    }
     std::unique_lock<std::shared_mutex> lock(ctx->mu);
     hipSetDevice(ctx->device);
     hipStream_t s = ctx->main_stream;
@@ -643,8 +728,49 @@ int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* param
     return MASP_HIP_OK;
 }
 
+// Multi-device front: the jobs of every circuit are cut into blocks of up to batch_cap proofs and the blocks are dealt
+// to the devices round-robin (so every device gets full batches of every circuit in the list); one host thread per
+// device runs the ordinary single-device call on its share.  Proofs are independent: there is no data-path exchange
+// between devices, the results are copied back to the jobs' own positions.
+static int prove_batch_multi(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, uint8_t* proofs_out) {
+    const size_t nd = ctx->children.size();
+    std::vector<std::vector<size_t>> share(nd);
+    {
+        std::map<std::pair<uint32_t, bool>, std::vector<size_t>> by_kind;
+        for (size_t j = 0; j < n; ++j) by_kind[{jobs[j].circuit, jobs[j].a != nullptr}].push_back(j);
+        size_t next = 0;
+        for (auto& kv : by_kind) {
+            // at least one block per device when the list is long enough to give every device a useful batch
+            size_t cap = std::min(ctx->batch_cap, std::max<size_t>((kv.second.size() + nd - 1) / nd, 8));
+            for (auto& g : even_groups(kv.second.size(), cap)) {
+                auto& dst = share[next++ % nd];
+                dst.insert(dst.end(), kv.second.begin() + g.first, kv.second.begin() + g.first + g.second);
+            }
+        }
+    }
+    std::vector<int> rcs(nd, MASP_HIP_OK);
+    std::vector<std::vector<uint8_t>> outs(nd);
+    std::vector<std::thread> th;
+    for (size_t d = 0; d < nd; ++d) {
+        if (share[d].empty()) continue;
+        th.emplace_back([&, d] {
+            std::vector<masp_hip_job> mine(share[d].size());
+            for (size_t k = 0; k < mine.size(); ++k) mine[k] = jobs[share[d][k]];
+            outs[d].resize(192 * mine.size());
+            rcs[d] = masp_hip_prove_batch(ctx->children[d], mine.size(), mine.data(), outs[d].data());
+        });
+    }
+    for (auto& t : th) t.join();
+    for (int rc : rcs)
+        if (rc) return rc;
+    for (size_t d = 0; d < nd; ++d)
+        for (size_t k = 0; k < share[d].size(); ++k) memcpy(proofs_out + 192 * share[d][k], outs[d].data() + 192 * k, 192);
+    return MASP_HIP_OK;
+}
+
 int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, uint8_t* proofs_out) {
     if (!ctx || (n && (!jobs || !proofs_out))) return MASP_HIP_E_INVALID_ARG;
+    if (!ctx->children.empty()) return prove_batch_multi(ctx, n, jobs, proofs_out);
     std::shared_lock<std::shared_mutex> lock(ctx->mu);  // concurrent with other provers, exclusive with circuit loads
     hipSetDevice(ctx->device);
     for (size_t j = 0; j < n; ++j) {
@@ -655,19 +781,19 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
         if (!rs_in_range(J.r) || !rs_in_range(J.s)) return MASP_HIP_E_SCALAR_RANGE;
     }
     // jobs are bucketed by (circuit, a/b/c mode) — whatever their order in the list — and every bucket is cut into
-    // batches of up to batch_cap() proofs; results go back to the jobs' own positions
+    // equal batches of at most batch_cap proofs (256 Spends with a cap of 96: 86 + 85 + 85, not 96 + 96 + 64); results go
+    // back to the jobs' own positions
     struct Group {
         std::vector<size_t> idx;
     };
     std::vector<Group> groups;
-    const size_t cap = batch_cap();
     {
         std::map<std::pair<uint32_t, bool>, std::vector<size_t>> by_kind;
         for (size_t j = 0; j < n; ++j) by_kind[{jobs[j].circuit, jobs[j].a != nullptr}].push_back(j);
         for (auto& kv : by_kind)
-            for (size_t o = 0; o < kv.second.size(); o += cap) {
+            for (auto& eg : even_groups(kv.second.size(), ctx->batch_cap)) {
                 Group g;
-                g.idx.assign(kv.second.begin() + o, kv.second.begin() + std::min(kv.second.size(), o + cap));
+                g.idx.assign(kv.second.begin() + eg.first, kv.second.begin() + eg.first + eg.second);
                 groups.push_back(std::move(g));
             }
     }
@@ -762,7 +888,11 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
             const Fr* abc[3] = {nullptr, nullptr, nullptr};
             if (has_abc)
                 for (int i = 0; i < 3; ++i) abc[i] = sl.abc.p + (size_t)C.nrows * np * i;
-            if ((rc = enqueue_proofs(sl, C, (uint32_t)np, sl.w.p, nv, abc, sl.rs.p, sl.proof.p))) {
+            if (hipMemsetAsync(sl.flags.p, 0, sizeof(int), sl.stream) != hipSuccess) {
+                last_hip_error() = "memset failed";
+                result = fail_shared(ctx, MASP_HIP_E_HIP);
+                ok = false;
+            } else if ((rc = enqueue_proofs(sl, C, (uint32_t)np, sl.w.p, nv, abc, sl.rs.p, sl.proof.p))) {
                 result = fail_shared(ctx, rc);
                 ok = false;
             }
@@ -843,15 +973,53 @@ static int msm_block(masp_hip_ctx* ctx, const uint8_t* bases, const uint8_t* sca
 }
 extern "C" {
 
+// (a multi-device context runs the building blocks and the measurement hooks on its first device)
+#define FIRST_DEVICE(ctx) ((ctx) && !(ctx)->children.empty() ? (ctx)->children[0] : (ctx))
+
 int masp_hip_msm_g1(masp_hip_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[96]) {
+    if (!ctx) return MASP_HIP_E_INVALID_ARG;
+    ctx = FIRST_DEVICE(ctx);
     return msm_block<FpOps, 96>(ctx, bases, scalars, n, out, ctx->tmp_g1);
 }
 int masp_hip_msm_g2(masp_hip_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[192]) {
+    if (!ctx) return MASP_HIP_E_INVALID_ARG;
+    ctx = FIRST_DEVICE(ctx);
     return msm_block<Fp2Ops, 192>(ctx, bases, scalars, n, out, ctx->tmp_g2);
+}
+
+// np MSMs over ONE base set (how a batch of proofs uses the engine: gridDim.y = np, one launch per stage):
+// scalars np x n x 32 B, out np x 96 B uncompressed.  window_bits 0 = the engine's own choice for n.
+int masp_hip_msm_g1_multi(masp_hip_ctx* ctx, const uint8_t* bases, size_t n, const uint8_t* scalars, size_t np, int window_bits, uint8_t* out) {
+    if (!ctx || !out || !np || np > 256 || !n || !bases || !scalars || n > (1u << 22) || window_bits < 0 || window_bits == 1 || window_bits > 16)
+        return MASP_HIP_E_INVALID_ARG;
+    ctx = FIRST_DEVICE(ctx);
+    std::unique_lock<std::shared_mutex> lock(ctx->mu);
+    hipSetDevice(ctx->device);
+    hipStream_t s = ctx->main_stream;
+    for (size_t i = 0; i < n * np; ++i)
+        if (!rs_in_range(scalars + 32 * i)) return MASP_HIP_E_SCALAR_RANGE;
+    BasesG1 B;
+    MsmWorkspace<FpOps> ws;
+    DevBuf<G1Xyzz> res;
+    DevBuf<uint8_t> d_out;
+    int rc;
+    if ((rc = B.load_host(bases, (uint32_t)n, s, 0xffffffffu, window_bits))) return fail(ctx, rc);
+    if (B.import_status & (PT_BAD_FLAGS | PT_NOT_CANONICAL)) return MASP_HIP_E_PARAMS_FORMAT;
+    if ((rc = ctx->tmp_scalars.upload((const Fr*)scalars, n * np, s)) || (rc = res.reserve(np)) || (rc = d_out.reserve(96 * np))) return fail(ctx, rc);
+    if ((rc = msm_enqueue(s, B, ws, (const uint32_t*)ctx->tmp_scalars.p, n * 8, res.p, 1, (uint32_t)np))) return fail(ctx, rc);
+    for (size_t p = 0; p < np; ++p) hipLaunchKernelGGL(k_g1_export, dim3(1), dim3(1), 0, s, res.p + p, d_out.p + 96 * p);
+    std::vector<uint8_t> tmp(96 * np);
+    if (hipMemcpyAsync(tmp.data(), d_out.p, tmp.size(), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        last_hip_error() = std::string("msm failed: ") + hipGetErrorString(hipGetLastError());
+        return fail(ctx, MASP_HIP_E_HIP);
+    }
+    memcpy(out, tmp.data(), tmp.size());
+    return MASP_HIP_OK;
 }
 
 int masp_hip_quotient_h(masp_hip_ctx* ctx, const uint8_t* a, const uint8_t* b, const uint8_t* c, size_t nrows, uint32_t logm, uint8_t* h_out) {
     if (!ctx || !a || !b || !c || !h_out || logm == 0 || logm > 20 || nrows > ((size_t)1 << logm)) return MASP_HIP_E_INVALID_ARG;
+    ctx = FIRST_DEVICE(ctx);
     std::unique_lock<std::shared_mutex> lock(ctx->mu);
     hipSetDevice(ctx->device);
     int rc;
@@ -878,6 +1046,7 @@ int masp_hip_quotient_h(masp_hip_ctx* ctx, const uint8_t* a, const uint8_t* b, c
 
 int masp_hip_ntt(masp_hip_ctx* ctx, uint8_t* data, uint32_t logm, int inverse) {
     if (!ctx || !data || logm == 0 || logm > 20) return MASP_HIP_E_INVALID_ARG;
+    ctx = FIRST_DEVICE(ctx);
     std::unique_lock<std::shared_mutex> lock(ctx->mu);
     hipSetDevice(ctx->device);
     int rc;
@@ -918,6 +1087,7 @@ size_t masp_hip_parameters_max_size(const masp_hip_r1cs* cs) {
 int masp_hip_generate_parameters(masp_hip_ctx* ctx, const masp_hip_r1cs* cs, const uint8_t toxic[160], uint8_t* out, size_t cap,
                                  size_t* out_len) {
     if (!ctx || !cs || !toxic || !out_len || cs->n_inputs == 0) return MASP_HIP_E_INVALID_ARG;
+    ctx = FIRST_DEVICE(ctx);
     std::unique_lock<std::shared_mutex> lock(ctx->mu);
     hipSetDevice(ctx->device);
     hipStream_t s = ctx->main_stream;
@@ -1082,6 +1252,7 @@ int masp_hip_generate_parameters(masp_hip_ctx* ctx, const masp_hip_r1cs* cs, con
 // ---- measurement hooks ----------------------------------------------------------------------------
 int masp_hip_batch_upload(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs) {
     if (!ctx || !n || !jobs) return -MASP_HIP_E_INVALID_ARG;
+    ctx = FIRST_DEVICE(ctx);
     std::unique_lock<std::shared_mutex> lock(ctx->mu);
     hipSetDevice(ctx->device);
     std::unique_ptr<ResidentBatch> B(new ResidentBatch);
@@ -1121,6 +1292,7 @@ int masp_hip_batch_upload(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs)
 }
 
 int masp_hip_batch_free(masp_hip_ctx* ctx, int handle) {
+    ctx = FIRST_DEVICE(ctx);
     if (!ctx || handle < 0 || (size_t)handle >= ctx->batches.size()) return MASP_HIP_E_INVALID_ARG;
     std::unique_lock<std::shared_mutex> lock(ctx->mu);
     hipSetDevice(ctx->device);
@@ -1128,52 +1300,72 @@ int masp_hip_batch_free(masp_hip_ctx* ctx, int handle) {
     return MASP_HIP_OK;
 }
 
-int masp_hip_batch_prove_resident(masp_hip_ctx* ctx, int handle, uint8_t* proofs_out, float* elapsed_ms) {
-    if (!ctx || handle < 0 || (size_t)handle >= ctx->batches.size() || !ctx->batches[handle] || !proofs_out) return MASP_HIP_E_INVALID_ARG;
+// Proves every resident job of `handle` `steps` times (step k with the blinding scalars rs[k][job] = r | s, 64 bytes per job,
+// or with the uploaded ones when rs is NULL): the whole launch sequence of all steps is enqueued on the slots' streams
+// without any host synchronisation in between.  proofs_out: steps x n x 192 bytes, job order inside every step.
+int masp_hip_batch_prove_resident_steps(masp_hip_ctx* ctx, int handle, size_t steps, const uint8_t* rs, uint8_t* proofs_out, float* elapsed_ms) {
+    ctx = FIRST_DEVICE(ctx);
+    if (!ctx || handle < 0 || (size_t)handle >= ctx->batches.size() || !ctx->batches[handle] || !proofs_out || !steps) return MASP_HIP_E_INVALID_ARG;
     std::unique_lock<std::shared_mutex> lock(ctx->mu);
     hipSetDevice(ctx->device);
     ResidentBatch& B = *ctx->batches[handle];
+    if (rs)
+        for (size_t i = 0; i < 2 * steps * B.n; ++i)
+            if (!rs_in_range(rs + 32 * i)) return MASP_HIP_E_SCALAR_RANGE;
     // groups of consecutive same-circuit jobs (their assignments are contiguous: stride = n_vars)
     struct Group {
         size_t first, count;
     };
     std::vector<Group> groups;
-    const size_t cap = batch_cap();
     for (size_t j = 0; j < B.n;) {
         size_t k = j + 1;
-        while (k < B.n && k - j < cap && B.circuit[k] == B.circuit[j]) ++k;
-        groups.push_back({j, k - j});
+        while (k < B.n && B.circuit[k] == B.circuit[j]) ++k;
+        for (auto& eg : even_groups(k - j, ctx->batch_cap)) groups.push_back({j + eg.first, eg.second});
         j = k;
     }
-    size_t ns = std::min<size_t>(groups.size(), n_slots_default());
+    size_t ns = std::min<size_t>(groups.size() * steps, (size_t)ctx->n_slots);
     int rc;
     if ((rc = ensure_slots(ctx, ns))) return fail(ctx, rc);
     DevBuf<uint8_t> d_proofs;
-    if ((rc = d_proofs.reserve(192 * B.n))) return fail(ctx, rc);
+    DevBuf<uint32_t> d_rs;
+    if ((rc = d_proofs.reserve(192 * B.n * steps))) return fail(ctx, rc);
+    hipStream_t ms = ctx->main_stream;
+    if (rs) {  // step-major, STORAGE order of the jobs inside a step
+        std::vector<uint8_t> tmp(64 * B.n * steps);
+        for (size_t st = 0; st < steps; ++st)
+            for (size_t k = 0; k < B.n; ++k) memcpy(&tmp[64 * (st * B.n + k)], rs + 64 * (st * B.n + B.order[k]), 64);
+        if ((rc = d_rs.reserve(16 * B.n * steps))) return fail(ctx, rc);
+        HIP_TRY(hipMemcpyAsync(d_rs.p, tmp.data(), tmp.size(), hipMemcpyHostToDevice, ms));
+        HIP_TRY(hipStreamSynchronize(ms));
+    }
     hipEvent_t ev_start, ev_stop;
     HIP_TRY(hipEventCreate(&ev_start));
     HIP_TRY(hipEventCreate(&ev_stop));
-    hipStream_t ms = ctx->main_stream;
+    for (size_t si = 0; si < ns; ++si) HIP_TRY(hipMemsetAsync(ctx->slots[si]->flags.p, 0, sizeof(int), ms));
     HIP_TRY(hipEventRecord(ev_start, ms));
     for (size_t si = 0; si < ns; ++si) HIP_TRY(hipStreamWaitEvent(ctx->slots[si]->stream, ev_start, 0));
     const Fr* none[3] = {nullptr, nullptr, nullptr};
-    for (size_t gi = 0; gi < groups.size(); ++gi) {
-        const Group& G = groups[gi];
-        Slot& sl = *ctx->slots[gi % ns];
-        Circuit& C = *ctx->circ[B.circuit[G.first]];
-        if ((rc = enqueue_proofs(sl, C, (uint32_t)G.count, B.w.p + B.w_off[G.first], (size_t)C.n_inputs + C.n_aux, none, B.rs.p + 16 * G.first,
-                                 d_proofs.p + 192 * G.first)))
-            return fail(ctx, rc);
-    }
+    size_t turn = 0;
+    for (size_t st = 0; st < steps; ++st)
+        for (size_t gi = 0; gi < groups.size(); ++gi, ++turn) {
+            const Group& G = groups[gi];
+            Slot& sl = *ctx->slots[turn % ns];
+            Circuit& C = *ctx->circ[B.circuit[G.first]];
+            const uint32_t* grs = rs ? d_rs.p + 16 * (st * B.n + G.first) : B.rs.p + 16 * G.first;
+            if ((rc = enqueue_proofs(sl, C, (uint32_t)G.count, B.w.p + B.w_off[G.first], (size_t)C.n_inputs + C.n_aux, none, grs,
+                                     d_proofs.p + 192 * (st * B.n + G.first))))
+                return fail(ctx, rc);
+        }
     for (size_t si = 0; si < ns; ++si) {
         HIP_TRY(hipEventRecord(ctx->slots[si]->done, ctx->slots[si]->stream));
         HIP_TRY(hipStreamWaitEvent(ms, ctx->slots[si]->done, 0));
     }
     HIP_TRY(hipEventRecord(ev_stop, ms));
-    std::vector<uint8_t> stored(192 * B.n);
-    HIP_TRY(hipMemcpyAsync(stored.data(), d_proofs.p, 192 * B.n, hipMemcpyDeviceToHost, ms));
+    std::vector<uint8_t> stored(192 * B.n * steps);
+    HIP_TRY(hipMemcpyAsync(stored.data(), d_proofs.p, stored.size(), hipMemcpyDeviceToHost, ms));
     HIP_TRY(hipStreamSynchronize(ms));
-    for (size_t k = 0; k < B.n; ++k) memcpy(proofs_out + 192 * B.order[k], stored.data() + 192 * k, 192);
+    for (size_t st = 0; st < steps; ++st)
+        for (size_t k = 0; k < B.n; ++k) memcpy(proofs_out + 192 * (st * B.n + B.order[k]), stored.data() + 192 * (st * B.n + k), 192);
     if (elapsed_ms) HIP_TRY(hipEventElapsedTime(elapsed_ms, ev_start, ev_stop));
     hipEventDestroy(ev_start);
     hipEventDestroy(ev_stop);
@@ -1186,8 +1378,13 @@ int masp_hip_batch_prove_resident(masp_hip_ctx* ctx, int handle, uint8_t* proofs
     return flags ? MASP_HIP_E_SCALAR_RANGE : MASP_HIP_OK;
 }
 
+int masp_hip_batch_prove_resident(masp_hip_ctx* ctx, int handle, uint8_t* proofs_out, float* elapsed_ms) {
+    return masp_hip_batch_prove_resident_steps(ctx, handle, 1, nullptr, proofs_out, elapsed_ms);
+}
+
 int masp_hip_profile_enable(masp_hip_ctx* ctx, int on) {
     if (!ctx) return MASP_HIP_E_INVALID_ARG;
+    ctx = FIRST_DEVICE(ctx);
     std::unique_lock<std::shared_mutex> lock(ctx->mu);
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
@@ -1201,6 +1398,7 @@ int masp_hip_profile_enable(masp_hip_ctx* ctx, int on) {
 
 int masp_hip_profile_read(masp_hip_ctx* ctx, double* total_ms, uint64_t* launches, uint64_t* alg_bytes) {
     if (!ctx) return MASP_HIP_E_INVALID_ARG;
+    ctx = FIRST_DEVICE(ctx);
     std::unique_lock<std::shared_mutex> lock(ctx->mu);
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
@@ -1222,7 +1420,7 @@ void* masp_hip_host_alloc(masp_hip_ctx* ctx, size_t bytes) {
     if (!ctx || !bytes) return nullptr;
     hipSetDevice(ctx->device);
     void* p = nullptr;
-    if (hipHostMalloc(&p, bytes) != hipSuccess) {
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {  // portable: every device of a multi-device context may read it
         (void)hipGetLastError();
         return nullptr;
     }
@@ -1236,11 +1434,17 @@ void masp_hip_host_free(masp_hip_ctx* ctx, void* ptr) {
 
 int masp_hip_sync(masp_hip_ctx* ctx) {
     if (!ctx) return MASP_HIP_E_INVALID_ARG;
+    if (!ctx->children.empty()) {
+        for (masp_hip_ctx* c : ctx->children)
+            if (int rc = masp_hip_sync(c)) return rc;
+        return MASP_HIP_OK;
+    }
     hipSetDevice(ctx->device);
     return hipDeviceSynchronize() == hipSuccess ? MASP_HIP_OK : MASP_HIP_E_HIP;
 }
 
 int masp_hip_bench_msm(masp_hip_ctx* ctx, int handle, size_t job, int which, int iters, float* avg_ms, uint32_t* n_bases) {
+    ctx = FIRST_DEVICE(ctx);
     if (!ctx || handle < 0 || (size_t)handle >= ctx->batches.size() || !ctx->batches[handle] || which < 0 || which > 3 || iters <= 0 || !avg_ms)
         return MASP_HIP_E_INVALID_ARG;
     std::unique_lock<std::shared_mutex> lock(ctx->mu);

@@ -45,6 +45,8 @@ def load_library():
     L = C.CDLL(path)
     vp, sz, u32 = C.c_void_p, C.c_size_t, C.c_uint32
     L.masp_hip_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.masp_hip_ctx_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.masp_hip_ctx_device_count.argtypes = [vp]
     L.masp_hip_ctx_destroy.argtypes = [vp]
     L.masp_hip_ctx_destroy.restype = None
     L.masp_hip_strerror.restype = C.c_char_p
@@ -58,10 +60,12 @@ def load_library():
     L.masp_hip_parameters_max_size.restype = sz
     L.masp_hip_msm_g1.argtypes = [vp, vp, vp, sz, vp]
     L.masp_hip_msm_g2.argtypes = [vp, vp, vp, sz, vp]
+    L.masp_hip_msm_g1_multi.argtypes = [vp, vp, sz, vp, sz, C.c_int, vp]
     L.masp_hip_quotient_h.argtypes = [vp, vp, vp, vp, sz, u32, vp]
     L.masp_hip_ntt.argtypes = [vp, vp, u32, C.c_int]
     L.masp_hip_batch_upload.argtypes = [vp, sz, vp]
     L.masp_hip_batch_prove_resident.argtypes = [vp, C.c_int, vp, C.POINTER(C.c_float)]
+    L.masp_hip_batch_prove_resident_steps.argtypes = [vp, C.c_int, sz, vp, vp, C.POINTER(C.c_float)]
     L.masp_hip_batch_free.argtypes = [vp, C.c_int]
     L.masp_hip_bench_msm.argtypes = [vp, C.c_int, sz, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(u32)]
     L.masp_hip_profile_enable.argtypes = [vp, C.c_int]
@@ -99,12 +103,18 @@ def _scalar32(x):
 
 
 class Context:
-    """One GPU.  Thread-safe (calls serialise inside the library)."""
+    """One GPU (`device` an int) or several GPUs of one node behind one prover (`device` a list of device indices:
+    masp_hip_ctx_create_multi — prove_batch then deals its jobs to the devices).  Thread-safe: prove / prove_batch are
+    re-entrant, everything else serialises inside the library."""
 
     def __init__(self, device=0):
         self._L = load_library()
         h = C.c_void_p()
-        rc = self._L.masp_hip_ctx_create(int(device), C.byref(h))
+        if isinstance(device, (list, tuple)):
+            arr = (C.c_int * len(device))(*[int(d) for d in device])
+            rc = self._L.masp_hip_ctx_create_multi(arr, len(device), C.byref(h))
+        else:
+            rc = self._L.masp_hip_ctx_create(int(device), C.byref(h))
         if rc:
             raise MaspHipError(rc)
         self._h = h
@@ -168,8 +178,9 @@ class Context:
         """-> 192-byte proof (A | B | C compressed)."""
         return self.prove_batch([(slot, inputs, aux, r, s, abc)])[0]
 
-    def prove_batch(self, jobs):
-        """jobs: iterable of (slot, inputs, aux, r, s[, (a,b,c)]) -> list of 192-byte proofs, job order."""
+    def marshal_jobs(self, jobs):
+        """jobs: iterable of (slot, inputs, aux, r, s[, (a,b,c)]) -> (masp_hip_job array, n, keep-alive list): the argument
+        of masp_hip_prove_batch, built once when the same list is proved repeatedly or timed."""
         jobs = list(jobs)
         arr = (JobStruct * len(jobs))()
         keep = []
@@ -178,9 +189,20 @@ class Context:
             abc = job[5] if len(job) > 5 else None
             arr[i], k = self._job(slot, inputs, aux, r, s, abc)
             keep.append(k)
-        out = np.zeros((len(jobs), 192), dtype=np.uint8)
-        self._check(self._L.masp_hip_prove_batch(self._h, len(jobs), arr, _p(out)))
-        return [out[i].tobytes() for i in range(len(jobs))]
+        return arr, len(jobs), keep
+
+    def prove_marshalled(self, arr, n, out=None):
+        """One masp_hip_prove_batch call -> u8[n,192]"""
+        if out is None:
+            out = np.zeros((n, 192), dtype=np.uint8)
+        self._check(self._L.masp_hip_prove_batch(self._h, n, arr, _p(out)))
+        return out
+
+    def prove_batch(self, jobs):
+        """jobs: iterable of (slot, inputs, aux, r, s[, (a,b,c)]) -> list of 192-byte proofs, job order."""
+        arr, n, keep = self.marshal_jobs(jobs)
+        out = self.prove_marshalled(arr, n)
+        return [out[i].tobytes() for i in range(n)]
 
     def generate_parameters(self, cs, toxic):
         """toxic: (tau, alpha, beta, gamma, delta) ints -> Parameters bytes (bellman wire format), np.uint8."""
@@ -203,6 +225,20 @@ class Context:
         out = np.zeros(192, dtype=np.uint8)
         self._check(self._L.masp_hip_msm_g2(self._h, _p(bases), _p(scalars), scalars.shape[0], _p(out)))
         return out.tobytes()
+
+    def msm_g1_multi(self, bases, scalars, window_bits=0):
+        """bases u8[n,96]; scalars u8[np,n,32] -> list of np 96-byte results (one batched launch sequence)."""
+        bases = _u8(bases, 96)
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint8)
+        npf, n = scalars.shape[0], scalars.shape[1]
+        assert scalars.shape == (npf, n, 32) and bases.shape[0] == n
+        out = np.zeros((npf, 96), dtype=np.uint8)
+        self._check(self._L.masp_hip_msm_g1_multi(self._h, _p(bases), n, _p(scalars), npf, int(window_bits), _p(out)))
+        return [out[i].tobytes() for i in range(npf)]
+
+    @property
+    def device_count(self):
+        return self._L.masp_hip_ctx_device_count(self._h)
 
     def quotient_h(self, a, b, c, logm):
         a, b, c = _u8(a, 32), _u8(b, 32), _u8(c, 32)
@@ -233,6 +269,17 @@ class Context:
         ms = C.c_float(0)
         self._check(self._L.masp_hip_batch_prove_resident(self._h, handle, _p(out), C.byref(ms)))
         return [out[i].tobytes() for i in range(n)], ms.value
+
+    def batch_prove_resident_steps(self, handle, n, steps, rs=None):
+        """Proves the n resident jobs `steps` times; rs: u8[steps, n, 64] (r | s per job and step) or None.
+        -> (u8[steps, n, 192], HIP-event milliseconds)"""
+        out = np.zeros((steps, n, 192), dtype=np.uint8)
+        ms = C.c_float(0)
+        if rs is not None:
+            rs = np.ascontiguousarray(rs, dtype=np.uint8)
+            assert rs.shape == (steps, n, 64)
+        self._check(self._L.masp_hip_batch_prove_resident_steps(self._h, handle, steps, _p(rs), _p(out), C.byref(ms)))
+        return out, ms.value
 
     def batch_free(self, handle):
         self._check(self._L.masp_hip_batch_free(self._h, handle))

@@ -58,6 +58,7 @@ def load_library():
         L.masp_host_point_uv.argtypes = [cp, cp]
         L.masp_host_jubjub_add.argtypes = [cp, cp, C.c_int, cp]
         L.masp_host_spend_leaf.argtypes = [cp, cp, cp, cp, cp, u64, cp, cp]
+        L.masp_host_allowed_conversion.argtypes = [C.c_size_t, cp, cp, cp]
         _lib = L
     return _lib
 
@@ -307,6 +308,46 @@ def convert_cmu(generator):
     if load_library().masp_host_convert_cmu(_b(generator), out):
         raise ValueError("invalid point")
     return out.raw
+
+
+class AllowedConversion:
+    """= masp_primitives::convert::AllowedConversion (/root/reference/masp_primitives/src/convert.rs:22-84,86-118).
+
+    `AllowedConversion(assets)` mirrors `From<I128Sum>`: assets = iterable of (asset identifier[32], signed 128-bit
+    value) — the components of the reference's I128Sum; generator = sum_i sign(v_i) [|v_i| as u64] asset_generator_i,
+    cofactor not cleared.  i128::MIN raises ValueError (the reference panics "invalid conversion")."""
+
+    def __init__(self, assets):
+        merged = {}
+        for ident, value in (assets.items() if isinstance(assets, dict) else assets):
+            ident = _b(ident)
+            merged[ident] = merged.get(ident, 0) + int(value)          # ValueSum addition merges equal asset types
+        self.assets = {k: v for k, v in sorted(merged.items()) if v != 0}
+        for v in self.assets.values():
+            if not -(1 << 127) <= v < (1 << 127):
+                raise OverflowError("value does not fit an i128")
+        ids = b"".join(self.assets.keys())
+        vals = b"".join(v.to_bytes(16, "little", signed=True) for v in self.assets.values())
+        out = C.create_string_buffer(32)
+        if load_library().masp_host_allowed_conversion(len(self.assets), ids, vals, out):
+            raise ValueError("invalid conversion")
+        self.generator = out.raw
+
+    def cmu(self):
+        """u-coordinate of PedersenHash(NoteCommitment, repr(generator)) (convert.rs:39-64), 32 bytes LE."""
+        return convert_cmu(self.generator)
+
+    commitment = cmu      # Node::from_scalar(self.cmu()) (convert.rs:80-84): the leaf of the conversion tree
+
+    def value_commitment(self, value, randomness):
+        """-> the commitment point cv = [value]([8]generator) + [randomness]G_vcr, 32 bytes (convert.rs:70-77, sapling.rs:204-209)."""
+        h = jubjub_mul(jubjub_mul(self.generator, 8), value)
+        g_rcv = point_bytes(*generator_uv(3))
+        return jubjub_add(h, jubjub_mul(g_rcv, randomness))
+
+    @staticmethod
+    def uncommitted():
+        return 1          # bls12_381::Scalar::ONE (convert.rs:32-36)
 
 
 def spend_leaf(ak, nsk, diversifier, rcm, asset_identifier, value):

@@ -43,13 +43,21 @@ class SaplingProvingContext:
         self.bsk = 0                                  # jubjub::Fr::zero()
         self.cv_sum = H.JUBJUB_IDENTITY               # jubjub::ExtendedPoint::identity()
 
+    # The reference adds rcv to bsk BEFORE anything can fail and cv to cv_sum only after the proof verified
+    # (sapling/prover.rs:69-75 vs :154): after an Err(()) the context holds the new bsk and the old cv_sum.
+    def _bsk_add(self, rcv, subtract=False):
+        self.bsk = (self.bsk - _int(rcv)) % RJ if subtract else (self.bsk + _int(rcv)) % RJ     # "Outputs subtract from the total."
+
+    def _cv_add(self, cv, subtract=False):
+        self.cv_sum = H.jubjub_add(self.cv_sum, cv, subtract=subtract)
+
     def _spend_like(self, rcv, cv):
-        self.bsk = (self.bsk + _int(rcv)) % RJ
-        self.cv_sum = H.jubjub_add(self.cv_sum, cv)
+        self._bsk_add(rcv)
+        self._cv_add(cv)
 
     def _output(self, rcv, cv):
-        self.bsk = (self.bsk - _int(rcv)) % RJ        # "Outputs subtract from the total."
-        self.cv_sum = H.jubjub_add(self.cv_sum, cv, subtract=True)
+        self._bsk_add(rcv, subtract=True)
+        self._cv_add(cv, subtract=True)
 
     def binding_sig(self, assets_and_values, sighash, rng=None):
         """= SaplingProvingContext::binding_sig (sapling/prover.rs:279-326).  assets_and_values: iterable of
@@ -175,10 +183,13 @@ class LocalTxProver:
         return dict(slot=OUTPUT, inputs=inputs, aux=aux, cv=cv, rcv=rcv, _pinned=buf)
 
     def prepare_convert(self, allowed_conversion, value, anchor, merkle_path, rcv):
+        """allowed_conversion: a host.AllowedConversion (masp_primitives/src/convert.rs:22-29), or just its generator point
+        (32 bytes) — the only part of it the circuit sees."""
         siblings, position = merkle_path
+        generator = allowed_conversion.generator if isinstance(allowed_conversion, H.AllowedConversion) else allowed_conversion
         buf = self._aux_take(CONVERT)
         try:
-            inputs, aux, cv = H.convert_assignment(allowed_conversion, value, anchor, siblings, position, rcv, aux_out=buf)
+            inputs, aux, cv = H.convert_assignment(generator, value, anchor, siblings, position, rcv, aux_out=buf)
         except H.HostError as e:
             self._aux_give([dict(slot=CONVERT, _pinned=buf)])
             raise ProvingError(str(e)) from None
@@ -224,36 +235,49 @@ class LocalTxProver:
                 return None
             return prep[kind](**kw)
 
+        failed = None
+        done_lock = threading.Lock()
         with ThreadPoolExecutor(max_workers=threads) as synth, ThreadPoolExecutor(max_workers=in_flight) as gpu:
             futures = [synth.submit(synthesize, kind, kw) for kind, kw in descriptions]
 
             def run_chunk(lo):
                 hi = min(n, lo + chunk)
                 jobs = [f.result() for f in futures[lo:hi]]
-                proofs = self.prove_prepared(jobs, rs[lo:hi])
-                if self._self_verify:
-                    for kind, vk in (("spend", self.spend_vk), ("convert", self.convert_vk)):
-                        sel = [i for i in range(hi - lo) if descriptions[lo + i][0] == kind]
-                        if not sel:
-                            continue
-                        pis = [public_input(kind, descriptions[lo + i][1], jobs[i]) for i in sel]
-                        if not vk.verify_batch([proofs[i] for i in sel], pis):
-                            bad = [lo + i for i, pi in zip(sel, pis) if not vk.verify(proofs[i], pi)]
-                            raise ProvingError("proof(s) %s failed self-verification" % bad)
-                self._aux_give(jobs)                       # proved and checked: the aux buffers go back to the pool
+                try:
+                    proofs = self.prove_prepared(jobs, rs[lo:hi])
+                    if self._self_verify:
+                        for kind, vk in (("spend", self.spend_vk), ("convert", self.convert_vk)):
+                            sel = [i for i in range(hi - lo) if descriptions[lo + i][0] == kind]
+                            if not sel:
+                                continue
+                            pis = [public_input(kind, descriptions[lo + i][1], jobs[i]) for i in sel]
+                            if not vk.verify_batch([proofs[i] for i in sel], pis):
+                                bad = [lo + i for i, pi in zip(sel, pis) if not vk.verify(proofs[i], pi)]
+                                raise ProvingError("proof(s) %s failed self-verification" % bad)
+                finally:
+                    self._aux_give(jobs)                   # proved and checked, or failed: the aux buffers go back to the pool
                 for _ in range(hi - lo):
                     ahead.release()
-                done[0] += hi - lo
+                with done_lock:
+                    done[0] += hi - lo
+                    so_far = done[0]
                 if progress is not None:
-                    progress(done[0], n)
+                    progress(so_far, n)
                 return jobs, proofs
             try:
                 results = list(gpu.map(run_chunk, range(0, n, chunk)))
-            except BaseException:
-                abort.set()                        # (an invalid diversifier, a failed self-check, a device error ...)
+            except BaseException as e:             # (an invalid diversifier, a failed self-check, a device error ...)
+                abort.set()
                 for _ in range(n):
                     ahead.release()
-                raise
+                failed = e
+        if failed is not None:
+            # both executors have shut down, so every synthesis task has finished: whatever it produced and no chunk gave
+            # back (the failing chunk's earlier jobs, later chunks, tasks that ran past the abort check) returns its
+            # page-locked buffer now — a service that keeps hitting bad inputs must not accumulate pinned memory.
+            # The context is left untouched: the builder drops it together with the failed transaction.
+            self._aux_give([f.result() for f in futures if f.done() and not f.cancelled() and f.exception() is None and f.result() is not None])
+            raise failed
         jobs = [j for js, _ in results for j in js]
         proofs = [p for _, ps in results for p in ps]
         out = []
@@ -275,35 +299,44 @@ class LocalTxProver:
     # ---- the TxProver methods ----
     def spend_proof(self, ctx, proof_generation_key, diversifier, rseed, ar, asset_type, value, anchor, merkle_path, rcv, rs=None):
         """-> (zkproof[192], cv, rk).  `rseed` is the note commitment randomness rcm = note.rcm() (Rseed::BeforeZip212 form)."""
+        ctx._bsk_add(rcv)                                                      # :69-75, before anything can fail
         job = self.prepare_spend(proof_generation_key, diversifier, rseed, ar, asset_type, value, anchor, merkle_path, rcv)
-        zkproof = self.prove_prepared([job], None if rs is None else [rs])[0]
-        self._aux_give([job])
+        try:
+            zkproof = self.prove_prepared([job], None if rs is None else [rs])[0]
+        finally:
+            self._aux_give([job])
         if self._self_verify:
             # public input built from the natively computed rk, cv, anchor and nullifier (sapling/prover.rs:121-145)
             public_input = list(H.point_uv(job["rk"])) + list(H.point_uv(job["cv"])) + [_int(anchor)] + H.multipack(job["nf"])
             if not self.spend_vk.verify(zkproof, public_input):
                 raise ProvingError("spend proof failed self-verification")      # .map_err(|_| ())? at :148
-        ctx._spend_like(rcv, job["cv"])
+        ctx._cv_add(job["cv"])                                                 # :154
         return zkproof, job["cv"], job["rk"]
 
     def output_proof(self, ctx, esk, payment_address, rcm, asset_type, value, rcv, rs=None):
         """-> (zkproof[192], cv); infallible for valid inputs like the reference (it panics if proving fails)."""
+        ctx._bsk_add(rcv, subtract=True)                                       # :177-183
         job = self.prepare_output(esk, payment_address, rcm, asset_type, value, rcv)
-        zkproof = self.prove_prepared([job], None if rs is None else [rs])[0]
-        self._aux_give([job])
-        ctx._output(rcv, job["cv"])
+        try:
+            zkproof = self.prove_prepared([job], None if rs is None else [rs])[0]
+        finally:
+            self._aux_give([job])
+        ctx._cv_add(job["cv"], subtract=True)                                  # :205
         return zkproof, job["cv"]
 
     def convert_proof(self, ctx, allowed_conversion, value, anchor, merkle_path, rcv, rs=None):
         """-> (zkproof[192], cv)"""
+        ctx._bsk_add(rcv)                                                      # :228-234
         job = self.prepare_convert(allowed_conversion, value, anchor, merkle_path, rcv)
-        zkproof = self.prove_prepared([job], None if rs is None else [rs])[0]
-        self._aux_give([job])
+        try:
+            zkproof = self.prove_prepared([job], None if rs is None else [rs])[0]
+        finally:
+            self._aux_give([job])
         if self._self_verify:
             public_input = list(H.point_uv(job["cv"])) + [_int(anchor)]            # sapling/prover.rs:256-263
             if not self.convert_vk.verify(zkproof, public_input):
                 raise ProvingError("convert proof failed self-verification")    # :266
-        ctx._spend_like(rcv, job["cv"])
+        ctx._cv_add(job["cv"])                                                 # :272
         return zkproof, job["cv"]
 
     def binding_sig(self, ctx, assets_and_values, sighash):

@@ -1,0 +1,180 @@
+"""Parity of the code path `bench.py` times: batch mode (np >= 8 proofs per launch sequence: 16-/12-bit windows, 2^18/np
+chunks, the 33 000-entry bucket-0 heavy path, G = 16 weighted sums) on the REAL circuits at real size, through the C ABI.
+
+Oracles: the toxic-waste closed form for every proof (no NTT / MSM involved: one QAP evaluation + fixed-base
+multiplications), the CPU restatement `create_proof` for a sample, and the pairing equation (host batch verifier,
+cross-checked against the oracle's independent pairing in tests/test_circuits.py).  Instances follow the reference's
+benches (masp_amd/workload.py: benches/sapling.rs:38-86, benches/convert.rs:31-66) — all distinct.
+Run with `-m gpu` on an MI355X."""
+import os
+import random
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from pyref import R
+
+pytestmark = pytest.mark.gpu
+
+KINDS = ("spend", "output", "convert")
+
+
+class Rig:
+    """One context with the three real circuits on a synthetic CRS of known toxic waste (MASP_HIP_BATCH = 96 like bench.py)."""
+
+    def __init__(self, device=0):
+        import masp_amd
+        from masp_amd import host as H
+        from masp_amd.synthetic import toxic_waste
+        os.environ["MASP_HIP_BATCH"] = "96"
+        self.ctx = masp_amd.Context(device)
+        self.cs = {k: H.circuit(k)[0] for k in KINDS}
+        self.toxic = {k: toxic_waste(40 + i) for i, k in enumerate(KINDS)}
+        self.params = {}
+        self.vk = {}
+        for slot, k in enumerate(KINDS):
+            self.params[k] = self.ctx.generate_parameters(self.cs[k], self.toxic[k])
+            self.ctx.load_circuit(slot, self.params[k], self.cs[k])
+            self.vk[k] = H.PreparedVerifyingKey(self.params[k])
+        self.threads = H.effective_cpus()
+
+    def close(self):
+        self.ctx.close()
+
+
+@pytest.fixture(scope="module")
+def rig():
+    r = Rig()
+    yield r
+    r.close()
+
+
+def _rs(rng, n):
+    return [(rng.randrange(R), rng.randrange(R)) for _ in range(n)]
+
+
+def _check(rig, kinds, insts, rs, proofs, n_cpu):
+    """every proof == closed form; the first n_cpu of each circuit == CPU restatement; all pass the batched pairing check"""
+    from masp_amd import workload as W
+    assert len(proofs) == len(insts) and all(len(p) == 192 for p in proofs) and len(set(proofs)) == len(proofs)
+
+    def closed(j):
+        k = kinds[j]
+        return O.closed_form_proof(rig.cs[k], rig.toxic[k], insts[j][0], insts[j][1], *rs[j])
+    with ThreadPoolExecutor(rig.threads) as ex:
+        expect = list(ex.map(closed, range(len(insts))))
+    bad = [j for j in range(len(insts)) if proofs[j] != expect[j]]
+    assert not bad, "proofs %s differ from the closed form" % bad[:10]
+    seen = {}
+    for j, k in enumerate(kinds):
+        if seen.get(k, 0) < n_cpu:
+            seen[k] = seen.get(k, 0) + 1
+            assert proofs[j] == O.create_proof(O.Params(rig.params[k]), rig.cs[k], insts[j][0], insts[j][1], *rs[j])
+    for k in set(kinds):
+        sel = [j for j in range(len(insts)) if kinds[j] == k]
+        assert rig.vk[k].verify_batch([proofs[j] for j in sel], [W.public_inputs(insts[j][0]) for j in sel])
+    # and the batch verifier does notice a wrong proof
+    k0 = kinds[0]
+    sel = [j for j in range(len(insts)) if kinds[j] == k0][:8]
+    if len(sel) >= 2:
+        swapped = [proofs[sel[1]], proofs[sel[0]]] + [proofs[j] for j in sel[2:]]
+        assert not rig.vk[k0].verify_batch(swapped, [W.public_inputs(insts[j][0]) for j in sel])
+
+
+def test_256_distinct_spends_through_one_call(rig):
+    """BASELINE.json configs[3]: a batch of 256 distinct Spend proofs on one GPU through ONE masp_hip_prove_batch
+    (-> groups of 86 / 85 / 85 proofs, batch mode)."""
+    from masp_amd import workload as W
+    insts = W.instances("spend", 256, first_seed=1000)
+    assert len(set(a.tobytes() for _, a in insts)) == 256
+    rs = _rs(random.Random(1), 256)
+    proofs = rig.ctx.prove_batch([(0, i, a, r, s) for (i, a), (r, s) in zip(insts, rs)])
+    _check(rig, ["spend"] * 256, insts, rs, proofs, n_cpu=8)
+    # the device-resident path bench.py times runs the same batches: same bytes
+    h, n = rig.ctx.batch_upload([(0, i, a, r, s) for (i, a), (r, s) in zip(insts, rs)])
+    again, ms = rig.ctx.batch_prove_resident(h, n)
+    rig.ctx.batch_free(h)
+    assert again == proofs and ms > 0
+
+
+@pytest.mark.parametrize("kind", ["output", "convert"])
+def test_64_distinct_proofs_of_the_smaller_circuits(rig, kind):
+    from masp_amd import workload as W
+    insts = W.instances(kind, 64, first_seed=2000)
+    rs = _rs(random.Random(2), 64)
+    slot = KINDS.index(kind)
+    proofs = rig.ctx.prove_batch([(slot, i, a, r, s) for (i, a), (r, s) in zip(insts, rs)])
+    _check(rig, [kind] * 64, insts, rs, proofs, n_cpu=4)
+
+
+def test_mixed_three_circuit_list_in_job_order(rig):
+    """BASELINE.json configs[4] job mix (job j of circuit j mod 3), 32 of each, interleaved in one call: every circuit's
+    jobs form their own batch (np = 32) and every proof comes back at its job's position."""
+    from masp_amd import workload as W
+    per = {k: W.instances(k, 32, first_seed=3000) for k in KINDS}
+    kinds = [KINDS[j % 3] for j in range(96)]
+    insts = [per[k][j // 3] for j, k in enumerate(kinds)]
+    rs = _rs(random.Random(3), 96)
+    proofs = rig.ctx.prove_batch([(KINDS.index(k), i, a, r, s) for k, (i, a), (r, s) in zip(kinds, insts, rs)])
+    _check(rig, kinds, insts, rs, proofs, n_cpu=2)
+
+
+def _le(x):
+    return np.frombuffer((x % R).to_bytes(32, "little"), np.uint8)
+
+
+@pytest.mark.parametrize("n,window_bits,shape", [(131071, 16, "uniform"), (100497, 12, "witness")])
+def test_msm_engine_batched_np16_full_size(rig, n, window_bits, shape):
+    """The MSM engine alone in batch mode: 16 scalar vectors over one base set in one launch sequence (gridDim.y = 16), at
+    the Spend sizes and window widths the prover uses (h: 131 071 uniform scalars, 16-bit windows; l: 100 497
+    witness-shaped scalars — 38 % zeros, 33 % ones, the rest full width — 12-bit windows), checked by the discrete-log
+    identity: with bases P_i = k_i G,  sum_i s_i P_i = (sum_i s_i k_i mod r) G."""
+    rng = random.Random(n)
+    np_ = 16
+    k_int = [rng.randrange(R) for _ in range(n)]
+    ks = np.frombuffer(b"".join(k.to_bytes(32, "little") for k in k_int), np.uint8).reshape(n, 32)
+    bases = O.g1_mul_gen_many(ks)
+    sc = np.zeros((np_, n, 32), np.uint8)
+    totals = []
+    for p in range(np_):
+        if shape == "uniform":
+            s_int = [rng.randrange(R) for _ in range(n)]
+            for i, e in enumerate([0, 1, R - 1, (1 << 255) % R, 0x8000, 0x8001, 0xffff, 0x10000][:8]):
+                s_int[(p * 8 + i) % n] = e
+        else:
+            s_int = [0 if u < 0.38 else 1 if u < 0.71 else rng.randrange(R) for u in (rng.random() for _ in range(n))]
+        sc[p] = np.frombuffer(b"".join(s.to_bytes(32, "little") for s in s_int), np.uint8).reshape(n, 32)
+        totals.append(sum(a * b for a, b in zip(k_int, s_int)) % R)
+    got = rig.ctx.msm_g1_multi(bases, sc, window_bits=window_bits)
+    want = O.g1_mul_gen_many(np.stack([_le(t) for t in totals]))
+    assert got == [want[p].tobytes() for p in range(np_)]
+    # np = 1 of the same data goes through lone-proof mode, and the generic entry point picks its own window: same point
+    assert rig.ctx.msm_g1_multi(bases, sc[:1], window_bits=window_bits)[0] == got[0]
+    assert rig.ctx.msm_g1(bases, sc[0]) == got[0]
+
+
+def test_multi_device_context_deals_batches_to_its_devices(rig):
+    """masp_hip_ctx_create_multi: one prover over several device contexts (here the same GPU twice — the sharding, the
+    per-device host threads and the reassembly are what is tested; with 8 GPUs the list is 0..7).  Same bytes as the
+    single-device context, job order preserved, mixed circuits."""
+    import masp_amd
+    from masp_amd import workload as W
+    multi = masp_amd.Context([0, 0])
+    assert multi.device_count == 2 and rig.ctx.device_count == 1
+    for slot, k in enumerate(KINDS[:2]):
+        multi.load_circuit(slot, rig.params[k], rig.cs[k])
+    sp, ou = W.instances("spend", 40, first_seed=4000), W.instances("output", 24, first_seed=4000)
+    kinds = ["spend" if j % 8 < 5 else "output" for j in range(64)]
+    it = {"spend": iter(sp), "output": iter(ou)}
+    insts = [next(it[k]) for k in kinds]
+    rs = _rs(random.Random(4), 64)
+    jobs = [(KINDS.index(k), i, a, r, s) for k, (i, a), (r, s) in zip(kinds, insts, rs)]
+    got = multi.prove_batch(jobs)
+    assert got == rig.ctx.prove_batch(jobs)
+    _check(rig, kinds, insts, rs, got, n_cpu=1)
+    with pytest.raises(masp_amd.MaspHipError) as e:
+        multi.prove_batch([(2, insts[0][0], insts[0][1], 1, 2)])        # Convert was not loaded on this prover
+    assert e.value.code == 7
+    multi.close()
