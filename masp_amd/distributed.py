@@ -14,15 +14,17 @@ def shard(n_jobs, rank, world):
 
 
 def gather_proofs(local_proofs, n_jobs, dist=None, device=None):
-    """Every rank passes the proofs of its shard (job order); rank 0 gets all n_jobs proofs in job order, others None."""
+    """Every rank passes the proofs of its shard in job order (a list of 192-byte strings or a u8 array [m, 192]); rank 0
+    gets all n_jobs proofs in job order as a list of bytes, the others None."""
     import torch
+    if not isinstance(local_proofs, np.ndarray):
+        local_proofs = np.frombuffer(b"".join(local_proofs), dtype=np.uint8).reshape(-1, PROOF_BYTES)
     if dist is None or dist.get_world_size() == 1:
-        return list(local_proofs)
+        return [local_proofs[i].tobytes() for i in range(local_proofs.shape[0])]
     world, rank = dist.get_world_size(), dist.get_rank()
     cap = (n_jobs + world - 1) // world               # gather needs equal sizes: pad to the largest shard
     buf = np.zeros((cap, PROOF_BYTES), dtype=np.uint8)
-    for i, p in enumerate(local_proofs):
-        buf[i] = np.frombuffer(p, dtype=np.uint8)
+    buf[:local_proofs.shape[0]] = local_proofs
     mine = torch.from_numpy(buf)
     if device is not None:
         mine = mine.to(device)
@@ -44,4 +46,13 @@ def max_over_ranks(value, dist=None, device=None):
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, dist=None, device=None):
+    import torch
+    if dist is None or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())

@@ -61,3 +61,31 @@ def test_gather_world_size_2_gloo(n_jobs):
     assert res[1][0] is None
     assert res[0][0] == [_fake_proof(j) for j in range(n_jobs)]
     assert res[0][1] == res[1][1] == 2.0
+
+
+def _run_bench(argv, env_extra, timeout=300):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_launches_its_own_ranks_world_size_2_gloo():
+    """`python bench.py --gpus 2` without a launcher must itself become 2 ranks (it re-executes under
+    torch.distributed.run), bring the process group up, gather every rank's proofs on rank 0 in job order and print ONE
+    line that says n_gpus = 2.  --dry-run + gloo: the GPU work is skipped, the launcher / sharding / gather path is real."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "0", "--dry-run"], {"MASP_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["dry_run"] is True and out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["max_rank_seen"] == 1
+    assert out["gathered"] == 2 * 3 * 256 and out["gather_ok"] is True and out["value"] is None
+    assert "exec" in r.stderr and "torch.distributed.run" in r.stderr and "2 rank(s)" in r.stderr
+
+
+def test_bench_refuses_a_gpu_count_it_was_not_launched_with():
+    """A launcher that started 1 rank while --gpus says 4 (or the reverse) gets an error, not a line with another n_gpus."""
+    r = _run_bench(["--gpus", "4", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "refusing" in r.stderr and "{" not in r.stdout
