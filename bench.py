@@ -180,6 +180,8 @@ def main():
 
     rs_warm, rs_a, rs_b = fresh_rs(max(Wm, 1)), fresh_rs(K), fresh_rs(K)
     handle, _ = ctx.batch_upload(jobs_with(rs_a[0]))
+    # set-up, not warm-up: every slot's workspace (hipMalloc on first use) gets its final size — two steps reach all four slots
+    ctx.batch_prove_resident_steps(handle, n, 2, fresh_rs(2))
     if Wm > 0:
         ctx.batch_prove_resident_steps(handle, n, Wm, rs_warm)
     marshalled = [ctx.marshal_jobs(jobs_with(rs_b[k])) for k in range(K)]

@@ -220,4 +220,10 @@ typedef Affine<Fp2Ops> G2Affine;
 typedef Xyzz<FpOps> G1Xyzz;
 typedef Xyzz<Fp2Ops> G2Xyzz;
 
+// the verifying-key points the prover itself uses (proof assembly)
+struct VkDevice {
+    G1Affine alpha_g1, beta_g1, delta_g1;
+    G2Affine beta_g2, delta_g2;
+};
+
 }  // namespace masp

@@ -1,0 +1,23 @@
+// 128-bit loads / stores of Fr elements (shared by the NTT, R1CS, assembly and set-up kernels).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "field.cuh"
+
+namespace masp {
+
+__device__ __forceinline__ Fr fr_load(const Fr* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1];
+    Fr r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void fr_store(Fr* p, const Fr& r) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
+
+}  // namespace masp

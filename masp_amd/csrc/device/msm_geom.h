@@ -1,0 +1,33 @@
+// Window geometry of one MSM (shared by the kernels and the host-side drivers).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace masp {
+
+struct MsmGeom {
+    int c;        // window bits
+    int W;        // windows = ceil(256 / c)
+    int nb;       // buckets = 2^(c-1)  (|digit| in 1..2^(c-1))
+};
+static inline MsmGeom msm_geom(int c) {
+    MsmGeom g;
+    g.c = c;
+    g.W = (256 + c - 1) / c;
+    g.nb = 1 << (c - 1);
+    return g;
+}
+
+// entries per lane of the accumulation kernel (the gather / heavy-bucket kernels derive the same value)
+__host__ __device__ static inline uint32_t msm_chunk_len(uint32_t total, uint32_t nchunks) {
+    uint32_t k = (total + nchunks - 1) / nchunks;
+    return k < 4 ? 4 : k;  // at least 4 additions per lane: fewer partials to gather
+}
+
+// weighted-sum geometry (k_msm_wsum_level): 128 lanes per workgroup, 2^G_LOG buckets per lane
+static constexpr unsigned WSUM_L_LOG = 7, WSUM_L = 1u << WSUM_L_LOG;
+static constexpr unsigned WSUM_G_LOG_MIN = 2;
+static constexpr unsigned MSM_SORT_THREADS = 1024;
+
+}  // namespace masp

@@ -7,32 +7,20 @@
 //
 // A transform of 2^logm points is: one bit-reversal pass (fused with whatever pointwise work
 // precedes it) and then ceil(logm / 10) LDS passes, each doing up to 10 butterfly stages on a
-// 1024-element (32 KiB) tile held in LDS.  The whole data set of a MASP circuit (<= 4 MiB) stays
-// in L2 / Infinity Cache between passes.
+// 1024-element (32 KiB) tile held in LDS.  A lone transform (<= 4 MiB) stays in L2 / Infinity Cache
+// between passes; in batch mode every pass runs over the whole batch (np x 4 MiB per buffer), which streams
+// through HBM — see enqueue_quotient for how the batch is cut so that a sub-batch's working set stays in MALL.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include "field.cuh"
+#include "fr_io.cuh"
+#include "ntt_geom.h"
 
 namespace masp {
 
-static constexpr int NTT_LT = 10;  // log2 of the LDS tile
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t k, uint32_t logm) { return __brev(k) >> (32 - logm); }
-
-__device__ __forceinline__ Fr fr_load(const Fr* p) {
-    const uint4* q = reinterpret_cast<const uint4*>(p);
-    uint4 a = q[0], b = q[1];
-    Fr r;
-    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
-    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
-    return r;
-}
-__device__ __forceinline__ void fr_store(Fr* p, const Fr& r) {
-    uint4* q = reinterpret_cast<uint4*>(p);
-    q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
-    q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
-}
 
 // table[k] = scale * base^k  (Montgomery in, Montgomery out; `plain` strips the Montgomery factor)
 __global__ void k_fr_powers(Fr* __restrict__ table, uint32_t n, Fr base, Fr scale, int plain) {

@@ -1,0 +1,55 @@
+// Witness -> (a, b, c) evaluation vectors from the static R1CS, range check and query-scalar gathering by density.
+// Restates, for the GPU, bellperson's `ProvingAssignment::enforce` evaluation (nam-bellperson 0.26.6-nam.1, un-vendored;
+// SURVEY.md A.3 step 2).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "fr_io.cuh"
+
+namespace masp {
+
+// canonical -> Montgomery, n elements; flags any value >= r
+__global__ void k_fr_to_mont(const Fr* __restrict__ x, size_t x_stride, Fr* __restrict__ y, uint32_t n, int* __restrict__ range_err) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    x += blockIdx.y * x_stride;
+    y += (size_t)blockIdx.y * n;
+    Fr v = fr_load(x + k);
+    if (fe_canonical_ge_mod(v)) atomicOr(range_err, 1);
+    fr_store(y + k, fe_to_mont(v));
+}
+
+// One CSR row per lane: out[row] = sum_t coef[t] * w[col[t]]  (all Montgomery).  Rows
+// n_constraints .. n_constraints + n_inputs - 1 are bellperson's extra "Input(i) * 0 = 0" rows:
+// a = input value, b = c = 0 (which == 0 selects matrix A).
+// Row lengths of the MASP circuits range from 1 to several hundred terms (bit packings): `order` lists the constraint
+// rows by decreasing length, so the 64 rows of a wave take about equally long.
+__global__ void k_r1cs_eval(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ order, const uint32_t* __restrict__ col,
+                            const Fr* __restrict__ coef, const Fr* __restrict__ w, uint32_t n_vars, uint32_t n_constraints, uint32_t n_inputs,
+                            int which, Fr* __restrict__ out) {
+    uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_constraints + n_inputs) return;
+    w += (size_t)blockIdx.y * n_vars;
+    out += (size_t)blockIdx.y * (n_constraints + n_inputs);
+    Fr acc = fe_zero<FrCfg>();
+    if (row < n_constraints) {
+        row = order[row];
+        uint32_t lo = rowptr[row], hi = rowptr[row + 1];
+        for (uint32_t t = lo; t < hi; ++t) acc = fe_add(acc, fe_mul(fr_load(coef + t), fr_load(w + col[t])));
+    } else if (which == 0) {
+        acc = fr_load(w + (row - n_constraints));
+    }
+    fr_store(out + row, acc);
+}
+
+// dst[k] = src[idx[k]]  (32-byte scalars)
+__global__ void k_gather_scalars(const Fr* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ idx, uint32_t n,
+                                 Fr* __restrict__ dst) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    src += blockIdx.y * src_stride;
+    dst += (size_t)blockIdx.y * n;
+    fr_store(dst + k, fr_load(src + idx[k]));
+}
+
+}  // namespace masp

@@ -11,8 +11,8 @@
 #include <hip/hip_runtime.h>
 
 #include "curve.cuh"
+#include "fr_io.cuh"
 #include "io.cuh"
-#include "ntt.cuh"
 
 namespace masp {
 

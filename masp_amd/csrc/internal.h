@@ -1,0 +1,272 @@
+// Host-side types shared by the translation units of libmasp_hip (prover.hip: context, CRS loading, pipeline, C ABI;
+// k_setup.hip: parameter generation).  No kernels here.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <shared_mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "device/io.cuh"
+#include "device/ntt_geom.h"
+#include "launch.h"
+#include "msm_host.h"
+#include "util.h"
+
+namespace masp {
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    int reserve(size_t n) {
+        if (n <= cap) return MASP_HIP_OK;
+        release();
+        HIP_TRY(hipMalloc(&p, sizeof(T) * std::max<size_t>(n, 1)));
+        cap = n;
+        return MASP_HIP_OK;
+    }
+    int upload(const T* h, size_t n, hipStream_t s) {
+        int rc = reserve(n);
+        if (rc) return rc;
+        if (n) HIP_TRY(hipMemcpyAsync(p, h, sizeof(T) * n, hipMemcpyHostToDevice, s));
+        return MASP_HIP_OK;
+    }
+};
+
+// host-side Fr helpers (the device field code is __host__ __device__)
+static inline Fr fr_from_u64_mont(uint64_t x) {
+    Fr v = fe_zero<FrCfg>();
+    v.v[0] = (uint32_t)x;
+    v.v[1] = (uint32_t)(x >> 32);
+    return fe_to_mont(v);
+}
+static inline Fr fr_const(const uint32_t* limbs) {
+    Fr v;
+    for (int i = 0; i < 8; ++i) v.v[i] = limbs[i];
+    return v;
+}
+
+struct NttDomain {
+    uint32_t logm = 0;
+    size_t m = 0;
+    DevBuf<Fr> tw_fwd, tw_inv, coset_scale, h_scale;
+    Fr zinv;
+    int init(uint32_t logm_, hipStream_t s) {
+        logm = logm_;
+        m = (size_t)1 << logm;
+        Fr omega = fr_const(FrCfg::ROOT_OF_UNITY);
+        for (uint32_t i = logm; i < 32; ++i) omega = fe_sqr(omega);
+        Fr omega_inv = fe_inv(omega);
+        Fr minv = fe_inv(fr_from_u64_mont(m));
+        Fr g = fr_const(FrCfg::GEN), ginv = fr_const(FrCfg::GEN_INV);
+        uint32_t e[2] = {(uint32_t)m, (uint32_t)((uint64_t)m >> 32)};
+        zinv = fe_inv(fe_sub(fe_pow(g, e, 2), fe_one<FrCfg>()));
+        Fr one = fe_one<FrCfg>();
+        size_t half = std::max<size_t>(m / 2, 1);
+        int rc;
+        if ((rc = tw_fwd.reserve(half)) || (rc = tw_inv.reserve(half)) || (rc = coset_scale.reserve(m)) || (rc = h_scale.reserve(m))) return rc;
+        launch_fr_powers(s, tw_fwd.p, (uint32_t)half, omega, one, 0);
+        launch_fr_powers(s, tw_inv.p, (uint32_t)half, omega_inv, one, 0);
+        launch_fr_powers(s, coset_scale.p, (uint32_t)m, g, minv, 0);
+        launch_fr_powers(s, h_scale.p, (uint32_t)m, ginv, minv, 1);
+        HIP_TRY(hipStreamSynchronize(s));
+        return MASP_HIP_OK;
+    }
+    // np transforms at data + p * m
+    void passes(hipStream_t s, Fr* data, const Fr* tw, uint32_t np = 1) const {
+        for (uint32_t s0 = 0; s0 < logm;) {
+            uint32_t nst = std::min<uint32_t>(NTT_LT, logm - s0);
+            launch_ntt_pass(s, data, tw, logm, s0, nst, np);
+            s0 += nst;
+        }
+    }
+};
+
+struct Circuit {
+    uint32_t n_inputs = 0, n_aux = 0, n_constraints = 0, nrows = 0, logm = 0;
+    size_t m = 0;
+    DevBuf<uint32_t> rowptr[3], col[3];
+    DevBuf<uint32_t> row_order[3];  // constraint rows by decreasing length: lanes of a wave get rows of similar length
+    DevBuf<Fr> coef[3];
+    DevBuf<uint32_t> a_var, b_var;
+    uint32_t na = 0, nbq = 0;
+    DevBuf<VkDevice> vk;
+    DevBuf<G1Xyzz> fb1;  // fixed-base tables of delta1, alpha1, beta1
+    DevBuf<G2Xyzz> fb2;  // fixed-base table of delta2
+    BasesG1 h, l, a, b1;
+    BasesG2 b2;
+    NttDomain* dom = nullptr;
+};
+
+// scratch for one batch of up to `ctx->batch_cap` proofs of the same circuit + a stream.  Every stage is ONE launch for the
+// whole batch (gridDim.y = proofs); a few slots let the stages of different batches overlap on the device.
+struct Slot {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    MsmWorkspace<FpOps> ws1;
+    MsmWorkspace<Fp2Ops> ws2;
+    // lone-proof mode (a batch too small to fill the chip): the five MSMs run side by side on their own streams, each
+    // with its own workspace, next to the quotient pipeline on the main stream
+    static constexpr int N_AUX = 4;
+    hipStream_t aux[N_AUX] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_sort_b = nullptr, ev_join[N_AUX] = {nullptr, nullptr, nullptr, nullptr};
+    MsmWorkspace<FpOps> ws_l, ws_a, ws_b;
+    DevBuf<Fr> w, abc, wm, ev[3], x0[3], x1[3], h, sa, sb;
+    DevBuf<G1Xyzz> res1;
+    DevBuf<G2Xyzz> res2;
+    DevBuf<uint32_t> rs;
+    DevBuf<uint8_t> proof;
+    DevBuf<int> flags;
+    MsmProfile prof;             // live HIP-event timing of k_msm_accumulate<G1> (bench roofline leg)
+    bool profiling = false;
+    uint8_t* h_stage = nullptr;  // pinned staging for the assignment
+    size_t h_stage_cap = 0;
+    uint8_t* h_proof = nullptr;  // pinned, batch_cap x 192
+    size_t h_proof_cap = 0;
+    int* h_flags = nullptr;      // pinned
+    ~Slot() {
+        if (stream) hipStreamDestroy(stream);
+        if (done) hipEventDestroy(done);
+        for (int i = 0; i < N_AUX; ++i) {
+            if (aux[i]) hipStreamDestroy(aux[i]);
+            if (ev_join[i]) hipEventDestroy(ev_join[i]);
+        }
+        if (ev_fork) hipEventDestroy(ev_fork);
+        if (ev_sort_b) hipEventDestroy(ev_sort_b);
+        if (h_stage) hipHostFree(h_stage);
+        if (h_proof) hipHostFree(h_proof);
+        if (h_flags) hipHostFree(h_flags);
+    }
+    int init() {
+        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_sort_b, hipEventDisableTiming));
+        for (int i = 0; i < N_AUX; ++i) {
+            HIP_TRY(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
+        }
+        HIP_TRY(hipHostMalloc(&h_flags, sizeof(int)));
+        int rc;
+        if ((rc = flags.reserve(1))) return rc;
+        return reserve_batch(1);
+    }
+    int reserve_batch(size_t np) {
+        int rc;
+        if ((rc = res1.reserve(4 * np)) || (rc = res2.reserve(np)) || (rc = rs.reserve(16 * np)) || (rc = proof.reserve(192 * np))) return rc;
+        if (np > h_proof_cap) {
+            if (h_proof) hipHostFree(h_proof);
+            h_proof = nullptr;
+            HIP_TRY(hipHostMalloc(&h_proof, 192 * np));
+            h_proof_cap = np;
+        }
+        return MASP_HIP_OK;
+    }
+    int stage_reserve(size_t bytes) {
+        if (bytes <= h_stage_cap) return MASP_HIP_OK;
+        if (h_stage) hipHostFree(h_stage);
+        h_stage = nullptr;
+        HIP_TRY(hipHostMalloc(&h_stage, bytes));
+        h_stage_cap = bytes;
+        return MASP_HIP_OK;
+    }
+};
+
+struct ResidentBatch {
+    size_t n = 0;
+    std::vector<uint32_t> circuit;  // in STORAGE order: jobs are stored grouped by circuit so that batches are strided
+    std::vector<size_t> order;      // storage position -> caller's job index
+    std::vector<size_t> w_off;      // element offsets into w
+    DevBuf<Fr> w;
+    DevBuf<uint32_t> rs;        // n x 16
+};
+
+}  // namespace masp
+
+using masp::Circuit;
+using masp::DevBuf;
+using masp::Fr;
+using masp::G1Affine;
+using masp::G1Xyzz;
+using masp::G2Affine;
+using masp::G2Xyzz;
+using masp::NttDomain;
+using masp::ResidentBatch;
+using masp::Slot;
+
+// Locking: `mu` is held SHARED by masp_hip_prove_batch (any number of host threads prove concurrently, each batch on
+// its own slot = stream + scratch) and EXCLUSIVE by everything that changes circuits or uses the shared scratch.  The
+// slot pool has its own small lock (`slot_mu`); `err` is read and written under it.  `slots` / `slot_busy` are reserved
+// to MAX_SLOTS at creation and never reallocate, so a prover thread may keep indexing them while another one adds a slot.
+struct masp_hip_ctx {
+    static constexpr size_t MAX_SLOTS = 64;
+    int device = 0;
+    // multi-device front (masp_hip_ctx_create_multi): one full context per device; this object only shards and forwards
+    std::vector<masp_hip_ctx*> children;
+    int n_slots = 4;       // MASP_HIP_SLOTS, read once at creation
+    size_t batch_cap = 64; // MASP_HIP_BATCH, read once at creation
+    std::shared_mutex mu;
+    mutable std::mutex slot_mu;
+    std::condition_variable slot_cv;
+    std::vector<char> slot_busy;
+    std::string err;
+    hipStream_t main_stream = nullptr;
+    std::unique_ptr<Circuit> circ[MASP_HIP_MAX_CIRCUITS];
+    std::map<uint32_t, std::unique_ptr<NttDomain>> domains;
+    std::vector<std::unique_ptr<Slot>> slots;
+    std::vector<std::unique_ptr<ResidentBatch>> batches;
+    bool profiling = false;
+    // scratch for the building-block entry points
+    DevBuf<Fr> tmp_scalars;
+    DevBuf<uint8_t> tmp_out;
+    DevBuf<G1Xyzz> tmp_g1;
+    DevBuf<G2Xyzz> tmp_g2;
+    // fixed-base tables of the standard generators (parameter generation)
+    DevBuf<G1Affine> fb_g1;
+    DevBuf<G2Affine> fb_g2;
+};
+
+namespace masp {
+
+static inline int fail(masp_hip_ctx* ctx, int rc) {
+    if (rc == MASP_HIP_E_HIP) {
+        std::lock_guard<std::mutex> g(ctx->slot_mu);
+        ctx->err = last_hip_error();
+    }
+    return rc;
+}
+
+static inline int get_domain(masp_hip_ctx* ctx, uint32_t logm, NttDomain** out) {
+    auto it = ctx->domains.find(logm);
+    if (it == ctx->domains.end()) {
+        std::unique_ptr<NttDomain> d(new NttDomain);
+        int rc = d->init(logm, ctx->main_stream);
+        if (rc) return rc;
+        it = ctx->domains.emplace(logm, std::move(d)).first;
+    }
+    *out = it->second.get();
+    return MASP_HIP_OK;
+}
+
+static inline uint32_t log2_ceil(uint32_t n) {
+    uint32_t k = 0;
+    while ((1ull << k) < n) ++k;
+    return k;
+}
+
+}  // namespace masp

@@ -1,0 +1,35 @@
+// Counting sort of the MSM digits: kernels (device/msm_sort.cuh) + their host-side enqueue.
+#include "device/msm_sort.cuh"
+#include "msm_host.h"
+
+namespace masp {
+
+int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb, const uint32_t* d_scalars, size_t scalar_stride,
+                                   uint32_t np) {
+    if (g.c < 2 || g.c > 16) {
+        last_hip_error() = "MSM window width must be 2..16 bits (the bucket histogram lives in LDS)";
+        return MASP_HIP_E_INVALID_ARG;
+    }
+    int rc = sb.reserve(n, g, np);
+    if (rc) return rc;
+    sb.n = n;
+    sb.np = np;
+    sb.g = g;
+    static bool lds_ok = [] {
+        int bytes = 4 << 15;
+        return hipFuncSetAttribute((const void*)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+               hipFuncSetAttribute((const void*)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+    }();
+    if (!lds_ok) {
+        last_hip_error() = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
+        return MASP_HIP_E_HIP;
+    }
+    const uint32_t ng = MsmSortBuf::ranges_for(n, np), nb = g.nb;
+    hipLaunchKernelGGL(k_msm_hist, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg);
+    hipLaunchKernelGGL(k_msm_offsets, dim3(1, np), dim3(1024), 0, s, sb.hist_wg, ng, nb, sb.start);
+    hipLaunchKernelGGL(k_msm_scatter, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg, sb.start,
+                       sb.sorted);
+    return MASP_HIP_OK;
+}
+
+}  // namespace masp

@@ -1,0 +1,46 @@
+// Fr NTT / quotient kernels and the static-R1CS kernels with their launch wrappers (launch.h).
+#include "device/ntt.cuh"
+#include "device/r1cs.cuh"
+#include "launch.h"
+
+namespace masp {
+
+void launch_fr_powers(hipStream_t s, Fr* table, uint32_t n, const Fr& base, const Fr& scale, int plain) {
+    hipLaunchKernelGGL(k_fr_powers, dim3((n + 255) / 256), dim3(256), 0, s, table, n, base, scale, plain);
+}
+void launch_ntt_pass(hipStream_t s, Fr* data, const Fr* tw, uint32_t logm, uint32_t s0, uint32_t nst, uint32_t np) {
+    const uint32_t lt = (uint32_t)NTT_LT < logm ? (uint32_t)NTT_LT : logm;
+    hipLaunchKernelGGL(k_ntt_pass, dim3(1u << (logm - lt), np), dim3(256), 0, s, data, tw, logm, s0, nst);
+}
+void launch_ntt_load_bitrev(hipStream_t s, const Fr* x, size_t x_stride, uint32_t nrows, Fr* y, uint32_t logm, uint32_t np) {
+    hipLaunchKernelGGL(k_ntt_load_bitrev, dim3(((1u << logm) + 255) / 256, np), dim3(256), 0, s, x, x_stride, nrows, y, logm);
+}
+void launch_ntt_copy_bitrev(hipStream_t s, const Fr* x, size_t x_stride, uint32_t nrows, Fr* y, uint32_t logm, uint32_t np) {
+    hipLaunchKernelGGL(k_ntt_copy_bitrev, dim3(((1u << logm) + 255) / 256, np), dim3(256), 0, s, x, x_stride, nrows, y, logm);
+}
+void launch_ntt_scale_bitrev(hipStream_t s, const Fr* x, const Fr* scale, Fr* y, uint32_t logm, uint32_t np) {
+    hipLaunchKernelGGL(k_ntt_scale_bitrev, dim3(((1u << logm) + 255) / 256, np), dim3(256), 0, s, x, scale, y, logm);
+}
+void launch_ntt_abc_bitrev(hipStream_t s, const Fr* a, const Fr* b, const Fr* c, const Fr& zinv, Fr* y, uint32_t logm, uint32_t np) {
+    hipLaunchKernelGGL(k_ntt_abc_bitrev, dim3(((1u << logm) + 255) / 256, np), dim3(256), 0, s, a, b, c, zinv, y, logm);
+}
+void launch_fr_scale(hipStream_t s, const Fr* x, const Fr* scale, Fr* y, uint32_t n, uint32_t np) {
+    hipLaunchKernelGGL(k_fr_scale, dim3((n + 255) / 256, np), dim3(256), 0, s, x, scale, y, n);
+}
+void launch_fr_from_mont(hipStream_t s, const Fr* x, Fr* y, uint32_t n) {
+    hipLaunchKernelGGL(k_fr_from_mont, dim3((n + 255) / 256), dim3(256), 0, s, x, y, n);
+}
+void launch_fr_to_mont(hipStream_t s, const Fr* x, size_t x_stride, Fr* y, uint32_t n, uint32_t np, int* range_err) {
+    hipLaunchKernelGGL(k_fr_to_mont, dim3((n + 255) / 256, np), dim3(256), 0, s, x, x_stride, y, n, range_err);
+}
+void launch_r1cs_eval(hipStream_t s, const uint32_t* rowptr, const uint32_t* order, const uint32_t* col, const Fr* coef, const Fr* w, uint32_t n_vars,
+                      uint32_t n_constraints, uint32_t n_inputs, int which, Fr* out, uint32_t np) {
+    const uint32_t nrows = n_constraints + n_inputs;
+    hipLaunchKernelGGL(k_r1cs_eval, dim3((nrows + 127) / 128, np), dim3(128), 0, s, rowptr, order, col, coef, w, n_vars, n_constraints, n_inputs, which,
+                       out);
+}
+void launch_gather_scalars(hipStream_t s, const Fr* src, size_t src_stride, const uint32_t* idx, uint32_t n, Fr* dst, uint32_t np) {
+    hipLaunchKernelGGL(k_gather_scalars, dim3((n + 255) / 256, np), dim3(256), 0, s, src, src_stride, idx, n, dst);
+}
+
+}  // namespace masp

@@ -1,0 +1,185 @@
+// Groth16 parameter generation from explicit toxic waste (kernels: device/setup.cuh) — mirrors bellperson's
+// `generate_random_parameters`, which the reference's benches call (/root/reference/masp_proofs/benches/sapling.rs:24-36).
+#include "device/setup.cuh"
+#include "internal.h"
+
+using namespace masp;
+
+#define FIRST_DEVICE(ctx) ((ctx) && !(ctx)->children.empty() ? (ctx)->children[0] : (ctx))
+
+extern "C" {
+
+// ---- parameter generation -------------------------------------------------------------------------
+size_t masp_hip_parameters_max_size(const masp_hip_r1cs* cs) {
+    if (!cs) return 0;
+    size_t nv = (size_t)cs->n_inputs + cs->n_aux;
+    size_t m = (size_t)1 << log2_ceil(cs->n_constraints + cs->n_inputs);
+    return 864 + 6 * 4 + 96 * ((size_t)cs->n_inputs + (m - 1) + cs->n_aux + 2 * nv) + 192 * nv;
+}
+
+int masp_hip_generate_parameters(masp_hip_ctx* ctx, const masp_hip_r1cs* cs, const uint8_t toxic[160], uint8_t* out, size_t cap,
+                                 size_t* out_len) {
+    if (!ctx || !cs || !toxic || !out_len || cs->n_inputs == 0) return MASP_HIP_E_INVALID_ARG;
+    ctx = FIRST_DEVICE(ctx);
+    std::unique_lock<std::shared_mutex> lock(ctx->mu);
+    hipSetDevice(ctx->device);
+    hipStream_t s = ctx->main_stream;
+    Fr tw[5];
+    for (int i = 0; i < 5; ++i) {
+        Fr v = fe_load_le<FrCfg>(toxic + 32 * i);
+        if (fe_canonical_ge_mod(v)) return MASP_HIP_E_SCALAR_RANGE;
+        tw[i] = fe_to_mont(v);
+    }
+    const Fr tau = tw[0], alpha = tw[1], beta = tw[2], gamma = tw[3], delta = tw[4];
+    if (fe_is_zero(gamma) || fe_is_zero(delta)) return MASP_HIP_E_UNEXPECTED_IDENTITY;
+    const uint32_t n_in = cs->n_inputs, n_aux = cs->n_aux, nc = cs->n_constraints, nv = n_in + n_aux;
+    const uint32_t nrows = nc + n_in, logm = log2_ceil(nrows);
+    const size_t m = (size_t)1 << logm;
+    Fr omega = fr_const(FrCfg::ROOT_OF_UNITY);
+    for (uint32_t i = logm; i < 32; ++i) omega = fe_sqr(omega);
+    uint32_t em[2] = {(uint32_t)m, (uint32_t)((uint64_t)m >> 32)};
+    Fr z = fe_sub(fe_pow(tau, em, 2), fe_one<FrCfg>());
+    Fr z_over_m = fe_mul(z, fe_inv(fr_from_u64_mont(m)));
+    Fr dinv = fe_inv(delta), ginv = fe_inv(gamma);
+    int rc;
+    // fixed-base tables (cached)
+    if (!ctx->fb_g1.p) {
+        if ((rc = ctx->fb_g1.reserve(32 * 255)) || (rc = ctx->fb_g2.reserve(32 * 255))) return fail(ctx, rc);
+        G1Affine g1;
+        G2Affine g2;
+        for (int i = 0; i < 12; ++i) {
+            g1.x.v[i] = FpCfg::G1_X[i];
+            g1.y.v[i] = FpCfg::G1_Y[i];
+            g2.x.c0.v[i] = FpCfg::G2_X0[i];
+            g2.x.c1.v[i] = FpCfg::G2_X1[i];
+            g2.y.c0.v[i] = FpCfg::G2_Y0[i];
+            g2.y.c1.v[i] = FpCfg::G2_Y1[i];
+        }
+        hipLaunchKernelGGL((k_setup_fixed_table<FpOps>), dim3(1), dim3(64), 0, s, g1, ctx->fb_g1.p);
+        hipLaunchKernelGGL((k_setup_fixed_table<Fp2Ops>), dim3(1), dim3(64), 0, s, g2, ctx->fb_g2.p);
+    }
+    // Lagrange basis at tau
+    DevBuf<Fr> lag, qt[3];
+    if ((rc = lag.reserve(nrows))) return fail(ctx, rc);
+    hipLaunchKernelGGL(k_setup_lagrange, dim3((nrows + 127) / 128), dim3(128), 0, s, lag.p, nrows, omega, tau, z_over_m);
+    // column-major copies of A, B, C (plain integer bucketing on the host), then one lane per variable
+    const uint32_t* rp[3] = {cs->a_rowptr, cs->b_rowptr, cs->c_rowptr};
+    const uint32_t* cl[3] = {cs->a_col, cs->b_col, cs->c_col};
+    const uint8_t* cf[3] = {cs->a_coef, cs->b_coef, cs->c_coef};
+    DevBuf<int> d_flag;
+    if ((rc = d_flag.reserve(1))) return fail(ctx, rc);
+    hipMemsetAsync(d_flag.p, 0, sizeof(int), s);
+    for (int mi = 0; mi < 3; ++mi) {
+        const uint32_t nnz = rp[mi][nc];
+        std::vector<uint32_t> colptr(nv + 1, 0), rowidx(nnz);
+        std::vector<Fr> coefs(nnz);
+        for (uint32_t t = 0; t < nnz; ++t) {
+            if (cl[mi][t] >= nv) return MASP_HIP_E_INVALID_ARG;
+            ++colptr[cl[mi][t] + 1];
+        }
+        for (uint32_t v = 0; v < nv; ++v) colptr[v + 1] += colptr[v];
+        std::vector<uint32_t> fill(colptr.begin(), colptr.end() - 1);
+        for (uint32_t row = 0; row < nc; ++row)
+            for (uint32_t t = rp[mi][row]; t < rp[mi][row + 1]; ++t) {
+                uint32_t pos = fill[cl[mi][t]]++;
+                rowidx[pos] = row;
+                memcpy(&coefs[pos], cf[mi] + 32 * (size_t)t, 32);
+            }
+        DevBuf<uint32_t> d_colptr, d_rowidx;
+        DevBuf<Fr> d_raw, d_coef;
+        if ((rc = d_colptr.upload(colptr.data(), nv + 1, s)) || (rc = d_rowidx.upload(rowidx.data(), nnz, s)) ||
+            (rc = d_raw.upload(coefs.data(), nnz, s)) || (rc = d_coef.reserve(nnz)) || (rc = qt[mi].reserve(nv)))
+            return fail(ctx, rc);
+        if (nnz) launch_fr_to_mont(s, d_raw.p, (size_t)0, d_coef.p, nnz, 1, d_flag.p);
+        hipLaunchKernelGGL(k_setup_qap, dim3((nv + 127) / 128), dim3(128), 0, s, d_colptr.p, d_rowidx.p, d_coef.p, lag.p, nv, n_in, nc,
+                           mi == 0 ? 1 : 0, qt[mi].p);
+        if (hipStreamSynchronize(s) != hipSuccess) {
+            last_hip_error() = std::string("qap evaluation failed: ") + hipGetErrorString(hipGetLastError());
+            return fail(ctx, MASP_HIP_E_HIP);
+        }
+    }
+    // which variables survive the identity filter of a / b
+    DevBuf<uint8_t> d_nz;
+    if ((rc = d_nz.reserve(2 * (size_t)nv))) return fail(ctx, rc);
+    hipLaunchKernelGGL(k_setup_nonzero, dim3((nv + 255) / 256), dim3(256), 0, s, qt[0].p, nv, d_nz.p);
+    hipLaunchKernelGGL(k_setup_nonzero, dim3((nv + 255) / 256), dim3(256), 0, s, qt[1].p, nv, d_nz.p + nv);
+    std::vector<uint8_t> nz(2 * (size_t)nv);
+    int hflag = 0;
+    if (hipMemcpyAsync(nz.data(), d_nz.p, nz.size(), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(&hflag, d_flag.p, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        return fail(ctx, MASP_HIP_E_HIP);
+    if (hflag) return MASP_HIP_E_SCALAR_RANGE;
+    std::vector<uint32_t> a_list, b_list;
+    for (uint32_t v = 0; v < nv; ++v) {
+        if (nz[v]) a_list.push_back(v);
+        if (nz[nv + v]) b_list.push_back(v);
+    }
+    // all G1 scalars in one array: [vk: alpha beta delta | ic | h | l | a | b_g1], G2: [beta gamma delta | b_g2]
+    const size_t n_h = m - 1, n_a = a_list.size(), n_b = b_list.size();
+    const size_t o_ic = 3, o_h = o_ic + n_in, o_l = o_h + n_h, o_a = o_l + n_aux, o_b = o_a + n_a, n_g1 = o_b + n_b;
+    const size_t n_g2 = 3 + n_b;
+    const size_t total = 864 + 6 * 4 + 96 * (n_g1 - 3) + 192 * n_b;
+    *out_len = total;
+    if (!out || cap < total) return MASP_HIP_E_INVALID_ARG;
+    DevBuf<Fr> k1, k2, lc;
+    DevBuf<uint32_t> d_alist, d_blist;
+    if ((rc = k1.reserve(n_g1)) || (rc = k2.reserve(n_g2)) || (rc = lc.reserve(nv)) || (rc = d_alist.upload(a_list.data(), n_a, s)) ||
+        (rc = d_blist.upload(b_list.data(), n_b, s)))
+        return fail(ctx, rc);
+    Fr head1[3] = {alpha, beta, delta}, head2[3] = {beta, gamma, delta};
+    if (hipMemcpyAsync(k1.p, head1, sizeof(head1), hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(k2.p, head2, sizeof(head2), hipMemcpyHostToDevice, s) != hipSuccess)
+        return fail(ctx, MASP_HIP_E_HIP);
+    // ic = lc / gamma (inputs), l = lc / delta (aux)
+    hipLaunchKernelGGL(k_setup_lc, dim3((n_in + 255) / 256), dim3(256), 0, s, qt[0].p, qt[1].p, qt[2].p, n_in, alpha, beta, ginv, k1.p + o_ic);
+    if (n_aux)
+        hipLaunchKernelGGL(k_setup_lc, dim3((n_aux + 255) / 256), dim3(256), 0, s, qt[0].p + n_in, qt[1].p + n_in, qt[2].p + n_in, n_aux, alpha,
+                           beta, dinv, k1.p + o_l);
+    hipLaunchKernelGGL(k_setup_h_scalars, dim3((n_h + 255) / 256), dim3(256), 0, s, tau, fe_mul(z, dinv), (uint32_t)n_h, k1.p + o_h);
+    if (n_a) hipLaunchKernelGGL(k_setup_gather, dim3((n_a + 255) / 256), dim3(256), 0, s, qt[0].p, d_alist.p, (uint32_t)n_a, k1.p + o_a);
+    if (n_b) {
+        hipLaunchKernelGGL(k_setup_gather, dim3((n_b + 255) / 256), dim3(256), 0, s, qt[1].p, d_blist.p, (uint32_t)n_b, k1.p + o_b);
+        hipLaunchKernelGGL(k_setup_gather, dim3((n_b + 255) / 256), dim3(256), 0, s, qt[1].p, d_blist.p, (uint32_t)n_b, k2.p + 3);
+    }
+    DevBuf<uint8_t> p1, p2;
+    if ((rc = p1.reserve(96 * n_g1)) || (rc = p2.reserve(192 * n_g2))) return fail(ctx, rc);
+    hipLaunchKernelGGL((k_setup_fixed_mul<FpOps, 96>), dim3((n_g1 + 63) / 64), dim3(64), 0, s, ctx->fb_g1.p, k1.p, (uint32_t)n_g1, 1, p1.p);
+    hipLaunchKernelGGL((k_setup_fixed_mul<Fp2Ops, 192>), dim3((n_g2 + 63) / 64), dim3(64), 0, s, ctx->fb_g2.p, k2.p, (uint32_t)n_g2, 1, p2.p);
+    std::vector<uint8_t> h1(96 * n_g1), h2(192 * n_g2);
+    if (hipMemcpyAsync(h1.data(), p1.p, h1.size(), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(h2.data(), p2.p, h2.size(), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        last_hip_error() = std::string("parameter generation failed: ") + hipGetErrorString(hipGetLastError());
+        return fail(ctx, MASP_HIP_E_HIP);
+    }
+    // bellman wire format
+    uint8_t* w = out;
+    auto put = [&](const uint8_t* src, size_t n) {
+        memcpy(w, src, n);
+        w += n;
+    };
+    auto put_len = [&](size_t n) {
+        uint8_t b[4] = {(uint8_t)(n >> 24), (uint8_t)(n >> 16), (uint8_t)(n >> 8), (uint8_t)n};
+        put(b, 4);
+    };
+    put(&h1[0], 96);           // alpha_g1
+    put(&h1[96], 96);          // beta_g1
+    put(&h2[0], 192);          // beta_g2
+    put(&h2[192], 192);        // gamma_g2
+    put(&h1[192], 96);         // delta_g1
+    put(&h2[384], 192);        // delta_g2
+    put_len(n_in);
+    put(&h1[96 * o_ic], 96 * (size_t)n_in);
+    put_len(n_h);
+    put(&h1[96 * o_h], 96 * n_h);
+    put_len(n_aux);
+    put(&h1[96 * o_l], 96 * (size_t)n_aux);
+    put_len(n_a);
+    put(&h1[96 * o_a], 96 * n_a);
+    put_len(n_b);
+    put(&h1[96 * o_b], 96 * n_b);
+    put_len(n_b);
+    put(&h2[192 * 3], 192 * n_b);
+    return (size_t)(w - out) == total ? MASP_HIP_OK : MASP_HIP_E_INVALID_ARG;
+}
+
+}  // extern "C"

@@ -1,0 +1,37 @@
+// Launch wrappers of the kernel families that live in their own translation units (k_ntt.hip, k_groth16.hip): what the
+// host-side pipeline (prover.hip, k_setup.hip) calls instead of launching those kernels itself, so that every kernel
+// family compiles once, side by side with the others.  All of them only enqueue on `s`.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device/curve.cuh"
+
+namespace masp {
+
+// ---- k_ntt.hip: Fr NTT / quotient kernels (device/ntt.cuh) and the R1CS kernels (device/r1cs.cuh) ----
+void launch_fr_powers(hipStream_t s, Fr* table, uint32_t n, const Fr& base, const Fr& scale, int plain);
+// stages [s0, s0 + nst) of np transforms of 2^logm points at data + p * 2^logm
+void launch_ntt_pass(hipStream_t s, Fr* data, const Fr* tw, uint32_t logm, uint32_t s0, uint32_t nst, uint32_t np);
+void launch_ntt_load_bitrev(hipStream_t s, const Fr* x, size_t x_stride, uint32_t nrows, Fr* y, uint32_t logm, uint32_t np);
+void launch_ntt_copy_bitrev(hipStream_t s, const Fr* x, size_t x_stride, uint32_t nrows, Fr* y, uint32_t logm, uint32_t np);
+void launch_ntt_scale_bitrev(hipStream_t s, const Fr* x, const Fr* scale, Fr* y, uint32_t logm, uint32_t np);
+void launch_ntt_abc_bitrev(hipStream_t s, const Fr* a, const Fr* b, const Fr* c, const Fr& zinv, Fr* y, uint32_t logm, uint32_t np);
+void launch_fr_scale(hipStream_t s, const Fr* x, const Fr* scale, Fr* y, uint32_t n, uint32_t np);
+void launch_fr_from_mont(hipStream_t s, const Fr* x, Fr* y, uint32_t n);
+void launch_fr_to_mont(hipStream_t s, const Fr* x, size_t x_stride, Fr* y, uint32_t n, uint32_t np, int* range_err);
+void launch_r1cs_eval(hipStream_t s, const uint32_t* rowptr, const uint32_t* order, const uint32_t* col, const Fr* coef, const Fr* w, uint32_t n_vars,
+                      uint32_t n_constraints, uint32_t n_inputs, int which, Fr* out, uint32_t np);
+void launch_gather_scalars(hipStream_t s, const Fr* src, size_t src_stride, const uint32_t* idx, uint32_t n, Fr* dst, uint32_t np);
+
+// ---- k_groth16.hip: proof assembly, point import / export, fixed-base tables (device/groth16.cuh) ----
+void launch_groth16_assemble(hipStream_t s, const VkDevice* vk, const G1Xyzz* fb1, const G2Xyzz* fb2, const G1Xyzz* msm_g1, const G2Xyzz* msm_g2,
+                             const uint32_t* rs, size_t rs_stride, uint8_t* proof, uint32_t np);
+void launch_g1_export(hipStream_t s, const G1Xyzz* p, uint8_t* out);
+void launch_g2_export(hipStream_t s, const G2Xyzz* p, uint8_t* out);
+void launch_g1_import_one(hipStream_t s, const uint8_t* raw, G1Affine* out, int* status);
+void launch_g2_import_one(hipStream_t s, const uint8_t* raw, G2Affine* out, int* status);
+// tabs[k * 32 * 255 ...] = fixed-base table of pts[k], k < npts
+void launch_fixed_table_g1(hipStream_t s, const G1Affine* pts, G1Xyzz* tabs, uint32_t npts);
+void launch_fixed_table_g2(hipStream_t s, const G2Affine* pts, G2Xyzz* tabs, uint32_t npts);
+
+}  // namespace masp

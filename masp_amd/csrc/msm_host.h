@@ -1,12 +1,16 @@
-// Host-side driver of the MSM kernels (device/msm.cuh): owns the precomputed window tables of one
-// base set and a reusable workspace, and enqueues one MSM on a HIP stream without any host sync.
+// Host-side driver of the MSM kernels: owns the precomputed window tables of one base set and a reusable workspace, and
+// enqueues one MSM on a HIP stream without any host sync.  This header holds types and declarations only; the functions
+// that launch kernels are defined in msm_impl.cuh / msm_acc_impl.cuh and instantiated in their own translation units
+// (k_msm_g1.hip, k_msm_g2.hip, k_msm_g1_acc.hip, k_msm_g2_acc.hip, k_msm_sort.hip), so that the kernel families compile side
+// by side and a change to one kernel recompiles one unit.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
 #include <vector>
 
-#include "device/msm.cuh"
+#include "device/curve.cuh"
+#include "device/msm_geom.h"
 #include "util.h"
 
 namespace masp {
@@ -29,28 +33,15 @@ struct MsmBases {
     // mixed additions, per bucket the gather + weighted sum cost ~5.5 full additions.
     static MsmGeom pick_geom(uint32_t n_eff) {
         int c = n_eff >= (1u << 16) ? 16 : n_eff >= (1u << 12) ? 12 : n_eff >= (1u << 8) ? 10 : 7;
-        const char* e = getenv("MASP_HIP_MSM_C");
-        if (e) c = atoi(e);
+        static const int forced = [] {  // experiment knob, read once per process
+            const char* e = getenv("MASP_HIP_MSM_C");
+            return e ? atoi(e) : 0;
+        }();
+        if (forced) c = forced;
         return msm_geom(c);
     }
-    // raw: device pointer to n uncompressed points (bellman wire format)
-    int load_device(const uint8_t* d_raw, uint32_t n_, hipStream_t s, uint32_t n_eff = 0xffffffffu, int force_c = 0) {
-        release();
-        n = n_;
-        g = force_c ? msm_geom(force_c) : pick_geom(std::min(n_eff, n_));
-        if (n == 0) return MASP_HIP_OK;
-        HIP_TRY(hipMalloc(&tab, sizeof(Affine<O>) * (size_t)g.W * n));
-        int* d_status;
-        HIP_TRY(hipMalloc(&d_status, sizeof(int)));
-        HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(int), s));
-        dim3 grid((n + 63) / 64), block(64);
-        hipLaunchKernelGGL((k_msm_import<O, BYTES>), grid, block, 0, s, d_raw, tab, n, d_status);
-        hipLaunchKernelGGL((k_msm_precompute<O>), grid, block, 0, s, tab, n, g.c, g.W);
-        HIP_TRY(hipMemcpyAsync(&import_status, d_status, sizeof(int), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        hipFree(d_status);
-        return MASP_HIP_OK;
-    }
+    // raw: device pointer to n uncompressed points (bellman wire format)          [msm_impl.cuh]
+    int load_device(const uint8_t* d_raw, uint32_t n_, hipStream_t s, uint32_t n_eff = 0xffffffffu, int force_c = 0);
     int load_host(const uint8_t* raw, uint32_t n_, hipStream_t s, uint32_t n_eff = 0xffffffffu, int force_c = 0) {
         uint8_t* d_raw = nullptr;
         if (n_) {
@@ -165,24 +156,9 @@ struct MsmWorkspace {
     }
 
     // per proof: reduce the `m` points at `src + p*src_stride` to one at `dst + p*dst_stride` (src must not be R[]).
-    // Workgroup tree reductions (fan-in 256, 8 dependent additions per pass).
+    // Workgroup tree reductions (fan-in 256, 8 dependent additions per pass).                      [msm_impl.cuh]
     void reduce_to_one(hipStream_t s, uint32_t np, const Xyzz<O>* src, size_t src_stride, uint32_t m, Xyzz<O>* dst, size_t dst_stride,
-                       size_t r_stride) {
-        int flip = 0;
-        const Xyzz<O>* cur = src;
-        size_t cur_stride = src_stride;
-        while (true) {
-            uint32_t outn = (m + 255) / 256;
-            Xyzz<O>* out = outn == 1 ? dst : R[flip];
-            size_t out_stride = outn == 1 ? dst_stride : r_stride;
-            hipLaunchKernelGGL((k_xyzz_reduce_block<O>), dim3(outn, np), dim3(256), 256 * sizeof(Xyzz<O>), s, cur, cur_stride, m, out, out_stride);
-            if (outn == 1) break;
-            cur = out;
-            cur_stride = out_stride;
-            m = outn;
-            flip ^= 1;
-        }
-    }
+                       size_t r_stride);
 };
 
 // Optional live timing of the dominant kernel (bucket accumulation) with HIP events on the launching stream.
@@ -233,113 +209,19 @@ struct MsmProfile {
 };
 
 // Counting sort of the signed window digits of `np` scalar vectors (n scalars each) by bucket, on stream `s`.
-// scalars_p = d_scalars + p * scalar_stride (u32 units), n x 8 canonical LE limbs each.  No host synchronisation.
-static inline int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb, const uint32_t* d_scalars, size_t scalar_stride,
-                                   uint32_t np) {
-    if (g.c < 2 || g.c > 16) {
-        last_hip_error() = "MSM window width must be 2..16 bits (the bucket histogram lives in LDS)";
-        return MASP_HIP_E_INVALID_ARG;
-    }
-    int rc = sb.reserve(n, g, np);
-    if (rc) return rc;
-    sb.n = n;
-    sb.np = np;
-    sb.g = g;
-    static bool lds_ok = [] {
-        int bytes = 4 << 15;
-        return hipFuncSetAttribute((const void*)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
-               hipFuncSetAttribute((const void*)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
-    }();
-    if (!lds_ok) {
-        last_hip_error() = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
-        return MASP_HIP_E_HIP;
-    }
-    const uint32_t ng = MsmSortBuf::ranges_for(n, np), nb = g.nb;
-    hipLaunchKernelGGL(k_msm_hist, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg);
-    hipLaunchKernelGGL(k_msm_offsets, dim3(1, np), dim3(1024), 0, s, sb.hist_wg, ng, nb, sb.start);
-    hipLaunchKernelGGL(k_msm_scatter, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg, sb.start,
-                       sb.sorted);
-    return MASP_HIP_OK;
-}
+// scalars_p = d_scalars + p * scalar_stride (u32 units), n x 8 canonical LE limbs each.  No host synchronisation.   [k_msm_sort.hip]
+int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb, const uint32_t* d_scalars, size_t scalar_stride, uint32_t np);
+
+// The dominant kernel on its own: bucket accumulation of the sorted digit list (k_msm_accumulate<O>).   [msm_acc_impl.cuh]
+template <class O>
+void msm_launch_accumulate(hipStream_t s, const Affine<O>* tab, const uint32_t* sorted, size_t ent_stride, const uint32_t* start, uint32_t nb,
+                           uint32_t nchunks, Xyzz<O>* part, uint32_t np);
 
 // Bucket accumulation + reduction of the MSM whose digits were sorted into `sb` (same n, geometry and batch size):
-// result p at d_out + p * out_stride.  No host synchronisation.
+// result p at d_out + p * out_stride.  No host synchronisation.                                    [msm_impl.cuh]
 template <class O, int BYTES>
 int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSortBuf& sb, MsmWorkspace<O>& ws, Xyzz<O>* d_out, size_t out_stride,
-                       MsmProfile* prof = nullptr) {
-    const MsmGeom& g = B.g;
-    const uint32_t n = B.n, np = sb.np;
-    if (sb.n != n || sb.g.c != g.c) {
-        last_hip_error() = "msm_reduce_enqueue: sort does not match the base set";
-        return MASP_HIP_E_INVALID_ARG;
-    }
-    int rc = ws.reserve(n, g, np);
-    if (rc) return rc;
-    {
-        // the LDS tree kernel keeps 256 XYZZ points per workgroup: 48 KiB (G1) / 96 KiB (G2) of the 160 KiB LDS
-        static bool lds_ok = [] {
-            int bytes = 256 * (int)sizeof(Xyzz<O>);
-            return hipFuncSetAttribute((const void*)k_xyzz_reduce_block<O>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
-        }();
-        if (!lds_ok) {
-            last_hip_error() = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
-            return MASP_HIP_E_HIP;
-        }
-    }
-    const uint32_t nb = g.nb;
-    const uint32_t total = n * g.W;
-    const uint32_t nchunks = ws.nchunks_for(n, g, np);
-    HIP_TRY(hipMemsetAsync(ws.n_heavy, 0, 4 * np, s));
-    MsmProfile::Rec rec{};
-    if (prof) {
-        rec = prof->acquire();
-        rec.alg_bytes = (uint64_t)np * n * (BYTES + 32);  // n x (affine base + scalar) per proof
-        hipEventRecord(rec.e0, s);
-    }
-    hipLaunchKernelGGL((k_msm_accumulate<O>), dim3((nchunks + 63) / 64, np), dim3(64), 0, s, B.tab, sb.sorted, (size_t)total, sb.start, nb,
-                       nchunks, ws.part);
-    if (prof) {
-        hipEventRecord(rec.e1, s);
-        prof->recs.push_back(rec);
-    }
-    const bool lone = np < 8;  // latency regime: short chains matter more than total work
-    hipLaunchKernelGGL((k_msm_bucket_gather<O>), dim3((nb + 63) / 64, np), dim3(64), 0, s, ws.part, sb.start, nb, nchunks, ws.bkt, ws.heavy,
-                       ws.n_heavy, lone ? 12u : 24u);
-    // (with a lone proof the chunks are short and most buckets of a narrow-window MSM count as heavy: give them the chip)
-    // Usually ONE workgroup per proof has work here (bucket 0).  Workgroups go to the 8 XCDs round-robin by linear id
-    // x + gridDim.x * y, so with gridDim.x a multiple of 8 every proof's working workgroup (x = 0) would land on the same
-    // XCD (measured: 9.9 ms instead of 4.1 ms for the G2 launch of a 64-proof batch): keep gridDim.x odd.
-    const uint32_t heavy_blocks = std::min<uint32_t>(std::max<uint32_t>(4096u / np, 16u), nb) | 1u;
-    hipLaunchKernelGGL((k_msm_bucket_heavy<O, 256>), dim3(heavy_blocks, np), dim3(256), 0, s, ws.part, sb.start, nb, nchunks, ws.bkt, ws.heavy,
-                       ws.n_heavy);
-    // weighted sum by levels of (G x 128)-bucket workgroups; G = 16 buckets per lane in a batch (least work per bucket:
-    // the latency of the launches with few buckets hides behind the other batches in flight; choosing G = 4 for those
-    // was measured 2 % slower), 4 for a lone proof (shortest dependent chain)
-    const uint32_t g_log = lone ? WSUM_G_LOG_MIN : 4;
-    const uint32_t cs = 1u << (g_log + WSUM_L_LOG);
-    const size_t st_stride = (nb + cs - 1) / cs;  // level-0 chunk count bounds every later level
-    const Xyzz<O>* bk = ws.bkt;
-    size_t bk_stride = nb;
-    uint32_t m = nb, off = 1;
-    int level = 0, flip = 0;
-    do {
-        uint32_t chunks = (m + cs - 1) / cs;
-        if (g_log == 4)
-            hipLaunchKernelGGL((k_msm_wsum_level<O, 4>), dim3(chunks, np), dim3(WSUM_L), 0, s, bk, bk_stride, m, off, ws.S[flip], ws.T, st_stride);
-        else
-            hipLaunchKernelGGL((k_msm_wsum_level<O, WSUM_G_LOG_MIN>), dim3(chunks, np), dim3(WSUM_L), 0, s, bk, bk_stride, m, off, ws.S[flip],
-                               ws.T, st_stride);
-        ws.reduce_to_one(s, np, ws.T, st_stride, chunks, ws.tsum + level, 32, st_stride);
-        bk = ws.S[flip];
-        bk_stride = st_stride;
-        flip ^= 1;
-        m = chunks;
-        off = 0;
-        ++level;
-    } while (m > 1);
-    hipLaunchKernelGGL((k_msm_combine<O>), dim3(1, np), dim3(64), 0, s, ws.tsum, level, (int)(g_log + WSUM_L_LOG), d_out, out_stride);
-    return MASP_HIP_OK;
-}
+                       MsmProfile* prof = nullptr);
 
 // Enqueue, for each of `np` proofs p, sum_i scalars_p[i] * P_i on stream `s` — one launch per stage for the whole batch.
 // scalars_p = d_scalars + p * scalar_stride (u32 units), n x 8 canonical LE limbs each; result p at d_out + p * out_stride.
@@ -356,5 +238,8 @@ int msm_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, MsmWorkspace<O>& ws,
     if (rc) return rc;
     return msm_reduce_enqueue(s, B, ws.sort, ws, d_out, out_stride, prof);
 }
+
+typedef MsmBases<FpOps, 96> BasesG1;
+typedef MsmBases<Fp2Ops, 192> BasesG2;
 
 }  // namespace masp

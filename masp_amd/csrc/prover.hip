@@ -20,255 +20,11 @@
 #include <thread>
 #include <vector>
 
-#include "device/groth16.cuh"
-#include "device/ntt.cuh"
-#include "device/setup.cuh"
-#include "msm_engine.cuh"
-#include "util.h"
+#include "internal.h"
 
 using namespace masp;
 
 namespace {
-
-typedef MsmBases<FpOps, 96> BasesG1;
-typedef MsmBases<Fp2Ops, 192> BasesG2;
-
-template <class T>
-struct DevBuf {
-    T* p = nullptr;
-    size_t cap = 0;
-    ~DevBuf() { release(); }
-    void release() {
-        if (p) hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-    int reserve(size_t n) {
-        if (n <= cap) return MASP_HIP_OK;
-        release();
-        HIP_TRY(hipMalloc(&p, sizeof(T) * std::max<size_t>(n, 1)));
-        cap = n;
-        return MASP_HIP_OK;
-    }
-    int upload(const T* h, size_t n, hipStream_t s) {
-        int rc = reserve(n);
-        if (rc) return rc;
-        if (n) HIP_TRY(hipMemcpyAsync(p, h, sizeof(T) * n, hipMemcpyHostToDevice, s));
-        return MASP_HIP_OK;
-    }
-};
-
-// host-side Fr helpers (the device field code is __host__ __device__)
-static Fr fr_from_u64_mont(uint64_t x) {
-    Fr v = fe_zero<FrCfg>();
-    v.v[0] = (uint32_t)x;
-    v.v[1] = (uint32_t)(x >> 32);
-    return fe_to_mont(v);
-}
-static Fr fr_const(const uint32_t* limbs) {
-    Fr v;
-    for (int i = 0; i < 8; ++i) v.v[i] = limbs[i];
-    return v;
-}
-
-struct NttDomain {
-    uint32_t logm = 0;
-    size_t m = 0;
-    DevBuf<Fr> tw_fwd, tw_inv, coset_scale, h_scale;
-    Fr zinv;
-    int init(uint32_t logm_, hipStream_t s) {
-        logm = logm_;
-        m = (size_t)1 << logm;
-        Fr omega = fr_const(FrCfg::ROOT_OF_UNITY);
-        for (uint32_t i = logm; i < 32; ++i) omega = fe_sqr(omega);
-        Fr omega_inv = fe_inv(omega);
-        Fr minv = fe_inv(fr_from_u64_mont(m));
-        Fr g = fr_const(FrCfg::GEN), ginv = fr_const(FrCfg::GEN_INV);
-        uint32_t e[2] = {(uint32_t)m, (uint32_t)((uint64_t)m >> 32)};
-        zinv = fe_inv(fe_sub(fe_pow(g, e, 2), fe_one<FrCfg>()));
-        Fr one = fe_one<FrCfg>();
-        size_t half = std::max<size_t>(m / 2, 1);
-        int rc;
-        if ((rc = tw_fwd.reserve(half)) || (rc = tw_inv.reserve(half)) || (rc = coset_scale.reserve(m)) || (rc = h_scale.reserve(m))) return rc;
-        hipLaunchKernelGGL(k_fr_powers, dim3((half + 255) / 256), dim3(256), 0, s, tw_fwd.p, (uint32_t)half, omega, one, 0);
-        hipLaunchKernelGGL(k_fr_powers, dim3((half + 255) / 256), dim3(256), 0, s, tw_inv.p, (uint32_t)half, omega_inv, one, 0);
-        hipLaunchKernelGGL(k_fr_powers, dim3((m + 255) / 256), dim3(256), 0, s, coset_scale.p, (uint32_t)m, g, minv, 0);
-        hipLaunchKernelGGL(k_fr_powers, dim3((m + 255) / 256), dim3(256), 0, s, h_scale.p, (uint32_t)m, ginv, minv, 1);
-        HIP_TRY(hipStreamSynchronize(s));
-        return MASP_HIP_OK;
-    }
-    // np transforms at data + p * m
-    void passes(hipStream_t s, Fr* data, const Fr* tw, uint32_t np = 1) const {
-        uint32_t lt = std::min<uint32_t>(NTT_LT, logm);
-        uint32_t tiles = (uint32_t)(m >> lt);
-        for (uint32_t s0 = 0; s0 < logm;) {
-            uint32_t nst = std::min<uint32_t>(NTT_LT, logm - s0);
-            hipLaunchKernelGGL(k_ntt_pass, dim3(tiles, np), dim3(256), 0, s, data, tw, logm, s0, nst);
-            s0 += nst;
-        }
-    }
-};
-
-struct Circuit {
-    uint32_t n_inputs = 0, n_aux = 0, n_constraints = 0, nrows = 0, logm = 0;
-    size_t m = 0;
-    DevBuf<uint32_t> rowptr[3], col[3];
-    DevBuf<uint32_t> row_order[3];  // constraint rows by decreasing length: lanes of a wave get rows of similar length
-    DevBuf<Fr> coef[3];
-    DevBuf<uint32_t> a_var, b_var;
-    uint32_t na = 0, nbq = 0;
-    DevBuf<VkDevice> vk;
-    DevBuf<G1Xyzz> fb1;  // fixed-base tables of delta1, alpha1, beta1
-    DevBuf<G2Xyzz> fb2;  // fixed-base table of delta2
-    BasesG1 h, l, a, b1;
-    BasesG2 b2;
-    NttDomain* dom = nullptr;
-};
-
-// scratch for one batch of up to `ctx->batch_cap` proofs of the same circuit + a stream.  Every stage is ONE launch for the
-// whole batch (gridDim.y = proofs); a few slots let the stages of different batches overlap on the device.
-struct Slot {
-    hipStream_t stream = nullptr;
-    hipEvent_t done = nullptr;
-    MsmWorkspace<FpOps> ws1;
-    MsmWorkspace<Fp2Ops> ws2;
-    // lone-proof mode (a batch too small to fill the chip): the five MSMs run side by side on their own streams, each
-    // with its own workspace, next to the quotient pipeline on the main stream
-    static constexpr int N_AUX = 4;
-    hipStream_t aux[N_AUX] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_sort_b = nullptr, ev_join[N_AUX] = {nullptr, nullptr, nullptr, nullptr};
-    MsmWorkspace<FpOps> ws_l, ws_a, ws_b;
-    DevBuf<Fr> w, abc, wm, ev[3], x0[3], x1[3], h, sa, sb;
-    DevBuf<G1Xyzz> res1;
-    DevBuf<G2Xyzz> res2;
-    DevBuf<uint32_t> rs;
-    DevBuf<uint8_t> proof;
-    DevBuf<int> flags;
-    MsmProfile prof;             // live HIP-event timing of k_msm_accumulate<G1> (bench roofline leg)
-    bool profiling = false;
-    uint8_t* h_stage = nullptr;  // pinned staging for the assignment
-    size_t h_stage_cap = 0;
-    uint8_t* h_proof = nullptr;  // pinned, batch_cap x 192
-    size_t h_proof_cap = 0;
-    int* h_flags = nullptr;      // pinned
-    ~Slot() {
-        if (stream) hipStreamDestroy(stream);
-        if (done) hipEventDestroy(done);
-        for (int i = 0; i < N_AUX; ++i) {
-            if (aux[i]) hipStreamDestroy(aux[i]);
-            if (ev_join[i]) hipEventDestroy(ev_join[i]);
-        }
-        if (ev_fork) hipEventDestroy(ev_fork);
-        if (ev_sort_b) hipEventDestroy(ev_sort_b);
-        if (h_stage) hipHostFree(h_stage);
-        if (h_proof) hipHostFree(h_proof);
-        if (h_flags) hipHostFree(h_flags);
-    }
-    int init() {
-        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&ev_sort_b, hipEventDisableTiming));
-        for (int i = 0; i < N_AUX; ++i) {
-            HIP_TRY(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
-        }
-        HIP_TRY(hipHostMalloc(&h_flags, sizeof(int)));
-        int rc;
-        if ((rc = flags.reserve(1))) return rc;
-        return reserve_batch(1);
-    }
-    int reserve_batch(size_t np) {
-        int rc;
-        if ((rc = res1.reserve(4 * np)) || (rc = res2.reserve(np)) || (rc = rs.reserve(16 * np)) || (rc = proof.reserve(192 * np))) return rc;
-        if (np > h_proof_cap) {
-            if (h_proof) hipHostFree(h_proof);
-            h_proof = nullptr;
-            HIP_TRY(hipHostMalloc(&h_proof, 192 * np));
-            h_proof_cap = np;
-        }
-        return MASP_HIP_OK;
-    }
-    int stage_reserve(size_t bytes) {
-        if (bytes <= h_stage_cap) return MASP_HIP_OK;
-        if (h_stage) hipHostFree(h_stage);
-        h_stage = nullptr;
-        HIP_TRY(hipHostMalloc(&h_stage, bytes));
-        h_stage_cap = bytes;
-        return MASP_HIP_OK;
-    }
-};
-
-struct ResidentBatch {
-    size_t n = 0;
-    std::vector<uint32_t> circuit;  // in STORAGE order: jobs are stored grouped by circuit so that batches are strided
-    std::vector<size_t> order;      // storage position -> caller's job index
-    std::vector<size_t> w_off;      // element offsets into w
-    DevBuf<Fr> w;
-    DevBuf<uint32_t> rs;        // n x 16
-};
-
-}  // namespace
-
-// Locking: `mu` is held SHARED by masp_hip_prove_batch (any number of host threads prove concurrently, each batch on
-// its own slot = stream + scratch) and EXCLUSIVE by everything that changes circuits or uses the shared scratch.  The
-// slot pool has its own small lock (`slot_mu`); `err` is read and written under it.  `slots` / `slot_busy` are reserved
-// to MAX_SLOTS at creation and never reallocate, so a prover thread may keep indexing them while another one adds a slot.
-struct masp_hip_ctx {
-    static constexpr size_t MAX_SLOTS = 64;
-    int device = 0;
-    // multi-device front (masp_hip_ctx_create_multi): one full context per device; this object only shards and forwards
-    std::vector<masp_hip_ctx*> children;
-    int n_slots = 4;       // MASP_HIP_SLOTS, read once at creation
-    size_t batch_cap = 64; // MASP_HIP_BATCH, read once at creation
-    std::shared_mutex mu;
-    mutable std::mutex slot_mu;
-    std::condition_variable slot_cv;
-    std::vector<char> slot_busy;
-    std::string err;
-    hipStream_t main_stream = nullptr;
-    std::unique_ptr<Circuit> circ[MASP_HIP_MAX_CIRCUITS];
-    std::map<uint32_t, std::unique_ptr<NttDomain>> domains;
-    std::vector<std::unique_ptr<Slot>> slots;
-    std::vector<std::unique_ptr<ResidentBatch>> batches;
-    bool profiling = false;
-    // scratch for the building-block entry points
-    DevBuf<Fr> tmp_scalars;
-    DevBuf<uint8_t> tmp_out;
-    DevBuf<G1Xyzz> tmp_g1;
-    DevBuf<G2Xyzz> tmp_g2;
-    // fixed-base tables of the standard generators (parameter generation)
-    DevBuf<G1Affine> fb_g1;
-    DevBuf<G2Affine> fb_g2;
-};
-
-namespace {
-
-static int fail(masp_hip_ctx* ctx, int rc) {
-    if (rc == MASP_HIP_E_HIP) {
-        std::lock_guard<std::mutex> g(ctx->slot_mu);
-        ctx->err = last_hip_error();
-    }
-    return rc;
-}
-
-static int get_domain(masp_hip_ctx* ctx, uint32_t logm, NttDomain** out) {
-    auto it = ctx->domains.find(logm);
-    if (it == ctx->domains.end()) {
-        std::unique_ptr<NttDomain> d(new NttDomain);
-        int rc = d->init(logm, ctx->main_stream);
-        if (rc) return rc;
-        it = ctx->domains.emplace(logm, std::move(d)).first;
-    }
-    *out = it->second.get();
-    return MASP_HIP_OK;
-}
-
-static uint32_t log2_ceil(uint32_t n) {
-    uint32_t k = 0;
-    while ((1ull << k) < n) ++k;
-    return k;
-}
 
 // environment knobs, read once when a context is created
 static int env_slots() {
@@ -363,22 +119,21 @@ static int fail_shared(masp_hip_ctx* ctx, int rc) {
 static int enqueue_quotient(Slot& sl, const NttDomain& D, const Fr* const in[3], size_t in_stride, uint32_t nrows, bool mont_in, uint32_t np) {
     hipStream_t s = sl.stream;
     const uint32_t m = (uint32_t)D.m, logm = D.logm;
-    dim3 grid((m + 255) / 256, np), block(256);
     int rc;
     for (int i = 0; i < 3; ++i) {
         if ((rc = sl.x0[i].reserve((size_t)m * np)) || (rc = sl.x1[i].reserve((size_t)m * np))) return rc;
         if (mont_in)
-            hipLaunchKernelGGL(k_ntt_copy_bitrev, grid, block, 0, s, in[i], in_stride, nrows, sl.x0[i].p, logm);
+            launch_ntt_copy_bitrev(s, in[i], in_stride, nrows, sl.x0[i].p, logm, np);
         else
-            hipLaunchKernelGGL(k_ntt_load_bitrev, grid, block, 0, s, in[i], in_stride, nrows, sl.x0[i].p, logm);
-        D.passes(s, sl.x0[i].p, D.tw_inv.p, np);                                                       // iNTT (unscaled)
-        hipLaunchKernelGGL(k_ntt_scale_bitrev, grid, block, 0, s, sl.x0[i].p, D.coset_scale.p, sl.x1[i].p, logm);  // * g^k / m
-        D.passes(s, sl.x1[i].p, D.tw_fwd.p, np);                                                       // coset NTT
+            launch_ntt_load_bitrev(s, in[i], in_stride, nrows, sl.x0[i].p, logm, np);
+        D.passes(s, sl.x0[i].p, D.tw_inv.p, np);                                      // iNTT (unscaled)
+        launch_ntt_scale_bitrev(s, sl.x0[i].p, D.coset_scale.p, sl.x1[i].p, logm, np);  // * g^k / m
+        D.passes(s, sl.x1[i].p, D.tw_fwd.p, np);                                      // coset NTT
     }
-    hipLaunchKernelGGL(k_ntt_abc_bitrev, grid, block, 0, s, sl.x1[0].p, sl.x1[1].p, sl.x1[2].p, D.zinv, sl.x0[0].p, logm);
+    launch_ntt_abc_bitrev(s, sl.x1[0].p, sl.x1[1].p, sl.x1[2].p, D.zinv, sl.x0[0].p, logm, np);
     D.passes(s, sl.x0[0].p, D.tw_inv.p, np);
     if ((rc = sl.h.reserve((size_t)m * np))) return rc;
-    hipLaunchKernelGGL(k_fr_scale, grid, block, 0, s, sl.x0[0].p, D.h_scale.p, sl.h.p, m);  // * g^-k / m, leaves Montgomery form
+    launch_fr_scale(s, sl.x0[0].p, D.h_scale.p, sl.h.p, m, np);  // * g^-k / m, leaves Montgomery form
     return MASP_HIP_OK;
 }
 
@@ -401,7 +156,7 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
         for (int i = 0; i < Slot::N_AUX; ++i) HIP_TRY(hipStreamWaitEvent(sl.aux[i], sl.ev_fork, 0));
     }
     // range check (+ Montgomery copy used by the SpMV)
-    hipLaunchKernelGGL(k_fr_to_mont, dim3((nv + 255) / 256, np), dim3(256), 0, s, d_w, w_stride, sl.wm.p, nv, sl.flags.p);
+    launch_fr_to_mont(s, d_w, w_stride, sl.wm.p, nv, np, sl.flags.p);
     const Fr* in[3];
     bool mont_in;
     if (d_abc[0]) {
@@ -412,8 +167,7 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
     } else {
         for (int i = 0; i < 3; ++i) {
             if ((rc = sl.ev[i].reserve((size_t)C.nrows * np))) return rc;
-            hipLaunchKernelGGL(k_r1cs_eval, dim3((C.nrows + 127) / 128, np), dim3(128), 0, s, C.rowptr[i].p, C.row_order[i].p, C.col[i].p,
-                               C.coef[i].p, sl.wm.p, nv, C.n_constraints, C.n_inputs, i, sl.ev[i].p);
+            launch_r1cs_eval(s, C.rowptr[i].p, C.row_order[i].p, C.col[i].p, C.coef[i].p, sl.wm.p, nv, C.n_constraints, C.n_inputs, i, sl.ev[i].p, np);
             in[i] = sl.ev[i].p;
         }
         mont_in = true;
@@ -426,9 +180,9 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
         // the four witness MSMs run on their own streams (forked above) while the main stream runs SpMV -> quotient -> H;
         // everything joins before the assembly
         if ((rc = msm_enqueue(sl.aux[0], C.l, sl.ws_l, (const uint32_t*)(d_w + C.n_inputs), w_stride * 8, sl.res1.p + 1, 4, np))) return rc;
-        if (C.na) hipLaunchKernelGGL(k_gather_scalars, dim3((C.na + 255) / 256, np), dim3(256), 0, sl.aux[1], d_w, w_stride, C.a_var.p, C.na, sl.sa.p);
+        if (C.na) launch_gather_scalars(sl.aux[1], d_w, w_stride, C.a_var.p, C.na, sl.sa.p, np);
         if ((rc = msm_enqueue(sl.aux[1], C.a, sl.ws_a, (const uint32_t*)sl.sa.p, (size_t)C.na * 8, sl.res1.p + 2, 4, np))) return rc;
-        if (C.nbq) hipLaunchKernelGGL(k_gather_scalars, dim3((C.nbq + 255) / 256, np), dim3(256), 0, sl.aux[2], d_w, w_stride, C.b_var.p, C.nbq, sl.sb.p);
+        if (C.nbq) launch_gather_scalars(sl.aux[2], d_w, w_stride, C.b_var.p, C.nbq, sl.sb.p, np);
         if (share_b) {
             if ((rc = msm_sort_enqueue(sl.aux[2], C.b1.n, C.b1.g, sl.ws_b.sort, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, np))) return rc;
             HIP_TRY(hipEventRecord(sl.ev_sort_b, sl.aux[2]));
@@ -450,8 +204,8 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
     } else {
         if ((rc = enqueue_quotient(sl, *C.dom, in, C.nrows, C.nrows, mont_in, np))) return rc;
         // query scalars selected by density
-        if (C.na) hipLaunchKernelGGL(k_gather_scalars, dim3((C.na + 255) / 256, np), dim3(256), 0, s, d_w, w_stride, C.a_var.p, C.na, sl.sa.p);
-        if (C.nbq) hipLaunchKernelGGL(k_gather_scalars, dim3((C.nbq + 255) / 256, np), dim3(256), 0, s, d_w, w_stride, C.b_var.p, C.nbq, sl.sb.p);
+        if (C.na) launch_gather_scalars(s, d_w, w_stride, C.a_var.p, C.na, sl.sa.p, np);
+        if (C.nbq) launch_gather_scalars(s, d_w, w_stride, C.b_var.p, C.nbq, sl.sb.p, np);
         if ((rc = msm_enqueue(s, C.h, sl.ws1, (const uint32_t*)sl.h.p, m8, sl.res1.p + 0, 4, np, prof))) return rc;
         if ((rc = msm_enqueue(s, C.l, sl.ws1, (const uint32_t*)(d_w + C.n_inputs), w_stride * 8, sl.res1.p + 1, 4, np, prof))) return rc;
         if ((rc = msm_enqueue(s, C.a, sl.ws1, (const uint32_t*)sl.sa.p, (size_t)C.na * 8, sl.res1.p + 2, 4, np, prof))) return rc;
@@ -462,7 +216,7 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
             return rc;
         }
     }
-    hipLaunchKernelGGL(k_groth16_assemble, dim3(np), dim3(192), 0, s, C.vk.p, C.fb1.p, C.fb2.p, sl.res1.p, sl.res2.p, d_rs, (size_t)16, d_proof);
+    launch_groth16_assemble(s, C.vk.p, C.fb1.p, C.fb2.p, sl.res1.p, sl.res2.p, d_rs, (size_t)16, d_proof, np);
     return MASP_HIP_OK;
 }
 
@@ -661,7 +415,7 @@ int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* param
         if ((rc = C->rowptr[mi].upload(rp[mi], cs->n_constraints + 1, s)) || (rc = C->col[mi].upload(cl[mi], nnz, s)) ||
             (rc = raw.upload((const Fr*)cf[mi], nnz, s)) || (rc = C->coef[mi].reserve(nnz)))
             return fail(ctx, rc);
-        if (nnz) hipLaunchKernelGGL(k_fr_to_mont, dim3((nnz + 255) / 256), dim3(256), 0, s, raw.p, (size_t)0, C->coef[mi].p, nnz, d_flag.p);
+        if (nnz) launch_fr_to_mont(s, raw.p, (size_t)0, C->coef[mi].p, nnz, 1, d_flag.p);
         if (hipStreamSynchronize(s) != hipSuccess) return fail(ctx, MASP_HIP_E_HIP);
     }
     // verifying-key points used by the prover
@@ -673,11 +427,11 @@ int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* param
         if ((rc = st.reserve(1))) return fail(ctx, rc);
         hipMemsetAsync(st.p, 0, sizeof(int), s);
         VkDevice* v = C->vk.p;
-        hipLaunchKernelGGL(k_g1_import_one, dim3(1), dim3(1), 0, s, raw.p + 0, &v->alpha_g1, st.p);
-        hipLaunchKernelGGL(k_g1_import_one, dim3(1), dim3(1), 0, s, raw.p + 96, &v->beta_g1, st.p);
-        hipLaunchKernelGGL(k_g2_import_one, dim3(1), dim3(1), 0, s, raw.p + 192, &v->beta_g2, st.p);
-        hipLaunchKernelGGL(k_g1_import_one, dim3(1), dim3(1), 0, s, raw.p + 576, &v->delta_g1, st.p);
-        hipLaunchKernelGGL(k_g2_import_one, dim3(1), dim3(1), 0, s, raw.p + 672, &v->delta_g2, st.p);
+        launch_g1_import_one(s, raw.p + 0, &v->alpha_g1, st.p);
+        launch_g1_import_one(s, raw.p + 96, &v->beta_g1, st.p);
+        launch_g2_import_one(s, raw.p + 192, &v->beta_g2, st.p);
+        launch_g1_import_one(s, raw.p + 576, &v->delta_g1, st.p);
+        launch_g2_import_one(s, raw.p + 672, &v->delta_g2, st.p);
         int hst = 0, hflag = 0;
         if (hipMemcpyAsync(&hst, st.p, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipMemcpyAsync(&hflag, d_flag.p, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
@@ -694,8 +448,8 @@ int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* param
         hipMemcpyAsync(p1.p + 1, &v->alpha_g1, sizeof(G1Affine), hipMemcpyDeviceToDevice, s);
         hipMemcpyAsync(p1.p + 2, &v->beta_g1, sizeof(G1Affine), hipMemcpyDeviceToDevice, s);
         hipMemcpyAsync(p2.p, &v->delta_g2, sizeof(G2Affine), hipMemcpyDeviceToDevice, s);
-        hipLaunchKernelGGL((k_fixed_table_xyzz<FpOps>), dim3(3), dim3(64), 0, s, p1.p, C->fb1.p);
-        hipLaunchKernelGGL((k_fixed_table_xyzz<Fp2Ops>), dim3(1), dim3(64), 0, s, p2.p, C->fb2.p);
+        launch_fixed_table_g1(s, p1.p, C->fb1.p, 3);
+        launch_fixed_table_g2(s, p2.p, C->fb2.p, 1);
         if (hipStreamSynchronize(s) != hipSuccess) {
             last_hip_error() = std::string("fixed-base tables failed: ") + hipGetErrorString(hipGetLastError());
             return fail(ctx, MASP_HIP_E_HIP);
@@ -960,9 +714,9 @@ static int msm_block(masp_hip_ctx* ctx, const uint8_t* bases, const uint8_t* sca
     if ((rc = ctx->tmp_scalars.upload((const Fr*)scalars, n, s)) || (rc = res.reserve(1)) || (rc = ctx->tmp_out.reserve(BYTES))) return fail(ctx, rc);
     if ((rc = msm_enqueue(s, B, ws, (const uint32_t*)ctx->tmp_scalars.p, 0, res.p, 1, 1))) return fail(ctx, rc);
     if constexpr (BYTES == 96)
-        hipLaunchKernelGGL(k_g1_export, dim3(1), dim3(1), 0, s, res.p, ctx->tmp_out.p);
+        launch_g1_export(s, res.p, ctx->tmp_out.p);
     else
-        hipLaunchKernelGGL(k_g2_export, dim3(1), dim3(1), 0, s, res.p, ctx->tmp_out.p);
+        launch_g2_export(s, res.p, ctx->tmp_out.p);
     uint8_t tmp[BYTES];
     if (hipMemcpyAsync(tmp, ctx->tmp_out.p, BYTES, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
         last_hip_error() = std::string("msm failed: ") + hipGetErrorString(hipGetLastError());
@@ -1007,7 +761,7 @@ int masp_hip_msm_g1_multi(masp_hip_ctx* ctx, const uint8_t* bases, size_t n, con
     if (B.import_status & (PT_BAD_FLAGS | PT_NOT_CANONICAL)) return MASP_HIP_E_PARAMS_FORMAT;
     if ((rc = ctx->tmp_scalars.upload((const Fr*)scalars, n * np, s)) || (rc = res.reserve(np)) || (rc = d_out.reserve(96 * np))) return fail(ctx, rc);
     if ((rc = msm_enqueue(s, B, ws, (const uint32_t*)ctx->tmp_scalars.p, n * 8, res.p, 1, (uint32_t)np))) return fail(ctx, rc);
-    for (size_t p = 0; p < np; ++p) hipLaunchKernelGGL(k_g1_export, dim3(1), dim3(1), 0, s, res.p + p, d_out.p + 96 * p);
+    for (size_t p = 0; p < np; ++p) launch_g1_export(s, res.p + p, d_out.p + 96 * p);
     std::vector<uint8_t> tmp(96 * np);
     if (hipMemcpyAsync(tmp.data(), d_out.p, tmp.size(), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
         last_hip_error() = std::string("msm failed: ") + hipGetErrorString(hipGetLastError());
@@ -1058,195 +812,21 @@ int masp_hip_ntt(masp_hip_ctx* ctx, uint8_t* data, uint32_t logm, int inverse) {
     if ((rc = sl.w.reserve(m)) || (rc = sl.x0[0].reserve(m)) || (rc = sl.x1[0].reserve(m))) return fail(ctx, rc);
     hipStream_t s = sl.stream;
     if (hipMemcpyAsync(sl.w.p, data, 32 * (size_t)m, hipMemcpyHostToDevice, s) != hipSuccess) return fail(ctx, MASP_HIP_E_HIP);
-    dim3 grid((m + 255) / 256), block(256);
-    hipLaunchKernelGGL(k_ntt_load_bitrev, grid, block, 0, s, sl.w.p, (size_t)0, m, sl.x0[0].p, logm);
+    launch_ntt_load_bitrev(s, sl.w.p, (size_t)0, m, sl.x0[0].p, logm, 1);
     D->passes(s, sl.x0[0].p, inverse ? D->tw_inv.p : D->tw_fwd.p);
     if (inverse) {
         // 1/m scaling: coset_scale[0] = g^0 / m
         Fr* minv_tab = sl.x1[0].p;
         Fr minv = fe_inv(fr_from_u64_mont(m));
-        hipLaunchKernelGGL(k_fr_powers, grid, block, 0, s, minv_tab, m, fe_one<FrCfg>(), minv, 0);
-        hipLaunchKernelGGL(k_fr_scale, grid, block, 0, s, sl.x0[0].p, minv_tab, sl.x0[0].p, m);
+        launch_fr_powers(s, minv_tab, m, fe_one<FrCfg>(), minv, 0);
+        launch_fr_scale(s, sl.x0[0].p, minv_tab, sl.x0[0].p, m, 1);
     }
-    hipLaunchKernelGGL(k_fr_from_mont, grid, block, 0, s, sl.x0[0].p, sl.w.p, m);
+    launch_fr_from_mont(s, sl.x0[0].p, sl.w.p, m);
     if (hipMemcpyAsync(data, sl.w.p, 32 * (size_t)m, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
         last_hip_error() = std::string("ntt failed: ") + hipGetErrorString(hipGetLastError());
         return fail(ctx, MASP_HIP_E_HIP);
     }
     return MASP_HIP_OK;
-}
-
-// ---- parameter generation -------------------------------------------------------------------------
-size_t masp_hip_parameters_max_size(const masp_hip_r1cs* cs) {
-    if (!cs) return 0;
-    size_t nv = (size_t)cs->n_inputs + cs->n_aux;
-    size_t m = (size_t)1 << log2_ceil(cs->n_constraints + cs->n_inputs);
-    return 864 + 6 * 4 + 96 * ((size_t)cs->n_inputs + (m - 1) + cs->n_aux + 2 * nv) + 192 * nv;
-}
-
-int masp_hip_generate_parameters(masp_hip_ctx* ctx, const masp_hip_r1cs* cs, const uint8_t toxic[160], uint8_t* out, size_t cap,
-                                 size_t* out_len) {
-    if (!ctx || !cs || !toxic || !out_len || cs->n_inputs == 0) return MASP_HIP_E_INVALID_ARG;
-    ctx = FIRST_DEVICE(ctx);
-    std::unique_lock<std::shared_mutex> lock(ctx->mu);
-    hipSetDevice(ctx->device);
-    hipStream_t s = ctx->main_stream;
-    Fr tw[5];
-    for (int i = 0; i < 5; ++i) {
-        Fr v = fe_load_le<FrCfg>(toxic + 32 * i);
-        if (fe_canonical_ge_mod(v)) return MASP_HIP_E_SCALAR_RANGE;
-        tw[i] = fe_to_mont(v);
-    }
-    const Fr tau = tw[0], alpha = tw[1], beta = tw[2], gamma = tw[3], delta = tw[4];
-    if (fe_is_zero(gamma) || fe_is_zero(delta)) return MASP_HIP_E_UNEXPECTED_IDENTITY;
-    const uint32_t n_in = cs->n_inputs, n_aux = cs->n_aux, nc = cs->n_constraints, nv = n_in + n_aux;
-    const uint32_t nrows = nc + n_in, logm = log2_ceil(nrows);
-    const size_t m = (size_t)1 << logm;
-    Fr omega = fr_const(FrCfg::ROOT_OF_UNITY);
-    for (uint32_t i = logm; i < 32; ++i) omega = fe_sqr(omega);
-    uint32_t em[2] = {(uint32_t)m, (uint32_t)((uint64_t)m >> 32)};
-    Fr z = fe_sub(fe_pow(tau, em, 2), fe_one<FrCfg>());
-    Fr z_over_m = fe_mul(z, fe_inv(fr_from_u64_mont(m)));
-    Fr dinv = fe_inv(delta), ginv = fe_inv(gamma);
-    int rc;
-    // fixed-base tables (cached)
-    if (!ctx->fb_g1.p) {
-        if ((rc = ctx->fb_g1.reserve(32 * 255)) || (rc = ctx->fb_g2.reserve(32 * 255))) return fail(ctx, rc);
-        G1Affine g1;
-        G2Affine g2;
-        for (int i = 0; i < 12; ++i) {
-            g1.x.v[i] = FpCfg::G1_X[i];
-            g1.y.v[i] = FpCfg::G1_Y[i];
-            g2.x.c0.v[i] = FpCfg::G2_X0[i];
-            g2.x.c1.v[i] = FpCfg::G2_X1[i];
-            g2.y.c0.v[i] = FpCfg::G2_Y0[i];
-            g2.y.c1.v[i] = FpCfg::G2_Y1[i];
-        }
-        hipLaunchKernelGGL((k_setup_fixed_table<FpOps>), dim3(1), dim3(64), 0, s, g1, ctx->fb_g1.p);
-        hipLaunchKernelGGL((k_setup_fixed_table<Fp2Ops>), dim3(1), dim3(64), 0, s, g2, ctx->fb_g2.p);
-    }
-    // Lagrange basis at tau
-    DevBuf<Fr> lag, qt[3];
-    if ((rc = lag.reserve(nrows))) return fail(ctx, rc);
-    hipLaunchKernelGGL(k_setup_lagrange, dim3((nrows + 127) / 128), dim3(128), 0, s, lag.p, nrows, omega, tau, z_over_m);
-    // column-major copies of A, B, C (plain integer bucketing on the host), then one lane per variable
-    const uint32_t* rp[3] = {cs->a_rowptr, cs->b_rowptr, cs->c_rowptr};
-    const uint32_t* cl[3] = {cs->a_col, cs->b_col, cs->c_col};
-    const uint8_t* cf[3] = {cs->a_coef, cs->b_coef, cs->c_coef};
-    DevBuf<int> d_flag;
-    if ((rc = d_flag.reserve(1))) return fail(ctx, rc);
-    hipMemsetAsync(d_flag.p, 0, sizeof(int), s);
-    for (int mi = 0; mi < 3; ++mi) {
-        const uint32_t nnz = rp[mi][nc];
-        std::vector<uint32_t> colptr(nv + 1, 0), rowidx(nnz);
-        std::vector<Fr> coefs(nnz);
-        for (uint32_t t = 0; t < nnz; ++t) {
-            if (cl[mi][t] >= nv) return MASP_HIP_E_INVALID_ARG;
-            ++colptr[cl[mi][t] + 1];
-        }
-        for (uint32_t v = 0; v < nv; ++v) colptr[v + 1] += colptr[v];
-        std::vector<uint32_t> fill(colptr.begin(), colptr.end() - 1);
-        for (uint32_t row = 0; row < nc; ++row)
-            for (uint32_t t = rp[mi][row]; t < rp[mi][row + 1]; ++t) {
-                uint32_t pos = fill[cl[mi][t]]++;
-                rowidx[pos] = row;
-                memcpy(&coefs[pos], cf[mi] + 32 * (size_t)t, 32);
-            }
-        DevBuf<uint32_t> d_colptr, d_rowidx;
-        DevBuf<Fr> d_raw, d_coef;
-        if ((rc = d_colptr.upload(colptr.data(), nv + 1, s)) || (rc = d_rowidx.upload(rowidx.data(), nnz, s)) ||
-            (rc = d_raw.upload(coefs.data(), nnz, s)) || (rc = d_coef.reserve(nnz)) || (rc = qt[mi].reserve(nv)))
-            return fail(ctx, rc);
-        if (nnz) hipLaunchKernelGGL(k_fr_to_mont, dim3((nnz + 255) / 256), dim3(256), 0, s, d_raw.p, (size_t)0, d_coef.p, nnz, d_flag.p);
-        hipLaunchKernelGGL(k_setup_qap, dim3((nv + 127) / 128), dim3(128), 0, s, d_colptr.p, d_rowidx.p, d_coef.p, lag.p, nv, n_in, nc,
-                           mi == 0 ? 1 : 0, qt[mi].p);
-        if (hipStreamSynchronize(s) != hipSuccess) {
-            last_hip_error() = std::string("qap evaluation failed: ") + hipGetErrorString(hipGetLastError());
-            return fail(ctx, MASP_HIP_E_HIP);
-        }
-    }
-    // which variables survive the identity filter of a / b
-    DevBuf<uint8_t> d_nz;
-    if ((rc = d_nz.reserve(2 * (size_t)nv))) return fail(ctx, rc);
-    hipLaunchKernelGGL(k_setup_nonzero, dim3((nv + 255) / 256), dim3(256), 0, s, qt[0].p, nv, d_nz.p);
-    hipLaunchKernelGGL(k_setup_nonzero, dim3((nv + 255) / 256), dim3(256), 0, s, qt[1].p, nv, d_nz.p + nv);
-    std::vector<uint8_t> nz(2 * (size_t)nv);
-    int hflag = 0;
-    if (hipMemcpyAsync(nz.data(), d_nz.p, nz.size(), hipMemcpyDeviceToHost, s) != hipSuccess ||
-        hipMemcpyAsync(&hflag, d_flag.p, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
-        return fail(ctx, MASP_HIP_E_HIP);
-    if (hflag) return MASP_HIP_E_SCALAR_RANGE;
-    std::vector<uint32_t> a_list, b_list;
-    for (uint32_t v = 0; v < nv; ++v) {
-        if (nz[v]) a_list.push_back(v);
-        if (nz[nv + v]) b_list.push_back(v);
-    }
-    // all G1 scalars in one array: [vk: alpha beta delta | ic | h | l | a | b_g1], G2: [beta gamma delta | b_g2]
-    const size_t n_h = m - 1, n_a = a_list.size(), n_b = b_list.size();
-    const size_t o_ic = 3, o_h = o_ic + n_in, o_l = o_h + n_h, o_a = o_l + n_aux, o_b = o_a + n_a, n_g1 = o_b + n_b;
-    const size_t n_g2 = 3 + n_b;
-    const size_t total = 864 + 6 * 4 + 96 * (n_g1 - 3) + 192 * n_b;
-    *out_len = total;
-    if (!out || cap < total) return MASP_HIP_E_INVALID_ARG;
-    DevBuf<Fr> k1, k2, lc;
-    DevBuf<uint32_t> d_alist, d_blist;
-    if ((rc = k1.reserve(n_g1)) || (rc = k2.reserve(n_g2)) || (rc = lc.reserve(nv)) || (rc = d_alist.upload(a_list.data(), n_a, s)) ||
-        (rc = d_blist.upload(b_list.data(), n_b, s)))
-        return fail(ctx, rc);
-    Fr head1[3] = {alpha, beta, delta}, head2[3] = {beta, gamma, delta};
-    if (hipMemcpyAsync(k1.p, head1, sizeof(head1), hipMemcpyHostToDevice, s) != hipSuccess ||
-        hipMemcpyAsync(k2.p, head2, sizeof(head2), hipMemcpyHostToDevice, s) != hipSuccess)
-        return fail(ctx, MASP_HIP_E_HIP);
-    // ic = lc / gamma (inputs), l = lc / delta (aux)
-    hipLaunchKernelGGL(k_setup_lc, dim3((n_in + 255) / 256), dim3(256), 0, s, qt[0].p, qt[1].p, qt[2].p, n_in, alpha, beta, ginv, k1.p + o_ic);
-    if (n_aux)
-        hipLaunchKernelGGL(k_setup_lc, dim3((n_aux + 255) / 256), dim3(256), 0, s, qt[0].p + n_in, qt[1].p + n_in, qt[2].p + n_in, n_aux, alpha,
-                           beta, dinv, k1.p + o_l);
-    hipLaunchKernelGGL(k_setup_h_scalars, dim3((n_h + 255) / 256), dim3(256), 0, s, tau, fe_mul(z, dinv), (uint32_t)n_h, k1.p + o_h);
-    if (n_a) hipLaunchKernelGGL(k_setup_gather, dim3((n_a + 255) / 256), dim3(256), 0, s, qt[0].p, d_alist.p, (uint32_t)n_a, k1.p + o_a);
-    if (n_b) {
-        hipLaunchKernelGGL(k_setup_gather, dim3((n_b + 255) / 256), dim3(256), 0, s, qt[1].p, d_blist.p, (uint32_t)n_b, k1.p + o_b);
-        hipLaunchKernelGGL(k_setup_gather, dim3((n_b + 255) / 256), dim3(256), 0, s, qt[1].p, d_blist.p, (uint32_t)n_b, k2.p + 3);
-    }
-    DevBuf<uint8_t> p1, p2;
-    if ((rc = p1.reserve(96 * n_g1)) || (rc = p2.reserve(192 * n_g2))) return fail(ctx, rc);
-    hipLaunchKernelGGL((k_setup_fixed_mul<FpOps, 96>), dim3((n_g1 + 63) / 64), dim3(64), 0, s, ctx->fb_g1.p, k1.p, (uint32_t)n_g1, 1, p1.p);
-    hipLaunchKernelGGL((k_setup_fixed_mul<Fp2Ops, 192>), dim3((n_g2 + 63) / 64), dim3(64), 0, s, ctx->fb_g2.p, k2.p, (uint32_t)n_g2, 1, p2.p);
-    std::vector<uint8_t> h1(96 * n_g1), h2(192 * n_g2);
-    if (hipMemcpyAsync(h1.data(), p1.p, h1.size(), hipMemcpyDeviceToHost, s) != hipSuccess ||
-        hipMemcpyAsync(h2.data(), p2.p, h2.size(), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-        last_hip_error() = std::string("parameter generation failed: ") + hipGetErrorString(hipGetLastError());
-        return fail(ctx, MASP_HIP_E_HIP);
-    }
-    // bellman wire format
-    uint8_t* w = out;
-    auto put = [&](const uint8_t* src, size_t n) {
-        memcpy(w, src, n);
-        w += n;
-    };
-    auto put_len = [&](size_t n) {
-        uint8_t b[4] = {(uint8_t)(n >> 24), (uint8_t)(n >> 16), (uint8_t)(n >> 8), (uint8_t)n};
-        put(b, 4);
-    };
-    put(&h1[0], 96);           // alpha_g1
-    put(&h1[96], 96);          // beta_g1
-    put(&h2[0], 192);          // beta_g2
-    put(&h2[192], 192);        // gamma_g2
-    put(&h1[192], 96);         // delta_g1
-    put(&h2[384], 192);        // delta_g2
-    put_len(n_in);
-    put(&h1[96 * o_ic], 96 * (size_t)n_in);
-    put_len(n_h);
-    put(&h1[96 * o_h], 96 * n_h);
-    put_len(n_aux);
-    put(&h1[96 * o_l], 96 * (size_t)n_aux);
-    put_len(n_a);
-    put(&h1[96 * o_a], 96 * n_a);
-    put_len(n_b);
-    put(&h1[96 * o_b], 96 * n_b);
-    put_len(n_b);
-    put(&h2[192 * 3], 192 * n_b);
-    return (size_t)(w - out) == total ? MASP_HIP_OK : MASP_HIP_E_INVALID_ARG;
 }
 
 // ---- measurement hooks ----------------------------------------------------------------------------

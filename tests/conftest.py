@@ -22,6 +22,6 @@ def _native_libraries_built():
     if not all(os.path.exists(p) for p in need):
         env = dict(os.environ)
         env["PATH"] = "/opt/rocm/bin:" + env.get("PATH", "")
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "masp_amd", "csrc")], env=env)
+        subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "masp_amd", "csrc")], env=env)
     if not os.path.exists(os.path.join(ROOT, "oracle", "_build", "liboracle.so")):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
