@@ -21,6 +21,12 @@ template <class O>
 struct Xyzz {
     typename O::T X, Y, ZZ, ZZZ;
 };
+// Row of an MSM window table: an affine point padded to whole 128-byte lines (96 -> 128 B on G1, 192 -> 256 B on G2), so
+// that a gathered row never straddles two lines (at a 96-byte stride half of all rows did: ~1.5 lines fetched per row).
+template <class O>
+struct alignas(128) TabRow {
+    Affine<O> p;
+};
 
 template <class O>
 MASP_HD bool aff_is_inf(const Affine<O>& p) {

@@ -249,8 +249,59 @@ __host__ inline Fe<C> fe_mul(const Fe<C>& a, const Fe<C>& b) {
     fe_reduce_once(r);
     return r;
 }
+// Montgomery square.  Device form: the same product scanning with the operand doubled ONCE up front (d = 2a < 2^(32N):
+// both moduli leave spare top bits).  With B = 2^32 and P_j = a mod B^j:
+//     2 sum_{i<j} a_i a_j B^(i+j) = sum_j a_j B^j (2 P_j),      2 P_j = sum_{i<j} d_i B^i + B^j msb(a_{j-1})
+// (the limbs of d below j are those of 2 P_j except for the bit that the shift pushed out of limb j-1), so column k is
+//     sum_{i < k-i} d_i a_{k-i}  +  [k = 2j] (a_j^2 + msb(a_{j-1}) a_j)  +  the reduction terms:
+// N(N+1)/2 + (N-1) + N^2 multiply-adds instead of 2 N^2 (233 instead of 288 for N = 12).
+template <int K, class C>
+__device__ __forceinline__ void sqr_columns_lo(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* a2, uint32_t* m) {
+    if constexpr (K < C::N) {
+        macs_vv<0, (K + 1) / 2, K, C>(acc, c2, a2, a);
+        if constexpr (K % 2 == 0) mac_vv(acc, c2, a[K / 2], a[K / 2]);
+        if constexpr (K % 2 == 0 && K >= 2) mac_vv(acc, c2, a[K / 2 - 1] >> 31, a[K / 2]);
+        macs_vs<0, K, K, C>(acc, c2, m);
+        m[K] = (uint32_t)acc * C::INV;
+        mac_vs(acc, c2, m[K], C::MOD[0]);  // low word is now 0
+        acc = (acc >> 32) | ((uint64_t)c2 << 32);
+        c2 = 0;
+        sqr_columns_lo<K + 1, C>(acc, c2, a, a2, m);
+    }
+}
+template <int K, class C>
+__device__ __forceinline__ void sqr_columns_hi(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* a2, const uint32_t* m, uint32_t* r) {
+    if constexpr (K < 2 * C::N - 1) {
+        macs_vv<K - C::N + 1, (K + 1) / 2, K, C>(acc, c2, a2, a);
+        if constexpr (K % 2 == 0) {
+            mac_vv(acc, c2, a[K / 2], a[K / 2]);
+            mac_vv(acc, c2, a[K / 2 - 1] >> 31, a[K / 2]);
+        }
+        macs_vs<K - C::N + 1, C::N, K, C>(acc, c2, m);
+        r[K - C::N] = (uint32_t)acc;
+        acc = (acc >> 32) | ((uint64_t)c2 << 32);
+        c2 = 0;
+        sqr_columns_hi<K + 1, C>(acc, c2, a, a2, m, r);
+    }
+}
 template <class C>
-MASP_HD Fe<C> fe_sqr(const Fe<C>& a) {
+__device__ __forceinline__ Fe<C> fe_sqr(const Fe<C>& a) {
+    constexpr int N = C::N;
+    uint32_t m[N], a2[N];
+    a2[0] = a.v[0] << 1;
+#pragma unroll
+    for (int i = 1; i < N; ++i) a2[i] = __funnelshift_l(a.v[i - 1], a.v[i], 1);
+    Fe<C> r;
+    uint64_t acc = 0;
+    uint32_t c2 = 0;
+    sqr_columns_lo<0, C>(acc, c2, a.v, a2, m);
+    sqr_columns_hi<N, C>(acc, c2, a.v, a2, m, r.v);
+    r.v[N - 1] = (uint32_t)acc;  // < 2p < 2^(32N)
+    fe_reduce_once(r);
+    return r;
+}
+template <class C>
+__host__ inline Fe<C> fe_sqr(const Fe<C>& a) {
     return fe_mul(a, a);
 }
 // Out-of-line product: used where code size matters more than the call (G2, cold kernels, serial tails).
@@ -270,6 +321,18 @@ __device__ __noinline__ FpRegs fp_mul_call(u32x4 a0, u32x4 a1, u32x4 a2, u32x4 b
     b.v[4] = b1.x; b.v[5] = b1.y; b.v[6] = b1.z; b.v[7] = b1.w;
     b.v[8] = b2.x; b.v[9] = b2.y; b.v[10] = b2.z; b.v[11] = b2.w;
     Fe<FpCfg> r = fe_mul(a, b);
+    FpRegs o;
+    o.q0 = u32x4{r.v[0], r.v[1], r.v[2], r.v[3]};
+    o.q1 = u32x4{r.v[4], r.v[5], r.v[6], r.v[7]};
+    o.q2 = u32x4{r.v[8], r.v[9], r.v[10], r.v[11]};
+    return o;
+}
+__device__ __noinline__ FpRegs fp_sqr_call(u32x4 a0, u32x4 a1, u32x4 a2) {
+    Fe<FpCfg> a;
+    a.v[0] = a0.x; a.v[1] = a0.y; a.v[2] = a0.z; a.v[3] = a0.w;
+    a.v[4] = a1.x; a.v[5] = a1.y; a.v[6] = a1.z; a.v[7] = a1.w;
+    a.v[8] = a2.x; a.v[9] = a2.y; a.v[10] = a2.z; a.v[11] = a2.w;
+    Fe<FpCfg> r = fe_sqr(a);
     FpRegs o;
     o.q0 = u32x4{r.v[0], r.v[1], r.v[2], r.v[3]};
     o.q1 = u32x4{r.v[4], r.v[5], r.v[6], r.v[7]};
@@ -298,6 +361,24 @@ MASP_HD Fe<C> fe_mul_nc(const Fe<C>& a, const Fe<C>& b) {
     }
 #else
     return fe_mul(a, b);
+#endif
+}
+
+template <class C>
+MASP_HD Fe<C> fe_sqr_nc(const Fe<C>& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (C::N == 12) {
+        FpRegs o = fp_sqr_call(u32x4{a.v[0], a.v[1], a.v[2], a.v[3]}, u32x4{a.v[4], a.v[5], a.v[6], a.v[7]}, u32x4{a.v[8], a.v[9], a.v[10], a.v[11]});
+        Fe<C> r;
+        r.v[0] = o.q0.x; r.v[1] = o.q0.y; r.v[2] = o.q0.z; r.v[3] = o.q0.w;
+        r.v[4] = o.q1.x; r.v[5] = o.q1.y; r.v[6] = o.q1.z; r.v[7] = o.q1.w;
+        r.v[8] = o.q2.x; r.v[9] = o.q2.y; r.v[10] = o.q2.z; r.v[11] = o.q2.w;
+        return r;
+    } else {
+        return fe_mul_ref(a, a);
+    }
+#else
+    return fe_mul(a, a);
 #endif
 }
 
@@ -336,7 +417,7 @@ MASP_NOINLINE Fe<C> fe_pow(const Fe<C>& a, const uint32_t* e, int nlimbs) {
     bool started = false;
     for (int i = nlimbs - 1; i >= 0; --i)
         for (int b = 31; b >= 0; --b) {
-            if (started) r = fe_mul_nc(r, r);
+            if (started) r = fe_sqr_nc(r);
             if ((e[i] >> b) & 1) {
                 r = started ? fe_mul_nc(r, a) : a;
                 started = true;
@@ -561,7 +642,7 @@ struct Fp2 {
 struct FpMulCold {
     typedef Fp T;
     static MASP_HD T mul(const T& a, const T& b) { return fe_mul_nc(a, b); }
-    static MASP_HD T sqr(const T& a) { return fe_mul_nc(a, a); }
+    static MASP_HD T sqr(const T& a) { return fe_sqr_nc(a); }
 };
 struct FpOps {
     typedef Fp T;

@@ -40,7 +40,7 @@ namespace masp {
 // raw uncompressed bytes -> T[0][i]; status word collects PT_* bits (infinity is legal in a generic
 // MSM and contributes nothing).
 template <class O, int BYTES>
-__global__ void k_msm_import(const uint8_t* __restrict__ raw, Affine<O>* __restrict__ tab, uint32_t n, int* __restrict__ status) {
+__global__ void k_msm_import(const uint8_t* __restrict__ raw, TabRow<O>* __restrict__ tab, uint32_t n, int* __restrict__ status) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Affine<O> p;
@@ -56,19 +56,19 @@ __global__ void k_msm_import(const uint8_t* __restrict__ raw, Affine<O>* __restr
     } else if (st & PT_INFINITY) {
         atomicOr(status, PT_INFINITY);
     }
-    tab[i] = p;
+    tab[i].p = p;
 }
 // T[j][i] = 2^c * T[j-1][i]
 template <class O>
-__global__ void k_msm_precompute(Affine<O>* __restrict__ tab, uint32_t n, int c, int W) {
+__global__ void k_msm_precompute(TabRow<O>* __restrict__ tab, uint32_t n, int c, int W) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Affine<O> p = tab[i];
+    Affine<O> p = tab[i].p;
     for (int j = 1; j < W; ++j) {
         Xyzz<O> q = xyzz_dbl_affine(p);
         for (int k = 1; k < c; ++k) q = xyzz_dbl(q);
         p = xyzz_to_affine(q);
-        tab[(size_t)j * n + i] = p;
+        tab[(size_t)j * n + i].p = p;
     }
 }
 

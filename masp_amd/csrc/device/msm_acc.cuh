@@ -20,7 +20,7 @@ namespace masp {
 #endif
 template <class O>
 __global__ void __launch_bounds__(64, MASP_ACC_MIN_WAVES)
-k_msm_accumulate(const Affine<O>* __restrict__ tab, const uint32_t* __restrict__ sorted, size_t ent_stride,
+k_msm_accumulate(const TabRow<O>* __restrict__ tab, const uint32_t* __restrict__ sorted, size_t ent_stride,
                  const uint32_t* __restrict__ start, uint32_t nb, uint32_t nchunks, Xyzz<O>* __restrict__ part) {
     const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= nchunks) return;
@@ -51,7 +51,7 @@ k_msm_accumulate(const Affine<O>* __restrict__ tab, const uint32_t* __restrict__
             } while (pos >= next);
         }
         uint32_t e = sorted[pos];
-        xyzz_madd(acc, tab[e & 0x7fffffffu], (e >> 31) != 0);
+        xyzz_madd(acc, tab[e & 0x7fffffffu].p, (e >> 31) != 0);
     }
     part[ch + b] = acc;
 }

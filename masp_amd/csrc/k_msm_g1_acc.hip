@@ -2,6 +2,6 @@
 #include "msm_acc_impl.cuh"
 
 namespace masp {
-template void msm_launch_accumulate<FpOps>(hipStream_t, const Affine<FpOps>*, const uint32_t*, size_t, const uint32_t*, uint32_t, uint32_t,
+template void msm_launch_accumulate<FpOps>(hipStream_t, const TabRow<FpOps>*, const uint32_t*, size_t, const uint32_t*, uint32_t, uint32_t,
                                            Xyzz<FpOps>*, uint32_t);
 }  // namespace masp

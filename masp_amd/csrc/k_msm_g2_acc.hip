@@ -2,6 +2,6 @@
 #include "msm_acc_impl.cuh"
 
 namespace masp {
-template void msm_launch_accumulate<Fp2Ops>(hipStream_t, const Affine<Fp2Ops>*, const uint32_t*, size_t, const uint32_t*, uint32_t, uint32_t,
+template void msm_launch_accumulate<Fp2Ops>(hipStream_t, const TabRow<Fp2Ops>*, const uint32_t*, size_t, const uint32_t*, uint32_t, uint32_t,
                                             Xyzz<Fp2Ops>*, uint32_t);
 }  // namespace masp

@@ -20,7 +20,7 @@ template <class O, int BYTES>
 struct MsmBases {
     MsmGeom g{};
     uint32_t n = 0;
-    Affine<O>* tab = nullptr;  // W * n rows
+    TabRow<O>* tab = nullptr;  // W * n rows of 128 / 256 bytes
     int import_status = 0;     // PT_* bits seen while decoding
 
     ~MsmBases() { release(); }
@@ -214,7 +214,7 @@ int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb
 
 // The dominant kernel on its own: bucket accumulation of the sorted digit list (k_msm_accumulate<O>).   [msm_acc_impl.cuh]
 template <class O>
-void msm_launch_accumulate(hipStream_t s, const Affine<O>* tab, const uint32_t* sorted, size_t ent_stride, const uint32_t* start, uint32_t nb,
+void msm_launch_accumulate(hipStream_t s, const TabRow<O>* tab, const uint32_t* sorted, size_t ent_stride, const uint32_t* start, uint32_t nb,
                            uint32_t nchunks, Xyzz<O>* part, uint32_t np);
 
 // Bucket accumulation + reduction of the MSM whose digits were sorted into `sb` (same n, geometry and batch size):

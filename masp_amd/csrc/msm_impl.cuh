@@ -12,7 +12,7 @@ int MsmBases<O, BYTES>::load_device(const uint8_t* d_raw, uint32_t n_, hipStream
         n = n_;
         g = force_c ? msm_geom(force_c) : pick_geom(std::min(n_eff, n_));
         if (n == 0) return MASP_HIP_OK;
-        HIP_TRY(hipMalloc(&tab, sizeof(Affine<O>) * (size_t)g.W * n));
+        HIP_TRY(hipMalloc(&tab, sizeof(TabRow<O>) * (size_t)g.W * n));
         int* d_status;
         HIP_TRY(hipMalloc(&d_status, sizeof(int)));
         HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(int), s));

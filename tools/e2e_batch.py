@@ -5,7 +5,6 @@ resident in HBM), this includes witness generation, the H2D copies and the pairi
     python tools/e2e_batch.py [N=256] [threads=os.cpu_count()]
 """
 import os
-import random
 import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -13,32 +12,15 @@ from concurrent.futures import ThreadPoolExecutor
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 os.environ.setdefault("MASP_HIP_SLOTS", "4")
-os.environ.setdefault("MASP_HIP_BATCH", "96")
+os.environ.setdefault("MASP_HIP_BATCH", "128")
 
 from masp_amd import host as H                     # noqa: E402
+from masp_amd import workload as W                 # noqa: E402
 from masp_amd.prover import LocalTxProver, _int    # noqa: E402
-
-R = H.FR_MODULUS
 
 
 def spend_description(seed):
-    rng = random.Random(seed)
-    ident = H.asset_identifier(b"benchmark")
-    rs = lambda: rng.randrange(H.JUBJUB_ORDER)     # noqa: E731
-    ak = H.jubjub_mul(H.point_bytes(*H.generator_uv(4)), rs())
-    nsk, ar, rcm, rcv = rs(), rs(), rs(), rs()
-    siblings = [rng.randrange(R) for _ in range(32)]
-    pos = rng.getrandbits(32)
-    while True:
-        d = bytes(rng.getrandbits(8) for _ in range(11))
-        try:
-            cmu, _ = H.spend_leaf(ak, nsk, d, rcm, ident, 1)
-            break
-        except H.HostError:
-            pass
-    anchor = H.merkle_root(cmu, siblings, pos)
-    return ("spend", dict(proof_generation_key=(ak, nsk), diversifier=d, rcm=rcm, ar=ar, asset_type=ident, value=1, anchor=anchor,
-                          merkle_path=(siblings, pos), rcv=rcv))
+    return W.description("spend", seed)
 
 
 def main():

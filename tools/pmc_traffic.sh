@@ -1,31 +1,58 @@
 #!/bin/bash
-# HBM traffic of the dominant kernel (k_msm_accumulate<G1>) from the PMC counters, in two separate rocprofv3 passes
-# (FETCH_SIZE and WRITE_SIZE do not fit one pass; --pmc is never combined with traces other than --kernel-trace).
-# Writes profiles/pmc_traffic.json.  usage (on the GPU box): tools/pmc_traffic.sh
+# HBM traffic of the dominant kernel (k_msm_accumulate<G1>) from the PMC counters, as MI355X_MICROARCH.md (§HBM, §rocprofv3
+# PMC slots) prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 passes (they do not fit one), --pmc combined with
+# nothing but --kernel-trace, and FETCH_SIZE calibrated on a known byte count in THIS access pattern (tools/pmc_calib.hip:
+# one 96-byte row gathered per lane at a 128-byte stride from a 3 GiB table) instead of assuming the x2 of wide streams.
+# The bench runs its default workload: 256 DISTINCT Spend witnesses per step.  Writes profiles/pmc_traffic.json.
+# usage (on the GPU box): tools/pmc_traffic.sh
 export TMPDIR=/tmp
 root=$PWD
 out=$root/gpurun_out/pmc
 rm -rf $out; mkdir -p $out
+(cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/calib -o run -- $root/tools/_build/pmc_calib > $out/calib.log 2>&1)
 for c in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/$c -o run -- python $root/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $out/$c.log 2>&1)
+  (cd /tmp && rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/$c -o run -- python $root/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $out/$c.log 2>&1)
 done
 python - <<PY
 import csv, glob, json, os
+out = "$out"
+def rows_of(d, counter):
+    f = glob.glob("%s/%s/**/*counter_collection.csv" % (out, d), recursive=True)[0]
+    return [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+# ---- calibration: reported KB per launch vs the bytes of the 128-byte lines the gather touches
+cal = rows_of("calib", "FETCH_SIZE")
+rows_per_launch = (1 << 20) * 16
+def avg(rows, pat):
+    v = [float(r["Counter_Value"]) for r in rows if pat in r["Kernel_Name"]]
+    return sum(v) / len(v)
+rep128, rep96 = avg(cal, "k_calib_gather<128>"), avg(cal, "k_calib_gather<96>")
+true128 = rows_per_launch * 128.0          # one line per row
+true96 = rows_per_launch * 1.5 * 128.0     # a 96-byte row at a 96-byte stride touches 1.5 lines on average
+factor = true128 / (rep128 * 1024.0)
+# ---- the kernel itself
 res = {}
-batch = int(os.environ.get("MASP_HIP_BATCH", "96"))
+batch = int(os.environ.get("MASP_HIP_BATCH", "128"))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob("$out/%s/**/*counter_collection.csv" % c, recursive=True)[0]
-    rows = [r for r in csv.DictReader(open(f)) if "k_msm_accumulate<masp::FpOps>" in r["Kernel_Name"] and r["Counter_Name"] == c]
+    rows = [r for r in rows_of(c, c) if "k_msm_accumulate<masp::FpOps>" in r["Kernel_Name"]]
     full = max(int(r["Grid_Size"]) for r in rows)          # the full batches (lone-proof launches have another grid)
     vals = [float(r["Counter_Value"]) for r in rows if int(r["Grid_Size"]) == full]
     res[c] = (sum(vals) / len(vals), len(vals))
 fetch_kb, n1 = res["FETCH_SIZE"]; write_kb, n2 = res["WRITE_SIZE"]
-json.dump({
+alg = batch * 48725632 / 4.0
+doc = {
  "kernel": "k_msm_accumulate<G1>",
- "command": "tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline",
+ "command": "tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline (256 distinct Spend witnesses per step); calibration pass on tools/_build/pmc_calib",
+ "calibration": {"pattern": "one 96-byte row (6 x global_load_dwordx4) per lane at a random index, 3 GiB table, 2^24 rows per launch",
+                 "stride128_reported_KB": rep128, "stride128_line_bytes": true128, "stride96_reported_KB": rep96, "stride96_expected_line_bytes": true96,
+                 "bytes_per_reported_byte": factor, "stride96_over_stride128_reported": rep96 / rep128,
+                 "reading": "FETCH_SIZE x %.3f = bytes of 128-B lines fetched for this gather pattern (the guide's x2 holds for wide coalesced streams)" % factor},
  "FETCH_SIZE_KB_avg_per_launch": fetch_kb, "WRITE_SIZE_KB_avg_per_launch": write_kb, "launches_sampled": min(n1, n2),
- "hbm_bytes_per_launch": (fetch_kb + write_kb) * 1024.0, "proofs_per_launch": batch,
- "note": "one launch covers one G1 query (h, l, a or b_g1) of a batch of %d proofs; counters averaged over the four queries. FETCH_SIZE is used as reported: the gfx950 x2 correction of MI355X_MICROARCH.md is calibrated for wide coalesced streams only, these are 96-byte gathers of window-table rows (doubling it gives the upper bound). Traffic exceeds the algorithmic bytes (n x 128 B per proof) because every non-zero digit reads its own 96-byte table row: that is the HBM-capacity-for-ALU trade of DESIGN.md." % batch,
-}, open("$root/profiles/pmc_traffic.json", "w"), indent=1)
-print(open("$root/profiles/pmc_traffic.json").read())
+ "fetch_bytes_per_launch_calibrated": fetch_kb * 1024.0 * factor, "write_bytes_per_launch_as_reported": write_kb * 1024.0,
+ "hbm_bytes_per_launch": fetch_kb * 1024.0 * factor + write_kb * 1024.0, "proofs_per_launch": batch,
+ "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (fetch_kb * 1024.0 * factor + write_kb * 1024.0) / alg,
+ "note": "one launch covers one G1 query (h, l, a or b_g1) of a batch of %d proofs; counters averaged over the four queries. Traffic exceeds the algorithmic bytes (n x 128 B per proof) because every non-zero window digit reads its own table row (16 rows per full-width scalar of h, 22 per non-trivial witness scalar): the HBM-capacity-for-ALU trade of DESIGN.md, not re-reads of the same data. WRITE_SIZE is uncalibrated (partial sums: 144-byte stores)." % batch,
+}
+json.dump(doc, open("$root/profiles/pmc_traffic.json", "w"), indent=1)
+print(json.dumps(doc, indent=1))
 PY
+cp $root/profiles/pmc_traffic.json $root/gpurun_out/pmc_traffic.json   # gpurun only merges gpurun_out/ back: copy it into profiles/ afterwards

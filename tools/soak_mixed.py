@@ -6,52 +6,28 @@ with a serial accumulation.  A stability run as much as a measurement.
     python tools/soak_mixed.py [N=4096]
 """
 import os
-import random
 import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-os.environ.setdefault("MASP_HIP_BATCH", "96")
+os.environ.setdefault("MASP_HIP_BATCH", "128")
 
-import e2e_batch as E                                   # noqa: E402
+from masp_amd import workload as W                     # noqa: E402
 from masp_amd import host as H                         # noqa: E402
 from masp_amd.prover import LocalTxProver, _int         # noqa: E402
-
-
-def output_description(seed):
-    rng = random.Random(seed)
-    sc = lambda: rng.randrange(1, H.JUBJUB_ORDER)       # noqa: E731
-    ident = H.asset_identifier(b"benchmark")
-    pk = H.jubjub_mul(H.point_bytes(*H.generator_uv(0)), sc())
-    while True:
-        d = bytes(rng.getrandbits(8) for _ in range(11))
-        try:
-            H.output_assignment(1, d, pk, 1, ident, 1, 1)
-            break
-        except H.HostError:
-            pass
-    return ("output", dict(esk=sc(), payment_address=(d, pk), rcm=sc(), asset_type=ident, value=1 + seed % 1000, rcv=sc()))
-
-
-def convert_description(seed):
-    rng = random.Random(seed)
-    gen = H.asset_generator(H.asset_identifier(b"asset %d" % (seed % 7)))
-    sib = [rng.randrange(H.FR_MODULUS) for _ in range(32)]
-    pos = rng.getrandbits(32)
-    return ("convert", dict(allowed_conversion=gen, value=1 + rng.getrandbits(40), anchor=H.merkle_root(H.convert_cmu(gen), sib, pos),
-                            merkle_path=(sib, pos), rcv=rng.randrange(1, H.JUBJUB_ORDER)))
 
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     prover = LocalTxProver.with_synthetic_parameters(seed=11)
     out_vk = H.PreparedVerifyingKey(prover.parameters["output"])
-    make = (E.spend_description, output_description, convert_description)
+    from concurrent.futures import ThreadPoolExecutor
     t = time.time()
-    descs = [make[i % 3](i) for i in range(n)]
+    with ThreadPoolExecutor(H.effective_cpus()) as ex:       # instances shaped like the reference's benches (masp_amd/workload.py)
+        descs = list(ex.map(lambda i: W.description(("spend", "output", "convert")[i % 3], i), range(n)))
     print("%d descriptions built in %.1f s" % (n, time.time() - t))
-    prover.prove_batch(prover.new_sapling_proving_context(), descs[:min(n, 15 * 96)])      # warm-up: every slot, every circuit, full batches
+    prover.prove_batch(prover.new_sapling_proving_context(), descs[:min(n, 12 * 128)])      # warm-up: every slot, every circuit, full batches
     ctx = prover.new_sapling_proving_context()
     seen = []
     t0 = time.time()
