@@ -81,6 +81,27 @@ inline void inv_pair(const Fr& c, Fr& inv_plus, Fr& inv_minus) {
     inv_minus = i * p;
 }
 
+// Affine coordinates of a whole chain of points from ONE field inversion (Montgomery's trick on the Z coordinates).  The
+// in-circuit Edwards additions / doublings allocate the affine result of every step (circuit/ecc.rs `EdwardsPoint::{add,
+// double}`), i.e. one inversion per step when computed step by step: ~1 050 of the ~1 500 inversions of a Spend.  The chains
+// of a fixed-base multiplication (table lookups) and of a variable-base multiplication are known in advance from the bits,
+// so they are first run natively in extended coordinates and converted here; the gadgets then take the results as hints.
+inline void batch_to_affine(const std::vector<JPoint>& pts, std::vector<JAffine>& out) {
+    const size_t n = pts.size();
+    out.resize(n);
+    if (!n) return;
+    std::vector<Fr> pre(n);
+    pre[0] = pts[0].Z;
+    for (size_t k = 1; k < n; ++k) pre[k] = pre[k - 1] * pts[k].Z;
+    Fr inv;
+    if (!pre[n - 1].invert(inv)) throw SynthesisError("DivisionByZero");  // Z = 0 does not occur on the complete curve
+    for (size_t k = n; k-- > 0;) {
+        const Fr zi = k ? inv * pre[k - 1] : inv;
+        inv = inv * pts[k].Z;
+        out[k] = {pts[k].U * zi, pts[k].V * zi};
+    }
+}
+
 // ------------------------------------------------------------------------------------------- Edwards gadget
 struct EdwardsPoint {
     AllocatedNum u, v;
@@ -99,7 +120,8 @@ struct EdwardsPoint {
         AllocatedNum v = AllocatedNum::alloc(cs, a.v);
         return interpret(cs, u, v);
     }
-    EdwardsPoint dbl(CS& cs) const {
+    // `hint`: the affine result if the caller already knows it (batch_to_affine); otherwise one inversion here
+    EdwardsPoint dbl(CS& cs, const JAffine* hint = nullptr) const {
         // T = (u + v)^2
         Fr tv = (u.value + v.value).square();
         AllocatedNum t = AllocatedNum::alloc(cs, tv);
@@ -110,14 +132,14 @@ struct EdwardsPoint {
         MASP_ENFORCE(cs, LC().add(a.var, edwards_d()), LC(a.var), LC(c.var));
         // u3 = 2A / (1 + C),  v3 = (T - 2A) / (1 - C): both inverses from one inversion of (1 + C)(1 - C)
         Fr ip = Fr::zero(), im = Fr::zero();
-        if (cs.has_witness()) inv_pair(c.value, ip, im);
-        AllocatedNum u3 = AllocatedNum::alloc(cs, a.value.dbl() * ip);
+        if (cs.has_witness() && !hint) inv_pair(c.value, ip, im);
+        AllocatedNum u3 = AllocatedNum::alloc(cs, hint ? hint->u : a.value.dbl() * ip);
         MASP_ENFORCE(cs, LC(ONE).add(c.var), LC(u3.var), LC(a.var).add(a.var));
-        AllocatedNum v3 = AllocatedNum::alloc(cs, (t.value - a.value.dbl()) * im);
+        AllocatedNum v3 = AllocatedNum::alloc(cs, hint ? hint->v : (t.value - a.value.dbl()) * im);
         MASP_ENFORCE(cs, LC(ONE).sub(c.var), LC(v3.var), LC(t.var).sub(a.var).sub(a.var));
         return {u3, v3};
     }
-    EdwardsPoint add(CS& cs, const EdwardsPoint& o) const {
+    EdwardsPoint add(CS& cs, const EdwardsPoint& o, const JAffine* hint = nullptr) const {
         // U = (u1 + v1)(u2 + v2)
         AllocatedNum uu = AllocatedNum::alloc(cs, (u.value + v.value) * (o.u.value + o.v.value));
         MASP_ENFORCE(cs, LC(u.var).add(v.var), LC(o.u.var).add(o.v.var), LC(uu.var));
@@ -126,10 +148,10 @@ struct EdwardsPoint {
         AllocatedNum c = AllocatedNum::alloc(cs, a.value * b.value * edwards_d());
         MASP_ENFORCE(cs, LC().add(a.var, edwards_d()), LC(b.var), LC(c.var));
         Fr ip = Fr::zero(), im = Fr::zero();
-        if (cs.has_witness()) inv_pair(c.value, ip, im);
-        AllocatedNum u3 = AllocatedNum::alloc(cs, (a.value + b.value) * ip);
+        if (cs.has_witness() && !hint) inv_pair(c.value, ip, im);
+        AllocatedNum u3 = AllocatedNum::alloc(cs, hint ? hint->u : (a.value + b.value) * ip);
         MASP_ENFORCE(cs, LC(ONE).add(c.var), LC(u3.var), LC(a.var).add(b.var));
-        AllocatedNum v3 = AllocatedNum::alloc(cs, (uu.value - a.value - b.value) * im);
+        AllocatedNum v3 = AllocatedNum::alloc(cs, hint ? hint->v : (uu.value - a.value - b.value) * im);
         MASP_ENFORCE(cs, LC(ONE).sub(c.var), LC(v3.var), LC(uu.var).sub(a.var).sub(b.var));
         return {u3, v3};
     }
@@ -157,11 +179,28 @@ struct EdwardsPoint {
         return {up, vp};
     }
     EdwardsPoint mul(CS& cs, const std::vector<Boolean>& by) const {
+        // the two chains (2^i P and the running sum) natively first: one inversion for all their affine coordinates
+        std::vector<JAffine> dbl_aff, sum_aff;
+        if (cs.has_witness() && by.size() > 1) {
+            std::vector<JPoint> dbls, sums;
+            JPoint cur = JPoint::from_affine({u.value, v.value}), acc = JPoint::identity();
+            for (size_t i = 0; i < by.size(); ++i) {
+                if (i > 0) {
+                    cur = cur.dbl();
+                    dbls.push_back(cur);
+                }
+                const JPoint sel = by[i].value() ? cur : JPoint::identity();
+                acc = i == 0 ? sel : acc.add(sel);
+                if (i > 0) sums.push_back(acc);
+            }
+            batch_to_affine(dbls, dbl_aff);
+            batch_to_affine(sums, sum_aff);
+        }
         EdwardsPoint curbase = *this, result = *this;
         for (size_t i = 0; i < by.size(); ++i) {
-            if (i > 0) curbase = curbase.dbl(cs);
+            if (i > 0) curbase = curbase.dbl(cs, dbl_aff.empty() ? nullptr : &dbl_aff[i - 1]);
             EdwardsPoint thisbase = curbase.conditionally_select(cs, by[i]);
-            result = i == 0 ? thisbase : result.add(cs, thisbase);
+            result = i == 0 ? thisbase : result.add(cs, thisbase, sum_aff.empty() ? nullptr : &sum_aff[i - 1]);
         }
         return result;
     }
@@ -170,12 +209,28 @@ struct EdwardsPoint {
 inline EdwardsPoint fixed_base_multiplication(CS& cs, const FixedGenerator& base, const std::vector<Boolean>& by) {
     EdwardsPoint result{};
     size_t nchunks = (by.size() + 2) / 3;
+    // the running sums of the selected window entries natively first: one inversion for the whole chain
+    std::vector<JAffine> sum_aff;
+    if (cs.has_witness() && nchunks > 1) {
+        std::vector<JPoint> sums;
+        JPoint acc = JPoint::identity();
+        for (size_t i = 0; i < nchunks && i < base.size(); ++i) {
+            int idx = 0;
+            for (int k = 0; k < 3; ++k)
+                if (3 * i + k < by.size() && by[3 * i + k].value()) idx |= 1 << k;
+            const Coord& c = base[i][idx];
+            const JPoint sel = JPoint::from_affine({c.first, c.second});
+            acc = i == 0 ? sel : acc.add(sel);
+            if (i > 0) sums.push_back(acc);
+        }
+        batch_to_affine(sums, sum_aff);
+    }
     for (size_t i = 0; i < nchunks && i < base.size(); ++i) {
         Boolean chunk[3];
         for (int k = 0; k < 3; ++k) chunk[k] = 3 * i + k < by.size() ? by[3 * i + k] : Boolean::constant(false);
         auto uv = lookup3_xy(cs, chunk, base[i]);
         EdwardsPoint p{uv.first, uv.second};
-        result = i == 0 ? p : result.add(cs, p);
+        result = i == 0 ? p : result.add(cs, p, sum_aff.empty() ? nullptr : &sum_aff[i - 1]);
     }
     return result;
 }
