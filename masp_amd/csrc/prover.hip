@@ -119,21 +119,34 @@ static int fail_shared(masp_hip_ctx* ctx, int rc) {
 static int enqueue_quotient(Slot& sl, const NttDomain& D, const Fr* const in[3], size_t in_stride, uint32_t nrows, bool mont_in, uint32_t np) {
     hipStream_t s = sl.stream;
     const uint32_t m = (uint32_t)D.m, logm = D.logm;
+    // A batch goes through the seven transforms in sub-batches whose six work buffers (sub x 6 x 32 m bytes: 192 MiB for
+    // eight Spend proofs) stay in the 256 MiB Infinity Cache from pass to pass, instead of every pass streaming the whole
+    // batch (np x 4 MiB per buffer) through HBM.  The work buffers are only sub proofs long; h is the per-batch result.
+    static const uint32_t sub_max = [] {
+        const char* e = getenv("MASP_HIP_NTT_SUB");  // experiment knob, read once: 0 = the whole batch at once
+        return e ? (uint32_t)atoi(e) : 8u;
+    }();
+    const uint32_t sub = sub_max ? std::min(sub_max, np) : np;
     int rc;
-    for (int i = 0; i < 3; ++i) {
-        if ((rc = sl.x0[i].reserve((size_t)m * np)) || (rc = sl.x1[i].reserve((size_t)m * np))) return rc;
-        if (mont_in)
-            launch_ntt_copy_bitrev(s, in[i], in_stride, nrows, sl.x0[i].p, logm, np);
-        else
-            launch_ntt_load_bitrev(s, in[i], in_stride, nrows, sl.x0[i].p, logm, np);
-        D.passes(s, sl.x0[i].p, D.tw_inv.p, np);                                      // iNTT (unscaled)
-        launch_ntt_scale_bitrev(s, sl.x0[i].p, D.coset_scale.p, sl.x1[i].p, logm, np);  // * g^k / m
-        D.passes(s, sl.x1[i].p, D.tw_fwd.p, np);                                      // coset NTT
-    }
-    launch_ntt_abc_bitrev(s, sl.x1[0].p, sl.x1[1].p, sl.x1[2].p, D.zinv, sl.x0[0].p, logm, np);
-    D.passes(s, sl.x0[0].p, D.tw_inv.p, np);
+    for (int i = 0; i < 3; ++i)
+        if ((rc = sl.x0[i].reserve((size_t)m * sub)) || (rc = sl.x1[i].reserve((size_t)m * sub))) return rc;
     if ((rc = sl.h.reserve((size_t)m * np))) return rc;
-    launch_fr_scale(s, sl.x0[0].p, D.h_scale.p, sl.h.p, m, np);  // * g^-k / m, leaves Montgomery form
+    for (uint32_t p0 = 0; p0 < np; p0 += sub) {
+        const uint32_t q = std::min(sub, np - p0);
+        for (int i = 0; i < 3; ++i) {
+            const Fr* src = in[i] + (size_t)p0 * in_stride;
+            if (mont_in)
+                launch_ntt_copy_bitrev(s, src, in_stride, nrows, sl.x0[i].p, logm, q);
+            else
+                launch_ntt_load_bitrev(s, src, in_stride, nrows, sl.x0[i].p, logm, q);
+            D.passes(s, sl.x0[i].p, D.tw_inv.p, q);                                      // iNTT (unscaled)
+            launch_ntt_scale_bitrev(s, sl.x0[i].p, D.coset_scale.p, sl.x1[i].p, logm, q);  // * g^k / m
+            D.passes(s, sl.x1[i].p, D.tw_fwd.p, q);                                      // coset NTT
+        }
+        launch_ntt_abc_bitrev(s, sl.x1[0].p, sl.x1[1].p, sl.x1[2].p, D.zinv, sl.x0[0].p, logm, q);
+        D.passes(s, sl.x0[0].p, D.tw_inv.p, q);
+        launch_fr_scale(s, sl.x0[0].p, D.h_scale.p, sl.h.p + (size_t)p0 * m, m, q);  // * g^-k / m, leaves Montgomery form
+    }
     return MASP_HIP_OK;
 }
 
