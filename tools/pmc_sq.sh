@@ -10,22 +10,26 @@ ctrs="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_I
 python - <<PY
 import csv, glob, json, collections
 f = glob.glob("$out/**/*counter_collection.csv", recursive=True)[0]
-rows = [r for r in csv.DictReader(open(f)) if "k_msm_accumulate<masp::FpOps>" in r["Kernel_Name"]]
-full = max(int(r["Grid_Size"]) for r in rows)
-acc = collections.defaultdict(list)
-for r in rows:
-    if int(r["Grid_Size"]) == full:
-        acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-avg = {k: sum(v) / len(v) for k, v in acc.items()}
-wave_cycles = avg.get("SQ_ACTIVE_INST_ANY", 0) + avg.get("SQ_WAIT_ANY", 0) + avg.get("SQ_WAIT_INST_ANY", 0)
-out = {"kernel": "k_msm_accumulate<G1>, one batch in flight (MASP_HIP_SLOTS=1), averages per launch of the full batch",
-       "command": "tools/pmc_sq.sh", "launches_sampled": len(next(iter(acc.values()))), "counters": avg,
-       "derived": {"wave_quad_cycles (ACTIVE_INST_ANY + WAIT_ANY + WAIT_INST_ANY, MI355X_MICROARCH.md)": wave_cycles,
-                   "share issuing VALU": avg.get("SQ_ACTIVE_INST_VALU", 0) / wave_cycles if wave_cycles else None,
-                   "share waiting on memory / barriers (WAIT_ANY)": avg.get("SQ_WAIT_ANY", 0) / wave_cycles if wave_cycles else None,
-                   "share stalled at issue (WAIT_INST_ANY)": avg.get("SQ_WAIT_INST_ANY", 0) / wave_cycles if wave_cycles else None,
-                   "VALU instructions per wave": avg.get("SQ_INSTS_VALU", 0) / avg["SQ_WAVES"] if avg.get("SQ_WAVES") else None}}
-json.dump(out, open("$root/profiles/pmc_sq_accumulate.json", "w"), indent=1)
-print(json.dumps(out, indent=1))
+allrows = list(csv.DictReader(open(f)))
+doc = {"command": "tools/pmc_sq.sh: MASP_HIP_SLOTS=1 rocprofv3 --pmc <8 SQ counters> --kernel-trace -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline",
+       "note": "one batch in flight (every kernel alone on the chip), averages per launch of the full 128-proof batch; quad-cycle units (MI355X_MICROARCH.md)"}
+for key, pat, vgprs in (("k_msm_accumulate<G1>", "k_msm_accumulate<masp::FpOps>", "226 VGPRs, no spills: 2 waves per SIMD"),
+                        ("k_msm_accumulate<G2>", "k_msm_accumulate<masp::Fp2Ops>", "512 VGPRs + 414 spilled (992 B scratch): 1 wave per SIMD; the 384-bit product is an out-of-line call")):
+    rows = [r for r in allrows if pat in r["Kernel_Name"]]
+    full = max(int(r["Grid_Size"]) for r in rows)
+    acc = collections.defaultdict(list)
+    for r in rows:
+        if int(r["Grid_Size"]) == full:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    avg = {k: sum(v) / len(v) for k, v in acc.items()}
+    wave_cycles = avg.get("SQ_ACTIVE_INST_ANY", 0) + avg.get("SQ_WAIT_ANY", 0) + avg.get("SQ_WAIT_INST_ANY", 0)
+    doc[key] = {"registers": vgprs, "launches_sampled": len(next(iter(acc.values()))), "counters": avg,
+                "derived": {"wave_quad_cycles (ACTIVE_INST_ANY + WAIT_ANY + WAIT_INST_ANY)": wave_cycles,
+                            "share issuing VALU": avg.get("SQ_ACTIVE_INST_VALU", 0) / wave_cycles if wave_cycles else None,
+                            "share waiting on memory / barriers (WAIT_ANY)": avg.get("SQ_WAIT_ANY", 0) / wave_cycles if wave_cycles else None,
+                            "share stalled at issue (WAIT_INST_ANY)": avg.get("SQ_WAIT_INST_ANY", 0) / wave_cycles if wave_cycles else None,
+                            "VALU instructions per wave": avg.get("SQ_INSTS_VALU", 0) / avg["SQ_WAVES"] if avg.get("SQ_WAVES") else None}}
+json.dump(doc, open("$root/profiles/pmc_sq_accumulate.json", "w"), indent=1)
+print(json.dumps(doc, indent=1))
 PY
 cp $root/profiles/pmc_sq_accumulate.json $root/gpurun_out/pmc_sq_accumulate.json   # gpurun only merges gpurun_out/ back: copy it into profiles/ afterwards
