@@ -124,6 +124,22 @@ int masp_hip_quotient_h(masp_hip_ctx* ctx, const uint8_t* a, const uint8_t* b, c
 /* in-place radix-2 NTT over Fr of 2^logm elements, natural order in and out */
 int masp_hip_ntt(masp_hip_ctx* ctx, uint8_t* data, uint32_t logm, int inverse);
 
+/* ---- Groth16 batch verification on the GPU ----
+ * <- bellman `verify_proofs_batch` (/root/reference/masp_proofs/src/sapling/verifier/batch.rs:24-31,201-239) and, batched, the
+ *    prover's own `verify_proof` self-checks (/root/reference/masp_proofs/src/sapling/prover.rs:148,266) with the
+ *    `PreparedVerifyingKey` of /root/reference/masp_proofs/src/lib.rs:391-393.
+ * masp_hip_vk_prepare: `params` = Parameters bytes (only the verifying-key prefix is read).
+ * masp_hip_verify_batch: n proofs (192 B each) of ONE circuit, their public inputs (n x n_public x 32 B, excluding ONE) and
+ * n x 16 B of caller-supplied randomness z (one random linear combination, as bellman does).  Proof decompression, the
+ * z_i-multiples and the n Miller loops (one wavefront per pairing) run on the device; the public-input combination, two
+ * pairings and the single final exponentiation on the host.  *all_valid = 1 iff every proof verifies (up to 2^-127);
+ * 0 says at least one does not, not which.  Takes the context exclusively. */
+typedef struct masp_hip_vk masp_hip_vk;
+int masp_hip_vk_prepare(masp_hip_ctx* ctx, const uint8_t* params, size_t params_len, masp_hip_vk** out);
+void masp_hip_vk_free(masp_hip_vk* vk);
+int masp_hip_verify_batch(masp_hip_ctx* ctx, const masp_hip_vk* vk, size_t n, const uint8_t* proofs, const uint8_t* public_inputs,
+                          uint32_t n_public, const uint8_t* z, int* all_valid);
+
 /* ---- measurement hooks (bench.py): device-resident workloads, HIP-event timing on the ctx stream ---- */
 /* Keeps `n` jobs' assignments resident in HBM; returns a handle (>= 0) or a negative error code. */
 int masp_hip_batch_upload(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs);

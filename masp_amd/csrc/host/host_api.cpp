@@ -7,72 +7,13 @@
 #include <memory>
 
 #include "circuits.h"
+#include "groth16_vk.h"
+#include "pairing_prog.h"
 #include "pairing.h"
 
 using namespace masp_host;
 
-namespace masp_host {
-namespace bls {
-const PairingK& pairing_k() {
-    static PairingK k = [] {
-        PairingK c;
-        // (p - 1) / 6
-        uint64_t e[6], one_[6] = {1, 0, 0, 0, 0, 0};
-        Fp::subr(e, Fp::P(), one_);
-        uint64_t rem = 0;
-        for (int i = 5; i >= 0; --i) {
-            u128 cur = ((u128)rem << 64) | e[i];
-            e[i] = (uint64_t)(cur / 6);
-            rem = (uint64_t)(cur % 6);
-        }
-        Fp2 xi = {Fp::one(), Fp::one()}, g = Fp2::one();
-        for (int i = 5; i >= 0; --i)
-            for (int b = 63; b >= 0; --b) {
-                g = g.sq();
-                if ((e[i] >> b) & 1) g = g * xi;
-            }
-        c.gamma[0] = Fp2::one();
-        for (int i = 1; i < 6; ++i) c.gamma[i] = c.gamma[i - 1] * g;
-        return c;
-    }();
-    return k;
-}
-}  // namespace bls
-}  // namespace masp_host
 
-namespace {
-// PreparedVerifyingKey (lib.rs:391-393): the Miller value of (alpha, beta) is computed once; each IC point carries a
-// table of d * 16^w * IC (d = 1..15, w = 0..63) so that the public-input combination costs 64 additions per input.
-struct PreparedVk {
-    bls::Fp12 alpha_beta;
-    bls::G2A gamma, delta;
-    std::vector<bls::G1A> ic;
-    std::vector<std::vector<bls::G1J>> ic_tab;  // [input][w * 15 + d - 1]
-    void build_tables() {
-        ic_tab.resize(ic.size());
-        for (size_t i = 1; i < ic.size(); ++i) {
-            auto& t = ic_tab[i];
-            t.resize(64 * 15);
-            bls::G1J base = bls::G1J::from(ic[i]);
-            for (int w = 0; w < 64; ++w) {
-                t[w * 15] = base;
-                for (int d = 2; d <= 15; ++d) t[w * 15 + d - 1] = t[w * 15 + d - 2].add(base);
-                base = t[w * 15 + 7].dbl();  // 16 * base
-            }
-        }
-    }
-    // IC_i * k for a 32-byte little-endian scalar
-    bls::G1J ic_mul(size_t i, const uint8_t* k32) const {
-        bls::G1J r = bls::G1J::inf();
-        const auto& t = ic_tab[i];
-        for (int w = 0; w < 64; ++w) {
-            int d = (k32[w >> 1] >> ((w & 1) * 4)) & 15;
-            if (d) r = r.add(t[w * 15 + d - 1]);
-        }
-        return r;
-    }
-};
-}  // namespace
 
 namespace {
 struct CircuitHandle {
@@ -265,20 +206,8 @@ int masp_host_convert_assignment(const uint8_t generator[32], uint64_t value, co
 // ---- Groth16 self-verification (sapling/prover.rs:148,266) ---------------------------------------------
 // params: the Parameters bytes (only the verifying-key prefix is read).  Returns a handle or NULL.
 void* masp_host_vk_prepare(const uint8_t* params, size_t len) {
-    if (len < 868) return nullptr;
     std::unique_ptr<PreparedVk> vk(new PreparedVk);
-    bls::G1A alpha, delta1;
-    bls::G2A beta;
-    if (!bls::g1_uncompressed(alpha, params) || !bls::g2_uncompressed(beta, params + 192) || !bls::g2_uncompressed(vk->gamma, params + 384) ||
-        !bls::g1_uncompressed(delta1, params + 576) || !bls::g2_uncompressed(vk->delta, params + 672))
-        return nullptr;
-    uint32_t n = ((uint32_t)params[864] << 24) | (params[865] << 16) | (params[866] << 8) | params[867];
-    if ((size_t)n * 96 + 868 > len || n == 0) return nullptr;
-    vk->ic.resize(n);
-    for (uint32_t i = 0; i < n; ++i)
-        if (!bls::g1_uncompressed(vk->ic[i], params + 868 + 96 * (size_t)i)) return nullptr;
-    vk->alpha_beta = bls::miller(alpha, beta);
-    vk->build_tables();
+    if (!prepare_vk(*vk, params, len)) return nullptr;
     return vk.release();
 }
 void masp_host_vk_free(void* h) { delete (PreparedVk*)h; }
@@ -317,8 +246,7 @@ int masp_host_vk_verify_batch(const void* h, size_t n, const uint8_t* proofs, co
     if ((size_t)n_public + 1 != vk.ic.size()) return -1;
     if (n == 0) return 1;
     std::vector<bls::MillerPair> pairs;
-    pairs.reserve(n + 2);
-    std::vector<Fr> coef(n_public + 1, Fr::zero());  // sum_i z_i * input_ij  (j = 0: the constant ONE)
+    pairs.reserve(n);
     bls::G1J csum = bls::G1J::inf();
     for (size_t i = 0; i < n; ++i) {
         const uint8_t* pr = proofs + 192 * i;
@@ -328,39 +256,65 @@ int masp_host_vk_verify_batch(const void* h, size_t n, const uint8_t* proofs, co
         uint8_t zi[32] = {0};
         memcpy(zi, z + 16 * i, 16);
         zi[0] |= 1;  // never zero
-        Fr zf;
-        Fr::from_bytes(zf, zi);
-        coef[0] = coef[0] + zf;
-        for (uint32_t j = 0; j < n_public; ++j) {
-            Fr in;
-            if (!Fr::from_bytes(in, public_inputs + 32 * ((size_t)i * n_public + j))) return -3;
-            coef[j + 1] = coef[j + 1] + zf * in;
-        }
         bls::G1A za = bls::G1J::from(a).mul_le(zi, 128).affine();
         csum = csum.add(bls::G1J::from(c).mul_le(zi, 128));
         if (!za.inf && !b.inf) pairs.emplace_back(za, b);
     }
-    uint8_t k32[32];
-    coef[0].to_bytes(k32);
-    bls::G1J acc = bls::G1J::from(vk.ic[0]).mul_le(k32, 256);
-    for (uint32_t j = 0; j < n_public; ++j) {
-        uint8_t kj[32];
-        coef[j + 1].to_bytes(kj);
-        acc = acc.add(vk.ic_mul(j + 1, kj));
+    return batch_verify_finish(vk, n, public_inputs, n_public, z, bls::multi_miller(pairs), csum.affine());
+}
+
+// The Miller loop of the GPU batch verifier exists as levelled straight-line programs (host/pairing_prog.h).  This runs
+// them on the host interpreter for one pair (P: 96 B uncompressed G1, Q: 192 B uncompressed G2) and compares the result,
+// coefficient for coefficient, with this library's own Miller loop (pairing.h) and with the templated tower instantiated
+// over the concrete field.  0 = equal.  stats (may be NULL): ops / steps / steps with products / products / slots of
+// the doubling program, then the same five of the addition program, then of the Fp12 product.
+int masp_host_pairing_program_selftest(const uint8_t* p96, const uint8_t* q192, uint32_t* stats) {
+    bls::G1A P;
+    bls::G2A Q;
+    if (!bls::g1_uncompressed(P, p96) || !bls::g2_uncompressed(Q, q192) || P.inf || Q.inf) return -1;
+    const prog::PairingPrograms& pp = prog::pairing_programs();
+    if (stats) {
+        const prog::Program* ps[3] = {&pp.dbl, &pp.add, &pp.mul12};
+        for (int i = 0; i < 3; ++i) {
+            stats[5 * i] = (uint32_t)ps[i]->ops.size();
+            stats[5 * i + 1] = (uint32_t)ps[i]->step_start.size() - 1;
+            stats[5 * i + 2] = ps[i]->n_mul_steps;
+            stats[5 * i + 3] = ps[i]->n_mul;
+            stats[5 * i + 4] = ps[i]->n_slots;
+        }
     }
-    bls::G1A nacc = acc.affine(), nc = csum.affine();
-    nacc.y = nacc.y.neg();
-    nc.y = nc.y.neg();
-    if (!nacc.inf) pairs.emplace_back(nacc, vk.gamma);
-    if (!nc.inf) pairs.emplace_back(nc, vk.delta);
-    // alpha_beta^(sum z)
-    bls::Fp12 ab = bls::Fp12::one();
-    for (int bit = 255; bit >= 0; --bit) {
-        ab = ab.sq();
-        if ((k32[bit >> 3] >> (bit & 7)) & 1) ab = ab * vk.alpha_beta;
+    const bls::Fp12 want = bls::miller(P, Q);
+    if (!(prog::miller_by_program(P, Q) == want)) return 1;
+    // the templated formulas over the concrete field, step by step
+    prog::Fp12T<bls::Fp> f = {{{bls::Fp::one(), bls::Fp::zero()}, {bls::Fp::zero(), bls::Fp::zero()}, {bls::Fp::zero(), bls::Fp::zero()}},
+                              {{bls::Fp::zero(), bls::Fp::zero()}, {bls::Fp::zero(), bls::Fp::zero()}, {bls::Fp::zero(), bls::Fp::zero()}}};
+    prog::MillerT<bls::Fp> m;
+    m.xp = P.x; m.yp = P.y;
+    m.xq = {Q.x.a, Q.x.b}; m.yq = {Q.y.a, Q.y.b};
+    m.X = m.xq; m.Y = m.yq; m.Z = {bls::Fp::one(), bls::Fp::zero()};
+    const uint64_t xabs = 0xd201000000010000ull;
+    for (int b = 62; b >= 0; --b) {
+        f = f.sq();
+        m.dbl_step(f);
+        if ((xabs >> b) & 1) m.add_step(f);
     }
-    bls::Fp12 f = bls::multi_miller(pairs) * ab.conj();
-    return bls::final_exp(f) == bls::Fp12::one() ? 1 : 0;
+    bls::Fp12 g = {{{f.a.a.a, f.a.a.b}, {f.a.b.a, f.a.b.b}, {f.a.c.a, f.a.c.b}}, {{f.b.a.a, f.b.a.b}, {f.b.b.a, f.b.b.b}, {f.b.c.a, f.b.c.b}}};
+    if (!(g.conj() == want)) return 2;
+    // Fp12 product program
+    std::vector<bls::Fp> sl(pp.n_slots, bls::Fp::zero());
+    const bls::Fp12 y = want.sq();
+    auto flat = [](const bls::Fp12& x, bls::Fp* o) {
+        const bls::Fp v[12] = {x.a.a.a, x.a.a.b, x.a.b.a, x.a.b.b, x.a.c.a, x.a.c.b, x.b.a.a, x.b.a.b, x.b.b.a, x.b.b.b, x.b.c.a, x.b.c.b};
+        for (int i = 0; i < 12; ++i) o[i] = v[i];
+    };
+    bls::Fp pf[12];
+    flat(want, &sl[prog::SLOT_F]);
+    flat(y, &sl[prog::SLOT_Y]);
+    prog::run_program(pp.mul12, sl.data());
+    flat(want * y, pf);
+    for (int i = 0; i < 12; ++i)
+        if (!(sl[prog::SLOT_F + i] == pf[i])) return 3;
+    return 0;
 }
 
 // ---- native primitives (pinned by the reference's vectors in tests/) ---------------------------------

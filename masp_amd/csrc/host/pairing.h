@@ -386,7 +386,31 @@ inline bool g2_compressed(G2A& p, const uint8_t* in) {
 struct PairingK {
     Fp2 gamma[6];  // gamma[i] = xi^(i (p-1)/6): (c w^i)^p = conj(c) gamma[i] w^i
 };
-const PairingK& pairing_k();  // host_api.cpp
+
+inline const PairingK& pairing_k() {
+    static PairingK k = [] {
+        PairingK c;
+        // (p - 1) / 6
+        uint64_t e[6], one_[6] = {1, 0, 0, 0, 0, 0};
+        Fp::subr(e, Fp::P(), one_);
+        uint64_t rem = 0;
+        for (int i = 5; i >= 0; --i) {
+            u128 cur = ((u128)rem << 64) | e[i];
+            e[i] = (uint64_t)(cur / 6);
+            rem = (uint64_t)(cur % 6);
+        }
+        Fp2 xi = {Fp::one(), Fp::one()}, g = Fp2::one();
+        for (int i = 5; i >= 0; --i)
+            for (int b = 63; b >= 0; --b) {
+                g = g.sq();
+                if ((e[i] >> b) & 1) g = g * xi;
+            }
+        c.gamma[0] = Fp2::one();
+        for (int i = 1; i < 6; ++i) c.gamma[i] = c.gamma[i - 1] * g;
+        return c;
+    }();
+    return k;
+}
 
 inline Fp2 fp2_conj(const Fp2& x) { return {x.a, x.b.neg()}; }
 inline Fp2 fp2_scale(const Fp2& x, const Fp& k) { return {x.a * k, x.b * k}; }

@@ -63,6 +63,10 @@ def load_library():
     L.masp_hip_msm_g1_multi.argtypes = [vp, vp, sz, vp, sz, C.c_int, vp]
     L.masp_hip_quotient_h.argtypes = [vp, vp, vp, vp, sz, u32, vp]
     L.masp_hip_ntt.argtypes = [vp, vp, u32, C.c_int]
+    L.masp_hip_vk_prepare.argtypes = [vp, vp, sz, C.POINTER(vp)]
+    L.masp_hip_vk_free.argtypes = [vp]
+    L.masp_hip_vk_free.restype = None
+    L.masp_hip_verify_batch.argtypes = [vp, vp, sz, vp, vp, u32, vp, C.POINTER(C.c_int)]
     L.masp_hip_batch_upload.argtypes = [vp, sz, vp]
     L.masp_hip_batch_prove_resident.argtypes = [vp, C.c_int, vp, C.POINTER(C.c_float)]
     L.masp_hip_batch_prove_resident_steps.argtypes = [vp, C.c_int, sz, vp, vp, C.POINTER(C.c_float)]
@@ -213,6 +217,11 @@ class Context:
         self._check(self._L.masp_hip_generate_parameters(self._h, cs.ref, t, _p(out), cap, C.byref(n)))
         return out[:n.value].copy()
 
+    # ---- Groth16 batch verification on the GPU ----
+    def prepare_verifying_key(self, params):
+        """-> GpuVerifyingKey (= PreparedVerifyingKey, masp_proofs/src/lib.rs:391-393, for masp_hip_verify_batch)"""
+        return GpuVerifyingKey(self, params)
+
     # ---- building blocks ----
     def msm_g1(self, bases, scalars):
         bases, scalars = _u8(bases, 96), _u8(scalars, 32)
@@ -300,3 +309,49 @@ class Context:
         ms, nb = C.c_float(0), C.c_uint32(0)
         self._check(self._L.masp_hip_bench_msm(self._h, handle, job, which, iters, C.byref(ms), C.byref(nb)))
         return ms.value, nb.value
+
+
+class GpuVerifyingKey:
+    """Groth16 batch verification with the Miller loops on the GPU (masp_hip_verify_batch): same interface as
+    host.PreparedVerifyingKey.verify_batch = bellman `verify_proofs_batch` (sapling/verifier/batch.rs:24-31)."""
+
+    def __init__(self, ctx, params):
+        self._ctx = ctx
+        buf = _u8(params)
+        n_ic = int.from_bytes(buf[864:868].tobytes(), "big")
+        self._buf = buf[:868 + 96 * n_ic].copy()
+        self.n_public = n_ic - 1
+        h = C.c_void_p()
+        ctx._check(ctx._L.masp_hip_vk_prepare(ctx._h, _p(self._buf), self._buf.size, C.byref(h)))
+        self._h = h
+
+    def verify_batch(self, proofs, public_inputs, randomness=None):
+        """proofs: list of 192-byte strings; public_inputs: one list of ints / 32-byte values per proof (excluding ONE).
+        True iff all verify (up to 2^-127); False says at least one is invalid, not which."""
+        import secrets
+        n = len(proofs)
+        if n == 0:
+            return True
+        if len(public_inputs) != n or any(len(pi) != self.n_public for pi in public_inputs):
+            return False
+        pr = np.frombuffer(b"".join(bytes(p) for p in proofs), dtype=np.uint8)
+        if pr.size != 192 * n:
+            return False
+        pi = np.frombuffer(b"".join(_scalar32(x) for row in public_inputs for x in row), dtype=np.uint8) if self.n_public else None
+        z = randomness if randomness is not None else secrets.token_bytes(16 * n)
+        assert len(z) == 16 * n
+        zb = np.frombuffer(z, dtype=np.uint8)
+        ok = C.c_int(0)
+        self._ctx._check(self._ctx._L.masp_hip_verify_batch(self._ctx._h, self._h, n, _p(pr), _p(pi), self.n_public, _p(zb), C.byref(ok)))
+        return ok.value == 1
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self._ctx, "_h", None):
+            self._ctx._L.masp_hip_vk_free(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
