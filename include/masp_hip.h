@@ -133,11 +133,12 @@ int masp_hip_ntt(masp_hip_ctx* ctx, uint8_t* data, uint32_t logm, int inverse);
  * n x 16 B of caller-supplied randomness z (one random linear combination, as bellman does).  Proof decompression, the
  * z_i-multiples and the n Miller loops (one wavefront per pairing) run on the device; the public-input combination, two
  * pairings and the single final exponentiation on the host.  *all_valid = 1 iff every proof verifies (up to 2^-127);
- * 0 says at least one does not, not which.  Takes the context exclusively. */
+ * 0 says at least one does not, not which.  Re-entrant: runs on the key's own stream next to proving calls (one verification
+ * at a time per key). */
 typedef struct masp_hip_vk masp_hip_vk;
 int masp_hip_vk_prepare(masp_hip_ctx* ctx, const uint8_t* params, size_t params_len, masp_hip_vk** out);
 void masp_hip_vk_free(masp_hip_vk* vk);
-int masp_hip_verify_batch(masp_hip_ctx* ctx, const masp_hip_vk* vk, size_t n, const uint8_t* proofs, const uint8_t* public_inputs,
+int masp_hip_verify_batch(masp_hip_ctx* ctx, masp_hip_vk* vk, size_t n, const uint8_t* proofs, const uint8_t* public_inputs,
                           uint32_t n_public, const uint8_t* z, int* all_valid);
 
 /* ---- measurement hooks (bench.py): device-resident workloads, HIP-event timing on the ctx stream ---- */

@@ -3,6 +3,8 @@
 // final exponentiation — work that does not grow with the batch).
 // Replaces bellman `verify_proofs_batch` as reached from /root/reference/masp_proofs/src/sapling/verifier/batch.rs:24-31,201-239
 // and the per-proof `verify_proof` self-checks of the prover (sapling/prover.rs:148,266) when they are batched.
+#include <mutex>
+
 #include "device/pairing.cuh"
 #include "host/groth16_vk.h"
 #include "host/pairing_prog.h"
@@ -16,7 +18,22 @@ struct masp_hip_vk {
     DevBuf<uint32_t> ops, steps;  // the three programs, concatenated
     PairingProgramDev dbl{}, add{}, mul12{};
     uint32_t n_slots = 0;
+    // work buffers, grown on demand and kept (hipFree would synchronise the device under the provers)
+    DevBuf<uint8_t> d_proofs, d_z, d_sum;
+    DevBuf<G1Affine> d_za;
+    DevBuf<G2Affine> d_b;
+    DevBuf<G1Xyzz> d_zc;
+    DevBuf<int> d_status;
+    DevBuf<Fp> d_f;
+    hipStream_t stream = nullptr;  // verification runs on its own stream, next to the provers' batches
+    std::mutex mu;                 // one verification at a time per key
+    ~masp_hip_vk() {
+        if (stream) hipStreamDestroy(stream);
+    }
 };
+
+// (fail() takes slot_mu for the error text: fine under the shared context lock too)
+static int fail_shared_v(masp_hip_ctx* ctx, int rc) { return fail(ctx, rc); }
 
 #define FIRST_DEVICE(ctx) ((ctx) && !(ctx)->children.empty() ? (ctx)->children[0] : (ctx))
 
@@ -52,6 +69,7 @@ int masp_hip_vk_prepare(masp_hip_ctx* ctx, const uint8_t* params, size_t params_
         dst[i]->n_steps = (uint32_t)ps[i]->step_start.size() - 1;
     }
     v->n_slots = pp.n_slots;
+    if (hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking) != hipSuccess) return fail(ctx, MASP_HIP_E_HIP);
     *out = v.release();
     return MASP_HIP_OK;
 }
@@ -62,7 +80,7 @@ void masp_hip_vk_free(masp_hip_vk* vk) {
     delete vk;
 }
 
-int masp_hip_verify_batch(masp_hip_ctx* ctx, const masp_hip_vk* vk, size_t n, const uint8_t* proofs, const uint8_t* public_inputs,
+int masp_hip_verify_batch(masp_hip_ctx* ctx, masp_hip_vk* vk, size_t n, const uint8_t* proofs, const uint8_t* public_inputs,
                           uint32_t n_public, const uint8_t* z, int* all_valid) {
     if (!ctx || !vk || !all_valid || (n && (!proofs || !z || (n_public && !public_inputs))) || n > (1u << 20)) return MASP_HIP_E_INVALID_ARG;
     if ((size_t)n_public + 1 != vk->vk.ic.size()) return MASP_HIP_E_PARAMS_SHAPE;
@@ -73,20 +91,21 @@ int masp_hip_verify_batch(masp_hip_ctx* ctx, const masp_hip_vk* vk, size_t n, co
     }
     ctx = FIRST_DEVICE(ctx);
     if (ctx->device != vk->device) return MASP_HIP_E_INVALID_ARG;
-    std::unique_lock<std::shared_mutex> lock(ctx->mu);
+    std::shared_lock<std::shared_mutex> lock(ctx->mu);  // concurrent with provers (and with verifications under other keys)
+    std::lock_guard<std::mutex> vlock(vk->mu);
     hipSetDevice(ctx->device);
-    hipStream_t s = ctx->main_stream;
+    hipStream_t s = vk->stream;
     const uint32_t nn = (uint32_t)n;
-    DevBuf<uint8_t> d_proofs, d_z, d_sum;
-    DevBuf<G1Affine> d_za;
-    DevBuf<G2Affine> d_b;
-    DevBuf<G1Xyzz> d_zc;
-    DevBuf<int> d_status;
-    DevBuf<Fp> d_f;
+    DevBuf<uint8_t>&d_proofs = vk->d_proofs, &d_z = vk->d_z, &d_sum = vk->d_sum;
+    DevBuf<G1Affine>& d_za = vk->d_za;
+    DevBuf<G2Affine>& d_b = vk->d_b;
+    DevBuf<G1Xyzz>& d_zc = vk->d_zc;
+    DevBuf<int>& d_status = vk->d_status;
+    DevBuf<Fp>& d_f = vk->d_f;
     int rc;
     if ((rc = d_proofs.upload(proofs, 192 * n, s)) || (rc = d_z.upload(z, 16 * n, s)) || (rc = d_za.reserve(n)) || (rc = d_b.reserve(n)) ||
         (rc = d_zc.reserve(n)) || (rc = d_status.reserve(n)) || (rc = d_f.reserve(12 * n)) || (rc = d_sum.reserve(96)))
-        return fail(ctx, rc);
+        return fail_shared_v(ctx, rc);
     HIP_TRY(hipMemsetAsync(d_status.p, 0, sizeof(int) * n, s));
     // the interpreter keeps its slots in LDS: n_slots x 48 bytes per wave
     const uint32_t lds = vk->n_slots * 48;
@@ -96,7 +115,7 @@ int masp_hip_verify_batch(masp_hip_ctx* ctx, const masp_hip_vk* vk, size_t n, co
     }();
     if (!lds_ok || lds > 64 * 1024) {
         last_hip_error() = "pairing interpreter: LDS configuration failed";
-        return fail(ctx, MASP_HIP_E_HIP);
+        return fail_shared_v(ctx, MASP_HIP_E_HIP);
     }
     hipLaunchKernelGGL(k_verify_prepare, dim3((nn + 63) / 64, 3), dim3(64), 0, s, d_proofs.p, d_z.p, nn, d_za.p, d_b.p, d_zc.p, d_status.p);
     hipLaunchKernelGGL(k_g1_sum_export, dim3(1), dim3(256), 0, s, d_zc.p, nn, d_sum.p);
@@ -112,14 +131,14 @@ int masp_hip_verify_batch(masp_hip_ctx* ctx, const masp_hip_vk* vk, size_t n, co
         hipMemcpyAsync(&f, d_f.p, 12 * 48, hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipMemcpyAsync(sum96, d_sum.p, 96, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
         last_hip_error() = std::string("batch verification failed: ") + hipGetErrorString(hipGetLastError());
-        return fail(ctx, MASP_HIP_E_HIP);
+        return fail_shared_v(ctx, MASP_HIP_E_HIP);
     }
     for (int st : status)
         if (st & (PT_BAD_FLAGS | PT_NOT_CANONICAL)) return MASP_HIP_OK;  // an undecodable proof: not valid (*all_valid stays 0)
     masp_host::bls::G1A csum;
     if (!masp_host::bls::g1_uncompressed(csum, sum96)) {
         last_hip_error() = "batch verification: device returned a malformed point";
-        return fail(ctx, MASP_HIP_E_HIP);
+        return fail_shared_v(ctx, MASP_HIP_E_HIP);
     }
     int v = masp_host::batch_verify_finish(vk->vk, n, public_inputs, n_public, z, f, csum);
     if (v < 0) return MASP_HIP_E_SCALAR_RANGE;

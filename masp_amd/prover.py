@@ -98,6 +98,9 @@ class LocalTxProver:
         # spend_vk / convert_vk: PreparedVerifyingKey (prover.rs:27-33, lib.rs:391-393); Output proofs are not self-checked
         self.spend_vk = H.PreparedVerifyingKey(spend_params)
         self.convert_vk = H.PreparedVerifyingKey(convert_params)
+        # the batched self-checks of prove_batch run their Miller loops on the GPU (masp_hip_verify_batch); the single-proof
+        # checks of the TxProver methods and the search for the culprit of a failing batch stay on the host
+        self._gpu_vk = {"spend": self._ctx.prepare_verifying_key(spend_params), "convert": self._ctx.prepare_verifying_key(convert_params)}
         for slot, kind, params in ((SPEND, "spend", spend_params), (OUTPUT, "output", output_params), (CONVERT, "convert", convert_params)):
             cs, _ = H.circuit(kind)
             self._ctx.load_circuit(slot, params, cs)
@@ -138,6 +141,8 @@ class LocalTxProver:
         return p
 
     def close(self):
+        for k in self._gpu_vk.values():
+            k.close()
         self._ctx.close()
 
     def new_sapling_proving_context(self):
@@ -204,8 +209,9 @@ class LocalTxProver:
         Three stages run as a pipeline over chunks of `chunk` descriptions (default: the GPU batch size):
         witness synthesis on `threads` host threads (the C++ synthesizer releases the GIL), proving on the GPU (each
         chunk in flight owns one slot of the native context, which is re-entrant), and self-verification of the Spend /
-        Convert proofs of a finished chunk as one `verify_proofs_batch`-style check per circuit (a failing batch is
-        re-checked proof by proof, so the outcome is that of the per-proof checks at sapling/prover.rs:148,266).
+        Convert proofs of a finished chunk as one `verify_proofs_batch`-style check per circuit, Miller loops on the GPU
+        (masp_hip_verify_batch; a failing batch is re-checked proof by proof on the host, so the outcome is that of the
+        per-proof checks at sapling/prover.rs:148,266).
         The context accumulates in description order afterwards, so bsk / cv_sum end up exactly as in the serial loops.
         `progress(done, total)` mirrors the builder's `Progress` notifications (builder.rs:946-952 etc.).
         -> list of (zkproof, cv[, rk])"""
@@ -251,7 +257,7 @@ class LocalTxProver:
                             if not sel:
                                 continue
                             pis = [public_input(kind, descriptions[lo + i][1], jobs[i]) for i in sel]
-                            if not vk.verify_batch([proofs[i] for i in sel], pis):
+                            if not self._gpu_vk[kind].verify_batch([proofs[i] for i in sel], pis):
                                 bad = [lo + i for i, pi in zip(sel, pis) if not vk.verify(proofs[i], pi)]
                                 raise ProvingError("proof(s) %s failed self-verification" % bad)
                 finally:
