@@ -149,4 +149,192 @@ k_msm_scatter(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32
     }
 }
 
+
+// ---- two-pass placement (replaces k_msm_scatter when the entries fit 24 bits) ------------------------------------------
+// k_msm_scatter writes every entry on its own: a wave's 64 entries go to 64 unrelated buckets, i.e. 64 four-byte writes
+// into 64 different lines — the kernel is bound by DRAM read-modify-write of partial lines (10.4 ms per 128-proof batch for
+// 1.76 GB of payload).  Here the same entries reach their places in two steps that only ever write runs:
+//   k_msm_partition  (one workgroup per scalar range)   entries -> COARSE bins of 128 buckets.  A tile of 1024 scalars is
+//                    sorted by bin inside LDS first (count, scan, place), then copied out bin by bin: runs of ~64 entries.
+//   k_msm_bucketize  (one workgroup per proof and bin)  the bin's entries -> their buckets, again through an LDS-sorted
+//                    tile of 4096 entries: runs of ~32 entries.
+// Between the two, an entry carries its bucket's low 7 bits:  row (24 bits) | fine << 24 | sign << 31.
+static constexpr uint32_t MSM_FINE_LOG = 7, MSM_FINE = 1u << MSM_FINE_LOG;
+static constexpr uint32_t MSM_PART_TILE = 1024;   // scalars per tile of k_msm_partition (= threads)
+static constexpr uint32_t MSM_BKT_TILE = 4096;    // entries per tile of k_msm_bucketize
+
+// crel[p][wg][B] = entries of bin B that come from earlier scalar ranges = sum over the bin's buckets of rel[p][wg][b]
+__global__ void __launch_bounds__(128) k_msm_coarse(const uint32_t* __restrict__ rel, uint32_t ng, uint32_t nb, uint32_t* __restrict__ crel) {
+    __shared__ uint32_t part[2];
+    const uint32_t B = blockIdx.x, nbins = nb >> MSM_FINE_LOG, tid = threadIdx.x;
+    rel += (size_t)MSM_P * ng * nb;
+    crel += (size_t)MSM_P * ng * nbins;
+    for (uint32_t w = 0; w < ng; ++w) {
+        uint32_t v = rel[(size_t)w * nb + (B << MSM_FINE_LOG) + tid];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+        if ((tid & 63) == 0) part[tid >> 6] = v;
+        __syncthreads();
+        if (tid == 0) crel[(size_t)w * nbins + B] = part[0] + part[1];
+        __syncthreads();
+    }
+}
+// position of k in the exclusive offsets off[0..n): largest i with off[i] <= k
+__device__ __forceinline__ uint32_t msm_find_run(const uint32_t* off, uint32_t n, uint32_t k) {
+    uint32_t i = 0, span = n;
+    while (span > 1) {
+        uint32_t half = span >> 1;
+        if (off[i + half] <= k) i += half;
+        span -= half;
+    }
+    return i;
+}
+// exclusive scan of cnt[0..n) (n <= 256) into off[], by the first four waves of the workgroup (shuffle scan inside each wave,
+// the waves' totals through wsum[4]); also clears fill[].  Two barriers inside: every thread of the workgroup must call it.
+__device__ __forceinline__ void msm_small_scan(const uint32_t* cnt, uint32_t* off, uint32_t* fill, uint32_t n, uint32_t* total, uint32_t* wsum) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    uint32_t v = 0, x = 0;
+    if (tid < 256) {
+        v = tid < n ? cnt[tid] : 0u;
+        x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t y = __shfl_up(x, d, 64);
+            if ((int)lane >= d) x += y;
+        }
+        if (lane == 63) wsum[tid >> 6] = x;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        uint32_t base = 0;
+        for (uint32_t w = 0; w < (tid >> 6); ++w) base += wsum[w];
+        if (tid < n) {
+            off[tid] = base + x - v;
+            fill[tid] = 0;
+        }
+        if (tid == 255) *total = base + x;
+    }
+}
+__global__ void __launch_bounds__(1024)
+k_msm_partition(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32_t n, MsmGeom g, uint32_t ng, const uint32_t* __restrict__ crel,
+                const uint32_t* __restrict__ start, uint32_t* __restrict__ tmp) {
+    extern __shared__ uint32_t msm_lds[];
+    const uint32_t tid = threadIdx.x, wg = blockIdx.x, nb = (uint32_t)g.nb, nbins = nb >> MSM_FINE_LOG;
+    uint32_t* cursor = msm_lds;            // [256] global position of the next entry of each bin from this workgroup
+    uint32_t* cnt = cursor + 256;          // [256] entries of the tile per bin
+    uint32_t* off = cnt + 256;             // [256] their exclusive scan
+    uint32_t* fill = off + 256;            // [256]
+    uint32_t* total = fill + 256;          // [1] (+3 pad)
+    uint32_t* wsum = total + 4;            // [4]
+    uint32_t* stage = wsum + 4;            // [MSM_PART_TILE * W]
+    scalars += MSM_P * scalar_stride;
+    crel += ((size_t)MSM_P * ng + wg) * nbins;
+    start += (size_t)MSM_P * (nb + 1);
+    tmp += (size_t)MSM_P * n * g.W;
+    if (tid < nbins) cursor[tid] = start[tid << MSM_FINE_LOG] + crel[tid];
+    const uint32_t per = (n + ng - 1) / ng, lo = wg * per, hi = lo + per < n ? lo + per : n;
+    for (uint32_t base = lo; base < hi; base += MSM_PART_TILE) {
+        if (tid < nbins) cnt[tid] = 0;
+        __syncthreads();
+        const uint32_t i = base + tid;
+        const uint32_t* sw = scalars + (size_t)i * 8;
+        const int cls = i < hi ? msm_scalar_class(sw) : 0;
+        const uint64_t ones = __ballot(cls == 1);
+        const int leader = ones ? __ffsll((unsigned long long)ones) - 1 : -1;
+        if (cls == 1) {
+            if ((int)(tid & 63u) == leader) atomicAdd(&cnt[0], (uint32_t)__popcll(ones));
+        } else if (cls == 2) {
+            MsmDigitIter it(sw, g.c);
+            for (int j = 0; j < g.W; ++j) {
+                uint32_t bucket, neg;
+                if (it.next(j, bucket, neg)) atomicAdd(&cnt[bucket >> MSM_FINE_LOG], 1u);
+            }
+        }
+        __syncthreads();
+        msm_small_scan(cnt, off, fill, nbins, total, wsum);
+        __syncthreads();
+        if (ones) {  // unit scalars: window 0, bucket 0, positive
+            uint32_t first = 0;
+            if ((int)(tid & 63u) == leader) first = atomicAdd(&fill[0], (uint32_t)__popcll(ones));
+            first = __shfl(first, leader, 64);
+            if (cls == 1) stage[off[0] + first + (uint32_t)__popcll(ones & ((1ull << (tid & 63u)) - 1ull))] = i;
+        }
+        if (cls == 2) {
+            MsmDigitIter it(sw, g.c);
+            for (int j = 0; j < g.W; ++j) {
+                uint32_t bucket, neg;
+                if (it.next(j, bucket, neg)) {
+                    const uint32_t B = bucket >> MSM_FINE_LOG;
+                    stage[off[B] + atomicAdd(&fill[B], 1u)] = ((uint32_t)j * n + i) | ((bucket & (MSM_FINE - 1u)) << 24) | (neg << 31);
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t tot = *total;
+        for (uint32_t k = tid; k < tot; k += MSM_PART_TILE) {
+            const uint32_t B = msm_find_run(off, nbins, k);
+            tmp[cursor[B] + (k - off[B])] = stage[k];
+        }
+        __syncthreads();
+        if (tid < nbins) cursor[tid] += cnt[tid];
+    }
+}
+__global__ void __launch_bounds__(1024)
+k_msm_bucketize(const uint32_t* __restrict__ tmp, size_t ent_stride, const uint32_t* __restrict__ start, uint32_t nb, uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t cur[MSM_FINE], cnt[MSM_FINE], off[MSM_FINE], fill[MSM_FINE], total[4], wsum[4], stage[MSM_BKT_TILE];
+    const uint32_t tid = threadIdx.x, B = blockIdx.x;
+    tmp += MSM_P * ent_stride;
+    sorted += MSM_P * ent_stride;
+    start += (size_t)MSM_P * (nb + 1);
+    const uint32_t b0 = B << MSM_FINE_LOG, lo = start[b0], hi = start[b0 + MSM_FINE];
+    if (tid < MSM_FINE) cur[tid] = start[b0 + tid];
+    for (uint32_t base = lo; base < hi; base += MSM_BKT_TILE) {
+        if (tid < MSM_FINE) cnt[tid] = 0;
+        __syncthreads();
+        uint32_t e[MSM_BKT_TILE / 1024];
+#pragma unroll
+        for (uint32_t q = 0; q < MSM_BKT_TILE / 1024; ++q) {
+            const uint32_t k = base + q * 1024 + tid;
+            e[q] = k < hi ? tmp[k] : 0xffffffffu;
+            // (a bucket that holds most of a tile — the unit scalars' bucket 0 — is counted once per wave, not 64 times)
+            const bool valid = k < hi;
+            const uint32_t f = (e[q] >> 24) & (MSM_FINE - 1u);
+            const uint64_t same = __ballot(valid && f == 0);
+            if (valid && f == 0) {
+                if ((uint32_t)__ffsll((unsigned long long)same) - 1u == (tid & 63u)) atomicAdd(&cnt[0], (uint32_t)__popcll(same));
+            } else if (valid) {
+                atomicAdd(&cnt[f], 1u);
+            }
+        }
+        __syncthreads();
+        msm_small_scan(cnt, off, fill, MSM_FINE, total, wsum);
+        __syncthreads();
+#pragma unroll
+        for (uint32_t q = 0; q < MSM_BKT_TILE / 1024; ++q) {
+            const uint32_t k = base + q * 1024 + tid;
+            const bool valid = k < hi;
+            const uint32_t f = (e[q] >> 24) & (MSM_FINE - 1u);
+            const uint32_t out = e[q] & 0x80ffffffu;
+            const uint64_t same = __ballot(valid && f == 0);
+            if (valid && f == 0) {
+                const int leader = __ffsll((unsigned long long)same) - 1;
+                uint32_t first = 0;
+                if ((int)(tid & 63u) == leader) first = atomicAdd(&fill[0], (uint32_t)__popcll(same));
+                first = __shfl(first, leader, 64);
+                stage[off[0] + first + (uint32_t)__popcll(same & ((1ull << (tid & 63u)) - 1ull))] = out;
+            } else if (valid) {
+                stage[off[f] + atomicAdd(&fill[f], 1u)] = out;
+            }
+        }
+        __syncthreads();
+        const uint32_t tot = *total;
+        for (uint32_t k = tid; k < tot; k += 1024) {
+            const uint32_t f = msm_find_run(off, MSM_FINE, k);
+            sorted[cur[f] + (k - off[f])] = stage[k];
+        }
+        __syncthreads();
+        if (tid < MSM_FINE) cur[tid] += cnt[tid];
+    }
+}
+
 }  // namespace masp

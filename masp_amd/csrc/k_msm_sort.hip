@@ -1,4 +1,6 @@
 // Counting sort of the MSM digits: kernels (device/msm_sort.cuh) + their host-side enqueue.
+#include <cstring>
+
 #include "device/msm_sort.cuh"
 #include "msm_host.h"
 
@@ -15,20 +17,36 @@ int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb
     sb.n = n;
     sb.np = np;
     sb.g = g;
+    const uint32_t ng = MsmSortBuf::ranges_for(n, np), nb = g.nb;
+    // two-pass placement (runs instead of single scattered words): the row index must leave room for the 7 low bucket bits
+    static const bool two_pass_enabled = [] {
+        const char* e = getenv("MASP_HIP_SORT");  // experiment knob, read once: "scatter" = the single-pass placement
+        return !(e && strcmp(e, "scatter") == 0);
+    }();
+    const bool two_pass = two_pass_enabled && nb >= MSM_FINE && (uint64_t)n * g.W <= (1u << 24);
+    const int part_lds = 4 * (4 * 256 + 8 + (int)MSM_PART_TILE * g.W);
     static bool lds_ok = [] {
         int bytes = 4 << 15;
         return hipFuncSetAttribute((const void*)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
-               hipFuncSetAttribute((const void*)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+               hipFuncSetAttribute((const void*)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+               hipFuncSetAttribute((const void*)k_msm_partition, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (4 * 256 + 8 + (int)MSM_PART_TILE * 32)) ==
+                   hipSuccess;
     }();
     if (!lds_ok) {
         last_hip_error() = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
         return MASP_HIP_E_HIP;
     }
-    const uint32_t ng = MsmSortBuf::ranges_for(n, np), nb = g.nb;
     hipLaunchKernelGGL(k_msm_hist, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg);
     hipLaunchKernelGGL(k_msm_offsets, dim3(1, np), dim3(1024), 0, s, sb.hist_wg, ng, nb, sb.start);
-    hipLaunchKernelGGL(k_msm_scatter, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg, sb.start,
-                       sb.sorted);
+    if (two_pass && g.W <= 32) {
+        const uint32_t nbins = nb >> MSM_FINE_LOG;
+        hipLaunchKernelGGL(k_msm_coarse, dim3(nbins, np), dim3(128), 0, s, sb.hist_wg, ng, nb, sb.crel);
+        hipLaunchKernelGGL(k_msm_partition, dim3(ng, np), dim3(MSM_PART_TILE), part_lds, s, d_scalars, scalar_stride, n, g, ng, sb.crel, sb.start, sb.tmp);
+        hipLaunchKernelGGL(k_msm_bucketize, dim3(nbins, np), dim3(1024), 0, s, sb.tmp, (size_t)n * g.W, sb.start, nb, sb.sorted);
+    } else {
+        hipLaunchKernelGGL(k_msm_scatter, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg, sb.start,
+                           sb.sorted);
+    }
     return MASP_HIP_OK;
 }
 

@@ -58,16 +58,17 @@ struct MsmBases {
 struct MsmSortBuf {
     size_t cap_ent = 0, cap_nb = 0, cap_np = 0, cap_ng = 0;
     uint32_t *sorted = nullptr, *hist_wg = nullptr, *start = nullptr;
+    uint32_t *tmp = nullptr, *crel = nullptr;  // two-pass placement: entries grouped by coarse bin; per-range offsets of the bins
     // what the last msm_sort_enqueue produced (consumed by msm_reduce_enqueue)
     uint32_t n = 0, np = 0;
     MsmGeom g{};
 
     ~MsmSortBuf() { release(); }
     void release() {
-        void* ptrs[] = {sorted, hist_wg, start};
+        void* ptrs[] = {sorted, hist_wg, start, tmp, crel};
         for (void* p : ptrs)
             if (p) hipFree(p);
-        sorted = hist_wg = start = nullptr;
+        sorted = hist_wg = start = tmp = crel = nullptr;
         cap_ent = cap_nb = cap_np = cap_ng = 0;
     }
     // scalar ranges (= sorting workgroups) per proof: enough to occupy the chip across the batch, not more
@@ -90,6 +91,8 @@ struct MsmSortBuf {
         HIP_TRY(hipMalloc(&sorted, cap_np * 4 * std::max<size_t>(cap_ent, 1)));
         HIP_TRY(hipMalloc(&hist_wg, cap_np * 4 * cap_ng * cap_nb));
         HIP_TRY(hipMalloc(&start, cap_np * 4 * (cap_nb + 1)));
+        HIP_TRY(hipMalloc(&tmp, cap_np * 4 * std::max<size_t>(cap_ent, 1)));
+        HIP_TRY(hipMalloc(&crel, cap_np * 4 * cap_ng * std::max<size_t>(cap_nb >> 7, 1)));
         return MASP_HIP_OK;
     }
 };
