@@ -77,8 +77,11 @@ __global__ void k_msm_precompute(TabRow<O>* __restrict__ tab, uint32_t n, int c,
 // ---- (5) gather: bucket b = sum of its partials part[c + b], c over the chunks its entries touch ---------
 // heavy_span: a bucket with at least this many partials is left to k_msm_bucket_heavy (24 in a batch, where work
 // counts; 12 for a lone proof, where the longest serial chain counts too — but a wave per bucket costs 64 lanes)
+#ifndef MASP_TAIL_MIN_WAVES
+#define MASP_TAIL_MIN_WAVES 1
+#endif
 template <class O>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, MASP_TAIL_MIN_WAVES)
 k_msm_bucket_gather(const Xyzz<O>* __restrict__ part, const uint32_t* __restrict__ start, uint32_t nb, uint32_t nchunks,
                     Xyzz<O>* __restrict__ bkt, uint32_t* __restrict__ heavy, uint32_t* __restrict__ n_heavy, uint32_t heavy_span) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -117,7 +120,7 @@ __device__ __forceinline__ Xyzz<O> xyzz_shfl_down(const Xyzz<O>& p, int d) {
 // (THREADS = 256 measured faster than a single wave in both regimes: one bucket of ~650 partials per proof in a batch,
 // thousands of buckets with ~80 partials each for a lone proof.)
 template <class O, uint32_t THREADS>
-__global__ void __launch_bounds__(THREADS)
+__global__ void __launch_bounds__(THREADS, MASP_TAIL_MIN_WAVES)
 k_msm_bucket_heavy(const Xyzz<O>* __restrict__ part, const uint32_t* __restrict__ start, uint32_t nb, uint32_t nchunks,
                    Xyzz<O>* __restrict__ bkt, const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ n_heavy) {
     __shared__ Xyzz<O> sh[THREADS / 64];
@@ -162,7 +165,7 @@ k_msm_bucket_heavy(const Xyzz<O>* __restrict__ part, const uint32_t* __restrict_
 // G = 2^G_LOG is chosen by the host: 16 for batches (least work per bucket: ~2.9 additions), 4 for a lone proof
 // (shortest dependent chain).
 template <class O, uint32_t G_LOG>
-__global__ void __launch_bounds__(128) k_msm_wsum_level(const Xyzz<O>* __restrict__ B, size_t b_stride, uint32_t m, uint32_t off,
+__global__ void __launch_bounds__(128, MASP_TAIL_MIN_WAVES) k_msm_wsum_level(const Xyzz<O>* __restrict__ B, size_t b_stride, uint32_t m, uint32_t off,
                                                         Xyzz<O>* __restrict__ S, Xyzz<O>* __restrict__ T, size_t st_stride) {
     constexpr uint32_t G = 1u << G_LOG, CS = G * WSUM_L;
     __shared__ Xyzz<O> sh[2];

@@ -82,15 +82,24 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
         prof->recs.push_back(rec);
     }
     const bool lone = np < 8;  // latency regime: short chains matter more than total work
+    // A bucket whose entries are spread over `span` chunks or more leaves the gather lanes for a workgroup of its own
+    // (k_msm_bucket_heavy: strided sums + shuffle tree).  Batches: span 8 and SINGLE-WAVE workgroups, 65 per proof — the G2
+    // kernels hold 512 VGPRs, i.e. a whole SIMD per wave, and all but a handful of these workgroups find no work: at four
+    // waves each the idle ones alone kept the chip busy (5.5 -> 2.3 ms for the G2 launch of a 128-proof batch, +3.5 % end to
+    // end).  A lone proof keeps span 12 and four waves (shortest chain for its one big bucket).
+    // Workgroups go to the 8 XCDs round-robin by linear id x + gridDim.x * y, so with gridDim.x a multiple of 8 every proof's
+    // first working workgroup (x = 0: bucket 0) would land on the same XCD: keep gridDim.x odd.
     hipLaunchKernelGGL((k_msm_bucket_gather<O>), dim3((nb + 63) / 64, np), dim3(64), 0, s, ws.part, sb.start, nb, nchunks, ws.bkt, ws.heavy,
-                       ws.n_heavy, lone ? 12u : 24u);
-    // (with a lone proof the chunks are short and most buckets of a narrow-window MSM count as heavy: give them the chip)
-    // Usually ONE workgroup per proof has work here (bucket 0).  Workgroups go to the 8 XCDs round-robin by linear id
-    // x + gridDim.x * y, so with gridDim.x a multiple of 8 every proof's working workgroup (x = 0) would land on the same
-    // XCD (measured: 9.9 ms instead of 4.1 ms for the G2 launch of a 64-proof batch): keep gridDim.x odd.
-    const uint32_t heavy_blocks = std::min<uint32_t>(std::max<uint32_t>(4096u / np, 16u), nb) | 1u;
-    hipLaunchKernelGGL((k_msm_bucket_heavy<O, 256>), dim3(heavy_blocks, np), dim3(256), 0, s, ws.part, sb.start, nb, nchunks, ws.bkt, ws.heavy,
-                       ws.n_heavy);
+                       ws.n_heavy, lone ? 12u : 8u);
+    if (lone) {
+        const uint32_t heavy_blocks = std::min<uint32_t>(std::max<uint32_t>(4096u / np, 16u), nb) | 1u;
+        hipLaunchKernelGGL((k_msm_bucket_heavy<O, 256>), dim3(heavy_blocks, np), dim3(256), 0, s, ws.part, sb.start, nb, nchunks, ws.bkt, ws.heavy,
+                           ws.n_heavy);
+    } else {
+        const uint32_t heavy_blocks = std::min<uint32_t>(64u, nb) | 1u;
+        hipLaunchKernelGGL((k_msm_bucket_heavy<O, 64>), dim3(heavy_blocks, np), dim3(64), 0, s, ws.part, sb.start, nb, nchunks, ws.bkt, ws.heavy,
+                           ws.n_heavy);
+    }
     // weighted sum by levels of (G x 128)-bucket workgroups; G = 16 buckets per lane in a batch (least work per bucket:
     // the latency of the launches with few buckets hides behind the other batches in flight; choosing G = 4 for those
     // was measured 2 % slower), 4 for a lone proof (shortest dependent chain)
