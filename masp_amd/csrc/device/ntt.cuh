@@ -113,7 +113,47 @@ __global__ void __launch_bounds__(256) k_ntt_pass(Fr* __restrict__ data, const F
         tile[tsize + L] = q[1];
     }
     __syncthreads();
-    for (uint32_t q = 0; q < nst; ++q) {
+    auto ld = [&](uint32_t L) {
+        Fr r;
+        uint4 a0 = tile[L], a1 = tile[tsize + L];
+        r.v[0] = a0.x; r.v[1] = a0.y; r.v[2] = a0.z; r.v[3] = a0.w; r.v[4] = a1.x; r.v[5] = a1.y; r.v[6] = a1.z; r.v[7] = a1.w;
+        return r;
+    };
+    auto st = [&](uint32_t L, const Fr& x) {
+        tile[L] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+        tile[tsize + L] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+    };
+    uint32_t q = 0;
+    // two stages at a time: a lane holds the four elements that differ in bits q, q + 1 of the butterfly index and does both
+    // stages in registers (same four products as two radix-2 stages, half the LDS round trips and barriers)
+    for (; q + 1 < nst; q += 2) {
+        const uint32_t s = s0 + q;
+        for (uint32_t gidx = threadIdx.x; gidx < (tsize >> 2); gidx += blockDim.x) {
+            const uint32_t cl = gidx & (cols - 1), r = gidx >> cols_log;
+            const uint32_t hj = r & ((1u << q) - 1u), hg = r >> q;
+            const uint32_t h00 = (hg << (q + 2)) | hj;
+            const uint32_t L0 = (h00 << cols_log) | cl, d = cols << q;  // elements at L0, L0 + d, L0 + 2d, L0 + 3d
+            const uint32_t lo = (col0 + cl) & lomask;
+            const uint32_t j1 = (hj << s0) | lo;                          // stage s: both pairs
+            const uint32_t j2a = j1, j2b = ((hj | (1u << q)) << s0) | lo;  // stage s + 1: pairs with bit q clear / set
+            const Fr w1 = fr_load(tw + ((size_t)j1 << (logm - s - 1)));
+            const Fr w2a = fr_load(tw + ((size_t)j2a << (logm - s - 2)));
+            const Fr w2b = fr_load(tw + ((size_t)j2b << (logm - s - 2)));
+            Fr x0 = ld(L0), x1 = ld(L0 + d), x2 = ld(L0 + 2 * d), x3 = ld(L0 + 3 * d);
+            Fr t = fe_mul(x1, w1);
+            Fr y0 = fe_add(x0, t), y1 = fe_sub(x0, t);
+            t = fe_mul(x3, w1);
+            Fr y2 = fe_add(x2, t), y3 = fe_sub(x2, t);
+            t = fe_mul(y2, w2a);
+            st(L0, fe_add(y0, t));
+            st(L0 + 2 * d, fe_sub(y0, t));
+            t = fe_mul(y3, w2b);
+            st(L0 + d, fe_add(y1, t));
+            st(L0 + 3 * d, fe_sub(y1, t));
+        }
+        __syncthreads();
+    }
+    for (; q < nst; ++q) {
         const uint32_t s = s0 + q;
         for (uint32_t b = threadIdx.x; b < (tsize >> 1); b += blockDim.x) {
             uint32_t cl = b & (cols - 1), hb = b >> cols_log;
@@ -123,16 +163,9 @@ __global__ void __launch_bounds__(256) k_ntt_pass(Fr* __restrict__ data, const F
             uint32_t col = col0 + cl;
             uint32_t jglob = (hj << s0) | (col & lomask);
             Fr w = fr_load(tw + ((size_t)jglob << (logm - s - 1)));
-            Fr u, v;
-            uint4 a0 = tile[L0], a1 = tile[tsize + L0], b0 = tile[L1], b1 = tile[tsize + L1];
-            u.v[0] = a0.x; u.v[1] = a0.y; u.v[2] = a0.z; u.v[3] = a0.w; u.v[4] = a1.x; u.v[5] = a1.y; u.v[6] = a1.z; u.v[7] = a1.w;
-            v.v[0] = b0.x; v.v[1] = b0.y; v.v[2] = b0.z; v.v[3] = b0.w; v.v[4] = b1.x; v.v[5] = b1.y; v.v[6] = b1.z; v.v[7] = b1.w;
-            v = fe_mul(v, w);
-            Fr x = fe_add(u, v), y = fe_sub(u, v);
-            tile[L0] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
-            tile[tsize + L0] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
-            tile[L1] = make_uint4(y.v[0], y.v[1], y.v[2], y.v[3]);
-            tile[tsize + L1] = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
+            Fr u = ld(L0), v = fe_mul(ld(L1), w);
+            st(L0, fe_add(u, v));
+            st(L1, fe_sub(u, v));
         }
         __syncthreads();
     }
