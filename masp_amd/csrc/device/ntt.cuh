@@ -77,11 +77,11 @@ __global__ void k_ntt_abc_bitrev(const Fr* __restrict__ a, const Fr* __restrict_
     fr_store(y + bitrev(k, logm), v);
 }
 // y[k] = x[k] * scale[k]  (no permutation; with a plain-form scale table this also leaves Montgomery form)
-__global__ void k_fr_scale(const Fr* __restrict__ x, const Fr* __restrict__ scale, Fr* __restrict__ y, uint32_t n) {
+__global__ void k_fr_scale(const Fr* __restrict__ x, const Fr* __restrict__ scale, Fr* __restrict__ y, uint32_t n, size_t y_stride) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     x += (size_t)NTT_P * n;
-    y += (size_t)NTT_P * n;
+    y += (size_t)NTT_P * y_stride;
     fr_store(y + k, fe_mul(fr_load(x + k), fr_load(scale + k)));
 }
 __global__ void k_fr_from_mont(const Fr* __restrict__ x, Fr* __restrict__ y, uint32_t n) {

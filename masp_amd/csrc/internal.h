@@ -109,6 +109,9 @@ struct Circuit {
     DevBuf<G1Xyzz> fb1;  // fixed-base tables of delta1, alpha1, beta1
     DevBuf<G2Xyzz> fb2;  // fixed-base table of delta2
     BasesG1 h, l, a, b1;
+    // h and l as ONE base set (h's points, then l's) on h's windows: C only needs H + L, so a batch runs them as one MSM over
+    // one bucket set — l's scalars then cost 16 window digits instead of 22 and its sort / bucket tails disappear
+    BasesG1 hl;
     BasesG2 b2;
     NttDomain* dom = nullptr;
 };
@@ -126,7 +129,7 @@ struct Slot {
     hipStream_t aux[N_AUX] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_sort_b = nullptr, ev_join[N_AUX] = {nullptr, nullptr, nullptr, nullptr};
     MsmWorkspace<FpOps> ws_l, ws_a, ws_b;
-    DevBuf<Fr> w, abc, wm, ev[3], x0[3], x1[3], h, sa, sb;
+    DevBuf<Fr> w, abc, wm, ev[3], x0[3], x1[3], h, hl, sa, sb;
     DevBuf<G1Xyzz> res1;
     DevBuf<G2Xyzz> res2;
     DevBuf<uint32_t> rs;

@@ -24,8 +24,8 @@ void launch_ntt_scale_bitrev(hipStream_t s, const Fr* x, const Fr* scale, Fr* y,
 void launch_ntt_abc_bitrev(hipStream_t s, const Fr* a, const Fr* b, const Fr* c, const Fr& zinv, Fr* y, uint32_t logm, uint32_t np) {
     hipLaunchKernelGGL(k_ntt_abc_bitrev, dim3(((1u << logm) + 255) / 256, np), dim3(256), 0, s, a, b, c, zinv, y, logm);
 }
-void launch_fr_scale(hipStream_t s, const Fr* x, const Fr* scale, Fr* y, uint32_t n, uint32_t np) {
-    hipLaunchKernelGGL(k_fr_scale, dim3((n + 255) / 256, np), dim3(256), 0, s, x, scale, y, n);
+void launch_fr_scale(hipStream_t s, const Fr* x, const Fr* scale, Fr* y, uint32_t n, uint32_t np, size_t y_stride) {
+    hipLaunchKernelGGL(k_fr_scale, dim3((n + 255) / 256, np), dim3(256), 0, s, x, scale, y, n, y_stride ? y_stride : (size_t)n);
 }
 void launch_fr_from_mont(hipStream_t s, const Fr* x, Fr* y, uint32_t n) {
     hipLaunchKernelGGL(k_fr_from_mont, dim3((n + 255) / 256), dim3(256), 0, s, x, y, n);

@@ -16,7 +16,8 @@ void launch_ntt_load_bitrev(hipStream_t s, const Fr* x, size_t x_stride, uint32_
 void launch_ntt_copy_bitrev(hipStream_t s, const Fr* x, size_t x_stride, uint32_t nrows, Fr* y, uint32_t logm, uint32_t np);
 void launch_ntt_scale_bitrev(hipStream_t s, const Fr* x, const Fr* scale, Fr* y, uint32_t logm, uint32_t np);
 void launch_ntt_abc_bitrev(hipStream_t s, const Fr* a, const Fr* b, const Fr* c, const Fr& zinv, Fr* y, uint32_t logm, uint32_t np);
-void launch_fr_scale(hipStream_t s, const Fr* x, const Fr* scale, Fr* y, uint32_t n, uint32_t np);
+// y_p = y + p * y_stride (0: n)
+void launch_fr_scale(hipStream_t s, const Fr* x, const Fr* scale, Fr* y, uint32_t n, uint32_t np, size_t y_stride = 0);
 void launch_fr_from_mont(hipStream_t s, const Fr* x, Fr* y, uint32_t n);
 void launch_fr_to_mont(hipStream_t s, const Fr* x, size_t x_stride, Fr* y, uint32_t n, uint32_t np, int* range_err);
 void launch_r1cs_eval(hipStream_t s, const uint32_t* rowptr, const uint32_t* order, const uint32_t* col, const Fr* coef, const Fr* w, uint32_t n_vars,

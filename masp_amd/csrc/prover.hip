@@ -116,7 +116,9 @@ static int fail_shared(masp_hip_ctx* ctx, int rc) {
 
 // Quotient for np proofs on slot buffers: in[i] + p * in_stride are Montgomery (mont_in) or canonical evaluation
 // vectors of `nrows` entries on the device; result: sl.h + p * m = canonical coefficients h[0..m-1).
-static int enqueue_quotient(Slot& sl, const NttDomain& D, const Fr* const in[3], size_t in_stride, uint32_t nrows, bool mont_in, uint32_t np) {
+// h_out (stride h_stride elements per proof; NULL: sl.h, stride m).
+static int enqueue_quotient(Slot& sl, const NttDomain& D, const Fr* const in[3], size_t in_stride, uint32_t nrows, bool mont_in, uint32_t np,
+                            Fr* h_out = nullptr, size_t h_stride = 0) {
     hipStream_t s = sl.stream;
     const uint32_t m = (uint32_t)D.m, logm = D.logm;
     // A batch goes through the seven transforms in sub-batches whose six work buffers (sub x 6 x 32 m bytes: 192 MiB for
@@ -130,7 +132,11 @@ static int enqueue_quotient(Slot& sl, const NttDomain& D, const Fr* const in[3],
     int rc;
     for (int i = 0; i < 3; ++i)
         if ((rc = sl.x0[i].reserve((size_t)m * sub)) || (rc = sl.x1[i].reserve((size_t)m * sub))) return rc;
-    if ((rc = sl.h.reserve((size_t)m * np))) return rc;
+    if (!h_out) {
+        if ((rc = sl.h.reserve((size_t)m * np))) return rc;
+        h_out = sl.h.p;
+        h_stride = m;
+    }
     for (uint32_t p0 = 0; p0 < np; p0 += sub) {
         const uint32_t q = std::min(sub, np - p0);
         for (int i = 0; i < 3; ++i) {
@@ -145,7 +151,7 @@ static int enqueue_quotient(Slot& sl, const NttDomain& D, const Fr* const in[3],
         }
         launch_ntt_abc_bitrev(s, sl.x1[0].p, sl.x1[1].p, sl.x1[2].p, D.zinv, sl.x0[0].p, logm, q);
         D.passes(s, sl.x0[0].p, D.tw_inv.p, q);
-        launch_fr_scale(s, sl.x0[0].p, D.h_scale.p, sl.h.p + (size_t)p0 * m, m, q);  // * g^-k / m, leaves Montgomery form
+        launch_fr_scale(s, sl.x0[0].p, D.h_scale.p, h_out + (size_t)p0 * h_stride, m, q, h_stride);  // * g^-k / m, leaves Montgomery form
     }
     return MASP_HIP_OK;
 }
@@ -215,12 +221,19 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
             HIP_TRY(hipStreamWaitEvent(s, sl.ev_join[i], 0));
         }
     } else {
-        if ((rc = enqueue_quotient(sl, *C.dom, in, C.nrows, C.nrows, mont_in, np))) return rc;
+        // H and L as one MSM over the merged base set (Circuit::hl): the scalars of a proof are its m - 1 quotient coefficients
+        // followed by its aux assignment (the quotient's m-th, unused, coefficient lands on the first aux slot and is then
+        // overwritten by the copy)
+        const size_t hl_stride = C.hl.n;
+        if ((rc = sl.hl.reserve(hl_stride * np + 1))) return rc;
+        if ((rc = enqueue_quotient(sl, *C.dom, in, C.nrows, C.nrows, mont_in, np, sl.hl.p, hl_stride))) return rc;
+        HIP_TRY(hipMemcpy2DAsync(sl.hl.p + (C.m - 1), hl_stride * sizeof(Fr), d_w + C.n_inputs, w_stride * sizeof(Fr), (size_t)C.n_aux * sizeof(Fr), np,
+                                 hipMemcpyDeviceToDevice, s));
         // query scalars selected by density
         if (C.na) launch_gather_scalars(s, d_w, w_stride, C.a_var.p, C.na, sl.sa.p, np);
         if (C.nbq) launch_gather_scalars(s, d_w, w_stride, C.b_var.p, C.nbq, sl.sb.p, np);
-        if ((rc = msm_enqueue(s, C.h, sl.ws1, (const uint32_t*)sl.h.p, m8, sl.res1.p + 0, 4, np, prof))) return rc;
-        if ((rc = msm_enqueue(s, C.l, sl.ws1, (const uint32_t*)(d_w + C.n_inputs), w_stride * 8, sl.res1.p + 1, 4, np, prof))) return rc;
+        if ((rc = msm_enqueue(s, C.hl, sl.ws1, (const uint32_t*)sl.hl.p, hl_stride * 8, sl.res1.p + 0, 4, np, prof))) return rc;
+        for (uint32_t p = 0; p < np; ++p) HIP_TRY(hipMemsetAsync(sl.res1.p + 4 * p + 1, 0, sizeof(G1Xyzz), s));  // L is inside H + L
         if ((rc = msm_enqueue(s, C.a, sl.ws1, (const uint32_t*)sl.sa.p, (size_t)C.na * 8, sl.res1.p + 2, 4, np, prof))) return rc;
         if ((rc = msm_enqueue(s, C.b1, sl.ws1, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res1.p + 3, 4, np, prof))) return rc;
         if (share_b) {
@@ -488,6 +501,13 @@ int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* param
         (rc = C->a.load_host(L.a, L.n_a, s, eff(L.n_a), c_la)) || (rc = C->b1.load_host(L.b_g1, L.n_b1, s, eff(L.n_b1), c_b)) ||
         (rc = C->b2.load_host(L.b_g2, L.n_b2, s, eff(L.n_b2), c_b)))
         return fail(ctx, rc);
+    {
+        const size_t nh = C->m - 1;
+        std::vector<uint8_t> cat(96 * (nh + L.n_l));
+        memcpy(cat.data(), L.h, 96 * nh);
+        memcpy(cat.data() + 96 * nh, L.l, 96 * (size_t)L.n_l);
+        if ((rc = C->hl.load_host(cat.data(), (uint32_t)(nh + L.n_l), s, 0xffffffffu, C->h.g.c))) return fail(ctx, rc);
+    }
     int st = C->h.import_status | C->l.import_status | C->a.import_status | C->b1.import_status | C->b2.import_status;
     if (st) return MASP_HIP_E_PARAMS_FORMAT;  // includes infinity inside a query vector, which bellman rejects
     if ((rc = get_domain(ctx, C->logm, &C->dom))) return fail(ctx, rc);
