@@ -304,7 +304,7 @@ def main():
                                "instances_per_s_all_threads": round(n / synth_wall, 1), "threads": threads},
             "ms_per_proof": elapsed * 1e3 / (K * n),
             "gpu_event_ms_per_step": gpu_ms / K,
-            "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate<G1> (bucket accumulation of the 4 G1 MSMs)",
+            "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate<G1> (bucket accumulation of the G1 MSMs: h+l merged, a, b_g1)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "launches": launches, "avg_launch_ms": acc_ms / launches if launches else None,
                          "alg_bytes_per_launch": alg_bytes / launches if launches else None,

@@ -38,7 +38,11 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     vals = [float(r["Counter_Value"]) for r in rows if int(r["Grid_Size"]) == full]
     res[c] = (sum(vals) / len(vals), len(vals))
 fetch_kb, n1 = res["FETCH_SIZE"]; write_kb, n2 = res["WRITE_SIZE"]
-alg = batch * 48725632 / 4.0
+# algorithmic bytes per launch as the bench itself reports them (n x 128 B per G1 MSM and proof; a batch runs three G1
+# accumulations: H+L merged, A, B1)
+import re
+line = [l for l in open("%s/FETCH_SIZE.log" % out).read().splitlines() if l.startswith("{")][-1]
+alg = json.loads(line)["roofline"]["alg_bytes_per_launch"]
 doc = {
  "kernel": "k_msm_accumulate<G1>",
  "command": "tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline (256 distinct Spend witnesses per step); calibration pass on tools/_build/pmc_calib",
@@ -50,7 +54,7 @@ doc = {
  "fetch_bytes_per_launch_calibrated": fetch_kb * 1024.0 * factor, "write_bytes_per_launch_as_reported": write_kb * 1024.0,
  "hbm_bytes_per_launch": fetch_kb * 1024.0 * factor + write_kb * 1024.0, "proofs_per_launch": batch,
  "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (fetch_kb * 1024.0 * factor + write_kb * 1024.0) / alg,
- "note": "one launch covers one G1 query (h, l, a or b_g1) of a batch of %d proofs; counters averaged over the four queries. Traffic exceeds the algorithmic bytes (n x 128 B per proof) because every non-zero window digit reads its own table row (16 rows per full-width scalar of h, 22 per non-trivial witness scalar): the HBM-capacity-for-ALU trade of DESIGN.md, not re-reads of the same data. WRITE_SIZE is uncalibrated (partial sums: 144-byte stores)." % batch,
+ "note": "one launch covers one G1 accumulation (h+l merged, a, or b_g1) of a batch of %d proofs; counters averaged over the three. Traffic exceeds the algorithmic bytes (n x 128 B per proof) because every non-zero window digit reads its own table row (16 rows per full-width scalar of h and l, 22 per non-trivial scalar of a / b_g1): the HBM-capacity-for-ALU trade of DESIGN.md, not re-reads of the same data. WRITE_SIZE is uncalibrated (partial sums: 144-byte stores)." % batch,
 }
 json.dump(doc, open("$root/profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(doc, indent=1))
