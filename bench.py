@@ -96,7 +96,7 @@ def main():
         sys.exit("bench.py: --gpus %d but the launcher started %d rank(s): refusing to report a figure for a different GPU count" % (args.gpus, world))
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # let independent batches' kernels overlap (ROCm default: 4)
     os.environ.setdefault("MASP_HIP_SLOTS", "4")
-    os.environ.setdefault("MASP_HIP_BATCH", "128")
+    os.environ.setdefault("MASP_HIP_BATCH", "256")
     dist = dev = None
     backend = os.environ.get("MASP_BENCH_BACKEND", "nccl")      # "nccl" = RCCL on ROCm; "gloo" only for the CPU dry run
     if world > 1 or os.environ.get("MASP_BENCH_FORCE_DIST"):
@@ -180,8 +180,10 @@ def main():
 
     rs_warm, rs_a, rs_b = fresh_rs(max(Wm, 1)), fresh_rs(K), fresh_rs(K)
     handle, _ = ctx.batch_upload(jobs_with(rs_a[0]))
-    # set-up, not warm-up: every slot's workspace (hipMalloc on first use) gets its final size — two steps reach all four slots
-    ctx.batch_prove_resident_steps(handle, n, 2, fresh_rs(2))
+    # set-up, not warm-up: every slot's workspace (hipMalloc on first use) gets its final size — enough steps to reach every slot
+    groups_per_step = sum(-(-job_kind.count(k) // int(os.environ["MASP_HIP_BATCH"])) for k in kinds)
+    sizing_steps = max(2, -(-int(os.environ["MASP_HIP_SLOTS"]) // groups_per_step))
+    ctx.batch_prove_resident_steps(handle, n, sizing_steps, fresh_rs(sizing_steps))
     if Wm > 0:
         ctx.batch_prove_resident_steps(handle, n, Wm, rs_warm)
     marshalled = [ctx.marshal_jobs(jobs_with(rs_b[k])) for k in range(K)]

@@ -129,7 +129,7 @@ struct Slot {
     hipStream_t aux[N_AUX] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_sort_b = nullptr, ev_join[N_AUX] = {nullptr, nullptr, nullptr, nullptr};
     MsmWorkspace<FpOps> ws_l, ws_a, ws_b;
-    DevBuf<Fr> w, abc, wm, ev[3], x0[3], x1[3], h, hl, sa, sb;
+    DevBuf<Fr> w, abc, wm, ev[3], x0, x1, h, hl, sa, sb;
     DevBuf<G1Xyzz> res1;
     DevBuf<G2Xyzz> res2;
     DevBuf<uint32_t> rs;

@@ -100,10 +100,20 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
         hipLaunchKernelGGL((k_msm_bucket_heavy<O, 64>), dim3(heavy_blocks, np), dim3(64), 0, s, ws.part, sb.start, nb, nchunks, ws.bkt, ws.heavy,
                            ws.n_heavy);
     }
-    // weighted sum by levels of (G x 128)-bucket workgroups; G = 16 buckets per lane in a batch (least work per bucket:
-    // the latency of the launches with few buckets hides behind the other batches in flight; choosing G = 4 for those
-    // was measured 2 % slower), 4 for a lone proof (shortest dependent chain)
-    const uint32_t g_log = lone ? WSUM_G_LOG_MIN : 4;
+    // weighted sum by levels of (G x 128)-bucket workgroups.  Per lane the kernel costs 2 G additions for its buckets plus
+    // ~19 for the two lane scans: a batch takes the largest G in {8 .. 64} that still fills one workgroup (2 048 buckets: 16,
+    // the 32 768 of h+l: 64 = 2.3 instead of 3.2 additions per bucket) — with other batches in flight total work counts, not
+    // the length of the chain; a lone proof takes 4 (shortest dependent chain).
+    uint32_t g_log = WSUM_G_LOG_MIN;
+    if (!lone) {
+        static const int forced = [] {
+            const char* e = getenv("MASP_HIP_WSUM_G_LOG");  // experiment knob: upper limit of G
+            return e ? atoi(e) : 0;
+        }();
+        const uint32_t hi = forced >= 3 && forced <= 6 ? (uint32_t)forced : 6u;
+        g_log = 3;
+        while (g_log < hi && (1u << (g_log + 1 + WSUM_L_LOG)) <= nb) ++g_log;
+    }
     const uint32_t cs = 1u << (g_log + WSUM_L_LOG);
     const size_t st_stride = (nb + cs - 1) / cs;  // level-0 chunk count bounds every later level
     const Xyzz<O>* bk = ws.bkt;
@@ -112,11 +122,13 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
     int level = 0, flip = 0;
     do {
         uint32_t chunks = (m + cs - 1) / cs;
-        if (g_log == 4)
-            hipLaunchKernelGGL((k_msm_wsum_level<O, 4>), dim3(chunks, np), dim3(WSUM_L), 0, s, bk, bk_stride, m, off, ws.S[flip], ws.T, st_stride);
-        else
-            hipLaunchKernelGGL((k_msm_wsum_level<O, WSUM_G_LOG_MIN>), dim3(chunks, np), dim3(WSUM_L), 0, s, bk, bk_stride, m, off, ws.S[flip],
-                               ws.T, st_stride);
+        const dim3 grid(chunks, np), block(WSUM_L);
+        switch (g_log) {
+#define MASP_WSUM_CASE(GL) \
+    case GL: hipLaunchKernelGGL((k_msm_wsum_level<O, GL>), grid, block, 0, s, bk, bk_stride, m, off, ws.S[flip], ws.T, st_stride); break;
+            MASP_WSUM_CASE(2) MASP_WSUM_CASE(3) MASP_WSUM_CASE(4) MASP_WSUM_CASE(5) MASP_WSUM_CASE(6)
+#undef MASP_WSUM_CASE
+        }
         ws.reduce_to_one(s, np, ws.T, st_stride, chunks, ws.tsum + level, 32, st_stride);
         bk = ws.S[flip];
         bk_stride = st_stride;

@@ -130,28 +130,32 @@ static int enqueue_quotient(Slot& sl, const NttDomain& D, const Fr* const in[3],
     }();
     const uint32_t sub = sub_max ? std::min(sub_max, np) : np;
     int rc;
-    for (int i = 0; i < 3; ++i)
-        if ((rc = sl.x0[i].reserve((size_t)m * sub)) || (rc = sl.x1[i].reserve((size_t)m * sub))) return rc;
+    // a, b and c go through every pass TOGETHER: the three transforms of a sub-batch lie back to back in one buffer
+    // ([a | b | c] x q proofs) and a pass is one launch over 3 q transforms — three times the workgroups per launch
+    // (a lone proof: 384 instead of 128 on 256 CUs) and 12 instead of 22 launches per sub-batch
+    if ((rc = sl.x0.reserve((size_t)3 * m * sub)) || (rc = sl.x1.reserve((size_t)3 * m * sub))) return rc;
     if (!h_out) {
         if ((rc = sl.h.reserve((size_t)m * np))) return rc;
         h_out = sl.h.p;
         h_stride = m;
     }
+    Fr *x0 = sl.x0.p, *x1 = sl.x1.p;
     for (uint32_t p0 = 0; p0 < np; p0 += sub) {
         const uint32_t q = std::min(sub, np - p0);
+        const size_t part = (size_t)q * m;  // one of a / b / c for the whole sub-batch
         for (int i = 0; i < 3; ++i) {
             const Fr* src = in[i] + (size_t)p0 * in_stride;
             if (mont_in)
-                launch_ntt_copy_bitrev(s, src, in_stride, nrows, sl.x0[i].p, logm, q);
+                launch_ntt_copy_bitrev(s, src, in_stride, nrows, x0 + i * part, logm, q);
             else
-                launch_ntt_load_bitrev(s, src, in_stride, nrows, sl.x0[i].p, logm, q);
-            D.passes(s, sl.x0[i].p, D.tw_inv.p, q);                                      // iNTT (unscaled)
-            launch_ntt_scale_bitrev(s, sl.x0[i].p, D.coset_scale.p, sl.x1[i].p, logm, q);  // * g^k / m
-            D.passes(s, sl.x1[i].p, D.tw_fwd.p, q);                                      // coset NTT
+                launch_ntt_load_bitrev(s, src, in_stride, nrows, x0 + i * part, logm, q);
         }
-        launch_ntt_abc_bitrev(s, sl.x1[0].p, sl.x1[1].p, sl.x1[2].p, D.zinv, sl.x0[0].p, logm, q);
-        D.passes(s, sl.x0[0].p, D.tw_inv.p, q);
-        launch_fr_scale(s, sl.x0[0].p, D.h_scale.p, h_out + (size_t)p0 * h_stride, m, q, h_stride);  // * g^-k / m, leaves Montgomery form
+        D.passes(s, x0, D.tw_inv.p, 3 * q);                                     // iNTT (unscaled)
+        launch_ntt_scale_bitrev(s, x0, D.coset_scale.p, x1, logm, 3 * q);       // * g^k / m
+        D.passes(s, x1, D.tw_fwd.p, 3 * q);                                     // coset NTT
+        launch_ntt_abc_bitrev(s, x1, x1 + part, x1 + 2 * part, D.zinv, x0, logm, q);
+        D.passes(s, x0, D.tw_inv.p, q);
+        launch_fr_scale(s, x0, D.h_scale.p, h_out + (size_t)p0 * h_stride, m, q, h_stride);  // * g^-k / m, leaves Montgomery form
     }
     return MASP_HIP_OK;
 }
@@ -842,19 +846,19 @@ int masp_hip_ntt(masp_hip_ctx* ctx, uint8_t* data, uint32_t logm, int inverse) {
     NttDomain* D;
     if ((rc = get_domain(ctx, logm, &D))) return fail(ctx, rc);
     uint32_t m = 1u << logm;
-    if ((rc = sl.w.reserve(m)) || (rc = sl.x0[0].reserve(m)) || (rc = sl.x1[0].reserve(m))) return fail(ctx, rc);
+    if ((rc = sl.w.reserve(m)) || (rc = sl.x0.reserve(m)) || (rc = sl.x1.reserve(m))) return fail(ctx, rc);
     hipStream_t s = sl.stream;
     if (hipMemcpyAsync(sl.w.p, data, 32 * (size_t)m, hipMemcpyHostToDevice, s) != hipSuccess) return fail(ctx, MASP_HIP_E_HIP);
-    launch_ntt_load_bitrev(s, sl.w.p, (size_t)0, m, sl.x0[0].p, logm, 1);
-    D->passes(s, sl.x0[0].p, inverse ? D->tw_inv.p : D->tw_fwd.p);
+    launch_ntt_load_bitrev(s, sl.w.p, (size_t)0, m, sl.x0.p, logm, 1);
+    D->passes(s, sl.x0.p, inverse ? D->tw_inv.p : D->tw_fwd.p);
     if (inverse) {
         // 1/m scaling: coset_scale[0] = g^0 / m
-        Fr* minv_tab = sl.x1[0].p;
+        Fr* minv_tab = sl.x1.p;
         Fr minv = fe_inv(fr_from_u64_mont(m));
         launch_fr_powers(s, minv_tab, m, fe_one<FrCfg>(), minv, 0);
-        launch_fr_scale(s, sl.x0[0].p, minv_tab, sl.x0[0].p, m, 1);
+        launch_fr_scale(s, sl.x0.p, minv_tab, sl.x0.p, m, 1);
     }
-    launch_fr_from_mont(s, sl.x0[0].p, sl.w.p, m);
+    launch_fr_from_mont(s, sl.x0.p, sl.w.p, m);
     if (hipMemcpyAsync(data, sl.w.p, 32 * (size_t)m, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
         last_hip_error() = std::string("ntt failed: ") + hipGetErrorString(hipGetLastError());
         return fail(ctx, MASP_HIP_E_HIP);

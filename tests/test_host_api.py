@@ -1,0 +1,70 @@
+"""Host-side mirror of the pieces of masp_primitives the proving path touches: AllowedConversion
+(/root/reference/masp_primitives/src/convert.rs:22-118), the canonical-scalar contract of jubjub::Fr, and the bench
+instances (masp_amd/workload.py, shaped like /root/reference/masp_proofs/benches/{sapling,convert}.rs)."""
+import pytest
+
+import oracle_lib as O
+
+
+def test_allowed_conversion_is_the_signed_sum_of_asset_generators():
+    from masp_amd import host as H
+    a, b, c = (H.asset_identifier(n) for n in (b"asset 7", b"asset 8", b"reward"))
+    ac = H.AllowedConversion([(a, -8), (b, 8), (c, 8)])                      # the reference bench's shape (benches/convert.rs:32-44)
+    g = H.JUBJUB_IDENTITY
+    for ident, v in ((a, -8), (b, 8), (c, 8)):
+        g = H.jubjub_add(g, H.jubjub_mul(H.asset_generator(ident), abs(v)), subtract=v < 0)
+    assert ac.generator == g and ac.cmu() == H.convert_cmu(g)
+    # ValueSum addition merges equal asset types and drops zeros; order does not matter
+    assert H.AllowedConversion([(c, 8), (a, -3), (b, 8), (a, -5), (b"\x01" * 32, 0)]).generator == g
+    assert H.AllowedConversion({}).generator == H.JUBJUB_IDENTITY
+    # `abs as u64` keeps the low 64 bits of |value| (convert.rs:96-99), and i128::MIN has no absolute value ("invalid conversion")
+    big = (1 << 64) + 5
+    assert H.AllowedConversion([(a, big)]).generator == H.AllowedConversion([(a, 5)]).generator
+    assert H.AllowedConversion([(a, -big)]).generator == H.AllowedConversion([(a, -5)]).generator
+    with pytest.raises(ValueError):
+        H.AllowedConversion([(a, -(1 << 127))])
+    # value commitment = [value]([8] generator) + [rcv] G_vcr, as the Convert circuit's native side computes it
+    from masp_amd import workload as W
+    kind, kw = W.description("convert", 3)
+    _, _, cv = H.convert_assignment(kw["allowed_conversion"].generator, kw["value"], kw["anchor"], kw["merkle_path"][0], kw["merkle_path"][1], kw["rcv"])
+    assert kw["allowed_conversion"].value_commitment(kw["value"], kw["rcv"]) == cv
+
+
+def test_unreduced_jubjub_scalars_are_rejected():
+    """jubjub::Fr is canonical by construction in the reference; raw bytes >= the subgroup order would make the circuit's
+    252-bit witness disagree with the natively computed cv / rk / cm — a silently invalid proof.  They are an error here."""
+    from masp_amd import host as H
+    from masp_amd import workload as W
+    kind, kw = W.description("spend", 1)
+    ak, nsk = kw["proof_generation_key"]
+    sib, pos = kw["merkle_path"]
+    args = [ak, nsk, kw["diversifier"], kw["rcm"], kw["ar"], kw["asset_type"], kw["value"], kw["anchor"], sib, pos, kw["rcv"]]
+    H.spend_assignment(*args)
+    for idx in (1, 3, 4, 10):                                # nsk, rcm, ar, rcv
+        bad = list(args)
+        bad[idx] = H.JUBJUB_ORDER + 5 if idx != 10 else H.JUBJUB_ORDER
+        with pytest.raises(H.HostError) as e:
+            H.spend_assignment(*bad)
+        assert e.value.code == 1
+    kind, kw = W.description("output", 1)
+    d, pk = kw["payment_address"]
+    with pytest.raises(H.HostError):
+        H.output_assignment((1 << 256) - 1, d, pk, kw["rcm"], kw["asset_type"], kw["value"], kw["rcv"])
+    kind, kw = W.description("convert", 1)
+    with pytest.raises(H.HostError):
+        H.convert_assignment(kw["allowed_conversion"].generator, 1, kw["anchor"], kw["merkle_path"][0], kw["merkle_path"][1], H.JUBJUB_ORDER)
+
+
+@pytest.mark.parametrize("kind", ["spend", "output", "convert"])
+def test_bench_instances_are_distinct_and_satisfy_their_circuits(kind):
+    from masp_amd import host as H
+    from masp_amd import workload as W
+    insts = W.instances(kind, 6, first_seed=50, threads=2)
+    cs = H.circuit(kind)[0]
+    assert len({a.tobytes() for _, a in insts}) == 6 and len({i.tobytes() for i, _ in insts}) == 6
+    for inputs, aux in insts:
+        assert O.r1cs_unsatisfied(cs, inputs, aux) == 0      # independent evaluation by the oracle
+        assert len(W.public_inputs(inputs)) == cs.n_inputs - 1
+    # deterministic in (kind, seed)
+    again = W.instances(kind, 2, first_seed=50, threads=1)
+    assert all((x[0] == y[0]).all() and (x[1] == y[1]).all() for x, y in zip(insts, again))

@@ -31,7 +31,7 @@ true96 = rows_per_launch * 1.5 * 128.0     # a 96-byte row at a 96-byte stride t
 factor = true128 / (rep128 * 1024.0)
 # ---- the kernel itself
 res = {}
-batch = int(os.environ.get("MASP_HIP_BATCH", "128"))
+batch = int(os.environ.get("MASP_HIP_BATCH", "256"))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     rows = [r for r in rows_of(c, c) if "k_msm_accumulate<masp::FpOps>" in r["Kernel_Name"]]
     full = max(int(r["Grid_Size"]) for r in rows)          # the full batches (lone-proof launches have another grid)

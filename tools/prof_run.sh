@@ -7,6 +7,6 @@ rm -rf $out; mkdir -p $out
 (cd /tmp && env "$@" rocprofv3 --kernel-trace -d $out -o run -- python $OLDPWD/bench.py ${PROF_ARGS:---no-cpu-baseline} > $out/bench.log 2>&1)
 db=$(find $out -name "*.db" | head -1)
 python tools/rocpd_stats.py $db > $out/all.txt
-python tools/rocpd_stats.py $db ${PROF_GY:-96} > $out/batch.txt
+python tools/rocpd_stats.py $db ${PROF_GY:-256} > $out/batch.txt
 tail -1 $out/bench.log | cut -c1-200
 cat $out/batch.txt
