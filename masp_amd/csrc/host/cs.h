@@ -67,12 +67,18 @@ class CS {
   public:
     CS(bool record, bool witness) : record_(record), witness_(witness) {
         inputs_.push_back(Fr::one());  // ONE
+        if (witness) aux_.reserve(1u << 17);  // the largest circuit (Spend) has 100 497 auxiliary variables
     }
     bool has_witness() const { return witness_; }
     bool recording() const { return record_; }
 
     Var alloc(const Fr& value) {
         aux_.push_back(value);
+        return AUX | (Var)(aux_.size() - 1);
+    }
+    Var alloc_bit(bool value) {
+        static const Fr bit[2] = {Fr::zero(), Fr::one()};
+        aux_.push_back(bit[value]);
         return AUX | (Var)(aux_.size() - 1);
     }
     Var alloc_input(const Fr& value) {
@@ -190,39 +196,39 @@ struct AllocatedBit {
     bool value;  // meaningful only with a witness
 
     static AllocatedBit alloc(CS& cs, bool value) {
-        Var v = cs.alloc(value ? Fr::one() : Fr::zero());
+        Var v = cs.alloc_bit(value);
         // (1 - a) * a = 0
         MASP_ENFORCE(cs, LC(ONE).sub(v), LC(v), LC());
         return {v, value};
     }
     // a may be true only if must_be_false is false:  (1 - must_be_false - a) * a = 0
     static AllocatedBit alloc_conditionally(CS& cs, bool value, const AllocatedBit& must_be_false) {
-        Var v = cs.alloc(value ? Fr::one() : Fr::zero());
+        Var v = cs.alloc_bit(value);
         MASP_ENFORCE(cs, LC(ONE).sub(must_be_false.var).sub(v), LC(v), LC());
         return {v, value};
     }
     static AllocatedBit xor_(CS& cs, const AllocatedBit& a, const AllocatedBit& b) {
         bool r = a.value ^ b.value;
-        Var v = cs.alloc(r ? Fr::one() : Fr::zero());
+        Var v = cs.alloc_bit(r);
         // (a + a) * b = a + b - c
         MASP_ENFORCE(cs, LC(a.var).add(a.var), LC(b.var), LC(a.var).add(b.var).sub(v));
         return {v, r};
     }
     static AllocatedBit and_(CS& cs, const AllocatedBit& a, const AllocatedBit& b) {
         bool r = a.value && b.value;
-        Var v = cs.alloc(r ? Fr::one() : Fr::zero());
+        Var v = cs.alloc_bit(r);
         MASP_ENFORCE(cs, LC(a.var), LC(b.var), LC(v));
         return {v, r};
     }
     static AllocatedBit and_not(CS& cs, const AllocatedBit& a, const AllocatedBit& b) {
         bool r = a.value && !b.value;
-        Var v = cs.alloc(r ? Fr::one() : Fr::zero());
+        Var v = cs.alloc_bit(r);
         MASP_ENFORCE(cs, LC(a.var), LC(ONE).sub(b.var), LC(v));
         return {v, r};
     }
     static AllocatedBit nor(CS& cs, const AllocatedBit& a, const AllocatedBit& b) {
         bool r = !a.value && !b.value;
-        Var v = cs.alloc(r ? Fr::one() : Fr::zero());
+        Var v = cs.alloc_bit(r);
         MASP_ENFORCE(cs, LC(ONE).sub(a.var), LC(ONE).sub(b.var), LC(v));
         return {v, r};
     }
@@ -344,14 +350,18 @@ struct AllocatedNum {
         uint8_t le[32];
         value.to_bytes(le);
         std::vector<Boolean> bits = bits_into_boolean_vec_le(cs, le, 255);
-        LC lc;
-        Fr coeff = Fr::one();
-        for (auto& b : bits) {
-            lc.add(b.bit.var, coeff);
-            coeff = coeff.dbl();
+        if (cs.recording()) {
+            LC lc;
+            Fr coeff = Fr::one();
+            for (auto& b : bits) {
+                lc.add(b.bit.var, coeff);
+                coeff = coeff.dbl();
+            }
+            lc.sub(var);
+            cs.enforce(LC(), LC(), lc);
+        } else {
+            cs.count_constraint();
         }
-        lc.sub(var);
-        MASP_ENFORCE(cs, LC(), LC(), lc);
         return bits;
     }
     // bits proven to be the canonical representation (<= r - 1): SURVEY.md Appendix B `to_bits_le_strict`
@@ -385,14 +395,18 @@ struct AllocatedNum {
                 result.push_back(AllocatedBit::alloc_conditionally(cs, a_bit, last_run));
             }
         }
-        LC lc;
-        Fr coeff = Fr::one();
-        for (size_t k = result.size(); k-- > 0;) {
-            lc.add(result[k].var, coeff);
-            coeff = coeff.dbl();
+        if (cs.recording()) {
+            LC lc;
+            Fr coeff = Fr::one();
+            for (size_t k = result.size(); k-- > 0;) {
+                lc.add(result[k].var, coeff);
+                coeff = coeff.dbl();
+            }
+            lc.sub(var);
+            cs.enforce(LC(), LC(), lc);
+        } else {
+            cs.count_constraint();
         }
-        lc.sub(var);
-        MASP_ENFORCE(cs, LC(), LC(), lc);
         std::vector<Boolean> out;
         for (size_t k = result.size(); k-- > 0;) out.push_back(Boolean::from(result[k]));
         return out;
@@ -499,6 +513,11 @@ struct MultiEq {
         rhs = LC();
         bits_used = 0;
     }
+    // proving mode: only the packing of the equalities into constraints is replayed (their count), no combination is built
+    void count_equal(int num_bits) {
+        if (254 <= bits_used + num_bits) accumulate();
+        bits_used += num_bits;
+    }
     void enforce_equal(int num_bits, const LC& l, const LC& r) {
         if (254 <= bits_used + num_bits) accumulate();  // Scalar::CAPACITY
         Fr coeff = Fr::one();
@@ -544,16 +563,19 @@ struct UInt32 {
     static UInt32 addmany(MultiEq& me, const std::vector<const UInt32*>& ops) {
         uint64_t max_value = (uint64_t)ops.size() * 0xffffffffull;
         uint64_t result_value = 0;
+        const bool record = me.cs.recording();
         LC lc;
         bool all_constants = true;
         for (const UInt32* op : ops) {
             result_value += op->value;
-            Fr coeff = Fr::one();
-            for (auto& bit : op->bits) {
-                lc.add(bit.lc(coeff));
-                all_constants &= bit.is_constant();
-                coeff = coeff.dbl();
+            if (record) {
+                Fr coeff = Fr::one();
+                for (auto& bit : op->bits) {
+                    lc.add(bit.lc(coeff));
+                    coeff = coeff.dbl();
+                }
             }
+            for (auto& bit : op->bits) all_constants &= bit.is_constant();
         }
         uint32_t modular = (uint32_t)result_value;
         if (all_constants) return constant(modular);
@@ -562,18 +584,22 @@ struct UInt32 {
         LC result_lc;
         Fr coeff = Fr::one();
         int i = 0;
-        std::vector<Boolean> rb;
+        r.bits.reserve(35);
         while (max_value != 0) {
             AllocatedBit b = AllocatedBit::alloc(me.cs, (result_value >> i) & 1);
-            result_lc.add(b.var, coeff);
-            rb.push_back(Boolean::from(b));
+            if (record) {
+                result_lc.add(b.var, coeff);
+                coeff = coeff.dbl();
+            }
+            r.bits.push_back(Boolean::from(b));
             max_value >>= 1;
             ++i;
-            coeff = coeff.dbl();
         }
-        me.enforce_equal(i, lc, result_lc);
-        rb.resize(32);
-        r.bits = rb;
+        if (record)
+            me.enforce_equal(i, lc, result_lc);
+        else
+            me.count_equal(i);
+        r.bits.resize(32);
         return r;
     }
 };

@@ -72,11 +72,10 @@ struct Fr {
     static void mont_mul(uint64_t* out, const uint64_t* a, const uint64_t* b) { mont_mul_n<4>(out, a, b, modulus(), k().inv); }
 
     static Fr zero() { return Fr{{0, 0, 0, 0}}; }
-    static Fr one() {
-        Fr r;
-        memcpy(r.l, k().r1, 32);
-        return r;
-    }
+    // 2^256 mod r (the Montgomery form of 1) as a constant: witness synthesis asks for it ~10^5 times per proof; k().r1 is
+    // the same value computed from the modulus (compared once in the circuit set-up, host_api.cpp)
+    static Fr one() { return Fr{{0x00000001fffffffeull, 0x5884b7fa00034802ull, 0x998c4fefecbc4ff5ull, 0x1824b159acc5056full}}; }
+    static bool one_constant_ok() { return memcmp(one().l, k().r1, 32) == 0; }
     static Fr from_u64(uint64_t x) {
         uint64_t v[4] = {x, 0, 0, 0};
         Fr r;

@@ -66,6 +66,7 @@ enum { MASP_HOST_OK = 0, MASP_HOST_E_INVALID = 1, MASP_HOST_E_DIVERSIFIER = 2, M
 
 // ---- static circuits: kind 0 spend, 1 output, 2 convert --------------------------------------------
 void* masp_host_circuit_setup(int kind) {
+    if (!Fr::one_constant_ok()) return nullptr;
     try {
         std::unique_ptr<CircuitHandle> h(new CircuitHandle);
         h->cs.reset(new CS(true, false));
