@@ -280,32 +280,25 @@ struct MontgomeryPoint {
 
 // The ~5 700 affine Montgomery additions of a Spend (one field inversion each for the slope, which the circuit
 // allocates: circuit/ecc.rs `MontgomeryPoint::add`) dominate witness synthesis.  For one segment of the Pedersen hash the
-// summands are table entries selected by the message bits, so the whole chain can first be run in projective
-// coordinates (no inversion), after which every denominator is known and ONE inversion serves the segment:
-//   acc = (X : Y : Z), next summand (x, y):  1 / (acc.x - x) = Z / (X - x Z).
-// pts[k] = value of the k-th lookup of the segment; hints[k] (k >= 1) = 1 / (sum_{j<k} pts[j]).x - pts[k].x).
+// summands are table entries selected by the message bits, so the whole chain of partial sums is first run natively on the
+// Edwards form of the same points in extended coordinates (7 products per step, no inversion); the Montgomery abscissa of a
+// partial sum (U : V : Z : T) is (Z + V) / (Z - V), so the denominator of the next in-circuit addition is
+//   acc.x - x = ((Z + V) - x (Z - V)) / (Z - V)
+// and ONE inversion serves the segment.  ed[k] / neg[k]: the k-th summand (jubjub.h pedersen_windows) and its sign;
+// x[k]: its Montgomery abscissa as the circuit sees it; hints[k] (k >= 1) = 1 / ((sum_{j<k} summand_j).x - x[k]).
 // On any degenerate input (a zero denominator) no hints are produced and the gadget inverts one by one as before.
-inline void pedersen_segment_hints(const std::vector<Coord>& pts, std::vector<Fr>& hints) {
+inline void pedersen_segment_hints(const std::vector<const JPoint::Niels*>& ed, const std::vector<bool>& neg, const std::vector<Fr>& x,
+                                   std::vector<Fr>& hints) {
     hints.clear();
-    const size_t n = pts.size();
+    const size_t n = ed.size();
     if (n < 2) return;
-    std::vector<Fr> e(n), z(n), pre(n);
-    Fr X = pts[0].first, Y = pts[0].second, Z = Fr::one();
-    const Fr A = montgomery_a();
+    std::vector<Fr> e(n), zmv(n), pre(n);
+    JPoint acc = JPoint::from_affine({neg[0] ? ed[0]->u.neg() : ed[0]->u, ed[0]->v});
     for (size_t k = 1; k < n; ++k) {
-        const Fr &x2 = pts[k].first, &y2 = pts[k].second;
-        const Fr x2z = x2 * Z;
-        e[k] = X - x2z;
-        z[k] = Z;
+        zmv[k] = acc.Z - acc.V;
+        e[k] = acc.Z + acc.V - x[k] * zmv[k];
         if (e[k].is_zero()) return;
-        // acc += (x2, y2): lambda = u / v
-        const Fr u = y2 * Z - Y, v = x2z - X;
-        const Fr v2 = v.square(), v3 = v2 * v;
-        const Fr x3n = u.square() * Z - (A * Z + X + x2z) * v2;  // x3 = x3n / (v^2 Z)
-        const Fr y3n = u * (X * v2 - x3n) - Y * v3;              // y3 = y3n / (v^3 Z)
-        X = x3n * v;
-        Y = y3n;
-        Z = v3 * Z;
+        if (k + 1 < n) acc = acc.add_niels(*ed[k], neg[k]);
     }
     // batch inversion of e[1..n)
     pre[1] = e[1];
@@ -316,7 +309,7 @@ inline void pedersen_segment_hints(const std::vector<Coord>& pts, std::vector<Fr
     for (size_t k = n - 1; k >= 1; --k) {
         const Fr ek_inv = k > 1 ? inv * pre[k - 1] : inv;
         inv = inv * e[k];
-        hints[k] = z[k] * ek_inv;
+        hints[k] = zmv[k] * ek_inv;
     }
 }
 
@@ -334,15 +327,19 @@ inline EdwardsPoint pedersen_hash_gadget(CS& cs, const Personalization& pers, co
         const auto& windows = gens.at(seg);
         std::vector<Fr> hints;
         if (cs.has_witness()) {  // the segment's summands, straight from the tables
-            std::vector<Coord> pts;
+            std::vector<const JPoint::Niels*> ed;
+            std::vector<bool> neg;
+            std::vector<Fr> xs;
+            const PedersenWindows& T = pedersen_windows();
             for (size_t w = 0, q = pos; w < windows.size() && q < bits.size(); ++w) {
                 const bool b0 = bits[q++].value(), b1 = q < bits.size() ? bits[q++].value() : false,
                            b2 = q < bits.size() ? bits[q++].value() : false;
-                Coord c = windows[w][(b0 ? 1 : 0) + (b1 ? 2 : 0)];
-                if (b2) c.second = c.second.neg();
-                pts.push_back(c);
+                const int idx = (b0 ? 1 : 0) + (b1 ? 2 : 0);
+                ed.push_back(&T.e[seg][w][idx]);
+                neg.push_back(b2);
+                xs.push_back(windows[w][idx].first);
             }
-            pedersen_segment_hints(pts, hints);
+            pedersen_segment_hints(ed, neg, xs, hints);
         }
         for (size_t w = 0; w < windows.size() && pos < bits.size(); ++w) {
             Boolean chunk[3];

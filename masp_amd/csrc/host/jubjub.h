@@ -7,6 +7,7 @@
 //   masp_primitives/src/convert.rs:39-64          (all paths under /root/reference).
 #pragma once
 #include <array>
+#include <stdexcept>
 #include <vector>
 
 #include "fr.h"
@@ -127,14 +128,39 @@ struct JPoint {
         Fr E = B - A, F = D - C, G = D + C, H = B + A;
         return {E * F, G * H, F * G, E * H};
     }
-    JPoint dbl() const { return add(*this); }
+    // dedicated doubling for a = -1 (4 squarings + 4 products; equals add(*this))
+    JPoint dbl() const {
+        const Fr A = U.square(), B = V.square(), C = Z.square().dbl();
+        const Fr E = (U + V).square() - A - B, G = B - A, F = G - C, H = (A + B).neg();
+        return {E * F, G * H, F * G, E * H};
+    }
     JPoint neg() const { return {U.neg(), V, Z, T.neg()}; }
-    // scalar: 32 bytes little-endian (any 256-bit integer)
+    // this + (u, v) given as (v - u, v + u, 2 d u v): 7 products
+    struct Niels {
+        Fr u, v, vmu, vpu, t2d;
+        static Niels from(const JAffine& a) { return {a.u, a.v, a.v - a.u, a.v + a.u, (a.u * a.v * edwards_d()).dbl()}; }
+    };
+    JPoint add_niels(const Niels& n, bool negate = false) const {
+        const Fr A = (V - U) * (negate ? n.vpu : n.vmu), B = (V + U) * (negate ? n.vmu : n.vpu);
+        Fr C = T * n.t2d;
+        if (negate) C = C.neg();
+        const Fr D = Z.dbl();
+        const Fr E = B - A, F = D - C, G = D + C, H = B + A;
+        return {E * F, G * H, F * G, E * H};
+    }
+    // scalar: 32 bytes little-endian (any 256-bit integer); 4-bit windows from the top non-zero nibble down
     JPoint mul(const uint8_t* scalar_le) const {
-        JPoint r = identity();
-        for (int i = 255; i >= 0; --i) {
-            r = r.dbl();
-            if ((scalar_le[i / 8] >> (i % 8)) & 1) r = r.add(*this);
+        int top = 63;
+        while (top >= 0 && ((scalar_le[top / 2] >> (4 * (top & 1))) & 15) == 0) --top;
+        if (top < 0) return identity();
+        JPoint tab[16];
+        tab[1] = *this;
+        for (int k = 2; k < 16; ++k) tab[k] = (k & 1) ? tab[k - 1].add(*this) : tab[k / 2].dbl();
+        JPoint r = tab[(scalar_le[top / 2] >> (4 * (top & 1))) & 15];
+        for (int i = top - 1; i >= 0; --i) {
+            r = r.dbl().dbl().dbl().dbl();
+            const unsigned nib = (scalar_le[i / 2] >> (4 * (i & 1))) & 15;
+            if (nib) r = r.add(tab[nib]);
         }
         return r;
     }
@@ -234,37 +260,47 @@ struct Personalization {
         return b;
     }
 };
+// (k + 1) * 16^w * G_s for k < 4, w < 63, s < 6 in affine form: the summands of the Pedersen hash.  Shared by the native hash
+// below and by the witness generator's projective pre-pass of the in-circuit hash (circuits.h).
+struct PedersenWindows {
+    JPoint::Niels e[6][63][4];
+};
+inline const PedersenWindows& pedersen_windows() {
+    static const PedersenWindows* t = [] {
+        PedersenWindows* x = new PedersenWindows;
+        for (int s = 0; s < 6; ++s) {
+            JPoint gen = generators().pedersen[s];
+            for (int w = 0; w < 63; ++w) {
+                JPoint p = gen;
+                for (int k = 0; k < 4; ++k) {
+                    x->e[s][w][k] = JPoint::Niels::from(p.to_affine());
+                    p = p.add(gen);
+                }
+                gen = gen.dbl().dbl().dbl().dbl();
+            }
+        }
+        return x;
+    }();
+    return *t;
+}
 // chunk (a,b,c) of window j contributes (1 + a + 2b) * (-1)^c * 2^(4j); 63 chunks per generator
 inline JPoint pedersen_hash(const Personalization& pers, const std::vector<bool>& msg) {
     std::vector<bool> bits;
     for (bool b : pers.bits()) bits.push_back(b);
     bits.insert(bits.end(), msg.begin(), msg.end());
+    const PedersenWindows& T = pedersen_windows();
     JPoint result = JPoint::identity();
     size_t pos = 0;
     int seg = 0;
     while (pos < bits.size()) {
-        // segment scalar as a signed 256-bit integer: positive and negative parts kept apart
-        uint8_t plus[33] = {0}, minus[33] = {0};
-        auto add_at = [](uint8_t* acc, unsigned value, unsigned shift) {  // acc += value << shift
-            unsigned byte = shift / 8, off = shift % 8;
-            uint32_t carry = value << off;
-            while (carry && byte < 33) {
-                uint32_t s = acc[byte] + (carry & 0xff);
-                acc[byte] = (uint8_t)s;
-                carry = (carry >> 8) + (s >> 8);
-                ++byte;
-            }
-        };
+        if (seg >= 6) throw std::runtime_error("pedersen_hash: message too long");
         for (int j = 0; j < 63 && pos < bits.size(); ++j) {
             bool a = bits[pos++];
             bool b = pos < bits.size() ? bits[pos++] : false;
             bool c = pos < bits.size() ? bits[pos++] : false;
-            unsigned mag = 1 + (a ? 1 : 0) + (b ? 2 : 0);
-            add_at(c ? minus : plus, mag, 4 * j);
+            result = result.add_niels(T.e[seg][j][(a ? 1 : 0) + (b ? 2 : 0)], c);
         }
-        const JPoint& g = generators().pedersen[seg++];
-        JPoint p = g.mul(plus).add(g.mul(minus).neg());
-        result = result.add(p);
+        ++seg;
     }
     return result;
 }
