@@ -1,5 +1,10 @@
 // Radix-2 NTT over the BLS12-381 scalar field and the Groth16 quotient  h = (A*B - C)/Z  for gfx950.
 //
+// Six transforms, not bellperson's seven: with Z = x^m - 1 and C = A B mod Z (c = a o b on the domain), the product reduced
+// on the coset g H is  A B mod (x^m - g^m) = (g^m - 1) h + C,  so  h = (icoset_fft(A B on the coset) - C) / (g^m - 1)  and C
+// never has to be carried onto the coset and back (its coefficients come out of the first inverse transform anyway).
+// Same field elements as the reference sequence: h is unique.
+//
 // Replaces bellperson's `EvaluationDomain::{ifft, coset_fft, mul_assign, sub_assign,
 // divide_by_z_on_coset, icoset_fft}` sequence (nam-bellperson 0.26.6-nam.1, un-vendored; SURVEY.md A.3
 // step 3, reached from /root/reference/masp_proofs/src/sapling/prover.rs:117,202,252) and the
@@ -64,17 +69,24 @@ __global__ void k_ntt_scale_bitrev(const Fr* __restrict__ x, const Fr* __restric
     y += (size_t)NTT_P << logm;
     fr_store(y + bitrev(k, logm), fe_mul(fr_load(x + k), fr_load(scale + k)));
 }
-// y[rev(k)] = (a[k] * b[k] - c[k]) * zinv
-__global__ void k_ntt_abc_bitrev(const Fr* __restrict__ a, const Fr* __restrict__ b, const Fr* __restrict__ c, Fr zinv,
-                                 Fr* __restrict__ y, uint32_t logm) {
+// y[rev(k)] = a[k] * b[k]
+__global__ void k_ntt_ab_bitrev(const Fr* __restrict__ a, const Fr* __restrict__ b, Fr* __restrict__ y, uint32_t logm) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= (1u << logm)) return;
     a += (size_t)NTT_P << logm;
     b += (size_t)NTT_P << logm;
-    c += (size_t)NTT_P << logm;
     y += (size_t)NTT_P << logm;
-    Fr v = fe_mul(fe_sub(fe_mul(fr_load(a + k), fr_load(b + k)), fr_load(c + k)), zinv);
-    fr_store(y + bitrev(k, logm), v);
+    fr_store(y + bitrev(k, logm), fe_mul(fr_load(a + k), fr_load(b + k)));
+}
+// y[k] = x[k] * scale[k] - c[k] * cscale   (plain-form scale factors: the result leaves Montgomery form)
+__global__ void k_fr_scale_sub(const Fr* __restrict__ x, const Fr* __restrict__ scale, const Fr* __restrict__ c, Fr cscale, Fr* __restrict__ y,
+                               uint32_t n, size_t y_stride) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    x += (size_t)NTT_P * n;
+    c += (size_t)NTT_P * n;
+    y += (size_t)NTT_P * y_stride;
+    fr_store(y + k, fe_sub(fe_mul(fr_load(x + k), fr_load(scale + k)), fe_mul(fr_load(c + k), cscale)));
 }
 // y[k] = x[k] * scale[k]  (no permutation; with a plain-form scale table this also leaves Montgomery form)
 __global__ void k_fr_scale(const Fr* __restrict__ x, const Fr* __restrict__ scale, Fr* __restrict__ y, uint32_t n, size_t y_stride) {

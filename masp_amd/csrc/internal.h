@@ -65,7 +65,7 @@ struct NttDomain {
     uint32_t logm = 0;
     size_t m = 0;
     DevBuf<Fr> tw_fwd, tw_inv, coset_scale, h_scale;
-    Fr zinv;
+    Fr c_scale;  // 1 / (m (g^m - 1)), plain form
     int init(uint32_t logm_, hipStream_t s) {
         logm = logm_;
         m = (size_t)1 << logm;
@@ -75,7 +75,9 @@ struct NttDomain {
         Fr minv = fe_inv(fr_from_u64_mont(m));
         Fr g = fr_const(FrCfg::GEN), ginv = fr_const(FrCfg::GEN_INV);
         uint32_t e[2] = {(uint32_t)m, (uint32_t)((uint64_t)m >> 32)};
-        zinv = fe_inv(fe_sub(fe_pow(g, e, 2), fe_one<FrCfg>()));
+        const Fr zinv = fe_inv(fe_sub(fe_pow(g, e, 2), fe_one<FrCfg>()));  // 1 / Z on the coset g H
+        const Fr mzinv = fe_mul(minv, zinv);
+        c_scale = fe_from_mont(mzinv);
         Fr one = fe_one<FrCfg>();
         size_t half = std::max<size_t>(m / 2, 1);
         int rc;
@@ -83,7 +85,7 @@ struct NttDomain {
         launch_fr_powers(s, tw_fwd.p, (uint32_t)half, omega, one, 0);
         launch_fr_powers(s, tw_inv.p, (uint32_t)half, omega_inv, one, 0);
         launch_fr_powers(s, coset_scale.p, (uint32_t)m, g, minv, 0);
-        launch_fr_powers(s, h_scale.p, (uint32_t)m, ginv, minv, 1);
+        launch_fr_powers(s, h_scale.p, (uint32_t)m, ginv, mzinv, 1);  // g^-k / (m (g^m - 1)), plain form
         HIP_TRY(hipStreamSynchronize(s));
         return MASP_HIP_OK;
     }

@@ -21,8 +21,11 @@ void launch_ntt_copy_bitrev(hipStream_t s, const Fr* x, size_t x_stride, uint32_
 void launch_ntt_scale_bitrev(hipStream_t s, const Fr* x, const Fr* scale, Fr* y, uint32_t logm, uint32_t np) {
     hipLaunchKernelGGL(k_ntt_scale_bitrev, dim3(((1u << logm) + 255) / 256, np), dim3(256), 0, s, x, scale, y, logm);
 }
-void launch_ntt_abc_bitrev(hipStream_t s, const Fr* a, const Fr* b, const Fr* c, const Fr& zinv, Fr* y, uint32_t logm, uint32_t np) {
-    hipLaunchKernelGGL(k_ntt_abc_bitrev, dim3(((1u << logm) + 255) / 256, np), dim3(256), 0, s, a, b, c, zinv, y, logm);
+void launch_ntt_ab_bitrev(hipStream_t s, const Fr* a, const Fr* b, Fr* y, uint32_t logm, uint32_t np) {
+    hipLaunchKernelGGL(k_ntt_ab_bitrev, dim3(((1u << logm) + 255) / 256, np), dim3(256), 0, s, a, b, y, logm);
+}
+void launch_fr_scale_sub(hipStream_t s, const Fr* x, const Fr* scale, const Fr* c, const Fr& cscale, Fr* y, uint32_t n, uint32_t np, size_t y_stride) {
+    hipLaunchKernelGGL(k_fr_scale_sub, dim3((n + 255) / 256, np), dim3(256), 0, s, x, scale, c, cscale, y, n, y_stride ? y_stride : (size_t)n);
 }
 void launch_fr_scale(hipStream_t s, const Fr* x, const Fr* scale, Fr* y, uint32_t n, uint32_t np, size_t y_stride) {
     hipLaunchKernelGGL(k_fr_scale, dim3((n + 255) / 256, np), dim3(256), 0, s, x, scale, y, n, y_stride ? y_stride : (size_t)n);

@@ -15,7 +15,8 @@ void launch_ntt_pass(hipStream_t s, Fr* data, const Fr* tw, uint32_t logm, uint3
 void launch_ntt_load_bitrev(hipStream_t s, const Fr* x, size_t x_stride, uint32_t nrows, Fr* y, uint32_t logm, uint32_t np);
 void launch_ntt_copy_bitrev(hipStream_t s, const Fr* x, size_t x_stride, uint32_t nrows, Fr* y, uint32_t logm, uint32_t np);
 void launch_ntt_scale_bitrev(hipStream_t s, const Fr* x, const Fr* scale, Fr* y, uint32_t logm, uint32_t np);
-void launch_ntt_abc_bitrev(hipStream_t s, const Fr* a, const Fr* b, const Fr* c, const Fr& zinv, Fr* y, uint32_t logm, uint32_t np);
+void launch_ntt_ab_bitrev(hipStream_t s, const Fr* a, const Fr* b, Fr* y, uint32_t logm, uint32_t np);
+void launch_fr_scale_sub(hipStream_t s, const Fr* x, const Fr* scale, const Fr* c, const Fr& cscale, Fr* y, uint32_t n, uint32_t np, size_t y_stride = 0);
 // y_p = y + p * y_stride (0: n)
 void launch_fr_scale(hipStream_t s, const Fr* x, const Fr* scale, Fr* y, uint32_t n, uint32_t np, size_t y_stride = 0);
 void launch_fr_from_mont(hipStream_t s, const Fr* x, Fr* y, uint32_t n);

@@ -121,7 +121,7 @@ static int enqueue_quotient(Slot& sl, const NttDomain& D, const Fr* const in[3],
                             Fr* h_out = nullptr, size_t h_stride = 0) {
     hipStream_t s = sl.stream;
     const uint32_t m = (uint32_t)D.m, logm = D.logm;
-    // A batch goes through the seven transforms in sub-batches whose six work buffers (sub x 6 x 32 m bytes: 192 MiB for
+    // A batch goes through the six transforms in sub-batches whose six work buffers (sub x 6 x 32 m bytes: 192 MiB for
     // eight Spend proofs) stay in the 256 MiB Infinity Cache from pass to pass, instead of every pass streaming the whole
     // batch (np x 4 MiB per buffer) through HBM.  The work buffers are only sub proofs long; h is the per-batch result.
     static const uint32_t sub_max = [] {
@@ -133,7 +133,7 @@ static int enqueue_quotient(Slot& sl, const NttDomain& D, const Fr* const in[3],
     // a, b and c go through every pass TOGETHER: the three transforms of a sub-batch lie back to back in one buffer
     // ([a | b | c] x q proofs) and a pass is one launch over 3 q transforms — three times the workgroups per launch
     // (a lone proof: 384 instead of 128 on 256 CUs) and 12 instead of 22 launches per sub-batch
-    if ((rc = sl.x0.reserve((size_t)3 * m * sub)) || (rc = sl.x1.reserve((size_t)3 * m * sub))) return rc;
+    if ((rc = sl.x0.reserve((size_t)3 * m * sub)) || (rc = sl.x1.reserve((size_t)2 * m * sub))) return rc;
     if (!h_out) {
         if ((rc = sl.h.reserve((size_t)m * np))) return rc;
         h_out = sl.h.p;
@@ -150,12 +150,13 @@ static int enqueue_quotient(Slot& sl, const NttDomain& D, const Fr* const in[3],
             else
                 launch_ntt_load_bitrev(s, src, in_stride, nrows, x0 + i * part, logm, q);
         }
-        D.passes(s, x0, D.tw_inv.p, 3 * q);                                     // iNTT (unscaled)
-        launch_ntt_scale_bitrev(s, x0, D.coset_scale.p, x1, logm, 3 * q);       // * g^k / m
-        D.passes(s, x1, D.tw_fwd.p, 3 * q);                                     // coset NTT
-        launch_ntt_abc_bitrev(s, x1, x1 + part, x1 + 2 * part, D.zinv, x0, logm, q);
-        D.passes(s, x0, D.tw_inv.p, q);
-        launch_fr_scale(s, x0, D.h_scale.p, h_out + (size_t)p0 * h_stride, m, q, h_stride);  // * g^-k / m, leaves Montgomery form
+        D.passes(s, x0, D.tw_inv.p, 3 * q);                                     // m A, m B, m C (coefficients)
+        launch_ntt_scale_bitrev(s, x0, D.coset_scale.p, x1, logm, 2 * q);       // A, B: * g^k / m
+        D.passes(s, x1, D.tw_fwd.p, 2 * q);                                     // A, B on the coset g H
+        launch_ntt_ab_bitrev(s, x1, x1 + part, x0, logm, q);
+        D.passes(s, x0, D.tw_inv.p, q);                                         // m g^k ((g^m - 1) h + C)_k
+        // h = (that * g^-k / m - C) / (g^m - 1); leaves Montgomery form
+        launch_fr_scale_sub(s, x0, D.h_scale.p, x0 + 2 * part, D.c_scale, h_out + (size_t)p0 * h_stride, m, q, h_stride);
     }
     return MASP_HIP_OK;
 }

@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 os.environ.setdefault("MASP_HIP_SLOTS", "4")
-os.environ.setdefault("MASP_HIP_BATCH", "128")
+os.environ.setdefault("MASP_HIP_BATCH", "256")
 
 from masp_amd import host as H                     # noqa: E402
 from masp_amd import workload as W                 # noqa: E402

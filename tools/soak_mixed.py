@@ -11,7 +11,7 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-os.environ.setdefault("MASP_HIP_BATCH", "128")
+os.environ.setdefault("MASP_HIP_BATCH", "256")
 
 from masp_amd import workload as W                     # noqa: E402
 from masp_amd import host as H                         # noqa: E402
