@@ -148,10 +148,19 @@ __global__ void __launch_bounds__(256) k_ntt_pass(Fr* __restrict__ data, const F
             const uint32_t lo = (col0 + cl) & lomask;
             const uint32_t j1 = (hj << s0) | lo;                          // stage s: both pairs
             const uint32_t j2a = j1, j2b = ((hj | (1u << q)) << s0) | lo;  // stage s + 1: pairs with bit q clear / set
+            Fr x0 = ld(L0), x1 = ld(L0 + d), x2 = ld(L0 + 2 * d), x3 = ld(L0 + 3 * d);
+            if (s == 0) {  // the first two stages of a transform: twiddles 1, 1 and (1, w^(m/4)) — one product instead of four
+                const Fr y0 = fe_add(x0, x1), y1 = fe_sub(x0, x1), y2 = fe_add(x2, x3), y3 = fe_sub(x2, x3);
+                st(L0, fe_add(y0, y2));
+                st(L0 + 2 * d, fe_sub(y0, y2));
+                const Fr t = fe_mul(y3, fr_load(tw + ((size_t)1 << (logm - 2))));
+                st(L0 + d, fe_add(y1, t));
+                st(L0 + 3 * d, fe_sub(y1, t));
+                continue;
+            }
             const Fr w1 = fr_load(tw + ((size_t)j1 << (logm - s - 1)));
             const Fr w2a = fr_load(tw + ((size_t)j2a << (logm - s - 2)));
             const Fr w2b = fr_load(tw + ((size_t)j2b << (logm - s - 2)));
-            Fr x0 = ld(L0), x1 = ld(L0 + d), x2 = ld(L0 + 2 * d), x3 = ld(L0 + 3 * d);
             Fr t = fe_mul(x1, w1);
             Fr y0 = fe_add(x0, t), y1 = fe_sub(x0, t);
             t = fe_mul(x3, w1);
