@@ -122,7 +122,10 @@ struct MsmWorkspace {
     // partial sums to write and to gather (each extra partial costs a full XYZZ addition later).
     static uint32_t nchunks_for(uint32_t n, const MsmGeom& g, uint32_t np) {
         uint64_t ent = (uint64_t)n * g.W;
-        uint64_t lanes = std::max<uint64_t>(NCHUNKS / std::max<uint32_t>(np, 1), 1u << 13);
+        // a batch: ~3 * 2^18 lanes across its proofs (six full rounds of the G1 kernel's 2 048 resident waves), between 3 072 and
+        // 8 192 per proof (256 proofs per launch sequence: 3 072 measured +1.5 % over 8 192, 2 048 and 5 120 worse again)
+        uint64_t lanes = np >= 8 ? std::min<uint64_t>(std::max<uint64_t>((3u << 18) / np, 3072), 1u << 13)
+                                 : std::max<uint64_t>(NCHUNKS / std::max<uint32_t>(np, 1), 1u << 13);
         // lone proof: about eight chunks per bucket, so that a bucket's partials are few enough for one gather lane
         // (otherwise every bucket of a 12-bit-window MSM becomes a "heavy" bucket with a workgroup of its own)
         if (np < 8) lanes = std::min<uint64_t>(lanes, std::max<uint64_t>(8ull * g.nb, 1u << 13));

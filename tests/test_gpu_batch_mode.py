@@ -1,5 +1,6 @@
 """Parity of the code path `bench.py` times: batch mode (np >= 8 proofs per launch sequence: 16-/12-bit windows, 2^18/np
-chunks, the 33 000-entry bucket-0 heavy path, G = 16 weighted sums) on the REAL circuits at real size, through the C ABI.
+chunks, the 33 000-entry bucket-0 heavy path, G = 16 .. 64 weighted sums, h + l as one MSM, six-transform quotient) on the REAL
+circuits at real size, through the C ABI, at 85 / 86 and at 256 proofs per launch sequence.
 
 Oracles: the toxic-waste closed form for every proof (no NTT / MSM involved: one QAP evaluation + fixed-base
 multiplications), the CPU restatement `create_proof` for a sample, and the pairing equation (host batch verifier,
@@ -22,21 +23,25 @@ KINDS = ("spend", "output", "convert")
 
 
 class Rig:
-    """One context with the three real circuits on a synthetic CRS of known toxic waste (MASP_HIP_BATCH = 96 like bench.py)."""
+    """One context with real circuits on a synthetic CRS of known toxic waste.  `cap` = MASP_HIP_BATCH, the proofs per launch
+    sequence: 96 cuts 256 Spends into 86 + 85 + 85, 256 (what bench.py sets) runs them as one."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, kinds=KINDS, cap="96"):
         import masp_amd
         from masp_amd import host as H
         from masp_amd.synthetic import toxic_waste
-        os.environ["MASP_HIP_BATCH"] = "96"
+        before = os.environ.get("MASP_HIP_BATCH")
+        os.environ["MASP_HIP_BATCH"] = cap             # read once, when the context is created
         self.ctx = masp_amd.Context(device)
-        self.cs = {k: H.circuit(k)[0] for k in KINDS}
-        self.toxic = {k: toxic_waste(40 + i) for i, k in enumerate(KINDS)}
+        if cap != "96":
+            os.environ["MASP_HIP_BATCH"] = before if before is not None else "96"
+        self.cs = {k: H.circuit(k)[0] for k in kinds}
+        self.toxic = {k: toxic_waste(40 + KINDS.index(k)) for k in kinds}
         self.params = {}
         self.vk = {}
-        for slot, k in enumerate(KINDS):
+        for k in kinds:
             self.params[k] = self.ctx.generate_parameters(self.cs[k], self.toxic[k])
-            self.ctx.load_circuit(slot, self.params[k], self.cs[k])
+            self.ctx.load_circuit(KINDS.index(k), self.params[k], self.cs[k])
             self.vk[k] = H.PreparedVerifyingKey(self.params[k])
         self.threads = H.effective_cpus()
 
@@ -97,6 +102,27 @@ def test_256_distinct_spends_through_one_call(rig):
     again, ms = rig.ctx.batch_prove_resident(h, n)
     rig.ctx.batch_free(h)
     assert again == proofs and ms > 0
+
+
+def test_256_distinct_spends_as_one_launch_sequence(rig):
+    """The configuration bench.py times since round 2: MASP_HIP_BATCH = 256, all 256 Spends in ONE launch sequence
+    (gridDim.y = 256: its own chunk geometry, 64 buckets per lane in the weighted sum of h + l).  Same toxic waste as the
+    96-proof rig, so besides the closed form the bytes must equal what the 86 / 85 / 85 split produces."""
+    from masp_amd import workload as W
+    insts = W.instances("spend", 256, first_seed=1000)
+    rs = _rs(random.Random(1), 256)
+    jobs = [(0, i, a, r, s) for (i, a), (r, s) in zip(insts, rs)]
+    big = Rig(kinds=("spend",), cap="256")
+    try:
+        proofs = big.ctx.prove_batch(jobs)
+        _check(big, ["spend"] * 256, insts, rs, proofs, n_cpu=2)
+        h, n = big.ctx.batch_upload(jobs)
+        again, ms = big.ctx.batch_prove_resident(h, n)
+        big.ctx.batch_free(h)
+        assert again == proofs and ms > 0
+    finally:
+        big.close()
+    assert proofs == rig.ctx.prove_batch(jobs)
 
 
 @pytest.mark.parametrize("kind", ["output", "convert"])
