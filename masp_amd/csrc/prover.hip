@@ -35,7 +35,7 @@ static int env_slots() {
 // proofs per batched launch sequence (upper bound: a list of n same-circuit jobs is cut into ceil(n / cap) equal groups)
 static size_t env_batch_cap() {
     const char* e = getenv("MASP_HIP_BATCH");
-    int n = e ? atoi(e) : 64;
+    int n = e ? atoi(e) : 256;  // the bench's configuration; scratch memory follows the batches actually formed
     return (size_t)std::max(1, std::min(n, 256));
 }
 // [0, n) cut into ceil(n / cap) groups whose sizes differ by at most one: (first, count) pairs

@@ -438,5 +438,12 @@ def test_local_tx_prover_batch_equals_serial(ctx):
     bad = ("spend", dict(descs[0][1], diversifier=bad_d))
     with pytest.raises(P.ProvingError):
         lp.prove_batch(lp.new_sapling_proving_context(), descs * 8 + [bad] + descs * 8, chunk=4, threads=4)
+    # every page-locked aux buffer is back in the pool (reserved in slabs before the GPU got busy, handed out, returned):
+    # a second failing call neither allocates more nor loses any
+    pooled = {k: len(v) for k, v in lp._pool.items()}
+    slabs = len(lp._ctx._pinned)
+    with pytest.raises(P.ProvingError):
+        lp.prove_batch(lp.new_sapling_proving_context(), descs * 8 + [bad] + descs * 8, chunk=4, threads=4)
+    assert {k: len(v) for k, v in lp._pool.items()} == pooled and len(lp._ctx._pinned) == slabs
     assert lp.prove_batch(lp.new_sapling_proving_context(), descs, rs=rs) == serial        # and the prover is still usable
     lp.close()

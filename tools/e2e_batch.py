@@ -2,7 +2,7 @@
 one GPU): host synthesis (C++ threads) -> GPU batch -> host self-verification, each stage timed.  Unlike bench.py (inputs
 resident in HBM), this includes witness generation, the H2D copies and the pairing checks.
 
-    python tools/e2e_batch.py [N=256] [threads=os.cpu_count()]
+    python tools/e2e_batch.py [N=256] [threads=os.cpu_count()] [chunk=MASP_HIP_BATCH]
 """
 import os
 import sys
@@ -25,7 +25,8 @@ def spend_description(seed):
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    threads = int(sys.argv[2]) if len(sys.argv) > 2 else H.effective_cpus()
+    threads = int(sys.argv[2]) if len(sys.argv) > 2 and int(sys.argv[2]) > 0 else H.effective_cpus()
+    chunk = int(sys.argv[3]) if len(sys.argv) > 3 else None
     t = time.time()
     prover = LocalTxProver.with_synthetic_parameters(seed=7)
     print("parameters generated + loaded: %.1f s" % (time.time() - t))
@@ -51,14 +52,14 @@ def main():
     assert ok
     ctx = prover.new_sapling_proving_context()
     t4 = time.time()
-    out = prover.prove_batch(ctx, descs, threads=threads)
+    out = prover.prove_batch(ctx, descs, threads=threads, chunk=chunk)
     t5 = time.time()
     assert len(out) == n
     print("N = %d Spend descriptions, %d host threads; stage by stage on the first %d:" % (n, threads, stage_n))
     print("  synthesis  %8.1f ms  (%.2f ms/proof wall, %.1f proofs/s)" % ((t1 - t0) * 1e3, (t1 - t0) * 1e3 / stage_n, stage_n / (t1 - t0)))
     print("  GPU batch  %8.1f ms  (%.2f ms/proof, %.1f proofs/s; includes H2D of witnesses, D2H of proofs)" % ((t2 - t1) * 1e3, (t2 - t1) * 1e3 / stage_n, stage_n / (t2 - t1)))
     print("  verify     %8.1f ms  (%.2f ms/proof wall)" % ((t3 - t2) * 1e3, (t3 - t2) * 1e3 / stage_n))
-    print("  prove_batch end to end %8.1f ms = %.1f proofs/s" % ((t5 - t4) * 1e3, n / (t5 - t4)))
+    print("  prove_batch end to end (chunks of %s descriptions) %8.1f ms = %.1f proofs/s" % (chunk or os.environ["MASP_HIP_BATCH"], (t5 - t4) * 1e3, n / (t5 - t4)))
 
 
 if __name__ == "__main__":
