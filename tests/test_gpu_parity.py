@@ -129,6 +129,29 @@ def test_msm_full_size_by_discrete_log_checksum(ctx, group, n, bool_share):
         assert ctx.msm_g2(O.g2_mul_gen_many(ks), sc) == O.g2_mul_gen_many(expect_scalar)[0].tobytes()
 
 
+def test_msm_g1_beyond_the_two_pass_sort_range(ctx):
+    """1 126 400 points on 16-bit windows: n x W = 18 M digit entries do not fit the 24-bit row index of the two-pass
+    placement, so the counting sort takes its single-pass scatter (the MASP circuits never get there: at most 3.7 M entries;
+    the toy circuits reach the same kernel through their narrow windows).  4 096 distinct bases repeated 275 times, checked
+    by the discrete-log identity."""
+    rng = random.Random(77)
+    distinct, reps = 4096, 275
+    ks = _rand_scalars(rng, distinct)
+    base = O.g1_mul_gen_many(ks)
+    n = distinct * reps
+    bases = np.tile(base, (reps, 1))
+    raw = np.random.default_rng(77).integers(0, 256, size=(n, 32), dtype=np.uint8)
+    raw[:, 31] &= 0x3f                                     # < 2^254 < r
+    raw[::1000] = 0                                        # some zeros and ones among them
+    raw[1::1000] = 0
+    raw[1::1000, 0] = 1
+    k_int = [int.from_bytes(k.tobytes(), "little") for k in ks]
+    s_int = [int.from_bytes(raw[i].tobytes(), "little") for i in range(n)]
+    total = sum(k_int[i % distinct] * s for i, s in enumerate(s_int)) % R
+    expect_scalar = np.frombuffer(_le(total), np.uint8).reshape(1, 32)
+    assert ctx.msm_g1(bases, raw) == O.g1_mul_gen_many(expect_scalar)[0].tobytes()
+
+
 @pytest.mark.parametrize("pattern", ["one_value", "all_ones", "all_r_minus_1", "two_values_and_zeros"])
 def test_msm_skewed_digit_distributions(ctx, pattern):
     """Digit distributions that put everything into a handful of buckets (the balanced chunking, the heavy-bucket path

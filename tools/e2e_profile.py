@@ -1,3 +1,5 @@
+"""Where the time of `LocalTxProver.prove_batch` goes: N Spend descriptions in chunks of `chunk`, four runs (the first pays the
+page-locked buffers), per-stage totals summed over threads.  usage: python tools/e2e_profile.py N chunk"""
 import os, sys, time, threading, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
