@@ -56,7 +56,7 @@ struct MsmBases {
 
 // ---- sort buffers (curve-independent): one counting sort can feed several MSMs over the same scalars ---------
 struct MsmSortBuf {
-    size_t cap_ent = 0, cap_nb = 0, cap_np = 0, cap_ng = 0;
+    size_t cap_ent = 0, cap_nb = 0, cap_np = 0, cap_hist = 0, cap_crel = 0;  // cap_hist, cap_crel: words
     uint32_t *sorted = nullptr, *hist_wg = nullptr, *start = nullptr;
     uint32_t *tmp = nullptr, *crel = nullptr;  // two-pass placement: entries grouped by coarse bin; per-range offsets of the bins
     // what the last msm_sort_enqueue produced (consumed by msm_reduce_enqueue)
@@ -69,7 +69,7 @@ struct MsmSortBuf {
         for (void* p : ptrs)
             if (p) hipFree(p);
         sorted = hist_wg = start = tmp = crel = nullptr;
-        cap_ent = cap_nb = cap_np = cap_ng = 0;
+        cap_ent = cap_nb = cap_np = cap_hist = cap_crel = 0;
     }
     // scalar ranges (= sorting workgroups) per proof: enough to occupy the chip across the batch, not more
     static uint32_t ranges_for(uint32_t n, uint32_t np) {
@@ -78,21 +78,27 @@ struct MsmSortBuf {
         return std::max(1u, std::min(ng, (n + 1023) / 1024));
     }
     int reserve(uint32_t n_, const MsmGeom& g_, uint32_t np_) {
-        size_t need_ent = (size_t)n_ * g_.W, need_ng = ranges_for(n_, np_);
-        if (need_ent <= cap_ent && (size_t)g_.nb <= cap_nb && np_ <= cap_np && need_ng <= cap_ng) return MASP_HIP_OK;
-        need_ent = std::max(need_ent, cap_ent);
-        size_t need_nb = std::max<size_t>(g_.nb, cap_nb), need_np = std::max<size_t>(np_, cap_np);
-        need_ng = std::max(need_ng, cap_ng);
+        // the per-workgroup histograms are addressed with the launch's own strides: np x ng x nb words, and np x ng <= 512
+        // for every batch size (ranges_for) — a batch of 64 proofs (8 ranges each) fits what a batch of 256 (2 each) allocated
+        const size_t need_ent = std::max((size_t)n_ * g_.W, cap_ent), ng = ranges_for(n_, np_);
+        const size_t bins = std::max<size_t>(g_.nb >> 7, 1);
+        const size_t hist_need = (size_t)np_ * ng * g_.nb, crel_need = (size_t)np_ * ng * bins;
+        if (need_ent <= cap_ent && (size_t)g_.nb <= cap_nb && np_ <= cap_np && hist_need <= cap_hist && crel_need <= cap_crel) return MASP_HIP_OK;
+        const size_t need_nb = std::max<size_t>(g_.nb, cap_nb), need_np = std::max<size_t>(np_, cap_np);
+        const size_t rows = std::max<size_t>(need_np, 512);
+        const size_t need_hist = std::max(std::max(hist_need, cap_hist), rows * need_nb);
+        const size_t need_crel = std::max(std::max(crel_need, cap_crel), rows * std::max<size_t>(need_nb >> 7, 1));
         release();
         cap_ent = need_ent;
         cap_nb = need_nb;
         cap_np = need_np;
-        cap_ng = need_ng;
+        cap_hist = need_hist;
+        cap_crel = need_crel;
         HIP_TRY(hipMalloc(&sorted, cap_np * 4 * std::max<size_t>(cap_ent, 1)));
-        HIP_TRY(hipMalloc(&hist_wg, cap_np * 4 * cap_ng * cap_nb));
+        HIP_TRY(hipMalloc(&hist_wg, 4 * cap_hist));
         HIP_TRY(hipMalloc(&start, cap_np * 4 * (cap_nb + 1)));
         HIP_TRY(hipMalloc(&tmp, cap_np * 4 * std::max<size_t>(cap_ent, 1)));
-        HIP_TRY(hipMalloc(&crel, cap_np * 4 * cap_ng * std::max<size_t>(cap_nb >> 7, 1)));
+        HIP_TRY(hipMalloc(&crel, 4 * cap_crel));
         return MASP_HIP_OK;
     }
 };
@@ -104,7 +110,7 @@ struct MsmWorkspace {
     static constexpr uint32_t NCHUNKS = 1u << 18;     // lanes of the accumulation kernel (1024 waves x 4 per SIMD)
 
     MsmSortBuf sort;  // used unless the caller shares another workspace's sort
-    size_t cap_nb = 0, cap_np = 0, cap_chunks = 0;
+    size_t cap_nb = 0, cap_np = 0, cap_part = 0;  // cap_part: elements of `part` (np x (chunks + nb) of the largest launch)
     uint32_t *heavy = nullptr, *n_heavy = nullptr;
     Xyzz<O>*part = nullptr, *bkt = nullptr, *S[2] = {nullptr, nullptr}, *T = nullptr, *R[2] = {nullptr, nullptr};
     Xyzz<O>* tsum = nullptr;
@@ -116,7 +122,7 @@ struct MsmWorkspace {
             if (p) hipFree(p);
         heavy = n_heavy = nullptr;
         part = bkt = S[0] = S[1] = T = R[0] = R[1] = tsum = nullptr;
-        cap_nb = cap_np = cap_chunks = 0;
+        cap_nb = cap_np = cap_part = 0;
     }
     // lanes of the accumulation kernel per proof: ~2^18 across the whole batch.  Fewer, longer chunks mean fewer
     // partial sums to write and to gather (each extra partial costs a full XYZZ addition later).
@@ -138,19 +144,22 @@ struct MsmWorkspace {
     }
     // room for `np` proofs of an n-point MSM with geometry g (every per-proof array is np-fold)
     int reserve(uint32_t n, const MsmGeom& g, uint32_t np) {
-        size_t need_chunks = nchunks_for(n, g, np);
-        if ((size_t)g.nb <= cap_nb && np <= cap_np && need_chunks <= cap_chunks) return MASP_HIP_OK;
-        need_chunks = std::max(need_chunks, cap_chunks);
+        // `part` is addressed with the launch's own stride (chunks + nb per proof), so what counts is the product np x (chunks +
+        // nb): a batch of 64 proofs (8 192 chunks each) fits the buffer of a batch of 256 (3 072 each) without a new hipMalloc
+        const size_t part_need = (size_t)np * ((size_t)nchunks_for(n, g, np) + g.nb);
+        if ((size_t)g.nb <= cap_nb && np <= cap_np && part_need <= cap_part) return MASP_HIP_OK;
         size_t need_nb = std::max<size_t>(g.nb, cap_nb), need_np = std::max<size_t>(np, cap_np);
+        // every batch shape of this base set: np x chunks <= 3 * 2^18 (nchunks_for), np x nb <= need_np x need_nb
+        const size_t need_part = std::max(std::max(part_need, cap_part), need_np * need_nb + ((size_t)3 << 18));
         release();
         cap_nb = need_nb;
         cap_np = need_np;
-        cap_chunks = need_chunks;
+        cap_part = need_part;
         const size_t P = cap_np;
         size_t chunks = (cap_nb + (1u << CS_LOG) - 1) >> CS_LOG;
         HIP_TRY(hipMalloc(&heavy, P * 4 * cap_nb));
         HIP_TRY(hipMalloc(&n_heavy, P * 4));
-        HIP_TRY(hipMalloc(&part, P * sizeof(Xyzz<O>) * (cap_chunks + cap_nb)));
+        HIP_TRY(hipMalloc(&part, sizeof(Xyzz<O>) * cap_part));
         HIP_TRY(hipMalloc(&bkt, P * sizeof(Xyzz<O>) * cap_nb));
         HIP_TRY(hipMalloc(&S[0], P * sizeof(Xyzz<O>) * chunks));
         HIP_TRY(hipMalloc(&S[1], P * sizeof(Xyzz<O>) * chunks));

@@ -220,7 +220,7 @@ class LocalTxProver:
         descriptions = [("spend", kwargs) | ("output", kwargs) | ("convert", kwargs)] with the keyword arguments of
         prepare_spend / prepare_output / prepare_convert.
 
-        Three stages run as a pipeline over chunks of `chunk` descriptions (default: the GPU batch size):
+        Three stages run as a pipeline over chunks of `chunk` descriptions (default 128):
         witness synthesis on `threads` host threads (the C++ synthesizer releases the GIL), proving on the GPU (each
         chunk in flight owns one slot of the native context, which is re-entrant), and self-verification of the Spend /
         Convert proofs of a finished chunk as one `verify_proofs_batch`-style check per circuit, Miller loops on the GPU
@@ -234,7 +234,9 @@ class LocalTxProver:
         if rs is None:
             rs = [(self._rng(), self._rng()) for _ in range(n)]
         threads = threads or H.effective_cpus()
-        chunk = chunk or int(os.environ.get("MASP_HIP_BATCH", "256"))
+        # 128 descriptions per GPU call: the first call starts after 128 instead of 256 syntheses (a 1 024-Spend list: 769
+        # against 730 proofs/s), long lists run at the same rate for 64 .. 256
+        chunk = chunk or min(128, int(os.environ.get("MASP_HIP_BATCH", "256")))
         in_flight = max(1, int(os.environ.get("MASP_HIP_SLOTS", "4")))    # one call per slot of the native context
         prep = {"spend": self.prepare_spend, "output": self.prepare_output, "convert": self.prepare_convert}
         done = [0]
