@@ -107,77 +107,101 @@ __device__ __forceinline__ void xyzz_add_coop(G1Xyzz& acc, const G1Xyzz& b, uint
 //   g_a = r*delta1 + alpha1 + A
 //   g_b = s*delta2 + beta2 + B2
 //   g_c = (r s)*delta1 + s*alpha1 + r*beta1 + s*A + r*B1 + H + L
-// One workgroup of three waves so that the three differently-shaped jobs do not serialise inside a wave:
-//   wave 0             : the two variable-base multiplications  s*A, r*B1: lanes 0..31 build the tables d*A, d*B1
-//                        (d < 16) in LDS, then lanes 0..7 run 4-bit fixed windows (252 doublings + <= 64 additions each,
-//                        four lanes per point; exact for any curve point: no endomorphism, the CRS is read unchecked like
-//                        the reference's)
-//   wave 1, lane 0     : s*delta2 on G2 through its fixed-base table          (<= 32 additions)
-//   wave 2, lanes 0..3 : r*delta1, s*alpha1, r*beta1, (r s)*delta1 through fixed-base tables
-// then three lanes normalise and encode.  rs: 8 limbs r | 8 limbs s (canonical).
-// fb1: tables of delta1, alpha1, beta1 (in that order); fb2: table of delta2.
-__global__ void __launch_bounds__(192) k_groth16_assemble(const VkDevice* __restrict__ vk, const G1Xyzz* __restrict__ fb1,
-                                                          const G2Xyzz* __restrict__ fb2, const G1Xyzz* __restrict__ msm_g1 /* H, L, A, B1 */,
-                                                          const G2Xyzz* __restrict__ msm_g2, const uint32_t* __restrict__ rs, size_t rs_stride,
-                                                          uint8_t* __restrict__ proof) {
-    __shared__ G1Xyzz part[6];
-    __shared__ G2Xyzz part2;
-    __shared__ G1Xyzz wtab[2][16];
-    const uint32_t tid = threadIdx.x;
-    msm_g1 += (size_t)blockIdx.x * 4;  // one workgroup per proof of the batch
-    msm_g2 += blockIdx.x;
+// as SIX small kernels (one workgroup per proof of the batch each) instead of one: every piece is a chain of dependent
+// 384-bit products on one to four lanes, and as one kernel (100 000 instructions, 512 VGPRs + 1 166 spilled) the pieces
+// could only start when the LAST multi-scalar multiplication of the proof was done.  Apart they start as soon as what they
+// read exists — the fixed-base multiplications (which only read r and s) at the very beginning of a lone proof, s*A and
+// r*B1 behind their own MSMs on their own streams — so that after the longest MSM chain only one finishing kernel is
+// left.  part[6 p ..] = r*delta1, s*alpha1, r*beta1, s*A, r*B1, (r s)*delta1;  part2[p] = s*delta2.
+// rs: 8 limbs r | 8 limbs s (canonical).  fb1: tables of delta1, alpha1, beta1 (in that order); fb2: table of delta2.
+
+// lanes 0..3: r*delta1, s*alpha1, r*beta1, (r s)*delta1 through the fixed-base tables (<= 32 additions each)
+__global__ void __launch_bounds__(64) k_groth16_fixed_g1(const G1Xyzz* __restrict__ fb1, const uint32_t* __restrict__ rs, size_t rs_stride,
+                                                         G1Xyzz* __restrict__ part) {
+    const uint32_t j = threadIdx.x;
+    if (j >= 4) return;
     rs += (size_t)blockIdx.x * rs_stride;
-    proof += (size_t)blockIdx.x * 192;
+    part += (size_t)blockIdx.x * 6;
     Fr r, s;
     for (int i = 0; i < 8; ++i) {
         r.v[i] = rs[i];
         s.v[i] = rs[8 + i];
     }
     constexpr size_t TAB = 32 * 255;
-    if (tid < 64) {
-        if (tid < 32) {  // wtab[j][d] = d * P_j by double-and-add over the 4 bits of d
-            const uint32_t j = tid >> 4, d = tid & 15;
-            const G1Xyzz P = msm_g1[2 + j];
-            G1Xyzz t = xyzz_inf<FpOps>();
-            for (int b = 3; b >= 0; --b) {
-                t = xyzz_dbl(t);
-                if ((d >> b) & 1) xyzz_add_nc(t, P);
-            }
-            wtab[j][d] = t;
+    const Fr rs_prod = fe_mul(fe_to_mont(r), s);  // mont(r) * s = r*s mod q, canonical
+    const G1Xyzz* tab = fb1 + (j == 1 ? TAB : j == 2 ? 2 * TAB : 0);
+    const Fr k = j == 0 ? r : j == 1 ? s : j == 2 ? r : rs_prod;
+    part[j == 3 ? 5 : j] = xyzz_fixed_mul<FpOps>(tab, k);
+}
+// one lane: s*delta2 on G2 through its fixed-base table
+__global__ void __launch_bounds__(64) k_groth16_fixed_g2(const G2Xyzz* __restrict__ fb2, const uint32_t* __restrict__ rs, size_t rs_stride,
+                                                         G2Xyzz* __restrict__ part2) {
+    if (threadIdx.x != 0) return;
+    rs += (size_t)blockIdx.x * rs_stride;
+    Fr s;
+    for (int i = 0; i < 8; ++i) s.v[i] = rs[8 + i];
+    part2[blockIdx.x] = xyzz_fixed_mul<Fp2Ops>(fb2, s);
+}
+// WHICH = 0: s*A -> part[3];  1: r*B1 -> part[4].  Lanes 0..15 build the table d*P (d < 16) in LDS, then lanes 0..3 run
+// 4-bit fixed windows (252 doublings + <= 64 additions, four lanes per point; exact for any curve point: no endomorphism,
+// the CRS is read unchecked like the reference's)
+template <int WHICH>
+__global__ void __launch_bounds__(64) k_groth16_var_mul(const G1Xyzz* __restrict__ msm_g1 /* H, L, A, B1 */, const uint32_t* __restrict__ rs,
+                                                        size_t rs_stride, G1Xyzz* __restrict__ part) {
+    __shared__ G1Xyzz wtab[16];
+    const uint32_t tid = threadIdx.x;
+    msm_g1 += (size_t)blockIdx.x * 4;
+    rs += (size_t)blockIdx.x * rs_stride + (WHICH == 0 ? 8 : 0);
+    part += (size_t)blockIdx.x * 6;
+    if (tid < 16) {  // wtab[d] = d * P by double-and-add over the 4 bits of d
+        const G1Xyzz P = msm_g1[2 + WHICH];
+        G1Xyzz t = xyzz_inf<FpOps>();
+        for (int b = 3; b >= 0; --b) {
+            t = xyzz_dbl(t);
+            if ((tid >> b) & 1) xyzz_add_nc(t, P);
         }
-        // same wave writes and reads the table: LDS is in order per wave, only the compiler must not reorder
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (tid < 8) {  // lanes 0..3: s*A, lanes 4..7: r*B1 — four lanes per point (see xyzz_dbl_coop)
-            const uint32_t grp = tid >> 2, lig = tid & 3;
-            const uint32_t* k = grp == 0 ? s.v : r.v;
-            G1Xyzz acc = xyzz_inf<FpOps>();
-            for (int w = 63; w >= 0; --w) {
-                if (w != 63)
-                    for (int q = 0; q < 4; ++q) acc = xyzz_dbl_coop(acc, lig);
-                const uint32_t d = (k[w >> 3] >> (4 * (w & 7))) & 15u;
-                if (d) xyzz_add_coop(acc, wtab[grp][d], lig);
-            }
-            if (lig == 0) part[3 + grp] = acc;
-        }
-    } else if (tid == 64) {
-        part2 = xyzz_fixed_mul<Fp2Ops>(fb2, s);
-    } else if (tid >= 128 && tid < 132) {
-        const uint32_t j = tid - 128;
-        Fr rs_prod = fe_mul(fe_to_mont(r), s);  // mont(r) * s = r*s mod q, canonical
-        const G1Xyzz* tab = fb1 + (j == 1 ? TAB : j == 2 ? 2 * TAB : 0);
-        Fr k = j == 0 ? r : j == 1 ? s : j == 2 ? r : rs_prod;
-        G1Xyzz v = xyzz_fixed_mul<FpOps>(tab, k);
-        part[j == 3 ? 5 : j] = v;  // 0: r*delta1, 1: s*alpha1, 2: r*beta1, 5: (r s)*delta1
+        wtab[tid] = t;
     }
-    __syncthreads();
+    // same wave writes and reads the table: LDS is in order per wave, only the compiler must not reorder
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (tid < 4) {  // four lanes per point (see xyzz_dbl_coop)
+        const uint32_t lig = tid;
+        uint32_t k[8];
+        for (int i = 0; i < 8; ++i) k[i] = rs[i];
+        G1Xyzz acc = xyzz_inf<FpOps>();
+        for (int w = 63; w >= 0; --w) {
+            if (w != 63)
+                for (int q = 0; q < 4; ++q) acc = xyzz_dbl_coop(acc, lig);
+            const uint32_t d = (k[w >> 3] >> (4 * (w & 7))) & 15u;
+            if (d) xyzz_add_coop(acc, wtab[d], lig);
+        }
+        if (lig == 0) part[3 + WHICH] = acc;
+    }
+}
+// one lane: g_b = s*delta2 + beta2 + B2, normalised and encoded
+__global__ void __launch_bounds__(64) k_groth16_finish_b(const VkDevice* __restrict__ vk, const G2Xyzz* __restrict__ part2,
+                                                         const G2Xyzz* __restrict__ msm_g2, uint8_t* __restrict__ proof) {
+    if (threadIdx.x != 0) return;
+    G2Xyzz gb = part2[blockIdx.x];
+    xyzz_madd_nc(gb, vk->beta_g2, false);
+    xyzz_add_nc(gb, msm_g2[blockIdx.x]);
+    g2_write_compressed(xyzz_to_affine<Fp2Ops, true>(gb), proof + (size_t)blockIdx.x * 192 + 48);
+}
+// two waves, one lane each: g_a and g_c, normalised and encoded
+__global__ void __launch_bounds__(128) k_groth16_finish_ac(const VkDevice* __restrict__ vk, const G1Xyzz* __restrict__ part,
+                                                           const G1Xyzz* __restrict__ msm_g1 /* H, L, A, B1 */, uint8_t* __restrict__ proof) {
+    const uint32_t tid = threadIdx.x;
+    part += (size_t)blockIdx.x * 6;
+    msm_g1 += (size_t)blockIdx.x * 4;
+    proof += (size_t)blockIdx.x * 192;
     if (tid == 0) {
         G1Xyzz ga = part[0];
         xyzz_madd_nc(ga, vk->alpha_g1, false);
         xyzz_add_nc(ga, msm_g1[2]);
         g1_write_compressed(xyzz_to_affine<FpOps, true>(ga), proof);
-    } else if (tid == 128) {
+    } else if (tid == 64) {
         G1Xyzz gc = part[5];
         xyzz_add_nc(gc, part[1]);
         xyzz_add_nc(gc, part[2]);
@@ -186,11 +210,6 @@ __global__ void __launch_bounds__(192) k_groth16_assemble(const VkDevice* __rest
         xyzz_add_nc(gc, msm_g1[0]);
         xyzz_add_nc(gc, msm_g1[1]);
         g1_write_compressed(xyzz_to_affine<FpOps, true>(gc), proof + 144);
-    } else if (tid == 64) {
-        G2Xyzz gb = part2;
-        xyzz_madd_nc(gb, vk->beta_g2, false);
-        xyzz_add_nc(gb, *msm_g2);
-        g2_write_compressed(xyzz_to_affine<Fp2Ops, true>(gb), proof + 48);
     }
 }
 

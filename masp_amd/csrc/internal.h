@@ -129,11 +129,11 @@ struct Slot {
     // with its own workspace, next to the quotient pipeline on the main stream
     static constexpr int N_AUX = 4;
     hipStream_t aux[N_AUX] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_sort_b = nullptr, ev_join[N_AUX] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_sort_b = nullptr, ev_fixed = nullptr, ev_join[N_AUX] = {nullptr, nullptr, nullptr, nullptr};
     MsmWorkspace<FpOps> ws_l, ws_a, ws_b;
     DevBuf<Fr> w, abc, wm, ev[3], x0, x1, h, hl, sa, sb;
-    DevBuf<G1Xyzz> res1;
-    DevBuf<G2Xyzz> res2;
+    DevBuf<G1Xyzz> res1, asm1;  // asm1: the six G1 pieces of the assembly per proof, asm2: s*delta2
+    DevBuf<G2Xyzz> res2, asm2;
     DevBuf<uint32_t> rs;
     DevBuf<uint8_t> proof;
     DevBuf<int> flags;
@@ -153,6 +153,7 @@ struct Slot {
         }
         if (ev_fork) hipEventDestroy(ev_fork);
         if (ev_sort_b) hipEventDestroy(ev_sort_b);
+        if (ev_fixed) hipEventDestroy(ev_fixed);
         if (h_stage) hipHostFree(h_stage);
         if (h_proof) hipHostFree(h_proof);
         if (h_flags) hipHostFree(h_flags);
@@ -162,6 +163,7 @@ struct Slot {
         HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ev_sort_b, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_fixed, hipEventDisableTiming));
         for (int i = 0; i < N_AUX; ++i) {
             HIP_TRY(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
@@ -173,7 +175,7 @@ struct Slot {
     }
     int reserve_batch(size_t np) {
         int rc;
-        if ((rc = res1.reserve(4 * np)) || (rc = res2.reserve(np)) || (rc = rs.reserve(16 * np)) || (rc = proof.reserve(192 * np))) return rc;
+        if ((rc = res1.reserve(4 * np)) || (rc = res2.reserve(np)) || (rc = asm1.reserve(6 * np)) || (rc = asm2.reserve(np)) || (rc = rs.reserve(16 * np)) || (rc = proof.reserve(192 * np))) return rc;
         if (np > h_proof_cap) {
             if (h_proof) hipHostFree(h_proof);
             h_proof = nullptr;

@@ -5,9 +5,23 @@
 
 namespace masp {
 
-void launch_groth16_assemble(hipStream_t s, const VkDevice* vk, const G1Xyzz* fb1, const G2Xyzz* fb2, const G1Xyzz* msm_g1, const G2Xyzz* msm_g2,
-                             const uint32_t* rs, size_t rs_stride, uint8_t* proof, uint32_t np) {
-    hipLaunchKernelGGL(k_groth16_assemble, dim3(np), dim3(192), 0, s, vk, fb1, fb2, msm_g1, msm_g2, rs, rs_stride, proof);
+void launch_groth16_fixed_g1(hipStream_t s, const G1Xyzz* fb1, const uint32_t* rs, size_t rs_stride, G1Xyzz* part, uint32_t np) {
+    hipLaunchKernelGGL(k_groth16_fixed_g1, dim3(np), dim3(64), 0, s, fb1, rs, rs_stride, part);
+}
+void launch_groth16_fixed_g2(hipStream_t s, const G2Xyzz* fb2, const uint32_t* rs, size_t rs_stride, G2Xyzz* part2, uint32_t np) {
+    hipLaunchKernelGGL(k_groth16_fixed_g2, dim3(np), dim3(64), 0, s, fb2, rs, rs_stride, part2);
+}
+void launch_groth16_var_mul(hipStream_t s, int which, const G1Xyzz* msm_g1, const uint32_t* rs, size_t rs_stride, G1Xyzz* part, uint32_t np) {
+    if (which == 0)
+        hipLaunchKernelGGL(k_groth16_var_mul<0>, dim3(np), dim3(64), 0, s, msm_g1, rs, rs_stride, part);
+    else
+        hipLaunchKernelGGL(k_groth16_var_mul<1>, dim3(np), dim3(64), 0, s, msm_g1, rs, rs_stride, part);
+}
+void launch_groth16_finish_b(hipStream_t s, const VkDevice* vk, const G2Xyzz* part2, const G2Xyzz* msm_g2, uint8_t* proof, uint32_t np) {
+    hipLaunchKernelGGL(k_groth16_finish_b, dim3(np), dim3(64), 0, s, vk, part2, msm_g2, proof);
+}
+void launch_groth16_finish_ac(hipStream_t s, const VkDevice* vk, const G1Xyzz* part, const G1Xyzz* msm_g1, uint8_t* proof, uint32_t np) {
+    hipLaunchKernelGGL(k_groth16_finish_ac, dim3(np), dim3(128), 0, s, vk, part, msm_g1, proof);
 }
 void launch_g1_export(hipStream_t s, const G1Xyzz* p, uint8_t* out) { hipLaunchKernelGGL(k_g1_export, dim3(1), dim3(1), 0, s, p, out); }
 void launch_g2_export(hipStream_t s, const G2Xyzz* p, uint8_t* out) { hipLaunchKernelGGL(k_g2_export, dim3(1), dim3(1), 0, s, p, out); }

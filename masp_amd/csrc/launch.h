@@ -26,8 +26,11 @@ void launch_r1cs_eval(hipStream_t s, const uint32_t* rowptr, const uint32_t* ord
 void launch_gather_scalars(hipStream_t s, const Fr* src, size_t src_stride, const uint32_t* idx, uint32_t n, Fr* dst, uint32_t np);
 
 // ---- k_groth16.hip: proof assembly, point import / export, fixed-base tables (device/groth16.cuh) ----
-void launch_groth16_assemble(hipStream_t s, const VkDevice* vk, const G1Xyzz* fb1, const G2Xyzz* fb2, const G1Xyzz* msm_g1, const G2Xyzz* msm_g2,
-                             const uint32_t* rs, size_t rs_stride, uint8_t* proof, uint32_t np);
+void launch_groth16_fixed_g1(hipStream_t s, const G1Xyzz* fb1, const uint32_t* rs, size_t rs_stride, G1Xyzz* part, uint32_t np);
+void launch_groth16_fixed_g2(hipStream_t s, const G2Xyzz* fb2, const uint32_t* rs, size_t rs_stride, G2Xyzz* part2, uint32_t np);
+void launch_groth16_var_mul(hipStream_t s, int which, const G1Xyzz* msm_g1, const uint32_t* rs, size_t rs_stride, G1Xyzz* part, uint32_t np);
+void launch_groth16_finish_b(hipStream_t s, const VkDevice* vk, const G2Xyzz* part2, const G2Xyzz* msm_g2, uint8_t* proof, uint32_t np);
+void launch_groth16_finish_ac(hipStream_t s, const VkDevice* vk, const G1Xyzz* part, const G1Xyzz* msm_g1, uint8_t* proof, uint32_t np);
 void launch_g1_export(hipStream_t s, const G1Xyzz* p, uint8_t* out);
 void launch_g2_export(hipStream_t s, const G2Xyzz* p, uint8_t* out);
 void launch_g1_import_one(hipStream_t s, const uint8_t* raw, G1Affine* out, int* status);

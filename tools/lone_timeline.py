@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timeline of the last lone-proof run in a rocprofv3 rocpd database: every dispatch between the last single-block
-k_groth16_assemble and `window_ms` before its end, with start / duration relative to the first of them and its queue.
+k_groth16_finish_ac and `window_ms` before its end, with start / duration relative to the first of them and its queue.
 usage: lone_timeline.py results.db [window_ms=40]"""
 import re
 import sqlite3
@@ -13,7 +13,7 @@ sym_cols = [r[1] for r in cur.execute("pragma table_info(rocpd_info_kernel_symbo
 name_col = "display_name" if "display_name" in sym_cols else "kernel_name"
 rows = list(cur.execute("select s.%s, d.start, d.end, d.queue_id, d.grid_size_x, d.grid_size_y from rocpd_kernel_dispatch d "
                         "join rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start" % name_col))
-last = [r for r in rows if "k_groth16_assemble" in r[0] and r[4] <= 192][-1]
+last = [r for r in rows if "k_groth16_finish_ac" in r[0] and r[4] <= 128][-1]   # grid of one workgroup: a lone proof
 t1 = last[2]
 sel = [r for r in rows if r[1] >= t1 - win * 1e6 and r[2] <= t1]
 # keep only the run that belongs to this proof: starts at the last k_fr_to_mont before the assemble
