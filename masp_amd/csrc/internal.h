@@ -115,6 +115,10 @@ struct Circuit {
     // one bucket set — l's scalars then cost 16 window digits instead of 22 and its sort / bucket tails disappear
     BasesG1 hl;
     BasesG2 b2;
+    // the same G2 points on narrow windows (128 buckets), for lone proofs only: B2's bucket tails are the longest chain of
+    // a lone proof (every G2 addition is 40 dependent 384-bit products on one lane), and with 128 instead of 2 048 buckets
+    // the gather / weighted-sum levels nearly vanish for 45 % more (chip-filling) accumulation work; n = 0: not built
+    BasesG2 b2_lone;
     NttDomain* dom = nullptr;
 };
 

@@ -134,7 +134,10 @@ struct MsmWorkspace {
                                  : std::max<uint64_t>(NCHUNKS / std::max<uint32_t>(np, 1), 1u << 13);
         // lone proof: about eight chunks per bucket, so that a bucket's partials are few enough for one gather lane
         // (otherwise every bucket of a 12-bit-window MSM becomes a "heavy" bucket with a workgroup of its own)
-        if (np < 8) lanes = std::min<uint64_t>(lanes, std::max<uint64_t>(8ull * g.nb, 1u << 13));
+        // ... except with so few buckets (a lone proof's B2 on 8-bit windows) that every bucket goes to the heavy-bucket
+        // workgroups anyway: there a lane's chunk is a chain of dependent additions on an otherwise idle chip, so the digit
+        // list is cut into one full round of waves
+        if (np < 8) lanes = g.nb <= 256 ? std::max<uint64_t>((1u << 16) / np, 1u << 13) : std::min<uint64_t>(lanes, std::max<uint64_t>(8ull * g.nb, 1u << 13));
         static const int forced = [] {  // experiment knob, read once per process
             const char* e = getenv("MASP_HIP_MSM_CHUNKS");
             return e ? std::max(1, atoi(e)) : 0;

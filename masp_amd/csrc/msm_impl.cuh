@@ -104,7 +104,7 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
     // ~19 for the two lane scans: a batch takes the largest G in {8 .. 64} that still fills one workgroup (2 048 buckets: 16,
     // the 32 768 of h+l: 64 = 2.3 instead of 3.2 additions per bucket) — with other batches in flight total work counts, not
     // the length of the chain; a lone proof takes 4 (shortest dependent chain).
-    uint32_t g_log = WSUM_G_LOG_MIN;
+    uint32_t g_log = nb <= WSUM_L ? 0 : WSUM_G_LOG_MIN;  // at most 128 buckets: one per lane, one workgroup, no second level
     if (!lone) {
         static const int forced = [] {
             const char* e = getenv("MASP_HIP_WSUM_G_LOG");  // experiment knob: upper limit of G
@@ -126,7 +126,7 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
         switch (g_log) {
 #define MASP_WSUM_CASE(GL) \
     case GL: hipLaunchKernelGGL((k_msm_wsum_level<O, GL>), grid, block, 0, s, bk, bk_stride, m, off, ws.S[flip], ws.T, st_stride); break;
-            MASP_WSUM_CASE(2) MASP_WSUM_CASE(3) MASP_WSUM_CASE(4) MASP_WSUM_CASE(5) MASP_WSUM_CASE(6)
+            MASP_WSUM_CASE(0) MASP_WSUM_CASE(2) MASP_WSUM_CASE(3) MASP_WSUM_CASE(4) MASP_WSUM_CASE(5) MASP_WSUM_CASE(6)
 #undef MASP_WSUM_CASE
         }
         ws.reduce_to_one(s, np, ws.T, st_stride, chunks, ws.tsum + level, 32, st_stride);

@@ -205,12 +205,19 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
         // The pieces of the assembly start as soon as what they read exists: the fixed-base multiplications (r and s only)
         // right away, s*A and r*B1 behind their MSMs, g_b behind B2 — after the join only g_a / g_c are left.
         // A lone proof is ~170 launches, i.e. more than a millisecond of host time: the streams are fed in the order of
-        // their chains' lengths — B2 (the longest: G2 tails), then the quotient and H, then B1, A, L.
+        // their chains' lengths — B2 (G2 tails), A and B1 (each followed by a variable-base multiplication), the quotient
+        // and H, L.
         launch_groth16_fixed_g1(sl.aux[0], C.fb1.p, d_rs, 16, sl.asm1.p, np);
         launch_groth16_fixed_g2(sl.aux[0], C.fb2.p, d_rs, 16, sl.asm2.p, np);
         HIP_TRY(hipEventRecord(sl.ev_fixed, sl.aux[0]));  // s*delta2 is read by g_b on aux[3]
         if (C.nbq) launch_gather_scalars(sl.aux[2], d_w, w_stride, C.b_var.p, C.nbq, sl.sb.p, np);
-        if (share_b) {
+        const bool own_b2 = C.b2_lone.n != 0;  // B2 on its own narrow windows: sorts for itself
+        if (own_b2) {
+            HIP_TRY(hipEventRecord(sl.ev_sort_b, sl.aux[2]));  // orders the read of sb after its gather
+            HIP_TRY(hipStreamWaitEvent(sl.aux[3], sl.ev_sort_b, 0));
+            if ((rc = msm_enqueue(sl.aux[3], C.b2_lone, sl.ws2, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res2.p, 1, np))) return rc;
+            if (share_b && (rc = msm_sort_enqueue(sl.aux[2], C.b1.n, C.b1.g, sl.ws_b.sort, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, np))) return rc;
+        } else if (share_b) {
             if ((rc = msm_sort_enqueue(sl.aux[2], C.b1.n, C.b1.g, sl.ws_b.sort, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, np))) return rc;
             HIP_TRY(hipEventRecord(sl.ev_sort_b, sl.aux[2]));
             HIP_TRY(hipStreamWaitEvent(sl.aux[3], sl.ev_sort_b, 0));
@@ -222,17 +229,18 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
         }
         HIP_TRY(hipStreamWaitEvent(sl.aux[3], sl.ev_fixed, 0));
         launch_groth16_finish_b(sl.aux[3], C.vk.p, sl.asm2.p, sl.res2.p, d_proof, np);
-        if ((rc = enqueue_quotient(sl, *C.dom, in, C.nrows, C.nrows, mont_in, np))) return rc;
-        if ((rc = msm_enqueue(s, C.h, sl.ws1, (const uint32_t*)sl.h.p, m8, sl.res1.p + 0, 4, np, prof))) return rc;
+        // A and B1 are followed by 3 ms of variable-base multiplication each: before the quotient and H
+        if (C.na) launch_gather_scalars(sl.aux[1], d_w, w_stride, C.a_var.p, C.na, sl.sa.p, np);
+        if ((rc = msm_enqueue(sl.aux[1], C.a, sl.ws_a, (const uint32_t*)sl.sa.p, (size_t)C.na * 8, sl.res1.p + 2, 4, np))) return rc;
+        launch_groth16_var_mul(sl.aux[1], 0, sl.res1.p, d_rs, 16, sl.asm1.p, np);
         if (share_b) {
             if ((rc = msm_reduce_enqueue(sl.aux[2], C.b1, sl.ws_b.sort, sl.ws_b, sl.res1.p + 3, 4))) return rc;
         } else if ((rc = msm_enqueue(sl.aux[2], C.b1, sl.ws_b, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res1.p + 3, 4, np))) {
             return rc;
         }
         launch_groth16_var_mul(sl.aux[2], 1, sl.res1.p, d_rs, 16, sl.asm1.p, np);
-        if (C.na) launch_gather_scalars(sl.aux[1], d_w, w_stride, C.a_var.p, C.na, sl.sa.p, np);
-        if ((rc = msm_enqueue(sl.aux[1], C.a, sl.ws_a, (const uint32_t*)sl.sa.p, (size_t)C.na * 8, sl.res1.p + 2, 4, np))) return rc;
-        launch_groth16_var_mul(sl.aux[1], 0, sl.res1.p, d_rs, 16, sl.asm1.p, np);
+        if ((rc = enqueue_quotient(sl, *C.dom, in, C.nrows, C.nrows, mont_in, np))) return rc;
+        if ((rc = msm_enqueue(s, C.h, sl.ws1, (const uint32_t*)sl.h.p, m8, sl.res1.p + 0, 4, np, prof))) return rc;
         if ((rc = msm_enqueue(sl.aux[0], C.l, sl.ws_l, (const uint32_t*)(d_w + C.n_inputs), w_stride * 8, sl.res1.p + 1, 4, np))) return rc;
         // g_a / g_c need L, s*A and r*B1 (aux[0..2]); g_b finishes on aux[3] by itself and is only joined before the proof leaves
         for (int i = 0; i < Slot::N_AUX - 1; ++i) {
@@ -531,6 +539,11 @@ int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* param
         (rc = C->a.load_host(L.a, L.n_a, s, eff(L.n_a), c_la)) || (rc = C->b1.load_host(L.b_g1, L.n_b1, s, eff(L.n_b1), c_b)) ||
         (rc = C->b2.load_host(L.b_g2, L.n_b2, s, eff(L.n_b2), c_b)))
         return fail(ctx, rc);
+    {
+        const char* e = getenv("MASP_HIP_MSM_C_B2_LONE");  // 0 = lone proofs share the batch tables (and B1's sort)
+        const int c_lone = e ? atoi(e) : 8;
+        if (c_lone > 0 && L.n_b2 && (rc = C->b2_lone.load_host(L.b_g2, L.n_b2, s, eff(L.n_b2), c_lone))) return fail(ctx, rc);
+    }
     {
         const size_t nh = C->m - 1;
         std::vector<uint8_t> cat(96 * (nh + L.n_l));
