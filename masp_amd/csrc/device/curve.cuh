@@ -177,6 +177,15 @@ MASP_HD void xyzz_madd(Xyzz<O>& acc, const Affine<O>& b, bool negate) {
     }
 }
 
+// the exceptional cases of a full addition (same x: doubling or the point at infinity), out of line for G2 (see xyzz_madd)
+template <class O>
+MASP_NOINLINE void xyzz_add_same_x(Xyzz<O>& acc, bool same_y) {
+    if (same_y)
+        acc = xyzz_dbl(acc);
+    else
+        acc = xyzz_inf<O>();
+}
+
 // acc += b, both XYZZ (add-2008-s)
 template <class O, class M = O>
 MASP_HD void xyzz_add(Xyzz<O>& acc, const Xyzz<O>& b) {
@@ -186,28 +195,50 @@ MASP_HD void xyzz_add(Xyzz<O>& acc, const Xyzz<O>& b) {
         acc = b;
         return;
     }
-    F U1 = M::mul(acc.X, b.ZZ);
-    F U2 = M::mul(b.X, acc.ZZ);
-    F S1 = M::mul(acc.Y, b.ZZZ);
-    F S2 = M::mul(b.Y, acc.ZZZ);
-    F P = O::sub(U2, U1);
-    F R = O::sub(S2, S1);
-    if (O::is_zero(P)) {
-        if (O::is_zero(R))
-            acc = xyzz_dbl(acc);
-        else
-            acc = xyzz_inf<O>();
-        return;
+    if constexpr (sizeof(F) > 48) {
+        // Fp2: as in xyzz_madd — every input is consumed as early as possible, the exceptional cases are a call
+        F U1 = M::mul(acc.X, b.ZZ);
+        F P = O::sub(M::mul(b.X, acc.ZZ), U1);
+        F S1 = M::mul(acc.Y, b.ZZZ);
+        F R = O::sub(M::mul(b.Y, acc.ZZZ), S1);
+        if (O::is_zero(P)) {
+            xyzz_add_same_x(acc, O::is_zero(R));
+            return;
+        }
+        acc.ZZ = M::mul(acc.ZZ, b.ZZ);
+        acc.ZZZ = M::mul(acc.ZZZ, b.ZZZ);
+        F PP = M::sqr(P);
+        acc.ZZ = M::mul(acc.ZZ, PP);
+        F PPP = M::mul(P, PP);
+        acc.ZZZ = M::mul(acc.ZZZ, PPP);
+        F Q = M::mul(U1, PP);
+        F T = M::mul(S1, PPP);
+        acc.X = O::sub(O::sub(M::sqr(R), PPP), O::dbl(Q));
+        acc.Y = O::sub(M::mul(R, O::sub(Q, acc.X)), T);
+    } else {
+        F U1 = M::mul(acc.X, b.ZZ);
+        F U2 = M::mul(b.X, acc.ZZ);
+        F S1 = M::mul(acc.Y, b.ZZZ);
+        F S2 = M::mul(b.Y, acc.ZZZ);
+        F P = O::sub(U2, U1);
+        F R = O::sub(S2, S1);
+        if (O::is_zero(P)) {
+            if (O::is_zero(R))
+                acc = xyzz_dbl(acc);
+            else
+                acc = xyzz_inf<O>();
+            return;
+        }
+        F PP = M::sqr(P);
+        F PPP = M::mul(P, PP);
+        F Q = M::mul(U1, PP);
+        F X3 = O::sub(O::sub(M::sqr(R), PPP), O::dbl(Q));
+        F Y3 = O::sub(M::mul(R, O::sub(Q, X3)), M::mul(S1, PPP));
+        acc.X = X3;
+        acc.Y = Y3;
+        acc.ZZ = M::mul(M::mul(acc.ZZ, b.ZZ), PP);
+        acc.ZZZ = M::mul(M::mul(acc.ZZZ, b.ZZZ), PPP);
     }
-    F PP = M::sqr(P);
-    F PPP = M::mul(P, PP);
-    F Q = M::mul(U1, PP);
-    F X3 = O::sub(O::sub(M::sqr(R), PPP), O::dbl(Q));
-    F Y3 = O::sub(M::mul(R, O::sub(Q, X3)), M::mul(S1, PPP));
-    acc.X = X3;
-    acc.Y = Y3;
-    acc.ZZ = M::mul(M::mul(acc.ZZ, b.ZZ), PP);
-    acc.ZZZ = M::mul(M::mul(acc.ZZZ, b.ZZZ), PPP);
 }
 
 // forms for cold kernels and serial tails: the group law inline (additions / subtractions, ~4 KiB), every field product

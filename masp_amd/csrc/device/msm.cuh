@@ -60,7 +60,7 @@ __global__ void k_msm_import(const uint8_t* __restrict__ raw, TabRow<O>* __restr
 }
 // T[j][i] = 2^c * T[j-1][i]
 template <class O>
-__global__ void k_msm_precompute(TabRow<O>* __restrict__ tab, uint32_t n, int c, int W) {
+__global__ void __launch_bounds__(64) k_msm_precompute(TabRow<O>* __restrict__ tab, uint32_t n, int c, int W) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Affine<O> p = tab[i].p;
@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(256) k_xyzz_reduce_block(const Xyzz<O>* __rest
 }
 // V = T0 + cs*(T1 + cs*(T2 + ...)) ;  tsum[l] holds the fully reduced T of level l.
 template <class O>
-__global__ void k_msm_combine(const Xyzz<O>* __restrict__ tsum, int levels, int cs_log, Xyzz<O>* __restrict__ out, size_t out_stride) {
+__global__ void __launch_bounds__(64) k_msm_combine(const Xyzz<O>* __restrict__ tsum, int levels, int cs_log, Xyzz<O>* __restrict__ out, size_t out_stride) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     tsum += (size_t)MSM_P * 32;
     out += MSM_P * out_stride;
