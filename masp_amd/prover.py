@@ -250,8 +250,16 @@ class LocalTxProver:
         # synthesis may run ahead of the GPU only so far: every job in flight owns a page-locked aux buffer (3.2 MB / Spend)
         window = (in_flight + 1) * chunk + threads       # synthesis runs one chunk ahead (measured: two buy nothing)
         ahead = threading.Semaphore(window)
+        # ... per circuit: the most descriptions of that circuit any `window` consecutive ones hold
+        most, inside = {}, {}
+        for i, (kind, _) in enumerate(descriptions):
+            inside[kind] = inside.get(kind, 0) + 1
+            if i >= window:
+                inside[descriptions[i - window][0]] -= 1
+            if inside[kind] > most.get(kind, 0):
+                most[kind] = inside[kind]
         for kind, slot in (("spend", SPEND), ("output", OUTPUT), ("convert", CONVERT)):
-            self._aux_reserve(slot, min(window, sum(1 for k, _ in descriptions if k == kind)))
+            self._aux_reserve(slot, most.get(kind, 0))
 
         abort = threading.Event()              # set when a chunk fails: queued synthesis tasks then return at once
 

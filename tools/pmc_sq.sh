@@ -14,7 +14,7 @@ allrows = list(csv.DictReader(open(f)))
 doc = {"command": "tools/pmc_sq.sh: MASP_HIP_SLOTS=1 rocprofv3 --pmc <8 SQ counters> --kernel-trace -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline",
        "note": "one batch in flight (every kernel alone on the chip), averages per launch of the full 128-proof batch; quad-cycle units (MI355X_MICROARCH.md)"}
 for key, pat, vgprs in (("k_msm_accumulate<G1>", "k_msm_accumulate<masp::FpOps>", "226 VGPRs, no spills: 2 waves per SIMD"),
-                        ("k_msm_accumulate<G2>", "k_msm_accumulate<masp::Fp2Ops>", "512 VGPRs + 414 spilled (992 B scratch): 1 wave per SIMD; the 384-bit product is an out-of-line call")):
+                        ("k_msm_accumulate<G2>", "k_msm_accumulate<masp::Fp2Ops>", "396 VGPRs, no spills in the loop (the exceptional cases of the addition are one out-of-line call: 512 B of scratch for its arguments): 1 wave per SIMD; the 384-bit product is an out-of-line call")):
     rows = [r for r in allrows if pat in r["Kernel_Name"]]
     full = max(int(r["Grid_Size"]) for r in rows)
     acc = collections.defaultdict(list)
