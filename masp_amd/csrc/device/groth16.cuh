@@ -145,11 +145,11 @@ __global__ void __launch_bounds__(64) k_groth16_fixed_g2(const G2Xyzz* __restric
 // WHICH = 0: s*A -> part[3];  1: r*B1 -> part[4].  Lanes 0..15 build the table d*P (d < 16) in LDS, then lanes 0..3 run
 // 4-bit fixed windows (252 doublings + <= 64 additions, four lanes per point; exact for any curve point: no endomorphism,
 // the CRS is read unchecked like the reference's)
-template <int WHICH>
-__global__ void __launch_bounds__(64) k_groth16_var_mul(const G1Xyzz* __restrict__ msm_g1 /* H, L, A, B1 */, const uint32_t* __restrict__ rs,
-                                                        size_t rs_stride, G1Xyzz* __restrict__ part) {
+// (gridDim.y = 2 runs both: WHICH = which0 + blockIdx.y)
+__global__ void __launch_bounds__(64) k_groth16_var_mul(uint32_t which0, const G1Xyzz* __restrict__ msm_g1 /* H, L, A, B1 */,
+                                                        const uint32_t* __restrict__ rs, size_t rs_stride, G1Xyzz* __restrict__ part) {
     __shared__ G1Xyzz wtab[16];
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, WHICH = which0 + blockIdx.y;
     msm_g1 += (size_t)blockIdx.x * 4;
     rs += (size_t)blockIdx.x * rs_stride + (WHICH == 0 ? 8 : 0);
     part += (size_t)blockIdx.x * 6;

@@ -11,11 +11,9 @@ void launch_groth16_fixed_g1(hipStream_t s, const G1Xyzz* fb1, const uint32_t* r
 void launch_groth16_fixed_g2(hipStream_t s, const G2Xyzz* fb2, const uint32_t* rs, size_t rs_stride, G2Xyzz* part2, uint32_t np) {
     hipLaunchKernelGGL(k_groth16_fixed_g2, dim3(np), dim3(64), 0, s, fb2, rs, rs_stride, part2);
 }
+// which = 0: s*A, 1: r*B1, 2: both in one launch
 void launch_groth16_var_mul(hipStream_t s, int which, const G1Xyzz* msm_g1, const uint32_t* rs, size_t rs_stride, G1Xyzz* part, uint32_t np) {
-    if (which == 0)
-        hipLaunchKernelGGL(k_groth16_var_mul<0>, dim3(np), dim3(64), 0, s, msm_g1, rs, rs_stride, part);
-    else
-        hipLaunchKernelGGL(k_groth16_var_mul<1>, dim3(np), dim3(64), 0, s, msm_g1, rs, rs_stride, part);
+    hipLaunchKernelGGL(k_groth16_var_mul, dim3(np, which == 2 ? 2 : 1), dim3(64), 0, s, which == 1 ? 1u : 0u, msm_g1, rs, rs_stride, part);
 }
 void launch_groth16_finish_b(hipStream_t s, const VkDevice* vk, const G2Xyzz* part2, const G2Xyzz* msm_g2, uint8_t* proof, uint32_t np) {
     hipLaunchKernelGGL(k_groth16_finish_b, dim3(np), dim3(64), 0, s, vk, part2, msm_g2, proof);
