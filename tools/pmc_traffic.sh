@@ -9,6 +9,7 @@ export TMPDIR=/tmp
 root=$PWD
 out=$root/gpurun_out/pmc
 rm -rf $out; mkdir -p $out
+[ -x $root/tools/_build/pmc_calib ] || { mkdir -p $root/tools/_build; /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $root/tools/pmc_calib.hip -o $root/tools/_build/pmc_calib; }
 (cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/calib -o run -- $root/tools/_build/pmc_calib > $out/calib.log 2>&1)
 for c in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/$c -o run -- python $root/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $out/$c.log 2>&1)
