@@ -241,33 +241,38 @@ k_msm_partition(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint
         const int cls = i < hi ? msm_scalar_class(sw) : 0;
         const uint64_t ones = __ballot(cls == 1);
         const int leader = ones ? __ffsll((unsigned long long)ones) - 1 : -1;
-        if (cls == 1) {
-            if ((int)(tid & 63u) == leader) atomicAdd(&cnt[0], (uint32_t)__popcll(ones));
-        } else if (cls == 2) {
+        // ONE pass over the digits of a tile: the counting atomic already hands out the entry's rank inside its bin, the entry
+        // and (bin, rank) wait in registers for the scan of the counts (the digits were extracted and counted twice before)
+        uint32_t ent[32], key[32];
+        uint32_t unit_rank = 0;
+        if (ones) {  // unit scalars: window 0, bucket 0, positive
+            if ((int)(tid & 63u) == leader) unit_rank = atomicAdd(&cnt[0], (uint32_t)__popcll(ones));
+            unit_rank = __shfl(unit_rank, leader, 64) + (uint32_t)__popcll(ones & ((1ull << (tid & 63u)) - 1ull));
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) key[j] = 0xffffffffu;
+        if (cls == 2) {
             MsmDigitIter it(sw, g.c);
-            for (int j = 0; j < g.W; ++j) {
-                uint32_t bucket, neg;
-                if (it.next(j, bucket, neg)) atomicAdd(&cnt[bucket >> MSM_FINE_LOG], 1u);
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                if (j < g.W) {
+                    uint32_t bucket, neg;
+                    if (it.next(j, bucket, neg)) {
+                        const uint32_t B = bucket >> MSM_FINE_LOG;
+                        key[j] = (B << 20) | atomicAdd(&cnt[B], 1u);
+                        ent[j] = ((uint32_t)j * n + i) | ((bucket & (MSM_FINE - 1u)) << 24) | (neg << 31);
+                    }
+                }
             }
         }
         __syncthreads();
         msm_small_scan(cnt, off, fill, nbins, total, wsum);
         __syncthreads();
-        if (ones) {  // unit scalars: window 0, bucket 0, positive
-            uint32_t first = 0;
-            if ((int)(tid & 63u) == leader) first = atomicAdd(&fill[0], (uint32_t)__popcll(ones));
-            first = __shfl(first, leader, 64);
-            if (cls == 1) stage[off[0] + first + (uint32_t)__popcll(ones & ((1ull << (tid & 63u)) - 1ull))] = i;
-        }
+        if (cls == 1) stage[off[0] + unit_rank] = i;
         if (cls == 2) {
-            MsmDigitIter it(sw, g.c);
-            for (int j = 0; j < g.W; ++j) {
-                uint32_t bucket, neg;
-                if (it.next(j, bucket, neg)) {
-                    const uint32_t B = bucket >> MSM_FINE_LOG;
-                    stage[off[B] + atomicAdd(&fill[B], 1u)] = ((uint32_t)j * n + i) | ((bucket & (MSM_FINE - 1u)) << 24) | (neg << 31);
-                }
-            }
+#pragma unroll
+            for (int j = 0; j < 32; ++j)
+                if (key[j] != 0xffffffffu) stage[off[key[j] >> 20] + (key[j] & 0xfffffu)] = ent[j];
         }
         __syncthreads();
         const uint32_t tot = *total;
