@@ -164,8 +164,9 @@ k_msm_bucket_heavy(const Xyzz<O>* __restrict__ part, const uint32_t* __restrict_
 // with a batch of proofs in flight the chip is throughput-bound here, so work counts, not just depth.
 // G = 2^G_LOG is chosen by the host: 16 for batches (least work per bucket: ~2.9 additions), 4 for a lone proof
 // (shortest dependent chain).
+// (the G1 kernels of a batch are held to 256 registers = two waves per SIMD: 219 spilled, launch 3.8 -> 3.05 ms for h + l)
 template <class O, uint32_t G_LOG>
-__global__ void __launch_bounds__(128, MASP_TAIL_MIN_WAVES) k_msm_wsum_level(const Xyzz<O>* __restrict__ B, size_t b_stride, uint32_t m, uint32_t off,
+__global__ void __launch_bounds__(128, (sizeof(Xyzz<O>) > 200 || G_LOG < 3 ? MASP_TAIL_MIN_WAVES : 2)) k_msm_wsum_level(const Xyzz<O>* __restrict__ B, size_t b_stride, uint32_t m, uint32_t off,
                                                         Xyzz<O>* __restrict__ S, Xyzz<O>* __restrict__ T, size_t st_stride) {
     constexpr uint32_t G = 1u << G_LOG, CS = G * WSUM_L;
     __shared__ Xyzz<O> sh[2];
