@@ -296,7 +296,7 @@ k_msm_bucketize(const uint32_t* __restrict__ tmp, size_t ent_stride, const uint3
     for (uint32_t base = lo; base < hi; base += MSM_BKT_TILE) {
         if (tid < MSM_FINE) cnt[tid] = 0;
         __syncthreads();
-        uint32_t e[MSM_BKT_TILE / 1024];
+        uint32_t e[MSM_BKT_TILE / 1024], rank[MSM_BKT_TILE / 1024];  // the counting atomic hands out the rank inside the bucket
 #pragma unroll
         for (uint32_t q = 0; q < MSM_BKT_TILE / 1024; ++q) {
             const uint32_t k = base + q * 1024 + tid;
@@ -305,11 +305,15 @@ k_msm_bucketize(const uint32_t* __restrict__ tmp, size_t ent_stride, const uint3
             const bool valid = k < hi;
             const uint32_t f = (e[q] >> 24) & (MSM_FINE - 1u);
             const uint64_t same = __ballot(valid && f == 0);
-            if (valid && f == 0) {
-                if ((uint32_t)__ffsll((unsigned long long)same) - 1u == (tid & 63u)) atomicAdd(&cnt[0], (uint32_t)__popcll(same));
-            } else if (valid) {
-                atomicAdd(&cnt[f], 1u);
+            rank[q] = 0;
+            if (same) {
+                const int leader = __ffsll((unsigned long long)same) - 1;
+                uint32_t first = 0;
+                if ((int)(tid & 63u) == leader) first = atomicAdd(&cnt[0], (uint32_t)__popcll(same));
+                first = __shfl(first, leader, 64);
+                if (valid && f == 0) rank[q] = first + (uint32_t)__popcll(same & ((1ull << (tid & 63u)) - 1ull));
             }
+            if (valid && f != 0) rank[q] = atomicAdd(&cnt[f], 1u);
         }
         __syncthreads();
         msm_small_scan(cnt, off, fill, MSM_FINE, total, wsum);
@@ -317,19 +321,7 @@ k_msm_bucketize(const uint32_t* __restrict__ tmp, size_t ent_stride, const uint3
 #pragma unroll
         for (uint32_t q = 0; q < MSM_BKT_TILE / 1024; ++q) {
             const uint32_t k = base + q * 1024 + tid;
-            const bool valid = k < hi;
-            const uint32_t f = (e[q] >> 24) & (MSM_FINE - 1u);
-            const uint32_t out = e[q] & 0x80ffffffu;
-            const uint64_t same = __ballot(valid && f == 0);
-            if (valid && f == 0) {
-                const int leader = __ffsll((unsigned long long)same) - 1;
-                uint32_t first = 0;
-                if ((int)(tid & 63u) == leader) first = atomicAdd(&fill[0], (uint32_t)__popcll(same));
-                first = __shfl(first, leader, 64);
-                stage[off[0] + first + (uint32_t)__popcll(same & ((1ull << (tid & 63u)) - 1ull))] = out;
-            } else if (valid) {
-                stage[off[f] + atomicAdd(&fill[f], 1u)] = out;
-            }
+            if (k < hi) stage[off[(e[q] >> 24) & (MSM_FINE - 1u)] + rank[q]] = e[q] & 0x80ffffffu;
         }
         __syncthreads();
         const uint32_t tot = *total;
