@@ -69,3 +69,22 @@ def test_gpu_reproduces_the_golden_proofs(name):
         assert got[:9] == [want] * 9 and got[9] != want
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c_lone", ["0", "6", "11"])
+def test_gpu_lone_proof_whatever_windows_its_g2_tables_use(c_lone, monkeypatch):
+    """A lone proof runs B2 on its own narrow-window tables (MASP_HIP_MSM_C_B2_LONE, default 8: covered by the test above).
+    Without them (0: the batch tables and B1's digit sort, as in round 1) and on other widths (6: fewer than 128 buckets, the
+    single-pass sort; 11) the bytes are the same."""
+    import masp_amd
+    cs, inputs, aux, toxic, r, s, want = _instance("spend")
+    monkeypatch.setenv("MASP_HIP_MSM_C_B2_LONE", c_lone)       # read when a circuit is loaded
+    ctx = masp_amd.Context(0)
+    try:
+        ctx.load_circuit(0, ctx.generate_parameters(cs, toxic), cs)
+        assert ctx.prove(0, inputs, aux, r, s) == want
+        got = ctx.prove_batch([(0, inputs, aux, r, s)] * 3)      # np = 3: lone-proof mode with gridDim.y = 3
+        assert got == [want] * 3
+    finally:
+        ctx.close()
