@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "../launch.h"
 #include "fr_io.cuh"
 
 namespace masp {
@@ -24,11 +25,16 @@ __global__ void k_fr_to_mont(const Fr* __restrict__ x, size_t x_stride, Fr* __re
 // a = input value, b = c = 0 (which == 0 selects matrix A).
 // Row lengths of the MASP circuits range from 1 to several hundred terms (bit packings): `order` lists the constraint
 // rows by decreasing length, so the 64 rows of a wave take about equally long.
-__global__ void k_r1cs_eval(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ order, const uint32_t* __restrict__ col,
-                            const Fr* __restrict__ coef, const Fr* __restrict__ w, uint32_t n_vars, uint32_t n_constraints, uint32_t n_inputs,
-                            int which, Fr* __restrict__ out) {
+// The three matrices in ONE launch: blockIdx.z selects A, B or C (R1csMatrices: launch.h).
+__global__ void k_r1cs_eval(R1csMatrices M, const Fr* __restrict__ w, uint32_t n_vars, uint32_t n_constraints, uint32_t n_inputs) {
     uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_constraints + n_inputs) return;
+    const int which = blockIdx.z;
+    const uint32_t* __restrict__ rowptr = M.rowptr[which];
+    const uint32_t* __restrict__ order = M.order[which];
+    const uint32_t* __restrict__ col = M.col[which];
+    const Fr* __restrict__ coef = M.coef[which];
+    Fr* __restrict__ out = M.out[which];
     w += (size_t)blockIdx.y * n_vars;
     out += (size_t)blockIdx.y * (n_constraints + n_inputs);
     Fr acc = fe_zero<FrCfg>();

@@ -21,8 +21,14 @@ void launch_fr_scale_sub(hipStream_t s, const Fr* x, const Fr* scale, const Fr* 
 void launch_fr_scale(hipStream_t s, const Fr* x, const Fr* scale, Fr* y, uint32_t n, uint32_t np, size_t y_stride = 0);
 void launch_fr_from_mont(hipStream_t s, const Fr* x, Fr* y, uint32_t n);
 void launch_fr_to_mont(hipStream_t s, const Fr* x, size_t x_stride, Fr* y, uint32_t n, uint32_t np, int* range_err);
-void launch_r1cs_eval(hipStream_t s, const uint32_t* rowptr, const uint32_t* order, const uint32_t* col, const Fr* coef, const Fr* w, uint32_t n_vars,
-                      uint32_t n_constraints, uint32_t n_inputs, int which, Fr* out, uint32_t np);
+struct R1csMatrices {  // the static R1CS of a circuit (CSR, rows by decreasing length) and where a, b, c go
+    const uint32_t* rowptr[3];
+    const uint32_t* order[3];
+    const uint32_t* col[3];
+    const Fr* coef[3];
+    Fr* out[3];
+};
+void launch_r1cs_eval(hipStream_t s, const R1csMatrices& M, const Fr* w, uint32_t n_vars, uint32_t n_constraints, uint32_t n_inputs, uint32_t np);
 void launch_gather_scalars(hipStream_t s, const Fr* src, size_t src_stride, const uint32_t* idx, uint32_t n, Fr* dst, uint32_t np);
 
 // ---- k_groth16.hip: proof assembly, point import / export, fixed-base tables (device/groth16.cuh) ----

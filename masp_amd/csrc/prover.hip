@@ -189,11 +189,17 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
         in[2] = d_abc[2];
         mont_in = false;
     } else {
+        R1csMatrices M;
         for (int i = 0; i < 3; ++i) {
             if ((rc = sl.ev[i].reserve((size_t)C.nrows * np))) return rc;
-            launch_r1cs_eval(s, C.rowptr[i].p, C.row_order[i].p, C.col[i].p, C.coef[i].p, sl.wm.p, nv, C.n_constraints, C.n_inputs, i, sl.ev[i].p, np);
+            M.rowptr[i] = C.rowptr[i].p;
+            M.order[i] = C.row_order[i].p;
+            M.col[i] = C.col[i].p;
+            M.coef[i] = C.coef[i].p;
+            M.out[i] = sl.ev[i].p;
             in[i] = sl.ev[i].p;
         }
+        launch_r1cs_eval(s, M, sl.wm.p, nv, C.n_constraints, C.n_inputs, np);  // a, b, c = A w, B w, C w in one launch
         mont_in = true;
     }
     if ((rc = sl.sa.reserve((size_t)C.na * np)) || (rc = sl.sb.reserve((size_t)C.nbq * np))) return rc;
