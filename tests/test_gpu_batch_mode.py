@@ -125,6 +125,20 @@ def test_256_distinct_spends_as_one_launch_sequence(rig):
     assert proofs == rig.ctx.prove_batch(jobs)
 
 
+def test_lone_and_batch_mode_meet_at_eight_proofs(rig):
+    """np < 8 runs in lone-proof mode (MSMs side by side on their own streams, h and l apart, B2 on its narrow windows, the
+    assembly's pieces spread over the streams), np >= 8 as a batch: 9 distinct Spends as one call of 9, as 8 + 1 and as 7 + 2
+    give the same bytes, all equal to the closed form."""
+    from masp_amd import workload as W
+    insts = W.instances("spend", 9, first_seed=7000)
+    rs = _rs(random.Random(7), 9)
+    jobs = [(0, i, a, r, s) for (i, a), (r, s) in zip(insts, rs)]
+    nine = rig.ctx.prove_batch(jobs)
+    _check(rig, ["spend"] * 9, insts, rs, nine, n_cpu=1)
+    assert rig.ctx.prove_batch(jobs[:8]) + rig.ctx.prove_batch(jobs[8:]) == nine
+    assert rig.ctx.prove_batch(jobs[:7]) + rig.ctx.prove_batch(jobs[7:]) == nine
+
+
 @pytest.mark.parametrize("kind", ["output", "convert"])
 def test_64_distinct_proofs_of_the_smaller_circuits(rig, kind):
     from masp_amd import workload as W
