@@ -249,7 +249,7 @@ int msm_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, MsmWorkspace<O>& ws,
                 Xyzz<O>* d_out, size_t out_stride, uint32_t np, MsmProfile* prof = nullptr) {
     if (np == 0) return MASP_HIP_OK;
     if (B.n == 0) {
-        for (uint32_t p = 0; p < np; ++p) HIP_TRY(hipMemsetAsync(d_out + p * out_stride, 0, sizeof(Xyzz<O>), s));  // infinity (ZZ = 0)
+        HIP_TRY(hipMemset2DAsync(d_out, out_stride * sizeof(Xyzz<O>), 0, sizeof(Xyzz<O>), np, s));  // infinity (ZZ = 0) for every proof
         return MASP_HIP_OK;
     }
     int rc = msm_sort_enqueue(s, B.n, B.g, ws.sort, d_scalars, scalar_stride, np);

@@ -266,7 +266,8 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
         if (C.na) launch_gather_scalars(s, d_w, w_stride, C.a_var.p, C.na, sl.sa.p, np);
         if (C.nbq) launch_gather_scalars(s, d_w, w_stride, C.b_var.p, C.nbq, sl.sb.p, np);
         if ((rc = msm_enqueue(s, C.hl, sl.ws1, (const uint32_t*)sl.hl.p, hl_stride * 8, sl.res1.p + 0, 4, np, prof))) return rc;
-        for (uint32_t p = 0; p < np; ++p) HIP_TRY(hipMemsetAsync(sl.res1.p + 4 * p + 1, 0, sizeof(G1Xyzz), s));  // L is inside H + L
+        // L is inside H + L: its slot of every proof is the point at infinity (one strided fill, not np of them)
+        HIP_TRY(hipMemset2DAsync(sl.res1.p + 1, 4 * sizeof(G1Xyzz), 0, sizeof(G1Xyzz), np, s));
         if ((rc = msm_enqueue(s, C.a, sl.ws1, (const uint32_t*)sl.sa.p, (size_t)C.na * 8, sl.res1.p + 2, 4, np, prof))) return rc;
         if ((rc = msm_enqueue(s, C.b1, sl.ws1, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res1.p + 3, 4, np, prof))) return rc;
         if (share_b) {
