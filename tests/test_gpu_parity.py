@@ -103,6 +103,29 @@ def test_msm_g1_all_equal_and_cancelling(ctx):
     assert ctx.msm_g1(b2, s2) == b"\x40" + bytes(95) == O.msm_g1(b2, s2)
 
 
+def test_msm_g2_repeated_and_cancelling_points(ctx):
+    """The exceptional cases of the G2 group law (one out-of-line call each since round 2: equal points -> doubling, opposite
+    points -> infinity) in the accumulation (mixed addition of a repeated table row) and in the bucket tails (full addition
+    of equal partial sums): the same point 600 times with one scalar, with different scalars, and P / -P pairs."""
+    rng = random.Random(78)
+    n = 600
+    one = O.g2_mul_gen_many(_rand_scalars(rng, 1))
+    same = np.tile(one, (n, 1))
+    for sc in (np.tile(_le(0x1234567), (n, 1)), _rand_scalars(rng, n), _edge_scalars(n, rng)):
+        assert ctx.msm_g2(same, sc) == O.msm_g2(same, sc)
+    half = n // 2
+    ks = _rand_scalars(rng, half)
+    kneg = np.stack([_le(R - int.from_bytes(k.tobytes(), "little")) for k in ks])
+    pm = O.g2_mul_gen_many(np.concatenate([ks, kneg]))
+    s3 = np.tile(_le(3), (n, 1))
+    assert ctx.msm_g2(pm, s3) == b"\x40" + bytes(191) == O.msm_g2(pm, s3)
+    # two copies of each point with the same random scalar: every bucket entry meets its twin
+    twice = np.concatenate([pm[:half], pm[:half]])
+    sc2 = _rand_scalars(rng, half)
+    sc2 = np.concatenate([sc2, sc2])
+    assert ctx.msm_g2(twice, sc2) == O.msm_g2(twice, sc2)
+
+
 @pytest.mark.parametrize("n", [1, 33, 700, 9000])
 def test_msm_g2_matches_oracle(ctx, n):
     rng = random.Random(n + 100)
