@@ -135,7 +135,7 @@ struct Slot {
     hipStream_t aux[N_AUX] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_sort_b = nullptr, ev_fixed = nullptr, ev_join[N_AUX] = {nullptr, nullptr, nullptr, nullptr};
     MsmWorkspace<FpOps> ws_l, ws_a, ws_b;
-    DevBuf<Fr> w, abc, wm, ev[3], x0, x1, h, hl, sa, sb;
+    DevBuf<Fr> w, inp, abc, wm, ev[3], x0, x1, h, hl, sa, sb;
     DevBuf<G1Xyzz> res1, asm1;  // asm1: the six G1 pieces of the assembly per proof, asm2: s*delta2
     DevBuf<G2Xyzz> res2, asm2;
     DevBuf<uint32_t> rs;

@@ -674,8 +674,9 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
         const bool has_abc = jobs[G.idx[0]].a != nullptr;
         // staging layout: [np][nv] witness | (a | b | c each [np][nrows]) | [np][16] r,s limbs
         const size_t w_bytes = 32 * nv * np, abc_bytes = has_abc ? 3 * 32 * (size_t)C.nrows * np : 0, rs_bytes = 64 * np;
+        const size_t in_bytes = 32 * (size_t)C.n_inputs * np;  // the public inputs once more, packed (see below)
         bool ok = true;
-        if ((rc = sl.stage_reserve(w_bytes + abc_bytes + rs_bytes)) || (rc = sl.w.reserve(nv * np)) ||
+        if ((rc = sl.stage_reserve(w_bytes + abc_bytes + rs_bytes + in_bytes)) || (rc = sl.w.reserve(nv * np)) || (rc = sl.inp.reserve((size_t)C.n_inputs * np)) ||
             (rc = sl.abc.reserve(has_abc ? 3 * (size_t)C.nrows * np : 1)) || (rc = sl.reserve_batch(np))) {
             result = fail_shared(ctx, rc);
             ok = false;
@@ -694,6 +695,7 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
             for (size_t p = 0; p < np; ++p) {
                 const masp_hip_job& J = jobs[G.idx[p]];
                 memcpy(hs + 32 * nv * p, J.inputs, 32 * (size_t)C.n_inputs);
+                memcpy(hs + w_bytes + abc_bytes + rs_bytes + 32 * (size_t)C.n_inputs * p, J.inputs, 32 * (size_t)C.n_inputs);
                 if (!direct[p]) memcpy(hs + 32 * nv * p + 32 * (size_t)C.n_inputs, J.aux, 32 * (size_t)C.n_aux);
                 if (has_abc) {
                     const uint8_t* src[3] = {J.a, J.b, J.c};
@@ -706,8 +708,11 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
             if (any_staged) {
                 ok = hipMemcpyAsync(sl.w.p, hs, w_bytes, hipMemcpyHostToDevice, s) == hipSuccess;
             } else {
-                for (size_t p = 0; p < np && ok; ++p)  // only the public inputs of each proof come from staging
-                    ok = hipMemcpyAsync(sl.w.p + nv * p, hs + 32 * nv * p, 32 * (size_t)C.n_inputs, hipMemcpyHostToDevice, s) == hipSuccess;
+                // only the public inputs of each proof come from staging: ONE packed copy to the device and a strided copy on the
+                // device instead of np small host-to-device copies (a strided host-to-device copy is the runtime's slow path)
+                ok = hipMemcpyAsync(sl.inp.p, hs + w_bytes + abc_bytes + rs_bytes, in_bytes, hipMemcpyHostToDevice, s) == hipSuccess &&
+                     hipMemcpy2DAsync(sl.w.p, 32 * nv, sl.inp.p, 32 * (size_t)C.n_inputs, 32 * (size_t)C.n_inputs, np, hipMemcpyDeviceToDevice, s) ==
+                         hipSuccess;
             }
             for (size_t p = 0; p < np && ok; ++p)
                 if (direct[p])
