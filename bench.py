@@ -11,9 +11,13 @@ witnesses with fresh blinding scalars (r, s), so every timed proof is different.
 selects the other workloads (mixed = configs[4]'s job mix: 512 jobs per GPU and step, job j of circuit j mod 3).
 
 Two timed regions, K steps each, bracketed by barrier + device synchronisation, max over ranks:
-  `value`         witnesses resident in HBM -> proofs on the host of rank 0 (RCCL gather of N*K*256*192 bytes inside the region)
-  `host_to_host`  witnesses in page-locked HOST memory -> proofs on the host, through masp_hip_prove_batch (BASELINE.md §4's
-                  region: H2D of 3.2 MB per Spend included)
+  `value`     BASELINE.md §4's region: witnesses in page-locked HOST memory -> proofs on the host of rank 0, through
+              masp_hip_prove_batch (H2D of 3.2 MB per Spend, D2H of the proofs and the RCCL gather of N*K*256*192 bytes inside)
+  `resident`  witnesses already resident in HBM -> proofs on the host (what rounds 1-2 reported as `value`; 2 % faster)
+plus `end_to_end`: LocalTxProver.prove_batch over 1 024 Spend descriptions per GPU — witness synthesis on the host cores, H2D,
+proving and the GPU batch self-verification (not part of `value`: the metric starts from witnesses).
+The library reads no environment; this script translates MASP_HIP_SLOTS / MASP_HIP_BATCH / MASP_HIP_NTT_SUB /
+MASP_HIP_MSM_C_{H,LA,B,B2_LONE} into masp_hip_options (A/B runs of the tools).
 After timing, EVERY timed proof is checked with the product's Groth16 batch verifier (pairing equation; no oracle involved)
 and a sample is compared byte for byte with the oracle's toxic-waste closed form; the line carries `verified`.
 Ranks shard the proofs with no data-path collective (weak scaling).  Prints ONE JSON line on rank 0.
@@ -38,6 +42,16 @@ WORKLOAD = os.environ.get("MASP_BENCH_CIRCUIT", "spend")
 KINDS = ("spend", "output", "convert")
 R = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
 PROOFS_PER_STEP = {"spend": 256, "output": 256, "convert": 256, "mixed": 512}   # configs[3]; configs[4] = 4096 / 8 GPUs
+
+
+ENV_OPTIONS = {"MASP_HIP_SLOTS": "slots", "MASP_HIP_BATCH": "batch_cap", "MASP_HIP_NTT_SUB": "ntt_sub_batch", "MASP_HIP_MSM_C_H": "window_bits_h",
+               "MASP_HIP_MSM_C_LA": "window_bits_la", "MASP_HIP_MSM_C_B": "window_bits_b", "MASP_HIP_MSM_C_B2_LONE": "window_bits_b2_lone",
+               "MASP_HIP_WITNESS_NONTRIVIAL_PERCENT": "witness_nontrivial_percent"}
+
+
+def options_from_env(env=os.environ):
+    """masp_hip_options fields from the MASP_HIP_* variables of bench.py / tools (the library itself reads none)."""
+    return {field: int(env[name]) for name, field in ENV_OPTIONS.items() if env.get(name, "") != ""}
 
 
 def relaunch_under_torchrun(args):
@@ -95,8 +109,6 @@ def main():
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but the launcher started %d rank(s): refusing to report a figure for a different GPU count" % (args.gpus, world))
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # let independent batches' kernels overlap (ROCm default: 4)
-    os.environ.setdefault("MASP_HIP_SLOTS", "4")
-    os.environ.setdefault("MASP_HIP_BATCH", "256")
     dist = dev = None
     backend = os.environ.get("MASP_BENCH_BACKEND", "nccl")      # "nccl" = RCCL on ROCm; "gloo" only for the CPU dry run
     if world > 1 or os.environ.get("MASP_BENCH_FORCE_DIST"):
@@ -144,18 +156,25 @@ def main():
     from masp_amd import synthetic
     from masp_amd import workload as W
 
-    ctx = masp_amd.Context(local_rank)
+    ctx = masp_amd.Context(local_rank, **options_from_env())
+    SLOTS, BATCH = ctx.options["slots"], ctx.options["batch_cap"]
     threads = max(1, H.effective_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
     kinds = list(KINDS) if WORKLOAD == "mixed" else [WORKLOAD]
     n = PROOFS_PER_STEP[WORKLOAD]
     K, Wm = args.steps, args.warmup
     # ---- circuits: the real MASP R1CS (structure hashes pinned to the reference's KATs) + CRS from known toxic waste, same on every rank
+    # (N ranks: rank 0 generates each CRS, the others receive the same bytes over the process group instead of running the
+    # set-up kernels eight times side by side)
     cs, params, vk = {}, {}, {}
+    t_setup = time.perf_counter()
     for kind in kinds:
         cs[kind] = H.circuit(kind)[0]
-        params[kind] = ctx.generate_parameters(cs[kind], synthetic.toxic_waste(1 + KINDS.index(kind)))
+        mine = ctx.generate_parameters(cs[kind], synthetic.toxic_waste(1 + KINDS.index(kind))) if rank == 0 else None
+        params[kind] = D.broadcast_bytes(mine, dist, dev)
         ctx.load_circuit(KINDS.index(kind), params[kind], cs[kind])
         vk[kind] = ctx.prepare_verifying_key(params[kind])      # Groth16 batch verifier, Miller loops on the GPU (product code)
+    setup_s = time.perf_counter() - t_setup
+    sys.stderr.write("bench.py: rank %d: CRS %s + window tables in %.1f s\n" % (rank, "generated" if rank == 0 else "received", setup_s))
     # ---- n distinct instances per rank, synthesised on the host cores before anything is timed, aux written to page-locked memory
     W.instances(kinds[0], 2, first_seed=10 ** 6, threads=2)          # one-time table construction of the synthesizer
     syn = {}
@@ -181,13 +200,18 @@ def main():
     rs_warm, rs_a, rs_b = fresh_rs(max(Wm, 1)), fresh_rs(K), fresh_rs(K)
     handle, _ = ctx.batch_upload(jobs_with(rs_a[0]))
     # set-up, not warm-up: every slot's workspace (hipMalloc on first use) gets its final size — enough steps to reach every slot
-    groups_per_step = sum(-(-job_kind.count(k) // int(os.environ["MASP_HIP_BATCH"])) for k in kinds)
-    sizing_steps = max(2, -(-int(os.environ["MASP_HIP_SLOTS"]) // groups_per_step))
+    groups_per_step = sum(-(-job_kind.count(k) // BATCH) for k in kinds)
+    sizing_steps = max(2, -(-SLOTS // groups_per_step))
     ctx.batch_prove_resident_steps(handle, n, sizing_steps, fresh_rs(sizing_steps))
     if Wm > 0:
         ctx.batch_prove_resident_steps(handle, n, Wm, rs_warm)
     marshalled = [ctx.marshal_jobs(jobs_with(rs_b[k])) for k in range(K)]
-    ctx.prove_marshalled(*ctx.marshal_jobs(jobs_with(rs_warm[0]))[:2])     # the host path's staging buffers get their size
+    h2h_calls = int(os.environ.get("MASP_BENCH_H2H_CALLS", SLOTS))
+    # the W warm-up steps of the region `value` is measured on: the same call pattern (h2h_calls masp_hip_prove_batch calls in
+    # flight), which also gives the host path's staging buffers their size
+    warm_b = [ctx.marshal_jobs(jobs_with(rs_warm[k])) for k in range(max(Wm, 1))]
+    with ThreadPoolExecutor(h2h_calls) as ex:
+        list(ex.map(lambda k: ctx.prove_marshalled(warm_b[k][0], n), range(len(warm_b))))
     # single-proof latency (not the headline value)
     one, _ = ctx.batch_upload(jobs_with(rs_warm[0])[:1])
     ctx.batch_prove_resident(one, 1)              # sizes the lone-proof workspace
@@ -206,7 +230,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # ---- region A (`value`): witnesses resident in HBM -> K steps -> proofs gathered on rank 0
+    # ---- region A (`resident`): witnesses resident in HBM -> K steps -> proofs gathered on rank 0
     ctx.profile_enable(True)
     barrier()
     t0 = time.perf_counter()
@@ -218,7 +242,7 @@ def main():
     # The same launches with ONE batch in flight (one launch sequence of the first circuit's jobs, nothing else on the chip):
     # with four batches in flight the HIP events around a launch also span the time it waits for the chip behind other
     # streams' kernels, which is not kernel time (rocprofv3's begin / end of the same launches agree with THIS figure).
-    first = [j for j in range(n) if job_kind[j] == kinds[0]][:int(os.environ["MASP_HIP_BATCH"])]
+    first = [j for j in range(n) if job_kind[j] == kinds[0]][:BATCH]
     excl, n_excl = ctx.batch_upload([jobs_with(rs_warm[0])[j] for j in first])
     ctx.sync()
     ctx.batch_prove_resident(excl, n_excl)
@@ -226,20 +250,21 @@ def main():
     x_ms, x_launches, x_bytes = x_ms - acc_ms, x_launches - launches, x_bytes - alg_bytes
     ctx.batch_free(excl)
     ctx.profile_enable(False)
-    # ---- region B: witnesses in page-locked host memory -> K masp_hip_prove_batch calls (one per slot in flight) -> proofs on the host
+    # ---- region B (`value`): witnesses in page-locked host memory -> K masp_hip_prove_batch calls (one per slot
+    # in flight) -> proofs on the host of rank 0 (H2D, D2H and the RCCL gather inside)
     out_b = np.zeros((K, n, 192), np.uint8)
     barrier()
     t0 = time.perf_counter()
-    h2h_calls = int(os.environ.get("MASP_BENCH_H2H_CALLS", os.environ["MASP_HIP_SLOTS"]))
     with ThreadPoolExecutor(h2h_calls) as ex:
-        list(ex.map(lambda k: ctx.prove_marshalled(marshalled[k][0], n, out_b[k]), range(K)))
+        list(ex.map(lambda k: ctx.prove_marshalled(marshalled[k][0], n, out_b[k]), range(K)))          # exactly K steps
+    gathered_b = D.gather_proofs(out_b.reshape(K * n, 192), K * n * world, dist, dev) if dist is not None else out_b.reshape(K * n, 192)
     barrier()
     elapsed_b = time.perf_counter() - t0
     if dist is not None:
         elapsed = D.max_over_ranks(elapsed, dist, dev)
         elapsed_b = D.max_over_ranks(elapsed_b, dist, dev)
         if rank == 0:
-            assert len(gathered) == K * n * world
+            assert len(gathered) == K * n * world and len(gathered_b) == K * n * world
     # ---- verification of what was timed (product code: GPU + host Groth16 batch verifiers; plus oracle closed form on a sample)
     pub = [W.public_inputs(i) for i, _ in insts]
 
@@ -267,39 +292,75 @@ def main():
     if rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
-        for st, j in ((0, 0), (K - 1, n - 1), (K // 2, n // 2), (0, 1)):
+        for got_, rs_, st, j in ((out_b, rs_b, 0, 0), (out_b, rs_b, K - 1, n - 1), (proofs_a, rs_a, K // 2, n // 2), (proofs_a, rs_a, 0, 1)):
             kind = job_kind[j]
             want = O.closed_form_proof(cs[kind], synthetic.toxic_waste(1 + KINDS.index(kind)), insts[j][0], insts[j][1],
-                                       int.from_bytes(rs_a[st, j, :32].tobytes(), "little"), int.from_bytes(rs_a[st, j, 32:].tobytes(), "little"))
-            if proofs_a[st, j].tobytes() != want:
+                                       int.from_bytes(rs_[st, j, :32].tobytes(), "little"), int.from_bytes(rs_[st, j, 32:].tobytes(), "little"))
+            if got_[st, j].tobytes() != want:
                 sys.exit("bench.py: timed proof (step %d, job %d) differs from the oracle's closed form — no figure reported" % (st, j))
             closed_ok += 1
-    verified_total = int(D.sum_over_ranks(float(verified_a), dist, dev))      # every rank verified all of its own proofs
+    verified_total = int(D.sum_over_ranks(float(verified_b), dist, dev))      # every rank verified all of its own proofs (both regions)
+    # ---- end to end (not part of `value`): LocalTxProver.prove_batch over E2E_N Spend descriptions per GPU — synthesis on this
+    # rank's share of the host cores, page-locked buffers, H2D, GPU batches, GPU batch self-verification (sapling/prover.rs:148)
+    e2e = None
+    base_instance = (per[kinds[0]][0][0].copy(), per[kinds[0]][0][1].copy())      # (the aux buffers are page-locked memory of `ctx`: gone once it closes)
+    e2e_n = int(os.environ.get("MASP_BENCH_E2E", "1024"))
+    if WORKLOAD == "spend" and e2e_n > 0:
+        for k_ in vk.values():
+            k_.close()
+        vk = {}
+        other = [ctx.generate_parameters(H.circuit(k)[0], synthetic.toxic_waste(1 + KINDS.index(k))) for k in ("output", "convert")]
+        ctx.close()                                # the end-to-end prover owns its own context (LocalTxProver::from_bytes)
+        ctx = None
+        from masp_amd.prover import LocalTxProver
+        t_e = time.perf_counter()
+        prover = LocalTxProver(params["spend"], other[0], other[1], device=local_rank, expected=None, options=options_from_env())
+        e2e_setup = time.perf_counter() - t_e
+        with ThreadPoolExecutor(threads) as ex:
+            descs = list(ex.map(lambda i: W.description("spend", 5 * 10 ** 6 + 10 ** 5 * rank + i), range(e2e_n)))
+        prover.prove_batch(prover.new_sapling_proving_context(), descs[:min(e2e_n, 2 * BATCH)], threads=threads)    # page-locks its buffer pool
+        if dist is not None:
+            dist.barrier()
+        t_e = time.perf_counter()
+        res = prover.prove_batch(prover.new_sapling_proving_context(), descs, threads=threads)
+        e2e_s = time.perf_counter() - t_e
+        assert len(res) == e2e_n and len(set(r[0] for r in res)) == e2e_n
+        prover.close()
+        e2e_s = D.max_over_ranks(e2e_s, dist, dev)
+        e2e = {"value": e2e_n * world / e2e_s, "unit": "proofs/s", "descriptions_per_gpu": e2e_n, "seconds": round(e2e_s, 3), "threads_per_gpu": threads,
+               "load_seconds": round(e2e_setup, 2),
+               "region": "LocalTxProver.prove_batch: Spend descriptions -> witness synthesis (libmasp_host, %d threads) -> page-locked host memory -> "
+                         "GPU batches -> GPU batch self-verification -> (zkproof, cv, rk); includes the ramp of the first synthesis chunk and the "
+                         "last verification" % threads}
     if rank == 0:
         total = K * n * world
         achieved = x_bytes / (x_ms * 1e-3) / 1e9 if x_ms > 0 else 0.0
-        traffic = None
+        # HBM bytes per launch of the same kernel: NOT measured by this run (PMC counters need rocprofv3 passes of their own) —
+        # read from the builder's tracked rocprofv3 result and labelled as such
+        traffic = traffic_source = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                doc = json.load(open(pmc))
+                traffic = doc.get("hbm_bytes_per_launch")
+                traffic_source = "profiles/pmc_traffic.json (builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this bench, %s; not " \
+                                 "measured by this run)" % doc.get("date", "round 2")
             except Exception:
-                traffic = None
+                traffic = traffic_source = None
         c0 = cs[kinds[0]]
         sh = synthetic.SHAPES[kinds[0]]
         config_name = {"spend": "BASELINE.json configs[3]: batch of 256 distinct Spend proofs per step on one MI355X (throughput mode)",
                        "mixed": "BASELINE.json configs[4]'s job mix: 512 jobs per GPU and step, job j of circuit j mod 3 (Spend / Output / Convert)"}.get(
                            WORKLOAD, "batch of 256 distinct %s proofs per step" % WORKLOAD)
         out = {
-            "metric": "Spend proofs/sec" if WORKLOAD == "spend" else "%s proofs/sec" % WORKLOAD, "value": total / elapsed, "unit": "proofs/s",
-            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak",
+            "metric": "Spend proofs/sec" if WORKLOAD == "spend" else "%s proofs/sec" % WORKLOAD, "value": total / elapsed_b, "unit": "proofs/s",
+            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": elapsed_b * 1e3 / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": "%s; the real MASP circuit(s) (structure hashes pinned to the reference's KATs), %d distinct witnesses per GPU from the "
                                    "C++ synthesizer (instances shaped like masp_proofs/benches), fresh (r, s) every step; synthetic CRS from known toxic "
-                                   "waste (first circuit: NTT 2^%d, G1 MSMs %d/%d/%d/%d, G2 MSM %d); `value`: witnesses resident in HBM when the region "
-                                   "starts, launch sequences of <= %s proofs on %s HIP streams"
-                                   % (config_name, n, c0.logm, (1 << c0.logm) - 1, c0.n_aux, sh[3] + c0.n_inputs, sh[4] + 1, sh[4] + 1,
-                                      os.environ.get("MASP_HIP_BATCH"), os.environ.get("MASP_HIP_SLOTS")),
+                                   "waste (first circuit: NTT 2^%d, G1 MSMs %d/%d/%d/%d, G2 MSM %d); `value`: BASELINE.md §4's region, witnesses in "
+                                   "page-locked host memory -> proofs in host memory; launch sequences of <= %d proofs on %d HIP streams"
+                                   % (config_name, n, c0.logm, (1 << c0.logm) - 1, c0.n_aux, sh[3] + c0.n_inputs, sh[4] + 1, sh[4] + 1, BATCH, SLOTS),
                        "proofs_per_step": n, "distinct_witnesses_per_gpu": n, "proofs_per_gpu": K * n,
                        "arithmetic": "384-bit Fp / 255-bit Fr modular integers in 32-bit limbs (v_mad_u64_u32)",
                        "parallelism": "proofs sharded over %d GPU(s), no data-path collective, RCCL gather of the proofs" % world},
@@ -308,18 +369,19 @@ def main():
                                                         "loops on the GPU), 64 per circuit also through the host verifier; %d of rank 0 byte-equal to the oracle's "
                                                         "toxic-waste closed form" % closed_ok,
             "verify_seconds": round(verify_s, 2),
-            "host_to_host": {"value": total / elapsed_b, "unit": "proofs/s", "ms_per_step": elapsed_b * 1e3 / K,
-                             "region": "witnesses in page-locked host memory -> K masp_hip_prove_batch calls (%d in flight) -> proofs in host memory " % h2h_calls +
-                                       "(BASELINE.md §4; H2D of the assignments and D2H of the proofs inside)"},
-            "single_proof_latency_ms": latency_ms,
+            "value_region": "witnesses in page-locked host memory -> K masp_hip_prove_batch calls (%d in flight) -> proofs in host memory of rank 0 " % h2h_calls +
+                            "(BASELINE.md §4; H2D of the assignments, D2H of the proofs and the gather inside)",
+            "resident": {"value": total / elapsed, "unit": "proofs/s", "ms_per_step": elapsed * 1e3 / K, "gpu_event_ms_per_step": gpu_ms / K,
+                         "region": "witnesses already resident in HBM -> proofs in host memory of rank 0 (rounds 1-2 reported this as `value`)"},
+            "end_to_end": e2e,
+            "single_proof_latency_ms": latency_ms, "setup_seconds_rank0": round(setup_s, 2),
             # not part of `value`: libmasp_host on the host cores, before the timed regions
             "host_synthesis": {"ms_per_proof_one_thread": {k: round(statistics.median(v["synthesize_ms"]), 2) for k, v in syn.items()},
                                "instances_per_s_all_threads": round(n / synth_wall, 1), "threads": threads},
-            "ms_per_proof": elapsed * 1e3 / (K * n),
-            "gpu_event_ms_per_step": gpu_ms / K,
+            "ms_per_proof": elapsed_b * 1e3 / (K * n),
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate<G1> (bucket accumulation of the G1 MSMs: h+l merged, a, b_g1)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "launches": x_launches, "avg_launch_ms": x_ms / x_launches if x_launches else None,
+                         "traffic": traffic, "traffic_source": traffic_source, "launches": x_launches, "avg_launch_ms": x_ms / x_launches if x_launches else None,
                          "alg_bytes_per_launch": x_bytes / x_launches if x_launches else None,
                          "timed_region": {"launches": launches, "avg_span_ms": acc_ms / launches if launches else None,
                                           "alg_bytes_per_launch": alg_bytes / launches if launches else None},
@@ -332,12 +394,13 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             k0 = kinds[0]
-            out["cpu_baseline"] = cpu_baseline(cs[k0], params[k0], per[k0][0][0], per[k0][0][1])
+            out["cpu_baseline"] = cpu_baseline(cs[k0], params[k0], base_instance[0], base_instance[1])
     else:
         out = None
     for k_ in vk.values():
         k_.close()
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

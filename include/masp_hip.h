@@ -73,7 +73,32 @@ typedef struct {
     uint8_t r[32], s[32];      /* Groth16 blinding scalars (the reference draws them from OsRng) */
 } masp_hip_job;
 
+/* Number of HIP devices this process can see (0 if the runtime is unusable). */
+int masp_hip_device_count(void);
+
+/* Tuning of a prover, fixed when the context is created (masp_hip_ctx_create_ex).  Every field: 0 = the default.  The
+ * library reads NO environment variables; bench.py and the tools translate their MASP_HIP_* variables into this. */
+typedef struct {
+    uint32_t struct_size;            /* sizeof(masp_hip_options) of the caller's header (versioning) */
+    int32_t slots;                   /* batches in flight per device, each on its own HIP stream + scratch: 1..64 (default 4) */
+    int32_t batch_cap;               /* proofs per launch sequence: 1..256 (default 256 = BASELINE.json configs[3]) */
+    int32_t ntt_sub_batch;           /* proofs per sub-batch of the quotient's transforms (default 8: 160 MiB of work buffers
+                                        stay in the Infinity Cache); -1 = the whole batch at once */
+    int32_t window_bits_h;           /* window width of the h query (default: 16 from 49 152 points, 15 from 16 384) */
+    int32_t window_bits_la;          /* ... of the l and a queries (default: from the expected non-trivial scalars) */
+    int32_t window_bits_b;           /* ... of b_g1 / b_g2 */
+    int32_t window_bits_b2_lone;     /* ... of the second b_g2 table set used by lone proofs (default 8); -1 = not built */
+    int32_t witness_nontrivial_percent; /* share of a witness that is neither 0 nor 1, for window selection (default 30) */
+    int32_t reserved[7];
+} masp_hip_options;
+void masp_hip_options_default(masp_hip_options* opt);
+
 int masp_hip_ctx_create(int device, masp_hip_ctx** out);
+/* The general constructor: n_devices == 1 gives a single-device context, more give the multi-device front described
+ * below; opt == NULL means defaults. */
+int masp_hip_ctx_create_ex(const int* devices, int n_devices, const masp_hip_options* opt, masp_hip_ctx** out);
+/* the options a context runs with, defaults resolved (ntt_sub_batch / window_bits_b2_lone: 0 here means "whole batch" / "not built") */
+int masp_hip_ctx_get_options(const masp_hip_ctx* ctx, masp_hip_options* out);
 /* One prover over several GPUs of a node (SURVEY.md §8b "devices, n_dev"): the serial per-description loops of
  * SaplingBuilder::build (/root/reference/masp_primitives/src/transaction/components/sapling/builder.rs:935-1140) become one
  * masp_hip_prove_batch call whose jobs are dealt to the devices in full batches, one host thread per device inside

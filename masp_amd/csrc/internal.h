@@ -143,6 +143,7 @@ struct Slot {
     DevBuf<int> flags;
     MsmProfile prof;             // live HIP-event timing of k_msm_accumulate<G1> (bench roofline leg)
     bool profiling = false;
+    uint32_t ntt_sub = 8;        // masp_hip_options::ntt_sub_batch of the owning context (0 = whole batch)
     uint8_t* h_stage = nullptr;  // pinned staging for the assignment
     size_t h_stage_cap = 0;
     uint8_t* h_proof = nullptr;  // pinned, batch_cap x 192
@@ -229,8 +230,9 @@ struct masp_hip_ctx {
     int device = 0;
     // multi-device front (masp_hip_ctx_create_multi): one full context per device; this object only shards and forwards
     std::vector<masp_hip_ctx*> children;
-    int n_slots = 4;       // MASP_HIP_SLOTS, read once at creation
-    size_t batch_cap = 64; // MASP_HIP_BATCH, read once at creation
+    masp_hip_options opt{};   // resolved at creation (prover.hip: resolve_options); the library reads no environment
+    int n_slots = 4;          // = opt.slots
+    size_t batch_cap = 256;   // = opt.batch_cap
     std::shared_mutex mu;
     mutable std::mutex slot_mu;
     std::condition_variable slot_cv;

@@ -19,19 +19,16 @@ int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb
     sb.g = g;
     const uint32_t ng = MsmSortBuf::ranges_for(n, np), nb = g.nb;
     // two-pass placement (runs instead of single scattered words): the row index must leave room for the 7 low bucket bits
-    static const bool two_pass_enabled = [] {
-        const char* e = getenv("MASP_HIP_SORT");  // experiment knob, read once: "scatter" = the single-pass placement
-        return !(e && strcmp(e, "scatter") == 0);
-    }();
-    const bool two_pass = two_pass_enabled && nb >= MSM_FINE && (uint64_t)n * g.W <= (1u << 24);
+    const bool two_pass = nb >= MSM_FINE && (uint64_t)n * g.W <= (1u << 24);
     const int part_lds = 4 * (4 * 256 + 8 + (int)MSM_PART_TILE * g.W);
-    static bool lds_ok = [] {
+    static PerDeviceOnce once;
+    const bool lds_ok = once([] {
         int bytes = 4 << 15;
         return hipFuncSetAttribute((const void*)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
                hipFuncSetAttribute((const void*)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
                hipFuncSetAttribute((const void*)k_msm_partition, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (4 * 256 + 8 + (int)MSM_PART_TILE * 32)) ==
                    hipSuccess;
-    }();
+    });
     if (!lds_ok) {
         last_hip_error() = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
         return MASP_HIP_E_HIP;

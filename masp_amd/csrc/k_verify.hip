@@ -18,6 +18,7 @@ struct masp_hip_vk {
     DevBuf<uint32_t> ops, steps;  // the three programs, concatenated
     PairingProgramDev dbl{}, add{}, mul12{};
     uint32_t n_slots = 0;
+    bool lds_ok = false;  // the interpreter kernels' LDS limit was raised on THIS key's device (the attribute is per device)
     // work buffers, grown on demand and kept (hipFree would synchronise the device under the provers)
     DevBuf<uint8_t> d_proofs, d_z, d_sum;
     DevBuf<G1Affine> d_za;
@@ -69,6 +70,8 @@ int masp_hip_vk_prepare(masp_hip_ctx* ctx, const uint8_t* params, size_t params_
         dst[i]->n_steps = (uint32_t)ps[i]->step_start.size() - 1;
     }
     v->n_slots = pp.n_slots;
+    v->lds_ok = hipFuncSetAttribute((const void*)k_miller_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess &&
+                hipFuncSetAttribute((const void*)k_fp12_product, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess;
     if (hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking) != hipSuccess) return fail(ctx, MASP_HIP_E_HIP);
     *out = v.release();
     return MASP_HIP_OK;
@@ -109,11 +112,7 @@ int masp_hip_verify_batch(masp_hip_ctx* ctx, masp_hip_vk* vk, size_t n, const ui
     HIP_TRY(hipMemsetAsync(d_status.p, 0, sizeof(int) * n, s));
     // the interpreter keeps its slots in LDS: n_slots x 48 bytes per wave
     const uint32_t lds = vk->n_slots * 48;
-    static bool lds_ok = [] {
-        return hipFuncSetAttribute((const void*)k_miller_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess &&
-               hipFuncSetAttribute((const void*)k_fp12_product, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess;
-    }();
-    if (!lds_ok || lds > 64 * 1024) {
+    if (!vk->lds_ok || lds > 64 * 1024) {
         last_hip_error() = "pairing interpreter: LDS configuration failed";
         return fail_shared_v(ctx, MASP_HIP_E_HIP);
     }

@@ -33,11 +33,6 @@ struct MsmBases {
     // mixed additions, per bucket the gather + weighted sum cost ~5.5 full additions.
     static MsmGeom pick_geom(uint32_t n_eff) {
         int c = n_eff >= (1u << 16) ? 16 : n_eff >= (1u << 12) ? 12 : n_eff >= (1u << 8) ? 10 : 7;
-        static const int forced = [] {  // experiment knob, read once per process
-            const char* e = getenv("MASP_HIP_MSM_C");
-            return e ? atoi(e) : 0;
-        }();
-        if (forced) c = forced;
         return msm_geom(c);
     }
     // raw: device pointer to n uncompressed points (bellman wire format)          [msm_impl.cuh]
@@ -88,17 +83,24 @@ struct MsmSortBuf {
         const size_t rows = std::max<size_t>(need_np, 512);
         const size_t need_hist = std::max(std::max(hist_need, cap_hist), rows * need_nb);
         const size_t need_crel = std::max(std::max(crel_need, cap_crel), rows * std::max<size_t>(need_nb >> 7, 1));
-        release();
+        release();  // (capacities are 0 from here on: a failed allocation below must not leave them claiming memory)
+        auto alloc_all = [&]() -> int {
+            HIP_TRY(hipMalloc(&sorted, need_np * 4 * std::max<size_t>(need_ent, 1)));
+            HIP_TRY(hipMalloc(&hist_wg, 4 * need_hist));
+            HIP_TRY(hipMalloc(&start, need_np * 4 * (need_nb + 1)));
+            HIP_TRY(hipMalloc(&tmp, need_np * 4 * std::max<size_t>(need_ent, 1)));
+            HIP_TRY(hipMalloc(&crel, 4 * need_crel));
+            return MASP_HIP_OK;
+        };
+        if (int rc = alloc_all()) {
+            release();
+            return rc;
+        }
         cap_ent = need_ent;
         cap_nb = need_nb;
         cap_np = need_np;
         cap_hist = need_hist;
         cap_crel = need_crel;
-        HIP_TRY(hipMalloc(&sorted, cap_np * 4 * std::max<size_t>(cap_ent, 1)));
-        HIP_TRY(hipMalloc(&hist_wg, 4 * cap_hist));
-        HIP_TRY(hipMalloc(&start, cap_np * 4 * (cap_nb + 1)));
-        HIP_TRY(hipMalloc(&tmp, cap_np * 4 * std::max<size_t>(cap_ent, 1)));
-        HIP_TRY(hipMalloc(&crel, 4 * cap_crel));
         return MASP_HIP_OK;
     }
 };
@@ -138,11 +140,6 @@ struct MsmWorkspace {
         // workgroups anyway: there a lane's chunk is a chain of dependent additions on an otherwise idle chip, so the digit
         // list is cut into one full round of waves
         if (np < 8) lanes = g.nb <= 256 ? std::max<uint64_t>((1u << 16) / np, 1u << 13) : std::min<uint64_t>(lanes, std::max<uint64_t>(8ull * g.nb, 1u << 13));
-        static const int forced = [] {  // experiment knob, read once per process
-            const char* e = getenv("MASP_HIP_MSM_CHUNKS");
-            return e ? std::max(1, atoi(e)) : 0;
-        }();
-        if (forced) lanes = (uint64_t)forced;
         return (uint32_t)std::min<uint64_t>(std::min<uint64_t>(lanes, NCHUNKS), std::max<uint64_t>(ent, 1));
     }
     // room for `np` proofs of an n-point MSM with geometry g (every per-proof array is np-fold)
@@ -154,22 +151,29 @@ struct MsmWorkspace {
         size_t need_nb = std::max<size_t>(g.nb, cap_nb), need_np = std::max<size_t>(np, cap_np);
         // every batch shape of this base set: np x chunks <= 3 * 2^18 (nchunks_for), np x nb <= need_np x need_nb
         const size_t need_part = std::max(std::max(part_need, cap_part), need_np * need_nb + ((size_t)3 << 18));
-        release();
+        release();  // (capacities are 0 from here on: a failed allocation below must not leave them claiming memory)
+        const size_t P = need_np;
+        size_t chunks = (need_nb + (1u << CS_LOG) - 1) >> CS_LOG;
+        auto alloc_all = [&]() -> int {
+            HIP_TRY(hipMalloc(&heavy, P * 4 * need_nb));
+            HIP_TRY(hipMalloc(&n_heavy, P * 4));
+            HIP_TRY(hipMalloc(&part, sizeof(Xyzz<O>) * need_part));
+            HIP_TRY(hipMalloc(&bkt, P * sizeof(Xyzz<O>) * need_nb));
+            HIP_TRY(hipMalloc(&S[0], P * sizeof(Xyzz<O>) * chunks));
+            HIP_TRY(hipMalloc(&S[1], P * sizeof(Xyzz<O>) * chunks));
+            HIP_TRY(hipMalloc(&T, P * sizeof(Xyzz<O>) * chunks));
+            HIP_TRY(hipMalloc(&R[0], P * sizeof(Xyzz<O>) * chunks));
+            HIP_TRY(hipMalloc(&R[1], P * sizeof(Xyzz<O>) * chunks));
+            HIP_TRY(hipMalloc(&tsum, P * sizeof(Xyzz<O>) * 32));
+            return MASP_HIP_OK;
+        };
+        if (int rc = alloc_all()) {
+            release();
+            return rc;
+        }
         cap_nb = need_nb;
         cap_np = need_np;
         cap_part = need_part;
-        const size_t P = cap_np;
-        size_t chunks = (cap_nb + (1u << CS_LOG) - 1) >> CS_LOG;
-        HIP_TRY(hipMalloc(&heavy, P * 4 * cap_nb));
-        HIP_TRY(hipMalloc(&n_heavy, P * 4));
-        HIP_TRY(hipMalloc(&part, sizeof(Xyzz<O>) * cap_part));
-        HIP_TRY(hipMalloc(&bkt, P * sizeof(Xyzz<O>) * cap_nb));
-        HIP_TRY(hipMalloc(&S[0], P * sizeof(Xyzz<O>) * chunks));
-        HIP_TRY(hipMalloc(&S[1], P * sizeof(Xyzz<O>) * chunks));
-        HIP_TRY(hipMalloc(&T, P * sizeof(Xyzz<O>) * chunks));
-        HIP_TRY(hipMalloc(&R[0], P * sizeof(Xyzz<O>) * chunks));
-        HIP_TRY(hipMalloc(&R[1], P * sizeof(Xyzz<O>) * chunks));
-        HIP_TRY(hipMalloc(&tsum, P * sizeof(Xyzz<O>) * 32));
         return MASP_HIP_OK;
     }
 

@@ -57,10 +57,11 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
     if (rc) return rc;
     {
         // the LDS tree kernel keeps 256 XYZZ points per workgroup: 48 KiB (G1) / 96 KiB (G2) of the 160 KiB LDS
-        static bool lds_ok = [] {
+        static PerDeviceOnce once;
+        const bool lds_ok = once([] {
             int bytes = 256 * (int)sizeof(Xyzz<O>);
             return hipFuncSetAttribute((const void*)k_xyzz_reduce_block<O>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
-        }();
+        });
         if (!lds_ok) {
             last_hip_error() = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
             return MASP_HIP_E_HIP;
@@ -106,11 +107,7 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
     // the length of the chain; a lone proof takes 4 (shortest dependent chain).
     uint32_t g_log = nb <= WSUM_L ? 0 : WSUM_G_LOG_MIN;  // at most 128 buckets: one per lane, one workgroup, no second level
     if (!lone) {
-        static const int forced = [] {
-            const char* e = getenv("MASP_HIP_WSUM_G_LOG");  // experiment knob: upper limit of G
-            return e ? atoi(e) : 0;
-        }();
-        const uint32_t hi = forced >= 3 && forced <= 6 ? (uint32_t)forced : 6u;
+        const uint32_t hi = 6u;
         g_log = 3;
         while (g_log < hi && (1u << (g_log + 1 + WSUM_L_LOG)) <= nb) ++g_log;
     }

@@ -26,17 +26,21 @@ using namespace masp;
 
 namespace {
 
-// environment knobs, read once when a context is created
-static int env_slots() {
-    const char* e = getenv("MASP_HIP_SLOTS");
-    int n = e ? atoi(e) : 4;
-    return std::max(1, std::min(n, (int)masp_hip_ctx::MAX_SLOTS));
-}
-// proofs per batched launch sequence (upper bound: a list of n same-circuit jobs is cut into ceil(n / cap) equal groups)
-static size_t env_batch_cap() {
-    const char* e = getenv("MASP_HIP_BATCH");
-    int n = e ? atoi(e) : 256;  // the bench's configuration; scratch memory follows the batches actually formed
-    return (size_t)std::max(1, std::min(n, 256));
+// options of a context (include/masp_hip.h: masp_hip_options) with every "0 = default" resolved; no environment is read
+static masp_hip_options resolve_options(const masp_hip_options* in) {
+    masp_hip_options o;
+    memset(&o, 0, sizeof o);
+    if (in) memcpy(&o, in, std::min<size_t>(in->struct_size ? in->struct_size : sizeof o, sizeof o));
+    o.struct_size = sizeof o;
+    o.slots = o.slots > 0 ? std::min<int>(o.slots, (int)masp_hip_ctx::MAX_SLOTS) : 4;
+    // proofs per batched launch sequence (upper bound: a list of n same-circuit jobs is cut into ceil(n / cap) equal groups);
+    // scratch memory follows the batches actually formed
+    o.batch_cap = o.batch_cap > 0 ? std::min<int>(o.batch_cap, 256) : 256;
+    o.ntt_sub_batch = o.ntt_sub_batch > 0 ? o.ntt_sub_batch : o.ntt_sub_batch < 0 ? 0 : 8;   // resolved: 0 = whole batch
+    o.window_bits_b2_lone = o.window_bits_b2_lone > 0 ? o.window_bits_b2_lone : o.window_bits_b2_lone < 0 ? 0 : 8;  // resolved: 0 = not built
+    // ~30 % of a MASP witness is neither 0 nor 1; measured +3..5 % throughput vs 100
+    o.witness_nontrivial_percent = o.witness_nontrivial_percent > 0 ? std::min<int>(o.witness_nontrivial_percent, 100) : 30;
+    return o;
 }
 // [0, n) cut into ceil(n / cap) groups whose sizes differ by at most one: (first, count) pairs
 static std::vector<std::pair<size_t, size_t>> even_groups(size_t n, size_t cap) {
@@ -62,7 +66,10 @@ static int ensure_slots(masp_hip_ctx* ctx, size_t want) {
         ctx->slots.push_back(std::move(s));
         ctx->slot_busy.push_back(0);
     }
-    for (auto& sl : ctx->slots) sl->profiling = ctx->profiling;
+    for (auto& sl : ctx->slots) {
+        sl->profiling = ctx->profiling;
+        sl->ntt_sub = (uint32_t)ctx->opt.ntt_sub_batch;
+    }
     return MASP_HIP_OK;
 }
 // Slot pool for concurrent provers.  try: a free slot, or a new one while fewer than ctx->n_slots exist.
@@ -80,6 +87,7 @@ static int slot_try_acquire(masp_hip_ctx* ctx, size_t* si) {
     int rc = s->init();
     if (rc) return rc;
     s->profiling = ctx->profiling;
+    s->ntt_sub = (uint32_t)ctx->opt.ntt_sub_batch;
     ctx->slots.push_back(std::move(s));
     ctx->slot_busy.push_back(1);
     *si = ctx->slots.size() - 1;
@@ -124,10 +132,7 @@ static int enqueue_quotient(Slot& sl, const NttDomain& D, const Fr* const in[3],
     // A batch goes through the six transforms in sub-batches whose six work buffers (sub x 6 x 32 m bytes: 192 MiB for
     // eight Spend proofs) stay in the 256 MiB Infinity Cache from pass to pass, instead of every pass streaming the whole
     // batch (np x 4 MiB per buffer) through HBM.  The work buffers are only sub proofs long; h is the per-batch result.
-    static const uint32_t sub_max = [] {
-        const char* e = getenv("MASP_HIP_NTT_SUB");  // experiment knob, read once: 0 = the whole batch at once
-        return e ? (uint32_t)atoi(e) : 8u;
-    }();
+    const uint32_t sub_max = sl.ntt_sub;  // masp_hip_options::ntt_sub_batch (0 = the whole batch at once)
     const uint32_t sub = sub_max ? std::min(sub_max, np) : np;
     int rc;
     // a, b and c go through every pass TOGETHER: the three transforms of a sub-batch lie back to back in one buffer
@@ -364,16 +369,27 @@ const char* masp_hip_last_error(const masp_hip_ctx* ctx) {
     return copy.c_str();
 }
 
-int masp_hip_ctx_create(int device, masp_hip_ctx** out) {
-    if (!out) return MASP_HIP_E_INVALID_ARG;
+int masp_hip_device_count(void) {
+    int count = 0;
+    return hipGetDeviceCount(&count) == hipSuccess && count > 0 ? count : 0;
+}
+
+void masp_hip_options_default(masp_hip_options* opt) {
+    if (!opt) return;
+    memset(opt, 0, sizeof *opt);   // every field: 0 = the default (resolved when a context is created)
+    opt->struct_size = sizeof *opt;
+}
+
+static int create_single(int device, const masp_hip_options& opt, masp_hip_ctx** out) {
     *out = nullptr;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return MASP_HIP_E_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return MASP_HIP_E_NO_DEVICE;
     std::unique_ptr<masp_hip_ctx> ctx(new masp_hip_ctx);
     ctx->device = device;
-    ctx->n_slots = env_slots();
-    ctx->batch_cap = env_batch_cap();
+    ctx->opt = opt;
+    ctx->n_slots = opt.slots;
+    ctx->batch_cap = (size_t)opt.batch_cap;
     ctx->slots.reserve(masp_hip_ctx::MAX_SLOTS);      // never reallocates: see the locking note on masp_hip_ctx
     ctx->slot_busy.reserve(masp_hip_ctx::MAX_SLOTS);
     if (hipStreamCreateWithFlags(&ctx->main_stream, hipStreamNonBlocking) != hipSuccess) return MASP_HIP_E_NO_DEVICE;
@@ -381,21 +397,55 @@ int masp_hip_ctx_create(int device, masp_hip_ctx** out) {
     return MASP_HIP_OK;
 }
 
-int masp_hip_ctx_create_multi(const int* devices, int n_devices, masp_hip_ctx** out) {
+int masp_hip_ctx_create_ex(const int* devices, int n_devices, const masp_hip_options* opt_in, masp_hip_ctx** out) {
     if (!out || !devices || n_devices <= 0 || n_devices > 64) return MASP_HIP_E_INVALID_ARG;
+    if (opt_in && opt_in->struct_size != 0 && opt_in->struct_size < 4 * sizeof(int32_t)) return MASP_HIP_E_INVALID_ARG;
     *out = nullptr;
+    const masp_hip_options opt = resolve_options(opt_in);
+    if (n_devices == 1) return create_single(devices[0], opt, out);
     std::unique_ptr<masp_hip_ctx> front(new masp_hip_ctx);
     front->device = devices[0];
-    front->batch_cap = env_batch_cap();
+    front->opt = opt;
+    front->n_slots = opt.slots;
+    front->batch_cap = (size_t)opt.batch_cap;
     for (int i = 0; i < n_devices; ++i) {
         masp_hip_ctx* ch = nullptr;
-        int rc = masp_hip_ctx_create(devices[i], &ch);
+        int rc = create_single(devices[i], opt, &ch);
         if (rc) {
             for (masp_hip_ctx* c : front->children) masp_hip_ctx_destroy(c);
             return rc;
         }
         front->children.push_back(ch);
     }
+    *out = front.release();
+    return MASP_HIP_OK;
+}
+
+int masp_hip_ctx_get_options(const masp_hip_ctx* ctx, masp_hip_options* out) {
+    if (!ctx || !out) return MASP_HIP_E_INVALID_ARG;
+    *out = ctx->opt;
+    return MASP_HIP_OK;
+}
+
+int masp_hip_ctx_create(int device, masp_hip_ctx** out) {
+    if (!out) return MASP_HIP_E_INVALID_ARG;
+    return masp_hip_ctx_create_ex(&device, 1, nullptr, out);
+}
+
+// (a list of ONE device still gives the multi-device front: its callers test the sharding path with the same GPU listed twice
+// or once)
+int masp_hip_ctx_create_multi(const int* devices, int n_devices, masp_hip_ctx** out) {
+    if (!out || !devices || n_devices <= 0 || n_devices > 64) return MASP_HIP_E_INVALID_ARG;
+    if (n_devices > 1) return masp_hip_ctx_create_ex(devices, n_devices, nullptr, out);
+    *out = nullptr;
+    std::unique_ptr<masp_hip_ctx> front(new masp_hip_ctx);
+    front->device = devices[0];
+    front->opt = resolve_options(nullptr);
+    front->batch_cap = (size_t)front->opt.batch_cap;
+    masp_hip_ctx* ch = nullptr;
+    int rc = create_single(devices[0], front->opt, &ch);
+    if (rc) return rc;
+    front->children.push_back(ch);
     *out = front.release();
     return MASP_HIP_OK;
 }
@@ -530,24 +580,18 @@ int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* param
     // query vectors + window tables
     // h scalars are uniform in Fr; the witness queries are mostly 0 / 1 (70 % of a Spend witness is
     // boolean-constrained), so their effective size for window selection is a fraction of their length
-    const char* fe = getenv("MASP_HIP_WITNESS_NONTRIVIAL_PERCENT");
-    const uint32_t pct = fe ? (uint32_t)atoi(fe) : 30;  // ~30 % of a MASP witness is neither 0 nor 1; measured +3..5 % throughput vs 100
+    const uint32_t pct = (uint32_t)ctx->opt.witness_nontrivial_percent;
     auto eff = [&](uint32_t n) { return (uint32_t)((uint64_t)n * pct / 100); };
-    auto envc = [](const char* name) {  // experiment knobs: window width of one query family
-        const char* e = getenv(name);
-        return e ? atoi(e) : 0;
-    };
-    const int c_la = envc("MASP_HIP_MSM_C_LA"), c_b = envc("MASP_HIP_MSM_C_B");
+    const int c_la = ctx->opt.window_bits_la, c_b = ctx->opt.window_bits_b;   // 0: chosen from the expected non-trivial scalars
     // h has uniform scalars: 16-bit windows from 48 k points (Spend 131 071, Convert 65 535), 15 bits below (Output 32 767)
     const uint32_t n_h = (uint32_t)(C->m - 1);
-    const int c_h = envc("MASP_HIP_MSM_C_H") ? envc("MASP_HIP_MSM_C_H") : n_h >= 49152 ? 16 : n_h >= 16384 ? 15 : 0;
+    const int c_h = ctx->opt.window_bits_h ? ctx->opt.window_bits_h : n_h >= 49152 ? 16 : n_h >= 16384 ? 15 : 0;
     if ((rc = C->h.load_host(L.h, (uint32_t)(C->m - 1), s, 0xffffffffu, c_h)) || (rc = C->l.load_host(L.l, L.n_l, s, eff(L.n_l), c_la)) ||
         (rc = C->a.load_host(L.a, L.n_a, s, eff(L.n_a), c_la)) || (rc = C->b1.load_host(L.b_g1, L.n_b1, s, eff(L.n_b1), c_b)) ||
         (rc = C->b2.load_host(L.b_g2, L.n_b2, s, eff(L.n_b2), c_b)))
         return fail(ctx, rc);
     {
-        const char* e = getenv("MASP_HIP_MSM_C_B2_LONE");  // 0 = lone proofs share the batch tables (and B1's sort)
-        const int c_lone = e ? atoi(e) : 8;
+        const int c_lone = ctx->opt.window_bits_b2_lone;  // 0 = lone proofs share the batch tables (and B1's sort)
         if (c_lone > 0 && L.n_b2 && (rc = C->b2_lone.load_host(L.b_g2, L.n_b2, s, eff(L.n_b2), c_lone))) return fail(ctx, rc);
     }
     {

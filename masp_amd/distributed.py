@@ -56,3 +56,27 @@ def sum_over_ranks(value, dist=None, device=None):
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def broadcast_bytes(data, dist=None, device=None, src=0):
+    """`data` (bytes / u8 array) on rank `src`, None elsewhere -> the same u8 array on every rank (two broadcasts: length, payload).
+    Used for the CRS: generated once, loaded by every rank from the same bytes."""
+    import torch
+    if dist is None or dist.get_world_size() == 1:
+        return np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data, dtype=np.uint8)
+    rank = dist.get_rank()
+    if rank == src:
+        arr = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data, dtype=np.uint8)
+        n = torch.tensor([arr.size], dtype=torch.int64, device=device)
+    else:
+        n = torch.zeros(1, dtype=torch.int64, device=device)
+    dist.broadcast(n, src=src)
+    size = int(n.item())
+    if rank == src:
+        t = torch.from_numpy(arr.copy())
+        if device is not None:
+            t = t.to(device)
+    else:
+        t = torch.empty(size, dtype=torch.uint8, device=device)
+    dist.broadcast(t, src=src)
+    return t.cpu().numpy()

@@ -20,6 +20,15 @@ class MaspHipError(RuntimeError):
         super().__init__("masp_hip error %d: %s%s" % (code, ERRORS.get(code, "?"), (" — " + detail) if detail else ""))
 
 
+OPTION_FIELDS = ("slots", "batch_cap", "ntt_sub_batch", "window_bits_h", "window_bits_la", "window_bits_b", "window_bits_b2_lone",
+                 "witness_nontrivial_percent")
+
+
+class OptionsStruct(C.Structure):
+    """masp_hip_options (include/masp_hip.h): every field 0 = the default."""
+    _fields_ = [("struct_size", C.c_uint32)] + [(f, C.c_int32) for f in OPTION_FIELDS] + [("reserved", C.c_int32 * 7)]
+
+
 class JobStruct(C.Structure):
     _fields_ = [("circuit", C.c_uint32), ("inputs", C.c_void_p), ("aux", C.c_void_p), ("a", C.c_void_p),
                 ("b", C.c_void_p), ("c", C.c_void_p), ("r", C.c_uint8 * 32), ("s", C.c_uint8 * 32)]
@@ -46,6 +55,11 @@ def load_library():
     vp, sz, u32 = C.c_void_p, C.c_size_t, C.c_uint32
     L.masp_hip_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.masp_hip_ctx_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.masp_hip_ctx_create_ex.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(OptionsStruct), C.POINTER(vp)]
+    L.masp_hip_ctx_get_options.argtypes = [vp, C.POINTER(OptionsStruct)]
+    L.masp_hip_device_count.argtypes = []
+    L.masp_hip_options_default.argtypes = [C.POINTER(OptionsStruct)]
+    L.masp_hip_options_default.restype = None
     L.masp_hip_ctx_device_count.argtypes = [vp]
     L.masp_hip_ctx_destroy.argtypes = [vp]
     L.masp_hip_ctx_destroy.restype = None
@@ -83,6 +97,11 @@ def load_library():
     return L
 
 
+def device_count():
+    """HIP devices visible to this process (masp_hip_device_count)."""
+    return int(load_library().masp_hip_device_count())
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
@@ -111,16 +130,33 @@ class Context:
     masp_hip_ctx_create_multi — prove_batch then deals its jobs to the devices).  Thread-safe: prove / prove_batch are
     re-entrant, everything else serialises inside the library."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, **options):
+        """options: the fields of masp_hip_options (slots, batch_cap, ntt_sub_batch, window_bits_*, ...); unset = default.
+        The library reads no environment variables: tuning comes through here."""
         self._L = load_library()
         h = C.c_void_p()
+        unknown = set(options) - set(OPTION_FIELDS)
+        if unknown:
+            raise TypeError("unknown context option(s): %s" % ", ".join(sorted(unknown)))
+        opt = OptionsStruct()
+        self._L.masp_hip_options_default(C.byref(opt))
+        for k, v in options.items():
+            if v is not None:
+                setattr(opt, k, int(v))
         if isinstance(device, (list, tuple)):
             arr = (C.c_int * len(device))(*[int(d) for d in device])
-            rc = self._L.masp_hip_ctx_create_multi(arr, len(device), C.byref(h))
+            if options or len(device) > 1:
+                rc = self._L.masp_hip_ctx_create_ex(arr, len(device), C.byref(opt), C.byref(h))
+            else:
+                rc = self._L.masp_hip_ctx_create_multi(arr, len(device), C.byref(h))
         else:
-            rc = self._L.masp_hip_ctx_create(int(device), C.byref(h))
+            arr = (C.c_int * 1)(int(device))
+            rc = self._L.masp_hip_ctx_create_ex(arr, 1, C.byref(opt), C.byref(h))
         if rc:
             raise MaspHipError(rc)
+        got = OptionsStruct()
+        self._L.masp_hip_ctx_get_options(h, C.byref(got))
+        self.options = {f: int(getattr(got, f)) for f in OPTION_FIELDS}      # defaults resolved
         self._h = h
         self._keep = []
         self._pinned = {}
@@ -342,7 +378,10 @@ class GpuVerifyingKey:
         assert len(z) == 16 * n
         zb = np.frombuffer(z, dtype=np.uint8)
         ok = C.c_int(0)
-        self._ctx._check(self._ctx._L.masp_hip_verify_batch(self._ctx._h, self._h, n, _p(pr), _p(pi), self.n_public, _p(zb), C.byref(ok)))
+        rc = self._ctx._L.masp_hip_verify_batch(self._ctx._h, self._h, n, _p(pr), _p(pi), self.n_public, _p(zb), C.byref(ok))
+        if rc == 8:        # MASP_HIP_E_SCALAR_RANGE: a public input >= r — "does not verify", as host.PreparedVerifyingKey.verify_batch says
+            return False
+        self._ctx._check(rc)
         return ok.value == 1
 
     def close(self):

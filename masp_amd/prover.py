@@ -84,13 +84,13 @@ class SaplingProvingContext:
 class LocalTxProver:
     """An implementation of `TxProver` using the MI355X prover.  Holds the three circuits' parameters for its lifetime."""
 
-    def __init__(self, spend_params, output_params, convert_params, device=0, rng=None, self_verify=True, expected=P.EXPECTED):
+    def __init__(self, spend_params, output_params, convert_params, device=0, rng=None, self_verify=True, expected=P.EXPECTED, options=None):
         """= LocalTxProver::from_bytes (prover.rs:81-95): parameter *bytes* in the bellman wire format, digests checked
         as `parse_parameters` does (lib.rs:333-388).  Malformed or mismatching parameters raise `params.ParameterError` /
         `hip.HipError` (the reference panics, lib.rs:290-293,337,359-362).  `expected=None`: parameters that are not the
         MPC files (benches, tests)."""
         spend_params, output_params, convert_params = P.parse_parameters(spend_params, output_params, convert_params, expected=expected)
-        self._ctx = Context(device)
+        self._ctx = Context(device, **(options or {}))      # options: masp_hip_options fields (slots, batch_cap, ...)
         self._pool = {SPEND: [], OUTPUT: [], CONVERT: []}           # recycled page-locked aux buffers per circuit
         self._pool_lock = threading.Lock()
         self._rng = rng or (lambda: secrets.randbelow(FR))          # r, s <- OsRng (sapling/prover.rs:66,174,225)
@@ -174,6 +174,8 @@ class LocalTxProver:
         """Return the aux buffers of finished jobs to the pool (the job dicts must not be proved again afterwards)."""
         with self._pool_lock:
             for j in jobs:
+                if j is None:            # a synthesis task that returned at once because the call had already failed
+                    continue
                 buf = j.pop("_pinned", None)
                 if buf is not None:
                     self._pool[j["slot"]].append(buf)
@@ -237,8 +239,8 @@ class LocalTxProver:
         # descriptions per GPU call: an eighth of the list, between 64 and the launch-sequence size (256).  Short lists want
         # the first call to start early (1 024 Spends: 769 proofs/s in chunks of 128 against 730 in chunks of 256), long mixed
         # lists want full batches per circuit (4 096 mixed: 1 104 proofs/s in chunks of 256 against 999 in chunks of 128)
-        chunk = chunk or max(64, min(int(os.environ.get("MASP_HIP_BATCH", "256")), n // 8))
-        in_flight = max(1, int(os.environ.get("MASP_HIP_SLOTS", "4")))    # one call per slot of the native context
+        chunk = chunk or max(64, min(self._ctx.options["batch_cap"], n // 8))
+        in_flight = max(1, self._ctx.options["slots"])    # one call per slot of the native context
         prep = {"spend": self.prepare_spend, "output": self.prepare_output, "convert": self.prepare_convert}
         done = [0]
 
@@ -276,7 +278,12 @@ class LocalTxProver:
 
             def run_chunk(lo):
                 hi = min(n, lo + chunk)
+                if abort.is_set():                      # an earlier chunk failed: the transaction is lost, do not spend GPU time on it
+                    raise ProvingError("batch aborted")
                 jobs = [f.result() for f in futures[lo:hi]]
+                if any(j is None for j in jobs):        # synthesis saw the abort flag
+                    self._aux_give(jobs)
+                    raise ProvingError("batch aborted")
                 try:
                     proofs = self.prove_prepared(jobs, rs[lo:hi])
                     if self._self_verify:
@@ -298,13 +305,23 @@ class LocalTxProver:
                 if progress is not None:
                     progress(so_far, n)
                 return jobs, proofs
+            first_error = []
+
+            def guarded(lo):
+                try:
+                    return run_chunk(lo)
+                except BaseException as e:          # the first failure stops the chunks still queued (they check `abort`)
+                    with done_lock:
+                        if not abort.is_set():
+                            first_error.append(e)   # the cause, not the "batch aborted" of the chunks that follow it
+                            abort.set()
+                            for _ in range(n):
+                                ahead.release()
+                    raise
             try:
-                results = list(gpu.map(run_chunk, range(0, n, chunk)))
+                results = list(gpu.map(guarded, range(0, n, chunk)))
             except BaseException as e:             # (an invalid diversifier, a failed self-check, a device error ...)
-                abort.set()
-                for _ in range(n):
-                    ahead.release()
-                failed = e
+                failed = first_error[0] if first_error else e
         if failed is not None:
             # both executors have shut down, so every synthesis task has finished: whatever it produced and no chunk gave
             # back (the failing chunk's earlier jobs, later chunks, tasks that ran past the abort check) returns its

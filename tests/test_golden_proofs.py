@@ -72,15 +72,15 @@ def test_gpu_reproduces_the_golden_proofs(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("c_lone", ["0", "6", "11"])
-def test_gpu_lone_proof_whatever_windows_its_g2_tables_use(c_lone, monkeypatch):
-    """A lone proof runs B2 on its own narrow-window tables (MASP_HIP_MSM_C_B2_LONE, default 8: covered by the test above).
-    Without them (0: the batch tables and B1's digit sort, as in round 1) and on other widths (6: fewer than 128 buckets, the
+@pytest.mark.parametrize("c_lone", [-1, 6, 11])
+def test_gpu_lone_proof_whatever_windows_its_g2_tables_use(c_lone):
+    """A lone proof runs B2 on its own narrow-window tables (masp_hip_options::window_bits_b2_lone, default 8: covered by the test above).
+    Without them (-1: the batch tables and B1's digit sort, as in round 1) and on other widths (6: fewer than 128 buckets, the
     single-pass sort; 11) the bytes are the same."""
     import masp_amd
     cs, inputs, aux, toxic, r, s, want = _instance("spend")
-    monkeypatch.setenv("MASP_HIP_MSM_C_B2_LONE", c_lone)       # read when a circuit is loaded
-    ctx = masp_amd.Context(0)
+    ctx = masp_amd.Context(0, window_bits_b2_lone=c_lone)
+    assert ctx.options["window_bits_b2_lone"] == max(c_lone, 0)
     try:
         ctx.load_circuit(0, ctx.generate_parameters(cs, toxic), cs)
         assert ctx.prove(0, inputs, aux, r, s) == want

@@ -11,8 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-os.environ.setdefault("MASP_HIP_SLOTS", "4")
-os.environ.setdefault("MASP_HIP_BATCH", "256")
+from bench import options_from_env              # noqa: E402  (MASP_HIP_* variables -> masp_hip_options; the library reads none)
 
 from masp_amd import host as H                     # noqa: E402
 from masp_amd import workload as W                 # noqa: E402
@@ -28,13 +27,13 @@ def main():
     threads = int(sys.argv[2]) if len(sys.argv) > 2 and int(sys.argv[2]) > 0 else H.effective_cpus()
     chunk = int(sys.argv[3]) if len(sys.argv) > 3 else None
     t = time.time()
-    prover = LocalTxProver.with_synthetic_parameters(seed=7)
+    prover = LocalTxProver.with_synthetic_parameters(seed=7, options=options_from_env())
     print("parameters generated + loaded: %.1f s" % (time.time() - t))
     with ThreadPoolExecutor(threads) as ex:
         descs = list(ex.map(spend_description, range(n)))
         # warm-up (workspace allocation, first-launch costs)
         # (five full batches: every slot's workspace gets its final size before anything is timed)
-        prover.prove_batch(prover.new_sapling_proving_context(), descs[:min(n, 5 * int(os.environ["MASP_HIP_BATCH"]))], threads=threads)
+        prover.prove_batch(prover.new_sapling_proving_context(), descs[:min(n, 5 * prover._ctx.options["batch_cap"])], threads=threads)
         stage_n = min(n, 256)                     # the staged measurement holds every aux buffer at once: bound it
         t0 = time.time()
         jobs = list(ex.map(lambda d: prover.prepare_spend(**d[1]), descs[:stage_n]))

@@ -43,6 +43,85 @@ G2Y1 = 0x0606c4a02ea734cc32acd2b02bc28b99cb3e287e85a763af267492ab572e99ab3f370d2
 RP = (1 << 384) % P
 fp_extra = ["    // standard generators (affine, Montgomery form); encodings KAT-checked in tests"] + [
     "    " + arr(n, v * RP % P, 12) for n, v in (("G1_X", G1X), ("G1_Y", G1Y), ("G2_X0", G2X0), ("G2_X1", G2X1), ("G2_Y0", G2Y0), ("G2_Y1", G2Y1))]
+# ---- constants of the subgroup membership tests (M. Scott, "A note on group membership tests for G1, G2 and GT on BLS
+# pairing-friendly curves"): computed here, checked on the generators below before anything is written.
+U = -0xd201000000010000                  # the curve parameter ("x" of BLS12-381)
+
+
+def f2mul(a, b):
+    return ((a[0] * b[0] - a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+
+
+def f2pow(a, e):
+    r = (1, 0)
+    while e:
+        if e & 1:
+            r = f2mul(r, a)
+        a = f2mul(a, a)
+        e >>= 1
+    return r
+
+
+def f2inv(a):
+    n = pow(a[0] * a[0] + a[1] * a[1], -1, P)
+    return (a[0] * n % P, (-a[1]) * n % P)
+
+
+def ec_add(mul, inv, p, q):
+    if p is None:
+        return q
+    if q is None:
+        return p
+    sub = (lambda a, b: (a - b) % P) if isinstance(p[0], int) else (lambda a, b: ((a[0] - b[0]) % P, (a[1] - b[1]) % P))
+    add = (lambda a, b: (a + b) % P) if isinstance(p[0], int) else (lambda a, b: ((a[0] + b[0]) % P, (a[1] + b[1]) % P))
+    if p[0] == q[0]:
+        if p[1] != q[1]:
+            return None
+        x2 = mul(p[0], p[0])
+        lam = mul(add(add(x2, x2), x2), inv(add(p[1], p[1])))
+    else:
+        lam = mul(sub(q[1], p[1]), inv(sub(q[0], p[0])))
+    x3 = sub(sub(mul(lam, lam), p[0]), q[0])
+    return (x3, sub(mul(lam, sub(p[0], x3)), p[1]))
+
+
+def ec_mul(mul, inv, p, k):
+    r = None
+    while k:
+        if k & 1:
+            r = ec_add(mul, inv, r, p)
+        p = ec_add(mul, inv, p, p)
+        k >>= 1
+    return r
+
+
+m1, i1 = (lambda a, b: a * b % P), (lambda a: pow(a, -1, P))
+# G1: phi(x, y) = (beta x, y) acts on G1 as multiplication by -u^2 for ONE of the two primitive cube roots of unity
+g = 2
+while pow(g, (P - 1) // 3, P) == 1:
+    g += 1
+BETA = None
+for cand in (pow(g, (P - 1) // 3, P), pow(g, 2 * (P - 1) // 3, P)):
+    if (cand * G1X % P, G1Y) == ec_mul(m1, i1, (G1X, G1Y), (-(U * U)) % R):
+        BETA = cand
+assert BETA is not None
+# G2: psi(x, y) = (cx conj(x), cy conj(y)) (untwist, Frobenius, twist) acts on G2 as multiplication by p = u (mod r)
+xi3, xi2 = f2pow((1, 1), (P - 1) // 3), f2pow((1, 1), (P - 1) // 2)
+PSI = None
+G2P = ((G2X0, G2X1), (G2Y0, G2Y1))
+want = ec_mul(f2mul, f2inv, G2P, U % R)
+for cx in (xi3, f2inv(xi3)):
+    for cy in (xi2, f2inv(xi2)):
+        conj = lambda a: (a[0], (-a[1]) % P)   # noqa: E731
+        if (f2mul(cx, conj(G2P[0])), f2mul(cy, conj(G2P[1]))) == want:
+            PSI = (cx, cy)
+assert PSI is not None
+fp_extra += ["    // subgroup membership tests (Scott): on G1 (beta x, y) = -[u^2] P; on G2 (cx conj x, cy conj y) = [u] Q; Montgomery form",
+             "    " + arr("ENDO_BETA", BETA * RP % P, 12),
+             "    " + arr("PSI_CX0", PSI[0][0] * RP % P, 12), "    " + arr("PSI_CX1", PSI[0][1] * RP % P, 12),
+             "    " + arr("PSI_CY0", PSI[1][0] * RP % P, 12), "    " + arr("PSI_CY1", PSI[1][1] * RP % P, 12),
+             "    " + arr("U_ABS", -U, 2) + "   // |u|, u = -0xd201000000010000",
+             "    " + arr("U_SQR", U * U, 4) + "   // u^2"]
 rou = pow(7, (R - 1) >> 32, R)
 fr_extra = ["    " + arr("ROOT_OF_UNITY", rou * (1 << 256) % R, 8) + "   // 7^((r-1)/2^32), Montgomery form",
             "    " + arr("GEN", 7 * (1 << 256) % R, 8) + "   // multiplicative generator 7, Montgomery form",

@@ -11,7 +11,7 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-os.environ.setdefault("MASP_HIP_BATCH", "256")
+from bench import options_from_env                     # noqa: E402
 
 from masp_amd import workload as W                     # noqa: E402
 from masp_amd import host as H                         # noqa: E402
@@ -20,7 +20,7 @@ from masp_amd.prover import LocalTxProver, _int         # noqa: E402
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-    prover = LocalTxProver.with_synthetic_parameters(seed=11)
+    prover = LocalTxProver.with_synthetic_parameters(seed=11, options=options_from_env())
     out_vk = H.PreparedVerifyingKey(prover.parameters["output"])
     from concurrent.futures import ThreadPoolExecutor
     t = time.time()

@@ -7,14 +7,13 @@ import time
 from concurrent.futures import ThreadPoolExecutor
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("MASP_HIP_BATCH", "128")
 import masp_amd                                   # noqa: E402
 from masp_amd import host as H, workload as W     # noqa: E402
 from masp_amd.synthetic import toxic_waste        # noqa: E402
 
 R = H.FR_MODULUS
 sizes = [int(x) for x in sys.argv[1:]] or [64, 256, 1024, 4096]
-ctx = masp_amd.Context(0)
+ctx = masp_amd.Context(0, batch_cap=128)
 cs = H.circuit("spend")[0]
 params = ctx.generate_parameters(cs, toxic_waste(3))
 ctx.load_circuit(0, params, cs)
