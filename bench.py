@@ -46,7 +46,8 @@ PROOFS_PER_STEP = {"spend": 256, "output": 256, "convert": 256, "mixed": 512}   
 
 ENV_OPTIONS = {"MASP_HIP_SLOTS": "slots", "MASP_HIP_BATCH": "batch_cap", "MASP_HIP_NTT_SUB": "ntt_sub_batch", "MASP_HIP_MSM_C_H": "window_bits_h",
                "MASP_HIP_MSM_C_LA": "window_bits_la", "MASP_HIP_MSM_C_B": "window_bits_b", "MASP_HIP_MSM_C_B2_LONE": "window_bits_b2_lone",
-               "MASP_HIP_WITNESS_NONTRIVIAL_PERCENT": "witness_nontrivial_percent"}
+               "MASP_HIP_WITNESS_NONTRIVIAL_PERCENT": "witness_nontrivial_percent", "MASP_HIP_TREE_LEVELS": "bucket_tree_levels",
+               "MASP_HIP_TREE_SUB": "bucket_tree_sub_batch", "MASP_HIP_TREE_LEVELS_G2": "bucket_tree_levels_g2"}
 
 
 def options_from_env(env=os.environ):

@@ -89,7 +89,11 @@ typedef struct {
     int32_t window_bits_b;           /* ... of b_g1 / b_g2 */
     int32_t window_bits_b2_lone;     /* ... of the second b_g2 table set used by lone proofs (default 8); -1 = not built */
     int32_t witness_nontrivial_percent; /* share of a witness that is neither 0 nor 1, for window selection (default 30) */
-    int32_t reserved[7];
+    int32_t bucket_tree_levels;      /* levels of shared-inversion affine additions in front of the bucket accumulation of a batch
+                                        (default 3, fewer for very short bucket runs); -1 = none (XYZZ accumulation only) */
+    int32_t bucket_tree_sub_batch;   /* proofs that go through the tree at a time (default 64; its scratch is ~0.4 GB per Spend proof) */
+    int32_t bucket_tree_levels_g2;   /* the same for the G2 MSM if it should differ (default: bucket_tree_levels) */
+    int32_t reserved[4];
 } masp_hip_options;
 void masp_hip_options_default(masp_hip_options* opt);
 
@@ -141,6 +145,9 @@ int masp_hip_msm_g2(masp_hip_ctx* ctx, const uint8_t* bases, const uint8_t* scal
  * gridDim.y = np): scalars np x n x 32, out np x 96.  window_bits: 0 = chosen from n, else 2..16 (the prover uses 16 for
  * the h query and 12 for the witness queries).  Exists so that the batched code path can be checked on its own. */
 int masp_hip_msm_g1_multi(masp_hip_ctx* ctx, const uint8_t* bases, size_t n, const uint8_t* scalars, size_t np, int window_bits,
+                          uint8_t* out);
+/* the same over G2 (bases n x 192, out np x 192) */
+int masp_hip_msm_g2_multi(masp_hip_ctx* ctx, const uint8_t* bases, size_t n, const uint8_t* scalars, size_t np, int window_bits,
                           uint8_t* out);
 /* h = ((A*B - C)/Z) coefficients from evaluation vectors a,b,c (nrows x 32 each, zero-padded to 2^logm);
  * h_out: (2^logm - 1) x 32 */

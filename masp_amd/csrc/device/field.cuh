@@ -616,6 +616,112 @@ MASP_NOINLINE Fe<C> fe_inv(const Fe<C>& a) {
     for (int i = 0; i < C::N; ++i) r2.v[i] = C::R2[i];
     return fe_mul_nc(fe_mul_nc(r, r2), r2);  // (aR)^-1 R^2 R^-1 = a^-1, once more: a^-1 R
 }
+// Inverse (inv(0) = 0) by the binary extended Euclid in 32-bit limbs, the form for a lane that inverts ONE value while its
+// neighbours do the same (the shared inversions of the batch-affine bucket trees, device/msm_tree.cuh): ~1.45 log2 p rounds of
+// ~150 full-rate integer instructions and not a single multiplication — on a lone wave ~6x sooner than the Fermat power
+// (570 dependent 384-bit products), and free of the 64/128-bit arithmetic the divsteps above are written in.
+// Invariants: a = u y, b = v y (mod p), b odd; a reaches 0 with b = gcd = 1 and v = 1 / y.  Branch-free inside a round
+// (lanes of a wave hold different values); the loop itself ends per lane.
+template <class C>
+MASP_HD void fe_bingcd_inv(uint32_t* out, const uint32_t* y) {
+    constexpr int N = C::N;
+    uint32_t a[N], b[N], u[N], v[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        a[i] = y[i];
+        b[i] = C::MOD[i];
+        u[i] = i == 0 ? 1u : 0u;
+        v[i] = 0u;
+    }
+    for (int round = 0; round < 64 * N + 2; ++round) {
+        uint32_t nz = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) nz |= a[i];
+        if (!nz) break;
+        const uint32_t odd = 0u - (a[0] & 1u);  // mask
+        // d = a - b, borrow <=> a < b
+        uint32_t d[N], w[N];
+        uint64_t br = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            uint64_t t = (uint64_t)a[i] - b[i] - br;
+            d[i] = (uint32_t)t;
+            br = (t >> 32) & 1;
+        }
+        const uint32_t lt = (0u - (uint32_t)br) & odd;  // odd and a < b: the roles swap
+        // w = u - v mod p
+        br = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            uint64_t t = (uint64_t)u[i] - v[i] - br;
+            w[i] = (uint32_t)t;
+            br = (t >> 32) & 1;
+        }
+        {
+            const uint32_t m = 0u - (uint32_t)br;
+            uint64_t c = 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                uint64_t t = (uint64_t)w[i] + (C::MOD[i] & m) + c;
+                w[i] = (uint32_t)t;
+                c = t >> 32;
+            }
+        }
+        // swap case: (a, b, u, v) <- (b - a, a, v - u, u) ; v - u = p - w unless w = 0.  |d| = -d when a < b.
+        uint32_t wz = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) wz |= w[i];
+        const uint32_t negw = lt & (0u - (uint32_t)(wz != 0));
+        {
+            // a <- odd ? |a - b| : a ;  b <- lt ? a : b
+            uint64_t c = lt & 1u;  // two's complement negate of d under lt: (~d) + 1
+            uint64_t brw = 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const uint32_t ai = a[i];
+                uint64_t t = (uint64_t)(d[i] ^ lt) + c;
+                c = t >> 32;
+                a[i] = (ai & ~odd) | ((uint32_t)t & odd);
+                b[i] = (b[i] & ~lt) | (ai & lt);
+                // u <- odd ? (lt ? p - w : w) : u ;  v <- lt ? u : v
+                const uint32_t ui = u[i];
+                uint64_t pw = (uint64_t)C::MOD[i] - w[i] - brw;
+                brw = (pw >> 32) & 1;
+                const uint32_t wn = (w[i] & ~negw) | ((uint32_t)pw & negw);
+                u[i] = (ui & ~odd) | (wn & odd);
+                v[i] = (v[i] & ~lt) | (ui & lt);
+            }
+        }
+        // a is even now: a >>= 1 ; u <- u / 2 mod p  (u + p if u is odd; u + p < 2^(32N) since p leaves a spare top bit)
+        {
+            const uint32_t uo = 0u - (u[0] & 1u);
+            uint64_t c = 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                uint64_t t = (uint64_t)u[i] + (C::MOD[i] & uo) + c;
+                u[i] = (uint32_t)t;
+                c = t >> 32;
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                a[i] = (a[i] >> 1) | (i + 1 < N ? a[i + 1] << 31 : 0u);
+                u[i] = (u[i] >> 1) | (i + 1 < N ? u[i + 1] << 31 : 0u);
+            }
+        }
+    }
+    // y = 0: a was 0 from the start, v = 0
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = v[i];
+}
+// a^-1 in Montgomery form from a in Montgomery form: (aR)^-1 = a^-1 R^-1, times R^3 (as a Montgomery product) = a^-1 R
+template <class C>
+MASP_HD Fe<C> fe_inv_bingcd(const Fe<C>& a) {
+    Fe<C> r, r3;
+    fe_bingcd_inv<C>(r.v, a.v);
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) r3.v[i] = C::R3[i];
+    return fe_mul(r, r3);
+}
 // canonical value > (p-1)/2 ?  (zcash "lexicographically largest")
 template <class C>
 MASP_HD bool fe_canonical_gt_half(const Fe<C>& canon) {
@@ -659,6 +765,7 @@ struct FpOps {
     static MASP_HD bool eq(const T& a, const T& b) { return fe_eq(a, b); }
     static MASP_HD T inv(const T& a) { return fe_inv(a); }
     static MASP_HD T inv_lone(const T& a) { return fe_inv_fermat(a); }  // for single-lane serial tails
+    static MASP_HD T inv_gcd(const T& a) { return fe_inv_bingcd(a); }   // for a few thousand lanes each inverting one value
 };
 struct Fp2Ops {
     typedef Fp2 T;
@@ -689,6 +796,10 @@ struct Fp2Ops {
     }
     static MASP_HD T inv_lone(const T& a) {
         Fp n = fe_inv_fermat(fe_add(fe_mul_nc(a.c0, a.c0), fe_mul_nc(a.c1, a.c1)));
+        return {fe_mul_nc(a.c0, n), fe_neg(fe_mul_nc(a.c1, n))};
+    }
+    static MASP_HD T inv_gcd(const T& a) {
+        Fp n = fe_inv_bingcd(fe_add(fe_mul_nc(a.c0, a.c0), fe_mul_nc(a.c1, a.c1)));
         return {fe_mul_nc(a.c0, n), fe_neg(fe_mul_nc(a.c1, n))};
     }
 };

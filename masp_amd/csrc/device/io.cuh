@@ -54,7 +54,7 @@ MASP_HD void fe_store_le(const Fe<C>& canon, uint8_t* out) {
 }
 
 // status bits returned by the point readers
-enum : int { PT_OK = 0, PT_BAD_FLAGS = 1, PT_NOT_CANONICAL = 2, PT_INFINITY = 4 };
+enum : int { PT_OK = 0, PT_BAD_FLAGS = 1, PT_NOT_CANONICAL = 2, PT_INFINITY = 4, PT_NOT_IN_SUBGROUP = 8 };
 
 __host__ __device__ inline int g1_read_uncompressed(const uint8_t* in, G1Affine& p) {
     if (in[0] & 0x80) return PT_BAD_FLAGS;

@@ -60,13 +60,52 @@ __device__ inline bool fp2_sqrt(const Fp2& v, Fp2& out) {  // host/pairing.h Fp2
     out = {x0, x1};
     return Fp2Ops::eq(Fp2Ops::sqr(out), v);
 }
+// ---- subgroup membership (M. Scott, "A note on group membership tests for G1, G2 and GT on BLS pairing-friendly curves") ----
+// `groth16::Proof::read` rejects points outside the prime-order subgroups (bellman `from_compressed`; the reference parses
+// proofs with it at /root/reference/masp_proofs/src/sapling/verifier/batch.rs:85,125,154).  The pairing is blind to the cofactor
+// part of a point, so a verifier that skipped this test would accept malleated proofs the reference refuses.
+// G1: phi(x, y) = (beta x, y) is multiplication by -u^2 exactly on the subgroup: test [u^2] P + phi(P) = O (a 128-bit multiple).
+// G2: psi = twist . Frobenius . untwist is multiplication by u on the subgroup: test psi(Q) = [u] Q (a 64-bit multiple), u < 0.
+// Constants: tools/gen_device_consts.py (derived there and checked on the generators).  `p` on the curve, not infinity.
+__device__ inline bool g1_in_subgroup(const G1Affine& p) {
+    uint32_t k[8] = {FpCfg::U_SQR[0], FpCfg::U_SQR[1], FpCfg::U_SQR[2], FpCfg::U_SQR[3], 0, 0, 0, 0};
+    const G1Xyzz m = xyzz_mul_scalar(xyzz_from_affine(p), k);
+    if (xyzz_is_inf(m)) return false;
+    Fp beta;
+    for (int i = 0; i < 12; ++i) beta.v[i] = FpCfg::ENDO_BETA[i];
+    // -m == phi(p)  <=>  m.X = beta x ZZ  and  m.Y = -y ZZZ
+    return fe_eq(m.X, fe_mul_nc(fe_mul_nc(beta, p.x), m.ZZ)) && fe_eq(m.Y, fe_neg(fe_mul_nc(p.y, m.ZZZ)));
+}
+__device__ inline bool g2_in_subgroup(const G2Affine& q) {
+    uint32_t k[8] = {FpCfg::U_ABS[0], FpCfg::U_ABS[1], 0, 0, 0, 0, 0, 0};
+    const G2Xyzz m = xyzz_mul_scalar(xyzz_from_affine(q), k);   // [|u|] Q = -[u] Q
+    if (xyzz_is_inf(m)) return false;
+    Fp2 cx, cy;
+    for (int i = 0; i < 12; ++i) {
+        cx.c0.v[i] = FpCfg::PSI_CX0[i];
+        cx.c1.v[i] = FpCfg::PSI_CX1[i];
+        cy.c0.v[i] = FpCfg::PSI_CY0[i];
+        cy.c1.v[i] = FpCfg::PSI_CY1[i];
+    }
+    const Fp2 px = Fp2Ops::mul(cx, Fp2{q.x.c0, fe_neg(q.x.c1)}), py = Fp2Ops::mul(cy, Fp2{q.y.c0, fe_neg(q.y.c1)});
+    // psi(q) == -m  <=>  m.X = px ZZ  and  m.Y = -py ZZZ
+    return Fp2Ops::eq(m.X, Fp2Ops::mul(px, m.ZZ)) && Fp2Ops::eq(m.Y, Fp2Ops::neg(Fp2Ops::mul(py, m.ZZZ)));
+}
+// the encoding of the point at infinity: compression and infinity flags, nothing else (bellman rejects stray bits)
+__device__ inline bool infinity_encoding_is_clean(const uint8_t* in, int len) {
+    if ((in[0] & 0x3f) != 0) return false;
+    uint32_t acc = 0;
+    for (int i = 1; i < len; ++i) acc |= in[i];
+    return acc == 0;
+}
+
 // zcash compressed encodings -> affine (Montgomery).  PT_* status; PT_BAD_FLAGS also for "not on the curve"
 __device__ inline int g1_read_compressed(const uint8_t* in, G1Affine& p) {
     if (!(in[0] & 0x80)) return PT_BAD_FLAGS;
     if (in[0] & 0x40) {
         p.x = fe_zero<FpCfg>();
         p.y = fe_zero<FpCfg>();
-        return PT_INFINITY;
+        return infinity_encoding_is_clean(in, 48) ? PT_INFINITY : PT_BAD_FLAGS;
     }
     uint8_t t[48];
     for (int i = 0; i < 48; ++i) t[i] = in[i];
@@ -86,7 +125,7 @@ __device__ inline int g2_read_compressed(const uint8_t* in, G2Affine& p) {
     if (in[0] & 0x40) {
         p.x = Fp2Ops::zero();
         p.y = Fp2Ops::zero();
-        return PT_INFINITY;
+        return infinity_encoding_is_clean(in, 96) ? PT_INFINITY : PT_BAD_FLAGS;
     }
     uint8_t t[96];
     for (int i = 0; i < 96; ++i) t[i] = in[i];
@@ -110,7 +149,8 @@ __device__ inline int g2_read_compressed(const uint8_t* in, G2Affine& p) {
 __global__ void __launch_bounds__(64) k_verify_prepare(const uint8_t* __restrict__ proofs, const uint8_t* __restrict__ z, uint32_t n,
                                                        G1Affine* __restrict__ za, G2Affine* __restrict__ b, G1Xyzz* __restrict__ zc,
                                                        int* __restrict__ status) {
-    // gridDim.y = 3: y = 0 -> A, 1 -> C, 2 -> B (every wave does one kind of work; the G2 square root is the longest chain)
+    // gridDim.y = 5: y = 0 -> z A, 1 -> z C, 2 -> B and its subgroup test, 3 / 4 -> the subgroup tests of A / C (every wave does
+    // one kind of work; B's square root + 64-bit multiple is the longest chain, the tests of A and C run next to their multiples)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, what = blockIdx.y;
     if (i >= n) return;
     const uint8_t* pr = proofs + 192 * (size_t)i;
@@ -123,7 +163,12 @@ __global__ void __launch_bounds__(64) k_verify_prepare(const uint8_t* __restrict
     if (what == 2) {
         G2Affine q;
         st = g2_read_compressed(pr + 48, q);
+        if (st == PT_OK && !g2_in_subgroup(q)) st = PT_NOT_IN_SUBGROUP;
         b[i] = q;
+    } else if (what >= 3) {
+        G1Affine p;
+        st = g1_read_compressed(pr + (what == 3 ? 0 : 144), p);
+        st = st == PT_OK && !g1_in_subgroup(p) ? PT_NOT_IN_SUBGROUP : 0;   // (decoding errors are reported by the lanes of y = 0 / 1)
     } else {
         G1Affine p;
         st = g1_read_compressed(pr + (what == 0 ? 0 : 144), p);

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <vector>
 
+#include "../device/consts.cuh"
 #include "mont.h"
 
 namespace masp_host {
@@ -347,11 +348,81 @@ inline bool g2_uncompressed(G2A& p, const uint8_t* in) {
     p.inf = false;
     return Fp::from_be(p.x.b, in) && Fp::from_be(p.x.a, in + 48) && Fp::from_be(p.y.b, in + 96) && Fp::from_be(p.y.a, in + 144);
 }
+// ---- subgroup membership (same tests and constants as the device verifier, device/pairing.cuh) ------------------------
+// `groth16::Proof::read` refuses points outside the prime-order subgroups (/root/reference/masp_proofs/src/sapling/verifier/
+// batch.rs:85,125,154 parse with it); the pairing cannot see the cofactor part of a point, so a verifier without this test
+// accepts malleated proofs.  G1: (beta x, y) = -[u^2] P.  G2: psi(Q) = [u] Q.  (M. Scott's membership tests.)
+template <class F>
+struct JacT {  // Jacobian coordinates over Fp or Fp2, a = 0
+    F X, Y, Z;
+    bool is_inf() const { return Z.is_zero(); }
+    JacT dbl() const {
+        if (Z.is_zero()) return *this;
+        F A = X.sq(), B = Y.sq(), C = B.sq();
+        F t = (X + B).sq() - A - C, D = t + t, E = A + A + A;
+        F X3 = E.sq() - (D + D), C8 = C + C;
+        C8 = C8 + C8;
+        C8 = C8 + C8;
+        F YZ = Y * Z;
+        return {X3, E * (D - X3) - C8, YZ + YZ};
+    }
+    JacT add_affine(const F& x, const F& y) const {  // + (x, y), which is not infinity
+        if (Z.is_zero()) return {x, y, F::one()};
+        F z1 = Z.sq(), u2 = x * z1, s2 = y * Z * z1;
+        if (u2 == X) return s2 == Y ? dbl() : JacT{F::one(), F::one(), F::zero()};
+        F H = u2 - X, HH = H.sq(), I = HH + HH;
+        I = I + I;
+        F J = H * I, r = s2 - Y;
+        r = r + r;
+        F V = X * I, X3 = r.sq() - J - (V + V), YJ = Y * J;
+        return {X3, r * (V - X3) - (YJ + YJ), (Z + H).sq() - z1 - HH};
+    }
+    static JacT mul_u64(const F& x, const F& y, const uint64_t* k, int limbs) {
+        JacT r{F::one(), F::one(), F::zero()};
+        for (int i = 64 * limbs - 1; i >= 0; --i) {
+            r = r.dbl();
+            if ((k[i / 64] >> (i % 64)) & 1) r = r.add_affine(x, y);
+        }
+        return r;
+    }
+};
+inline Fp fp_from_mont_limbs32(const uint32_t* v) {  // device constants (32-bit limbs, radix 2^384) are the same bytes as ours
+    Fp r;
+    memcpy(r.l, v, 48);
+    return r;
+}
+inline bool g1_in_subgroup(const G1A& p) {  // p on the curve, not infinity
+    const uint64_t k[2] = {(uint64_t)masp::FpCfg::U_SQR[0] | ((uint64_t)masp::FpCfg::U_SQR[1] << 32),
+                           (uint64_t)masp::FpCfg::U_SQR[2] | ((uint64_t)masp::FpCfg::U_SQR[3] << 32)};
+    const JacT<Fp> m = JacT<Fp>::mul_u64(p.x, p.y, k, 2);
+    if (m.is_inf()) return false;
+    const Fp z2 = m.Z.sq(), z3 = z2 * m.Z, bx = fp_from_mont_limbs32(masp::FpCfg::ENDO_BETA) * p.x;
+    return m.X == bx * z2 && m.Y == (p.y * z3).neg();  // [u^2] P = -phi(P)
+}
+inline bool g2_in_subgroup(const G2A& q) {
+    const uint64_t k[1] = {(uint64_t)masp::FpCfg::U_ABS[0] | ((uint64_t)masp::FpCfg::U_ABS[1] << 32)};
+    const JacT<Fp2> m = JacT<Fp2>::mul_u64(q.x, q.y, k, 1);  // [|u|] Q = -[u] Q
+    if (m.is_inf()) return false;
+    const Fp2 cx{fp_from_mont_limbs32(masp::FpCfg::PSI_CX0), fp_from_mont_limbs32(masp::FpCfg::PSI_CX1)};
+    const Fp2 cy{fp_from_mont_limbs32(masp::FpCfg::PSI_CY0), fp_from_mont_limbs32(masp::FpCfg::PSI_CY1)};
+    const Fp2 px = cx * Fp2{q.x.a, q.x.b.neg()}, py = cy * Fp2{q.y.a, q.y.b.neg()};
+    const Fp2 z2 = m.Z.sq(), z3 = z2 * m.Z;
+    return m.X == px * z2 && m.Y == (py * z3).neg();
+}
+// the point at infinity is the compression + infinity flags and nothing else (bellman rejects stray bits)
+inline bool infinity_encoding_is_clean(const uint8_t* in, int len) {
+    if (in[0] & 0x3f) return false;
+    for (int i = 1; i < len; ++i)
+        if (in[i]) return false;
+    return true;
+}
+
+// zcash compressed encodings as `Proof::read` accepts them: canonical, on the curve AND in the prime-order subgroup
 inline bool g1_compressed(G1A& p, const uint8_t* in) {
     if (!(in[0] & 0x80)) return false;
     if (in[0] & 0x40) {
         p = {Fp::zero(), Fp::zero(), true};
-        return true;
+        return infinity_encoding_is_clean(in, 48);
     }
     uint8_t t[48];
     memcpy(t, in, 48);
@@ -361,13 +432,13 @@ inline bool g1_compressed(G1A& p, const uint8_t* in) {
     if (!(p.x.sq() * p.x + Fp::from_u64(4)).sqrt(p.y)) return false;
     if (p.y.lex_largest() != big) p.y = p.y.neg();
     p.inf = false;
-    return true;
+    return g1_in_subgroup(p);
 }
 inline bool g2_compressed(G2A& p, const uint8_t* in) {
     if (!(in[0] & 0x80)) return false;
     if (in[0] & 0x40) {
         p = {Fp2::zero(), Fp2::zero(), true};
-        return true;
+        return infinity_encoding_is_clean(in, 96);
     }
     uint8_t t[96];
     memcpy(t, in, 96);
@@ -379,7 +450,7 @@ inline bool g2_compressed(G2A& p, const uint8_t* in) {
     bool lg = p.y.b.is_zero() ? p.y.a.lex_largest() : p.y.b.lex_largest();
     if (lg != big) p.y = p.y.neg();
     p.inf = false;
-    return true;
+    return g2_in_subgroup(p);
 }
 
 // ---- pairing ---------------------------------------------------------------------------------------------

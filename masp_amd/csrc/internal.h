@@ -163,6 +163,14 @@ struct Slot {
         if (h_proof) hipHostFree(h_proof);
         if (h_flags) hipHostFree(h_flags);
     }
+    // the options of the owning context that the slot's launch sequences depend on
+    void configure(const masp_hip_options& o) {
+        ntt_sub = (uint32_t)o.ntt_sub_batch;
+        ws1.tree_levels = o.bucket_tree_levels;
+        ws2.tree_levels = o.bucket_tree_levels_g2;
+        ws1.tree_sub = ws2.tree_sub = (uint32_t)o.bucket_tree_sub_batch;
+        ws2.tree.arena = &ws1.tree.own;   // the G1 and G2 MSMs of a batch follow each other on the slot's stream: one tree arena
+    }
     int init() {
         HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));

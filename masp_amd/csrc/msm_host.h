@@ -20,6 +20,7 @@ template <class O, int BYTES>
 struct MsmBases {
     MsmGeom g{};
     uint32_t n = 0;
+    uint32_t n_eff = 0;        // scalars expected to be neither 0 nor 1 (<= n): the mean length of a bucket's run follows from it
     TabRow<O>* tab = nullptr;  // W * n rows of 128 / 256 bytes
     int import_status = 0;     // PT_* bits seen while decoding
 
@@ -105,6 +106,48 @@ struct MsmSortBuf {
     }
 };
 
+// ---- scratch of the batch-affine pre-reduction (device/msm_tree.cuh) for up to q proofs at a time ---------------------
+// One byte arena serves every tree of a slot (its G1 and G2 MSMs run one after the other on the slot's stream): the views below
+// are carved out of it anew by every msm_tree_enqueue.
+struct MsmTreeArena {
+    uint8_t* p = nullptr;
+    size_t cap = 0;
+    ~MsmTreeArena() { release(); }
+    void release() {
+        if (p) hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return MASP_HIP_OK;
+        release();  // (capacity is 0 from here on: a failed allocation must not leave it claiming memory)
+        HIP_TRY(hipMalloc(&p, bytes));
+        cap = bytes;
+        return MASP_HIP_OK;
+    }
+};
+template <class O>
+struct MsmTreeWs {
+    typedef typename O::T F;
+    static constexpr uint32_t BINV_C = 16, BINV_MID = 4096;  // chain length / lanes with an inversion of their own (batch_invert)
+    MsmTreeArena own;
+    MsmTreeArena* arena = &own;           // a slot points the trees of its workspaces at one arena
+    uint32_t *D = nullptr, *Q = nullptr;  // [level][proof][nb + 1]
+    uint4* rec = nullptr;  // pair records: uint4 at level 0, uint2 (same buffer) at the deeper levels
+    F *pre = nullptr, *tp = nullptr, *tinv = nullptr, *bpre = nullptr, *btot = nullptr, *bitot = nullptr, *bpre2 = nullptr;
+    F *px[2] = {nullptr, nullptr}, *py[2] = {nullptr, nullptr};  // points of the odd / even levels
+    // what the last msm_tree_enqueue produced
+    uint32_t q = 0, nb = 0, T = 0;
+    size_t stride[2] = {0, 0};
+
+    int reserve(uint64_t E_ub, uint32_t nb, uint32_t q, uint32_t T);                 // [msm_tree_impl.cuh]
+    void batch_invert(hipStream_t s, const F* in, uint32_t n, F* out);              // [msm_tree_impl.cuh]
+    const F* points_x() const { return px[T & 1]; }
+    const F* points_y() const { return py[T & 1]; }
+    size_t point_stride() const { return stride[T & 1]; }
+    const uint32_t* plan_D(uint32_t L) const { return D + (size_t)L * q * (nb + 1); }
+};
+
 // ---- workspace of the group arithmetic ---------------------------------------------------------------
 template <class O>
 struct MsmWorkspace {
@@ -112,6 +155,13 @@ struct MsmWorkspace {
     static constexpr uint32_t NCHUNKS = 1u << 18;     // lanes of the accumulation kernel (1024 waves x 4 per SIMD)
 
     MsmSortBuf sort;  // used unless the caller shares another workspace's sort
+    // batch-affine pre-reduction of the bucket runs (batches only): tree_levels < 0 off, 0 = the default (3, fewer for very
+    // short runs), else that many levels; tree_sub proofs go through the tree at a time (its scratch is ~0.4 GB per Spend proof)
+    MsmTreeWs<O> tree;
+    int tree_levels = 0;
+    uint32_t tree_sub = 64;
+    uint32_t* startT = nullptr;  // [np][nb + 1] bucket offsets of the points the tree leaves
+    size_t cap_startT = 0;
     size_t cap_nb = 0, cap_np = 0, cap_part = 0;  // cap_part: elements of `part` (np x (chunks + nb) of the largest launch)
     uint32_t *heavy = nullptr, *n_heavy = nullptr;
     Xyzz<O>*part = nullptr, *bkt = nullptr, *S[2] = {nullptr, nullptr}, *T = nullptr, *R[2] = {nullptr, nullptr};
@@ -119,10 +169,11 @@ struct MsmWorkspace {
 
     ~MsmWorkspace() { release(); }
     void release() {
-        void* ptrs[] = {heavy, n_heavy, part, bkt, S[0], S[1], T, R[0], R[1], tsum};
+        void* ptrs[] = {heavy, n_heavy, part, bkt, S[0], S[1], T, R[0], R[1], tsum, startT};
         for (void* p : ptrs)
             if (p) hipFree(p);
-        heavy = n_heavy = nullptr;
+        heavy = n_heavy = startT = nullptr;
+        cap_startT = 0;
         part = bkt = S[0] = S[1] = T = R[0] = R[1] = tsum = nullptr;
         cap_nb = cap_np = cap_part = 0;
     }
@@ -165,6 +216,7 @@ struct MsmWorkspace {
             HIP_TRY(hipMalloc(&R[0], P * sizeof(Xyzz<O>) * chunks));
             HIP_TRY(hipMalloc(&R[1], P * sizeof(Xyzz<O>) * chunks));
             HIP_TRY(hipMalloc(&tsum, P * sizeof(Xyzz<O>) * 32));
+            HIP_TRY(hipMalloc(&startT, P * 4 * (need_nb + 1)));
             return MASP_HIP_OK;
         };
         if (int rc = alloc_all()) {
@@ -238,6 +290,14 @@ int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb
 template <class O>
 void msm_launch_accumulate(hipStream_t s, const TabRow<O>* tab, const uint32_t* sorted, size_t ent_stride, const uint32_t* start, uint32_t nb,
                            uint32_t nchunks, Xyzz<O>* part, uint32_t np);
+
+// Batch-affine pre-reduction (device/msm_tree.cuh) of proofs [p0, p0 + q) of the sort `sb`: T levels.   [msm_tree_impl.cuh]
+template <class O, int BYTES>
+int msm_tree_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSortBuf& sb, MsmTreeWs<O>& tw, uint32_t p0, uint32_t q, uint32_t T);
+// k_msm_accumulate over explicit points instead of gathered table rows                                   [msm_tree_impl.cuh]
+template <class O>
+void msm_launch_accumulate_pts(hipStream_t s, const typename O::T* xs, const typename O::T* ys, size_t pt_stride, const uint32_t* start, uint32_t nb,
+                               uint32_t nchunks, Xyzz<O>* part, uint32_t np);
 
 // Bucket accumulation + reduction of the MSM whose digits were sorted into `sb` (same n, geometry and batch size):
 // result p at d_out + p * out_stride.  No host synchronisation.                                    [msm_impl.cuh]

@@ -6,10 +6,17 @@
 
 namespace masp {
 
+static inline uint32_t log2_ceil_u64(uint64_t n) {
+    uint32_t k = 0;
+    while ((1ull << k) < n) ++k;
+    return k;
+}
+
 template <class O, int BYTES>
 int MsmBases<O, BYTES>::load_device(const uint8_t* d_raw, uint32_t n_, hipStream_t s, uint32_t n_eff, int force_c) {
         release();
         n = n_;
+        this->n_eff = std::min(n_eff, n_);
         g = force_c ? msm_geom(force_c) : pick_geom(std::min(n_eff, n_));
         if (n == 0) return MASP_HIP_OK;
         HIP_TRY(hipMalloc(&tab, sizeof(TabRow<O>) * (size_t)g.W * n));
@@ -77,12 +84,36 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
         rec.alg_bytes = (uint64_t)np * n * (BYTES + 32);  // n x (affine base + scalar) per proof
         hipEventRecord(rec.e0, s);
     }
-    msm_launch_accumulate<O>(s, B.tab, sb.sorted, (size_t)total, sb.start, nb, nchunks, ws.part, np);
+    const bool lone = np < 8;  // latency regime: short chains matter more than total work
+    // The tree halves the bucket runs T times: 1 - 2^-T of the additions at 5.8 instead of 9.6 products.  Every level costs two
+    // passes over its points and a latency-bound shared inversion (~0.6 ms per sub-batch), so T stays small: measured on 256
+    // Spend proofs, 4 batches in flight, sub-batches of 64: T = 3 +7 %, 4 +6 %, 5 +5.5 %, T = log2(mean run) - 1 = 6 / 8 +3 % over
+    // the XYZZ accumulation alone.  Runs shorter than 16 points (mean: n_eff W digits over nb buckets) get fewer levels.
+    uint32_t tree_T = 0;
+    if (!lone && ws.tree_levels >= 0) {
+        const uint64_t mean = std::max<uint64_t>((uint64_t)std::max(B.n_eff, 1u) * g.W / nb, 1);
+        const uint32_t by_len = log2_ceil_u64(mean) > 1 ? (uint32_t)log2_ceil_u64(mean) - 1 : 0;
+        tree_T = ws.tree_levels > 0 ? std::min((uint32_t)ws.tree_levels, 12u) : std::min(3u, by_len);
+    }
+    const uint32_t* start = sb.start;
+    if (tree_T) {
+        const uint32_t sub = std::max(1u, std::min(ws.tree_sub, np));
+        for (uint32_t p0 = 0; p0 < np; p0 += sub) {
+            const uint32_t q = std::min(sub, np - p0);
+            if ((rc = msm_tree_enqueue<O, BYTES>(s, B, sb, ws.tree, p0, q, tree_T))) return rc;
+            msm_launch_accumulate_pts<O>(s, ws.tree.points_x(), ws.tree.points_y(), ws.tree.point_stride(), ws.tree.plan_D(tree_T), nb, nchunks,
+                                         ws.part + (size_t)p0 * ((size_t)nchunks + nb), q);
+            // the bucket tails run over the whole batch: keep this sub-batch's offsets (the next one overwrites the plan)
+            HIP_TRY(hipMemcpyAsync(ws.startT + (size_t)p0 * (nb + 1), ws.tree.plan_D(tree_T), sizeof(uint32_t) * q * (nb + 1), hipMemcpyDeviceToDevice, s));
+        }
+        start = ws.startT;
+    } else {
+        msm_launch_accumulate<O>(s, B.tab, sb.sorted, (size_t)total, sb.start, nb, nchunks, ws.part, np);
+    }
     if (prof) {
         hipEventRecord(rec.e1, s);
         prof->recs.push_back(rec);
     }
-    const bool lone = np < 8;  // latency regime: short chains matter more than total work
     // A bucket whose entries are spread over `span` chunks or more leaves the gather lanes for a workgroup of its own
     // (k_msm_bucket_heavy: strided sums + shuffle tree).  Batches: span 8 and SINGLE-WAVE workgroups, 65 per proof — the G2
     // kernels hold 512 VGPRs, i.e. a whole SIMD per wave, and all but a handful of these workgroups find no work: at four
@@ -90,15 +121,15 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
     // end).  A lone proof keeps span 12 and four waves (shortest chain for its one big bucket).
     // Workgroups go to the 8 XCDs round-robin by linear id x + gridDim.x * y, so with gridDim.x a multiple of 8 every proof's
     // first working workgroup (x = 0: bucket 0) would land on the same XCD: keep gridDim.x odd.
-    hipLaunchKernelGGL((k_msm_bucket_gather<O>), dim3((nb + 63) / 64, np), dim3(64), 0, s, ws.part, sb.start, nb, nchunks, ws.bkt, ws.heavy,
+    hipLaunchKernelGGL((k_msm_bucket_gather<O>), dim3((nb + 63) / 64, np), dim3(64), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy,
                        ws.n_heavy, lone ? 12u : 8u);
     if (lone) {
         const uint32_t heavy_blocks = std::min<uint32_t>(std::max<uint32_t>(4096u / np, 16u), nb) | 1u;
-        hipLaunchKernelGGL((k_msm_bucket_heavy<O, 256>), dim3(heavy_blocks, np), dim3(256), 0, s, ws.part, sb.start, nb, nchunks, ws.bkt, ws.heavy,
+        hipLaunchKernelGGL((k_msm_bucket_heavy<O, 256>), dim3(heavy_blocks, np), dim3(256), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy,
                            ws.n_heavy);
     } else {
         const uint32_t heavy_blocks = std::min<uint32_t>(64u, nb) | 1u;
-        hipLaunchKernelGGL((k_msm_bucket_heavy<O, 64>), dim3(heavy_blocks, np), dim3(64), 0, s, ws.part, sb.start, nb, nchunks, ws.bkt, ws.heavy,
+        hipLaunchKernelGGL((k_msm_bucket_heavy<O, 64>), dim3(heavy_blocks, np), dim3(64), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy,
                            ws.n_heavy);
     }
     // weighted sum by levels of (G x 128)-bucket workgroups.  Per lane the kernel costs 2 G additions for its buckets plus

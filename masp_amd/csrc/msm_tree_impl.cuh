@@ -1,0 +1,131 @@
+// Host driver of the batch-affine pre-reduction (device/msm_tree.cuh): instantiated per curve in k_msm_g1_tree.hip /
+// k_msm_g2_tree.hip.
+#pragma once
+#include "device/msm_tree.cuh"
+#include "msm_host.h"
+
+namespace masp {
+
+// ---- geometry of a level (host side; the device works with the exact counts of D / Q) -----------------------------------
+// E_ub: upper bound of a proof's digit-list length.  Points of level L <= E / 2^L + nb, pairs <= E / 2^(L+1) + nb / 2 + 1.
+static inline uint32_t tree_points_ub(uint64_t E_ub, uint32_t nb, uint32_t L) { return (uint32_t)((E_ub >> L) + nb + 1); }
+static inline uint32_t tree_pairs_ub(uint64_t E_ub, uint32_t nb, uint32_t L) { return (uint32_t)((E_ub >> (L + 1)) + nb / 2 + 1); }
+// lanes per proof of the two passes: ~MSM_TREE_KP pairs per lane, whole workgroups
+static constexpr uint32_t MSM_TREE_KP = 32;
+static inline uint32_t tree_lanes(uint64_t E_ub, uint32_t nb, uint32_t L) {
+    const uint32_t pairs = tree_pairs_ub(E_ub, nb, L);
+    return std::max<uint32_t>(256u, ((pairs + MSM_TREE_KP - 1) / MSM_TREE_KP + 255u) & ~255u);
+}
+
+template <class O>
+int MsmTreeWs<O>::reserve(uint64_t E_ub, uint32_t nb, uint32_t q, uint32_t T) {
+    const size_t plan = (size_t)(T + 1) * q * (nb + 1);
+    const size_t recs = (size_t)q * tree_pairs_ub(E_ub, nb, 0);
+    const size_t NT0 = tree_lanes(E_ub, nb, 0);
+    const size_t lanes = (size_t)q * NT0;
+    // pre[(j q + p) NT + t], j < ceil(pairs / NT) <= KP (+1 for the rounding of NT): bounded by level 0
+    const size_t pres = (size_t)((tree_pairs_ub(E_ub, nb, 0) + NT0 - 1) / NT0) * lanes;
+    const size_t pts1 = (size_t)q * tree_points_ub(E_ub, nb, 1), pts2 = T >= 2 ? (size_t)q * tree_points_ub(E_ub, nb, 2) : 0;
+    const size_t m1 = (lanes + BINV_C - 1) / BINV_C;
+    // carve: every view 256-byte aligned
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return at;
+    };
+    const size_t oD = take(4 * plan), oQ = take(4 * plan), oRec = take(sizeof(uint4) * recs), oPre = take(sizeof(F) * pres), oTp = take(sizeof(F) * lanes),
+                 oTinv = take(sizeof(F) * lanes), oBpre = take(sizeof(F) * lanes), oBtot = take(sizeof(F) * m1), oBitot = take(sizeof(F) * m1),
+                 oBpre2 = take(sizeof(F) * m1), oX1 = take(sizeof(F) * pts1), oY1 = take(sizeof(F) * pts1), oX0 = take(sizeof(F) * pts2),
+                 oY0 = take(sizeof(F) * pts2);
+    int rc = arena->reserve(off);
+    if (rc) return rc;
+    uint8_t* b = arena->p;
+    D = (uint32_t*)(b + oD);
+    Q = (uint32_t*)(b + oQ);
+    rec = (uint4*)(b + oRec);
+    pre = (F*)(b + oPre);
+    tp = (F*)(b + oTp);
+    tinv = (F*)(b + oTinv);
+    bpre = (F*)(b + oBpre);
+    btot = (F*)(b + oBtot);
+    bitot = (F*)(b + oBitot);
+    bpre2 = (F*)(b + oBpre2);
+    px[1] = (F*)(b + oX1);
+    py[1] = (F*)(b + oY1);
+    px[0] = (F*)(b + oX0);
+    py[0] = (F*)(b + oY0);
+    return MASP_HIP_OK;
+}
+
+// out[i] = 1 / in[i], i < n (no zeros among them), on stream s: chains of BINV_C products, then <= BINV_MID lanes with one
+// inversion each, then the chains backwards
+template <class O>
+void MsmTreeWs<O>::batch_invert(hipStream_t s, const F* in, uint32_t n, F* out) {
+    if (n <= 4 * BINV_MID) {
+        const uint32_t M = std::min<uint32_t>(n, BINV_MID);
+        hipLaunchKernelGGL((k_binv_mid<O>), dim3((M + 63) / 64), dim3(64), 0, s, in, n, M, bpre, out);
+        return;
+    }
+    const uint32_t M1 = (n + BINV_C - 1) / BINV_C, M2 = std::min<uint32_t>(M1, BINV_MID);
+    hipLaunchKernelGGL((k_binv_fwd<O>), dim3((M1 + 255) / 256), dim3(256), 0, s, in, n, M1, bpre, btot);
+    hipLaunchKernelGGL((k_binv_mid<O>), dim3((M2 + 63) / 64), dim3(64), 0, s, (const F*)btot, M1, M2, bpre2, bitot);
+    hipLaunchKernelGGL((k_binv_bwd<O>), dim3((M1 + 255) / 256), dim3(256), 0, s, in, n, M1, (const F*)bpre, (const F*)bitot, out);
+}
+
+// T levels of pairwise affine additions over the digit lists of proofs [p0, p0 + q) of the sort `sb`.  Afterwards the points of
+// proof p0 + i lie at points_x() / points_y() + i * point_stride(), bucket b of it at [DT[b], DT[b + 1]) with
+// DT = plan_D(T) + i * (nb + 1).  No host synchronisation.
+template <class O, int BYTES>
+int msm_tree_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSortBuf& sb, MsmTreeWs<O>& tw, uint32_t p0, uint32_t q, uint32_t T) {
+    typedef typename O::T F;
+    const uint32_t nb = (uint32_t)B.g.nb;
+    const uint64_t E_ub = (uint64_t)B.n * B.g.W;
+    int rc = tw.reserve(E_ub, nb, q, T);
+    if (rc) return rc;
+    tw.q = q;
+    tw.nb = nb;
+    tw.T = T;
+    tw.stride[1] = tree_points_ub(E_ub, nb, 1);
+    tw.stride[0] = tree_points_ub(E_ub, nb, 2);
+    const size_t ent_stride = E_ub;
+    const uint32_t* sorted = sb.sorted + (size_t)p0 * ent_stride;
+    const uint32_t* start = sb.start + (size_t)p0 * (nb + 1);
+    hipLaunchKernelGGL(k_tree_plan, dim3(T + 1, q), dim3(1024), 0, s, start, nb, tw.D, tw.Q);
+    const size_t lvl = (size_t)q * (nb + 1);
+    const size_t rec_stride = tree_pairs_ub(E_ub, nb, 0);
+    for (uint32_t L = 0; L < T; ++L) {
+        const uint32_t *Dl = tw.D + L * lvl, *Dn = tw.D + (L + 1) * lvl, *Ql = tw.Q + L * lvl;
+        const uint32_t NT = tree_lanes(E_ub, nb, L), pairs_ub = tree_pairs_ub(E_ub, nb, L);
+        const F *xi = tw.px[L & 1], *yi = tw.py[L & 1];
+        F *xo = tw.px[(L + 1) & 1], *yo = tw.py[(L + 1) & 1];
+        const size_t si = tw.stride[L & 1], so = tw.stride[(L + 1) & 1];
+        const dim3 rgrid(std::min<uint32_t>((pairs_ub + 255) / 256, 4096u), q), grid(NT / 256, q), cgrid((nb + 255) / 256, q), block(256);
+        if (L == 0) {
+            hipLaunchKernelGGL(k_tree_records<true>, rgrid, block, 0, s, sorted, ent_stride, Dl, Dn, Ql, nb, (void*)tw.rec, rec_stride);
+            hipLaunchKernelGGL((k_tree_pass1<O, true>), grid, block, 0, s, B.tab, xi, yi, si, (const void*)tw.rec, rec_stride, Ql, nb, NT, tw.pre, tw.tp);
+        } else {
+            hipLaunchKernelGGL(k_tree_records<false>, rgrid, block, 0, s, sorted, ent_stride, Dl, Dn, Ql, nb, (void*)tw.rec, rec_stride);
+            hipLaunchKernelGGL((k_tree_pass1<O, false>), grid, block, 0, s, B.tab, xi, yi, si, (const void*)tw.rec, rec_stride, Ql, nb, NT, tw.pre, tw.tp);
+        }
+        tw.batch_invert(s, tw.tp, q * NT, tw.tinv);
+        if (L == 0) {
+            hipLaunchKernelGGL((k_tree_pass2<O, true>), grid, block, 0, s, B.tab, xi, yi, si, (const void*)tw.rec, rec_stride, Ql, nb, NT, (const F*)tw.pre,
+                               (const F*)tw.tinv, xo, yo, so);
+            hipLaunchKernelGGL((k_tree_copy<O, true>), cgrid, block, 0, s, B.tab, sorted, ent_stride, xi, yi, si, Dl, Dn, nb, xo, yo, so);
+        } else {
+            hipLaunchKernelGGL((k_tree_pass2<O, false>), grid, block, 0, s, B.tab, xi, yi, si, (const void*)tw.rec, rec_stride, Ql, nb, NT, (const F*)tw.pre,
+                               (const F*)tw.tinv, xo, yo, so);
+            hipLaunchKernelGGL((k_tree_copy<O, false>), cgrid, block, 0, s, B.tab, sorted, ent_stride, xi, yi, si, Dl, Dn, nb, xo, yo, so);
+        }
+    }
+    return MASP_HIP_OK;
+}
+
+template <class O>
+void msm_launch_accumulate_pts(hipStream_t s, const typename O::T* xs, const typename O::T* ys, size_t pt_stride, const uint32_t* start, uint32_t nb,
+                               uint32_t nchunks, Xyzz<O>* part, uint32_t np) {
+    hipLaunchKernelGGL((k_msm_accumulate_pts<O>), dim3((nchunks + 63) / 64, np), dim3(64), 0, s, xs, ys, pt_stride, start, nb, nchunks, part);
+}
+
+}  // namespace masp

@@ -40,6 +40,9 @@ static masp_hip_options resolve_options(const masp_hip_options* in) {
     o.window_bits_b2_lone = o.window_bits_b2_lone > 0 ? o.window_bits_b2_lone : o.window_bits_b2_lone < 0 ? 0 : 8;  // resolved: 0 = not built
     // ~30 % of a MASP witness is neither 0 nor 1; measured +3..5 % throughput vs 100
     o.witness_nontrivial_percent = o.witness_nontrivial_percent > 0 ? std::min<int>(o.witness_nontrivial_percent, 100) : 30;
+    o.bucket_tree_levels = o.bucket_tree_levels > 0 ? std::min<int>(o.bucket_tree_levels, 12) : o.bucket_tree_levels < 0 ? -1 : 0;  // resolved: 0 = automatic
+    o.bucket_tree_sub_batch = o.bucket_tree_sub_batch > 0 ? std::min<int>(o.bucket_tree_sub_batch, 256) : 64;
+    o.bucket_tree_levels_g2 = o.bucket_tree_levels_g2 > 0 ? std::min<int>(o.bucket_tree_levels_g2, 12) : o.bucket_tree_levels_g2 < 0 ? -1 : o.bucket_tree_levels;
     return o;
 }
 // [0, n) cut into ceil(n / cap) groups whose sizes differ by at most one: (first, count) pairs
@@ -63,12 +66,13 @@ static int ensure_slots(masp_hip_ctx* ctx, size_t want) {
         std::unique_ptr<Slot> s(new Slot);
         int rc = s->init();
         if (rc) return rc;
+        s->configure(ctx->opt);
         ctx->slots.push_back(std::move(s));
         ctx->slot_busy.push_back(0);
     }
     for (auto& sl : ctx->slots) {
         sl->profiling = ctx->profiling;
-        sl->ntt_sub = (uint32_t)ctx->opt.ntt_sub_batch;
+        sl->configure(ctx->opt);
     }
     return MASP_HIP_OK;
 }
@@ -87,7 +91,7 @@ static int slot_try_acquire(masp_hip_ctx* ctx, size_t* si) {
     int rc = s->init();
     if (rc) return rc;
     s->profiling = ctx->profiling;
-    s->ntt_sub = (uint32_t)ctx->opt.ntt_sub_batch;
+    s->configure(ctx->opt);
     ctx->slots.push_back(std::move(s));
     ctx->slot_busy.push_back(1);
     *si = ctx->slots.size() - 1;
@@ -829,6 +833,43 @@ int masp_hip_prove(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* inputs, cons
 }  // extern "C"
 
 // ---- building blocks ----------------------------------------------------------------------------
+// np MSMs over ONE base set (how a batch of proofs uses the engine: gridDim.y = np, one launch per stage):
+// scalars np x n x 32 B, out np x BYTES uncompressed.  window_bits 0 = the engine's own choice for n.
+template <class O, int BYTES>
+static int msm_multi(masp_hip_ctx* ctx, const uint8_t* bases, size_t n, const uint8_t* scalars, size_t np, int window_bits, uint8_t* out) {
+    if (!ctx || !out || !np || np > 256 || !n || !bases || !scalars || n > (1u << 22) || window_bits < 0 || window_bits == 1 || window_bits > 16)
+        return MASP_HIP_E_INVALID_ARG;
+    if (!ctx->children.empty()) ctx = ctx->children[0];
+    std::unique_lock<std::shared_mutex> lock(ctx->mu);
+    hipSetDevice(ctx->device);
+    hipStream_t s = ctx->main_stream;
+    for (size_t i = 0; i < n * np; ++i)
+        if (!rs_in_range(scalars + 32 * i)) return MASP_HIP_E_SCALAR_RANGE;
+    MsmBases<O, BYTES> B;
+    MsmWorkspace<O> ws;
+    ws.tree_levels = ctx->opt.bucket_tree_levels;
+    ws.tree_sub = (uint32_t)ctx->opt.bucket_tree_sub_batch;
+    DevBuf<Xyzz<O>> res;
+    DevBuf<uint8_t> d_out;
+    int rc;
+    if ((rc = B.load_host(bases, (uint32_t)n, s, 0xffffffffu, window_bits))) return fail(ctx, rc);
+    if (B.import_status & (PT_BAD_FLAGS | PT_NOT_CANONICAL)) return MASP_HIP_E_PARAMS_FORMAT;
+    if ((rc = ctx->tmp_scalars.upload((const Fr*)scalars, n * np, s)) || (rc = res.reserve(np)) || (rc = d_out.reserve(BYTES * np))) return fail(ctx, rc);
+    if ((rc = msm_enqueue(s, B, ws, (const uint32_t*)ctx->tmp_scalars.p, n * 8, res.p, 1, (uint32_t)np))) return fail(ctx, rc);
+    for (size_t p = 0; p < np; ++p) {
+        if constexpr (BYTES == 96)
+            launch_g1_export(s, res.p + p, d_out.p + BYTES * p);
+        else
+            launch_g2_export(s, res.p + p, d_out.p + BYTES * p);
+    }
+    std::vector<uint8_t> tmp(BYTES * np);
+    if (hipMemcpyAsync(tmp.data(), d_out.p, tmp.size(), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        last_hip_error() = std::string("msm failed: ") + hipGetErrorString(hipGetLastError());
+        return fail(ctx, MASP_HIP_E_HIP);
+    }
+    memcpy(out, tmp.data(), tmp.size());
+    return MASP_HIP_OK;
+}
 template <class O, int BYTES, class X>
 static int msm_block(masp_hip_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t* out, DevBuf<X>& res) {
     if (!ctx || !out || (n && (!bases || !scalars)) || n > (1u << 26)) return MASP_HIP_E_INVALID_ARG;
@@ -872,34 +913,11 @@ int masp_hip_msm_g2(masp_hip_ctx* ctx, const uint8_t* bases, const uint8_t* scal
     return msm_block<Fp2Ops, 192>(ctx, bases, scalars, n, out, ctx->tmp_g2);
 }
 
-// np MSMs over ONE base set (how a batch of proofs uses the engine: gridDim.y = np, one launch per stage):
-// scalars np x n x 32 B, out np x 96 B uncompressed.  window_bits 0 = the engine's own choice for n.
 int masp_hip_msm_g1_multi(masp_hip_ctx* ctx, const uint8_t* bases, size_t n, const uint8_t* scalars, size_t np, int window_bits, uint8_t* out) {
-    if (!ctx || !out || !np || np > 256 || !n || !bases || !scalars || n > (1u << 22) || window_bits < 0 || window_bits == 1 || window_bits > 16)
-        return MASP_HIP_E_INVALID_ARG;
-    ctx = FIRST_DEVICE(ctx);
-    std::unique_lock<std::shared_mutex> lock(ctx->mu);
-    hipSetDevice(ctx->device);
-    hipStream_t s = ctx->main_stream;
-    for (size_t i = 0; i < n * np; ++i)
-        if (!rs_in_range(scalars + 32 * i)) return MASP_HIP_E_SCALAR_RANGE;
-    BasesG1 B;
-    MsmWorkspace<FpOps> ws;
-    DevBuf<G1Xyzz> res;
-    DevBuf<uint8_t> d_out;
-    int rc;
-    if ((rc = B.load_host(bases, (uint32_t)n, s, 0xffffffffu, window_bits))) return fail(ctx, rc);
-    if (B.import_status & (PT_BAD_FLAGS | PT_NOT_CANONICAL)) return MASP_HIP_E_PARAMS_FORMAT;
-    if ((rc = ctx->tmp_scalars.upload((const Fr*)scalars, n * np, s)) || (rc = res.reserve(np)) || (rc = d_out.reserve(96 * np))) return fail(ctx, rc);
-    if ((rc = msm_enqueue(s, B, ws, (const uint32_t*)ctx->tmp_scalars.p, n * 8, res.p, 1, (uint32_t)np))) return fail(ctx, rc);
-    for (size_t p = 0; p < np; ++p) launch_g1_export(s, res.p + p, d_out.p + 96 * p);
-    std::vector<uint8_t> tmp(96 * np);
-    if (hipMemcpyAsync(tmp.data(), d_out.p, tmp.size(), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-        last_hip_error() = std::string("msm failed: ") + hipGetErrorString(hipGetLastError());
-        return fail(ctx, MASP_HIP_E_HIP);
-    }
-    memcpy(out, tmp.data(), tmp.size());
-    return MASP_HIP_OK;
+    return msm_multi<FpOps, 96>(ctx, bases, n, scalars, np, window_bits, out);
+}
+int masp_hip_msm_g2_multi(masp_hip_ctx* ctx, const uint8_t* bases, size_t n, const uint8_t* scalars, size_t np, int window_bits, uint8_t* out) {
+    return msm_multi<Fp2Ops, 192>(ctx, bases, n, scalars, np, window_bits, out);
 }
 
 int masp_hip_quotient_h(masp_hip_ctx* ctx, const uint8_t* a, const uint8_t* b, const uint8_t* c, size_t nrows, uint32_t logm, uint8_t* h_out) {

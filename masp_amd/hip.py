@@ -21,12 +21,12 @@ class MaspHipError(RuntimeError):
 
 
 OPTION_FIELDS = ("slots", "batch_cap", "ntt_sub_batch", "window_bits_h", "window_bits_la", "window_bits_b", "window_bits_b2_lone",
-                 "witness_nontrivial_percent")
+                 "witness_nontrivial_percent", "bucket_tree_levels", "bucket_tree_sub_batch", "bucket_tree_levels_g2")
 
 
 class OptionsStruct(C.Structure):
     """masp_hip_options (include/masp_hip.h): every field 0 = the default."""
-    _fields_ = [("struct_size", C.c_uint32)] + [(f, C.c_int32) for f in OPTION_FIELDS] + [("reserved", C.c_int32 * 7)]
+    _fields_ = [("struct_size", C.c_uint32)] + [(f, C.c_int32) for f in OPTION_FIELDS] + [("reserved", C.c_int32 * 4)]
 
 
 class JobStruct(C.Structure):
@@ -75,6 +75,7 @@ def load_library():
     L.masp_hip_msm_g1.argtypes = [vp, vp, vp, sz, vp]
     L.masp_hip_msm_g2.argtypes = [vp, vp, vp, sz, vp]
     L.masp_hip_msm_g1_multi.argtypes = [vp, vp, sz, vp, sz, C.c_int, vp]
+    L.masp_hip_msm_g2_multi.argtypes = [vp, vp, sz, vp, sz, C.c_int, vp]
     L.masp_hip_quotient_h.argtypes = [vp, vp, vp, vp, sz, u32, vp]
     L.masp_hip_ntt.argtypes = [vp, vp, u32, C.c_int]
     L.masp_hip_vk_prepare.argtypes = [vp, vp, sz, C.POINTER(vp)]
@@ -279,6 +280,16 @@ class Context:
         assert scalars.shape == (npf, n, 32) and bases.shape[0] == n
         out = np.zeros((npf, 96), dtype=np.uint8)
         self._check(self._L.masp_hip_msm_g1_multi(self._h, _p(bases), n, _p(scalars), npf, int(window_bits), _p(out)))
+        return [out[i].tobytes() for i in range(npf)]
+
+    def msm_g2_multi(self, bases, scalars, window_bits=0):
+        """bases u8[n,192]; scalars u8[np,n,32] -> list of np 192-byte results (one batched launch sequence)."""
+        bases = _u8(bases, 192)
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint8)
+        npf, n = scalars.shape[0], scalars.shape[1]
+        assert scalars.shape == (npf, n, 32) and bases.shape[0] == n
+        out = np.zeros((npf, 192), dtype=np.uint8)
+        self._check(self._L.masp_hip_msm_g2_multi(self._h, _p(bases), n, _p(scalars), npf, int(window_bits), _p(out)))
         return [out[i].tobytes() for i in range(npf)]
 
     @property

@@ -5,7 +5,7 @@
 using namespace masp;
 
 extern "C" {
-// op: 0 add 1 sub 2 mul 3 inv 4 neg 5 sqr; canonical little-endian in/out; which: 0 Fp (48 B), 1 Fr (32 B)
+// op: 0 add 1 sub 2 mul 3 inv 4 neg 5 sqr 6 inv (binary gcd) 7 inv (Fermat); canonical little-endian in/out; which: 0 Fp (48 B), 1 Fr (32 B)
 int mh_field_op(int which, int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
     if (which == 0) {
         Fp x = fe_to_mont(fe_load_le<FpCfg>(a)), y = fe_to_mont(fe_load_le<FpCfg>(b)), r;
@@ -15,6 +15,8 @@ int mh_field_op(int which, int op, const uint8_t* a, const uint8_t* b, uint8_t* 
             case 2: r = fe_mul(x, y); break;
             case 3: r = fe_inv(x); break;
             case 4: r = fe_neg(x); break;
+            case 6: r = fe_inv_bingcd(x); break;
+            case 7: r = fe_inv_fermat(x); break;
             default: r = fe_sqr(x);
         }
         fe_store_le(fe_from_mont(r), out);
@@ -26,6 +28,8 @@ int mh_field_op(int which, int op, const uint8_t* a, const uint8_t* b, uint8_t* 
             case 2: r = fe_mul(x, y); break;
             case 3: r = fe_inv(x); break;
             case 4: r = fe_neg(x); break;
+            case 6: r = fe_inv_bingcd(x); break;
+            case 7: r = fe_inv_fermat(x); break;
             default: r = fe_sqr(x);
         }
         fe_store_le(fe_from_mont(r), out);

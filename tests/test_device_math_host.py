@@ -45,6 +45,10 @@ def test_field_ops(mh):
             assert op(5, a) == a * a % mod
         for a in vals[:12]:
             assert op(3, a) == (pow(a, -1, mod) if a else 0)
+        for a in vals:                                          # the binary-gcd inverse of the bucket trees' shared inversions
+            assert op(6, a) == (pow(a, -1, mod) if a else 0)
+        for a in vals[:4]:
+            assert op(7, a) == (pow(a, -1, mod) if a else 0)
 
 
 def _le(x):

@@ -1,0 +1,110 @@
+"""The batch-affine pre-reduction of the bucket runs (masp_amd/csrc/device/msm_tree.cuh: pairwise affine additions whose
+inversions are shared across the grid) through the C ABI, in the regime that uses it (np >= 8 MSMs per launch sequence):
+against the CPU restatement's multiexp on every exceptional case of the affine group law — P + P (a doubling inside the
+shared inversion), P + (-P) (the point at infinity as a RESULT that later levels meet as an operand), bases at infinity,
+buckets of every length around the powers of two — for G1 and G2, with the tree forced to more levels than any run is long,
+switched off (the XYZZ accumulation alone must give the same points), and in sub-batches that do not divide the batch.
+Run with `-m gpu` on an MI355X."""
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from pyref import R
+
+pytestmark = pytest.mark.gpu
+
+
+def _le(x):
+    return np.frombuffer((x % R).to_bytes(32, "little"), np.uint8)
+
+
+def _rand(rng, n):
+    return np.stack([_le(rng.randrange(R)) for _ in range(n)])
+
+
+@pytest.fixture(scope="module")
+def ctxs():
+    import masp_amd
+    made = {"auto": masp_amd.Context(0), "off": masp_amd.Context(0, bucket_tree_levels=-1),
+            "deep": masp_amd.Context(0, bucket_tree_levels=11, bucket_tree_sub_batch=5)}
+    assert made["off"].options["bucket_tree_levels"] == -1 and made["deep"].options["bucket_tree_sub_batch"] == 5
+    yield made
+    for c in made.values():
+        c.close()
+
+
+def _cases(rng, n, mul_gen):
+    """-> bases, list of scalar vectors (one per proof of the batch)"""
+    half = n // 2
+    ks = _rand(rng, half)
+    kneg = np.stack([_le(R - int.from_bytes(k.tobytes(), "little")) for k in ks])
+    pm = mul_gen(np.concatenate([ks, kneg]))                 # P_0 .. P_{h-1}, -P_0 .. -P_{h-1}
+    vec = []
+    vec.append(np.tile(_le(3), (n, 1)))                      # every P meets its -P in the same bucket: infinity everywhere
+    vec.append(np.tile(_le(0x1234567), (n, 1)))              # the same, on several windows
+    same = _rand(rng, half)
+    vec.append(np.concatenate([same, same]))                 # P and -P with the same random scalar
+    v = _rand(rng, n)
+    v[::7] = _le(0)
+    v[1::7] = _le(1)
+    v[2::7] = _le(R - 1)
+    vec.append(v)                                            # zeros, ones, -1
+    for _ in range(12):
+        vec.append(_rand(rng, n))
+    return pm, np.stack(vec)
+
+
+@pytest.mark.parametrize("window_bits", [4, 7, 12])
+@pytest.mark.parametrize("which", ["auto", "off", "deep"])
+def test_g1_batch_of_msms_with_every_exceptional_pair(ctxs, which, window_bits):
+    rng = random.Random(1000 + window_bits)
+    n = 640
+    pm, sc = _cases(rng, n, O.g1_mul_gen_many)
+    want = [O.msm_g1(pm, sc[p]) for p in range(sc.shape[0])]
+    assert ctxs[which].msm_g1_multi(pm, sc, window_bits=window_bits) == want
+    # the same point n times: every pair of every level is a doubling
+    one = O.g1_mul_gen_many(_rand(rng, 1))
+    rep = np.tile(one, (n, 1))
+    sc2 = np.stack([np.tile(_le(rng.randrange(R)), (n, 1)) for _ in range(8)] + [_rand(rng, n) for _ in range(3)])
+    assert ctxs[which].msm_g1_multi(rep, sc2, window_bits=window_bits) == [O.msm_g1(rep, sc2[p]) for p in range(sc2.shape[0])]
+    # bases at infinity among ordinary ones
+    mixed = pm.copy()
+    mixed[3::5, :] = 0
+    mixed[3::5, 0] = 0x40
+    assert ctxs[which].msm_g1_multi(mixed, sc[3:13], window_bits=window_bits) == [O.msm_g1(mixed, sc[p]) for p in range(3, 13)]
+
+
+@pytest.mark.parametrize("which", ["auto", "off", "deep"])
+def test_g2_batch_of_msms_with_every_exceptional_pair(ctxs, which):
+    rng = random.Random(2000)
+    n = 320
+    pm, sc = _cases(rng, n, O.g2_mul_gen_many)
+    sc = sc[:10]
+    want = [O.msm_g2(pm, sc[p]) for p in range(sc.shape[0])]
+    assert ctxs[which].msm_g2_multi(pm, sc, window_bits=7) == want
+    one = O.g2_mul_gen_many(_rand(rng, 1))
+    rep = np.tile(one, (n, 1))
+    sc2 = np.stack([np.tile(_le(rng.randrange(R)), (n, 1)) for _ in range(6)] + [_rand(rng, n) for _ in range(2)])
+    assert ctxs[which].msm_g2_multi(rep, sc2, window_bits=7) == [O.msm_g2(rep, sc2[p]) for p in range(sc2.shape[0])]
+
+
+def test_bucket_runs_of_every_length_around_the_powers_of_two(ctxs):
+    """Scalars chosen so that bucket b of the only window holds exactly b + 1 entries (b = 0 .. 63: lengths 1 .. 64, every
+    odd / even / power-of-two pattern of pairs and pass-through points), by the discrete-log identity."""
+    rng = random.Random(3000)
+    digits = [d for d in range(1, 65) for _ in range(d)]          # digit d appears d times
+    n = len(digits)
+    k_int = [rng.randrange(R) for _ in range(n)]
+    bases = O.g1_mul_gen_many(np.stack([_le(k) for k in k_int]))
+    np_ = 9
+    sc, totals = [], []
+    for p in range(np_):
+        order = digits[:]
+        rng.shuffle(order)
+        sc.append(np.stack([_le(d) for d in order]))
+        totals.append(sum(a * b for a, b in zip(k_int, order)) % R)
+    want = O.g1_mul_gen_many(np.stack([_le(t) for t in totals]))
+    for which in ("auto", "deep", "off"):
+        assert ctxs[which].msm_g1_multi(bases, np.stack(sc), window_bits=8) == [want[p].tobytes() for p in range(np_)]
