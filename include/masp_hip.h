@@ -90,7 +90,7 @@ typedef struct {
     int32_t window_bits_b2_lone;     /* ... of the second b_g2 table set used by lone proofs (default 8); -1 = not built */
     int32_t witness_nontrivial_percent; /* share of a witness that is neither 0 nor 1, for window selection (default 30) */
     int32_t bucket_tree_levels;      /* levels of shared-inversion affine additions in front of the bucket accumulation of a batch
-                                        (default 3, fewer for very short bucket runs); -1 = none (XYZZ accumulation only) */
+                                        (default 4, fewer for very short bucket runs); -1 = none (XYZZ accumulation only) */
     int32_t bucket_tree_sub_batch;   /* proofs that go through the tree at a time (default 64; its scratch is ~0.4 GB per Spend proof) */
     int32_t bucket_tree_levels_g2;   /* the same for the G2 MSM if it should differ (default: bucket_tree_levels) */
     int32_t reserved[4];

@@ -713,11 +713,183 @@ MASP_HD void fe_bingcd_inv(uint32_t* out, const uint32_t* y) {
 #pragma unroll
     for (int i = 0; i < N; ++i) out[i] = v[i];
 }
+// The same inverse with the rounds taken 30 at a time (T. Pornin, "Optimized Binary GCD for Modular Inversion"): 30 rounds
+// are decided on 64-bit approximations of a and b — their 30 low bits, which the parities depend on, and the 34 top bits of
+// the larger, which the comparisons depend on — while a 2x2 matrix (f0 g0; f1 g1), |f| + |g| <= 2^30 per row, records what was
+// done; then a, b, u, v are each replaced by their combination under that matrix divided by 2^30 (exactly for a and b, modulo p
+// for u and v).  A wrong comparison near equality only makes a or b negative, which is repaired by negating a matrix row.
+// ceil((2 len - 1) / 30) such steps always suffice: 26 for Fp, 18 for Fr; ~5x fewer instructions than one round at a time.
+template <class C>
+MASP_HD void fe_bingcd30_inv(uint32_t* out, const uint32_t* y) {
+    constexpr int N = C::N, K = 30, STEPS = (2 * 32 * N + K - 1) / K;
+    constexpr uint32_t KMASK = (1u << K) - 1u;
+    const uint32_t minv = (0u - C::INV) & KMASK;  // p^-1 mod 2^30 (C::INV = -p^-1 mod 2^32)
+    uint32_t a[N], b[N], u[N], v[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        a[i] = y[i];
+        b[i] = C::MOD[i];
+        u[i] = i == 0 ? 1u : 0u;
+        v[i] = 0u;
+    }
+    for (int step = 0; step < STEPS; ++step) {
+        // ---- approximations: the three top limbs of max(a, b), normalised, and limb 0
+        uint32_t a2 = 0, a1 = 0, a0 = 0, b2 = 0, b1 = 0, b0 = 0;
+        bool found = false;
+#pragma unroll
+        for (int i = N - 1; i >= 2; --i) {
+            const bool here = !found && (a[i] | b[i]) != 0;
+            if (here) {
+                a2 = a[i]; a1 = a[i - 1]; a0 = a[i - 2];
+                b2 = b[i]; b1 = b[i - 1]; b0 = b[i - 2];
+            }
+            found = found || here;
+        }
+        uint64_t xa, xb;
+        if (!found) {  // both below 2^64: exact
+            xa = ((uint64_t)a[1] << 32) | a[0];
+            xb = ((uint64_t)b[1] << 32) | b[0];
+        } else {
+            const uint32_t top = a2 | b2;
+            int sh = 0;  // leading zeros of top (top != 0)
+            for (uint32_t t = top; !(t & 0x80000000u); t <<= 1) ++sh;
+            uint64_t ha = ((uint64_t)a2 << 32) | a1, hb = ((uint64_t)b2 << 32) | b1;
+            if (sh) {
+                ha = (ha << sh) | (a0 >> (32 - sh));
+                hb = (hb << sh) | (b0 >> (32 - sh));
+            }
+            xa = ((ha >> K) << K) | (a[0] & KMASK);  // 34 top bits | 30 low bits
+            xb = ((hb >> K) << K) | (b[0] & KMASK);
+        }
+        // ---- 30 rounds on the approximations
+        int32_t f0 = 1, g0 = 0, f1 = 0, g1 = 1;
+        for (int r = 0; r < K; ++r) {
+            const uint64_t odd = 0ull - (xa & 1ull);
+            const uint64_t sw = odd & (0ull - (uint64_t)(xa < xb));
+            const uint32_t odd32 = (uint32_t)odd, sw32 = (uint32_t)sw;
+            const uint64_t tx = (xa ^ xb) & sw;
+            xa ^= tx;
+            xb ^= tx;
+            const uint32_t tf = (uint32_t)(f0 ^ f1) & sw32, tg = (uint32_t)(g0 ^ g1) & sw32;
+            f0 = (int32_t)((uint32_t)f0 ^ tf);
+            f1 = (int32_t)((uint32_t)f1 ^ tf);
+            g0 = (int32_t)((uint32_t)g0 ^ tg);
+            g1 = (int32_t)((uint32_t)g1 ^ tg);
+            xa -= xb & odd;
+            f0 -= (int32_t)((uint32_t)f1 & odd32);
+            g0 -= (int32_t)((uint32_t)g1 & odd32);
+            xa >>= 1;
+            f1 = (int32_t)((uint32_t)f1 << 1);
+            g1 = (int32_t)((uint32_t)g1 << 1);
+        }
+        // ---- (a, b) <- (f0 a + g0 b, f1 a + g1 b) / 2^30, made non-negative
+        uint32_t ta[N + 1], tb[N + 1];
+        {
+            int64_t ca = 0, cb = 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                ca += (int64_t)f0 * (int64_t)(uint64_t)a[i] + (int64_t)g0 * (int64_t)(uint64_t)b[i];
+                cb += (int64_t)f1 * (int64_t)(uint64_t)a[i] + (int64_t)g1 * (int64_t)(uint64_t)b[i];
+                ta[i] = (uint32_t)ca;
+                tb[i] = (uint32_t)cb;
+                ca >>= 32;
+                cb >>= 32;
+            }
+            ta[N] = (uint32_t)ca;
+            tb[N] = (uint32_t)cb;
+            const uint32_t na = 0u - (uint32_t)(ca < 0), nb_ = 0u - (uint32_t)(cb < 0);
+            uint64_t c1 = na & 1u, c2 = nb_ & 1u;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const uint32_t sa = (ta[i] >> K) | (ta[i + 1] << (32 - K)), sb = (tb[i] >> K) | (tb[i + 1] << (32 - K));
+                c1 += (uint64_t)(sa ^ na);
+                c2 += (uint64_t)(sb ^ nb_);
+                a[i] = (uint32_t)c1;
+                b[i] = (uint32_t)c2;
+                c1 >>= 32;
+                c2 >>= 32;
+            }
+            // a negated value means the opposite matrix row was applied
+            f0 = (int32_t)(((uint32_t)f0 ^ na) - na);
+            g0 = (int32_t)(((uint32_t)g0 ^ na) - na);
+            f1 = (int32_t)(((uint32_t)f1 ^ nb_) - nb_);
+            g1 = (int32_t)(((uint32_t)g1 ^ nb_) - nb_);
+        }
+        // ---- (u, v) <- (f0 u + g0 v, f1 u + g1 v) / 2^30 mod p: add the multiple of p that clears the 30 low bits, shift, and
+        // bring the result (in (-p, 2p)) back into [0, p)
+        {
+            int64_t cu = 0, cv = 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                cu += (int64_t)f0 * (int64_t)(uint64_t)u[i] + (int64_t)g0 * (int64_t)(uint64_t)v[i];
+                cv += (int64_t)f1 * (int64_t)(uint64_t)u[i] + (int64_t)g1 * (int64_t)(uint64_t)v[i];
+                ta[i] = (uint32_t)cu;
+                tb[i] = (uint32_t)cv;
+                cu >>= 32;
+                cv >>= 32;
+            }
+            const uint32_t qu = ((0u - ta[0]) * minv) & KMASK, qv = ((0u - tb[0]) * minv) & KMASK;
+            uint64_t du = 0, dv = 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                du += (uint64_t)qu * C::MOD[i] + ta[i];
+                dv += (uint64_t)qv * C::MOD[i] + tb[i];
+                ta[i] = (uint32_t)du;
+                tb[i] = (uint32_t)dv;
+                du >>= 32;
+                dv >>= 32;
+            }
+            cu += (int64_t)du;
+            cv += (int64_t)dv;
+            ta[N] = (uint32_t)cu;
+            tb[N] = (uint32_t)cv;
+            const bool negu = cu < 0, negv = cv < 0;  // (after the shift the sign sits in the bits above N limbs)
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                u[i] = (ta[i] >> K) | (ta[i + 1] << (32 - K));
+                v[i] = (tb[i] >> K) | (tb[i + 1] << (32 - K));
+            }
+            // negative: + p (the N-limb two's complement wraps to the right value); otherwise - p if >= p
+            {
+                const uint32_t mu = 0u - (uint32_t)negu, mv = 0u - (uint32_t)negv;
+                uint64_t c1 = 0, c2 = 0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    c1 += (uint64_t)u[i] + (C::MOD[i] & mu);
+                    c2 += (uint64_t)v[i] + (C::MOD[i] & mv);
+                    u[i] = (uint32_t)c1;
+                    v[i] = (uint32_t)c2;
+                    c1 >>= 32;
+                    c2 >>= 32;
+                }
+                uint32_t su[N], sv[N];
+                uint64_t b1 = 0, b2 = 0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    uint64_t t1 = (uint64_t)u[i] - C::MOD[i] - b1, t2 = (uint64_t)v[i] - C::MOD[i] - b2;
+                    su[i] = (uint32_t)t1;
+                    sv[i] = (uint32_t)t2;
+                    b1 = (t1 >> 32) & 1;
+                    b2 = (t2 >> 32) & 1;
+                }
+                const uint32_t ku = 0u - (uint32_t)(b1 == 0), kv = 0u - (uint32_t)(b2 == 0);  // no borrow: value >= p
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    u[i] = (u[i] & ~ku) | (su[i] & ku);
+                    v[i] = (v[i] & ~kv) | (sv[i] & kv);
+                }
+            }
+        }
+    }
+    // a = 0, b = gcd = 1 (y = 0: b = p, v = 0): v = 1 / y
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = v[i];
+}
 // a^-1 in Montgomery form from a in Montgomery form: (aR)^-1 = a^-1 R^-1, times R^3 (as a Montgomery product) = a^-1 R
 template <class C>
 MASP_HD Fe<C> fe_inv_bingcd(const Fe<C>& a) {
     Fe<C> r, r3;
-    fe_bingcd_inv<C>(r.v, a.v);
+    fe_bingcd30_inv<C>(r.v, a.v);
 #pragma unroll
     for (int i = 0; i < C::N; ++i) r3.v[i] = C::R3[i];
     return fe_mul(r, r3);

@@ -155,7 +155,7 @@ struct MsmWorkspace {
     static constexpr uint32_t NCHUNKS = 1u << 18;     // lanes of the accumulation kernel (1024 waves x 4 per SIMD)
 
     MsmSortBuf sort;  // used unless the caller shares another workspace's sort
-    // batch-affine pre-reduction of the bucket runs (batches only): tree_levels < 0 off, 0 = the default (3, fewer for very
+    // batch-affine pre-reduction of the bucket runs (batches only): tree_levels < 0 off, 0 = the default (4, fewer for very
     // short runs), else that many levels; tree_sub proofs go through the tree at a time (its scratch is ~0.4 GB per Spend proof)
     MsmTreeWs<O> tree;
     int tree_levels = 0;

@@ -45,8 +45,13 @@ def test_field_ops(mh):
             assert op(5, a) == a * a % mod
         for a in vals[:12]:
             assert op(3, a) == (pow(a, -1, mod) if a else 0)
-        for a in vals:                                          # the binary-gcd inverse of the bucket trees' shared inversions
-            assert op(6, a) == (pow(a, -1, mod) if a else 0)
+        # the binary-gcd inverse (30 rounds at a time on 64-bit approximations) of the bucket trees' shared inversions: random values
+        # and the shapes that stress the approximations (powers of two and their neighbours, long runs of zero / one bits)
+        bits = mod.bit_length()
+        special = [1 << k for k in range(1, bits - 1)] + [(1 << k) - 1 for k in range(2, bits - 1)] + [mod - (1 << k) for k in range(0, bits - 2)] + \
+                  [((1 << 62) + 1) << k for k in range(0, bits - 64, 7)] + [(mod >> k) | 1 for k in range(1, 200, 3)]
+        for a in vals + [x % mod for x in special] + [rng.randrange(mod) for _ in range(1500)] + [rng.randrange(1 << rng.randrange(1, bits)) for _ in range(500)]:
+            assert op(6, a) == (pow(a, -1, mod) if a else 0), hex(a)
         for a in vals[:4]:
             assert op(7, a) == (pow(a, -1, mod) if a else 0)
 
