@@ -92,16 +92,77 @@ def cpu_baseline(cs, params, inputs, aux):
             "median_ms_per_proof": med * 1e3, "phase_ms_per_proof": {k: round(statistics.median(v), 2) for k, v in phases.items()}}
 
 
+def main_in_library(args):
+    """The other way to all GPUs of a node: ONE process, no torch / RCCL — masp_hip_ctx_create_ex over devices
+    0 .. N-1, every step one masp_hip_prove_batch of N x 256 jobs that the library deals to its devices (one host thread per
+    device inside the library), `slots` such calls in flight.  Same witnesses-in-page-locked-host-memory region as `value` of the
+    process-per-GPU mode; prints one line in the same format (launcher: "in-library")."""
+    import masp_amd
+    from masp_amd import host as H
+    from masp_amd import synthetic
+    from masp_amd import workload as W
+    N, K, Wm = args.gpus, args.steps, args.warmup
+    kind, n = "spend", PROOFS_PER_STEP["spend"]
+    ctx = masp_amd.Context(list(range(N)), **options_from_env())
+    assert ctx.device_count == N
+    SLOTS = ctx.options["slots"]
+    cs = H.circuit(kind)[0]
+    t0 = time.perf_counter()
+    params = ctx.generate_parameters(cs, synthetic.toxic_waste(1))
+    ctx.load_circuit(0, params, cs)                      # replicated on every device
+    setup_s = time.perf_counter() - t0
+    vk = ctx.prepare_verifying_key(params)
+    threads = H.effective_cpus()
+    W.instances(kind, 2, first_seed=10 ** 6, threads=2)
+    insts = W.instances(kind, N * n, first_seed=0, threads=threads, alloc=lambda kk: ctx.host_alloc(cs.n_aux, 32))
+    rng = random.Random(0x5962be3d)
+
+    def jobs_for_step():
+        return [(0, i, a, rng.randrange(R).to_bytes(32, "little"), rng.randrange(R).to_bytes(32, "little")) for i, a in insts]
+
+    # (set-up + warm-up: two rounds of `slots` concurrent calls, so that every slot of every device has its scratch at its final size)
+    warm = [ctx.marshal_jobs(jobs_for_step()) for _ in range(max(Wm, 2 * SLOTS))]
+    timed = [ctx.marshal_jobs(jobs_for_step()) for _ in range(K)]
+    with ThreadPoolExecutor(SLOTS) as ex:
+        list(ex.map(lambda k: ctx.prove_marshalled(warm[k][0], N * n), range(len(warm))))          # also sizes every device's scratch
+    out = np.zeros((K, N * n, 192), np.uint8)
+    ctx.sync()
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(SLOTS) as ex:
+        list(ex.map(lambda k: ctx.prove_marshalled(timed[k][0], N * n, out[k]), range(K)))           # exactly K steps
+    ctx.sync()
+    elapsed = time.perf_counter() - t0
+    pub = [W.public_inputs(i) for i, _ in insts]
+    for k in range(K):
+        if not vk.verify_batch([out[k, j].tobytes() for j in range(N * n)], pub):
+            sys.exit("bench.py: a timed proof FAILED the pairing check — no figure reported")
+    assert len(set(p.tobytes() for p in out.reshape(-1, 192))) == K * N * n
+    vk.close()
+    ctx.close()
+    print(json.dumps({"metric": "Spend proofs/sec", "value": K * N * n / elapsed, "unit": "proofs/s", "n_gpus": N, "steps": K, "warmup": Wm,
+                      "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+                      "launcher": "in-library: one process, masp_hip_ctx_create_ex over %d device(s), no torch / RCCL" % N,
+                      "config": {"workload": "BASELINE.json configs[3] per GPU: %d distinct Spend proofs per GPU and step, one masp_hip_prove_batch of %d jobs per "
+                                             "step dealt to the devices inside the library, %d calls in flight; witnesses in page-locked host memory -> proofs "
+                                             "in host memory (BASELINE.md §4)" % (n, N * n, SLOTS),
+                                 "proofs_per_step": N * n, "parallelism": "proofs dealt to %d device context(s) by the library, no collective" % N},
+                      "verified": K * N * n, "setup_seconds": round(setup_s, 2)}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8, help="timed steps; one step = one batch of 256 distinct proofs per GPU")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-library", action="store_true", help="one process over all --gpus devices through masp_hip_ctx_create_ex (no torch, no RCCL)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / process-group / gather path only, no GPU work, no figure (CPU test hook)")
     args = ap.parse_args()
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
         sys.exit("bench.py: --gpus and --steps must be >= 1, --warmup >= 0")
+    if args.in_library:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+        return main_in_library(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         relaunch_under_torchrun(args)
     rank = int(os.environ.get("RANK", "0"))
@@ -142,14 +203,20 @@ def main():
         fake[:, 1:5] = np.arange(n_local, dtype=np.uint32).view(np.uint8).reshape(n_local, 4)
         got = D.gather_proofs(fake, n_local * world, dist, dev)
         t = D.max_over_ranks(float(rank), dist, dev)
+        # the CRS path of N ranks: rank 0's bytes reach every rank unchanged (here: a 5 MB stand-in)
+        import hashlib
+        blob = np.frombuffer(hashlib.sha256(b"crs").digest() * (5 * 2 ** 20 // 32), np.uint8) if rank == 0 else None
+        crs = D.broadcast_bytes(blob, dist, dev)
+        crs_ok = int(D.sum_over_ranks(float(hashlib.sha256(crs.tobytes()).hexdigest() == hashlib.sha256(hashlib.sha256(b"crs").digest() * (5 * 2 ** 20 // 32)).hexdigest()),
+                                      dist, dev))
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
         if rank == 0:
             ok = len(got) == n_local * world and all(got[r * n_local + i][0] == r and int.from_bytes(got[r * n_local + i][1:5], "little") == i
-                                                     for r in range(world) for i in (0, n_local - 1))
+                                                     for r in range(world) for i in range(n_local))
             print(json.dumps({"dry_run": True, "n_gpus": world, "rccl_ranks": world, "backend": backend, "gathered": len(got), "gather_ok": bool(ok),
-                              "max_rank_seen": int(t), "value": None}), flush=True)
+                              "max_rank_seen": int(t), "crs_broadcast_ok_ranks": crs_ok, "value": None}), flush=True)
         return
     import masp_amd
     from masp_amd import distributed as D

@@ -89,3 +89,28 @@ def test_bench_refuses_a_gpu_count_it_was_not_launched_with():
     """A launcher that started 1 rank while --gpus says 4 (or the reverse) gets an error, not a line with another n_gpus."""
     r = _run_bench(["--gpus", "4", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "refusing" in r.stderr and "{" not in r.stdout
+
+
+def test_bench_dress_rehearsal_eight_ranks_as_the_driver_launches_them():
+    """The 8-GPU line of SCALE_rNN.json, without the GPUs: the driver's own command (python -m torch.distributed.run --nnodes=1
+    --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...), gloo instead of RCCL, --dry-run instead of
+    proving.  Eight ranks come up, the CRS bytes of rank 0 reach all of them, each rank's K x 256 proofs arrive on rank 0 at
+    their job positions, one line comes out and it says n_gpus = 8."""
+    import json
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MASP_BENCH_BACKEND"] = "gloo"
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port",
+                        str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and out["max_rank_seen"] == 7
+    assert out["gathered"] == 8 * 2 * 256 and out["gather_ok"] is True and out["crs_broadcast_ok_ranks"] == 8
