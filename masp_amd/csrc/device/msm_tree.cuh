@@ -221,10 +221,14 @@ k_tree_pass1(const TabRow<O>* __restrict__ tab, const typename O::T* __restrict_
         if (t + NT < P) rb = rec[t + NT];
         src.load_x(ra, x1, x2);
     }
+    // (gfx9 counts loads and stores in ONE counter and stores may complete out of order, so a wait for loaded data drains every
+    // store issued before it: the prefix of pair j is therefore stored at the top of iteration j + 1, right after that
+    // iteration's wait and before its loads — by the next wait it has had a whole iteration to complete)
     uint32_t j = 0;
     for (uint32_t q = t; q < P; q += NT, ++j) {
         const Rec cr = ra;
         const F cx1 = x1, cx2 = x2;
+        if (j) pre[((size_t)(j - 1) * np + p) * NT + t] = chain;
         ra = rb;
         if (q + NT < P) src.load_x(ra, x1, x2);
         if (q + 2 * (uint64_t)NT < P) rb = rec[q + 2 * NT];
@@ -235,8 +239,8 @@ k_tree_pass1(const TabRow<O>* __restrict__ tab, const typename O::T* __restrict_
             if (tree_classify<O>(cx1, y1, cx2, y2, d) > TREE_DBL) d = O::one();
         }
         chain = O::mul(chain, d);
-        pre[((size_t)j * np + p) * NT + t] = chain;
     }
+    if (j) pre[((size_t)(j - 1) * np + p) * NT + t] = chain;
     tp[(size_t)p * NT + t] = chain;
 }
 
@@ -276,12 +280,19 @@ k_tree_pass2(const TabRow<O>* __restrict__ tab, const typename O::T* __restrict_
     if (j) rb = rec[t + (j - 1) * NT];
     Ops nxt;
     fetch(ra, nxt);
+    // (the result of a pair is stored at the top of the NEXT iteration, after that iteration's wait for its operands and before
+    // its loads: see pass 1 — a store in flight would otherwise be drained by the wait)
+    F hx = O::zero(), hy = O::zero();
+    uint32_t hout = 0;
+    bool held = false;
     for (;; --j) {
         Ops c = nxt;
         const Rec cr = ra;
         ra = rb;
-        // this pair's prefix (a streaming load: back by the time the first product, I d, is done), the next pair's operands
-        // (two random rows at level 0: they have the whole iteration), the record after that
+        if (held) {
+            ox[hout] = hx;
+            oy[hout] = hy;
+        }
         F pp = O::one();
         if (j) pp = pre[((size_t)(j - 1) * np + p) * NT + t];
         if (j) fetch(ra, nxt);
@@ -316,10 +327,14 @@ k_tree_pass2(const TabRow<O>* __restrict__ tab, const typename O::T* __restrict_
             x3 = O::zero();
             y3 = O::zero();
         }
-        ox[out] = x3;
-        oy[out] = y3;
+        hx = x3;
+        hy = y3;
+        hout = out;
+        held = true;
         if (!j) break;
     }
+    ox[hout] = hx;
+    oy[hout] = hy;
 }
 
 // the last point of a bucket with an odd number of points goes to the next level as it is.  grid (nb / 256, np)
