@@ -226,6 +226,8 @@ def main():
 
     ctx = masp_amd.Context(local_rank, **options_from_env())
     SLOTS, BATCH = ctx.options["slots"], ctx.options["batch_cap"]
+    ctx_tree_levels = {0: "4 (default)", -1: "no"}.get(ctx.options["bucket_tree_levels"], str(ctx.options["bucket_tree_levels"]))
+    ctx_tree_sub = ctx.options["bucket_tree_sub_batch"]
     threads = max(1, H.effective_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
     kinds = list(KINDS) if WORKLOAD == "mixed" else [WORKLOAD]
     n = PROOFS_PER_STEP[WORKLOAD]
@@ -447,15 +449,19 @@ def main():
             "host_synthesis": {"ms_per_proof_one_thread": {k: round(statistics.median(v["synthesize_ms"]), 2) for k, v in syn.items()},
                                "instances_per_s_all_threads": round(n / synth_wall, 1), "threads": threads},
             "ms_per_proof": elapsed_b * 1e3 / (K * n),
-            "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate<G1> (bucket accumulation of the G1 MSMs: h+l merged, a, b_g1)",
+            "roofline": {"bound": "hbm",
+                         "kernel": "G1 bucket-accumulation stage of one G1 MSM (h+l merged, a, b_g1): shared-inversion affine tree, %s levels in sub-batches of %d "
+                                   "proofs (k_tree_pass1 / k_tree_pass2 / k_binv_* / k_tree_copy), then k_msm_accumulate_pts<G1> over what is left"
+                                   % (ctx_tree_levels, ctx_tree_sub),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source, "launches": x_launches, "avg_launch_ms": x_ms / x_launches if x_launches else None,
                          "alg_bytes_per_launch": x_bytes / x_launches if x_launches else None,
                          "timed_region": {"launches": launches, "avg_span_ms": acc_ms / launches if launches else None,
                                           "alg_bytes_per_launch": alg_bytes / launches if launches else None},
                          "note": "algorithmic bytes = n x (96 B base + 32 B scalar) per G1 MSM and proof.  avg_launch_ms / achieved: HIP events "
-                                 "around the launches of one launch sequence run right after the timed region with nothing else on the chip = "
-                                 "kernel time (rocprofv3's figure for the launches of the timed region agrees with it, profiles/).  timed_region: the "
+                                 "around the stage (all its kernels, including the latency-bound shared inversions between the tree's passes) in one "
+                                 "launch sequence run right after the timed region with nothing else on the chip (rocprofv3's kernel durations of "
+                                 "the same stage: profiles/).  timed_region: the "
                                  "same events inside the timed region, where a launch also waits for the chip behind the other three batches' "
                                  "kernels - a wall span, not kernel time.  This path is bound by 32-bit integer multiply throughput, not HBM "
                                  "(DESIGN.md §4)"},

@@ -17,9 +17,11 @@ __global__ void k_rate(uint32_t* out, uint32_t seed, int iters) {
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            if (OP == 0) {  // v_mad_u64_u32, 4 independent chains
-                x0 = (uint64_t)(uint32_t)x0 * a + x0; x1 = (uint64_t)(uint32_t)x1 * b + x1;
-                x2 = (uint64_t)(uint32_t)x2 * c + x2; x3 = (uint64_t)(uint32_t)x3 * d + x3;
+            if (OP == 0) {  // v_mad_u64_u32, 4 independent chains (inline asm: as plain C++ the compiler folds the chain away —
+                            // the round-2 row of this tool printed 693 560 Gop/s for it)
+                asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_mad_u64_u32 %1, vcc, %4, %6, %1\n\t"
+                             "v_mad_u64_u32 %2, vcc, %5, %7, %2\n\tv_mad_u64_u32 %3, vcc, %6, %7, %3\n\t"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a), "v"(b), "v"(c), "v"(d) : "vcc");
             } else if (OP == 1) {  // v_mul_lo_u32
                 a = a * b + 1; b = b * c + 1; c = c * d + 1; d = d * a + 1;
             } else if (OP == 2) {  // v_mul_hi_u32
