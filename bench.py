@@ -388,7 +388,9 @@ def main():
         e2e_setup = time.perf_counter() - t_e
         with ThreadPoolExecutor(threads) as ex:
             descs = list(ex.map(lambda i: W.description("spend", 5 * 10 ** 6 + 10 ** 5 * rank + i), range(e2e_n)))
-        prover.prove_batch(prover.new_sapling_proving_context(), descs[:min(e2e_n, 2 * BATCH)], threads=threads)    # page-locks its buffer pool
+        # set-up, not measurement: the same call once — its chunk size decides how many page-locked aux buffers the prover's pool holds
+        # (page-locking is slow while the GPU is busy: 17 ms per 3 MB buffer) and which batch shapes the GPU scratch is sized for
+        prover.prove_batch(prover.new_sapling_proving_context(), descs, threads=threads)
         if dist is not None:
             dist.barrier()
         t_e = time.perf_counter()
