@@ -27,7 +27,8 @@ class HostError(RuntimeError):
 def load_library():
     global _lib
     if _lib is None:
-        path = os.path.join(_HERE, "libmasp_host.so")
+        # MASP_HOST_LIBRARY: another build of the same library (tools/sanitize_host.sh runs the CPU tests over an ASan / UBSan build)
+        path = os.environ.get("MASP_HOST_LIBRARY") or os.path.join(_HERE, "libmasp_host.so")
         if not os.path.exists(path):
             raise ImportError("libmasp_host.so is not built: run `make -C masp_amd/csrc`")
         L = C.CDLL(path)

@@ -10,7 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-_SO = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+_SO = os.environ.get("MASP_ORACLE_LIBRARY") or os.path.join(ROOT, "oracle", "_build", "liboracle.so")   # (override: tools/sanitize_host.sh)
 
 
 def build():
