@@ -71,7 +71,15 @@ typedef struct {
     const uint8_t* b;
     const uint8_t* c;
     uint8_t r[32], s[32];      /* Groth16 blinding scalars (the reference draws them from OsRng) */
+    uint32_t aux_form;         /* MASP_HIP_AUX_CANONICAL (0): aux[i] = Scalar::to_repr(), 32 bytes little-endian canonical;
+                                  MASP_HIP_AUX_MONTGOMERY (1): aux[i] = the Montgomery residue a * 2^256 mod r as four little-endian
+                                  u64 limbs — the IN-MEMORY form of blst_fr / bls12_381::Scalar: a binding can hand
+                                  over the Vec<Scalar> of its recording constraint system without converting 100 000 elements per
+                                  Spend (libmasp_host does: 16 % of its synthesis time).  inputs, a, b, c, r, s stay canonical. */
+    uint32_t reserved;
 } masp_hip_job;
+#define MASP_HIP_AUX_CANONICAL 0
+#define MASP_HIP_AUX_MONTGOMERY 1
 
 /* Number of HIP devices this process can see (0 if the runtime is unusable). */
 int masp_hip_device_count(void);

@@ -19,6 +19,22 @@ __global__ void k_fr_to_mont(const Fr* __restrict__ x, size_t x_stride, Fr* __re
     if (fe_canonical_ge_mod(v)) atomicOr(range_err, 1);
     fr_store(y + k, fe_to_mont(v));
 }
+// The same for an assignment whose elements from index `mont_from` on arrived as Montgomery residues (masp_hip_job::aux_form):
+// those are range-checked as they are, copied to y, and REPLACED in x by their canonical value (the MSMs read canonical scalars).
+__global__ void k_fr_split_forms(Fr* __restrict__ x, size_t x_stride, Fr* __restrict__ y, uint32_t n, uint32_t mont_from, int* __restrict__ range_err) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    x += blockIdx.y * x_stride;
+    y += (size_t)blockIdx.y * n;
+    Fr v = fr_load(x + k);
+    if (fe_canonical_ge_mod(v)) atomicOr(range_err, 1);
+    if (k < mont_from) {
+        fr_store(y + k, fe_to_mont(v));
+    } else {
+        fr_store(y + k, v);
+        fr_store(x + k, fe_from_mont(v));
+    }
+}
 
 // One CSR row per lane: out[row] = sum_t coef[t] * w[col[t]]  (all Montgomery).  Rows
 // n_constraints .. n_constraints + n_inputs - 1 are bellperson's extra "Input(i) * 0 = 0" rows:

@@ -21,8 +21,15 @@ struct CircuitHandle {
 };
 Var remap(Var v, uint32_t n_inputs) { return (v & AUX) ? n_inputs + (v & ~AUX) : v; }
 
-void write_assignment(const CS& cs, uint8_t* inputs, uint8_t* aux) {
+// aux_montgomery: the aux assignment leaves as Montgomery residues (four little-endian u64 limbs: blst_fr's memory, what
+// masp_hip_job::aux_form = MASP_HIP_AUX_MONTGOMERY announces) — no conversion of ~30 000 non-boolean elements per Spend
+void write_assignment(const CS& cs, uint8_t* inputs, uint8_t* aux, bool aux_montgomery = false) {
     for (size_t i = 0; i < cs.num_inputs(); ++i) cs.inputs()[i].to_bytes(inputs + 32 * i);
+    if (aux_montgomery) {
+        static_assert(sizeof(Fr) == 32, "Fr is four 64-bit Montgomery limbs");
+        memcpy(aux, cs.aux().data(), 32 * cs.num_aux());
+        return;
+    }
     // 70 % of a MASP witness is 0 or 1 (booleans): no Montgomery conversion needed for those
     const Fr one = Fr::one();
     for (size_t j = 0; j < cs.num_aux(); ++j) {
@@ -117,7 +124,8 @@ void masp_host_circuit_hash(void* hh, char* out65) {
 }
 
 // ---- witness generation -----------------------------------------------------------------------------
-// check != 0: additionally record the constraints and fail with MASP_HOST_E_UNSATISFIED if any is violated.
+// check & 1: additionally record the constraints and fail with MASP_HOST_E_UNSATISFIED if any is violated.
+// check & 2: write the aux assignment as Montgomery residues (see write_assignment) instead of canonical bytes.
 // rcm is the note commitment randomness `note.rcm()` (sapling.rs:856-863) as 32 bytes LE.
 int masp_host_spend_assignment(const uint8_t ak[32], const uint8_t nsk[32], const uint8_t diversifier[11], const uint8_t rcm[32],
                                const uint8_t ar[32], const uint8_t asset_identifier[32], uint64_t value, const uint8_t anchor[32],
@@ -149,10 +157,10 @@ int masp_host_spend_assignment(const uint8_t ak[32], const uint8_t nsk[32], cons
         cv.to_bytes(cv_out);
         rk.to_bytes(rk_out);
         nullifier(nf_out, cm, position, nk);
-        CS cs(check != 0, true);
+        CS cs((check & 1) != 0, true);
         synthesize_spend(cs, w);
-        if (check && cs.first_unsatisfied() >= 0) return MASP_HOST_E_UNSATISFIED;
-        write_assignment(cs, inputs, aux);
+        if ((check & 1) && cs.first_unsatisfied() >= 0) return MASP_HOST_E_UNSATISFIED;
+        write_assignment(cs, inputs, aux, (check & 2) != 0);
         return MASP_HOST_OK;
     } catch (const SynthesisError&) {
         return MASP_HOST_E_SYNTHESIS;
@@ -173,10 +181,10 @@ int masp_host_output_assignment(const uint8_t esk[32], const uint8_t diversifier
         memcpy(w.rcm, rcm, 32);
         memcpy(w.esk, esk, 32);
         value_commitment(w.vc.asset_generator, value, rcv).to_bytes(cv_out);
-        CS cs(check != 0, true);
+        CS cs((check & 1) != 0, true);
         synthesize_output(cs, w);
-        if (check && cs.first_unsatisfied() >= 0) return MASP_HOST_E_UNSATISFIED;
-        write_assignment(cs, inputs, aux);
+        if ((check & 1) && cs.first_unsatisfied() >= 0) return MASP_HOST_E_UNSATISFIED;
+        write_assignment(cs, inputs, aux, (check & 2) != 0);
         return MASP_HOST_OK;
     } catch (const SynthesisError&) {
         return MASP_HOST_E_SYNTHESIS;
@@ -194,10 +202,10 @@ int masp_host_convert_assignment(const uint8_t generator[32], uint64_t value, co
         memcpy(w.vc.randomness, rcv, 32);
         if (!Fr::from_bytes(w.anchor, anchor) || !load_path(w.path, path_siblings, position)) return MASP_HOST_E_INVALID;
         value_commitment(w.vc.asset_generator, value, rcv).to_bytes(cv_out);
-        CS cs(check != 0, true);
+        CS cs((check & 1) != 0, true);
         synthesize_convert(cs, w);
-        if (check && cs.first_unsatisfied() >= 0) return MASP_HOST_E_UNSATISFIED;
-        write_assignment(cs, inputs, aux);
+        if ((check & 1) && cs.first_unsatisfied() >= 0) return MASP_HOST_E_UNSATISFIED;
+        write_assignment(cs, inputs, aux, (check & 2) != 0);
         return MASP_HOST_OK;
     } catch (const SynthesisError&) {
         return MASP_HOST_E_SYNTHESIS;

@@ -36,6 +36,9 @@ void launch_fr_from_mont(hipStream_t s, const Fr* x, Fr* y, uint32_t n) {
 void launch_fr_to_mont(hipStream_t s, const Fr* x, size_t x_stride, Fr* y, uint32_t n, uint32_t np, int* range_err) {
     hipLaunchKernelGGL(k_fr_to_mont, dim3((n + 255) / 256, np), dim3(256), 0, s, x, x_stride, y, n, range_err);
 }
+void launch_fr_split_forms(hipStream_t s, Fr* x, size_t x_stride, Fr* y, uint32_t n, uint32_t mont_from, uint32_t np, int* range_err) {
+    hipLaunchKernelGGL(k_fr_split_forms, dim3((n + 255) / 256, np), dim3(256), 0, s, x, x_stride, y, n, mont_from, range_err);
+}
 void launch_r1cs_eval(hipStream_t s, const R1csMatrices& M, const Fr* w, uint32_t n_vars, uint32_t n_constraints, uint32_t n_inputs, uint32_t np) {
     const uint32_t nrows = n_constraints + n_inputs;
     hipLaunchKernelGGL(k_r1cs_eval, dim3((nrows + 127) / 128, np, 3), dim3(128), 0, s, M, w, n_vars, n_constraints, n_inputs);

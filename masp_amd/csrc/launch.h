@@ -21,6 +21,7 @@ void launch_fr_scale_sub(hipStream_t s, const Fr* x, const Fr* scale, const Fr* 
 void launch_fr_scale(hipStream_t s, const Fr* x, const Fr* scale, Fr* y, uint32_t n, uint32_t np, size_t y_stride = 0);
 void launch_fr_from_mont(hipStream_t s, const Fr* x, Fr* y, uint32_t n);
 void launch_fr_to_mont(hipStream_t s, const Fr* x, size_t x_stride, Fr* y, uint32_t n, uint32_t np, int* range_err);
+void launch_fr_split_forms(hipStream_t s, Fr* x, size_t x_stride, Fr* y, uint32_t n, uint32_t mont_from, uint32_t np, int* range_err);
 struct R1csMatrices {  // the static R1CS of a circuit (CSR, rows by decreasing length) and where a, b, c go
     const uint32_t* rowptr[3];
     const uint32_t* order[3];

@@ -173,8 +173,10 @@ static int enqueue_quotient(Slot& sl, const NttDomain& D, const Fr* const in[3],
 // Enqueue np proofs of circuit C as one batch.  d_w + p * w_stride: n_vars canonical scalars on the device (inputs then
 // aux).  d_abc[i] + p * nrows: canonical evaluation vectors on the device, or all NULL.  d_rs + p * 16: r | s limbs.
 // d_proof + p * 192: output.
+// aux_montgomery: the aux part of every assignment (d_w + p * w_stride + n_inputs ...) holds Montgomery residues
+// (masp_hip_job::aux_form); it is converted to canonical form in place first (d_w must then be writable).
 static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size_t w_stride, const Fr* const d_abc[3], const uint32_t* d_rs,
-                          uint8_t* d_proof) {
+                          uint8_t* d_proof, bool aux_montgomery = false) {
     hipStream_t s = sl.stream;
     const uint32_t nv = C.n_inputs + C.n_aux;
     int rc;
@@ -182,14 +184,16 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
     // (sl.flags accumulates: the caller clears it before the first batch it will read the flag for)
     if ((rc = sl.wm.reserve((size_t)nv * np))) return rc;
     const bool lone = np < 8;
+    // range check (+ Montgomery copy used by the SpMV); an aux part that arrived as Montgomery residues becomes canonical here,
+    // BEFORE anything reads it as scalars
+    if (aux_montgomery) launch_fr_split_forms(s, const_cast<Fr*>(d_w), w_stride, sl.wm.p, nv, C.n_inputs, np, sl.flags.p);
     if (lone) {
         // lone-proof mode: L, A, B1 and B2 only read the assignment (already on the device when this stream gets here), so
         // their streams fork NOW, before the range check and the SpMV are queued on the main stream
         HIP_TRY(hipEventRecord(sl.ev_fork, s));
         for (int i = 0; i < Slot::N_AUX; ++i) HIP_TRY(hipStreamWaitEvent(sl.aux[i], sl.ev_fork, 0));
     }
-    // range check (+ Montgomery copy used by the SpMV)
-    launch_fr_to_mont(s, d_w, w_stride, sl.wm.p, nv, np, sl.flags.p);
+    if (!aux_montgomery) launch_fr_to_mont(s, d_w, w_stride, sl.wm.p, nv, np, sl.flags.p);
     const Fr* in[3];
     bool mont_in;
     if (d_abc[0]) {
@@ -621,7 +625,7 @@ static int prove_batch_multi(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jo
     std::vector<std::vector<size_t>> share(nd);
     {
         std::map<std::pair<uint32_t, bool>, std::vector<size_t>> by_kind;
-        for (size_t j = 0; j < n; ++j) by_kind[{jobs[j].circuit, jobs[j].a != nullptr}].push_back(j);
+        for (size_t j = 0; j < n; ++j) by_kind[{jobs[j].circuit | (jobs[j].aux_form ? 0x100u : 0u), jobs[j].a != nullptr}].push_back(j);
         size_t next = 0;
         for (auto& kv : by_kind) {
             // at least one block per device when the list is long enough to give every device a useful batch
@@ -662,6 +666,7 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
         if (J.circuit >= MASP_HIP_MAX_CIRCUITS || !J.inputs || !J.aux) return MASP_HIP_E_INVALID_ARG;
         if (!ctx->circ[J.circuit]) return MASP_HIP_E_NOT_LOADED;
         if ((J.a || J.b || J.c) && !(J.a && J.b && J.c)) return MASP_HIP_E_INVALID_ARG;
+        if (J.aux_form > MASP_HIP_AUX_MONTGOMERY || (J.aux_form && J.a)) return MASP_HIP_E_INVALID_ARG;  // (a, b, c given: nothing reads aux as Montgomery)
         if (!rs_in_range(J.r) || !rs_in_range(J.s)) return MASP_HIP_E_SCALAR_RANGE;
     }
     // jobs are bucketed by (circuit, a/b/c mode) — whatever their order in the list — and every bucket is cut into
@@ -673,7 +678,7 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
     std::vector<Group> groups;
     {
         std::map<std::pair<uint32_t, bool>, std::vector<size_t>> by_kind;
-        for (size_t j = 0; j < n; ++j) by_kind[{jobs[j].circuit, jobs[j].a != nullptr}].push_back(j);
+        for (size_t j = 0; j < n; ++j) by_kind[{jobs[j].circuit | (jobs[j].aux_form ? 0x100u : 0u), jobs[j].a != nullptr}].push_back(j);
         for (auto& kv : by_kind)
             for (auto& eg : even_groups(kv.second.size(), ctx->batch_cap)) {
                 Group g;
@@ -781,7 +786,7 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
                 last_hip_error() = "memset failed";
                 result = fail_shared(ctx, MASP_HIP_E_HIP);
                 ok = false;
-            } else if ((rc = enqueue_proofs(sl, C, (uint32_t)np, sl.w.p, nv, abc, sl.rs.p, sl.proof.p))) {
+            } else if ((rc = enqueue_proofs(sl, C, (uint32_t)np, sl.w.p, nv, abc, sl.rs.p, sl.proof.p, jobs[G.idx[0]].aux_form == MASP_HIP_AUX_MONTGOMERY))) {
                 result = fail_shared(ctx, rc);
                 ok = false;
             }
@@ -822,6 +827,8 @@ int masp_hip_prove(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* inputs, cons
     J.a = a;
     J.b = b;
     J.c = c;
+    J.aux_form = MASP_HIP_AUX_CANONICAL;
+    J.reserved = 0;
     memcpy(J.r, r, 32);
     memcpy(J.s, s, 32);
     uint8_t tmp[192];
@@ -990,6 +997,7 @@ int masp_hip_batch_upload(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs)
     for (size_t j = 0; j < n; ++j) {
         if (jobs[j].circuit >= MASP_HIP_MAX_CIRCUITS || !ctx->circ[jobs[j].circuit]) return -MASP_HIP_E_NOT_LOADED;
         if (!rs_in_range(jobs[j].r) || !rs_in_range(jobs[j].s)) return -MASP_HIP_E_SCALAR_RANGE;
+        if (jobs[j].aux_form != MASP_HIP_AUX_CANONICAL) return -MASP_HIP_E_INVALID_ARG;  // resident assignments are proved repeatedly: canonical only
     }
     for (uint32_t c = 0; c < MASP_HIP_MAX_CIRCUITS; ++c)
         for (size_t j = 0; j < n; ++j)

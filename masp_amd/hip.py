@@ -31,7 +31,11 @@ class OptionsStruct(C.Structure):
 
 class JobStruct(C.Structure):
     _fields_ = [("circuit", C.c_uint32), ("inputs", C.c_void_p), ("aux", C.c_void_p), ("a", C.c_void_p),
-                ("b", C.c_void_p), ("c", C.c_void_p), ("r", C.c_uint8 * 32), ("s", C.c_uint8 * 32)]
+                ("b", C.c_void_p), ("c", C.c_void_p), ("r", C.c_uint8 * 32), ("s", C.c_uint8 * 32), ("aux_form", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+AUX_CANONICAL, AUX_MONTGOMERY = 0, 1     # masp_hip_job::aux_form
 
 
 def library_path():
@@ -201,9 +205,10 @@ class Context:
         params = _u8(params)
         self._check(self._L.masp_hip_circuit_load(self._h, slot, _p(params), params.size, cs.ref))
 
-    def _job(self, slot, inputs, aux, r, s, abc=None):
+    def _job(self, slot, inputs, aux, r, s, abc=None, aux_form=AUX_CANONICAL):
         j = JobStruct()
         j.circuit = slot
+        j.aux_form = int(aux_form)
         inputs, aux = _u8(inputs, 32), _u8(aux, 32)
         keep = [inputs, aux]
         j.inputs, j.aux = inputs.ctypes.data, aux.ctypes.data
@@ -220,7 +225,7 @@ class Context:
         return self.prove_batch([(slot, inputs, aux, r, s, abc)])[0]
 
     def marshal_jobs(self, jobs):
-        """jobs: iterable of (slot, inputs, aux, r, s[, (a,b,c)]) -> (masp_hip_job array, n, keep-alive list): the argument
+        """jobs: iterable of (slot, inputs, aux, r, s[, (a,b,c)[, aux_form]]) -> (masp_hip_job array, n, keep-alive list): the argument
         of masp_hip_prove_batch, built once when the same list is proved repeatedly or timed."""
         jobs = list(jobs)
         arr = (JobStruct * len(jobs))()
@@ -228,7 +233,7 @@ class Context:
         for i, job in enumerate(jobs):
             slot, inputs, aux, r, s = job[:5]
             abc = job[5] if len(job) > 5 else None
-            arr[i], k = self._job(slot, inputs, aux, r, s, abc)
+            arr[i], k = self._job(slot, inputs, aux, r, s, abc, job[6] if len(job) > 6 else AUX_CANONICAL)
             keep.append(k)
         return arr, len(jobs), keep
 

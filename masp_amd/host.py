@@ -138,8 +138,9 @@ def _aux_buffer(cs, aux_out):
 
 
 def spend_assignment(ak, nsk, diversifier, rcm, ar, asset_identifier, value, anchor, path_siblings, position, rcv, check=False,
-                     aux_out=None):
-    """-> (inputs u8[8,32], aux u8[100497,32], cv, rk, nf)   — SaplingProvingContext::spend_proof up to the prover call."""
+                     aux_out=None, montgomery=False):
+    """-> (inputs u8[8,32], aux u8[100497,32], cv, rk, nf)   — SaplingProvingContext::spend_proof up to the prover call.
+    montgomery: aux leaves as Montgomery residues (blst_fr memory; masp_hip_job.aux_form = 1) instead of canonical bytes."""
     L = load_library()
     cs, _ = circuit("spend")
     inputs = np.zeros((cs.n_inputs, 32), np.uint8)
@@ -147,30 +148,31 @@ def spend_assignment(ak, nsk, diversifier, rcm, ar, asset_identifier, value, anc
     cv, rk, nf = (C.create_string_buffer(32) for _ in range(3))
     p = _path(path_siblings)
     _check(L.masp_host_spend_assignment(_b(ak), _b(nsk), _b(diversifier, 11), _b(rcm), _b(ar), _b(asset_identifier), value, _b(anchor),
-                                        p.ctypes.data, position, _b(rcv), 1 if check else 0, inputs.ctypes.data, aux.ctypes.data, cv, rk, nf))
+                                        p.ctypes.data, position, _b(rcv), (1 if check else 0) | (2 if montgomery else 0), inputs.ctypes.data,
+                                        aux.ctypes.data, cv, rk, nf))
     return inputs, aux, cv.raw, rk.raw, nf.raw
 
 
-def output_assignment(esk, diversifier, pk_d, rcm, asset_identifier, value, rcv, check=False, aux_out=None):
+def output_assignment(esk, diversifier, pk_d, rcm, asset_identifier, value, rcv, check=False, aux_out=None, montgomery=False):
     L = load_library()
     cs, _ = circuit("output")
     inputs = np.zeros((cs.n_inputs, 32), np.uint8)
     aux = _aux_buffer(cs, aux_out)
     cv = C.create_string_buffer(32)
     _check(L.masp_host_output_assignment(_b(esk), _b(diversifier, 11), _b(pk_d), _b(rcm), _b(asset_identifier), value, _b(rcv),
-                                         1 if check else 0, inputs.ctypes.data, aux.ctypes.data, cv))
+                                         (1 if check else 0) | (2 if montgomery else 0), inputs.ctypes.data, aux.ctypes.data, cv))
     return inputs, aux, cv.raw
 
 
-def convert_assignment(generator, value, anchor, path_siblings, position, rcv, check=False, aux_out=None):
+def convert_assignment(generator, value, anchor, path_siblings, position, rcv, check=False, aux_out=None, montgomery=False):
     L = load_library()
     cs, _ = circuit("convert")
     inputs = np.zeros((cs.n_inputs, 32), np.uint8)
     aux = _aux_buffer(cs, aux_out)
     cv = C.create_string_buffer(32)
     p = _path(path_siblings)
-    _check(L.masp_host_convert_assignment(_b(generator), value, _b(anchor), p.ctypes.data, position, _b(rcv), 1 if check else 0,
-                                          inputs.ctypes.data, aux.ctypes.data, cv))
+    _check(L.masp_host_convert_assignment(_b(generator), value, _b(anchor), p.ctypes.data, position, _b(rcv),
+                                          (1 if check else 0) | (2 if montgomery else 0), inputs.ctypes.data, aux.ctypes.data, cv))
     return inputs, aux, cv.raw
 
 

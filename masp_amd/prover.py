@@ -187,21 +187,21 @@ class LocalTxProver:
         buf = self._aux_take(SPEND)
         try:
             inputs, aux, cv, rk, nf = H.spend_assignment(ak, nsk, diversifier, rcm, ar, asset_type, value, anchor, siblings, position, rcv,
-                                                         aux_out=buf)
+                                                         aux_out=buf, montgomery=True)
         except H.HostError as e:
             self._aux_give([dict(slot=SPEND, _pinned=buf)])
             raise ProvingError(str(e)) from None           # invalid diversifier -> Err(()) (sapling/prover.rs:84)
-        return dict(slot=SPEND, inputs=inputs, aux=aux, cv=cv, rk=rk, nf=nf, rcv=rcv, _pinned=buf)
+        return dict(slot=SPEND, inputs=inputs, aux=aux, aux_form=1, cv=cv, rk=rk, nf=nf, rcv=rcv, _pinned=buf)
 
     def prepare_output(self, esk, payment_address, rcm, asset_type, value, rcv):
         diversifier, pk_d = payment_address
         buf = self._aux_take(OUTPUT)
         try:
-            inputs, aux, cv = H.output_assignment(esk, diversifier, pk_d, rcm, asset_type, value, rcv, aux_out=buf)
+            inputs, aux, cv = H.output_assignment(esk, diversifier, pk_d, rcm, asset_type, value, rcv, aux_out=buf, montgomery=True)
         except H.HostError as e:
             self._aux_give([dict(slot=OUTPUT, _pinned=buf)])
             raise ProvingError(str(e)) from None
-        return dict(slot=OUTPUT, inputs=inputs, aux=aux, cv=cv, rcv=rcv, _pinned=buf)
+        return dict(slot=OUTPUT, inputs=inputs, aux=aux, aux_form=1, cv=cv, rcv=rcv, _pinned=buf)
 
     def prepare_convert(self, allowed_conversion, value, anchor, merkle_path, rcv):
         """allowed_conversion: a host.AllowedConversion (masp_primitives/src/convert.rs:22-29), or just its generator point
@@ -210,11 +210,11 @@ class LocalTxProver:
         generator = allowed_conversion.generator if isinstance(allowed_conversion, H.AllowedConversion) else allowed_conversion
         buf = self._aux_take(CONVERT)
         try:
-            inputs, aux, cv = H.convert_assignment(generator, value, anchor, siblings, position, rcv, aux_out=buf)
+            inputs, aux, cv = H.convert_assignment(generator, value, anchor, siblings, position, rcv, aux_out=buf, montgomery=True)
         except H.HostError as e:
             self._aux_give([dict(slot=CONVERT, _pinned=buf)])
             raise ProvingError(str(e)) from None
-        return dict(slot=CONVERT, inputs=inputs, aux=aux, cv=cv, rcv=rcv, _pinned=buf)
+        return dict(slot=CONVERT, inputs=inputs, aux=aux, aux_form=1, cv=cv, rcv=rcv, _pinned=buf)
 
     def prove_batch(self, ctx, descriptions, threads=None, rs=None, chunk=None, progress=None):
         """Batched form of the serial per-description loops of `SaplingBuilder::build`
@@ -345,7 +345,8 @@ class LocalTxProver:
         """jobs: outputs of prepare_*; rs: optional explicit [(r, s)] (deterministic replay) -> list of 192-byte proofs."""
         if rs is None:
             rs = [(self._rng(), self._rng()) for _ in jobs]
-        return self._ctx.prove_batch([(j["slot"], j["inputs"], j["aux"], r, s) for j, (r, s) in zip(jobs, rs)])
+        # (the aux assignments come from libmasp_host as Montgomery residues — masp_hip_job::aux_form = 1: no conversion on the host)
+        return self._ctx.prove_batch([(j["slot"], j["inputs"], j["aux"], r, s, None, j.get("aux_form", 0)) for j, (r, s) in zip(jobs, rs)])
 
     # ---- the TxProver methods ----
     def spend_proof(self, ctx, proof_generation_key, diversifier, rseed, ar, asset_type, value, anchor, merkle_path, rcv, rs=None):

@@ -493,3 +493,36 @@ def test_local_tx_prover_batch_equals_serial(ctx):
     assert {k: len(v) for k, v in lp._pool.items()} == pooled and len(lp._ctx._pinned) == slabs
     assert lp.prove_batch(lp.new_sapling_proving_context(), descs, rs=rs) == serial        # and the prover is still usable
     lp.close()
+
+
+def test_aux_as_montgomery_residues_gives_the_same_proofs(ctx):
+    """masp_hip_job::aux_form = MASP_HIP_AUX_MONTGOMERY: the aux assignment arrives as Montgomery residues (blst_fr memory) and is
+    made canonical on the device before anything reads it as scalars.  Same bytes as the canonical hand-over, lone and in a
+    batch, mixed with canonical jobs in one call; a residue >= r is refused like a non-canonical scalar."""
+    import masp_amd
+    from masp_amd import host as H
+    from masp_amd import workload as W
+    from masp_amd.synthetic import toxic_waste
+    cs = H.circuit("output")[0]
+    params = ctx.generate_parameters(cs, toxic_waste(91))
+    ctx.load_circuit(1, params, cs)
+    rng = random.Random(12)
+    descs = [W.description("output", 500 + i)[1] for i in range(12)]
+
+    def asg(kw, mont):
+        d, pk = kw["payment_address"]
+        return H.output_assignment(kw["esk"], d, pk, kw["rcm"], kw["asset_type"], kw["value"], kw["rcv"], montgomery=mont)[:2]
+    canon = [asg(kw, False) for kw in descs]
+    mont = [asg(kw, True) for kw in descs]
+    rs = [(rng.randrange(R), rng.randrange(R)) for _ in descs]
+    want = ctx.prove_batch([(1, i, a, r, s) for (i, a), (r, s) in zip(canon, rs)])
+    got = ctx.prove_batch([(1, i, a, r, s, None, 1) for (i, a), (r, s) in zip(mont, rs)])
+    assert got == want
+    assert ctx.prove_batch([(1, mont[0][0], mont[0][1], rs[0][0], rs[0][1], None, 1)]) == want[:1]          # lone-proof mode
+    mixed = [(1, *(mont[j] if j % 2 else canon[j]), rs[j][0], rs[j][1], None, j % 2) for j in range(12)]
+    assert ctx.prove_batch(mixed) == want
+    bad = mont[1][1].copy()
+    bad[5] = np.frombuffer((R + 1).to_bytes(32, "little"), np.uint8)
+    with pytest.raises(masp_amd.MaspHipError) as e:
+        ctx.prove_batch([(1, mont[1][0], bad, 1, 2, None, 1)])
+    assert e.value.code == 8

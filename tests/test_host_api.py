@@ -68,3 +68,31 @@ def test_bench_instances_are_distinct_and_satisfy_their_circuits(kind):
     # deterministic in (kind, seed)
     again = W.instances(kind, 2, first_seed=50, threads=1)
     assert all((x[0] == y[0]).all() and (x[1] == y[1]).all() for x, y in zip(insts, again))
+
+
+def test_aux_assignment_as_montgomery_residues():
+    """masp_hip_job::aux_form = 1: libmasp_host can hand over the aux assignment as Montgomery residues (four little-endian u64
+    limbs of a * 2^256 mod r: the in-memory form of blst_fr) instead of canonical bytes; same witness, other encoding."""
+    import numpy as np
+    from masp_amd import host as H
+    from masp_amd import workload as W
+    R = H.FR_MODULUS
+    for kind in ("spend", "output", "convert"):
+        _, kw = W.description(kind, 3)
+        inputs, aux = W.assignment(kind, kw)
+        if kind == "spend":
+            ak, nsk = kw["proof_generation_key"]
+            sib, pos = kw["merkle_path"]
+            in2, aux2, *_ = H.spend_assignment(ak, nsk, kw["diversifier"], kw["rcm"], kw["ar"], kw["asset_type"], kw["value"], kw["anchor"], sib, pos,
+                                               kw["rcv"], montgomery=True)
+        elif kind == "output":
+            d, pk = kw["payment_address"]
+            in2, aux2, _ = H.output_assignment(kw["esk"], d, pk, kw["rcm"], kw["asset_type"], kw["value"], kw["rcv"], montgomery=True)
+        else:
+            sib, pos = kw["merkle_path"]
+            in2, aux2, _ = H.convert_assignment(kw["allowed_conversion"].generator, kw["value"], kw["anchor"], sib, pos, kw["rcv"], montgomery=True)
+        assert (in2 == inputs).all() and aux2.shape == aux.shape
+        rng = np.random.default_rng(1)
+        for j in list(rng.integers(0, aux.shape[0], 300)) + [0, aux.shape[0] - 1]:
+            a = int.from_bytes(aux[j].tobytes(), "little")
+            assert int.from_bytes(aux2[j].tobytes(), "little") == a * (1 << 256) % R
