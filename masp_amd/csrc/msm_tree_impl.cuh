@@ -11,7 +11,10 @@ namespace masp {
 static inline uint32_t tree_points_ub(uint64_t E_ub, uint32_t nb, uint32_t L) { return (uint32_t)((E_ub >> L) + nb + 1); }
 static inline uint32_t tree_pairs_ub(uint64_t E_ub, uint32_t nb, uint32_t L) { return (uint32_t)((E_ub >> (L + 1)) + nb / 2 + 1); }
 // lanes per proof of the two passes: ~MSM_TREE_KP pairs per lane, whole workgroups
-static constexpr uint32_t MSM_TREE_KP = 32;
+#ifndef MASP_TREE_KP
+#define MASP_TREE_KP 128   // pairs per lane of the two passes (16 / 32 / 64 / 128 / 256 measured: 955 / 981 / 997 / 1007 / 1009 proofs/s)
+#endif
+static constexpr uint32_t MSM_TREE_KP = MASP_TREE_KP;
 static inline uint32_t tree_lanes(uint64_t E_ub, uint32_t nb, uint32_t L) {
     const uint32_t pairs = tree_pairs_ub(E_ub, nb, L);
     return std::max<uint32_t>(256u, ((pairs + MSM_TREE_KP - 1) / MSM_TREE_KP + 255u) & ~255u);
