@@ -217,6 +217,49 @@ __device__ __forceinline__ Fe<C> fe_mul(const Fe<C>& a, const Fe<C>& b) {
     fe_reduce_once(r);
     return r;
 }
+// Montgomery form of a*b + z*w with ONE reduction: the two products are summed column by column before the quotient digit
+// of the column is taken (3 N^2 multiply-adds instead of 4 N^2 for two products and an addition).  Needs 2 p^2 < p R, i.e.
+// p < R / 2, to come out below 2p: true for both moduli (p < 2^381, q < 2^255).
+template <int K, class C>
+__device__ __forceinline__ void mont2_columns_lo(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* b, const uint32_t* z,
+                                                 const uint32_t* w, uint32_t* m) {
+    if constexpr (K < C::N) {
+        macs_vv<0, K + 1, K, C>(acc, c2, a, b);
+        macs_vv<0, K + 1, K, C>(acc, c2, z, w);
+        macs_vs<0, K, K, C>(acc, c2, m);
+        m[K] = (uint32_t)acc * C::INV;
+        mac_vs(acc, c2, m[K], C::MOD[0]);  // low word is now 0
+        acc = (acc >> 32) | ((uint64_t)c2 << 32);
+        c2 = 0;
+        mont2_columns_lo<K + 1, C>(acc, c2, a, b, z, w, m);
+    }
+}
+template <int K, class C>
+__device__ __forceinline__ void mont2_columns_hi(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* b, const uint32_t* z,
+                                                 const uint32_t* w, const uint32_t* m, uint32_t* r) {
+    if constexpr (K < 2 * C::N - 1) {
+        macs_vv<K - C::N + 1, C::N, K, C>(acc, c2, a, b);
+        macs_vv<K - C::N + 1, C::N, K, C>(acc, c2, z, w);
+        macs_vs<K - C::N + 1, C::N, K, C>(acc, c2, m);
+        r[K - C::N] = (uint32_t)acc;
+        acc = (acc >> 32) | ((uint64_t)c2 << 32);
+        c2 = 0;
+        mont2_columns_hi<K + 1, C>(acc, c2, a, b, z, w, m, r);
+    }
+}
+template <class C>
+__device__ __forceinline__ Fe<C> fe_mul2(const Fe<C>& a, const Fe<C>& b, const Fe<C>& z, const Fe<C>& w) {
+    constexpr int N = C::N;
+    uint32_t m[N];
+    Fe<C> r;
+    uint64_t acc = 0;
+    uint32_t c2 = 0;
+    mont2_columns_lo<0, C>(acc, c2, a.v, b.v, z.v, w.v, m);
+    mont2_columns_hi<N, C>(acc, c2, a.v, b.v, z.v, w.v, m, r.v);
+    r.v[N - 1] = (uint32_t)acc;  // (2 p^2 + R p) / R < 2p < 2^(32N): nothing above
+    fe_reduce_once(r);
+    return r;
+}
 // CIOS.  Because 2p - 1 < 2^(32N) the running value fits in N+1 limbs (invariant t <= 2p - 1 after
 // every outer iteration).
 template <class C>
@@ -925,6 +968,8 @@ struct FpMulCold {
 struct FpOps {
     typedef Fp T;
     typedef FpMulCold Cold;
+    typedef FpOps Base;                     // the ops of the stored element (see Fp2PairOps)
+    static constexpr uint32_t LANES = 1;    // lanes that hold one element
     static MASP_HD T zero() { return fe_zero<FpCfg>(); }
     static MASP_HD T one() { return fe_one<FpCfg>(); }
     static MASP_HD T add(const T& a, const T& b) { return fe_add(a, b); }
@@ -942,6 +987,8 @@ struct FpOps {
 struct Fp2Ops {
     typedef Fp2 T;
     typedef Fp2Ops Cold;  // already call-based
+    typedef Fp2Ops Base;
+    static constexpr uint32_t LANES = 1;
     static MASP_HD T zero() { return {fe_zero<FpCfg>(), fe_zero<FpCfg>()}; }
     static MASP_HD T one() { return {fe_one<FpCfg>(), fe_zero<FpCfg>()}; }
     static MASP_HD T add(const T& a, const T& b) { return {fe_add(a.c0, b.c0), fe_add(a.c1, b.c1)}; }
@@ -975,5 +1022,59 @@ struct Fp2Ops {
         return {fe_mul_nc(a.c0, n), fe_neg(fe_mul_nc(a.c1, n))};
     }
 };
+
+#if defined(__HIPCC__)
+// Fp2 over a PAIR of adjacent lanes: the even lane holds c0, the odd lane c1, and the partner's half arrives through a DPP
+// quad permutation (a register move, no LDS).  An element costs a lane 12 VGPRs instead of 24, so a kernel written over
+// Fp2PairOps has the register footprint of its G1 twin (two waves per SIMD where the Fp2Ops form gets one), and the products
+// cost what Karatsuba costs:  mul = one fused a b + z w per lane (3 N^2 multiply-adds x 2 lanes = 3 products' worth, one
+// reduction each), sqr = one product per lane.  Both lanes of a pair must be active and take the same branches.
+// A stored Fp2 (c0 | c1, 96 bytes) is reached as  reinterpret_cast<const Fp*>(ptr)[2 * index + half].
+struct Fp2PairOps {
+    typedef Fp T;
+    typedef Fp2Ops Base;
+    static constexpr uint32_t LANES = 2;
+    static __device__ __forceinline__ uint32_t half() { return threadIdx.x & 1u; }  // (one-dimensional workgroups)
+    static __device__ __forceinline__ uint32_t swap32(uint32_t v) {
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1, 0, 3, 2] */, 0xf, 0xf, true);
+    }
+    static __device__ __forceinline__ T partner(const T& a) {
+        T r;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) r.v[i] = swap32(a.v[i]);
+        return r;
+    }
+    static __device__ __forceinline__ T pick(bool odd, const T& e, const T& o) {
+        T r;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) r.v[i] = odd ? o.v[i] : e.v[i];
+        return r;
+    }
+    static __device__ __forceinline__ T zero() { return fe_zero<FpCfg>(); }
+    static __device__ __forceinline__ T one() { return half() ? fe_zero<FpCfg>() : fe_one<FpCfg>(); }
+    static __device__ __forceinline__ T add(const T& a, const T& b) { return fe_add(a, b); }
+    static __device__ __forceinline__ T sub(const T& a, const T& b) { return fe_sub(a, b); }
+    static __device__ __forceinline__ T neg(const T& a) { return fe_neg(a); }
+    static __device__ __forceinline__ T dbl(const T& a) { return fe_dbl(a); }
+    // even: a0 b0 - a1 b1 = a b + (-a') b';   odd: a0 b1 + a1 b0 = a' b + a b'     (' = the partner's half)
+    static __device__ __forceinline__ T mul(const T& a, const T& b) {
+        const bool odd = half();
+        const T ap = partner(a), bp = partner(b);
+        return fe_mul2(pick(odd, a, ap), b, pick(odd, fe_neg(ap), a), bp);
+    }
+    // even: (a0 + a1)(a0 - a1);   odd: 2 a0 a1
+    static __device__ __forceinline__ T sqr(const T& a) {
+        const bool odd = half();
+        const T ap = partner(a);
+        return fe_mul(pick(odd, fe_add(a, ap), fe_dbl(ap)), pick(odd, fe_sub(a, ap), a));
+    }
+    static __device__ __forceinline__ bool both(bool mine) {
+        const uint32_t f = mine ? 1u : 0u;
+        return (f & swap32(f)) != 0u;
+    }
+    static __device__ __forceinline__ bool is_zero(const T& a) { return both(fe_is_zero(a)); }
+    static __device__ __forceinline__ bool eq(const T& a, const T& b) { return both(fe_eq(a, b)); }
+};
+#endif
 
 }  // namespace masp

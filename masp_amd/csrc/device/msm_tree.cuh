@@ -153,26 +153,37 @@ template <class O, bool L0>
 struct TreeSrc {
     typedef typename O::T F;
     typedef typename TreeRec<L0>::type Rec;
-    const TabRow<O>* tab;
+    // O::LANES lanes hold one element (Fp2PairOps: 2): lane `h` of them reads part h of every stored element
+    const TabRow<typename O::Base>* tab;
     const F *xs, *ys;  // this proof's points (deeper levels)
+    uint32_t h;
+    static __device__ __forceinline__ uint32_t lane_part() {
+        if constexpr (O::LANES > 1)
+            return O::half();
+        else
+            return 0u;
+    }
+    __device__ __forceinline__ const F& row_x(uint32_t w) const { return reinterpret_cast<const F*>(&tab[w & 0x7fffffffu].p.x)[h]; }
+    __device__ __forceinline__ const F& row_y(uint32_t w) const { return reinterpret_cast<const F*>(&tab[w & 0x7fffffffu].p.y)[h]; }
+    __device__ __forceinline__ size_t at(size_t i) const { return i * O::LANES + h; }
     __device__ __forceinline__ void load_x(const Rec& r, F& x1, F& x2) const {
         if constexpr (L0) {
-            x1 = tab[r.x & 0x7fffffffu].p.x;
-            x2 = tab[r.y & 0x7fffffffu].p.x;
+            x1 = row_x(r.x);
+            x2 = row_x(r.y);
         } else {
-            x1 = xs[r.x];
-            x2 = xs[r.x + 1];
+            x1 = xs[at(r.x)];
+            x2 = xs[at(r.x + 1)];
         }
     }
     // the y coordinates as stored (no arithmetic on them here: a load that is consumed at once cannot be overlapped with the
     // previous pair's products) ...
     __device__ __forceinline__ void load_y_raw(const Rec& r, F& y1, F& y2) const {
         if constexpr (L0) {
-            y1 = tab[r.x & 0x7fffffffu].p.y;
-            y2 = tab[r.y & 0x7fffffffu].p.y;
+            y1 = row_y(r.x);
+            y2 = row_y(r.y);
         } else {
-            y1 = ys[r.x];
-            y2 = ys[r.x + 1];
+            y1 = ys[at(r.x)];
+            y2 = ys[at(r.x + 1)];
         }
     }
     // ... and the signs of the digits applied (level 0)
@@ -211,6 +222,7 @@ k_tree_pass1(const TabRow<O>* __restrict__ tab, const typename O::T* __restrict_
     src.tab = tab;
     src.xs = xs + (size_t)p * pt_stride;
     src.ys = ys + (size_t)p * pt_stride;
+    src.h = 0;
     F chain = O::one();
     // two-stage software pipeline: the record of pair j + 2 and the operands of pair j + 1 are requested before pair j is
     // multiplied in — an operand is two dependent loads away (record, then row / point) and nothing else hides that
@@ -247,25 +259,27 @@ k_tree_pass1(const TabRow<O>* __restrict__ tab, const typename O::T* __restrict_
 // ---- pass 2: the additions --------------------------------------------------------------------------------------------
 // tinv[p NT + t] = 1 / tp[p NT + t].  The lane walks its pairs backwards: 1 / d_j = (1 / (d_0 .. d_j)) (d_0 .. d_{j-1}).
 template <class O, bool L0>
-__global__ void __launch_bounds__(256, (sizeof(typename O::T) > 48 ? 1 : 2))   // G1: two waves per SIMD (<= 256 VGPRs); G2 needs a SIMD per wave
-k_tree_pass2(const TabRow<O>* __restrict__ tab, const typename O::T* __restrict__ xs, const typename O::T* __restrict__ ys, size_t pt_stride,
-             const void* __restrict__ rec_, size_t rec_stride, const uint32_t* __restrict__ Ql, uint32_t nb, uint32_t NT,
+__global__ void __launch_bounds__(256, (sizeof(typename O::T) > 48 ? 1 : 2))   // two waves per SIMD (<= 256 VGPRs) where an element is 12 registers
+k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O::T* __restrict__ xs, const typename O::T* __restrict__ ys,
+             size_t pt_stride, const void* __restrict__ rec_, size_t rec_stride, const uint32_t* __restrict__ Ql, uint32_t nb, uint32_t NT,
              const typename O::T* __restrict__ pre, const typename O::T* __restrict__ tinv, typename O::T* __restrict__ ox,
              typename O::T* __restrict__ oy, size_t out_stride) {
     typedef typename O::T F;
     typedef typename TreeRec<L0>::type Rec;
-    const uint32_t p = MSM_P, np = gridDim.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr uint32_t LN = O::LANES;  // lanes per element; every stride and index below counts ELEMENTS (LN values of F each)
+    const uint32_t p = MSM_P, np = gridDim.y, t = (blockIdx.x * blockDim.x + threadIdx.x) / LN;
     if (t >= NT) return;
     const uint32_t P = Ql[(size_t)p * (nb + 1) + nb];
     if (t >= P) return;
     const Rec* rec = reinterpret_cast<const Rec*>(rec_) + (size_t)p * rec_stride;
-    ox += (size_t)p * out_stride;
-    oy += (size_t)p * out_stride;
+    ox += (size_t)p * out_stride * LN;
+    oy += (size_t)p * out_stride * LN;
     TreeSrc<O, L0> src;
     src.tab = tab;
-    src.xs = xs + (size_t)p * pt_stride;
-    src.ys = ys + (size_t)p * pt_stride;
-    F I = tinv[(size_t)p * NT + t];
+    src.xs = xs + (size_t)p * pt_stride * LN;
+    src.ys = ys + (size_t)p * pt_stride * LN;
+    src.h = TreeSrc<O, L0>::lane_part();
+    F I = tinv[src.at((size_t)p * NT + t)];
     // two-stage software pipeline, backwards: the record of pair j - 2 and the operands of pair j - 1 are requested before pair
     // j is computed (see pass 1)
     struct Ops {
@@ -290,11 +304,11 @@ k_tree_pass2(const TabRow<O>* __restrict__ tab, const typename O::T* __restrict_
         const Rec cr = ra;
         ra = rb;
         if (held) {
-            ox[hout] = hx;
-            oy[hout] = hy;
+            ox[src.at(hout)] = hx;
+            oy[src.at(hout)] = hy;
         }
         F pp = O::one();
-        if (j) pp = pre[((size_t)(j - 1) * np + p) * NT + t];
+        if (j) pp = pre[src.at(((size_t)(j - 1) * np + p) * NT + t)];
         if (j) fetch(ra, nxt);
         if (j > 1) rb = rec[t + (j - 2) * NT];
         const uint32_t out = TreeSrc<O, L0>::out_index(cr);
@@ -333,8 +347,8 @@ k_tree_pass2(const TabRow<O>* __restrict__ tab, const typename O::T* __restrict_
         held = true;
         if (!j) break;
     }
-    ox[hout] = hx;
-    oy[hout] = hy;
+    ox[src.at(hout)] = hx;
+    oy[src.at(hout)] = hy;
 }
 
 // the last point of a bucket with an odd number of points goes to the next level as it is.  grid (nb / 256, np)

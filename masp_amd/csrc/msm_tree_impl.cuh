@@ -3,6 +3,7 @@
 #pragma once
 #include "device/msm_tree.cuh"
 #include "msm_host.h"
+#include <type_traits>
 
 namespace masp {
 
@@ -11,6 +12,9 @@ namespace masp {
 static inline uint32_t tree_points_ub(uint64_t E_ub, uint32_t nb, uint32_t L) { return (uint32_t)((E_ub >> L) + nb + 1); }
 static inline uint32_t tree_pairs_ub(uint64_t E_ub, uint32_t nb, uint32_t L) { return (uint32_t)((E_ub >> (L + 1)) + nb / 2 + 1); }
 // lanes per proof of the two passes: ~MSM_TREE_KP pairs per lane, whole workgroups
+#ifndef MASP_TREE_G2_PAIR
+#define MASP_TREE_G2_PAIR 1
+#endif
 #ifndef MASP_TREE_KP
 #define MASP_TREE_KP 128   // pairs per lane of the two passes (16 / 32 / 64 / 128 / 256 measured: 955 / 981 / 997 / 1007 / 1009 proofs/s)
 #endif
@@ -112,15 +116,20 @@ int msm_tree_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSortBu
             hipLaunchKernelGGL((k_tree_pass1<O, false>), grid, block, 0, s, B.tab, xi, yi, si, (const void*)tw.rec, rec_stride, Ql, nb, NT, tw.pre, tw.tp);
         }
         tw.batch_invert(s, tw.tp, q * NT, tw.tinv);
-        if (L == 0) {
-            hipLaunchKernelGGL((k_tree_pass2<O, true>), grid, block, 0, s, B.tab, xi, yi, si, (const void*)tw.rec, rec_stride, Ql, nb, NT, (const F*)tw.pre,
-                               (const F*)tw.tinv, xo, yo, so);
+        // pass 2 of G2 runs over lane pairs (Fp2PairOps: half an element per lane, two waves per SIMD instead of one)
+        typedef typename std::conditional<(MASP_TREE_G2_PAIR != 0) && std::is_same<O, Fp2Ops>::value, Fp2PairOps, O>::type O2;
+        typedef typename O2::T F2;
+        const dim3 grid2(NT * O2::LANES / 256, q);
+        if (L == 0)
+            hipLaunchKernelGGL((k_tree_pass2<O2, true>), grid2, block, 0, s, B.tab, (const F2*)xi, (const F2*)yi, si, (const void*)tw.rec, rec_stride, Ql,
+                               nb, NT, (const F2*)tw.pre, (const F2*)tw.tinv, (F2*)xo, (F2*)yo, so);
+        else
+            hipLaunchKernelGGL((k_tree_pass2<O2, false>), grid2, block, 0, s, B.tab, (const F2*)xi, (const F2*)yi, si, (const void*)tw.rec, rec_stride, Ql,
+                               nb, NT, (const F2*)tw.pre, (const F2*)tw.tinv, (F2*)xo, (F2*)yo, so);
+        if (L == 0)
             hipLaunchKernelGGL((k_tree_copy<O, true>), cgrid, block, 0, s, B.tab, sorted, ent_stride, xi, yi, si, Dl, Dn, nb, xo, yo, so);
-        } else {
-            hipLaunchKernelGGL((k_tree_pass2<O, false>), grid, block, 0, s, B.tab, xi, yi, si, (const void*)tw.rec, rec_stride, Ql, nb, NT, (const F*)tw.pre,
-                               (const F*)tw.tinv, xo, yo, so);
+        else
             hipLaunchKernelGGL((k_tree_copy<O, false>), cgrid, block, 0, s, B.tab, sorted, ent_stride, xi, yi, si, Dl, Dn, nb, xo, yo, so);
-        }
     }
     return MASP_HIP_OK;
 }

@@ -4,7 +4,7 @@
 A=$1; B=$2; reps=${3:-3}; shift 3
 for i in $(seq $reps); do
   for L in $A $B; do
-    v=$(MASP_HIP_LIBRARY=$PWD/$L python bench.py --steps 8 --warmup 2 --no-cpu-baseline "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.1f  h2h %.1f  lat %.2f' % (d['value'], d['host_to_host']['value'], d['single_proof_latency_ms']))")
+    v=$(MASP_HIP_LIBRARY=$PWD/$L python bench.py --steps 8 --warmup 2 --no-cpu-baseline "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.1f  resident %.1f  lat %.2f' % (d['value'], d['resident']['value'], d['single_proof_latency_ms']))")
     echo "$L: $v"
   done
 done
