@@ -1033,6 +1033,7 @@ struct Fp2Ops {
 struct Fp2PairOps {
     typedef Fp T;
     typedef Fp2Ops Base;
+    typedef Fp2PairOps Cold;
     static constexpr uint32_t LANES = 2;
     static __device__ __forceinline__ uint32_t half() { return threadIdx.x & 1u; }  // (one-dimensional workgroups)
     static __device__ __forceinline__ uint32_t swap32(uint32_t v) {
@@ -1074,6 +1075,12 @@ struct Fp2PairOps {
     }
     static __device__ __forceinline__ bool is_zero(const T& a) { return both(fe_is_zero(a)); }
     static __device__ __forceinline__ bool eq(const T& a, const T& b) { return both(fe_eq(a, b)); }
+    // 1 / (a0 + a1 u) = (a0 - a1 u) / (a0^2 + a1^2): both lanes invert the same norm
+    static __device__ __forceinline__ T inv_gcd(const T& a) {
+        const T ap = partner(a);
+        const T r = fe_mul(a, fe_inv_bingcd(fe_mul2(a, a, ap, ap)));
+        return half() ? fe_neg(r) : r;
+    }
 };
 #endif
 

@@ -209,20 +209,21 @@ struct TreeSrc {
 // grid (NT / 256, np).  pre[(j np + p) NT + t] = product of the denominators of lane (p, t)'s pairs 0 .. j; tp[p NT + t] = all of them.
 template <class O, bool L0>
 __global__ void __launch_bounds__(256)
-k_tree_pass1(const TabRow<O>* __restrict__ tab, const typename O::T* __restrict__ xs, const typename O::T* __restrict__ ys, size_t pt_stride,
-             const void* __restrict__ rec_, size_t rec_stride, const uint32_t* __restrict__ Ql, uint32_t nb, uint32_t NT, typename O::T* __restrict__ pre,
-             typename O::T* __restrict__ tp) {
+k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O::T* __restrict__ xs, const typename O::T* __restrict__ ys,
+             size_t pt_stride, const void* __restrict__ rec_, size_t rec_stride, const uint32_t* __restrict__ Ql, uint32_t nb, uint32_t NT,
+             typename O::T* __restrict__ pre, typename O::T* __restrict__ tp) {
     typedef typename O::T F;
     typedef typename TreeRec<L0>::type Rec;
-    const uint32_t p = MSM_P, np = gridDim.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr uint32_t LN = O::LANES;  // lanes per element (see k_tree_pass2)
+    const uint32_t p = MSM_P, np = gridDim.y, t = (blockIdx.x * blockDim.x + threadIdx.x) / LN;
     if (t >= NT) return;
     const uint32_t P = Ql[(size_t)p * (nb + 1) + nb];
     const Rec* rec = reinterpret_cast<const Rec*>(rec_) + (size_t)p * rec_stride;
     TreeSrc<O, L0> src;
     src.tab = tab;
-    src.xs = xs + (size_t)p * pt_stride;
-    src.ys = ys + (size_t)p * pt_stride;
-    src.h = 0;
+    src.xs = xs + (size_t)p * pt_stride * LN;
+    src.ys = ys + (size_t)p * pt_stride * LN;
+    src.h = TreeSrc<O, L0>::lane_part();
     F chain = O::one();
     // two-stage software pipeline: the record of pair j + 2 and the operands of pair j + 1 are requested before pair j is
     // multiplied in — an operand is two dependent loads away (record, then row / point) and nothing else hides that
@@ -240,7 +241,7 @@ k_tree_pass1(const TabRow<O>* __restrict__ tab, const typename O::T* __restrict_
     for (uint32_t q = t; q < P; q += NT, ++j) {
         const Rec cr = ra;
         const F cx1 = x1, cx2 = x2;
-        if (j) pre[((size_t)(j - 1) * np + p) * NT + t] = chain;
+        if (j) pre[src.at(((size_t)(j - 1) * np + p) * NT + t)] = chain;
         ra = rb;
         if (q + NT < P) src.load_x(ra, x1, x2);
         if (q + 2 * (uint64_t)NT < P) rb = rec[q + 2 * NT];
@@ -252,8 +253,8 @@ k_tree_pass1(const TabRow<O>* __restrict__ tab, const typename O::T* __restrict_
         }
         chain = O::mul(chain, d);
     }
-    if (j) pre[((size_t)(j - 1) * np + p) * NT + t] = chain;
-    tp[(size_t)p * NT + t] = chain;
+    if (j) pre[src.at(((size_t)(j - 1) * np + p) * NT + t)] = chain;
+    tp[src.at((size_t)p * NT + t)] = chain;
 }
 
 // ---- pass 2: the additions --------------------------------------------------------------------------------------------
@@ -379,54 +380,59 @@ k_tree_copy(const TabRow<O>* __restrict__ tab, const uint32_t* __restrict__ sort
 }
 
 // ---- grid-wide batch inversion (Montgomery's trick as chains of products) ------------------------------------------------
-// forward: thread m < M takes elements m, m + M, m + 2 M, ... < n: pre[k M + m] = product of its first k + 1, tot[m] = all
+// (all of these also run over lane pairs — O::LANES = 2, Fp2PairOps —: a chain is a string of dependent products, and a pair
+// finishes one in half the instructions)
+// forward: chain m < M takes elements m, m + M, m + 2 M, ... < n: pre[k M + m] = product of its first k + 1, tot[m] = all
 template <class O>
 __global__ void __launch_bounds__(256) k_binv_fwd(const typename O::T* __restrict__ in, uint32_t n, uint32_t M, typename O::T* __restrict__ pre,
                                                    typename O::T* __restrict__ tot) {
     typedef typename O::T F;
-    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr uint32_t LN = O::LANES;
+    const uint32_t m = (blockIdx.x * blockDim.x + threadIdx.x) / LN, h = threadIdx.x % LN;
     if (m >= M) return;
     F chain = O::one();
     uint32_t k = 0;
     for (uint32_t i = m; i < n; i += M, ++k) {
-        chain = O::mul(chain, in[i]);
-        pre[(size_t)k * M + m] = chain;
+        chain = O::mul(chain, in[(size_t)i * LN + h]);
+        pre[((size_t)k * M + m) * LN + h] = chain;
     }
-    tot[m] = chain;
+    tot[(size_t)m * LN + h] = chain;
 }
 // backward: out[i] = 1 / in[i] given itot[m] = 1 / tot[m]
 template <class O>
 __global__ void __launch_bounds__(256) k_binv_bwd(const typename O::T* __restrict__ in, uint32_t n, uint32_t M, const typename O::T* __restrict__ pre,
                                                    const typename O::T* __restrict__ itot, typename O::T* __restrict__ out) {
     typedef typename O::T F;
-    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr uint32_t LN = O::LANES;
+    const uint32_t m = (blockIdx.x * blockDim.x + threadIdx.x) / LN, h = threadIdx.x % LN;
     if (m >= M || m >= n) return;
-    F I = itot[m];
+    F I = itot[(size_t)m * LN + h];
     for (uint32_t k = (n - 1 - m) / M + 1; k-- > 0;) {
         const size_t i = (size_t)k * M + m;
-        const F v = in[i];
-        out[i] = k ? O::mul(I, pre[(size_t)(k - 1) * M + m]) : I;
+        const F v = in[i * LN + h];
+        out[i * LN + h] = k ? O::mul(I, pre[((size_t)(k - 1) * M + m) * LN + h]) : I;
         I = O::mul(I, v);
     }
 }
-// the middle: thread m < M inverts elements m, m + M, ... < n of `in` by one chain with its own inversion (binary gcd)
+// the middle: chain m < M inverts elements m, m + M, ... < n of `in` with its own inversion (binary gcd)
 template <class O>
 __global__ void __launch_bounds__(64) k_binv_mid(const typename O::T* __restrict__ in, uint32_t n, uint32_t M, typename O::T* __restrict__ pre,
                                                   typename O::T* __restrict__ out) {
     typedef typename O::T F;
-    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr uint32_t LN = O::LANES;
+    const uint32_t m = (blockIdx.x * blockDim.x + threadIdx.x) / LN, h = threadIdx.x % LN;
     if (m >= M || m >= n) return;
     F chain = O::one();
     uint32_t k = 0;
     for (uint32_t i = m; i < n; i += M, ++k) {
-        chain = O::mul(chain, in[i]);
-        pre[(size_t)k * M + m] = chain;
+        chain = O::mul(chain, in[(size_t)i * LN + h]);
+        pre[((size_t)k * M + m) * LN + h] = chain;
     }
     F I = O::inv_gcd(chain);
     while (k-- > 0) {
         const size_t i = (size_t)k * M + m;
-        const F v = in[i];
-        out[i] = k ? O::mul(I, pre[(size_t)(k - 1) * M + m]) : I;
+        const F v = in[i * LN + h];
+        out[i * LN + h] = k ? O::mul(I, pre[((size_t)(k - 1) * M + m) * LN + h]) : I;
         I = O::mul(I, v);
     }
 }
@@ -436,11 +442,13 @@ __global__ void __launch_bounds__(64) k_binv_mid(const typename O::T* __restrict
 template <class O>
 __global__ void __launch_bounds__(64, 1)
 k_msm_accumulate_pts(const typename O::T* __restrict__ xs, const typename O::T* __restrict__ ys, size_t pt_stride, const uint32_t* __restrict__ start,
-                     uint32_t nb, uint32_t nchunks, Xyzz<O>* __restrict__ part) {
-    const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
+                     uint32_t nb, uint32_t nchunks, Xyzz<typename O::Base>* __restrict__ part) {
+    typedef typename O::T F;
+    constexpr uint32_t LN = O::LANES;
+    const uint32_t ch = (blockIdx.x * blockDim.x + threadIdx.x) / LN, h = threadIdx.x % LN;
     if (ch >= nchunks) return;
-    xs += (size_t)MSM_P * pt_stride;
-    ys += (size_t)MSM_P * pt_stride;
+    xs += (size_t)MSM_P * pt_stride * LN;
+    ys += (size_t)MSM_P * pt_stride * LN;
     start += (size_t)MSM_P * (nb + 1);
     part += (size_t)MSM_P * ((size_t)nchunks + nb);
     const uint32_t total = start[nb];
@@ -454,11 +462,18 @@ k_msm_accumulate_pts(const typename O::T* __restrict__ xs, const typename O::T* 
         if (start[b + half] <= lo) b += half;
         span -= half;
     }
+    auto put = [&](uint32_t slot, const Xyzz<O>& v) {  // a stored XYZZ point is four elements of LN parts each
+        F* q = reinterpret_cast<F*>(part + slot);
+        q[h] = v.X;
+        q[LN + h] = v.Y;
+        q[2 * LN + h] = v.ZZ;
+        q[3 * LN + h] = v.ZZZ;
+    };
     uint32_t next = start[b + 1];
     Xyzz<O> acc = xyzz_inf<O>();
     for (uint32_t pos = lo; pos < hi; ++pos) {
         if (pos >= next) {
-            part[ch + b] = acc;
+            put(ch + b, acc);
             acc = xyzz_inf<O>();
             do {
                 ++b;
@@ -466,11 +481,11 @@ k_msm_accumulate_pts(const typename O::T* __restrict__ xs, const typename O::T* 
             } while (pos >= next);
         }
         Affine<O> pt;
-        pt.x = xs[pos];
-        pt.y = ys[pos];
+        pt.x = xs[(size_t)pos * LN + h];
+        pt.y = ys[(size_t)pos * LN + h];
         xyzz_madd(acc, pt, false);
     }
-    part[ch + b] = acc;
+    put(ch + b, acc);
 }
 
 }  // namespace masp

@@ -12,9 +12,15 @@ namespace masp {
 static inline uint32_t tree_points_ub(uint64_t E_ub, uint32_t nb, uint32_t L) { return (uint32_t)((E_ub >> L) + nb + 1); }
 static inline uint32_t tree_pairs_ub(uint64_t E_ub, uint32_t nb, uint32_t L) { return (uint32_t)((E_ub >> (L + 1)) + nb / 2 + 1); }
 // lanes per proof of the two passes: ~MSM_TREE_KP pairs per lane, whole workgroups
+// G2 kernels that run over lane pairs (Fp2PairOps, field.cuh: half an Fp2 per lane, two waves per SIMD where the Fp2Ops form
+// gets one).  Bits: 1 pass 2, 2 pass 1, 4 the shared inversions, 8 the accumulation of the level-T points.
 #ifndef MASP_TREE_G2_PAIR
-#define MASP_TREE_G2_PAIR 1
+#define MASP_TREE_G2_PAIR 15
 #endif
+template <class O, int BIT>
+struct TreeLaneOps {
+    typedef typename std::conditional<((MASP_TREE_G2_PAIR) & BIT) != 0 && std::is_same<O, Fp2Ops>::value, Fp2PairOps, O>::type type;
+};
 #ifndef MASP_TREE_KP
 #define MASP_TREE_KP 128   // pairs per lane of the two passes (16 / 32 / 64 / 128 / 256 measured: 955 / 981 / 997 / 1007 / 1009 proofs/s)
 #endif
@@ -69,15 +75,18 @@ int MsmTreeWs<O>::reserve(uint64_t E_ub, uint32_t nb, uint32_t q, uint32_t T) {
 // inversion each, then the chains backwards
 template <class O>
 void MsmTreeWs<O>::batch_invert(hipStream_t s, const F* in, uint32_t n, F* out) {
+    typedef typename TreeLaneOps<O, 4>::type OI;
+    typedef typename OI::T FI;
+    constexpr uint32_t LN = OI::LANES;
     if (n <= 4 * BINV_MID) {
         const uint32_t M = std::min<uint32_t>(n, BINV_MID);
-        hipLaunchKernelGGL((k_binv_mid<O>), dim3((M + 63) / 64), dim3(64), 0, s, in, n, M, bpre, out);
+        hipLaunchKernelGGL((k_binv_mid<OI>), dim3((M * LN + 63) / 64), dim3(64), 0, s, (const FI*)in, n, M, (FI*)bpre, (FI*)out);
         return;
     }
     const uint32_t M1 = (n + BINV_C - 1) / BINV_C, M2 = std::min<uint32_t>(M1, BINV_MID);
-    hipLaunchKernelGGL((k_binv_fwd<O>), dim3((M1 + 255) / 256), dim3(256), 0, s, in, n, M1, bpre, btot);
-    hipLaunchKernelGGL((k_binv_mid<O>), dim3((M2 + 63) / 64), dim3(64), 0, s, (const F*)btot, M1, M2, bpre2, bitot);
-    hipLaunchKernelGGL((k_binv_bwd<O>), dim3((M1 + 255) / 256), dim3(256), 0, s, in, n, M1, (const F*)bpre, (const F*)bitot, out);
+    hipLaunchKernelGGL((k_binv_fwd<OI>), dim3((M1 * LN + 255) / 256), dim3(256), 0, s, (const FI*)in, n, M1, (FI*)bpre, (FI*)btot);
+    hipLaunchKernelGGL((k_binv_mid<OI>), dim3((M2 * LN + 63) / 64), dim3(64), 0, s, (const FI*)btot, M1, M2, (FI*)bpre2, (FI*)bitot);
+    hipLaunchKernelGGL((k_binv_bwd<OI>), dim3((M1 * LN + 255) / 256), dim3(256), 0, s, (const FI*)in, n, M1, (const FI*)bpre, (const FI*)bitot, (FI*)out);
 }
 
 // T levels of pairwise affine additions over the digit lists of proofs [p0, p0 + q) of the sort `sb`.  Afterwards the points of
@@ -108,16 +117,20 @@ int msm_tree_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSortBu
         F *xo = tw.px[(L + 1) & 1], *yo = tw.py[(L + 1) & 1];
         const size_t si = tw.stride[L & 1], so = tw.stride[(L + 1) & 1];
         const dim3 rgrid(std::min<uint32_t>((pairs_ub + 255) / 256, 4096u), q), grid(NT / 256, q), cgrid((nb + 255) / 256, q), block(256);
+        typedef typename TreeLaneOps<O, 2>::type O1;
+        typedef typename O1::T F1;
+        const dim3 grid1(NT * O1::LANES / 256, q);
         if (L == 0) {
             hipLaunchKernelGGL(k_tree_records<true>, rgrid, block, 0, s, sorted, ent_stride, Dl, Dn, Ql, nb, (void*)tw.rec, rec_stride);
-            hipLaunchKernelGGL((k_tree_pass1<O, true>), grid, block, 0, s, B.tab, xi, yi, si, (const void*)tw.rec, rec_stride, Ql, nb, NT, tw.pre, tw.tp);
+            hipLaunchKernelGGL((k_tree_pass1<O1, true>), grid1, block, 0, s, B.tab, (const F1*)xi, (const F1*)yi, si, (const void*)tw.rec, rec_stride, Ql, nb,
+                               NT, (F1*)tw.pre, (F1*)tw.tp);
         } else {
             hipLaunchKernelGGL(k_tree_records<false>, rgrid, block, 0, s, sorted, ent_stride, Dl, Dn, Ql, nb, (void*)tw.rec, rec_stride);
-            hipLaunchKernelGGL((k_tree_pass1<O, false>), grid, block, 0, s, B.tab, xi, yi, si, (const void*)tw.rec, rec_stride, Ql, nb, NT, tw.pre, tw.tp);
+            hipLaunchKernelGGL((k_tree_pass1<O1, false>), grid1, block, 0, s, B.tab, (const F1*)xi, (const F1*)yi, si, (const void*)tw.rec, rec_stride, Ql, nb,
+                               NT, (F1*)tw.pre, (F1*)tw.tp);
         }
         tw.batch_invert(s, tw.tp, q * NT, tw.tinv);
-        // pass 2 of G2 runs over lane pairs (Fp2PairOps: half an element per lane, two waves per SIMD instead of one)
-        typedef typename std::conditional<(MASP_TREE_G2_PAIR != 0) && std::is_same<O, Fp2Ops>::value, Fp2PairOps, O>::type O2;
+        typedef typename TreeLaneOps<O, 1>::type O2;
         typedef typename O2::T F2;
         const dim3 grid2(NT * O2::LANES / 256, q);
         if (L == 0)
@@ -137,7 +150,10 @@ int msm_tree_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSortBu
 template <class O>
 void msm_launch_accumulate_pts(hipStream_t s, const typename O::T* xs, const typename O::T* ys, size_t pt_stride, const uint32_t* start, uint32_t nb,
                                uint32_t nchunks, Xyzz<O>* part, uint32_t np) {
-    hipLaunchKernelGGL((k_msm_accumulate_pts<O>), dim3((nchunks + 63) / 64, np), dim3(64), 0, s, xs, ys, pt_stride, start, nb, nchunks, part);
+    typedef typename TreeLaneOps<O, 8>::type OA;
+    typedef typename OA::T FA;
+    hipLaunchKernelGGL((k_msm_accumulate_pts<OA>), dim3((nchunks * OA::LANES + 63) / 64, np), dim3(64), 0, s, (const FA*)xs, (const FA*)ys, pt_stride, start,
+                       nb, nchunks, part);
 }
 
 }  // namespace masp
