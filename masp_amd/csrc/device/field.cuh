@@ -937,6 +937,11 @@ MASP_HD Fe<C> fe_inv_bingcd(const Fe<C>& a) {
     for (int i = 0; i < C::N; ++i) r3.v[i] = C::R3[i];
     return fe_mul(r, r3);
 }
+// out of line, for the serial tails (one lane converting one point): ~0.1 ms where the Fermat power takes ~1.1 ms
+template <class C>
+MASP_NOINLINE Fe<C> fe_inv_bingcd_nc(const Fe<C>& a) {
+    return fe_inv_bingcd(a);
+}
 // canonical value > (p-1)/2 ?  (zcash "lexicographically largest")
 template <class C>
 MASP_HD bool fe_canonical_gt_half(const Fe<C>& canon) {
@@ -981,7 +986,7 @@ struct FpOps {
     static MASP_HD bool is_zero(const T& a) { return fe_is_zero(a); }
     static MASP_HD bool eq(const T& a, const T& b) { return fe_eq(a, b); }
     static MASP_HD T inv(const T& a) { return fe_inv(a); }
-    static MASP_HD T inv_lone(const T& a) { return fe_inv_fermat(a); }  // for single-lane serial tails
+    static MASP_HD T inv_lone(const T& a) { return fe_inv_bingcd_nc(a); }  // for single-lane serial tails
     static MASP_HD T inv_gcd(const T& a) { return fe_inv_bingcd(a); }   // for a few thousand lanes each inverting one value
 };
 struct Fp2Ops {
@@ -1014,7 +1019,7 @@ struct Fp2Ops {
         return {fe_mul_nc(a.c0, n), fe_neg(fe_mul_nc(a.c1, n))};
     }
     static MASP_HD T inv_lone(const T& a) {
-        Fp n = fe_inv_fermat(fe_add(fe_mul_nc(a.c0, a.c0), fe_mul_nc(a.c1, a.c1)));
+        Fp n = fe_inv_bingcd_nc(fe_add(fe_mul_nc(a.c0, a.c0), fe_mul_nc(a.c1, a.c1)));
         return {fe_mul_nc(a.c0, n), fe_neg(fe_mul_nc(a.c1, n))};
     }
     static MASP_HD T inv_gcd(const T& a) {
@@ -1030,48 +1035,102 @@ struct Fp2Ops {
 // cost what Karatsuba costs:  mul = one fused a b + z w per lane (3 N^2 multiply-adds x 2 lanes = 3 products' worth, one
 // reduction each), sqr = one product per lane.  Both lanes of a pair must be active and take the same branches.
 // A stored Fp2 (c0 | c1, 96 bytes) is reached as  reinterpret_cast<const Fp*>(ptr)[2 * index + half].
-struct Fp2PairOps {
-    typedef Fp T;
-    typedef Fp2Ops Base;
-    typedef Fp2PairOps Cold;
-    static constexpr uint32_t LANES = 2;
+struct Fp2PairLanes {
     static __device__ __forceinline__ uint32_t half() { return threadIdx.x & 1u; }  // (one-dimensional workgroups)
     static __device__ __forceinline__ uint32_t swap32(uint32_t v) {
         return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1, 0, 3, 2] */, 0xf, 0xf, true);
     }
-    static __device__ __forceinline__ T partner(const T& a) {
-        T r;
+    static __device__ __forceinline__ Fp partner(const Fp& a) {
+        Fp r;
 #pragma unroll
         for (int i = 0; i < 12; ++i) r.v[i] = swap32(a.v[i]);
         return r;
     }
-    static __device__ __forceinline__ T pick(bool odd, const T& e, const T& o) {
-        T r;
+    static __device__ __forceinline__ Fp pick(bool odd, const Fp& e, const Fp& o) {
+        Fp r;
 #pragma unroll
         for (int i = 0; i < 12; ++i) r.v[i] = odd ? o.v[i] : e.v[i];
         return r;
     }
+    // even: a0 b0 - a1 b1 = a b + (-a') b';   odd: a0 b1 + a1 b0 = a' b + a b'     (' = the partner's half)
+    static __device__ __forceinline__ Fp mul(const Fp& a, const Fp& b) {
+        const bool odd = half();
+        const Fp ap = partner(a), bp = partner(b);
+        return fe_mul2(pick(odd, a, ap), b, pick(odd, fe_neg(ap), a), bp);
+    }
+    // even: (a0 + a1)(a0 - a1);   odd: 2 a0 a1
+    static __device__ __forceinline__ Fp sqr(const Fp& a) {
+        const bool odd = half();
+        const Fp ap = partner(a);
+        return fe_mul(pick(odd, fe_add(a, ap), fe_dbl(ap)), pick(odd, fe_sub(a, ap), a));
+    }
+};
+// the same products out of line, operands in registers (see fp_mul_call): for the tails, where code size and registers count
+__device__ __noinline__ FpRegs fp2pair_mul_call(u32x4 a0, u32x4 a1, u32x4 a2, u32x4 b0, u32x4 b1, u32x4 b2) {
+    Fp a, b;
+    a.v[0] = a0.x; a.v[1] = a0.y; a.v[2] = a0.z; a.v[3] = a0.w;
+    a.v[4] = a1.x; a.v[5] = a1.y; a.v[6] = a1.z; a.v[7] = a1.w;
+    a.v[8] = a2.x; a.v[9] = a2.y; a.v[10] = a2.z; a.v[11] = a2.w;
+    b.v[0] = b0.x; b.v[1] = b0.y; b.v[2] = b0.z; b.v[3] = b0.w;
+    b.v[4] = b1.x; b.v[5] = b1.y; b.v[6] = b1.z; b.v[7] = b1.w;
+    b.v[8] = b2.x; b.v[9] = b2.y; b.v[10] = b2.z; b.v[11] = b2.w;
+    const Fp r = Fp2PairLanes::mul(a, b);
+    FpRegs o;
+    o.q0 = u32x4{r.v[0], r.v[1], r.v[2], r.v[3]};
+    o.q1 = u32x4{r.v[4], r.v[5], r.v[6], r.v[7]};
+    o.q2 = u32x4{r.v[8], r.v[9], r.v[10], r.v[11]};
+    return o;
+}
+__device__ __noinline__ FpRegs fp2pair_sqr_call(u32x4 a0, u32x4 a1, u32x4 a2) {
+    Fp a;
+    a.v[0] = a0.x; a.v[1] = a0.y; a.v[2] = a0.z; a.v[3] = a0.w;
+    a.v[4] = a1.x; a.v[5] = a1.y; a.v[6] = a1.z; a.v[7] = a1.w;
+    a.v[8] = a2.x; a.v[9] = a2.y; a.v[10] = a2.z; a.v[11] = a2.w;
+    const Fp r = Fp2PairLanes::sqr(a);
+    FpRegs o;
+    o.q0 = u32x4{r.v[0], r.v[1], r.v[2], r.v[3]};
+    o.q1 = u32x4{r.v[4], r.v[5], r.v[6], r.v[7]};
+    o.q2 = u32x4{r.v[8], r.v[9], r.v[10], r.v[11]};
+    return o;
+}
+struct Fp2PairCold {
+    typedef Fp T;
+    static __device__ __forceinline__ T mul(const T& a, const T& b) {
+        FpRegs o = fp2pair_mul_call(u32x4{a.v[0], a.v[1], a.v[2], a.v[3]}, u32x4{a.v[4], a.v[5], a.v[6], a.v[7]}, u32x4{a.v[8], a.v[9], a.v[10], a.v[11]},
+                                    u32x4{b.v[0], b.v[1], b.v[2], b.v[3]}, u32x4{b.v[4], b.v[5], b.v[6], b.v[7]}, u32x4{b.v[8], b.v[9], b.v[10], b.v[11]});
+        T r;
+        r.v[0] = o.q0.x; r.v[1] = o.q0.y; r.v[2] = o.q0.z; r.v[3] = o.q0.w;
+        r.v[4] = o.q1.x; r.v[5] = o.q1.y; r.v[6] = o.q1.z; r.v[7] = o.q1.w;
+        r.v[8] = o.q2.x; r.v[9] = o.q2.y; r.v[10] = o.q2.z; r.v[11] = o.q2.w;
+        return r;
+    }
+    static __device__ __forceinline__ T sqr(const T& a) {
+        FpRegs o = fp2pair_sqr_call(u32x4{a.v[0], a.v[1], a.v[2], a.v[3]}, u32x4{a.v[4], a.v[5], a.v[6], a.v[7]}, u32x4{a.v[8], a.v[9], a.v[10], a.v[11]});
+        T r;
+        r.v[0] = o.q0.x; r.v[1] = o.q0.y; r.v[2] = o.q0.z; r.v[3] = o.q0.w;
+        r.v[4] = o.q1.x; r.v[5] = o.q1.y; r.v[6] = o.q1.z; r.v[7] = o.q1.w;
+        r.v[8] = o.q2.x; r.v[9] = o.q2.y; r.v[10] = o.q2.z; r.v[11] = o.q2.w;
+        return r;
+    }
+};
+struct Fp2PairOps {
+    typedef Fp T;
+    typedef Fp2Ops Base;
+    typedef Fp2PairCold Cold;
+    static constexpr uint32_t LANES = 2;
+    static __device__ __forceinline__ uint32_t half() { return Fp2PairLanes::half(); }
+    static __device__ __forceinline__ T partner(const T& a) { return Fp2PairLanes::partner(a); }
     static __device__ __forceinline__ T zero() { return fe_zero<FpCfg>(); }
     static __device__ __forceinline__ T one() { return half() ? fe_zero<FpCfg>() : fe_one<FpCfg>(); }
     static __device__ __forceinline__ T add(const T& a, const T& b) { return fe_add(a, b); }
     static __device__ __forceinline__ T sub(const T& a, const T& b) { return fe_sub(a, b); }
     static __device__ __forceinline__ T neg(const T& a) { return fe_neg(a); }
     static __device__ __forceinline__ T dbl(const T& a) { return fe_dbl(a); }
-    // even: a0 b0 - a1 b1 = a b + (-a') b';   odd: a0 b1 + a1 b0 = a' b + a b'     (' = the partner's half)
-    static __device__ __forceinline__ T mul(const T& a, const T& b) {
-        const bool odd = half();
-        const T ap = partner(a), bp = partner(b);
-        return fe_mul2(pick(odd, a, ap), b, pick(odd, fe_neg(ap), a), bp);
-    }
-    // even: (a0 + a1)(a0 - a1);   odd: 2 a0 a1
-    static __device__ __forceinline__ T sqr(const T& a) {
-        const bool odd = half();
-        const T ap = partner(a);
-        return fe_mul(pick(odd, fe_add(a, ap), fe_dbl(ap)), pick(odd, fe_sub(a, ap), a));
-    }
+    static __device__ __forceinline__ T mul(const T& a, const T& b) { return Fp2PairLanes::mul(a, b); }
+    static __device__ __forceinline__ T sqr(const T& a) { return Fp2PairLanes::sqr(a); }
     static __device__ __forceinline__ bool both(bool mine) {
         const uint32_t f = mine ? 1u : 0u;
-        return (f & swap32(f)) != 0u;
+        return (f & Fp2PairLanes::swap32(f)) != 0u;
     }
     static __device__ __forceinline__ bool is_zero(const T& a) { return both(fe_is_zero(a)); }
     static __device__ __forceinline__ bool eq(const T& a, const T& b) { return both(fe_eq(a, b)); }

@@ -115,11 +115,21 @@ __device__ __forceinline__ void xyzz_add_coop(G1Xyzz& acc, const G1Xyzz& b, uint
 // left.  part[6 p ..] = r*delta1, s*alpha1, r*beta1, s*A, r*B1, (r s)*delta1;  part2[p] = s*delta2.
 // rs: 8 limbs r | 8 limbs s (canonical).  fb1: tables of delta1, alpha1, beta1 (in that order); fb2: table of delta2.
 
-// lanes 0..3: r*delta1, s*alpha1, r*beta1, (r s)*delta1 through the fixed-base tables (<= 32 additions each)
-__global__ void __launch_bounds__(64) k_groth16_fixed_g1(const G1Xyzz* __restrict__ fb1, const uint32_t* __restrict__ rs, size_t rs_stride,
-                                                         G1Xyzz* __restrict__ part) {
-    const uint32_t j = threadIdx.x;
-    if (j >= 4) return;
+// value of lane (lane + d) of the wave, limb by limb
+template <class O>
+__device__ __forceinline__ Xyzz<O> xyzz_lane_down(const Xyzz<O>& p, int d) {
+    Xyzz<O> r;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&p);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+    for (uint32_t i = 0; i < sizeof(Xyzz<O>) / 4; ++i) dst[i] = (uint32_t)__shfl_down((int)src[i], d, 64);
+    return r;
+}
+// r*delta1, s*alpha1, r*beta1, (r s)*delta1 through the fixed-base tables: 128 lanes, 32 per product — lane w of a product
+// fetches the table entry of its 8-bit window, a shuffle tree adds the 32 entries (5 dependent additions instead of 32)
+__global__ void __launch_bounds__(128) k_groth16_fixed_g1(const G1Xyzz* __restrict__ fb1, const uint32_t* __restrict__ rs, size_t rs_stride,
+                                                          G1Xyzz* __restrict__ part) {
+    const uint32_t j = threadIdx.x >> 5, w = threadIdx.x & 31;
     rs += (size_t)blockIdx.x * rs_stride;
     part += (size_t)blockIdx.x * 6;
     Fr r, s;
@@ -128,19 +138,46 @@ __global__ void __launch_bounds__(64) k_groth16_fixed_g1(const G1Xyzz* __restric
         s.v[i] = rs[8 + i];
     }
     constexpr size_t TAB = 32 * 255;
-    const Fr rs_prod = fe_mul(fe_to_mont(r), s);  // mont(r) * s = r*s mod q, canonical
     const G1Xyzz* tab = fb1 + (j == 1 ? TAB : j == 2 ? 2 * TAB : 0);
-    const Fr k = j == 0 ? r : j == 1 ? s : j == 2 ? r : rs_prod;
-    part[j == 3 ? 5 : j] = xyzz_fixed_mul<FpOps>(tab, k);
+    Fr k = j == 1 ? s : r;
+    if (j == 3) k = fe_mul(fe_to_mont(r), s);  // mont(r) * s = r*s mod q, canonical
+    uint32_t d = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d = (w >> 2) == (uint32_t)i ? k.v[i] : d;
+    d = (d >> (8 * (w & 3))) & 0xffu;
+    G1Xyzz acc = d ? tab[w * 255 + d - 1] : xyzz_inf<FpOps>();
+    for (int dd = 16; dd >= 1; dd >>= 1) {
+        const G1Xyzz other = xyzz_lane_down(acc, dd);
+        if ((int)w < dd) xyzz_add_nc(acc, other);
+    }
+    if (w == 0) part[j == 3 ? 5 : j] = acc;
 }
-// one lane: s*delta2 on G2 through its fixed-base table
+// s*delta2 on G2 the same way over 32 lane PAIRS (Fp2PairOps: half a coordinate per lane)
 __global__ void __launch_bounds__(64) k_groth16_fixed_g2(const G2Xyzz* __restrict__ fb2, const uint32_t* __restrict__ rs, size_t rs_stride,
                                                          G2Xyzz* __restrict__ part2) {
-    if (threadIdx.x != 0) return;
+    typedef Fp2PairOps O;
+    const uint32_t w = threadIdx.x >> 1, h = threadIdx.x & 1u;
     rs += (size_t)blockIdx.x * rs_stride;
-    Fr s;
-    for (int i = 0; i < 8; ++i) s.v[i] = rs[8 + i];
-    part2[blockIdx.x] = xyzz_fixed_mul<Fp2Ops>(fb2, s);
+    const uint32_t d = (rs[8 + (w >> 2)] >> (8 * (w & 3))) & 0xffu;
+    Xyzz<O> acc = xyzz_inf<O>();
+    if (d) {
+        const Fp* q = reinterpret_cast<const Fp*>(fb2 + w * 255 + d - 1);
+        acc.X = q[h];
+        acc.Y = q[2 + h];
+        acc.ZZ = q[4 + h];
+        acc.ZZZ = q[6 + h];
+    }
+    for (int dd = 16; dd >= 1; dd >>= 1) {
+        const Xyzz<O> other = xyzz_lane_down(acc, 2 * dd);
+        if ((int)w < dd) xyzz_add_nc(acc, other);
+    }
+    if (w == 0) {
+        Fp* q = reinterpret_cast<Fp*>(part2 + blockIdx.x);
+        q[h] = acc.X;
+        q[2 + h] = acc.Y;
+        q[4 + h] = acc.ZZ;
+        q[6 + h] = acc.ZZZ;
+    }
 }
 // WHICH = 0: s*A -> part[3];  1: r*B1 -> part[4].  Lanes 0..15 build the table d*P (d < 16) in LDS, then lanes 0..3 run
 // 4-bit fixed windows (252 doublings + <= 64 additions, four lanes per point; exact for any curve point: no endomorphism,

@@ -80,11 +80,33 @@ __global__ void __launch_bounds__(64) k_msm_precompute(TabRow<O>* __restrict__ t
 #ifndef MASP_TAIL_MIN_WAVES
 #define MASP_TAIL_MIN_WAVES 1
 #endif
+// The tail kernels are written over O::LANES lanes per point (1; 2 for Fp2PairOps: the even lane holds the c0 halves of the four
+// coordinates, the odd lane the c1 halves — G2 at the register footprint of G1).  A stored point is Xyzz<O::Base>.
+template <class O>
+__device__ __forceinline__ Xyzz<O> xyzz_load(const Xyzz<typename O::Base>* __restrict__ p, uint32_t h) {
+    const typename O::T* q = reinterpret_cast<const typename O::T*>(p);
+    Xyzz<O> r;
+    r.X = q[h];
+    r.Y = q[O::LANES + h];
+    r.ZZ = q[2 * O::LANES + h];
+    r.ZZZ = q[3 * O::LANES + h];
+    return r;
+}
+template <class O>
+__device__ __forceinline__ void xyzz_store(Xyzz<typename O::Base>* __restrict__ p, const Xyzz<O>& v, uint32_t h) {
+    typename O::T* q = reinterpret_cast<typename O::T*>(p);
+    q[h] = v.X;
+    q[O::LANES + h] = v.Y;
+    q[2 * O::LANES + h] = v.ZZ;
+    q[3 * O::LANES + h] = v.ZZZ;
+}
+// launch with 64 lanes per workgroup: 64 / LANES buckets
 template <class O>
 __global__ void __launch_bounds__(64, MASP_TAIL_MIN_WAVES)
-k_msm_bucket_gather(const Xyzz<O>* __restrict__ part, const uint32_t* __restrict__ start, uint32_t nb, uint32_t nchunks,
-                    Xyzz<O>* __restrict__ bkt, uint32_t* __restrict__ heavy, uint32_t* __restrict__ n_heavy, uint32_t heavy_span) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+k_msm_bucket_gather(const Xyzz<typename O::Base>* __restrict__ part, const uint32_t* __restrict__ start, uint32_t nb, uint32_t nchunks,
+                    Xyzz<typename O::Base>* __restrict__ bkt, uint32_t* __restrict__ heavy, uint32_t* __restrict__ n_heavy, uint32_t heavy_span) {
+    constexpr uint32_t LN = O::LANES;
+    const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) / LN, h = threadIdx.x % LN;
     if (b >= nb) return;
     part += (size_t)MSM_P * ((size_t)nchunks + nb);
     start += (size_t)MSM_P * (nb + 1);
@@ -97,13 +119,13 @@ k_msm_bucket_gather(const Xyzz<O>* __restrict__ part, const uint32_t* __restrict
         const uint32_t K = msm_chunk_len(start[nb], nchunks);
         const uint32_t c0 = s0 / K, c1 = (s1 - 1) / K;
         if (c1 - c0 >= heavy_span) {
-            heavy[atomicAdd(n_heavy, 1u)] = b;
+            if (h == 0) heavy[atomicAdd(n_heavy, 1u)] = b;
             return;  // written by k_msm_bucket_heavy
         }
-        acc = part[c0 + b];
-        for (uint32_t c = c0 + 1; c <= c1; ++c) xyzz_add_nc(acc, part[c + b]);
+        acc = xyzz_load<O>(part + c0 + b, h);
+        for (uint32_t c = c0 + 1; c <= c1; ++c) xyzz_add_nc(acc, xyzz_load<O>(part + c + b, h));
     }
-    bkt[b] = acc;
+    xyzz_store<O>(bkt + b, acc, h);
 }
 // value of lane (lane + d) of the wave, limb by limb (a point is 36 / 96 dwords: noise next to one group addition)
 template <class O>
@@ -121,10 +143,11 @@ __device__ __forceinline__ Xyzz<O> xyzz_shfl_down(const Xyzz<O>& p, int d) {
 // thousands of buckets with ~80 partials each for a lone proof.)
 template <class O, uint32_t THREADS>
 __global__ void __launch_bounds__(THREADS, MASP_TAIL_MIN_WAVES)
-k_msm_bucket_heavy(const Xyzz<O>* __restrict__ part, const uint32_t* __restrict__ start, uint32_t nb, uint32_t nchunks,
-                   Xyzz<O>* __restrict__ bkt, const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ n_heavy) {
-    __shared__ Xyzz<O> sh[THREADS / 64];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+k_msm_bucket_heavy(const Xyzz<typename O::Base>* __restrict__ part, const uint32_t* __restrict__ start, uint32_t nb, uint32_t nchunks,
+                   Xyzz<typename O::Base>* __restrict__ bkt, const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ n_heavy) {
+    constexpr uint32_t LN = O::LANES, WE = 64 / LN, EL = THREADS / LN;  // points per wave / per workgroup
+    __shared__ Xyzz<typename O::Base> sh[THREADS / 64];
+    const uint32_t tid = threadIdx.x, e = tid / LN, h = tid % LN, le = (tid & 63) / LN, wid = tid >> 6;
     part += (size_t)MSM_P * ((size_t)nchunks + nb);
     start += (size_t)MSM_P * (nb + 1);
     bkt += (size_t)MSM_P * nb;
@@ -132,78 +155,82 @@ k_msm_bucket_heavy(const Xyzz<O>* __restrict__ part, const uint32_t* __restrict_
     n_heavy += MSM_P;
     const uint32_t nh = *n_heavy;
     const uint32_t K = msm_chunk_len(start[nb], nchunks);
-    for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
-        const uint32_t b = heavy[h];
+    for (uint32_t hb = blockIdx.x; hb < nh; hb += gridDim.x) {
+        const uint32_t b = heavy[hb];
         const uint32_t c0 = start[b] / K, c1 = (start[b + 1] - 1) / K;
         Xyzz<O> acc = xyzz_inf<O>();
-        for (uint32_t c = c0 + tid; c <= c1; c += THREADS) xyzz_add_nc(acc, part[c + b]);
-        const uint32_t span = c1 - c0 + 1;  // lanes >= span hold infinity: skip the tree levels that only move infinities
-        for (int d = 32; d >= 1; d >>= 1) {
-            if ((uint32_t)d >= span) continue;
-            Xyzz<O> other = xyzz_shfl_down(acc, d);
-            if ((int)lane < d) xyzz_add_nc(acc, other);
+        for (uint32_t c = c0 + e; c <= c1; c += EL) xyzz_add_nc(acc, xyzz_load<O>(part + c + b, h));
+        const uint32_t span = c1 - c0 + 1;  // points >= span hold infinity: skip the tree levels that only move infinities
+        for (uint32_t d = WE / 2; d >= 1; d >>= 1) {
+            if (d >= span) continue;
+            Xyzz<O> other = xyzz_shfl_down(acc, (int)(d * LN));
+            if (le < d) xyzz_add_nc(acc, other);
         }
         if constexpr (THREADS > 64) {
-            if (lane == 0) sh[wid] = acc;
+            if (le == 0) xyzz_store<O>(sh + wid, acc, h);
             __syncthreads();
-            if (tid == 0)
-                for (uint32_t w = 1; w < THREADS / 64; ++w) xyzz_add_nc(acc, sh[w]);
+            if (e == 0)
+                for (uint32_t w = 1; w < THREADS / 64; ++w) xyzz_add_nc(acc, xyzz_load<O>(sh + w, h));
         }
-        if (tid == 0) bkt[b] = acc;
+        if (e == 0) xyzz_store<O>(bkt + b, acc, h);
         if constexpr (THREADS > 64) __syncthreads();
     }
 }
 
 // ---- (6) reductions -----------------------------------------------------------------------------
-// One level of the weighted sum  V(B, off) = sum_k (k + off) * B[k].  A workgroup of WSUM_L lanes owns a chunk of
-// WSUM_CS = WSUM_G * WSUM_L elements and produces  S[ch] = sum_l B[ch*cs + l],  T[ch] = sum_l (l + off) * B[ch*cs + l];
+// One level of the weighted sum  V(B, off) = sum_k (k + off) * B[k].  A workgroup of WSUM_L points (WSUM_L x LANES lanes) owns
+// a chunk of WSUM_CS = WSUM_G * WSUM_L elements and produces  S[ch] = sum_l B[ch*cs + l],  T[ch] = sum_l (l + off) * B[ch*cs + l];
 // then V(B, off) = sum_ch T[ch] + cs * V(S, 0).
-//   phase 1  every lane runs the classic running sum over its own WSUM_G consecutive elements (2G - 1 additions);
+//   phase 1  every lane (pair) runs the classic running sum over its own WSUM_G consecutive elements (2G - 1 additions);
 //   phase 2  the per-lane sums are combined with a log-depth suffix scan and one tree through LDS.
 // ~4.5 additions per bucket in total (a pure log-depth scan costs 16) at a depth of 33 dependent additions:
 // with a batch of proofs in flight the chip is throughput-bound here, so work counts, not just depth.
 // G = 2^G_LOG is chosen by the host: 16 for batches (least work per bucket: ~2.9 additions), 4 for a lone proof
 // (shortest dependent chain).
 // (the G1 kernels of a batch are held to 256 registers = two waves per SIMD: 219 spilled, launch 3.8 -> 3.05 ms for h + l)
+#ifndef MASP_WSUM_PAIR_WAVES
+#define MASP_WSUM_PAIR_WAVES 2
+#endif
 template <class O, uint32_t G_LOG>
-__global__ void __launch_bounds__(128, (sizeof(Xyzz<O>) > 200 || G_LOG < 3 ? MASP_TAIL_MIN_WAVES : 2)) k_msm_wsum_level(const Xyzz<O>* __restrict__ B, size_t b_stride, uint32_t m, uint32_t off,
-                                                        Xyzz<O>* __restrict__ S, Xyzz<O>* __restrict__ T, size_t st_stride) {
-    constexpr uint32_t G = 1u << G_LOG, CS = G * WSUM_L;
-    __shared__ Xyzz<O> sh[2];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+__global__ void __launch_bounds__(WSUM_L * O::LANES, (O::LANES > 1 ? MASP_WSUM_PAIR_WAVES : sizeof(Xyzz<O>) > 200 || G_LOG < 3 ? MASP_TAIL_MIN_WAVES : 2))
+k_msm_wsum_level(const Xyzz<typename O::Base>* __restrict__ B, size_t b_stride, uint32_t m, uint32_t off, Xyzz<typename O::Base>* __restrict__ S,
+                 Xyzz<typename O::Base>* __restrict__ T, size_t st_stride) {
+    constexpr uint32_t G = 1u << G_LOG, CS = G * WSUM_L, LN = O::LANES, WE = 64 / LN, NW = WSUM_L / WE;  // points per wave, waves
+    __shared__ Xyzz<typename O::Base> sh[2][NW];
+    const uint32_t tid = threadIdx.x, e = tid / LN, h = tid % LN, le = (tid & 63) / LN, wid = tid >> 6;
     B += MSM_P * b_stride;
     S += MSM_P * st_stride;
     T += MSM_P * st_stride;
     // phase 1: lane-local running sum, top element first:  run = sum B_l,  acc = sum (l + off) B_l  (l local)
-    const uint32_t base = blockIdx.x * CS + tid * G;
+    const uint32_t base = blockIdx.x * CS + e * G;
     Xyzz<O> run = xyzz_inf<O>(), acc = xyzz_inf<O>();
     for (uint32_t l = G; l-- > 0;) {
-        if (base + l < m) xyzz_add_nc(run, B[base + l]);
+        if (base + l < m) xyzz_add_nc(run, xyzz_load<O>(B + base + l, h));
         if (l > 0 || off) xyzz_add_nc(acc, run);
     }
-    // phase 2: lanes.  sum_lane (lane * G) * run_lane = G * sum_{i >= 1} x_i  with x = inclusive suffix scan of run over
-    // the 128 lanes: a shuffle scan inside each wave, then wave 0 adds the total of wave 1
+    // phase 2: lanes.  sum_e (e * G) * run_e = G * sum_{i >= 1} x_i  with x = inclusive suffix scan of run over the WSUM_L
+    // points: a shuffle scan inside each wave, then every wave adds the totals of the waves behind it
     Xyzz<O> x = run;
-    for (int d = 1; d < 64; d <<= 1) {
-        Xyzz<O> other = xyzz_shfl_down(x, d);
-        if ((int)lane + d < 64) xyzz_add_nc(x, other);
+    for (uint32_t d = 1; d < WE; d <<= 1) {
+        Xyzz<O> other = xyzz_shfl_down(x, (int)(d * LN));
+        if (le + d < WE) xyzz_add_nc(x, other);
     }
-    if (wid == 1 && lane == 0) sh[0] = x;
+    if (wid > 0 && le == 0) xyzz_store<O>(&sh[0][wid], x, h);
     __syncthreads();
-    if (wid == 0) xyzz_add_nc(x, sh[0]);
-    Xyzz<O> y = tid > 0 ? x : xyzz_inf<O>();
+    for (uint32_t w = wid + 1; w < NW; ++w) xyzz_add_nc(x, xyzz_load<O>(&sh[0][w], h));
+    Xyzz<O> y = e > 0 ? x : xyzz_inf<O>();
     for (uint32_t k = 0; k < G_LOG; ++k) y = xyzz_dbl(y);
     xyzz_add_nc(y, acc);
-    for (int d = 32; d >= 1; d >>= 1) {
-        Xyzz<O> other = xyzz_shfl_down(y, d);
-        if ((int)lane < d) xyzz_add_nc(y, other);
+    for (uint32_t d = WE / 2; d >= 1; d >>= 1) {
+        Xyzz<O> other = xyzz_shfl_down(y, (int)(d * LN));
+        if (le < d) xyzz_add_nc(y, other);
     }
-    if (wid == 1 && lane == 0) sh[1] = y;
+    if (wid > 0 && le == 0) xyzz_store<O>(&sh[1][wid], y, h);
     __syncthreads();
-    if (tid == 0) {
-        xyzz_add_nc(y, sh[1]);
-        S[blockIdx.x] = x;
-        T[blockIdx.x] = y;
+    if (e == 0) {
+        for (uint32_t w = 1; w < NW; ++w) xyzz_add_nc(y, xyzz_load<O>(&sh[1][w], h));
+        xyzz_store<O>(S + blockIdx.x, x, h);
+        xyzz_store<O>(T + blockIdx.x, y, h);
     }
 }
 // out[b] = sum of in[b*256 .. min(n, b*256+256)) by an LDS tree (8 dependent additions)

@@ -6,7 +6,7 @@
 namespace masp {
 
 void launch_groth16_fixed_g1(hipStream_t s, const G1Xyzz* fb1, const uint32_t* rs, size_t rs_stride, G1Xyzz* part, uint32_t np) {
-    hipLaunchKernelGGL(k_groth16_fixed_g1, dim3(np), dim3(64), 0, s, fb1, rs, rs_stride, part);
+    hipLaunchKernelGGL(k_groth16_fixed_g1, dim3(np), dim3(128), 0, s, fb1, rs, rs_stride, part);
 }
 void launch_groth16_fixed_g2(hipStream_t s, const G2Xyzz* fb2, const uint32_t* rs, size_t rs_stride, G2Xyzz* part2, uint32_t np) {
     hipLaunchKernelGGL(k_groth16_fixed_g2, dim3(np), dim3(64), 0, s, fb2, rs, rs_stride, part2);

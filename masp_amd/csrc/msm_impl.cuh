@@ -3,8 +3,18 @@
 #pragma once
 #include "device/msm.cuh"
 #include "msm_host.h"
+#include <type_traits>
 
 namespace masp {
+
+// the G2 bucket tails (gather, heavy buckets, weighted sums) run over lane pairs (Fp2PairOps, field.cuh); 0: one lane per point
+#ifndef MASP_G2_PAIR_TAILS
+#define MASP_G2_PAIR_TAILS 1
+#endif
+template <class O>
+struct TailLaneOps {
+    typedef typename std::conditional<(MASP_G2_PAIR_TAILS) != 0 && std::is_same<O, Fp2Ops>::value, Fp2PairOps, O>::type type;
+};
 
 static inline uint32_t log2_ceil_u64(uint64_t n) {
     uint32_t k = 0;
@@ -121,15 +131,17 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
     // end).  A lone proof keeps span 12 and four waves (shortest chain for its one big bucket).
     // Workgroups go to the 8 XCDs round-robin by linear id x + gridDim.x * y, so with gridDim.x a multiple of 8 every proof's
     // first working workgroup (x = 0: bucket 0) would land on the same XCD: keep gridDim.x odd.
-    hipLaunchKernelGGL((k_msm_bucket_gather<O>), dim3((nb + 63) / 64, np), dim3(64), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy,
+    typedef typename TailLaneOps<O>::type OT;
+    constexpr uint32_t LN = OT::LANES;
+    hipLaunchKernelGGL((k_msm_bucket_gather<OT>), dim3((nb * LN + 63) / 64, np), dim3(64), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy,
                        ws.n_heavy, lone ? 12u : 8u);
     if (lone) {
         const uint32_t heavy_blocks = std::min<uint32_t>(std::max<uint32_t>(4096u / np, 16u), nb) | 1u;
-        hipLaunchKernelGGL((k_msm_bucket_heavy<O, 256>), dim3(heavy_blocks, np), dim3(256), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy,
+        hipLaunchKernelGGL((k_msm_bucket_heavy<OT, 256>), dim3(heavy_blocks, np), dim3(256), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy,
                            ws.n_heavy);
     } else {
         const uint32_t heavy_blocks = std::min<uint32_t>(64u, nb) | 1u;
-        hipLaunchKernelGGL((k_msm_bucket_heavy<O, 64>), dim3(heavy_blocks, np), dim3(64), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy,
+        hipLaunchKernelGGL((k_msm_bucket_heavy<OT, 64>), dim3(heavy_blocks, np), dim3(64), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy,
                            ws.n_heavy);
     }
     // weighted sum by levels of (G x 128)-bucket workgroups.  Per lane the kernel costs 2 G additions for its buckets plus
@@ -150,10 +162,10 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
     int level = 0, flip = 0;
     do {
         uint32_t chunks = (m + cs - 1) / cs;
-        const dim3 grid(chunks, np), block(WSUM_L);
+        const dim3 grid(chunks, np), block(WSUM_L * LN);
         switch (g_log) {
 #define MASP_WSUM_CASE(GL) \
-    case GL: hipLaunchKernelGGL((k_msm_wsum_level<O, GL>), grid, block, 0, s, bk, bk_stride, m, off, ws.S[flip], ws.T, st_stride); break;
+    case GL: hipLaunchKernelGGL((k_msm_wsum_level<OT, GL>), grid, block, 0, s, bk, bk_stride, m, off, ws.S[flip], ws.T, st_stride); break;
             MASP_WSUM_CASE(0) MASP_WSUM_CASE(2) MASP_WSUM_CASE(3) MASP_WSUM_CASE(4) MASP_WSUM_CASE(5) MASP_WSUM_CASE(6)
 #undef MASP_WSUM_CASE
         }
