@@ -51,6 +51,7 @@ k_msm_accumulate(const TabRow<O>* __restrict__ tab, const uint32_t* __restrict__
             } while (pos >= next);
         }
         uint32_t e = sorted[pos];
+        if (e == MSM_PAD_ENTRY) continue;  // aligned runs (MsmSortBuf::pad_log): the padding behind a run
         xyzz_madd(acc, tab[e & 0x7fffffffu].p, (e >> 31) != 0);
     }
     part[ch + b] = acc;

@@ -29,5 +29,7 @@ __host__ __device__ static inline uint32_t msm_chunk_len(uint32_t total, uint32_
 static constexpr unsigned WSUM_L_LOG = 7, WSUM_L = 1u << WSUM_L_LOG;
 static constexpr unsigned WSUM_G_LOG_MIN = 2;
 static constexpr unsigned MSM_SORT_THREADS = 1024;
+// the entry that fills the gap behind a bucket's run when runs are aligned (MsmSortBuf::pad_log): the point at infinity
+static constexpr uint32_t MSM_PAD_ENTRY = 0xffffffffu;
 
 }  // namespace masp

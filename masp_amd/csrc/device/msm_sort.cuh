@@ -79,14 +79,17 @@ k_msm_hist(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32_t 
     __syncthreads();
     for (uint32_t b = tid; b < nb; b += MSM_SORT_THREADS) hist_wg[b] = msm_lds[b];
 }
-// one workgroup per proof: hist_wg[wg][b] -> rel[wg][b] (in place), start[0..nb] (start[nb] = number of entries)
-__global__ void __launch_bounds__(1024) k_msm_offsets(uint32_t* __restrict__ hist_wg, uint32_t ng, uint32_t nb, uint32_t* __restrict__ start) {
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t base;
+// one workgroup per proof: hist_wg[wg][b] -> rel[wg][b] (in place); dense[0..nb] = offsets of the runs packed (dense[nb] =
+// number of entries), start[0..nb] = offsets with every run starting at a multiple of 2^pad_log (start[nb] likewise rounded up)
+__global__ void __launch_bounds__(1024)
+k_msm_offsets(uint32_t* __restrict__ hist_wg, uint32_t ng, uint32_t nb, uint32_t* __restrict__ start, uint32_t* __restrict__ dense, uint32_t pad_log) {
+    __shared__ uint32_t wsum[2][16];
+    __shared__ uint32_t base[2];
     hist_wg += (size_t)MSM_P * ng * nb;
     start += (size_t)MSM_P * (nb + 1);
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) base = 0;
+    dense += (size_t)MSM_P * (nb + 1);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, pad = (1u << pad_log) - 1u;
+    if (tid == 0) base[0] = base[1] = 0;
     __syncthreads();
     for (uint32_t b0 = 0; b0 < nb; b0 += blockDim.x) {
         const uint32_t b = b0 + tid;
@@ -97,33 +100,52 @@ __global__ void __launch_bounds__(1024) k_msm_offsets(uint32_t* __restrict__ his
                 hist_wg[(size_t)w * nb + b] = v;
                 v += h;
             }
-        uint32_t x = v;
+        const uint32_t pv = (v + pad) & ~pad;
+        uint32_t x = v, px = pv;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            uint32_t y = __shfl_up(x, d, 64);
-            if ((int)lane >= d) x += y;
+            uint32_t y = __shfl_up(x, d, 64), py = __shfl_up(px, d, 64);
+            if ((int)lane >= d) {
+                x += y;
+                px += py;
+            }
         }
-        if (lane == 63) wsum[wid] = x;
+        if (lane == 63) {
+            wsum[0][wid] = x;
+            wsum[1][wid] = px;
+        }
         __syncthreads();
-        uint32_t woff = 0;
-        for (uint32_t k = 0; k < wid; ++k) woff += wsum[k];
-        const uint32_t bs = base;
-        if (b < nb) start[b] = bs + woff + x - v;
+        uint32_t woff = 0, pwoff = 0;
+        for (uint32_t k = 0; k < wid; ++k) {
+            woff += wsum[0][k];
+            pwoff += wsum[1][k];
+        }
+        const uint32_t bs = base[0], pbs = base[1];
+        if (b < nb) {
+            dense[b] = bs + woff + x - v;
+            start[b] = pbs + pwoff + px - pv;
+        }
         __syncthreads();
-        if (tid == blockDim.x - 1) base = bs + woff + x;
+        if (tid == blockDim.x - 1) {
+            base[0] = bs + woff + x;
+            base[1] = pbs + pwoff + px;
+        }
         __syncthreads();
     }
-    if (tid == 0) start[nb] = base;
+    if (tid == 0) {
+        dense[nb] = base[0];
+        start[nb] = base[1];
+    }
 }
 __global__ void __launch_bounds__(1024)
 k_msm_scatter(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32_t n, MsmGeom g, uint32_t ng, const uint32_t* __restrict__ rel,
-              const uint32_t* __restrict__ start, uint32_t* __restrict__ sorted) {
+              const uint32_t* __restrict__ start, uint32_t* __restrict__ sorted, size_t sorted_stride) {
     extern __shared__ uint32_t msm_lds[];
     const uint32_t tid = threadIdx.x, wg = blockIdx.x, nb = (uint32_t)g.nb;
     scalars += MSM_P * scalar_stride;
     rel += ((size_t)MSM_P * ng + wg) * nb;
     start += (size_t)MSM_P * (nb + 1);
-    sorted += (size_t)MSM_P * n * g.W;
+    sorted += (size_t)MSM_P * sorted_stride;
     for (uint32_t b = tid; b < nb; b += MSM_SORT_THREADS) msm_lds[b] = start[b] + rel[b];
     __syncthreads();
     const uint32_t per = (n + ng - 1) / ng, lo = wg * per, hi = lo + per < n ? lo + per : n;
@@ -217,7 +239,7 @@ __device__ __forceinline__ void msm_small_scan(const uint32_t* cnt, uint32_t* of
 }
 __global__ void __launch_bounds__(1024)
 k_msm_partition(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32_t n, MsmGeom g, uint32_t ng, const uint32_t* __restrict__ crel,
-                const uint32_t* __restrict__ start, uint32_t* __restrict__ tmp) {
+                const uint32_t* __restrict__ start /* packed offsets: MsmSortBuf::dense */, uint32_t* __restrict__ tmp) {
     extern __shared__ uint32_t msm_lds[];
     const uint32_t tid = threadIdx.x, wg = blockIdx.x, nb = (uint32_t)g.nb, nbins = nb >> MSM_FINE_LOG;
     uint32_t* cursor = msm_lds;            // [256] global position of the next entry of each bin from this workgroup
@@ -285,14 +307,16 @@ k_msm_partition(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint
     }
 }
 __global__ void __launch_bounds__(1024)
-k_msm_bucketize(const uint32_t* __restrict__ tmp, size_t ent_stride, const uint32_t* __restrict__ start, uint32_t nb, uint32_t* __restrict__ sorted) {
+k_msm_bucketize(const uint32_t* __restrict__ tmp, size_t tmp_stride, const uint32_t* __restrict__ dense, const uint32_t* __restrict__ start, uint32_t nb,
+                uint32_t* __restrict__ sorted, size_t sorted_stride) {
     __shared__ uint32_t cur[MSM_FINE], cnt[MSM_FINE], off[MSM_FINE], fill[MSM_FINE], total[4], wsum[4], stage[MSM_BKT_TILE];
     const uint32_t tid = threadIdx.x, B = blockIdx.x;
-    tmp += MSM_P * ent_stride;
-    sorted += MSM_P * ent_stride;
+    tmp += MSM_P * tmp_stride;
+    sorted += MSM_P * sorted_stride;
     start += (size_t)MSM_P * (nb + 1);
-    const uint32_t b0 = B << MSM_FINE_LOG, lo = start[b0], hi = start[b0 + MSM_FINE];
-    if (tid < MSM_FINE) cur[tid] = start[b0 + tid];
+    dense += (size_t)MSM_P * (nb + 1);
+    const uint32_t b0 = B << MSM_FINE_LOG, lo = dense[b0], hi = dense[b0 + MSM_FINE];  // the bin in `tmp`: packed
+    if (tid < MSM_FINE) cur[tid] = start[b0 + tid];                                      // its buckets in `sorted`: aligned runs
     for (uint32_t base = lo; base < hi; base += MSM_BKT_TILE) {
         if (tid < MSM_FINE) cnt[tid] = 0;
         __syncthreads();
@@ -332,6 +356,10 @@ k_msm_bucketize(const uint32_t* __restrict__ tmp, size_t ent_stride, const uint3
         __syncthreads();
         if (tid < MSM_FINE) cur[tid] += cnt[tid];
     }
+    // aligned runs: the gap between the end of a run and the start of the next holds the point at infinity
+    __syncthreads();
+    if (tid < MSM_FINE)
+        for (uint32_t k = cur[tid], end = start[b0 + tid + 1]; k < end; ++k) sorted[k] = MSM_PAD_ENTRY;
 }
 
 }  // namespace masp

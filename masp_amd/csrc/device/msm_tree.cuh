@@ -10,8 +10,9 @@
 //
 // One level (input: points of level L, dense, bucket after bucket; D_L[b] = first point of bucket b; level 0 = the digit list):
 //   k_tree_plan     (once, all levels)  D_L[], Q_L[] = exclusive scans of len_L = ceil(len_0 / 2^L) and of len_L >> 1
-//   k_tree_records  pair q of the level -> its record (first input point — at level 0 the two digit words —, output point): a
-//                   binary search in Q_L
+//   k_tree_records  (levels >= 1) pair q of the level -> its record (first input point, output point): a binary search in Q_L.
+//                   Level 0 needs none: the sort pads every run to an even length (MsmSortBuf::pad_log = 1, padding = the point
+//                   at infinity), so pair q is entries 2q, 2q + 1 of the digit list and lands at point q of level 1
 //   k_tree_pass1    lane t of a proof takes pairs t, t + NT, t + 2 NT, ... (every access of a wave is contiguous): denominator
 //                   of each pair, running product along the lane, prefixes to `pre`, the lane's product to `tp`
 //   k_binv_*        tp -> 1 / tp for all lanes: chains of products, ~4 096 binary-gcd inversions in the middle
@@ -91,19 +92,17 @@ static __global__ void __launch_bounds__(1024) k_tree_plan(const uint32_t* __res
     }
 }
 
-// pair q of a level -> its record.  Deeper levels: uint2 (index of the first input point, index of the output point).  Level 0:
-// uint4 (the two digit-list words of the pair — table row | sign << 31 —, index of the output point, unused): the passes then
-// reach a table row with ONE dependent load after the record instead of two.  Dl / Dn / Ql: this level's D, the next level's D,
-// this level's Q (per proof: stride nb + 1).  Grid-stride over the pairs the proof really has; a binary search in Q_L per pair
-// (one lane per bucket writing its pairs in a loop was measured 2.8x slower: the one long bucket of a witness MSM).
-template <bool L0>
+// pair q of a level >= 1 -> its record: uint2 (index of the first input point, index of the output point).  Dl / Dn / Ql: this
+// level's D, the next level's D, this level's Q (per proof: stride nb + 1).  Grid-stride over the pairs the proof really has; a
+// binary search in Q_L per pair (one lane per bucket writing its pairs in a loop was measured 2.8x slower: the one long bucket of
+// a witness MSM).  Level 0 has no records: its pairs are the digit list read two entries at a time (see the top of the file).
 static __global__ void __launch_bounds__(256)
-k_tree_records(const uint32_t* __restrict__ sorted, size_t ent_stride, const uint32_t* __restrict__ Dl, const uint32_t* __restrict__ Dn,
-               const uint32_t* __restrict__ Ql, uint32_t nb, void* __restrict__ rec_, size_t rec_stride) {
+k_tree_records(const uint32_t* __restrict__ Dl, const uint32_t* __restrict__ Dn, const uint32_t* __restrict__ Ql, uint32_t nb, uint2* __restrict__ rec,
+               size_t rec_stride) {
     Dl += (size_t)MSM_P * (nb + 1);
     Dn += (size_t)MSM_P * (nb + 1);
     Ql += (size_t)MSM_P * (nb + 1);
-    sorted += (size_t)MSM_P * ent_stride;
+    rec += (size_t)MSM_P * rec_stride;
     const uint32_t P = Ql[nb];
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < P; q += gridDim.x * blockDim.x) {
         uint32_t b = 0, span = nb;  // largest b with Ql[b] <= q (then Ql[b + 1] > q: bucket b holds pair q)
@@ -112,11 +111,8 @@ k_tree_records(const uint32_t* __restrict__ sorted, size_t ent_stride, const uin
             if (Ql[b + half] <= q) b += half;
             span -= half;
         }
-        const uint32_t j = q - Ql[b], in = Dl[b] + 2u * j, out = Dn[b] + j;
-        if (L0)
-            (reinterpret_cast<uint4*>(rec_) + (size_t)MSM_P * rec_stride)[q] = make_uint4(sorted[in], sorted[in + 1], out, 0u);
-        else
-            (reinterpret_cast<uint2*>(rec_) + (size_t)MSM_P * rec_stride)[q] = make_uint2(in, out);
+        const uint32_t j = q - Ql[b];
+        rec[q] = make_uint2(Dl[b] + 2u * j, Dn[b] + j);
     }
 }
 
@@ -139,15 +135,12 @@ __device__ __forceinline__ int tree_classify(const typename O::T& x1, const type
     return TREE_INF;  // P + (-P)  (or a point of order two added to itself)
 }
 
-// the operands of a pair from its record: level 0 gathers the two table rows (negated if the digit is negative), deeper levels
-// read the previous level's points
+// the operands of a pair from its record — level 0: the two digit-list words (table row | sign << 31, or the padding entry =
+// the point at infinity), gathered from the table and negated if the digit is negative; deeper levels: (first input point,
+// output point), read from the previous level's points
 template <bool L0>
 struct TreeRec {
     typedef uint2 type;
-};
-template <>
-struct TreeRec<true> {
-    typedef uint4 type;
 };
 template <class O, bool L0>
 struct TreeSrc {
@@ -163,8 +156,14 @@ struct TreeSrc {
         else
             return 0u;
     }
-    __device__ __forceinline__ const F& row_x(uint32_t w) const { return reinterpret_cast<const F*>(&tab[w & 0x7fffffffu].p.x)[h]; }
-    __device__ __forceinline__ const F& row_y(uint32_t w) const { return reinterpret_cast<const F*>(&tab[w & 0x7fffffffu].p.y)[h]; }
+    __device__ __forceinline__ F row_x(uint32_t w) const {
+        if (w == MSM_PAD_ENTRY) return O::zero();
+        return reinterpret_cast<const F*>(&tab[w & 0x7fffffffu].p.x)[h];
+    }
+    __device__ __forceinline__ F row_y(uint32_t w) const {
+        if (w == MSM_PAD_ENTRY) return O::zero();
+        return reinterpret_cast<const F*>(&tab[w & 0x7fffffffu].p.y)[h];
+    }
     __device__ __forceinline__ size_t at(size_t i) const { return i * O::LANES + h; }
     __device__ __forceinline__ void load_x(const Rec& r, F& x1, F& x2) const {
         if constexpr (L0) {
@@ -186,7 +185,7 @@ struct TreeSrc {
             y2 = ys[at(r.x + 1)];
         }
     }
-    // ... and the signs of the digits applied (level 0)
+    // ... and the signs of the digits applied (level 0; the padding entry stays (0, 0): -0 = 0)
     static __device__ __forceinline__ void fix_y(const Rec& r, F& y1, F& y2) {
         if constexpr (L0) {
             if (r.x >> 31) y1 = O::neg(y1);
@@ -197,9 +196,9 @@ struct TreeSrc {
         load_y_raw(r, y1, y2);
         fix_y(r, y1, y2);
     }
-    static __device__ __forceinline__ uint32_t out_index(const Rec& r) {
+    static __device__ __forceinline__ uint32_t out_index(const Rec& r, uint32_t q) {  // level 0: pair q -> point q of level 1
         if constexpr (L0)
-            return r.z;
+            return q;
         else
             return r.y;
     }
@@ -312,7 +311,7 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         if (j) pp = pre[src.at(((size_t)(j - 1) * np + p) * NT + t)];
         if (j) fetch(ra, nxt);
         if (j > 1) rb = rec[t + (j - 2) * NT];
-        const uint32_t out = TreeSrc<O, L0>::out_index(cr);
+        const uint32_t out = TreeSrc<O, L0>::out_index(cr, t + j * NT);
         TreeSrc<O, L0>::fix_y(cr, c.y1, c.y2);
         F d = O::sub(c.x2, c.x1);
         int kind = TREE_ADD;

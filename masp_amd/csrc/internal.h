@@ -168,6 +168,7 @@ struct Slot {
         ntt_sub = (uint32_t)o.ntt_sub_batch;
         ws1.tree_levels = o.bucket_tree_levels;
         ws2.tree_levels = o.bucket_tree_levels_g2;
+        ws1.tree_levels_shared = o.bucket_tree_levels_g2;  // B2 is reduced from B1's sort (ws1.sort): padded if either wants a tree
         ws1.tree_sub = ws2.tree_sub = (uint32_t)o.bucket_tree_sub_batch;
         ws2.tree.arena = &ws1.tree.own;   // the G1 and G2 MSMs of a batch follow each other on the slot's stream: one tree arena
     }

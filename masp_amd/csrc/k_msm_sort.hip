@@ -7,16 +7,22 @@
 namespace masp {
 
 int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb, const uint32_t* d_scalars, size_t scalar_stride,
-                                   uint32_t np) {
+                                   uint32_t np, uint32_t pad_log) {
     if (g.c < 2 || g.c > 16) {
         last_hip_error() = "MSM window width must be 2..16 bits (the bucket histogram lives in LDS)";
         return MASP_HIP_E_INVALID_ARG;
     }
-    int rc = sb.reserve(n, g, np);
+    if (pad_log > 12) {
+        last_hip_error() = "msm_sort_enqueue: runs can be aligned to at most 2^12 entries";
+        return MASP_HIP_E_INVALID_ARG;
+    }
+    int rc = sb.reserve(n, g, np, pad_log);
     if (rc) return rc;
     sb.n = n;
     sb.np = np;
     sb.g = g;
+    sb.pad_log = pad_log;
+    sb.ent_stride = MsmSortBuf::padded_entries(n, g, pad_log);
     const uint32_t ng = MsmSortBuf::ranges_for(n, np), nb = g.nb;
     // two-pass placement (runs instead of single scattered words): the row index must leave room for the 7 low bucket bits
     const bool two_pass = nb >= MSM_FINE && (uint64_t)n * g.W <= (1u << 24);
@@ -34,15 +40,17 @@ int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb
         return MASP_HIP_E_HIP;
     }
     hipLaunchKernelGGL(k_msm_hist, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg);
-    hipLaunchKernelGGL(k_msm_offsets, dim3(1, np), dim3(1024), 0, s, sb.hist_wg, ng, nb, sb.start);
+    hipLaunchKernelGGL(k_msm_offsets, dim3(1, np), dim3(1024), 0, s, sb.hist_wg, ng, nb, sb.start, sb.dense, pad_log);
     if (two_pass && g.W <= 32) {
         const uint32_t nbins = nb >> MSM_FINE_LOG;
         hipLaunchKernelGGL(k_msm_coarse, dim3(nbins, np), dim3(128), 0, s, sb.hist_wg, ng, nb, sb.crel);
-        hipLaunchKernelGGL(k_msm_partition, dim3(ng, np), dim3(MSM_PART_TILE), part_lds, s, d_scalars, scalar_stride, n, g, ng, sb.crel, sb.start, sb.tmp);
-        hipLaunchKernelGGL(k_msm_bucketize, dim3(nbins, np), dim3(1024), 0, s, sb.tmp, (size_t)n * g.W, sb.start, nb, sb.sorted);
+        hipLaunchKernelGGL(k_msm_partition, dim3(ng, np), dim3(MSM_PART_TILE), part_lds, s, d_scalars, scalar_stride, n, g, ng, sb.crel, sb.dense, sb.tmp);
+        hipLaunchKernelGGL(k_msm_bucketize, dim3(nbins, np), dim3(1024), 0, s, sb.tmp, (size_t)n * g.W, sb.dense, sb.start, nb, sb.sorted, sb.ent_stride);
     } else {
+        // (the single-pass placement writes entries only: aligned runs get their padding from a fill first)
+        if (pad_log) HIP_TRY(hipMemsetAsync(sb.sorted, 0xff, 4 * sb.ent_stride * np, s));
         hipLaunchKernelGGL(k_msm_scatter, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg, sb.start,
-                           sb.sorted);
+                           sb.sorted, sb.ent_stride);
     }
     return MASP_HIP_OK;
 }

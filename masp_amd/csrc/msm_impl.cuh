@@ -95,16 +95,8 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
         hipEventRecord(rec.e0, s);
     }
     const bool lone = np < 8;  // latency regime: short chains matter more than total work
-    // The tree halves the bucket runs T times: 1 - 2^-T of the additions at 5.8 instead of 9.6 products.  Every level costs two
-    // passes over its points and a latency-bound shared inversion (~0.35 ms per sub-batch), so T stays small: measured on 256
-    // Spend proofs, 4 batches in flight, sub-batches of 64: T = 3 +7.5 %, 4 +9 %, 5 +8.5 %, T = log2(mean run) - 1 = 6 / 8 +3 % over
-    // the XYZZ accumulation alone.  Runs shorter than 32 points (mean: n_eff W digits over nb buckets) get fewer levels.
-    uint32_t tree_T = 0;
-    if (!lone && ws.tree_levels >= 0) {
-        const uint64_t mean = std::max<uint64_t>((uint64_t)std::max(B.n_eff, 1u) * g.W / nb, 1);
-        const uint32_t by_len = log2_ceil_u64(mean) > 1 ? (uint32_t)log2_ceil_u64(mean) - 1 : 0;
-        tree_T = ws.tree_levels > 0 ? std::min((uint32_t)ws.tree_levels, 12u) : std::min(4u, by_len);
-    }
+    // the batch-affine tree in front (msm_tree_levels, msm_host.h): it needs the sort's runs padded to even lengths
+    const uint32_t tree_T = sb.pad_log == 1 ? msm_tree_levels(B.n_eff, g, np, ws.tree_levels) : 0;
     const uint32_t* start = sb.start;
     if (tree_T) {
         const uint32_t sub = std::max(1u, std::min(ws.tree_sub, np));
@@ -118,7 +110,7 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
         }
         start = ws.startT;
     } else {
-        msm_launch_accumulate<O>(s, B.tab, sb.sorted, (size_t)total, sb.start, nb, nchunks, ws.part, np);
+        msm_launch_accumulate<O>(s, B.tab, sb.sorted, sb.ent_stride, sb.start, nb, nchunks, ws.part, np);
     }
     if (prof) {
         hipEventRecord(rec.e1, s);

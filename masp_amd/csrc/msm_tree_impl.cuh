@@ -33,7 +33,7 @@ static inline uint32_t tree_lanes(uint64_t E_ub, uint32_t nb, uint32_t L) {
 template <class O>
 int MsmTreeWs<O>::reserve(uint64_t E_ub, uint32_t nb, uint32_t q, uint32_t T) {
     const size_t plan = (size_t)(T + 1) * q * (nb + 1);
-    const size_t recs = (size_t)q * tree_pairs_ub(E_ub, nb, 0);
+    const size_t recs = (size_t)q * tree_pairs_ub(E_ub, nb, 1);
     const size_t NT0 = tree_lanes(E_ub, nb, 0);
     const size_t lanes = (size_t)q * NT0;
     // pre[(j q + p) NT + t], j < ceil(pairs / NT) <= KP (+1 for the rounding of NT): bounded by level 0
@@ -47,7 +47,7 @@ int MsmTreeWs<O>::reserve(uint64_t E_ub, uint32_t nb, uint32_t q, uint32_t T) {
         off += (bytes + 255) & ~(size_t)255;
         return at;
     };
-    const size_t oD = take(4 * plan), oQ = take(4 * plan), oRec = take(sizeof(uint4) * recs), oPre = take(sizeof(F) * pres), oTp = take(sizeof(F) * lanes),
+    const size_t oD = take(4 * plan), oQ = take(4 * plan), oRec = take(sizeof(uint2) * recs), oPre = take(sizeof(F) * pres), oTp = take(sizeof(F) * lanes),
                  oTinv = take(sizeof(F) * lanes), oBpre = take(sizeof(F) * lanes), oBtot = take(sizeof(F) * m1), oBitot = take(sizeof(F) * m1),
                  oBpre2 = take(sizeof(F) * m1), oX1 = take(sizeof(F) * pts1), oY1 = take(sizeof(F) * pts1), oX0 = take(sizeof(F) * pts2),
                  oY0 = take(sizeof(F) * pts2);
@@ -56,7 +56,7 @@ int MsmTreeWs<O>::reserve(uint64_t E_ub, uint32_t nb, uint32_t q, uint32_t T) {
     uint8_t* b = arena->p;
     D = (uint32_t*)(b + oD);
     Q = (uint32_t*)(b + oQ);
-    rec = (uint4*)(b + oRec);
+    rec = (uint2*)(b + oRec);
     pre = (F*)(b + oPre);
     tp = (F*)(b + oTp);
     tinv = (F*)(b + oTinv);
@@ -96,7 +96,11 @@ template <class O, int BYTES>
 int msm_tree_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSortBuf& sb, MsmTreeWs<O>& tw, uint32_t p0, uint32_t q, uint32_t T) {
     typedef typename O::T F;
     const uint32_t nb = (uint32_t)B.g.nb;
-    const uint64_t E_ub = (uint64_t)B.n * B.g.W;
+    if (sb.pad_log != 1) {
+        last_hip_error() = "msm_tree_enqueue: the sort must pad every run to an even length (MsmSortBuf::pad_log = 1)";
+        return MASP_HIP_E_INVALID_ARG;
+    }
+    const uint64_t E_ub = sb.ent_stride;  // entries per proof, the padding included
     int rc = tw.reserve(E_ub, nb, q, T);
     if (rc) return rc;
     tw.q = q;
@@ -109,7 +113,7 @@ int msm_tree_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSortBu
     const uint32_t* start = sb.start + (size_t)p0 * (nb + 1);
     hipLaunchKernelGGL(k_tree_plan, dim3(T + 1, q), dim3(1024), 0, s, start, nb, tw.D, tw.Q);
     const size_t lvl = (size_t)q * (nb + 1);
-    const size_t rec_stride = tree_pairs_ub(E_ub, nb, 0);
+    const size_t rec_stride = tree_pairs_ub(E_ub, nb, 1);
     for (uint32_t L = 0; L < T; ++L) {
         const uint32_t *Dl = tw.D + L * lvl, *Dn = tw.D + (L + 1) * lvl, *Ql = tw.Q + L * lvl;
         const uint32_t NT = tree_lanes(E_ub, nb, L), pairs_ub = tree_pairs_ub(E_ub, nb, L);
@@ -120,12 +124,14 @@ int msm_tree_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSortBu
         typedef typename TreeLaneOps<O, 2>::type O1;
         typedef typename O1::T F1;
         const dim3 grid1(NT * O1::LANES / 256, q);
+        // level 0: the "records" are the digit list itself, two entries at a time (runs of even length: pair q = entries 2q, 2q + 1)
+        const void* rec0 = (const void*)sorted;
+        const size_t rec0_stride = ent_stride / 2;
         if (L == 0) {
-            hipLaunchKernelGGL(k_tree_records<true>, rgrid, block, 0, s, sorted, ent_stride, Dl, Dn, Ql, nb, (void*)tw.rec, rec_stride);
-            hipLaunchKernelGGL((k_tree_pass1<O1, true>), grid1, block, 0, s, B.tab, (const F1*)xi, (const F1*)yi, si, (const void*)tw.rec, rec_stride, Ql, nb,
-                               NT, (F1*)tw.pre, (F1*)tw.tp);
+            hipLaunchKernelGGL((k_tree_pass1<O1, true>), grid1, block, 0, s, B.tab, (const F1*)xi, (const F1*)yi, si, rec0, rec0_stride, Ql, nb, NT,
+                               (F1*)tw.pre, (F1*)tw.tp);
         } else {
-            hipLaunchKernelGGL(k_tree_records<false>, rgrid, block, 0, s, sorted, ent_stride, Dl, Dn, Ql, nb, (void*)tw.rec, rec_stride);
+            hipLaunchKernelGGL(k_tree_records, rgrid, block, 0, s, Dl, Dn, Ql, nb, tw.rec, rec_stride);
             hipLaunchKernelGGL((k_tree_pass1<O1, false>), grid1, block, 0, s, B.tab, (const F1*)xi, (const F1*)yi, si, (const void*)tw.rec, rec_stride, Ql, nb,
                                NT, (F1*)tw.pre, (F1*)tw.tp);
         }
@@ -134,15 +140,13 @@ int msm_tree_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSortBu
         typedef typename O2::T F2;
         const dim3 grid2(NT * O2::LANES / 256, q);
         if (L == 0)
-            hipLaunchKernelGGL((k_tree_pass2<O2, true>), grid2, block, 0, s, B.tab, (const F2*)xi, (const F2*)yi, si, (const void*)tw.rec, rec_stride, Ql,
-                               nb, NT, (const F2*)tw.pre, (const F2*)tw.tinv, (F2*)xo, (F2*)yo, so);
+            hipLaunchKernelGGL((k_tree_pass2<O2, true>), grid2, block, 0, s, B.tab, (const F2*)xi, (const F2*)yi, si, rec0, rec0_stride, Ql, nb, NT,
+                               (const F2*)tw.pre, (const F2*)tw.tinv, (F2*)xo, (F2*)yo, so);
         else
             hipLaunchKernelGGL((k_tree_pass2<O2, false>), grid2, block, 0, s, B.tab, (const F2*)xi, (const F2*)yi, si, (const void*)tw.rec, rec_stride, Ql,
                                nb, NT, (const F2*)tw.pre, (const F2*)tw.tinv, (F2*)xo, (F2*)yo, so);
-        if (L == 0)
-            hipLaunchKernelGGL((k_tree_copy<O, true>), cgrid, block, 0, s, B.tab, sorted, ent_stride, xi, yi, si, Dl, Dn, nb, xo, yo, so);
-        else
-            hipLaunchKernelGGL((k_tree_copy<O, false>), cgrid, block, 0, s, B.tab, sorted, ent_stride, xi, yi, si, Dl, Dn, nb, xo, yo, so);
+        // (level 0 has no odd runs: a run of odd length met its padding entry as P + infinity)
+        if (L) hipLaunchKernelGGL((k_tree_copy<O, false>), cgrid, block, 0, s, B.tab, sorted, ent_stride, xi, yi, si, Dl, Dn, nb, xo, yo, so);
     }
     return MASP_HIP_OK;
 }
