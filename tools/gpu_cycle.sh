@@ -12,7 +12,7 @@ python bench.py --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/$tag/bench.j
 python - <<PY
 import json
 d=json.loads(open("gpurun_out/$tag/bench.json").read().strip().splitlines()[-1])
-print("BENCH value %.1f  h2h %.1f  verified %d  latency %.2f ms  acc_launch %.2f ms" % (d["value"], d["host_to_host"]["value"], d["verified"], d["single_proof_latency_ms"], d["roofline"]["avg_launch_ms"]))
+print("BENCH value %.1f  resident %.1f  verified %d  latency %.2f ms  acc_launch %.2f ms" % (d["value"], d["resident"]["value"], d["verified"], d["single_proof_latency_ms"], d["roofline"]["avg_launch_ms"]))
 PY
 PROF_ARGS="--steps 3 --warmup 1 --no-cpu-baseline" PROF_GY=256 bash tools/prof_run.sh ${tag}_default > gpurun_out/$tag/prof_default.txt 2>&1
 PROF_ARGS="--steps 2 --warmup 1 --no-cpu-baseline" PROF_GY=256 bash tools/prof_run.sh ${tag}_slots1 MASP_HIP_SLOTS=1 > gpurun_out/$tag/prof_slots1.txt 2>&1

@@ -35,8 +35,10 @@ factor = true128 / (rep128 * 1024.0)
 # the number of G1 MSMs of full batches (= dispatches of k_msm_combine<G1> with gridDim.y = batch: one per MSM).
 res = {}
 batch = int(os.environ.get("MASP_HIP_BATCH", "256"))
+# (k_tree_plan / k_tree_records are curve-independent kernels: their G2 dispatches — a quarter of them, ~1 % of the stage's bytes —
+# are counted too)
 STAGE = ("k_tree_pass1<masp::FpOps", "k_tree_pass2<masp::FpOps", "k_tree_copy<masp::FpOps", "k_binv_fwd<masp::FpOps", "k_binv_mid<masp::FpOps",
-         "k_binv_bwd<masp::FpOps", "k_msm_accumulate_pts<masp::FpOps", "k_msm_accumulate<masp::FpOps")
+         "k_binv_bwd<masp::FpOps", "k_msm_accumulate_pts<masp::FpOps", "k_msm_accumulate<masp::FpOps", "k_tree_records", "k_tree_plan")
 per_kernel = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     rows = rows_of(c, c)
@@ -60,7 +62,7 @@ import re, time
 line = [l for l in open("%s/FETCH_SIZE.log" % out).read().splitlines() if l.startswith("{")][-1]
 alg = json.loads(line)["roofline"]["alg_bytes_per_launch"]
 doc = {
- "kernel": "G1 bucket-accumulation stage per G1 MSM: k_tree_pass1 / k_tree_pass2 / k_tree_copy / k_binv_* over 4 tree levels in sub-batches of 64 proofs, then k_msm_accumulate_pts",
+ "kernel": "G1 bucket-accumulation stage per G1 MSM: k_tree_plan / k_tree_records / k_tree_pass1 / k_tree_pass2 / k_tree_copy / k_binv_* over 4 tree levels in sub-batches of 64 proofs, then k_msm_accumulate_pts",
  "date": time.strftime("%Y-%m-%d"),
  "command": "tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline (256 distinct Spend witnesses per step); calibration pass on tools/_build/pmc_calib",
  "calibration": {"pattern": "one 96-byte row (6 x global_load_dwordx4) per lane at a random index, 3 GiB table, 2^24 rows per launch",
