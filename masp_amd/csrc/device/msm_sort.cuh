@@ -95,10 +95,17 @@ k_msm_offsets(uint32_t* __restrict__ hist_wg, uint32_t ng, uint32_t nb, uint32_t
         const uint32_t b = b0 + tid;
         uint32_t v = 0;
         if (b < nb)
-            for (uint32_t w = 0; w < ng; ++w) {
-                uint32_t h = hist_wg[(size_t)w * nb + b];
-                hist_wg[(size_t)w * nb + b] = v;
-                v += h;
+            // (sixteen loads in flight at a time: one after the other, a lone proof's 64 ranges x 32 768 buckets took 0.5 ms)
+            for (uint32_t w0 = 0; w0 < ng; w0 += 16) {
+                uint32_t h[16];
+#pragma unroll
+                for (uint32_t k = 0; k < 16; ++k) h[k] = w0 + k < ng ? hist_wg[(size_t)(w0 + k) * nb + b] : 0u;
+#pragma unroll
+                for (uint32_t k = 0; k < 16; ++k)
+                    if (w0 + k < ng) {
+                        hist_wg[(size_t)(w0 + k) * nb + b] = v;
+                        v += h[k];
+                    }
             }
         const uint32_t pv = (v + pad) & ~pad;
         uint32_t x = v, px = pv;

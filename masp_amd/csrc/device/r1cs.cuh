@@ -36,16 +36,18 @@ __global__ void k_fr_split_forms(Fr* __restrict__ x, size_t x_stride, Fr* __rest
     }
 }
 
-// One CSR row per lane: out[row] = sum_t coef[t] * w[col[t]]  (all Montgomery).  Rows
+// out[row] = sum_t coef[t] * w[col[t]]  (all Montgomery), one CSR row per lane — except the long rows.  Rows
 // n_constraints .. n_constraints + n_inputs - 1 are bellperson's extra "Input(i) * 0 = 0" rows:
 // a = input value, b = c = 0 (which == 0 selects matrix A).
-// Row lengths of the MASP circuits range from 1 to several hundred terms (bit packings): `order` lists the constraint
-// rows by decreasing length, so the 64 rows of a wave take about equally long.
-// The three matrices in ONE launch: blockIdx.z selects A, B or C (R1csMatrices: launch.h).
+// Row lengths of the MASP circuits range from 1 to several hundred terms (Spend: 93 rows of A with 577 terms, 168 rows of C
+// with 256: bit packings): `order` lists the constraint rows by decreasing length, so the 64 rows of a wave take about equally
+// long, and the first n_long of them (>= R1CS_LONG_ROW terms) get a WAVE each — lanes stride over the terms, a shuffle tree adds
+// the 64 partial sums.  (One lane per row made a lone proof wait 1 ms for 577 dependent load-multiply-add steps.)
+// The three matrices in ONE launch: blockIdx.z selects A, B or C (R1csMatrices: launch.h).  Lanes: n_long x 64, then one per
+// remaining row.
 __global__ void k_r1cs_eval(R1csMatrices M, const Fr* __restrict__ w, uint32_t n_vars, uint32_t n_constraints, uint32_t n_inputs) {
-    uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n_constraints + n_inputs) return;
     const int which = blockIdx.z;
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x, nl = M.n_long[which];
     const uint32_t* __restrict__ rowptr = M.rowptr[which];
     const uint32_t* __restrict__ order = M.order[which];
     const uint32_t* __restrict__ col = M.col[which];
@@ -53,6 +55,22 @@ __global__ void k_r1cs_eval(R1csMatrices M, const Fr* __restrict__ w, uint32_t n
     Fr* __restrict__ out = M.out[which];
     w += (size_t)blockIdx.y * n_vars;
     out += (size_t)blockIdx.y * (n_constraints + n_inputs);
+    if (v < nl * 64u) {  // (whole waves: the branch is uniform)
+        const uint32_t row = order[v >> 6], lane = v & 63u;
+        const uint32_t lo = rowptr[row], hi = rowptr[row + 1];
+        Fr acc = fe_zero<FrCfg>();
+        for (uint32_t t = lo + lane; t < hi; t += 64) acc = fe_add(acc, fe_mul(fr_load(coef + t), fr_load(w + col[t])));
+        for (int d = 32; d >= 1; d >>= 1) {
+            Fr other;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) other.v[i] = (uint32_t)__shfl_down((int)acc.v[i], d, 64);
+            acc = fe_add(acc, other);
+        }
+        if (lane == 0) fr_store(out + row, acc);
+        return;
+    }
+    uint32_t row = v - nl * 64u + nl;
+    if (row >= n_constraints + n_inputs) return;
     Fr acc = fe_zero<FrCfg>();
     if (row < n_constraints) {
         row = order[row];

@@ -104,6 +104,7 @@ struct Circuit {
     size_t m = 0;
     DevBuf<uint32_t> rowptr[3], col[3];
     DevBuf<uint32_t> row_order[3];  // constraint rows by decreasing length: lanes of a wave get rows of similar length
+    uint32_t n_long_rows[3] = {0, 0, 0};  // rows of >= R1CS_LONG_ROW terms (the head of row_order): a wave each
     DevBuf<Fr> coef[3];
     DevBuf<uint32_t> a_var, b_var;
     uint32_t na = 0, nbq = 0;

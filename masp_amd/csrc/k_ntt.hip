@@ -1,4 +1,5 @@
 // Fr NTT / quotient kernels and the static-R1CS kernels with their launch wrappers (launch.h).
+#include <algorithm>
 #include "device/ntt.cuh"
 #include "device/r1cs.cuh"
 #include "launch.h"
@@ -40,8 +41,9 @@ void launch_fr_split_forms(hipStream_t s, Fr* x, size_t x_stride, Fr* y, uint32_
     hipLaunchKernelGGL(k_fr_split_forms, dim3((n + 255) / 256, np), dim3(256), 0, s, x, x_stride, y, n, mont_from, range_err);
 }
 void launch_r1cs_eval(hipStream_t s, const R1csMatrices& M, const Fr* w, uint32_t n_vars, uint32_t n_constraints, uint32_t n_inputs, uint32_t np) {
-    const uint32_t nrows = n_constraints + n_inputs;
-    hipLaunchKernelGGL(k_r1cs_eval, dim3((nrows + 127) / 128, np, 3), dim3(128), 0, s, M, w, n_vars, n_constraints, n_inputs);
+    // lanes: 64 per long row, one per remaining row (the matrix with the most long rows sizes the grid)
+    const uint32_t nl = std::max(M.n_long[0], std::max(M.n_long[1], M.n_long[2])), lanes = n_constraints + n_inputs + nl * 63u;
+    hipLaunchKernelGGL(k_r1cs_eval, dim3((lanes + 127) / 128, np, 3), dim3(128), 0, s, M, w, n_vars, n_constraints, n_inputs);
 }
 void launch_gather_scalars(hipStream_t s, const Fr* src, size_t src_stride, const uint32_t* idx, uint32_t n, Fr* dst, uint32_t np) {
     hipLaunchKernelGGL(k_gather_scalars, dim3((n + 255) / 256, np), dim3(256), 0, s, src, src_stride, idx, n, dst);

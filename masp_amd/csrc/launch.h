@@ -28,7 +28,9 @@ struct R1csMatrices {  // the static R1CS of a circuit (CSR, rows by decreasing 
     const uint32_t* col[3];
     const Fr* coef[3];
     Fr* out[3];
+    uint32_t n_long[3];  // the first n_long rows of `order` (>= R1CS_LONG_ROW terms) are summed by a wave each
 };
+static constexpr uint32_t R1CS_LONG_ROW = 64;
 void launch_r1cs_eval(hipStream_t s, const R1csMatrices& M, const Fr* w, uint32_t n_vars, uint32_t n_constraints, uint32_t n_inputs, uint32_t np);
 void launch_gather_scalars(hipStream_t s, const Fr* src, size_t src_stride, const uint32_t* idx, uint32_t n, Fr* dst, uint32_t np);
 

@@ -207,6 +207,7 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
             if ((rc = sl.ev[i].reserve((size_t)C.nrows * np))) return rc;
             M.rowptr[i] = C.rowptr[i].p;
             M.order[i] = C.row_order[i].p;
+            M.n_long[i] = C.n_long_rows[i];
             M.col[i] = C.col[i].p;
             M.coef[i] = C.coef[i].p;
             M.out[i] = sl.ev[i].p;
@@ -223,44 +224,54 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
         // the four witness MSMs run on their own streams (forked above) while the main stream runs SpMV -> quotient -> H.
         // The pieces of the assembly start as soon as what they read exists: the fixed-base multiplications (r and s only)
         // right away, s*A and r*B1 behind their MSMs, g_b behind B2 — after the join only g_a / g_c are left.
-        // A lone proof is ~170 launches, i.e. more than a millisecond of host time: the streams are fed in the order of
-        // their chains' lengths — B2 (G2 tails), A and B1 (each followed by a variable-base multiplication), the quotient
-        // and H, L.
         launch_groth16_fixed_g1(sl.aux[0], C.fb1.p, d_rs, 16, sl.asm1.p, np);
         launch_groth16_fixed_g2(sl.aux[0], C.fb2.p, d_rs, 16, sl.asm2.p, np);
         HIP_TRY(hipEventRecord(sl.ev_fixed, sl.aux[0]));  // s*delta2 is read by g_b on aux[3]
-        if (C.nbq) launch_gather_scalars(sl.aux[2], d_w, w_stride, C.b_var.p, C.nbq, sl.sb.p, np);
+        // Enqueueing a lone proof takes the host ~3 ms (~250 launches) — as long as its longest chain runs, so whatever is
+        // enqueued last starts 3 ms late: the chains go out longest first — A and B1 + B2 (an MSM followed by 2.3 ms of
+        // variable-base multiplication; B2's G2 tails), then the quotient and H (the SpMV in front of them is 25 us), then L,
+        // which only reads the witness and is the shortest.  (Helper threads enqueueing the chains side by side, and high-
+        // priority streams for A / B1, were measured: every chain then starts within 0.5 ms, they slow each other down and the
+        // proof takes the same 6.1 - 6.4 ms: profiles/r03x_same_box_ab_lone_threads.txt.)
         const bool own_b2 = C.b2_lone.n != 0;  // B2 on its own narrow windows: sorts for itself
-        if (own_b2) {
-            HIP_TRY(hipEventRecord(sl.ev_sort_b, sl.aux[2]));  // orders the read of sb after its gather
+        auto chain_a = [&]() -> int {
+            int r;
+            if (C.na) launch_gather_scalars(sl.aux[1], d_w, w_stride, C.a_var.p, C.na, sl.sa.p, np);
+            if ((r = msm_enqueue(sl.aux[1], C.a, sl.ws_a, (const uint32_t*)sl.sa.p, (size_t)C.na * 8, sl.res1.p + 2, 4, np))) return r;
+            launch_groth16_var_mul(sl.aux[1], 0, sl.res1.p, d_rs, 16, sl.asm1.p, np);
+            return MASP_HIP_OK;
+        };
+        auto chain_b = [&]() -> int {
+            int r;
+            if (C.nbq) launch_gather_scalars(sl.aux[2], d_w, w_stride, C.b_var.p, C.nbq, sl.sb.p, np);
+            HIP_TRY(hipEventRecord(sl.ev_sort_b, sl.aux[2]));  // B2 on aux[3] reads sb (and, without tables of its own, B1's sort) behind this
+            if (share_b) {
+                if ((r = msm_sort_enqueue(sl.aux[2], C.b1.n, C.b1.g, sl.ws_b.sort, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, np))) return r;
+                if (!own_b2) HIP_TRY(hipEventRecord(sl.ev_sort_b, sl.aux[2]));
+                if ((r = msm_reduce_enqueue(sl.aux[2], C.b1, sl.ws_b.sort, sl.ws_b, sl.res1.p + 3, 4))) return r;
+            } else if ((r = msm_enqueue(sl.aux[2], C.b1, sl.ws_b, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res1.p + 3, 4, np))) {
+                return r;
+            }
+            launch_groth16_var_mul(sl.aux[2], 1, sl.res1.p, d_rs, 16, sl.asm1.p, np);
             HIP_TRY(hipStreamWaitEvent(sl.aux[3], sl.ev_sort_b, 0));
-            if ((rc = msm_enqueue(sl.aux[3], C.b2_lone, sl.ws2, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res2.p, 1, np))) return rc;
-            if (share_b && (rc = msm_sort_enqueue(sl.aux[2], C.b1.n, C.b1.g, sl.ws_b.sort, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, np))) return rc;
-        } else if (share_b) {
-            if ((rc = msm_sort_enqueue(sl.aux[2], C.b1.n, C.b1.g, sl.ws_b.sort, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, np))) return rc;
-            HIP_TRY(hipEventRecord(sl.ev_sort_b, sl.aux[2]));
-            HIP_TRY(hipStreamWaitEvent(sl.aux[3], sl.ev_sort_b, 0));
-            if ((rc = msm_reduce_enqueue(sl.aux[3], C.b2, sl.ws_b.sort, sl.ws2, sl.res2.p, 1))) return rc;
-        } else {
-            HIP_TRY(hipEventRecord(sl.ev_sort_b, sl.aux[2]));  // orders the read of sb after its gather
-            HIP_TRY(hipStreamWaitEvent(sl.aux[3], sl.ev_sort_b, 0));
-            if ((rc = msm_enqueue(sl.aux[3], C.b2, sl.ws2, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res2.p, 1, np))) return rc;
-        }
-        HIP_TRY(hipStreamWaitEvent(sl.aux[3], sl.ev_fixed, 0));
-        launch_groth16_finish_b(sl.aux[3], C.vk.p, sl.asm2.p, sl.res2.p, d_proof, np);
-        // A and B1 are followed by 3 ms of variable-base multiplication each: before the quotient and H
-        if (C.na) launch_gather_scalars(sl.aux[1], d_w, w_stride, C.a_var.p, C.na, sl.sa.p, np);
-        if ((rc = msm_enqueue(sl.aux[1], C.a, sl.ws_a, (const uint32_t*)sl.sa.p, (size_t)C.na * 8, sl.res1.p + 2, 4, np))) return rc;
-        launch_groth16_var_mul(sl.aux[1], 0, sl.res1.p, d_rs, 16, sl.asm1.p, np);
-        if (share_b) {
-            if ((rc = msm_reduce_enqueue(sl.aux[2], C.b1, sl.ws_b.sort, sl.ws_b, sl.res1.p + 3, 4))) return rc;
-        } else if ((rc = msm_enqueue(sl.aux[2], C.b1, sl.ws_b, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res1.p + 3, 4, np))) {
-            return rc;
-        }
-        launch_groth16_var_mul(sl.aux[2], 1, sl.res1.p, d_rs, 16, sl.asm1.p, np);
+            if (own_b2) {
+                if ((r = msm_enqueue(sl.aux[3], C.b2_lone, sl.ws2, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res2.p, 1, np))) return r;
+            } else if (share_b) {
+                if ((r = msm_reduce_enqueue(sl.aux[3], C.b2, sl.ws_b.sort, sl.ws2, sl.res2.p, 1))) return r;
+            } else if ((r = msm_enqueue(sl.aux[3], C.b2, sl.ws2, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res2.p, 1, np))) {
+                return r;
+            }
+            HIP_TRY(hipStreamWaitEvent(sl.aux[3], sl.ev_fixed, 0));
+            launch_groth16_finish_b(sl.aux[3], C.vk.p, sl.asm2.p, sl.res2.p, d_proof, np);
+            return MASP_HIP_OK;
+        };
+        auto chain_l = [&]() -> int {
+            return msm_enqueue(sl.aux[0], C.l, sl.ws_l, (const uint32_t*)(d_w + C.n_inputs), w_stride * 8, sl.res1.p + 1, 4, np);
+        };
+        if ((rc = chain_a()) || (rc = chain_b())) return rc;
         if ((rc = enqueue_quotient(sl, *C.dom, in, C.nrows, C.nrows, mont_in, np))) return rc;
         if ((rc = msm_enqueue(s, C.h, sl.ws1, (const uint32_t*)sl.h.p, m8, sl.res1.p + 0, 4, np, prof))) return rc;
-        if ((rc = msm_enqueue(sl.aux[0], C.l, sl.ws_l, (const uint32_t*)(d_w + C.n_inputs), w_stride * 8, sl.res1.p + 1, 4, np))) return rc;
+        if ((rc = chain_l())) return rc;
         // g_a / g_c need L, s*A and r*B1 (aux[0..2]); g_b finishes on aux[3] by itself and is only joined before the proof leaves
         for (int i = 0; i < Slot::N_AUX - 1; ++i) {
             HIP_TRY(hipEventRecord(sl.ev_join[i], sl.aux[i]));
@@ -540,6 +551,11 @@ int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* param
         std::stable_sort(order.begin(), order.end(),
                          [&](uint32_t x, uint32_t y) { return rp[mi][x + 1] - rp[mi][x] > rp[mi][y + 1] - rp[mi][y]; });
         if ((rc = C->row_order[mi].upload(order.data(), order.size(), s))) return fail(ctx, rc);
+        C->n_long_rows[mi] = 0;
+        for (uint32_t r : order) {
+            if (rp[mi][r + 1] - rp[mi][r] < R1CS_LONG_ROW) break;
+            ++C->n_long_rows[mi];
+        }
         if ((rc = C->rowptr[mi].upload(rp[mi], cs->n_constraints + 1, s)) || (rc = C->col[mi].upload(cl[mi], nnz, s)) ||
             (rc = raw.upload((const Fr*)cf[mi], nnz, s)) || (rc = C->coef[mi].reserve(nnz)))
             return fail(ctx, rc);
