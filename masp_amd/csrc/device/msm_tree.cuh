@@ -11,8 +11,9 @@
 // One level (input: points of level L, dense, bucket after bucket; D_L[b] = first point of bucket b; level 0 = the digit list):
 //   k_tree_plan     (once, all levels)  D_L[], Q_L[] = exclusive scans of len_L = ceil(len_0 / 2^L) and of len_L >> 1
 //   k_tree_records  (levels >= 1) pair q of the level -> its record (first input point, output point): a binary search in Q_L.
-//                   Level 0 needs none: the sort pads every run to an even length (MsmSortBuf::pad_log = 1, padding = the point
-//                   at infinity), so pair q is entries 2q, 2q + 1 of the digit list and lands at point q of level 1
+//                   Level 0 needs none: the sort pads every run to an even length (MsmSortBuf::pad_log >= 1, padding = the point
+//                   at infinity), so pair q is entries 2q, 2q + 1 of the digit list and lands at point q of level 1; with
+//                   pad_log = 2 (runs padded to multiples of four) the same holds for level 1
 //   k_tree_pass1    lane t of a proof takes pairs t, t + NT, t + 2 NT, ... (every access of a wave is contiguous): denominator
 //                   of each pair, running product along the lane, prefixes to `pre`, the lane's product to `tp`
 //   k_binv_*        tp -> 1 / tp for all lanes: chains of products, ~4 096 binary-gcd inversions in the middle
@@ -217,7 +218,11 @@ k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
     const uint32_t p = MSM_P, np = gridDim.y, t = (blockIdx.x * blockDim.x + threadIdx.x) / LN;
     if (t >= NT) return;
     const uint32_t P = Ql[(size_t)p * (nb + 1) + nb];
-    const Rec* rec = reinterpret_cast<const Rec*>(rec_) + (size_t)p * rec_stride;
+    // rec_ == nullptr: a level >= 1 whose runs all have even lengths (the sort padded to a multiple of 2^(level + 1)): pair q is
+    // points 2q, 2q + 1 and lands at point q, like level 0 over the digit list
+    const Rec* recs = reinterpret_cast<const Rec*>(rec_) + (size_t)p * rec_stride;
+    const bool synth = rec_ == nullptr;
+    auto rec_at = [&](uint32_t q) -> Rec { return synth ? make_uint2(2u * q, q) : recs[q]; };
     TreeSrc<O, L0> src;
     src.tab = tab;
     src.xs = xs + (size_t)p * pt_stride * LN;
@@ -229,8 +234,8 @@ k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
     Rec ra{}, rb{};
     F x1 = O::zero(), x2 = O::zero();
     if (t < P) {
-        ra = rec[t];
-        if (t + NT < P) rb = rec[t + NT];
+        ra = rec_at(t);
+        if (t + NT < P) rb = rec_at(t + NT);
         src.load_x(ra, x1, x2);
     }
     // (gfx9 counts loads and stores in ONE counter and stores may complete out of order, so a wait for loaded data drains every
@@ -243,7 +248,7 @@ k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         if (j) pre[src.at(((size_t)(j - 1) * np + p) * NT + t)] = chain;
         ra = rb;
         if (q + NT < P) src.load_x(ra, x1, x2);
-        if (q + 2 * (uint64_t)NT < P) rb = rec[q + 2 * NT];
+        if (q + 2 * (uint64_t)NT < P) rb = rec_at(q + 2 * NT);
         F d = O::sub(cx2, cx1);
         if (O::is_zero(cx1) || O::is_zero(cx2) || O::is_zero(d)) {  // rare: needs the y coordinates to decide
             F y1, y2;
@@ -271,7 +276,11 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
     if (t >= NT) return;
     const uint32_t P = Ql[(size_t)p * (nb + 1) + nb];
     if (t >= P) return;
-    const Rec* rec = reinterpret_cast<const Rec*>(rec_) + (size_t)p * rec_stride;
+    // rec_ == nullptr: a level >= 1 whose runs all have even lengths (the sort padded to a multiple of 2^(level + 1)): pair q is
+    // points 2q, 2q + 1 and lands at point q, like level 0 over the digit list
+    const Rec* recs = reinterpret_cast<const Rec*>(rec_) + (size_t)p * rec_stride;
+    const bool synth = rec_ == nullptr;
+    auto rec_at = [&](uint32_t q) -> Rec { return synth ? make_uint2(2u * q, q) : recs[q]; };
     ox += (size_t)p * out_stride * LN;
     oy += (size_t)p * out_stride * LN;
     TreeSrc<O, L0> src;
@@ -290,8 +299,8 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         src.load_y_raw(r, o.y1, o.y2);
     };
     uint32_t j = (P - 1 - t) / NT;
-    Rec ra = rec[t + j * NT], rb{};
-    if (j) rb = rec[t + (j - 1) * NT];
+    Rec ra = rec_at(t + j * NT), rb{};
+    if (j) rb = rec_at(t + (j - 1) * NT);
     Ops nxt;
     fetch(ra, nxt);
     // (the result of a pair is stored at the top of the NEXT iteration, after that iteration's wait for its operands and before
@@ -310,7 +319,7 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         F pp = O::one();
         if (j) pp = pre[src.at(((size_t)(j - 1) * np + p) * NT + t)];
         if (j) fetch(ra, nxt);
-        if (j > 1) rb = rec[t + (j - 2) * NT];
+        if (j > 1) rb = rec_at(t + (j - 2) * NT);
         const uint32_t out = TreeSrc<O, L0>::out_index(cr, t + j * NT);
         TreeSrc<O, L0>::fix_y(cr, c.y1, c.y2);
         F d = O::sub(c.x2, c.x1);

@@ -60,9 +60,11 @@ struct MsmSortBuf {
     uint32_t n = 0, np = 0;
     MsmGeom g{};
     // Every bucket's run in `sorted` starts at a multiple of 2^pad_log entries; the gap behind a run holds MSM_PAD_ENTRY (the
-    // point at infinity).  The batch-affine tree (device/msm_tree.cuh) asks for pad_log = 1: every run has an even length, so
-    // pair q of level 0 is simply entries 2q, 2q + 1 and lands at point q of level 1 — no per-pair records for the level that
-    // holds half of all pairs.  start[] counts the padding; ent_stride = entries per proof of `sorted`.
+    // point at infinity).  The batch-affine tree (device/msm_tree.cuh) asks for pad_log = 2 (MASP_TREE_PAD_LOG): every run's
+    // length is a multiple of four, so pair q of level 0 is simply entries 2q, 2q + 1 and lands at point q of level 1, and the
+    // same again for level 1 — no per-pair records for the two levels that hold three quarters of all pairs (1 / 2 / 3
+    // measured: stage 54.1 / 52.7 / 54.2 ms per G1 MSM; padding to 2^levels costs more pair slots than records: DESIGN.md §6).
+    // start[] counts the padding; ent_stride = entries per proof of `sorted`.
     uint32_t pad_log = 0;
     size_t ent_stride = 0;
     static size_t padded_entries(uint32_t n_, const MsmGeom& g_, uint32_t pad_log_) {
@@ -301,6 +303,10 @@ struct MsmProfile {
 int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb, const uint32_t* d_scalars, size_t scalar_stride, uint32_t np,
                      uint32_t pad_log = 0);
 
+// runs of the digit list padded to multiples of 2^MASP_TREE_PAD_LOG entries when a tree follows: that many levels need no records
+#ifndef MASP_TREE_PAD_LOG
+#define MASP_TREE_PAD_LOG 2
+#endif
 // levels of the batch-affine tree for an MSM of `np` proofs over a base set with n_eff non-trivial scalars (0: none).  The tree
 // halves the bucket runs T times: 1 - 2^-T of the additions at 5.8 instead of 9.6 products.  Every level costs two passes over
 // its points and a latency-bound shared inversion, so T stays small (measured on 256 Spend proofs, 4 batches in flight,
@@ -347,7 +353,7 @@ int msm_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, MsmWorkspace<O>& ws,
     }
     // the tree wants runs of even length
     const bool tree = msm_tree_levels(B.n_eff, B.g, np, ws.tree_levels) || msm_tree_levels(B.n_eff, B.g, np, ws.tree_levels_shared);
-    int rc = msm_sort_enqueue(s, B.n, B.g, ws.sort, d_scalars, scalar_stride, np, tree ? 1u : 0u);
+    int rc = msm_sort_enqueue(s, B.n, B.g, ws.sort, d_scalars, scalar_stride, np, tree ? (uint32_t)MASP_TREE_PAD_LOG : 0u);
     if (rc) return rc;
     return msm_reduce_enqueue(s, B, ws.sort, ws, d_out, out_stride, prof);
 }

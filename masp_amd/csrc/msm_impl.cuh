@@ -96,7 +96,7 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
     }
     const bool lone = np < 8;  // latency regime: short chains matter more than total work
     // the batch-affine tree in front (msm_tree_levels, msm_host.h): it needs the sort's runs padded to even lengths
-    const uint32_t tree_T = sb.pad_log == 1 ? msm_tree_levels(B.n_eff, g, np, ws.tree_levels) : 0;
+    const uint32_t tree_T = sb.pad_log >= 1 ? msm_tree_levels(B.n_eff, g, np, ws.tree_levels) : 0;
     const uint32_t* start = sb.start;
     if (tree_T) {
         const uint32_t sub = std::max(1u, std::min(ws.tree_sub, np));

@@ -96,8 +96,8 @@ template <class O, int BYTES>
 int msm_tree_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSortBuf& sb, MsmTreeWs<O>& tw, uint32_t p0, uint32_t q, uint32_t T) {
     typedef typename O::T F;
     const uint32_t nb = (uint32_t)B.g.nb;
-    if (sb.pad_log != 1) {
-        last_hip_error() = "msm_tree_enqueue: the sort must pad every run to an even length (MsmSortBuf::pad_log = 1)";
+    if (sb.pad_log < 1) {
+        last_hip_error() = "msm_tree_enqueue: the sort must pad every run to an even length (MsmSortBuf::pad_log >= 1)";
         return MASP_HIP_E_INVALID_ARG;
     }
     const uint64_t E_ub = sb.ent_stride;  // entries per proof, the padding included
@@ -125,14 +125,16 @@ int msm_tree_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSortBu
         typedef typename O1::T F1;
         const dim3 grid1(NT * O1::LANES / 256, q);
         // level 0: the "records" are the digit list itself, two entries at a time (runs of even length: pair q = entries 2q, 2q + 1)
+        const void* recL = L >= sb.pad_log ? (const void*)tw.rec : nullptr;  // levels >= 1: records, or none below pad_log
         const void* rec0 = (const void*)sorted;
         const size_t rec0_stride = ent_stride / 2;
         if (L == 0) {
             hipLaunchKernelGGL((k_tree_pass1<O1, true>), grid1, block, 0, s, B.tab, (const F1*)xi, (const F1*)yi, si, rec0, rec0_stride, Ql, nb, NT,
                                (F1*)tw.pre, (F1*)tw.tp);
         } else {
-            hipLaunchKernelGGL(k_tree_records, rgrid, block, 0, s, Dl, Dn, Ql, nb, tw.rec, rec_stride);
-            hipLaunchKernelGGL((k_tree_pass1<O1, false>), grid1, block, 0, s, B.tab, (const F1*)xi, (const F1*)yi, si, (const void*)tw.rec, rec_stride, Ql, nb,
+            // (a level below the sort's pad_log has runs of even lengths only: no records, no odd points to copy)
+            if (L >= sb.pad_log) hipLaunchKernelGGL(k_tree_records, rgrid, block, 0, s, Dl, Dn, Ql, nb, tw.rec, rec_stride);
+            hipLaunchKernelGGL((k_tree_pass1<O1, false>), grid1, block, 0, s, B.tab, (const F1*)xi, (const F1*)yi, si, recL, rec_stride, Ql, nb,
                                NT, (F1*)tw.pre, (F1*)tw.tp);
         }
         tw.batch_invert(s, tw.tp, q * NT, tw.tinv);
@@ -143,10 +145,10 @@ int msm_tree_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSortBu
             hipLaunchKernelGGL((k_tree_pass2<O2, true>), grid2, block, 0, s, B.tab, (const F2*)xi, (const F2*)yi, si, rec0, rec0_stride, Ql, nb, NT,
                                (const F2*)tw.pre, (const F2*)tw.tinv, (F2*)xo, (F2*)yo, so);
         else
-            hipLaunchKernelGGL((k_tree_pass2<O2, false>), grid2, block, 0, s, B.tab, (const F2*)xi, (const F2*)yi, si, (const void*)tw.rec, rec_stride, Ql,
+            hipLaunchKernelGGL((k_tree_pass2<O2, false>), grid2, block, 0, s, B.tab, (const F2*)xi, (const F2*)yi, si, recL, rec_stride, Ql,
                                nb, NT, (const F2*)tw.pre, (const F2*)tw.tinv, (F2*)xo, (F2*)yo, so);
         // (level 0 has no odd runs: a run of odd length met its padding entry as P + infinity)
-        if (L) hipLaunchKernelGGL((k_tree_copy<O, false>), cgrid, block, 0, s, B.tab, sorted, ent_stride, xi, yi, si, Dl, Dn, nb, xo, yo, so);
+        if (L >= sb.pad_log) hipLaunchKernelGGL((k_tree_copy<O, false>), cgrid, block, 0, s, B.tab, sorted, ent_stride, xi, yi, si, Dl, Dn, nb, xo, yo, so);
     }
     return MASP_HIP_OK;
 }
