@@ -46,6 +46,67 @@ __global__ void k_femul(Fp* data, int iters) {
     for (int i = 0; i < iters; ++i) { a = fe_mul(a, b); b = fe_mul(b, a); }
     data[t] = fe_add(a, b);
 }
+// An experiment kept here only: the product with TWO column accumulators (operand products / reduction products), i.e. two
+// independent multiply-add chains for a lone wave.  Measured slower than fe_mul on a lone wave (1.56 vs 1.34 us): a lone wave
+// already runs fe_mul at its issue time, the extra ~6 instructions per column only cost.
+namespace masp {
+template <int K, class C>
+__device__ __forceinline__ void montl_columns_lo(uint64_t& accA, uint32_t& cA, const uint32_t* a, const uint32_t* b, uint32_t* m) {
+    if constexpr (K < C::N) {
+        uint64_t accB = 0;
+        uint32_t cB = 0;
+        macs_vv<0, K + 1, K, C>(accA, cA, a, b);
+        macs_vs<0, K, K, C>(accB, cB, m);
+        m[K] = ((uint32_t)accA + (uint32_t)accB) * C::INV;
+        mac_vs(accB, cB, m[K], C::MOD[0]);
+        const uint64_t t = accA + accB;
+        const uint32_t c = cA + cB + (t < accA ? 1u : 0u);
+        accA = (t >> 32) | ((uint64_t)c << 32);
+        cA = 0;
+        montl_columns_lo<K + 1, C>(accA, cA, a, b, m);
+    }
+}
+template <int K, class C>
+__device__ __forceinline__ void montl_columns_hi(uint64_t& accA, uint32_t& cA, const uint32_t* a, const uint32_t* b, const uint32_t* m, uint32_t* r) {
+    if constexpr (K < 2 * C::N - 1) {
+        uint64_t accB = 0;
+        uint32_t cB = 0;
+        macs_vv<K - C::N + 1, C::N, K, C>(accA, cA, a, b);
+        macs_vs<K - C::N + 1, C::N, K, C>(accB, cB, m);
+        const uint64_t t = accA + accB;
+        const uint32_t c = cA + cB + (t < accA ? 1u : 0u);
+        r[K - C::N] = (uint32_t)t;
+        accA = (t >> 32) | ((uint64_t)c << 32);
+        cA = 0;
+        montl_columns_hi<K + 1, C>(accA, cA, a, b, m, r);
+    }
+}
+template <class C>
+__device__ __forceinline__ Fe<C> fe_mul_lat(const Fe<C>& a, const Fe<C>& b) {
+    constexpr int N = C::N;
+    uint32_t m[N];
+    Fe<C> r;
+    uint64_t acc = 0;
+    uint32_t c2 = 0;
+    montl_columns_lo<0, C>(acc, c2, a.v, b.v, m);
+    montl_columns_hi<N, C>(acc, c2, a.v, b.v, m, r.v);
+    r.v[N - 1] = (uint32_t)acc;
+    fe_reduce_once(r);
+    return r;
+}
+}  // namespace masp
+__global__ void k_femul_lat(Fp* data, int iters) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    Fp a = data[t], b = data[t ^ 1];
+    for (int i = 0; i < iters; ++i) { a = fe_mul_lat(a, b); b = fe_mul_lat(b, a); }
+    data[t] = fe_add(a, b);
+}
+__global__ void k_femul_call(Fp* data, int iters) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    Fp a = data[t], b = data[t ^ 1];
+    for (int i = 0; i < iters; ++i) { a = fe_mul_nc(a, b); b = fe_mul_nc(b, a); }
+    data[t] = fe_add(a, b);
+}
 __global__ void k_frmul(Fr* data, int iters) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     Fr a = data[t], b = data[t ^ 1];
@@ -104,6 +165,12 @@ int main() {
         // single wave latency
         ms = time_ms([&] { hipLaunchKernelGGL(k_femul, dim3(1), dim3(64), 0, 0, d, 2000); });
         printf("Fp  fe_mul single-wave latency: %.3f us per mul\n", ms * 1e3 / 4000);
+        ms = time_ms([&] { hipLaunchKernelGGL(k_femul_call, dim3(1), dim3(64), 0, 0, d, 2000); });
+        printf("Fp  fe_mul_nc (call) single-wave latency: %.3f us per mul\n", ms * 1e3 / 4000);
+        ms = time_ms([&] { hipLaunchKernelGGL(k_femul_lat, dim3(1), dim3(64), 0, 0, d, 2000); });
+        printf("Fp  two-accumulator product single-wave latency: %.3f us per mul\n", ms * 1e3 / 4000);
+        ms = time_ms([&] { hipLaunchKernelGGL(k_femul_lat, dim3(blocks), dim3(threads), 0, 0, d, it); });
+        printf("Fp  two-accumulator product  %8.3f ms  %8.2f Gmul/s (full chip)\n", ms, (double)n * it * 2 / ms / 1e6);
     }
     {
         int waves_per_cu[] = {4, 8, 16};
