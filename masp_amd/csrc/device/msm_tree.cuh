@@ -10,15 +10,15 @@
 //
 // One level (input: points of level L, dense, bucket after bucket; D_L[b] = first point of bucket b; level 0 = the digit list):
 //   k_tree_plan     (once, all levels)  D_L[], Q_L[] = exclusive scans of len_L = ceil(len_0 / 2^L) and of len_L >> 1
-//   k_tree_records  (levels >= 1) pair q of the level -> its record (first input point, output point): a binary search in Q_L.
-//                   Level 0 needs none: the sort pads every run to an even length (MsmSortBuf::pad_log >= 1, padding = the point
-//                   at infinity), so pair q is entries 2q, 2q + 1 of the digit list and lands at point q of level 1; with
-//                   pad_log = 2 (runs padded to multiples of four) the same holds for level 1
+//   k_tree_records  (levels >= pad_log) pair q of the level -> its record (first input point, output point): a binary search in
+//                   Q_L.  The sort pads every run to a multiple of 2^pad_log entries (MsmSortBuf::pad_log, 2 by default; the
+//                   padding is the point at infinity), so on levels below pad_log pair q is simply entries 2q, 2q + 1 (level 0:
+//                   of the digit list itself) and lands at point q of the next level: no records, no odd points to copy
 //   k_tree_pass1    lane t of a proof takes pairs t, t + NT, t + 2 NT, ... (every access of a wave is contiguous): denominator
 //                   of each pair, running product along the lane, prefixes to `pre`, the lane's product to `tp`
 //   k_binv_*        tp -> 1 / tp for all lanes: chains of products, ~4 096 binary-gcd inversions in the middle
 //   k_tree_pass2    the same lanes backwards: 1 / d from the prefixes, the affine addition, the point to its place in level L+1
-//   k_tree_copy     the last point of an odd bucket passes through
+//   k_tree_copy     (levels >= pad_log) the last point of an odd bucket passes through
 // The price is memory: a level reads its points twice and keeps 48 bytes per pair in between; level 0 gathers every table row
 // twice (measured: random 128-byte rows arrive at 6.5 TB/s, tools/batch_affine_ubench.hip).
 // Exceptional pairs (P + P, P - P, the point at infinity as an operand) are handled exactly, like everywhere else: proof bytes
