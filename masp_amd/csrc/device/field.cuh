@@ -58,27 +58,32 @@ MASP_HD bool fe_eq(const Fe<C>& a, const Fe<C>& b) {
     return acc == 0;
 }
 
-// r = a - p if a >= p else a   (a < 2p)
+// ---- add / sub / neg / dbl / conditional subtraction ------------------------------------------------------------------
+// Host forms (tests, tiny set-up computations): portable C++ with 64-bit intermediates.
+// Device forms: carry chains written out (v_add_co / v_addc_co / v_sub_co / v_subb_co in their VOP3 encodings, the carry in
+// an explicit SGPR pair so that a chain can span several asm statements of four limbs each).  Left to the compiler, the
+// portable source became 64-bit additions with the carries rebuilt by shifts and moves: ~140 instructions for a 12-limb
+// subtraction, ~180 for an addition, ~100 for the conditional subtraction that ends every product — a quarter of all
+// instructions of the bucket-tree's additions pass (round 4; 37 / 48 / 36 now).  gfx9 VALU instructions read at most ONE
+// scalar operand, and a carry-in is one: a modulus limb can therefore not be an SGPR or a literal inside a chain — it is moved
+// into the destination register first (v_mov with a literal, inside the statement so that no register outlives it).
 template <class C>
-MASP_HD void fe_reduce_once(Fe<C>& a) {
+__host__ inline void fe_reduce_once(Fe<C>& a) {
     uint32_t t[C::N];
     uint64_t borrow = 0;
-#pragma unroll
     for (int i = 0; i < C::N; ++i) {
         uint64_t d = (uint64_t)a.v[i] - C::MOD[i] - borrow;
         t[i] = (uint32_t)d;
         borrow = (d >> 32) & 1;
     }
     if (!borrow) {
-#pragma unroll
         for (int i = 0; i < C::N; ++i) a.v[i] = t[i];
     }
 }
 template <class C>
-MASP_HD Fe<C> fe_add(const Fe<C>& a, const Fe<C>& b) {
+__host__ inline Fe<C> fe_add(const Fe<C>& a, const Fe<C>& b) {
     Fe<C> r;
     uint64_t carry = 0;
-#pragma unroll
     for (int i = 0; i < C::N; ++i) {
         uint64_t s = (uint64_t)a.v[i] + b.v[i] + carry;
         r.v[i] = (uint32_t)s;
@@ -89,10 +94,9 @@ MASP_HD Fe<C> fe_add(const Fe<C>& a, const Fe<C>& b) {
     return r;
 }
 template <class C>
-MASP_HD Fe<C> fe_sub(const Fe<C>& a, const Fe<C>& b) {
+__host__ inline Fe<C> fe_sub(const Fe<C>& a, const Fe<C>& b) {
     Fe<C> r;
     uint64_t borrow = 0;
-#pragma unroll
     for (int i = 0; i < C::N; ++i) {
         uint64_t d = (uint64_t)a.v[i] - b.v[i] - borrow;
         r.v[i] = (uint32_t)d;
@@ -100,7 +104,6 @@ MASP_HD Fe<C> fe_sub(const Fe<C>& a, const Fe<C>& b) {
     }
     uint32_t mask = (uint32_t)0 - (uint32_t)borrow;
     uint64_t carry = 0;
-#pragma unroll
     for (int i = 0; i < C::N; ++i) {
         uint64_t s = (uint64_t)r.v[i] + (C::MOD[i] & mask) + carry;
         r.v[i] = (uint32_t)s;
@@ -109,12 +112,143 @@ MASP_HD Fe<C> fe_sub(const Fe<C>& a, const Fe<C>& b) {
     return r;
 }
 template <class C>
-MASP_HD Fe<C> fe_neg(const Fe<C>& a) {
+__host__ inline Fe<C> fe_neg(const Fe<C>& a) {
     return fe_sub(fe_zero<C>(), a);  // 0 - 0 = 0 stays canonical
 }
 template <class C>
-MASP_HD Fe<C> fe_dbl(const Fe<C>& a) {
+__host__ inline Fe<C> fe_dbl(const Fe<C>& a) {
     return fe_add(a, a);
+}
+
+// four limbs of a chain; `c` = the carry / borrow (a wave-wide lane mask in an SGPR pair)
+template <bool FIRST>
+__device__ __forceinline__ void chain_add4(uint32_t* r, const uint32_t* b, uint64_t& c) {
+    if constexpr (FIRST)
+        asm("v_add_co_u32_e64 %0, %4, %0, %5\n\tv_addc_co_u32_e64 %1, %4, %1, %6, %4\n\tv_addc_co_u32_e64 %2, %4, %2, %7, %4\n\t"
+            "v_addc_co_u32_e64 %3, %4, %3, %8, %4"
+            : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "=&s"(c)
+            : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+    else
+        asm("v_addc_co_u32_e64 %0, %4, %0, %5, %4\n\tv_addc_co_u32_e64 %1, %4, %1, %6, %4\n\tv_addc_co_u32_e64 %2, %4, %2, %7, %4\n\t"
+            "v_addc_co_u32_e64 %3, %4, %3, %8, %4"
+            : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+s"(c)
+            : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+}
+template <bool FIRST>
+__device__ __forceinline__ void chain_sub4(uint32_t* r, const uint32_t* b, uint64_t& c) {  // r -= b
+    if constexpr (FIRST)
+        asm("v_sub_co_u32_e64 %0, %4, %0, %5\n\tv_subb_co_u32_e64 %1, %4, %1, %6, %4\n\tv_subb_co_u32_e64 %2, %4, %2, %7, %4\n\t"
+            "v_subb_co_u32_e64 %3, %4, %3, %8, %4"
+            : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "=&s"(c)
+            : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+    else
+        asm("v_subb_co_u32_e64 %0, %4, %0, %5, %4\n\tv_subb_co_u32_e64 %1, %4, %1, %6, %4\n\tv_subb_co_u32_e64 %2, %4, %2, %7, %4\n\t"
+            "v_subb_co_u32_e64 %3, %4, %3, %8, %4"
+            : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+s"(c)
+            : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+}
+template <bool FIRST>
+__device__ __forceinline__ void chain_neg4(uint32_t* r, uint64_t& c) {  // r = 0 - r
+    if constexpr (FIRST)
+        asm("v_sub_co_u32_e64 %0, %4, 0, %0\n\tv_subb_co_u32_e64 %1, %4, 0, %1, %4\n\tv_subb_co_u32_e64 %2, %4, 0, %2, %4\n\t"
+            "v_subb_co_u32_e64 %3, %4, 0, %3, %4"
+            : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "=&s"(c));
+    else
+        asm("v_subb_co_u32_e64 %0, %4, 0, %0, %4\n\tv_subb_co_u32_e64 %1, %4, 0, %1, %4\n\tv_subb_co_u32_e64 %2, %4, 0, %2, %4\n\t"
+            "v_subb_co_u32_e64 %3, %4, 0, %3, %4"
+            : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+s"(c));
+}
+// t = s - (limbs K .. K+3 of the modulus)
+template <class C, int K>
+__device__ __forceinline__ void chain_submod4(uint32_t* t, const uint32_t* s, uint64_t& c) {
+    if constexpr (K == 0)
+        asm("v_mov_b32_e32 %0, %9\n\tv_sub_co_u32_e64 %0, %4, %5, %0\n\tv_mov_b32_e32 %1, %10\n\tv_subb_co_u32_e64 %1, %4, %6, %1, %4\n\t"
+            "v_mov_b32_e32 %2, %11\n\tv_subb_co_u32_e64 %2, %4, %7, %2, %4\n\tv_mov_b32_e32 %3, %12\n\tv_subb_co_u32_e64 %3, %4, %8, %3, %4"
+            : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&s"(c)
+            : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "i"(C::MOD[K]), "i"(C::MOD[K + 1]), "i"(C::MOD[K + 2]), "i"(C::MOD[K + 3]));
+    else
+        asm("v_mov_b32_e32 %0, %9\n\tv_subb_co_u32_e64 %0, %4, %5, %0, %4\n\tv_mov_b32_e32 %1, %10\n\tv_subb_co_u32_e64 %1, %4, %6, %1, %4\n\t"
+            "v_mov_b32_e32 %2, %11\n\tv_subb_co_u32_e64 %2, %4, %7, %2, %4\n\tv_mov_b32_e32 %3, %12\n\tv_subb_co_u32_e64 %3, %4, %8, %3, %4"
+            : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "+s"(c)
+            : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "i"(C::MOD[K]), "i"(C::MOD[K + 1]), "i"(C::MOD[K + 2]), "i"(C::MOD[K + 3]));
+}
+// t = c ? s : t  (per lane)
+__device__ __forceinline__ void chain_sel4(uint32_t* t, const uint32_t* s, uint64_t c) {
+    asm("v_cndmask_b32_e64 %0, %0, %4, %8\n\tv_cndmask_b32_e64 %1, %1, %5, %8\n\tv_cndmask_b32_e64 %2, %2, %6, %8\n\tv_cndmask_b32_e64 %3, %3, %7, %8"
+        : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3])
+        : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "s"(c));
+}
+template <class C, int K>
+__device__ __forceinline__ void chain_submod(uint32_t* t, const uint32_t* s, uint64_t& c) {
+    if constexpr (K < C::N) {
+        chain_submod4<C, K>(t + K, s + K, c);
+        chain_submod<C, K + 4>(t, s, c);
+    }
+}
+// a < 2p  ->  a - p if a >= p else a
+template <class C>
+__device__ __forceinline__ void fe_reduce_once(Fe<C>& a) {
+    static_assert(C::N % 4 == 0, "limb chains are written four at a time");
+    uint32_t t[C::N];
+    uint64_t borrow;
+    chain_submod<C, 0>(t, a.v, borrow);
+#pragma unroll
+    for (int k = 0; k < C::N; k += 4) chain_sel4(t + k, a.v + k, borrow);
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) a.v[i] = t[i];
+}
+template <class C>
+__device__ __forceinline__ Fe<C> fe_add(const Fe<C>& a, const Fe<C>& b) {
+    Fe<C> r = a;
+    uint64_t carry;
+    chain_add4<true>(r.v, b.v, carry);
+#pragma unroll
+    for (int k = 4; k < C::N; k += 4) chain_add4<false>(r.v + k, b.v + k, carry);
+    // both moduli leave a spare top bit, so a + b < 2p < 2^(32N): no carry out
+    fe_reduce_once(r);
+    return r;
+}
+// r += p where the lanes of `borrow` are set
+template <class C>
+__device__ __forceinline__ void fe_add_mod_if(Fe<C>& r, uint64_t borrow) {
+    uint32_t mask;
+    asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(mask) : "s"(borrow));
+    uint32_t t[C::N];
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) t[i] = C::MOD[i] & mask;
+    uint64_t carry;
+    chain_add4<true>(r.v, t, carry);
+#pragma unroll
+    for (int k = 4; k < C::N; k += 4) chain_add4<false>(r.v + k, t + k, carry);
+}
+template <class C>
+__device__ __forceinline__ Fe<C> fe_sub(const Fe<C>& a, const Fe<C>& b) {
+    Fe<C> r = a;
+    uint64_t borrow;
+    chain_sub4<true>(r.v, b.v, borrow);
+#pragma unroll
+    for (int k = 4; k < C::N; k += 4) chain_sub4<false>(r.v + k, b.v + k, borrow);
+    fe_add_mod_if(r, borrow);
+    return r;
+}
+template <class C>
+__device__ __forceinline__ Fe<C> fe_neg(const Fe<C>& a) {
+    Fe<C> r = a;
+    uint64_t borrow;  // set iff a != 0: 0 - 0 = 0 stays canonical
+    chain_neg4<true>(r.v, borrow);
+#pragma unroll
+    for (int k = 4; k < C::N; k += 4) chain_neg4<false>(r.v + k, borrow);
+    fe_add_mod_if(r, borrow);
+    return r;
+}
+template <class C>
+__device__ __forceinline__ Fe<C> fe_dbl(const Fe<C>& a) {
+    Fe<C> r;
+    r.v[0] = a.v[0] << 1;
+#pragma unroll
+    for (int i = 1; i < C::N; ++i) r.v[i] = (a.v[i] << 1) | (a.v[i - 1] >> 31);   // 2a < 2p < 2^(32N)
+    fe_reduce_once(r);
+    return r;
 }
 
 // Montgomery product a*b*R^-1 mod p.

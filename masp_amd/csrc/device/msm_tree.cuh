@@ -37,6 +37,62 @@ namespace masp {
 #define MSM_P (blockIdx.y)
 #endif
 
+// ---- planes ------------------------------------------------------------------------------------------------------------
+// The tree's big arrays — the points of a level (x[], y[]) and the running products `pre` — are PLANES of `cap` 48-byte field
+// elements cut into three 16-byte slices: element e lives at b[e], b[cap + e], b[2 cap + e] (uint4 units).  A wave reading or
+// writing elements e0 .. e0 + 63 then moves 1 KiB of whole 128-byte lines per instruction.  With the elements stored whole
+// (12 words after each other) every one of the three 16-byte instructions of an access touched all 24 lines of the wave's
+// 3 KiB, a third of each: with ~30 such streams in flight per CU the lines did not survive in L2 between the three (round 3:
+// FETCH_SIZE / WRITE_SIZE of the passes ~1.6x the bytes they need).  An Fp2 (one lane per point: Fp2Ops) is two consecutive
+// elements, as in the lane-pair form.  MASP_TREE_SLICED=0 keeps the elements whole (A/B builds).
+#ifndef MASP_TREE_SLICED
+#define MASP_TREE_SLICED 1
+#endif
+__device__ __forceinline__ Fp plane_ld_fp(const uint4* __restrict__ b, size_t cap, size_t u) {
+    const uint4 a = b[u], c = b[cap + u], d = b[2 * cap + u];
+    Fp r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = c.x; r.v[5] = c.y; r.v[6] = c.z; r.v[7] = c.w;
+    r.v[8] = d.x; r.v[9] = d.y; r.v[10] = d.z; r.v[11] = d.w;
+    return r;
+}
+__device__ __forceinline__ void plane_st_fp(uint4* __restrict__ b, size_t cap, size_t u, const Fp& v) {
+    b[u] = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
+    b[cap + u] = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
+    b[2 * cap + u] = make_uint4(v.v[8], v.v[9], v.v[10], v.v[11]);
+}
+// element e of a plane of `cap` elements of type F (Fp, or Fp2 = two Fp)
+template <class F>
+__device__ __forceinline__ F plane_ld(const F* __restrict__ base, size_t cap, size_t e) {
+#if MASP_TREE_SLICED
+    const uint4* b = reinterpret_cast<const uint4*>(base);
+    if constexpr (sizeof(F) == sizeof(Fp)) {
+        return plane_ld_fp(b, cap, e);
+    } else {
+        F r;
+        r.c0 = plane_ld_fp(b, 2 * cap, 2 * e);
+        r.c1 = plane_ld_fp(b, 2 * cap, 2 * e + 1);
+        return r;
+    }
+#else
+    return base[e];
+#endif
+}
+template <class F>
+__device__ __forceinline__ void plane_st(F* __restrict__ base, size_t cap, size_t e, const F& v) {
+#if MASP_TREE_SLICED
+    uint4* b = reinterpret_cast<uint4*>(base);
+    if constexpr (sizeof(F) == sizeof(Fp)) {
+        plane_st_fp(b, cap, e, v);
+    } else {
+        plane_st_fp(b, 2 * cap, 2 * e, v.c0);
+        plane_st_fp(b, 2 * cap, 2 * e + 1, v.c1);
+    }
+#else
+    base[e] = v;
+#endif
+}
+
 // ---- plan -------------------------------------------------------------------------------------------------------
 // grid (T + 1, np), 1024 threads.  Level L = blockIdx.x of proof p = blockIdx.y:
 //   D[(L np + p)(nb + 1) + b] = sum_{b' < b} len_L(b')        (D[0] = start; D[L][nb] = points of level L)
@@ -117,6 +173,27 @@ k_tree_records(const uint32_t* __restrict__ Dl, const uint32_t* __restrict__ Dn,
     }
 }
 
+// Where point i of a proof lives in a plane of cap = np * pt_stride * LN elements (LN lanes per point, part h of it): points
+// with even and odd index in separate halves of the plane — the two operands of pair q (points 2q, 2q + 1 where the runs are
+// padded, a record's r.x, r.x + 1 elsewhere) are then each contiguous across the lanes of a wave, and so are the results
+// (point t + j NT from lane t).  pt_stride is even.  Elements whole (MASP_TREE_SLICED=0): proof after proof, point after point.
+template <uint32_t LN>
+__device__ __forceinline__ size_t tree_pt_base(uint32_t p, size_t pt_stride) {
+#if MASP_TREE_SLICED
+    return (size_t)p * (pt_stride >> 1) * LN;
+#else
+    return (size_t)p * pt_stride * LN;
+#endif
+}
+template <uint32_t LN>
+__device__ __forceinline__ size_t tree_pt_slot(size_t i, uint32_t h, size_t cap) {
+#if MASP_TREE_SLICED
+    return (i >> 1) * LN + h + (i & 1) * (cap >> 1);
+#else
+    return i * LN + h;
+#endif
+}
+
 // ---- the two operands of a pair ------------------------------------------------------------------------------------
 enum : int { TREE_ADD = 0, TREE_DBL = 1, TREE_FIRST = 2, TREE_SECOND = 3, TREE_INF = 4 };  // FIRST / SECOND: the result is that operand
 
@@ -149,7 +226,8 @@ struct TreeSrc {
     typedef typename TreeRec<L0>::type Rec;
     // O::LANES lanes hold one element (Fp2PairOps: 2): lane `h` of them reads part h of every stored element
     const TabRow<typename O::Base>* tab;
-    const F *xs, *ys;  // this proof's points (deeper levels)
+    const F *xs, *ys;  // the level's point planes (deeper levels): `cap` elements each
+    size_t cap, off;   // (set() below)
     uint32_t h;
     static __device__ __forceinline__ uint32_t lane_part() {
         if constexpr (O::LANES > 1)
@@ -166,13 +244,22 @@ struct TreeSrc {
         return reinterpret_cast<const F*>(&tab[w & 0x7fffffffu].p.y)[h];
     }
     __device__ __forceinline__ size_t at(size_t i) const { return i * O::LANES + h; }
+    // proof p of np, pt_stride points per proof (even)
+    __device__ __forceinline__ void set(const F* xs_, const F* ys_, uint32_t p, uint32_t np, size_t pt_stride) {
+        xs = xs_;
+        ys = ys_;
+        h = lane_part();
+        cap = (size_t)np * pt_stride * O::LANES;
+        off = tree_pt_base<O::LANES>(p, pt_stride);
+    }
+    __device__ __forceinline__ size_t slot(size_t i) const { return off + tree_pt_slot<O::LANES>(i, h, cap); }
     __device__ __forceinline__ void load_x(const Rec& r, F& x1, F& x2) const {
         if constexpr (L0) {
             x1 = row_x(r.x);
             x2 = row_x(r.y);
         } else {
-            x1 = xs[at(r.x)];
-            x2 = xs[at(r.x + 1)];
+            x1 = plane_ld(xs, cap, slot(r.x));
+            x2 = plane_ld(xs, cap, slot(r.x + 1));
         }
     }
     // the y coordinates as stored (no arithmetic on them here: a load that is consumed at once cannot be overlapped with the
@@ -182,15 +269,27 @@ struct TreeSrc {
             y1 = row_y(r.x);
             y2 = row_y(r.y);
         } else {
-            y1 = ys[at(r.x)];
-            y2 = ys[at(r.x + 1)];
+            y1 = plane_ld(ys, cap, slot(r.x));
+            y2 = plane_ld(ys, cap, slot(r.x + 1));
         }
     }
     // ... and the signs of the digits applied (level 0; the padding entry stays (0, 0): -0 = 0)
+    // (word-wise selects of an unconditional negation: as `if (sign) y = -y` the compiler built two exec-masked blocks of ~190
+    // instructions each around the 36 of the negation — 8 % of the instructions of level 0's additions pass)
+    static __device__ __forceinline__ F neg_if(const F& y, uint32_t sign_word) {
+        const F n = O::neg(y);
+        const uint32_t m = (uint32_t)((int32_t)sign_word >> 31);
+        F r;
+        const uint32_t *py = reinterpret_cast<const uint32_t*>(&y), *pn = reinterpret_cast<const uint32_t*>(&n);
+        uint32_t* pr = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+        for (uint32_t i = 0; i < sizeof(F) / 4; ++i) pr[i] = (pn[i] & m) | (py[i] & ~m);
+        return r;
+    }
     static __device__ __forceinline__ void fix_y(const Rec& r, F& y1, F& y2) {
         if constexpr (L0) {
-            if (r.x >> 31) y1 = O::neg(y1);
-            if (r.y >> 31) y2 = O::neg(y2);
+            y1 = neg_if(y1, r.x);
+            y2 = neg_if(y2, r.y);
         }
     }
     __device__ __forceinline__ void load_y(const Rec& r, F& y1, F& y2) const {
@@ -211,7 +310,7 @@ template <class O, bool L0>
 __global__ void __launch_bounds__(256)
 k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O::T* __restrict__ xs, const typename O::T* __restrict__ ys,
              size_t pt_stride, const void* __restrict__ rec_, size_t rec_stride, const uint32_t* __restrict__ Ql, uint32_t nb, uint32_t NT,
-             typename O::T* __restrict__ pre, typename O::T* __restrict__ tp) {
+             typename O::T* __restrict__ pre, size_t pre_cap, typename O::T* __restrict__ tp) {
     typedef typename O::T F;
     typedef typename TreeRec<L0>::type Rec;
     constexpr uint32_t LN = O::LANES;  // lanes per element (see k_tree_pass2)
@@ -225,9 +324,7 @@ k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
     auto rec_at = [&](uint32_t q) -> Rec { return synth ? make_uint2(2u * q, q) : recs[q]; };
     TreeSrc<O, L0> src;
     src.tab = tab;
-    src.xs = xs + (size_t)p * pt_stride * LN;
-    src.ys = ys + (size_t)p * pt_stride * LN;
-    src.h = TreeSrc<O, L0>::lane_part();
+    src.set(xs, ys, p, np, pt_stride);
     F chain = O::one();
     // two-stage software pipeline: the record of pair j + 2 and the operands of pair j + 1 are requested before pair j is
     // multiplied in — an operand is two dependent loads away (record, then row / point) and nothing else hides that
@@ -245,7 +342,7 @@ k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
     for (uint32_t q = t; q < P; q += NT, ++j) {
         const Rec cr = ra;
         const F cx1 = x1, cx2 = x2;
-        if (j) pre[src.at(((size_t)(j - 1) * np + p) * NT + t)] = chain;
+        if (j) plane_st(pre, pre_cap, src.at(((size_t)(j - 1) * np + p) * NT + t), chain);
         ra = rb;
         if (q + NT < P) src.load_x(ra, x1, x2);
         if (q + 2 * (uint64_t)NT < P) rb = rec_at(q + 2 * NT);
@@ -257,7 +354,7 @@ k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         }
         chain = O::mul(chain, d);
     }
-    if (j) pre[src.at(((size_t)(j - 1) * np + p) * NT + t)] = chain;
+    if (j) plane_st(pre, pre_cap, src.at(((size_t)(j - 1) * np + p) * NT + t), chain);
     tp[src.at((size_t)p * NT + t)] = chain;
 }
 
@@ -267,8 +364,8 @@ template <class O, bool L0>
 __global__ void __launch_bounds__(256, (sizeof(typename O::T) > 48 ? 1 : 2))   // two waves per SIMD (<= 256 VGPRs) where an element is 12 registers
 k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O::T* __restrict__ xs, const typename O::T* __restrict__ ys,
              size_t pt_stride, const void* __restrict__ rec_, size_t rec_stride, const uint32_t* __restrict__ Ql, uint32_t nb, uint32_t NT,
-             const typename O::T* __restrict__ pre, const typename O::T* __restrict__ tinv, typename O::T* __restrict__ ox,
-             typename O::T* __restrict__ oy, size_t out_stride) {
+             const typename O::T* __restrict__ pre, size_t pre_cap, const typename O::T* __restrict__ tinv, typename O::T* __restrict__ ox,
+             typename O::T* __restrict__ oy, size_t out_stride, uint32_t out_whole) {
     typedef typename O::T F;
     typedef typename TreeRec<L0>::type Rec;
     constexpr uint32_t LN = O::LANES;  // lanes per element; every stride and index below counts ELEMENTS (LN values of F each)
@@ -281,13 +378,22 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
     const Rec* recs = reinterpret_cast<const Rec*>(rec_) + (size_t)p * rec_stride;
     const bool synth = rec_ == nullptr;
     auto rec_at = [&](uint32_t q) -> Rec { return synth ? make_uint2(2u * q, q) : recs[q]; };
-    ox += (size_t)p * out_stride * LN;
-    oy += (size_t)p * out_stride * LN;
     TreeSrc<O, L0> src;
     src.tab = tab;
-    src.xs = xs + (size_t)p * pt_stride * LN;
-    src.ys = ys + (size_t)p * pt_stride * LN;
-    src.h = TreeSrc<O, L0>::lane_part();
+    src.set(xs, ys, p, np, pt_stride);
+    // the results: point `out` of the next level's planes — or, from the last level (out_whole), whole elements proof after
+    // proof, point after point: k_msm_accumulate_pts walks them one lane per chunk
+    const size_t out_cap = (size_t)np * out_stride * LN, out_off = tree_pt_base<LN>(p, out_stride), whole_off = (size_t)p * out_stride * LN;
+    auto put = [&](uint32_t out, const F& x, const F& y) {
+        if (out_whole) {
+            ox[whole_off + src.at(out)] = x;
+            oy[whole_off + src.at(out)] = y;
+        } else {
+            const size_t e = out_off + tree_pt_slot<LN>(out, src.h, out_cap);
+            plane_st(ox, out_cap, e, x);
+            plane_st(oy, out_cap, e, y);
+        }
+    };
     F I = tinv[src.at((size_t)p * NT + t)];
     // two-stage software pipeline, backwards: the record of pair j - 2 and the operands of pair j - 1 are requested before pair
     // j is computed (see pass 1)
@@ -312,12 +418,9 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         Ops c = nxt;
         const Rec cr = ra;
         ra = rb;
-        if (held) {
-            ox[src.at(hout)] = hx;
-            oy[src.at(hout)] = hy;
-        }
+        if (held) put(hout, hx, hy);
         F pp = O::one();
-        if (j) pp = pre[src.at(((size_t)(j - 1) * np + p) * NT + t)];
+        if (j) pp = plane_ld(pre, pre_cap, src.at(((size_t)(j - 1) * np + p) * NT + t));
         if (j) fetch(ra, nxt);
         if (j > 1) rb = rec_at(t + (j - 2) * NT);
         const uint32_t out = TreeSrc<O, L0>::out_index(cr, t + j * NT);
@@ -356,8 +459,7 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         held = true;
         if (!j) break;
     }
-    ox[src.at(hout)] = hx;
-    oy[src.at(hout)] = hy;
+    put(hout, hx, hy);
 }
 
 // the last point of a bucket with an odd number of points goes to the next level as it is.  grid (nb / 256, np)
@@ -365,8 +467,8 @@ template <class O, bool L0>
 __global__ void __launch_bounds__(256)
 k_tree_copy(const TabRow<O>* __restrict__ tab, const uint32_t* __restrict__ sorted, size_t ent_stride, const typename O::T* __restrict__ xs,
             const typename O::T* __restrict__ ys, size_t pt_stride, const uint32_t* __restrict__ Dl, const uint32_t* __restrict__ Dn, uint32_t nb,
-            typename O::T* __restrict__ ox, typename O::T* __restrict__ oy, size_t out_stride) {
-    const uint32_t p = MSM_P, b = blockIdx.x * blockDim.x + threadIdx.x;
+            typename O::T* __restrict__ ox, typename O::T* __restrict__ oy, size_t out_stride, uint32_t out_whole) {
+    const uint32_t p = MSM_P, np = gridDim.y, b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     Dl += (size_t)p * (nb + 1);
     Dn += (size_t)p * (nb + 1);
@@ -380,11 +482,18 @@ k_tree_copy(const TabRow<O>* __restrict__ tab, const uint32_t* __restrict__ sort
         x = pt.x;
         y = (w >> 31) ? O::neg(pt.y) : pt.y;
     } else {
-        x = xs[(size_t)p * pt_stride + in];
-        y = ys[(size_t)p * pt_stride + in];
+        const size_t cap = (size_t)np * pt_stride, e = tree_pt_base<1>(p, pt_stride) + tree_pt_slot<1>(in, 0, cap);
+        x = plane_ld(xs, cap, e);
+        y = plane_ld(ys, cap, e);
     }
-    ox[(size_t)p * out_stride + out] = x;
-    oy[(size_t)p * out_stride + out] = y;
+    if (out_whole) {
+        ox[(size_t)p * out_stride + out] = x;
+        oy[(size_t)p * out_stride + out] = y;
+    } else {
+        const size_t cap = (size_t)np * out_stride, e = tree_pt_base<1>(p, out_stride) + tree_pt_slot<1>(out, 0, cap);
+        plane_st(ox, cap, e, x);
+        plane_st(oy, cap, e, y);
+    }
 }
 
 // ---- grid-wide batch inversion (Montgomery's trick as chains of products) ------------------------------------------------

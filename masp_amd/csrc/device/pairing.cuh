@@ -145,7 +145,7 @@ __device__ inline int g2_read_compressed(const uint8_t* in, G2Affine& p) {
 
 // ---- stage 1: decode + randomise ---------------------------------------------------------------------------------
 // proofs: n x 192 B; z: n x 16 B (little-endian, bit 0 forced to 1 like the host verifier).  Outputs per proof: za = z A
-// (affine), b = B (affine), zc = z C (XYZZ), status = PT_* bits of the three points (PT_INFINITY is legal).
+// (affine), b = B (affine), zc = z C (XYZZ), status = PT_* bits of the three points (the host refuses every one of them, PT_INFINITY included: k_verify.hip).
 __global__ void __launch_bounds__(64) k_verify_prepare(const uint8_t* __restrict__ proofs, const uint8_t* __restrict__ z, uint32_t n,
                                                        G1Affine* __restrict__ za, G2Affine* __restrict__ b, G1Xyzz* __restrict__ zc,
                                                        int* __restrict__ status) {

@@ -227,6 +227,7 @@ int masp_host_vk_verify(const void* h, const uint8_t proof[192], const uint8_t* 
     bls::G1A a, c;
     bls::G2A b;
     if (!bls::g1_compressed(a, proof) || !bls::g2_compressed(b, proof + 48) || !bls::g1_compressed(c, proof + 144)) return -2;
+    if (a.inf || b.inf || c.inf) return -2;  // bellman's Proof::read refuses the identity in any of the three ("point at infinity")
     bls::G1J acc = bls::G1J::from(vk.ic[0]);
     for (uint32_t i = 0; i < n_public; ++i) {
         Fr chk;
@@ -262,6 +263,7 @@ int masp_host_vk_verify_batch(const void* h, size_t n, const uint8_t* proofs, co
         bls::G1A a, c;
         bls::G2A b;
         if (!bls::g1_compressed(a, pr) || !bls::g2_compressed(b, pr + 48) || !bls::g1_compressed(c, pr + 144)) return -2;
+        if (a.inf || b.inf || c.inf) return -2;  // (as above: Proof::read refuses the identity)
         uint8_t zi[32] = {0};
         memcpy(zi, z + 16 * i, 16);
         zi[0] |= 1;  // never zero

@@ -39,20 +39,20 @@ int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb
         last_hip_error() = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
         return MASP_HIP_E_HIP;
     }
-    hipLaunchKernelGGL(k_msm_hist, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg);
-    hipLaunchKernelGGL(k_msm_offsets, dim3(1, np), dim3(1024), 0, s, sb.hist_wg, ng, nb, sb.start, sb.dense, pad_log);
+    MASP_LAUNCH(k_msm_hist, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg);
+    MASP_LAUNCH(k_msm_offsets, dim3(1, np), dim3(1024), 0, s, sb.hist_wg, ng, nb, sb.start, sb.dense, pad_log);
     if (two_pass && g.W <= 32) {
         const uint32_t nbins = nb >> MSM_FINE_LOG;
-        hipLaunchKernelGGL(k_msm_coarse, dim3(nbins, np), dim3(128), 0, s, sb.hist_wg, ng, nb, sb.crel);
-        hipLaunchKernelGGL(k_msm_partition, dim3(ng, np), dim3(MSM_PART_TILE), part_lds, s, d_scalars, scalar_stride, n, g, ng, sb.crel, sb.dense, sb.tmp);
-        hipLaunchKernelGGL(k_msm_bucketize, dim3(nbins, np), dim3(1024), 0, s, sb.tmp, (size_t)n * g.W, sb.dense, sb.start, nb, sb.sorted, sb.ent_stride);
+        MASP_LAUNCH(k_msm_coarse, dim3(nbins, np), dim3(128), 0, s, sb.hist_wg, ng, nb, sb.crel);
+        MASP_LAUNCH(k_msm_partition, dim3(ng, np), dim3(MSM_PART_TILE), part_lds, s, d_scalars, scalar_stride, n, g, ng, sb.crel, sb.dense, sb.tmp);
+        MASP_LAUNCH(k_msm_bucketize, dim3(nbins, np), dim3(1024), 0, s, sb.tmp, (size_t)n * g.W, sb.dense, sb.start, nb, sb.sorted, sb.ent_stride);
     } else {
         // (the single-pass placement writes entries only: aligned runs get their padding from a fill first)
         if (pad_log) HIP_TRY(hipMemsetAsync(sb.sorted, 0xff, 4 * sb.ent_stride * np, s));
-        hipLaunchKernelGGL(k_msm_scatter, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg, sb.start,
+        MASP_LAUNCH(k_msm_scatter, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg, sb.start,
                            sb.sorted, sb.ent_stride);
     }
-    return MASP_HIP_OK;
+    return launch_status();
 }
 
 }  // namespace masp

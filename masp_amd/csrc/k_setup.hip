@@ -55,13 +55,13 @@ int masp_hip_generate_parameters(masp_hip_ctx* ctx, const masp_hip_r1cs* cs, con
             g2.y.c0.v[i] = FpCfg::G2_Y0[i];
             g2.y.c1.v[i] = FpCfg::G2_Y1[i];
         }
-        hipLaunchKernelGGL((k_setup_fixed_table<FpOps>), dim3(1), dim3(64), 0, s, g1, ctx->fb_g1.p);
-        hipLaunchKernelGGL((k_setup_fixed_table<Fp2Ops>), dim3(1), dim3(64), 0, s, g2, ctx->fb_g2.p);
+        MASP_LAUNCH((k_setup_fixed_table<FpOps>), dim3(1), dim3(64), 0, s, g1, ctx->fb_g1.p);
+        MASP_LAUNCH((k_setup_fixed_table<Fp2Ops>), dim3(1), dim3(64), 0, s, g2, ctx->fb_g2.p);
     }
     // Lagrange basis at tau
     DevBuf<Fr> lag, qt[3];
     if ((rc = lag.reserve(nrows))) return fail(ctx, rc);
-    hipLaunchKernelGGL(k_setup_lagrange, dim3((nrows + 127) / 128), dim3(128), 0, s, lag.p, nrows, omega, tau, z_over_m);
+    MASP_LAUNCH(k_setup_lagrange, dim3((nrows + 127) / 128), dim3(128), 0, s, lag.p, nrows, omega, tau, z_over_m);
     // column-major copies of A, B, C (plain integer bucketing on the host), then one lane per variable
     const uint32_t* rp[3] = {cs->a_rowptr, cs->b_rowptr, cs->c_rowptr};
     const uint32_t* cl[3] = {cs->a_col, cs->b_col, cs->c_col};
@@ -91,7 +91,7 @@ int masp_hip_generate_parameters(masp_hip_ctx* ctx, const masp_hip_r1cs* cs, con
             (rc = d_raw.upload(coefs.data(), nnz, s)) || (rc = d_coef.reserve(nnz)) || (rc = qt[mi].reserve(nv)))
             return fail(ctx, rc);
         if (nnz) launch_fr_to_mont(s, d_raw.p, (size_t)0, d_coef.p, nnz, 1, d_flag.p);
-        hipLaunchKernelGGL(k_setup_qap, dim3((nv + 127) / 128), dim3(128), 0, s, d_colptr.p, d_rowidx.p, d_coef.p, lag.p, nv, n_in, nc,
+        MASP_LAUNCH(k_setup_qap, dim3((nv + 127) / 128), dim3(128), 0, s, d_colptr.p, d_rowidx.p, d_coef.p, lag.p, nv, n_in, nc,
                            mi == 0 ? 1 : 0, qt[mi].p);
         if (hipStreamSynchronize(s) != hipSuccess) {
             last_hip_error() = std::string("qap evaluation failed: ") + hipGetErrorString(hipGetLastError());
@@ -101,8 +101,8 @@ int masp_hip_generate_parameters(masp_hip_ctx* ctx, const masp_hip_r1cs* cs, con
     // which variables survive the identity filter of a / b
     DevBuf<uint8_t> d_nz;
     if ((rc = d_nz.reserve(2 * (size_t)nv))) return fail(ctx, rc);
-    hipLaunchKernelGGL(k_setup_nonzero, dim3((nv + 255) / 256), dim3(256), 0, s, qt[0].p, nv, d_nz.p);
-    hipLaunchKernelGGL(k_setup_nonzero, dim3((nv + 255) / 256), dim3(256), 0, s, qt[1].p, nv, d_nz.p + nv);
+    MASP_LAUNCH(k_setup_nonzero, dim3((nv + 255) / 256), dim3(256), 0, s, qt[0].p, nv, d_nz.p);
+    MASP_LAUNCH(k_setup_nonzero, dim3((nv + 255) / 256), dim3(256), 0, s, qt[1].p, nv, d_nz.p + nv);
     std::vector<uint8_t> nz(2 * (size_t)nv);
     int hflag = 0;
     if (hipMemcpyAsync(nz.data(), d_nz.p, nz.size(), hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -131,20 +131,20 @@ int masp_hip_generate_parameters(masp_hip_ctx* ctx, const masp_hip_r1cs* cs, con
         hipMemcpyAsync(k2.p, head2, sizeof(head2), hipMemcpyHostToDevice, s) != hipSuccess)
         return fail(ctx, MASP_HIP_E_HIP);
     // ic = lc / gamma (inputs), l = lc / delta (aux)
-    hipLaunchKernelGGL(k_setup_lc, dim3((n_in + 255) / 256), dim3(256), 0, s, qt[0].p, qt[1].p, qt[2].p, n_in, alpha, beta, ginv, k1.p + o_ic);
+    MASP_LAUNCH(k_setup_lc, dim3((n_in + 255) / 256), dim3(256), 0, s, qt[0].p, qt[1].p, qt[2].p, n_in, alpha, beta, ginv, k1.p + o_ic);
     if (n_aux)
-        hipLaunchKernelGGL(k_setup_lc, dim3((n_aux + 255) / 256), dim3(256), 0, s, qt[0].p + n_in, qt[1].p + n_in, qt[2].p + n_in, n_aux, alpha,
+        MASP_LAUNCH(k_setup_lc, dim3((n_aux + 255) / 256), dim3(256), 0, s, qt[0].p + n_in, qt[1].p + n_in, qt[2].p + n_in, n_aux, alpha,
                            beta, dinv, k1.p + o_l);
-    hipLaunchKernelGGL(k_setup_h_scalars, dim3((n_h + 255) / 256), dim3(256), 0, s, tau, fe_mul(z, dinv), (uint32_t)n_h, k1.p + o_h);
-    if (n_a) hipLaunchKernelGGL(k_setup_gather, dim3((n_a + 255) / 256), dim3(256), 0, s, qt[0].p, d_alist.p, (uint32_t)n_a, k1.p + o_a);
+    MASP_LAUNCH(k_setup_h_scalars, dim3((n_h + 255) / 256), dim3(256), 0, s, tau, fe_mul(z, dinv), (uint32_t)n_h, k1.p + o_h);
+    if (n_a) MASP_LAUNCH(k_setup_gather, dim3((n_a + 255) / 256), dim3(256), 0, s, qt[0].p, d_alist.p, (uint32_t)n_a, k1.p + o_a);
     if (n_b) {
-        hipLaunchKernelGGL(k_setup_gather, dim3((n_b + 255) / 256), dim3(256), 0, s, qt[1].p, d_blist.p, (uint32_t)n_b, k1.p + o_b);
-        hipLaunchKernelGGL(k_setup_gather, dim3((n_b + 255) / 256), dim3(256), 0, s, qt[1].p, d_blist.p, (uint32_t)n_b, k2.p + 3);
+        MASP_LAUNCH(k_setup_gather, dim3((n_b + 255) / 256), dim3(256), 0, s, qt[1].p, d_blist.p, (uint32_t)n_b, k1.p + o_b);
+        MASP_LAUNCH(k_setup_gather, dim3((n_b + 255) / 256), dim3(256), 0, s, qt[1].p, d_blist.p, (uint32_t)n_b, k2.p + 3);
     }
     DevBuf<uint8_t> p1, p2;
     if ((rc = p1.reserve(96 * n_g1)) || (rc = p2.reserve(192 * n_g2))) return fail(ctx, rc);
-    hipLaunchKernelGGL((k_setup_fixed_mul<FpOps, 96>), dim3((n_g1 + 63) / 64), dim3(64), 0, s, ctx->fb_g1.p, k1.p, (uint32_t)n_g1, 1, p1.p);
-    hipLaunchKernelGGL((k_setup_fixed_mul<Fp2Ops, 192>), dim3((n_g2 + 63) / 64), dim3(64), 0, s, ctx->fb_g2.p, k2.p, (uint32_t)n_g2, 1, p2.p);
+    MASP_LAUNCH((k_setup_fixed_mul<FpOps, 96>), dim3((n_g1 + 63) / 64), dim3(64), 0, s, ctx->fb_g1.p, k1.p, (uint32_t)n_g1, 1, p1.p);
+    MASP_LAUNCH((k_setup_fixed_mul<Fp2Ops, 192>), dim3((n_g2 + 63) / 64), dim3(64), 0, s, ctx->fb_g2.p, k2.p, (uint32_t)n_g2, 1, p2.p);
     std::vector<uint8_t> h1(96 * n_g1), h2(192 * n_g2);
     if (hipMemcpyAsync(h1.data(), p1.p, h1.size(), hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipMemcpyAsync(h2.data(), p2.p, h2.size(), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {

@@ -116,12 +116,12 @@ int masp_hip_verify_batch(masp_hip_ctx* ctx, masp_hip_vk* vk, size_t n, const ui
         last_hip_error() = "pairing interpreter: LDS configuration failed";
         return fail_shared_v(ctx, MASP_HIP_E_HIP);
     }
-    hipLaunchKernelGGL(k_verify_prepare, dim3((nn + 63) / 64, 5), dim3(64), 0, s, d_proofs.p, d_z.p, nn, d_za.p, d_b.p, d_zc.p, d_status.p);
-    hipLaunchKernelGGL(k_g1_sum_export, dim3(1), dim3(256), 0, s, d_zc.p, nn, d_sum.p);
-    hipLaunchKernelGGL(k_miller_pairs, dim3(nn), dim3(64), lds, s, vk->dbl, vk->add, vk->n_slots, d_za.p, d_b.p, d_f.p);
+    MASP_LAUNCH(k_verify_prepare, dim3((nn + 63) / 64, 5), dim3(64), 0, s, d_proofs.p, d_z.p, nn, d_za.p, d_b.p, d_zc.p, d_status.p);
+    MASP_LAUNCH(k_g1_sum_export, dim3(1), dim3(256), 0, s, d_zc.p, nn, d_sum.p);
+    MASP_LAUNCH(k_miller_pairs, dim3(nn), dim3(64), lds, s, vk->dbl, vk->add, vk->n_slots, d_za.p, d_b.p, d_f.p);
     const uint32_t g = std::min<uint32_t>(nn, 64);
-    hipLaunchKernelGGL(k_fp12_product, dim3(g), dim3(64), lds, s, vk->mul12, vk->n_slots, d_f.p, nn, g);
-    if (g > 1) hipLaunchKernelGGL(k_fp12_product, dim3(1), dim3(64), lds, s, vk->mul12, vk->n_slots, d_f.p, g, 1u);
+    MASP_LAUNCH(k_fp12_product, dim3(g), dim3(64), lds, s, vk->mul12, vk->n_slots, d_f.p, nn, g);
+    if (g > 1) MASP_LAUNCH(k_fp12_product, dim3(1), dim3(64), lds, s, vk->mul12, vk->n_slots, d_f.p, g, 1u);
     std::vector<int> status(n);
     masp_host::bls::Fp12 f;
     uint8_t sum96[96];
@@ -133,7 +133,7 @@ int masp_hip_verify_batch(masp_hip_ctx* ctx, masp_hip_vk* vk, size_t n, const ui
         return fail_shared_v(ctx, MASP_HIP_E_HIP);
     }
     for (int st : status)
-        if (st & (PT_BAD_FLAGS | PT_NOT_CANONICAL | PT_NOT_IN_SUBGROUP)) return MASP_HIP_OK;  // what Proof::read refuses: not valid (*all_valid stays 0)
+        if (st & (PT_BAD_FLAGS | PT_NOT_CANONICAL | PT_NOT_IN_SUBGROUP | PT_INFINITY)) return MASP_HIP_OK;  // what Proof::read refuses (the identity included: "point at infinity"): not valid (*all_valid stays 0)
     masp_host::bls::G1A csum;
     if (!masp_host::bls::g1_uncompressed(csum, sum96)) {
         last_hip_error() = "batch verification: device returned a malformed point";

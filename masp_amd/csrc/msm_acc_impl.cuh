@@ -9,7 +9,7 @@ namespace masp {
 template <class O>
 void msm_launch_accumulate(hipStream_t s, const TabRow<O>* tab, const uint32_t* sorted, size_t ent_stride, const uint32_t* start, uint32_t nb,
                            uint32_t nchunks, Xyzz<O>* part, uint32_t np) {
-    hipLaunchKernelGGL((k_msm_accumulate<O>), dim3((nchunks + 63) / 64, np), dim3(64), 0, s, tab, sorted, ent_stride, start, nb, nchunks, part);
+    MASP_LAUNCH((k_msm_accumulate<O>), dim3((nchunks + 63) / 64, np), dim3(64), 0, s, tab, sorted, ent_stride, start, nb, nchunks, part);
 }
 
 }  // namespace masp

@@ -153,6 +153,7 @@ struct MsmTreeWs {
     // what the last msm_tree_enqueue produced
     uint32_t q = 0, nb = 0, T = 0;
     size_t stride[2] = {0, 0};
+    size_t pre_cap = 0;  // elements of the plane `pre`
 
     int reserve(uint64_t E_ub, uint32_t nb, uint32_t q, uint32_t T);                 // [msm_tree_impl.cuh]
     void batch_invert(hipStream_t s, const F* in, uint32_t n, F* out);              // [msm_tree_impl.cuh]

@@ -34,8 +34,8 @@ int MsmBases<O, BYTES>::load_device(const uint8_t* d_raw, uint32_t n_, hipStream
         HIP_TRY(hipMalloc(&d_status, sizeof(int)));
         HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(int), s));
         dim3 grid((n + 63) / 64), block(64);
-        hipLaunchKernelGGL((k_msm_import<O, BYTES>), grid, block, 0, s, d_raw, tab, n, d_status);
-        hipLaunchKernelGGL((k_msm_precompute<O>), grid, block, 0, s, tab, n, g.c, g.W);
+        MASP_LAUNCH((k_msm_import<O, BYTES>), grid, block, 0, s, d_raw, tab, n, d_status);
+        MASP_LAUNCH((k_msm_precompute<O>), grid, block, 0, s, tab, n, g.c, g.W);
         HIP_TRY(hipMemcpyAsync(&import_status, d_status, sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         hipFree(d_status);
@@ -52,7 +52,7 @@ void MsmWorkspace<O>::reduce_to_one(hipStream_t s, uint32_t np, const Xyzz<O>* s
             uint32_t outn = (m + 255) / 256;
             Xyzz<O>* out = outn == 1 ? dst : R[flip];
             size_t out_stride = outn == 1 ? dst_stride : r_stride;
-            hipLaunchKernelGGL((k_xyzz_reduce_block<O>), dim3(outn, np), dim3(256), 256 * sizeof(Xyzz<O>), s, cur, cur_stride, m, out, out_stride);
+            MASP_LAUNCH((k_xyzz_reduce_block<O>), dim3(outn, np), dim3(256), 256 * sizeof(Xyzz<O>), s, cur, cur_stride, m, out, out_stride);
             if (outn == 1) break;
             cur = out;
             cur_stride = out_stride;
@@ -125,15 +125,15 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
     // first working workgroup (x = 0: bucket 0) would land on the same XCD: keep gridDim.x odd.
     typedef typename TailLaneOps<O>::type OT;
     constexpr uint32_t LN = OT::LANES;
-    hipLaunchKernelGGL((k_msm_bucket_gather<OT>), dim3((nb * LN + 63) / 64, np), dim3(64), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy,
+    MASP_LAUNCH((k_msm_bucket_gather<OT>), dim3((nb * LN + 63) / 64, np), dim3(64), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy,
                        ws.n_heavy, lone ? 12u : 8u);
     if (lone) {
         const uint32_t heavy_blocks = std::min<uint32_t>(std::max<uint32_t>(4096u / np, 16u), nb) | 1u;
-        hipLaunchKernelGGL((k_msm_bucket_heavy<OT, 256>), dim3(heavy_blocks, np), dim3(256), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy,
+        MASP_LAUNCH((k_msm_bucket_heavy<OT, 256>), dim3(heavy_blocks, np), dim3(256), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy,
                            ws.n_heavy);
     } else {
         const uint32_t heavy_blocks = std::min<uint32_t>(64u, nb) | 1u;
-        hipLaunchKernelGGL((k_msm_bucket_heavy<OT, 64>), dim3(heavy_blocks, np), dim3(64), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy,
+        MASP_LAUNCH((k_msm_bucket_heavy<OT, 64>), dim3(heavy_blocks, np), dim3(64), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy,
                            ws.n_heavy);
     }
     // weighted sum by levels of (G x 128)-bucket workgroups.  Per lane the kernel costs 2 G additions for its buckets plus
@@ -157,7 +157,7 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
         const dim3 grid(chunks, np), block(WSUM_L * LN);
         switch (g_log) {
 #define MASP_WSUM_CASE(GL) \
-    case GL: hipLaunchKernelGGL((k_msm_wsum_level<OT, GL>), grid, block, 0, s, bk, bk_stride, m, off, ws.S[flip], ws.T, st_stride); break;
+    case GL: MASP_LAUNCH((k_msm_wsum_level<OT, GL>), grid, block, 0, s, bk, bk_stride, m, off, ws.S[flip], ws.T, st_stride); break;
             MASP_WSUM_CASE(0) MASP_WSUM_CASE(2) MASP_WSUM_CASE(3) MASP_WSUM_CASE(4) MASP_WSUM_CASE(5) MASP_WSUM_CASE(6)
 #undef MASP_WSUM_CASE
         }
@@ -169,8 +169,8 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
         off = 0;
         ++level;
     } while (m > 1);
-    hipLaunchKernelGGL((k_msm_combine<O>), dim3(1, np), dim3(64), 0, s, ws.tsum, level, (int)(g_log + WSUM_L_LOG), d_out, out_stride);
-    return MASP_HIP_OK;
+    MASP_LAUNCH((k_msm_combine<O>), dim3(1, np), dim3(64), 0, s, ws.tsum, level, (int)(g_log + WSUM_L_LOG), d_out, out_stride);
+    return launch_status();  // (a launch the runtime refused: MASP_LAUNCH, util.h)
 }
 
 

@@ -9,7 +9,8 @@ namespace masp {
 
 // ---- geometry of a level (host side; the device works with the exact counts of D / Q) -----------------------------------
 // E_ub: upper bound of a proof's digit-list length.  Points of level L <= E / 2^L + nb, pairs <= E / 2^(L+1) + nb / 2 + 1.
-static inline uint32_t tree_points_ub(uint64_t E_ub, uint32_t nb, uint32_t L) { return (uint32_t)((E_ub >> L) + nb + 1); }
+// (even: the planes keep points of even and odd index in separate halves, device/msm_tree.cuh)
+static inline uint32_t tree_points_ub(uint64_t E_ub, uint32_t nb, uint32_t L) { return (uint32_t)(((E_ub >> L) + nb + 2) & ~(uint64_t)1); }
 static inline uint32_t tree_pairs_ub(uint64_t E_ub, uint32_t nb, uint32_t L) { return (uint32_t)((E_ub >> (L + 1)) + nb / 2 + 1); }
 // lanes per proof of the two passes: ~MSM_TREE_KP pairs per lane, whole workgroups
 // G2 kernels that run over lane pairs (Fp2PairOps, field.cuh: half an Fp2 per lane, two waves per SIMD where the Fp2Ops form
@@ -38,6 +39,7 @@ int MsmTreeWs<O>::reserve(uint64_t E_ub, uint32_t nb, uint32_t q, uint32_t T) {
     const size_t lanes = (size_t)q * NT0;
     // pre[(j q + p) NT + t], j < ceil(pairs / NT) <= KP (+1 for the rounding of NT): bounded by level 0
     const size_t pres = (size_t)((tree_pairs_ub(E_ub, nb, 0) + NT0 - 1) / NT0) * lanes;
+    pre_cap = pres;
     const size_t pts1 = (size_t)q * tree_points_ub(E_ub, nb, 1), pts2 = T >= 2 ? (size_t)q * tree_points_ub(E_ub, nb, 2) : 0;
     const size_t m1 = (lanes + BINV_C - 1) / BINV_C;
     // carve: every view 256-byte aligned
@@ -80,13 +82,13 @@ void MsmTreeWs<O>::batch_invert(hipStream_t s, const F* in, uint32_t n, F* out) 
     constexpr uint32_t LN = OI::LANES;
     if (n <= 4 * BINV_MID) {
         const uint32_t M = std::min<uint32_t>(n, BINV_MID);
-        hipLaunchKernelGGL((k_binv_mid<OI>), dim3((M * LN + 63) / 64), dim3(64), 0, s, (const FI*)in, n, M, (FI*)bpre, (FI*)out);
+        MASP_LAUNCH((k_binv_mid<OI>), dim3((M * LN + 63) / 64), dim3(64), 0, s, (const FI*)in, n, M, (FI*)bpre, (FI*)out);
         return;
     }
     const uint32_t M1 = (n + BINV_C - 1) / BINV_C, M2 = std::min<uint32_t>(M1, BINV_MID);
-    hipLaunchKernelGGL((k_binv_fwd<OI>), dim3((M1 * LN + 255) / 256), dim3(256), 0, s, (const FI*)in, n, M1, (FI*)bpre, (FI*)btot);
-    hipLaunchKernelGGL((k_binv_mid<OI>), dim3((M2 * LN + 63) / 64), dim3(64), 0, s, (const FI*)btot, M1, M2, (FI*)bpre2, (FI*)bitot);
-    hipLaunchKernelGGL((k_binv_bwd<OI>), dim3((M1 * LN + 255) / 256), dim3(256), 0, s, (const FI*)in, n, M1, (const FI*)bpre, (const FI*)bitot, (FI*)out);
+    MASP_LAUNCH((k_binv_fwd<OI>), dim3((M1 * LN + 255) / 256), dim3(256), 0, s, (const FI*)in, n, M1, (FI*)bpre, (FI*)btot);
+    MASP_LAUNCH((k_binv_mid<OI>), dim3((M2 * LN + 63) / 64), dim3(64), 0, s, (const FI*)btot, M1, M2, (FI*)bpre2, (FI*)bitot);
+    MASP_LAUNCH((k_binv_bwd<OI>), dim3((M1 * LN + 255) / 256), dim3(256), 0, s, (const FI*)in, n, M1, (const FI*)bpre, (const FI*)bitot, (FI*)out);
 }
 
 // T levels of pairwise affine additions over the digit lists of proofs [p0, p0 + q) of the sort `sb`.  Afterwards the points of
@@ -111,7 +113,7 @@ int msm_tree_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSortBu
     const size_t ent_stride = E_ub;
     const uint32_t* sorted = sb.sorted + (size_t)p0 * ent_stride;
     const uint32_t* start = sb.start + (size_t)p0 * (nb + 1);
-    hipLaunchKernelGGL(k_tree_plan, dim3(T + 1, q), dim3(1024), 0, s, start, nb, tw.D, tw.Q);
+    MASP_LAUNCH(k_tree_plan, dim3(T + 1, q), dim3(1024), 0, s, start, nb, tw.D, tw.Q);
     const size_t lvl = (size_t)q * (nb + 1);
     const size_t rec_stride = tree_pairs_ub(E_ub, nb, 1);
     for (uint32_t L = 0; L < T; ++L) {
@@ -124,33 +126,38 @@ int msm_tree_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSortBu
         typedef typename TreeLaneOps<O, 2>::type O1;
         typedef typename O1::T F1;
         const dim3 grid1(NT * O1::LANES / 256, q);
+        // `pre` is a plane of tw.pre_cap curve elements (device/msm_tree.cuh): its capacity in the kernels' element types
+        const size_t pre_cap1 = tw.pre_cap * sizeof(F) / sizeof(F1);
+        const uint32_t out_whole = L + 1 == T;  // the last level's points as whole elements: what k_msm_accumulate_pts reads
         // level 0: the "records" are the digit list itself, two entries at a time (runs of even length: pair q = entries 2q, 2q + 1)
         const void* recL = L >= sb.pad_log ? (const void*)tw.rec : nullptr;  // levels >= 1: records, or none below pad_log
         const void* rec0 = (const void*)sorted;
         const size_t rec0_stride = ent_stride / 2;
         if (L == 0) {
-            hipLaunchKernelGGL((k_tree_pass1<O1, true>), grid1, block, 0, s, B.tab, (const F1*)xi, (const F1*)yi, si, rec0, rec0_stride, Ql, nb, NT,
-                               (F1*)tw.pre, (F1*)tw.tp);
+            MASP_LAUNCH((k_tree_pass1<O1, true>), grid1, block, 0, s, B.tab, (const F1*)xi, (const F1*)yi, si, rec0, rec0_stride, Ql, nb, NT,
+                               (F1*)tw.pre, pre_cap1, (F1*)tw.tp);
         } else {
             // (a level below the sort's pad_log has runs of even lengths only: no records, no odd points to copy)
-            if (L >= sb.pad_log) hipLaunchKernelGGL(k_tree_records, rgrid, block, 0, s, Dl, Dn, Ql, nb, tw.rec, rec_stride);
-            hipLaunchKernelGGL((k_tree_pass1<O1, false>), grid1, block, 0, s, B.tab, (const F1*)xi, (const F1*)yi, si, recL, rec_stride, Ql, nb,
-                               NT, (F1*)tw.pre, (F1*)tw.tp);
+            if (L >= sb.pad_log) MASP_LAUNCH(k_tree_records, rgrid, block, 0, s, Dl, Dn, Ql, nb, tw.rec, rec_stride);
+            MASP_LAUNCH((k_tree_pass1<O1, false>), grid1, block, 0, s, B.tab, (const F1*)xi, (const F1*)yi, si, recL, rec_stride, Ql, nb,
+                               NT, (F1*)tw.pre, pre_cap1, (F1*)tw.tp);
         }
         tw.batch_invert(s, tw.tp, q * NT, tw.tinv);
         typedef typename TreeLaneOps<O, 1>::type O2;
         typedef typename O2::T F2;
         const dim3 grid2(NT * O2::LANES / 256, q);
+        const size_t pre_cap2 = tw.pre_cap * sizeof(F) / sizeof(F2);
         if (L == 0)
-            hipLaunchKernelGGL((k_tree_pass2<O2, true>), grid2, block, 0, s, B.tab, (const F2*)xi, (const F2*)yi, si, rec0, rec0_stride, Ql, nb, NT,
-                               (const F2*)tw.pre, (const F2*)tw.tinv, (F2*)xo, (F2*)yo, so);
+            MASP_LAUNCH((k_tree_pass2<O2, true>), grid2, block, 0, s, B.tab, (const F2*)xi, (const F2*)yi, si, rec0, rec0_stride, Ql, nb, NT,
+                               (const F2*)tw.pre, pre_cap2, (const F2*)tw.tinv, (F2*)xo, (F2*)yo, so, out_whole);
         else
-            hipLaunchKernelGGL((k_tree_pass2<O2, false>), grid2, block, 0, s, B.tab, (const F2*)xi, (const F2*)yi, si, recL, rec_stride, Ql,
-                               nb, NT, (const F2*)tw.pre, (const F2*)tw.tinv, (F2*)xo, (F2*)yo, so);
+            MASP_LAUNCH((k_tree_pass2<O2, false>), grid2, block, 0, s, B.tab, (const F2*)xi, (const F2*)yi, si, recL, rec_stride, Ql,
+                               nb, NT, (const F2*)tw.pre, pre_cap2, (const F2*)tw.tinv, (F2*)xo, (F2*)yo, so, out_whole);
         // (level 0 has no odd runs: a run of odd length met its padding entry as P + infinity)
-        if (L >= sb.pad_log) hipLaunchKernelGGL((k_tree_copy<O, false>), cgrid, block, 0, s, B.tab, sorted, ent_stride, xi, yi, si, Dl, Dn, nb, xo, yo, so);
+        if (L >= sb.pad_log)
+            MASP_LAUNCH((k_tree_copy<O, false>), cgrid, block, 0, s, B.tab, sorted, ent_stride, xi, yi, si, Dl, Dn, nb, xo, yo, so, out_whole);
     }
-    return MASP_HIP_OK;
+    return launch_status();
 }
 
 template <class O>
@@ -158,7 +165,7 @@ void msm_launch_accumulate_pts(hipStream_t s, const typename O::T* xs, const typ
                                uint32_t nchunks, Xyzz<O>* part, uint32_t np) {
     typedef typename TreeLaneOps<O, 8>::type OA;
     typedef typename OA::T FA;
-    hipLaunchKernelGGL((k_msm_accumulate_pts<OA>), dim3((nchunks * OA::LANES + 63) / 64, np), dim3(64), 0, s, (const FA*)xs, (const FA*)ys, pt_stride, start,
+    MASP_LAUNCH((k_msm_accumulate_pts<OA>), dim3((nchunks * OA::LANES + 63) / 64, np), dim3(64), 0, s, (const FA*)xs, (const FA*)ys, pt_stride, start,
                        nb, nchunks, part);
 }
 

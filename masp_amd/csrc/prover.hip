@@ -826,6 +826,9 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
         owned.push_back({si, gi});
     }
     while (!owned.empty()) slot_release(ctx, retire_oldest());
+    // a launch the runtime refused on this thread (MASP_LAUNCH keeps the first: kernel, file:line, HIP's text)
+    const int launch_rc = launch_status();
+    if (launch_rc && result == MASP_HIP_OK) result = fail_shared(ctx, launch_rc);
     if (hipGetLastError() != hipSuccess && result == MASP_HIP_OK) {
         last_hip_error() = "kernel launch failed";
         result = fail_shared(ctx, MASP_HIP_E_HIP);

@@ -16,6 +16,26 @@ inline std::string& last_hip_error() {
     static thread_local std::string s;
     return s;
 }
+// hipLaunchKernelGGL reports nothing itself: a launch that the runtime refuses (dynamic LDS above the device's limit, a block
+// too large, an invalid grid) would only show at the next synchronisation, or as wrong bytes.  MASP_LAUNCH asks hipGetLastError()
+// after every launch and keeps the FIRST failure of this host thread here (kernel, file:line, HIP's text); launch_status() hands
+// it to the caller as MASP_HIP_E_HIP + masp_hip_last_error() and clears it.
+inline std::string& launch_error() {
+    static thread_local std::string s;
+    return s;
+}
+inline void note_launch_error(hipError_t e, const char* kernel, const char* file, int line) {
+    if (!launch_error().empty()) return;
+    char b[640];
+    snprintf(b, sizeof(b), "%s:%d: launch of %s -> %s", file, line, kernel, hipGetErrorString(e));
+    launch_error() = b;
+}
+inline int launch_status() {
+    if (launch_error().empty()) return MASP_HIP_OK;
+    last_hip_error() = launch_error();
+    launch_error().clear();
+    return MASP_HIP_E_HIP;
+}
 // hipFuncSetAttribute applies to the CURRENT device: a process that proves on several GPUs (masp_hip_ctx_create_multi, one
 // host thread per device) has to raise a kernel's dynamic-LDS limit on each of them.  One instance per call site; `f` runs
 // once per device and its verdict is remembered.
@@ -36,6 +56,13 @@ struct PerDeviceOnce {
     }
 };
 }  // namespace masp
+
+#define MASP_LAUNCH(kernel, grid, block, shmem, stream, ...)                                \
+    do {                                                                                    \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                \
+        const hipError_t _le = hipGetLastError();                                           \
+        if (_le != hipSuccess) masp::note_launch_error(_le, #kernel, __FILE__, __LINE__);   \
+    } while (0)
 
 #define HIP_TRY(expr)                                                                                     \
     do {                                                                                                  \

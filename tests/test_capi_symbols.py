@@ -46,3 +46,21 @@ def test_libmasp_host_exports():
     for n in ("masp_host_circuit_setup", "masp_host_spend_assignment", "masp_host_output_assignment", "masp_host_convert_assignment",
               "masp_host_vk_prepare", "masp_host_vk_verify", "masp_host_pedersen_hash", "masp_host_generator"):
         assert hasattr(lib, n), n
+
+
+def _dynamic_symbols(lib):
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "masp_amd", lib)], text=True)
+    return [line.split()[-1] for line in out.splitlines() if line.strip()]
+
+
+def test_libraries_export_nothing_but_their_c_abi():
+    """The ABI surface is the header, not whatever the compiler happened to emit: linked with version scripts
+    (masp_amd/csrc/exports_*.map), `nm -D --defined-only` lists the entry points only."""
+    hip = _dynamic_symbols("libmasp_hip.so")
+    assert hip and all(s.startswith("masp_hip_") for s in hip), [s for s in hip if not s.startswith("masp_hip_")][:10]
+    hdr = open(os.path.join(ROOT, "include", "masp_hip.h")).read()
+    declared = set(re.findall(r"\b(masp_hip_[a-z0-9_]+)\s*\(", hdr))
+    assert set(hip) == declared, (sorted(set(hip) - declared), sorted(declared - set(hip)))
+    host = _dynamic_symbols("libmasp_host.so")
+    assert host and all(s.startswith("masp_host_") for s in host), [s for s in host if not s.startswith("masp_host_")][:10]

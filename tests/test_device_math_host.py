@@ -56,6 +56,30 @@ def test_field_ops(mh):
             assert op(7, a) == (pow(a, -1, mod) if a else 0)
 
 
+@pytest.mark.gpu
+def test_field_ops_on_the_device(mh):
+    """The DEVICE overloads of add / sub / neg / dbl / the conditional subtraction behind every product are hand-written carry
+    chains (field.cuh) that the host build never compiles: the same operations on the GPU, against python integers — the
+    edge values against each other (sums and differences that land exactly on 0, p - 1, p, 2p - 2) and random pairs."""
+    rng = random.Random(11)
+    for which, mod, nb in ((0, P, 48), (1, R, 32)):
+        edge = [0, 1, 2, mod - 1, mod - 2, (mod - 1) // 2, (mod + 1) // 2, 0xffffffff, 1 << 32, (1 << 32) - 1, 1 << 64, (1 << 96) - 1,
+                (1 << (8 * nb - 8)) % mod, mod - (1 << 32), mod - (1 << 64) + 1, (1 << (mod.bit_length() - 1)), (1 << (mod.bit_length() - 1)) - 1]
+        pairs = [(a, b) for a in edge for b in edge] + [(a, mod - a) for a in edge if a] + \
+                [(rng.randrange(mod), rng.randrange(mod)) for _ in range(4000)]
+        n = len(pairs)
+        A = b"".join(a.to_bytes(nb, "little") for a, _ in pairs)
+        B = b"".join(b.to_bytes(nb, "little") for _, b in pairs)
+        out = C.create_string_buffer(nb * n)
+        want = {0: lambda a, b: (a + b) % mod, 1: lambda a, b: (a - b) % mod, 2: lambda a, b: a * b % mod, 4: lambda a, b: (-a) % mod,
+                5: lambda a, b: a * a % mod, 8: lambda a, b: 2 * a % mod}
+        for op, f in want.items():
+            assert mh.mh_field_ops_gpu(which, op, A, B, out, n) == 0
+            got = [int.from_bytes(out.raw[nb * i:nb * (i + 1)], "little") for i in range(n)]
+            bad = [i for i in range(n) if got[i] != f(*pairs[i])]
+            assert not bad, (which, op, hex(pairs[bad[0]][0]), hex(pairs[bad[0]][1]), hex(got[bad[0]]))
+
+
 def _le(x):
     return np.frombuffer(x.to_bytes(32, "little"), np.uint8)
 

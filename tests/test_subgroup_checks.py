@@ -106,6 +106,16 @@ def test_host_verifier_refuses_points_outside_the_subgroups():
         assert not vk.verify(enc + proof[48:], pub)
         assert not vk.verify(proof[:144] + enc, pub)
     assert not vk.verify(proof[:48] + bytes([0xe0]) + bytes(95) + proof[144:], pub)
+    # a CLEAN encoding of the point at infinity (0xc0 || zeros) in any of the three positions: bellman's Proof::read refuses the
+    # identity after decompression ("point at infinity"), so such bytes are never a proof — single and batched
+    for bad in _with_infinity(proof):
+        assert not vk.verify(bad, pub)
+        assert not vk.verify_batch([proof, bad], [pub] * 2)
+
+
+def _with_infinity(proof):
+    inf1, inf2 = bytes([0xc0]) + bytes(47), bytes([0xc0]) + bytes(95)
+    return [inf1 + proof[48:], proof[:48] + inf2 + proof[144:], proof[:144] + inf1, inf1 + inf2 + inf1]
 
 
 @pytest.mark.gpu
@@ -123,6 +133,9 @@ def test_gpu_batch_verifier_refuses_points_outside_the_subgroups():
             assert not gvk.verify_batch([enc + proof[48:]], [pub])
             assert not gvk.verify_batch([proof[:144] + enc], [pub])
         assert not gvk.verify_batch([proof[:48] + bytes([0xe0]) + bytes(95) + proof[144:]], [pub])
+        for bad in _with_infinity(proof):                 # clean infinity encodings are refused like by Proof::read
+            assert not gvk.verify_batch([bad], [pub])
+            assert not gvk.verify_batch([proof, bad, proof], [pub] * 3)
         assert gvk.verify_batch([proof] * 2, [pub] * 2)
         gvk.close()
     finally:

@@ -12,10 +12,10 @@ rm -rf $out; mkdir -p $out
 [ -x $root/tools/_build/pmc_calib ] || { mkdir -p $root/tools/_build; /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $root/tools/pmc_calib.hip -o $root/tools/_build/pmc_calib; }
 (cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/calib -o run -- $root/tools/_build/pmc_calib > $out/calib.log 2>&1)
 for c in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/$c -o run -- python $root/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $out/$c.log 2>&1)
+  (cd /tmp && rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/$c -o run -- python $root/bench.py --steps ${PMC_STEPS:-4} --warmup 1 --no-cpu-baseline > $out/$c.log 2>&1)
 done
 python - <<PY
-import csv, glob, json, os
+import csv, glob, json, os, re
 out = "$out"
 def rows_of(d, counter):
     f = glob.glob("%s/%s/**/*counter_collection.csv" % (out, d), recursive=True)[0]
@@ -49,8 +49,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             # (k_msm_accumulate<G1> itself only runs for lone proofs now: gridDim.y = 1, excluded)
             if k in r["Kernel_Name"] and not ("k_msm_accumulate<masp::FpOps" in k and int(r["Grid_Size"]) < 64 * 3072):
                 tot += float(r["Counter_Value"])
-                per_kernel.setdefault(k.split("<")[0], {}).setdefault(c, 0.0)
-                per_kernel[k.split("<")[0]][c] += float(r["Counter_Value"])
+                kk = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("masp::", "")   # template arguments kept: level 0 / deeper levels apart
+                per_kernel.setdefault(kk, {}).setdefault(c, 0.0)
+                per_kernel[kk][c] += float(r["Counter_Value"])
     res[c] = (tot / max(msms, 1), msms)
 fetch_kb, n1 = res["FETCH_SIZE"]; write_kb, n2 = res["WRITE_SIZE"]
 for k in per_kernel:
@@ -76,7 +77,6 @@ doc = {
  "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (fetch_kb * 1024.0 * factor + write_kb * 1024.0) / alg,
  "note": "one 'launch' = the bucket accumulation of one G1 MSM (h+l merged, a, or b_g1) of a batch of %d proofs; counters summed over the stage's kernels and averaged over the three MSMs. Traffic exceeds the algorithmic bytes (n x 128 B per proof) because (1) every non-zero window digit reads its own 128-byte table row (16 rows per full-width scalar of h and l, 22 per non-trivial scalar of a / b_g1) - the HBM-capacity-for-ALU trade of DESIGN.md - and (2) the shared-inversion tree reads every point of a level twice (denominators, then additions) and keeps 48 bytes per pair in between: memory traffic bought to save 40 %% of the field products. WRITE_SIZE is uncalibrated." % batch,
 }
-json.dump(doc, open("$root/profiles/pmc_traffic.json", "w"), indent=1)
+json.dump(doc, open("$root/gpurun_out/${PMC_OUT:-pmc_traffic}.json", "w"), indent=1)   # gpurun only merges gpurun_out/ back: copy it into profiles/ afterwards
 print(json.dumps(doc, indent=1))
 PY
-cp $root/profiles/pmc_traffic.json $root/gpurun_out/pmc_traffic.json   # gpurun only merges gpurun_out/ back: copy it into profiles/ afterwards
