@@ -114,11 +114,11 @@ def main_in_library(args):
     vk = ctx.prepare_verifying_key(params)
     threads = H.effective_cpus()
     W.instances(kind, 2, first_seed=10 ** 6, threads=2)
-    insts = W.instances(kind, N * n, first_seed=0, threads=threads, alloc=lambda kk: ctx.host_alloc(cs.n_aux, 32))
+    insts = W.instances(kind, N * n, first_seed=0, threads=threads, montgomery=True, alloc=lambda kk: ctx.host_alloc(cs.n_aux, 32))
     rng = random.Random(0x5962be3d)
 
     def jobs_for_step():
-        return [(0, i, a, rng.randrange(R).to_bytes(32, "little"), rng.randrange(R).to_bytes(32, "little")) for i, a in insts]
+        return [(0, i, a, rng.randrange(R).to_bytes(32, "little"), rng.randrange(R).to_bytes(32, "little"), None, 1) for i, a in insts]
 
     # (set-up + warm-up: two rounds of `slots` concurrent calls, so that every slot of every device has its scratch at its final size)
     warm = [ctx.marshal_jobs(jobs_for_step()) for _ in range(max(Wm, 2 * SLOTS))]
@@ -250,7 +250,9 @@ def main():
     syn = {}
     job_kind = [kinds[j % len(kinds)] for j in range(n)]
     t_syn = time.perf_counter()
-    per = {k: W.instances(k, job_kind.count(k), first_seed=100000 * rank, threads=threads, timing=syn,
+    # (aux as Montgomery residues — the in-memory form of blst_fr, masp_hip_job::aux_form = 1: the synthesizer writes straight into
+    # the page-locked buffer; host.GROUP witnesses per native call, their Merkle blocks side by side)
+    per = {k: W.instances(k, job_kind.count(k), first_seed=100000 * rank, threads=threads, timing=syn, montgomery=True,
                           alloc=lambda kk: ctx.host_alloc(cs[kk].n_aux, 32)) for k in kinds}
     synth_wall = time.perf_counter() - t_syn
     it = {k: iter(per[k]) for k in kinds}
@@ -265,7 +267,7 @@ def main():
         return np.frombuffer(bytes(b), np.uint8).reshape(steps, n, 64)
 
     def jobs_with(rs_step):
-        return [(KINDS.index(k), i, a, bytes(rs_step[j, :32]), bytes(rs_step[j, 32:])) for j, (k, (i, a)) in enumerate(zip(job_kind, insts))]
+        return [(KINDS.index(k), i, a, bytes(rs_step[j, :32]), bytes(rs_step[j, 32:]), None, 1) for j, (k, (i, a)) in enumerate(zip(job_kind, insts))]
 
     rs_warm, rs_a, rs_b = fresh_rs(max(Wm, 1)), fresh_rs(K), fresh_rs(K)
     handle, _ = ctx.batch_upload(jobs_with(rs_a[0]))
@@ -364,7 +366,7 @@ def main():
         import oracle_lib as O
         for got_, rs_, st, j in ((out_b, rs_b, 0, 0), (out_b, rs_b, K - 1, n - 1), (proofs_a, rs_a, K // 2, n // 2), (proofs_a, rs_a, 0, 1)):
             kind = job_kind[j]
-            want = O.closed_form_proof(cs[kind], synthetic.toxic_waste(1 + KINDS.index(kind)), insts[j][0], insts[j][1],
+            want = O.closed_form_proof(cs[kind], synthetic.toxic_waste(1 + KINDS.index(kind)), insts[j][0], H.aux_from_montgomery(insts[j][1]),
                                        int.from_bytes(rs_[st, j, :32].tobytes(), "little"), int.from_bytes(rs_[st, j, 32:].tobytes(), "little"))
             if got_[st, j].tobytes() != want:
                 sys.exit("bench.py: timed proof (step %d, job %d) differs from the oracle's closed form — no figure reported" % (st, j))
@@ -373,7 +375,8 @@ def main():
     # ---- end to end (not part of `value`): LocalTxProver.prove_batch over E2E_N Spend descriptions per GPU — synthesis on this
     # rank's share of the host cores, page-locked buffers, H2D, GPU batches, GPU batch self-verification (sapling/prover.rs:148)
     e2e = None
-    base_instance = (per[kinds[0]][0][0].copy(), per[kinds[0]][0][1].copy())      # (the aux buffers are page-locked memory of `ctx`: gone once it closes)
+    # (the aux buffers are page-locked memory of `ctx`: gone once it closes; the checker wants canonical values)
+    base_instance = (per[kinds[0]][0][0].copy(), H.aux_from_montgomery(per[kinds[0]][0][1]))
     e2e_n = int(os.environ.get("MASP_BENCH_E2E", "1024"))
     if WORKLOAD == "spend" and e2e_n > 0:
         for k_ in vk.values():

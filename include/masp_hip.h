@@ -76,7 +76,9 @@ typedef struct {
                                   u64 limbs — the IN-MEMORY form of blst_fr / bls12_381::Scalar: a binding can hand
                                   over the Vec<Scalar> of its recording constraint system without converting 100 000 elements per
                                   Spend (libmasp_host does: 16 % of its synthesis time).  inputs, a, b, c, r, s stay canonical. */
-    uint32_t reserved;
+    uint32_t reserved;         /* must be 0 (MASP_HIP_E_INVALID_ARG otherwise).  ABI note: aux_form and reserved were appended in round 3
+                                  (sizeof 88 -> 96 on LP64); the struct carries no size field, so a binding built against the older
+                                  header must be rebuilt — INTEGRATION.md "ABI revisions" */
 } masp_hip_job;
 #define MASP_HIP_AUX_CANONICAL 0
 #define MASP_HIP_AUX_MONTGOMERY 1
@@ -101,7 +103,13 @@ typedef struct {
                                         (default 4, fewer for very short bucket runs); -1 = none (XYZZ accumulation only) */
     int32_t bucket_tree_sub_batch;   /* proofs that go through the tree at a time (default 64; its scratch is ~0.4 GB per Spend proof) */
     int32_t bucket_tree_levels_g2;   /* the same for the G2 MSM if it should differ (default: bucket_tree_levels) */
-    int32_t reserved[4];
+    int32_t bucket_tree_scratch_mb;  /* upper bound of the tree's scratch per slot in MiB (default 0: whatever the device gives).  If the
+                                        scratch of a sub-batch does not fit — this bound, or the device is out of memory — the sub-batch
+                                        is halved (down to 8 proofs), then the rest of the batch goes through the XYZZ accumulation: same
+                                        bytes, fewer proofs per second, never an error */
+    int32_t bucket_tree_fallback_proofs; /* OUTPUT of masp_hip_ctx_get_options (ignored on input): proofs whose bucket runs went through
+                                        the XYZZ accumulation for lack of tree scratch; bucket_tree_sub_batch there = the sub-batch in use now */
+    int32_t reserved[2];
 } masp_hip_options;
 void masp_hip_options_default(masp_hip_options* opt);
 
@@ -120,6 +128,9 @@ int masp_hip_ctx_get_options(const masp_hip_ctx* ctx, masp_hip_options* out);
 int masp_hip_ctx_create_multi(const int* devices, int n_devices, masp_hip_ctx** out);
 /* number of device contexts behind `ctx` (1 for masp_hip_ctx_create) */
 int masp_hip_ctx_device_count(const masp_hip_ctx* ctx);
+/* counts[d] = proofs written so far by device context d (d < min(cap, masp_hip_ctx_device_count)): lets a caller (and the
+ * configs[4] test) see that a multi-device prover really deals its batches to all of its devices */
+int masp_hip_ctx_device_proofs(const masp_hip_ctx* ctx, uint64_t* counts, int cap);
 void masp_hip_ctx_destroy(masp_hip_ctx* ctx);
 const char* masp_hip_strerror(int code);
 /* last HIP runtime error text seen by this context ("" if none); the pointer belongs to the calling thread and stays

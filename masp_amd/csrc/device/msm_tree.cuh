@@ -48,6 +48,13 @@ namespace masp {
 #ifndef MASP_TREE_SLICED
 #define MASP_TREE_SLICED 1
 #endif
+// 1: pass 1 leaves, per pair, (numerator of the slope) x (product of the denominators before the pair) instead of the running
+// product alone: pass 2 — the kernel that saturates the multiplier — gets the slope with ONE product instead of two, and pass 1,
+// which waits for memory three quarters of its time, does the other one (it then reads the y coordinates too: at level 0 they
+// lie in the 128-byte row it gathers anyway).  0: the round-3 form (A/B builds).
+#ifndef MASP_TREE_QNUM
+#define MASP_TREE_QNUM 1
+#endif
 __device__ __forceinline__ Fp plane_ld_fp(const uint4* __restrict__ b, size_t cap, size_t u) {
     const uint4 a = b[u], c = b[cap + u], d = b[2 * cap + u];
     Fp r;
@@ -273,6 +280,18 @@ struct TreeSrc {
             y2 = plane_ld(ys, cap, slot(r.x + 1));
         }
     }
+    __device__ __forceinline__ void load_y1_raw(const Rec& r, F& y1) const {
+        if constexpr (L0)
+            y1 = row_y(r.x);
+        else
+            y1 = plane_ld(ys, cap, slot(r.x));
+    }
+    __device__ __forceinline__ void load_y2_raw(const Rec& r, F& y2) const {
+        if constexpr (L0)
+            y2 = row_y(r.y);
+        else
+            y2 = plane_ld(ys, cap, slot(r.x + 1));
+    }
     // ... and the signs of the digits applied (level 0; the padding entry stays (0, 0): -0 = 0)
     // (word-wise selects of an unconditional negation: as `if (sign) y = -y` the compiler built two exec-masked blocks of ~190
     // instructions each around the 36 of the negation — 8 % of the instructions of level 0's additions pass)
@@ -291,6 +310,12 @@ struct TreeSrc {
             y1 = neg_if(y1, r.x);
             y2 = neg_if(y2, r.y);
         }
+    }
+    static __device__ __forceinline__ void fix_y1(const Rec& r, F& y1) {
+        if constexpr (L0) y1 = neg_if(y1, r.x);
+    }
+    static __device__ __forceinline__ void fix_y2(const Rec& r, F& y2) {
+        if constexpr (L0) y2 = neg_if(y2, r.y);
     }
     __device__ __forceinline__ void load_y(const Rec& r, F& y1, F& y2) const {
         load_y_raw(r, y1, y2);
@@ -326,6 +351,53 @@ k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
     src.tab = tab;
     src.set(xs, ys, p, np, pt_stride);
     F chain = O::one();
+#if MASP_TREE_QNUM
+    // two-stage software pipeline: the record of pair j + 2 and the operands of pair j + 1 are requested before pair j is
+    // multiplied in — an operand is two dependent loads away (record, then row / point) and nothing else hides that
+    struct Ops {
+        F x1, y1, x2, y2;
+    };
+    auto fetch = [&](const Rec& r, Ops& o) {
+        src.load_x(r, o.x1, o.x2);
+        src.load_y_raw(r, o.y1, o.y2);
+    };
+    Rec ra{}, rb{};
+    Ops nxt{O::zero(), O::zero(), O::zero(), O::zero()};
+    if (t < P) {
+        ra = rec_at(t);
+        if (t + NT < P) rb = rec_at(t + NT);
+        fetch(ra, nxt);
+    }
+    // (gfx9 counts loads and stores in ONE counter and stores may complete out of order, so a wait for loaded data drains every
+    // store issued before it: what pair j leaves is therefore stored at the top of iteration j + 1, right after that
+    // iteration's wait and before its loads — by the next wait it has had a whole iteration to complete)
+    F hq = O::zero();
+    uint32_t j = 0;
+    for (uint32_t q = t; q < P; q += NT, ++j) {
+        const Rec cr = ra;
+        Ops c = nxt;
+        if (j) plane_st(pre, pre_cap, src.at(((size_t)(j - 1) * np + p) * NT + t), hq);
+        ra = rb;
+        if (q + NT < P) fetch(ra, nxt);
+        if (q + 2 * (uint64_t)NT < P) rb = rec_at(q + 2 * NT);
+        TreeSrc<O, L0>::fix_y(cr, c.y1, c.y2);
+        F d = O::sub(c.x2, c.x1), n = O::sub(c.y2, c.y1);
+        if (O::is_zero(c.x1) || O::is_zero(c.x2) || O::is_zero(d)) {  // rare
+            const int kind = tree_classify<O>(c.x1, c.y1, c.x2, c.y2, d);
+            if (kind == TREE_DBL) {
+                const F s2 = O::sqr(c.x1);
+                n = O::add(O::dbl(s2), s2);  // the slope of the tangent: 3 x^2 over 2 y (tree_classify left d = 2 y)
+            } else if (kind > TREE_DBL) {
+                d = O::one();  // nothing is divided here, and pass 2 does not read this pair's numerator
+                n = O::one();
+            }
+        }
+        hq = O::mul(n, chain);    // numerator x (denominators before this pair): pass 2 multiplies by 1 / (denominators up to this pair)
+        chain = O::mul(chain, d);
+    }
+    if (j) plane_st(pre, pre_cap, src.at(((size_t)(j - 1) * np + p) * NT + t), hq);
+    tp[src.at((size_t)p * NT + t)] = chain;
+#else
     // two-stage software pipeline: the record of pair j + 2 and the operands of pair j + 1 are requested before pair j is
     // multiplied in — an operand is two dependent loads away (record, then row / point) and nothing else hides that
     Rec ra{}, rb{};
@@ -356,6 +428,7 @@ k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
     }
     if (j) plane_st(pre, pre_cap, src.at(((size_t)(j - 1) * np + p) * NT + t), chain);
     tp[src.at((size_t)p * NT + t)] = chain;
+#endif
 }
 
 // ---- pass 2: the additions --------------------------------------------------------------------------------------------
@@ -395,6 +468,70 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         }
     };
     F I = tinv[src.at((size_t)p * NT + t)];
+#if MASP_TREE_QNUM
+    // two-stage software pipeline, backwards: the record of pair j - 2 and the operands of pair j - 1 are requested before pair
+    // j is computed (see pass 1).  y2 is only read where a pair is exceptional: its slope's numerator came with `pre`.
+    struct Ops {
+        F x1, y1, x2;
+    };
+    auto fetch = [&](const Rec& r, Ops& o) {
+        src.load_x(r, o.x1, o.x2);
+        src.load_y1_raw(r, o.y1);
+    };
+    uint32_t j = (P - 1 - t) / NT;
+    Rec ra = rec_at(t + j * NT), rb{};
+    if (j) rb = rec_at(t + (j - 1) * NT);
+    Ops nxt;
+    fetch(ra, nxt);
+    // (the result of a pair is stored at the top of the NEXT iteration, after that iteration's wait for its operands and before
+    // its loads: see pass 1 — a store in flight would otherwise be drained by the wait)
+    F hx = O::zero(), hy = O::zero();
+    uint32_t hout = 0;
+    bool held = false;
+    for (;; --j) {
+        Ops c = nxt;
+        const Rec cr = ra;
+        ra = rb;
+        if (held) put(hout, hx, hy);
+        const F qn = plane_ld(pre, pre_cap, src.at(((size_t)j * np + p) * NT + t));
+        if (j) fetch(ra, nxt);
+        if (j > 1) rb = rec_at(t + (j - 2) * NT);
+        const uint32_t out = TreeSrc<O, L0>::out_index(cr, t + j * NT);
+        TreeSrc<O, L0>::fix_y1(cr, c.y1);
+        F d = O::sub(c.x2, c.x1);
+        int kind = TREE_ADD;
+        F y2 = O::zero();
+        if (O::is_zero(c.x1) || O::is_zero(c.x2) || O::is_zero(d)) {  // rare
+            src.load_y2_raw(cr, y2);
+            TreeSrc<O, L0>::fix_y2(cr, y2);
+            kind = tree_classify<O>(c.x1, c.y1, c.x2, y2, d);
+        }
+        F x3, y3;
+        if (kind <= TREE_DBL) {
+            const F Inext = O::mul(I, d);
+            const F lam = O::mul(I, qn);  // (numerator x denominators before this pair) / (denominators up to this pair)
+            I = Inext;
+            const F xx = kind == TREE_ADD ? c.x2 : c.x1;
+            x3 = O::sub(O::sub(O::sqr(lam), c.x1), xx);
+            y3 = O::sub(O::mul(lam, O::sub(c.x1, x3)), c.y1);
+        } else if (kind == TREE_FIRST) {
+            x3 = c.x1;
+            y3 = c.y1;
+        } else if (kind == TREE_SECOND) {
+            x3 = c.x2;
+            y3 = y2;
+        } else {
+            x3 = O::zero();
+            y3 = O::zero();
+        }
+        hx = x3;
+        hy = y3;
+        hout = out;
+        held = true;
+        if (!j) break;
+    }
+    put(hout, hx, hy);
+#else
     // two-stage software pipeline, backwards: the record of pair j - 2 and the operands of pair j - 1 are requested before pair
     // j is computed (see pass 1)
     struct Ops {
@@ -460,6 +597,7 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         if (!j) break;
     }
     put(hout, hx, hy);
+#endif
 }
 
 // the last point of a bucket with an odd number of points goes to the next level as it is.  grid (nb / 256, np)

@@ -434,6 +434,193 @@ inline AllocatedNum merkle_ascend(CS& cs, AllocatedNum cur, const MerklePathW& p
     }
     return cur;
 }
+// ---- the Merkle block of B witnesses in lockstep (proving mode only) ---------------------------------------------------
+// merkle_ascend is 60 % of a Spend's (90 % of a Convert's) synthesis time: 32 Pedersen hashes of 172 windows, every window an
+// affine Montgomery addition whose slope needs a field inversion that the circuit allocates.  One witness alone has only three
+// independent chains of additions (the hash's segments), so its inversions were amortised by running each chain natively in
+// extended Edwards coordinates first (7 products per step), normalising, and deriving the slopes from that: ~17 products and a
+// dozen small heap allocations per window.  B witnesses side by side have 3 B independent chains: the additions are done
+// directly in the affine Montgomery form the circuit wants, ONE inversion per window index for all of them (Montgomery's trick:
+// 3 products per element), 3 more for slope, x', y' — ~6.5 products per window — and every value goes straight into the
+// assignment in the order the gadgets would have allocated it (tests/test_host_fast_merkle.py compares the two paths byte for
+// byte: same variables, same values, same constraint count).
+// cs[b]: witness b's constraint system (witness mode, not recording); cur[b]: in the leaf (cm.u), out the root, both as allocated
+// numbers; pos_bits[b] (may be null): receives the 32 position bits.  Returns false if a denominator vanished somewhere (never
+// for honest inputs: the caller then runs the generic gadgets, which raise the reference's DivisionByZero).
+inline bool fr_batch_invert(Fr* v, size_t n, Fr* scratch) {  // v[i] <- 1 / v[i]; false (v untouched) if any is zero
+    if (n == 0) return true;
+    scratch[0] = v[0];
+    for (size_t i = 1; i < n; ++i) scratch[i] = scratch[i - 1] * v[i];
+    Fr inv;
+    if (!scratch[n - 1].invert(inv)) return false;
+    for (size_t i = n; i-- > 1;) {
+        const Fr t = inv * scratch[i - 1];
+        inv = inv * v[i];
+        v[i] = t;
+    }
+    v[0] = inv;
+    return true;
+}
+inline bool merkle_block_batch(size_t B, CS* const* cs, AllocatedNum* cur, const MerklePathW* const* paths, std::vector<Boolean>* const* pos_bits) {
+    constexpr int NBITS = 6 + 255 + 255, NWIN = NBITS / 3, NSEG = 3;
+    static_assert(NBITS % 3 == 0, "whole windows");
+    const auto& gens = tables().pedersen;
+    int seg_first[NSEG + 1];
+    {
+        int w0 = 0;
+        for (int s = 0; s < NSEG; ++s) {
+            seg_first[s] = w0;
+            w0 += (int)std::min<size_t>(gens.at(s).size(), (size_t)(NWIN - w0));
+        }
+        seg_first[NSEG] = w0;
+        if (w0 != NWIN) return false;
+    }
+    const int max_len = std::max(std::max(seg_first[1] - seg_first[0], seg_first[2] - seg_first[1]), seg_first[3] - seg_first[2]);
+    struct Level {  // what one witness allocates at one level, in computation order
+        Fr left, right;
+        uint8_t bits[NBITS];
+        Fr y[NWIN];                          // the looked-up ordinate of every window (sign applied)
+        Fr lam[NWIN], xp[NWIN], yp[NWIN];    // the addition that folds window w (w > first of its segment) into the segment's sum
+        Fr u[NSEG], v[NSEG];                 // the segments' sums on the Edwards form
+        Fr ed[NSEG][6];                      // uu, a, b, c, u3, v3 of the addition that folds segment s >= 1 into the result
+    };
+    std::vector<Level> lv(B);
+    std::vector<Fr> accx(B * NSEG), accy(B * NSEG), den(B * NSEG), scratch(B * NSEG), wx(B * NSEG);
+    std::vector<Fr> value(B);
+    for (size_t b = 0; b < B; ++b) value[b] = cur[b].value;
+    const Fr one = Fr::one(), A = montgomery_a(), scale = montgomery_scale(), D = edwards_d();
+    for (int depth = 0; depth < TREE_DEPTH; ++depth) {
+        // ---- bits and table entries
+        for (size_t b = 0; b < B; ++b) {
+            Level& L = lv[b];
+            const auto& node = paths[b]->auth_path.at(depth);
+            L.left = node.second ? node.first : value[b];
+            L.right = node.second ? value[b] : node.first;
+            for (int i = 0; i < 6; ++i) L.bits[i] = (depth >> i) & 1;
+            uint8_t le[32];
+            L.left.to_bytes(le);
+            for (int i = 0; i < 255; ++i) L.bits[6 + i] = (le[i / 8] >> (i % 8)) & 1;
+            L.right.to_bytes(le);
+            for (int i = 0; i < 255; ++i) L.bits[261 + i] = (le[i / 8] >> (i % 8)) & 1;
+        }
+        // ---- the three chains of every witness, one window index at a time
+        for (int k = 0; k < max_len; ++k) {
+            size_t m = 0;
+            for (size_t b = 0; b < B; ++b) {
+                Level& L = lv[b];
+                for (int s = 0; s < NSEG; ++s) {
+                    const int w = seg_first[s] + k;
+                    if (w >= seg_first[s + 1]) continue;
+                    const uint8_t* c = L.bits + 3 * w;
+                    const Coord& e = gens[s][k][c[0] + 2 * c[1]];
+                    L.y[w] = c[2] ? e.second.neg() : e.second;
+                    if (k == 0) {
+                        accx[b * NSEG + s] = e.first;
+                        accy[b * NSEG + s] = L.y[w];
+                    } else {
+                        wx[m] = e.first;
+                        den[m++] = accx[b * NSEG + s] - e.first;   // (o.x - x) of MontgomeryPoint::add: o = the sum so far
+                    }
+                }
+            }
+            if (k == 0) continue;
+            if (!fr_batch_invert(den.data(), m, scratch.data())) return false;
+            m = 0;
+            for (size_t b = 0; b < B; ++b) {
+                Level& L = lv[b];
+                for (int s = 0; s < NSEG; ++s) {
+                    const int w = seg_first[s] + k;
+                    if (w >= seg_first[s + 1]) continue;
+                    Fr &ax = accx[b * NSEG + s], &ay = accy[b * NSEG + s];
+                    const Fr& x = wx[m];
+                    const Fr lam = (ay - L.y[w]) * den[m];
+                    const Fr xp = lam.square() - A - x - ax;
+                    const Fr yp = ((xp - x) * lam + L.y[w]).neg();
+                    L.lam[w] = lam;
+                    L.xp[w] = xp;
+                    L.yp[w] = yp;
+                    ax = xp;
+                    ay = yp;
+                    ++m;
+                }
+            }
+        }
+        // ---- into_edwards: u = scale x / y, v = (x - 1) / (x + 1), both from 1 / (y (x + 1))
+        for (size_t i = 0; i < B * NSEG; ++i) den[i] = accy[i] * (accx[i] + one);
+        if (!fr_batch_invert(den.data(), B * NSEG, scratch.data())) return false;
+        for (size_t b = 0; b < B; ++b)
+            for (int s = 0; s < NSEG; ++s) {
+                const size_t i = b * NSEG + s;
+                const Fr x1 = accx[i] + one;
+                lv[b].u[s] = accx[i] * scale * (den[i] * x1);
+                lv[b].v[s] = (accx[i] - one) * (den[i] * accy[i]);
+            }
+        // ---- the two Edwards additions: this = segment s, o = the result so far
+        std::vector<Fr> ru(B), rv(B);
+        for (size_t b = 0; b < B; ++b) {
+            ru[b] = lv[b].u[0];
+            rv[b] = lv[b].v[0];
+        }
+        for (int s = 1; s < NSEG; ++s) {
+            for (size_t b = 0; b < B; ++b) {
+                Fr* e = lv[b].ed[s];
+                const Fr &u = lv[b].u[s], &v = lv[b].v[s];
+                e[0] = (u + v) * (ru[b] + rv[b]);
+                e[1] = rv[b] * u;
+                e[2] = ru[b] * v;
+                e[3] = e[1] * e[2] * D;
+                den[2 * b] = one + e[3];
+                den[2 * b + 1] = one - e[3];
+            }
+            if (!fr_batch_invert(den.data(), 2 * B, scratch.data())) return false;
+            for (size_t b = 0; b < B; ++b) {
+                Fr* e = lv[b].ed[s];
+                e[4] = (e[1] + e[2]) * den[2 * b];
+                e[5] = (e[0] - e[1] - e[2]) * den[2 * b + 1];
+                ru[b] = e[4];
+                rv[b] = e[5];
+            }
+        }
+        // ---- the level's variables, in the gadgets' order (merkle_ascend, pedersen_hash_gadget)
+        for (size_t b = 0; b < B; ++b) {
+            CS& c = *cs[b];
+            const Level& L = lv[b];
+            const auto& node = paths[b]->auth_path.at(depth);
+            const AllocatedBit right{c.alloc_bit(node.second), node.second};
+            if (pos_bits && pos_bits[b]) pos_bits[b]->push_back(Boolean::from(right));
+            c.alloc(node.first);
+            c.alloc(L.left);
+            c.alloc(L.right);
+            for (int i = 6; i < NBITS; ++i) c.alloc_bit(L.bits[i]);
+            Var last = 0;
+            for (int s = 0; s < NSEG; ++s) {
+                for (int w = seg_first[s]; w < seg_first[s + 1]; ++w) {
+                    c.alloc(L.y[w]);
+                    if (3 * w >= 6) c.alloc_bit(L.bits[3 * w] && L.bits[3 * w + 1]);  // (the first two windows are the constant personalisation bits)
+                    if (w > seg_first[s]) {
+                        c.alloc(L.lam[w]);
+                        c.alloc(L.xp[w]);
+                        c.alloc(L.yp[w]);
+                    }
+                }
+                last = c.alloc(L.u[s]);
+                c.alloc(L.v[s]);
+                if (s >= 1) {
+                    for (int q = 0; q < 4; ++q) c.alloc(L.ed[s][q]);
+                    last = c.alloc(L.ed[s][4]);
+                    c.alloc(L.ed[s][5]);
+                }
+            }
+            // constraints: bit 1, reverse 2, two unpackings 2 x 256, per window 1 lookup (+ 1 for its AND bit), 3 per addition,
+            // 2 per into_edwards, 6 per Edwards addition
+            c.count_constraints(1 + 2 + 512 + NWIN + (NWIN - 2) + 3 * (NWIN - NSEG) + 2 * NSEG + 6 * (NSEG - 1));
+            value[b] = ru[b];
+            cur[b] = AllocatedNum{last, ru[b]};
+        }
+    }
+    return true;
+}
+
 inline void conditional_anchor(CS& cs, const AllocatedNum& cur, const Num& value_num, const Fr& anchor) {
     AllocatedNum rt = AllocatedNum::alloc(cs, anchor);
     // (cur - rt) * value = 0
@@ -441,8 +628,14 @@ inline void conditional_anchor(CS& cs, const AllocatedNum& cur, const Num& value
     rt.inputize(cs);
 }
 
-// circuit/sapling.rs:139-417
-inline void synthesize_spend(CS& cs, const SpendW& w) {
+// circuit/sapling.rs:139-417, in three parts so that the Merkle block of several witnesses can run in lockstep
+struct SpendState {
+    EdwardsPoint cm;
+    Num value_num = Num::zero();
+    std::vector<Boolean> nf_preimage, position_bits;
+    AllocatedNum cur;
+};
+inline void synthesize_spend_pre(CS& cs, const SpendW& w, SpendState& st) {
     EdwardsPoint ak = EdwardsPoint::witness(cs, w.ak);
     ak.assert_not_small_order(cs);
     {
@@ -493,9 +686,17 @@ inline void synthesize_spend(CS& cs, const SpendW& w) {
         EdwardsPoint rcmp = fixed_base_multiplication(cs, tables().note_commitment_randomness, rcm);
         cm = cm.add(cs, rcmp);
     }
-    std::vector<Boolean> position_bits;
-    AllocatedNum cur = merkle_ascend(cs, cm.u, w.path, &position_bits);
-    conditional_anchor(cs, cur, value_num, w.anchor);
+    st.cm = cm;
+    st.value_num = value_num;
+    st.nf_preimage = nf_preimage;
+    st.cur = cm.u;
+}
+// ... then the Merkle path from st.cur (merkle_ascend, or merkle_block_batch for several witnesses at once) ...
+inline void synthesize_spend_post(CS& cs, const SpendW& w, SpendState& st) {
+    const EdwardsPoint& cm = st.cm;
+    std::vector<Boolean>& nf_preimage = st.nf_preimage;
+    const std::vector<Boolean>& position_bits = st.position_bits;
+    conditional_anchor(cs, st.cur, st.value_num, w.anchor);
     EdwardsPoint rho = cm;
     {
         EdwardsPoint position = fixed_base_multiplication(cs, tables().nullifier_position, position_bits);
@@ -507,6 +708,12 @@ inline void synthesize_spend(CS& cs, const SpendW& w) {
     }
     std::vector<Boolean> nf = blake2s_gadget(cs, nf_preimage, "MASP__nf");
     pack_into_inputs(cs, nf);
+}
+inline void synthesize_spend(CS& cs, const SpendW& w) {
+    SpendState st;
+    synthesize_spend_pre(cs, w, st);
+    st.cur = merkle_ascend(cs, st.cur, w.path, &st.position_bits);
+    synthesize_spend_post(cs, w, st);
 }
 
 // circuit/sapling.rs:419-596
@@ -548,8 +755,12 @@ inline void synthesize_output(CS& cs, const OutputW& w) {
     cm.u.inputize(cs);
 }
 
-// circuit/convert.rs:29-128
-inline void synthesize_convert(CS& cs, const ConvertW& w) {
+// circuit/convert.rs:29-128 (in three parts like the Spend circuit)
+struct ConvertState {
+    Num value_num = Num::zero();
+    AllocatedNum cur;
+};
+inline void synthesize_convert_pre(CS& cs, const ConvertW& w, ConvertState& st) {
     Num value_num = Num::zero();
     std::vector<Boolean> asset_generator_bits, value_bits;
     expose_value_commitment(cs, w.vc, asset_generator_bits, value_bits);
@@ -561,8 +772,15 @@ inline void synthesize_convert(CS& cs, const ConvertW& w) {
         }
     }
     EdwardsPoint cm = pedersen_hash_gadget(cs, {true, 0}, asset_generator_bits);
-    AllocatedNum cur = merkle_ascend(cs, cm.u, w.path, nullptr);
-    conditional_anchor(cs, cur, value_num, w.anchor);
+    st.value_num = value_num;
+    st.cur = cm.u;
+}
+inline void synthesize_convert_post(CS& cs, const ConvertW& w, ConvertState& st) { conditional_anchor(cs, st.cur, st.value_num, w.anchor); }
+inline void synthesize_convert(CS& cs, const ConvertW& w) {
+    ConvertState st;
+    synthesize_convert_pre(cs, w, st);
+    st.cur = merkle_ascend(cs, st.cur, w.path, nullptr);
+    synthesize_convert_post(cs, w, st);
 }
 
 }  // namespace masp_host

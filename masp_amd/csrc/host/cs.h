@@ -12,7 +12,10 @@
 //                                                 on the GPU from the static R1CS)
 //   record = true,  witness = true  : testing  -> is_satisfied()
 #pragma once
+#include <array>
+#include <cstring>
 #include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -38,54 +41,88 @@ static const Var ONE = 0;
             (CS_).count_constraint();              \
     } while (0)
 
+// Linear combinations exist to be recorded: while no constraint system of this thread records (proving mode), building one is
+// a no-op — the gadgets' `Num`s carry their LC along, which cost ~17 000 small heap allocations per Spend for nothing.
+inline int& lc_recording_depth() {
+    static thread_local int d = 0;
+    return d;
+}
 struct LC {
     std::vector<std::pair<Var, Fr>> t;
+    static bool on() { return lc_recording_depth() > 0; }
     LC() {}
-    LC(Var v) { t.push_back({v, Fr::one()}); }
+    LC(Var v) {
+        if (on()) t.push_back({v, Fr::one()});
+    }
     LC& add(Var v, const Fr& c) {
-        t.push_back({v, c});
+        if (on()) t.push_back({v, c});
         return *this;
     }
     LC& add(Var v) { return add(v, Fr::one()); }
     LC& sub(Var v) { return add(v, Fr::one().neg()); }
     LC& add(const LC& o) {
-        t.insert(t.end(), o.t.begin(), o.t.end());
+        if (on()) t.insert(t.end(), o.t.begin(), o.t.end());
         return *this;
     }
     LC& sub(const LC& o) {
-        for (auto& x : o.t) t.push_back({x.first, x.second.neg()});
+        if (on())
+            for (auto& x : o.t) t.push_back({x.first, x.second.neg()});
         return *this;
     }
     LC scaled(const Fr& k) const {
         LC r;
-        for (auto& x : t) r.t.push_back({x.first, x.second * k});
+        if (on())
+            for (auto& x : t) r.t.push_back({x.first, x.second * k});
         return r;
     }
 };
 
 class CS {
   public:
-    CS(bool record, bool witness) : record_(record), witness_(witness) {
+    // ext / ext_cap: where the auxiliary assignment goes, if the caller wants it in place (Fr is the Montgomery residue as four
+    // little-endian u64 limbs: masp_hip_job::aux_form = MASP_HIP_AUX_MONTGOMERY reads exactly this memory — no 4 MB vector per
+    // witness, no copy at the end); otherwise the object owns its storage
+    CS(bool record, bool witness, Fr* ext = nullptr, size_t ext_cap = 0) : record_(record), witness_(witness) {
         inputs_.push_back(Fr::one());  // ONE
-        if (witness) aux_.reserve(1u << 17);  // the largest circuit (Spend) has 100 497 auxiliary variables
+        if (ext) {
+            aux_p_ = ext;
+            aux_cap_ = ext_cap;
+        } else if (witness) {
+            grow(1u << 17);  // the largest circuit (Spend) has 100 497 auxiliary variables
+        }
+        ext_ = ext != nullptr;
+        if (record_) ++lc_recording_depth();
     }
+    ~CS() {
+        if (record_) --lc_recording_depth();
+    }
+    CS(const CS&) = delete;
+    CS& operator=(const CS&) = delete;
     bool has_witness() const { return witness_; }
     bool recording() const { return record_; }
 
     Var alloc(const Fr& value) {
-        aux_.push_back(value);
-        return AUX | (Var)(aux_.size() - 1);
+        if (aux_n_ == aux_cap_) grow(aux_cap_ ? 2 * aux_cap_ : 1024);
+        aux_p_[aux_n_] = value;
+        return AUX | (Var)(aux_n_++);
     }
     Var alloc_bit(bool value) {
         static const Fr bit[2] = {Fr::zero(), Fr::one()};
-        aux_.push_back(bit[value]);
-        return AUX | (Var)(aux_.size() - 1);
+        if (aux_n_ == aux_cap_) grow(aux_cap_ ? 2 * aux_cap_ : 1024);
+        aux_p_[aux_n_] = bit[value];
+        return AUX | (Var)(aux_n_++);
     }
     Var alloc_input(const Fr& value) {
         inputs_.push_back(value);
         return (Var)(inputs_.size() - 1);
     }
     void count_constraint() { ++n_constraints_; }
+    void count_constraints(size_t k) { n_constraints_ += k; }
+    // proving mode: forget the auxiliary variables from index `n` on (a block that is to be redone another way; the constraint
+    // count is left alone: nothing reads it in proving mode)
+    void truncate_aux(size_t n) {
+        if (n < aux_n_) aux_n_ = n;
+    }  // proving mode: a block whose constraints nobody records (merkle_block_batch)
     void enforce(const LC& a, const LC& b, const LC& c) {
         ++n_constraints_;
         if (!record_) return;
@@ -93,17 +130,18 @@ class CS {
         push_row(1, b);
         push_row(2, c);
     }
-    Fr value(Var v) const { return (v & AUX) ? aux_[v & ~AUX] : inputs_[v]; }
+    Fr value(Var v) const { return (v & AUX) ? aux_p_[v & ~AUX] : inputs_[v]; }
     Fr eval(const LC& lc) const {
         Fr acc = Fr::zero();
         for (auto& x : lc.t) acc = acc + x.second * value(x.first);
         return acc;
     }
     size_t num_inputs() const { return inputs_.size(); }
-    size_t num_aux() const { return aux_.size(); }
+    size_t num_aux() const { return aux_n_; }
+    bool aux_in_place() const { return ext_; }
     size_t num_constraints() const { return n_constraints_; }
     const std::vector<Fr>& inputs() const { return inputs_; }
-    const std::vector<Fr>& aux() const { return aux_; }
+    const Fr* aux() const { return aux_p_; }
 
     // merged, zero-free rows (inputs first, then aux, ascending) — the form hashed by TestConstraintSystem and
     // the form whose pattern equals bellperson's density trackers
@@ -137,7 +175,7 @@ class CS {
             h.update(b, 8);
         };
         put64(inputs_.size());
-        put64(aux_.size());
+        put64(aux_n_);
         put64(n_constraints_);
         for (size_t r = 0; r + 1 < m_[0].rowptr.size(); ++r)
             for (int i = 0; i < 3; ++i) {
@@ -185,7 +223,19 @@ class CS {
         M.rowptr.push_back((uint32_t)M.col.size());
     }
     bool record_, witness_;
-    std::vector<Fr> inputs_, aux_;
+    std::vector<Fr> inputs_;
+    std::unique_ptr<Fr[]> own_;   // (not a vector: its resize would clear 4 MB per witness for nothing)
+    Fr* aux_p_ = nullptr;
+    size_t aux_n_ = 0, aux_cap_ = 0;
+    bool ext_ = false;
+    void grow(size_t cap) {
+        if (ext_) throw SynthesisError("auxiliary assignment larger than the caller's buffer");
+        std::unique_ptr<Fr[]> bigger(new Fr[cap]);
+        if (aux_n_) memcpy(bigger.get(), aux_p_, sizeof(Fr) * aux_n_);
+        own_ = std::move(bigger);
+        aux_p_ = own_.get();
+        aux_cap_ = cap;
+    }
     size_t n_constraints_ = 0;
     Matrix m_[3];
 };
@@ -306,6 +356,7 @@ inline std::vector<Boolean> u64_into_boolean_vec_le(CS& cs, uint64_t value) {
 // circuit/gadgets.rs:6-50 (252 bits for jubjub::Fr, 255 for bls12_381::Scalar)
 inline std::vector<Boolean> bits_into_boolean_vec_le(CS& cs, const uint8_t* le32, int nbits) {
     std::vector<Boolean> out;
+    out.reserve(nbits);
     for (int i = 0; i < nbits; ++i) out.push_back(Boolean::from(AllocatedBit::alloc(cs, (le32[i / 8] >> (i % 8)) & 1)));
     return out;
 }
@@ -532,35 +583,36 @@ struct MultiEq {
 };
 
 struct UInt32 {
-    std::vector<Boolean> bits;  // LSB first, 32
+    std::array<Boolean, 32> bits;  // LSB first (a fixed array: the BLAKE2s gadget builds ~2 000 of these per compression)
     uint32_t value;
     static UInt32 constant(uint32_t v) {
         UInt32 r;
         r.value = v;
-        for (int i = 0; i < 32; ++i) r.bits.push_back(Boolean::constant((v >> i) & 1));
+        for (int i = 0; i < 32; ++i) r.bits[i] = Boolean::constant((v >> i) & 1);
         return r;
     }
     static UInt32 from_bits(const std::vector<Boolean>& b) {
         UInt32 r;
-        r.bits = b;
         r.value = 0;
-        for (int i = 0; i < 32; ++i)
+        for (int i = 0; i < 32; ++i) {
+            r.bits[i] = b[i];
             if (b[i].value()) r.value |= 1u << i;
+        }
         return r;
     }
     UInt32 rotr(int by) const {
         UInt32 r;
-        for (int i = 0; i < 32; ++i) r.bits.push_back(bits[(i + by) % 32]);
+        for (int i = 0; i < 32; ++i) r.bits[i] = bits[(i + by) % 32];
         r.value = (value >> by) | (value << (32 - by));
         return r;
     }
     UInt32 xor_(CS& cs, const UInt32& o) const {
         UInt32 r;
         r.value = value ^ o.value;
-        for (int i = 0; i < 32; ++i) r.bits.push_back(Boolean::xor_(cs, bits[i], o.bits[i]));
+        for (int i = 0; i < 32; ++i) r.bits[i] = Boolean::xor_(cs, bits[i], o.bits[i]);
         return r;
     }
-    static UInt32 addmany(MultiEq& me, const std::vector<const UInt32*>& ops) {
+    static UInt32 addmany(MultiEq& me, std::initializer_list<const UInt32*> ops) {
         uint64_t max_value = (uint64_t)ops.size() * 0xffffffffull;
         uint64_t result_value = 0;
         const bool record = me.cs.recording();
@@ -584,14 +636,13 @@ struct UInt32 {
         LC result_lc;
         Fr coeff = Fr::one();
         int i = 0;
-        r.bits.reserve(35);
-        while (max_value != 0) {
+        while (max_value != 0) {   // (the bits above 31 are allocated too: they carry the overflow of the sum)
             AllocatedBit b = AllocatedBit::alloc(me.cs, (result_value >> i) & 1);
             if (record) {
                 result_lc.add(b.var, coeff);
                 coeff = coeff.dbl();
             }
-            r.bits.push_back(Boolean::from(b));
+            if (i < 32) r.bits[i] = Boolean::from(b);
             max_value >>= 1;
             ++i;
         }
@@ -599,7 +650,6 @@ struct UInt32 {
             me.enforce_equal(i, lc, result_lc);
         else
             me.count_equal(i);
-        r.bits.resize(32);
         return r;
     }
 };

@@ -27,7 +27,7 @@ void write_assignment(const CS& cs, uint8_t* inputs, uint8_t* aux, bool aux_mont
     for (size_t i = 0; i < cs.num_inputs(); ++i) cs.inputs()[i].to_bytes(inputs + 32 * i);
     if (aux_montgomery) {
         static_assert(sizeof(Fr) == 32, "Fr is four 64-bit Montgomery limbs");
-        memcpy(aux, cs.aux().data(), 32 * cs.num_aux());
+        if (!cs.aux_in_place()) memcpy(aux, cs.aux(), 32 * cs.num_aux());   // (in place: the constraint system wrote into `aux` itself)
         return;
     }
     // 70 % of a MASP witness is 0 or 1 (booleans): no Montgomery conversion needed for those
@@ -57,6 +57,37 @@ bool jubjub_scalar_canonical(const uint8_t s[32]) {
     }
     return false;  // equal to the order
 }
+// auxiliary variables of circuit `kind` (0 spend, 1 output, 2 convert): the size of the caller's aux buffer
+size_t aux_count(int kind) {
+    static const size_t n[3] = {[] {
+                                    CS cs(false, false);
+                                    SpendW w{};
+                                    w.vc.asset_generator = w.ak = w.g_d = w.pk_d = JPoint::identity();
+                                    synthesize_spend(cs, w);
+                                    return cs.num_aux();
+                                }(),
+                                [] {
+                                    CS cs(false, false);
+                                    OutputW w{};
+                                    w.vc.asset_generator = w.g_d = w.pk_d = JPoint::identity();
+                                    synthesize_output(cs, w);
+                                    return cs.num_aux();
+                                }(),
+                                [] {
+                                    CS cs(false, false);
+                                    ConvertW w{};
+                                    w.vc.asset_generator = JPoint::identity();
+                                    synthesize_convert(cs, w);
+                                    return cs.num_aux();
+                                }()};
+    return n[kind];
+}
+// the constraint system of one witness: straight into the caller's aux buffer when that is to hold Montgomery residues (check & 2)
+// and nothing is recorded
+CS* new_witness_cs(int kind, int check, uint8_t* aux) {
+    if ((check & 2) && !(check & 1) && ((uintptr_t)aux % alignof(Fr)) == 0) return new CS(false, true, reinterpret_cast<Fr*>(aux), aux_count(kind));
+    return new CS((check & 1) != 0, true);
+}
 bool load_path(MerklePathW& p, const uint8_t* siblings, uint64_t position) {
     for (int i = 0; i < TREE_DEPTH; ++i) {
         Fr s;
@@ -66,6 +97,15 @@ bool load_path(MerklePathW& p, const uint8_t* siblings, uint64_t position) {
     return true;
 }
 }  // namespace
+
+#ifdef MASP_HOST_TIMING
+#include <chrono>
+#define TIMING_T0 auto _t = std::chrono::steady_clock::now(); static double _acc[8]; static const char* _nm[8]; static int _calls; int _k = 0;
+#define TIMING_MARK(NAME) { auto _n = std::chrono::steady_clock::now(); int _i = 0; for (; _i < 8 && _nm[_i] && strcmp(_nm[_i], NAME); ++_i); _nm[_i] = NAME; _acc[_i] += std::chrono::duration<double, std::milli>(_n - _t).count(); _t = _n; }
+#else
+#define TIMING_T0
+#define TIMING_MARK(NAME)
+#endif
 
 extern "C" {
 
@@ -157,7 +197,8 @@ int masp_host_spend_assignment(const uint8_t ak[32], const uint8_t nsk[32], cons
         cv.to_bytes(cv_out);
         rk.to_bytes(rk_out);
         nullifier(nf_out, cm, position, nk);
-        CS cs((check & 1) != 0, true);
+        std::unique_ptr<CS> cs_owner(new_witness_cs(0, check, aux));
+        CS& cs = *cs_owner;
         synthesize_spend(cs, w);
         if ((check & 1) && cs.first_unsatisfied() >= 0) return MASP_HOST_E_UNSATISFIED;
         write_assignment(cs, inputs, aux, (check & 2) != 0);
@@ -181,7 +222,8 @@ int masp_host_output_assignment(const uint8_t esk[32], const uint8_t diversifier
         memcpy(w.rcm, rcm, 32);
         memcpy(w.esk, esk, 32);
         value_commitment(w.vc.asset_generator, value, rcv).to_bytes(cv_out);
-        CS cs((check & 1) != 0, true);
+        std::unique_ptr<CS> cs_owner(new_witness_cs(1, check, aux));
+        CS& cs = *cs_owner;
         synthesize_output(cs, w);
         if ((check & 1) && cs.first_unsatisfied() >= 0) return MASP_HOST_E_UNSATISFIED;
         write_assignment(cs, inputs, aux, (check & 2) != 0);
@@ -202,7 +244,8 @@ int masp_host_convert_assignment(const uint8_t generator[32], uint64_t value, co
         memcpy(w.vc.randomness, rcv, 32);
         if (!Fr::from_bytes(w.anchor, anchor) || !load_path(w.path, path_siblings, position)) return MASP_HOST_E_INVALID;
         value_commitment(w.vc.asset_generator, value, rcv).to_bytes(cv_out);
-        CS cs((check & 1) != 0, true);
+        std::unique_ptr<CS> cs_owner(new_witness_cs(2, check, aux));
+        CS& cs = *cs_owner;
         synthesize_convert(cs, w);
         if ((check & 1) && cs.first_unsatisfied() >= 0) return MASP_HOST_E_UNSATISFIED;
         write_assignment(cs, inputs, aux, (check & 2) != 0);
@@ -210,6 +253,237 @@ int masp_host_convert_assignment(const uint8_t generator[32], uint64_t value, co
     } catch (const SynthesisError&) {
         return MASP_HOST_E_SYNTHESIS;
     }
+}
+
+// n field elements as Montgomery residues (four little-endian u64 limbs: what `check & 2` makes the synthesizers write) ->
+// 32-byte little-endian canonical values.  For callers that need both forms of an assignment (a checker next to the prover).
+void masp_host_fr_from_montgomery(const uint8_t* in, uint8_t* out, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        Fr v;
+        memcpy(v.l, in + 32 * i, 32);
+        v.to_bytes(out + 32 * i);
+    }
+}
+
+// ---- several witnesses per call: the Merkle blocks in lockstep (circuits.h merkle_block_batch) -------------------------
+// One job = the arguments of masp_host_spend_assignment / masp_host_convert_assignment plus its return code.  `check` as there
+// (check & 1 records and verifies the constraints: that goes witness by witness through the generic gadgets).  Returns the number
+// of jobs whose rc is not MASP_HOST_OK.  A caller gives each of its threads a group of ~16 jobs.
+struct masp_host_spend_job {
+    const uint8_t *ak, *nsk, *diversifier, *rcm, *ar, *asset_identifier;
+    uint64_t value;
+    const uint8_t *anchor, *path_siblings;
+    uint64_t position;
+    const uint8_t* rcv;
+    uint8_t *inputs, *aux, *cv_out, *rk_out, *nf_out;
+    int rc;
+};
+struct masp_host_convert_job {
+    const uint8_t* generator;
+    uint64_t value;
+    const uint8_t *anchor, *path_siblings;
+    uint64_t position;
+    const uint8_t* rcv;
+    uint8_t *inputs, *aux, *cv_out;
+    int rc;
+};
+int masp_host_spend_assignments(size_t n, masp_host_spend_job* jobs, int check) {
+    if (check & 1) {
+        int bad = 0;
+        for (size_t j = 0; j < n; ++j) {
+            masp_host_spend_job& J = jobs[j];
+            J.rc = masp_host_spend_assignment(J.ak, J.nsk, J.diversifier, J.rcm, J.ar, J.asset_identifier, J.value, J.anchor, J.path_siblings, J.position,
+                                              J.rcv, check, J.inputs, J.aux, J.cv_out, J.rk_out, J.nf_out);
+            bad += J.rc != MASP_HOST_OK;
+        }
+        return bad;
+    }
+    std::vector<SpendW> w(n);
+    std::vector<std::unique_ptr<CS>> cs(n);
+    std::vector<SpendState> st(n);
+    std::vector<size_t> live;
+    TIMING_T0
+    for (size_t j = 0; j < n; ++j) {
+        masp_host_spend_job& J = jobs[j];
+        J.rc = MASP_HOST_OK;
+        try {
+            SpendW& W = w[j];
+            if (!jubjub_scalar_canonical(J.nsk) || !jubjub_scalar_canonical(J.rcm) || !jubjub_scalar_canonical(J.ar) || !jubjub_scalar_canonical(J.rcv) ||
+                !asset_generator(W.vc.asset_generator, J.asset_identifier) || !JPoint::from_bytes(W.ak, J.ak)) {
+                J.rc = MASP_HOST_E_INVALID;
+                continue;
+            }
+            W.vc.value = J.value;
+            memcpy(W.vc.randomness, J.rcv, 32);
+            memcpy(W.nsk, J.nsk, 32);
+            memcpy(W.rcm, J.rcm, 32);
+            memcpy(W.ar, J.ar, 32);
+            if (!Fr::from_bytes(W.anchor, J.anchor) || !load_path(W.path, J.path_siblings, J.position)) {
+                J.rc = MASP_HOST_E_INVALID;
+                continue;
+            }
+            JPoint nk = generators().proof_generation_key.mul(J.nsk);
+            uint8_t ivk[32];
+            crh_ivk(ivk, W.ak, nk);
+            if (!group_hash(W.g_d, J.diversifier, 11, "MASP__gd")) {
+                J.rc = MASP_HOST_E_DIVERSIFIER;
+                continue;
+            }
+            W.pk_d = W.g_d.mul(ivk);
+            JPoint cv = value_commitment(W.vc.asset_generator, J.value, J.rcv);
+            JPoint rk = W.ak.add(generators().spending_key.mul(J.ar));
+            JPoint cm = note_commitment(W.vc.asset_generator, J.value, W.g_d, W.pk_d, J.rcm);
+            cv.to_bytes(J.cv_out);
+            rk.to_bytes(J.rk_out);
+            nullifier(J.nf_out, cm, J.position, nk);
+            cs[j].reset(new_witness_cs(0, check, J.aux));
+            synthesize_spend_pre(*cs[j], W, st[j]);
+            live.push_back(j);
+        } catch (const SynthesisError&) {
+            J.rc = MASP_HOST_E_SYNTHESIS;
+        }
+    }
+    TIMING_MARK("pre")
+    // the Merkle blocks of all live witnesses side by side
+    {
+        std::vector<CS*> c;
+        std::vector<AllocatedNum> cur;
+        std::vector<const MerklePathW*> paths;
+        std::vector<std::vector<Boolean>*> pos;
+        std::vector<size_t> mark;
+        for (size_t j : live) {
+            c.push_back(cs[j].get());
+            cur.push_back(st[j].cur);
+            paths.push_back(&w[j].path);
+            pos.push_back(&st[j].position_bits);
+            mark.push_back(cs[j]->num_aux());
+        }
+        bool fast = false;
+        try {
+            fast = !live.empty() && merkle_block_batch(live.size(), c.data(), cur.data(), paths.data(), pos.data());
+        } catch (const std::exception&) {
+            fast = false;
+        }
+        for (size_t i = 0; i < live.size(); ++i) {
+            const size_t j = live[i];
+            if (fast) {
+                st[j].cur = cur[i];
+                continue;
+            }
+            try {  // a vanished denominator somewhere in the batch: every witness through the gadgets, which report it as the reference does
+                cs[j]->truncate_aux(mark[i]);
+                st[j].position_bits.clear();
+                st[j].cur = merkle_ascend(*cs[j], st[j].cur, w[j].path, &st[j].position_bits);
+            } catch (const SynthesisError&) {
+                jobs[j].rc = MASP_HOST_E_SYNTHESIS;
+            }
+        }
+    }
+    TIMING_MARK("merkle")
+    int bad = 0;
+    for (size_t j = 0; j < n; ++j) {
+        masp_host_spend_job& J = jobs[j];
+        if (J.rc == MASP_HOST_OK) {
+            try {
+                synthesize_spend_post(*cs[j], w[j], st[j]);
+                TIMING_MARK("post")
+                write_assignment(*cs[j], J.inputs, J.aux, (check & 2) != 0);
+                TIMING_MARK("write")
+            } catch (const SynthesisError&) {
+                J.rc = MASP_HOST_E_SYNTHESIS;
+            }
+        }
+        bad += J.rc != MASP_HOST_OK;
+    }
+#ifdef MASP_HOST_TIMING
+    if (++_calls % 4 == 0) { for (int i = 0; i < 8 && _nm[i]; ++i) fprintf(stderr, "%s %.3f ms/inst  ", _nm[i], _acc[i] / (_calls * n)); fprintf(stderr, "\n"); }
+#endif
+    return bad;
+}
+int masp_host_convert_assignments(size_t n, masp_host_convert_job* jobs, int check) {
+    if (check & 1) {
+        int bad = 0;
+        for (size_t j = 0; j < n; ++j) {
+            masp_host_convert_job& J = jobs[j];
+            J.rc = masp_host_convert_assignment(J.generator, J.value, J.anchor, J.path_siblings, J.position, J.rcv, check, J.inputs, J.aux, J.cv_out);
+            bad += J.rc != MASP_HOST_OK;
+        }
+        return bad;
+    }
+    std::vector<ConvertW> w(n);
+    std::vector<std::unique_ptr<CS>> cs(n);
+    std::vector<ConvertState> st(n);
+    std::vector<size_t> live;
+    for (size_t j = 0; j < n; ++j) {
+        masp_host_convert_job& J = jobs[j];
+        J.rc = MASP_HOST_OK;
+        try {
+            ConvertW& W = w[j];
+            if (!jubjub_scalar_canonical(J.rcv) || !JPoint::from_bytes(W.vc.asset_generator, J.generator)) {
+                J.rc = MASP_HOST_E_INVALID;
+                continue;
+            }
+            W.vc.value = J.value;
+            memcpy(W.vc.randomness, J.rcv, 32);
+            if (!Fr::from_bytes(W.anchor, J.anchor) || !load_path(W.path, J.path_siblings, J.position)) {
+                J.rc = MASP_HOST_E_INVALID;
+                continue;
+            }
+            value_commitment(W.vc.asset_generator, J.value, J.rcv).to_bytes(J.cv_out);
+            cs[j].reset(new_witness_cs(2, check, J.aux));
+            synthesize_convert_pre(*cs[j], W, st[j]);
+            live.push_back(j);
+        } catch (const SynthesisError&) {
+            J.rc = MASP_HOST_E_SYNTHESIS;
+        }
+    }
+    {
+        std::vector<CS*> c;
+        std::vector<AllocatedNum> cur;
+        std::vector<const MerklePathW*> paths;
+        std::vector<std::vector<Boolean>*> pos;
+        std::vector<size_t> mark;
+        for (size_t j : live) {
+            c.push_back(cs[j].get());
+            cur.push_back(st[j].cur);
+            paths.push_back(&w[j].path);
+            pos.push_back(nullptr);
+            mark.push_back(cs[j]->num_aux());
+        }
+        bool fast = false;
+        try {
+            fast = !live.empty() && merkle_block_batch(live.size(), c.data(), cur.data(), paths.data(), pos.data());
+        } catch (const std::exception&) {
+            fast = false;
+        }
+        for (size_t i = 0; i < live.size(); ++i) {
+            const size_t j = live[i];
+            if (fast) {
+                st[j].cur = cur[i];
+                continue;
+            }
+            try {
+                cs[j]->truncate_aux(mark[i]);
+                st[j].cur = merkle_ascend(*cs[j], st[j].cur, w[j].path, nullptr);
+            } catch (const SynthesisError&) {
+                jobs[j].rc = MASP_HOST_E_SYNTHESIS;
+            }
+        }
+    }
+    int bad = 0;
+    for (size_t j = 0; j < n; ++j) {
+        masp_host_convert_job& J = jobs[j];
+        if (J.rc == MASP_HOST_OK) {
+            try {
+                synthesize_convert_post(*cs[j], w[j], st[j]);
+                write_assignment(*cs[j], J.inputs, J.aux, (check & 2) != 0);
+            } catch (const SynthesisError&) {
+                J.rc = MASP_HOST_E_SYNTHESIS;
+            }
+        }
+        bad += J.rc != MASP_HOST_OK;
+    }
+    return bad;
 }
 
 // ---- Groth16 self-verification (sapling/prover.rs:148,266) ---------------------------------------------

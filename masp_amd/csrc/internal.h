@@ -19,6 +19,7 @@
 #include "device/ntt_geom.h"
 #include "launch.h"
 #include "msm_host.h"
+#include <atomic>
 #include "util.h"
 
 namespace masp {
@@ -172,6 +173,7 @@ struct Slot {
         ws1.tree_levels_shared = o.bucket_tree_levels_g2;  // B2 is reduced from B1's sort (ws1.sort): padded if either wants a tree
         ws1.tree_sub = ws2.tree_sub = (uint32_t)o.bucket_tree_sub_batch;
         ws2.tree.arena = &ws1.tree.own;   // the G1 and G2 MSMs of a batch follow each other on the slot's stream: one tree arena
+        ws1.tree.own.limit = (size_t)o.bucket_tree_scratch_mb << 20;
     }
     int init() {
         HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -254,6 +256,7 @@ struct masp_hip_ctx {
     std::vector<std::unique_ptr<Slot>> slots;
     std::vector<std::unique_ptr<ResidentBatch>> batches;
     bool profiling = false;
+    std::atomic<uint64_t> proofs_done{0};   // proofs this device context has written (masp_hip_ctx_device_proofs)
     // scratch for the building-block entry points
     DevBuf<Fr> tmp_scalars;
     DevBuf<uint8_t> tmp_out;

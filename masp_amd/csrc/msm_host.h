@@ -123,9 +123,14 @@ struct MsmSortBuf {
 // ---- scratch of the batch-affine pre-reduction (device/msm_tree.cuh) for up to q proofs at a time ---------------------
 // One byte arena serves every tree of a slot (its G1 and G2 MSMs run one after the other on the slot's stream): the views below
 // are carved out of it anew by every msm_tree_enqueue.
+// internal: the tree's scratch does not fit (device out of memory, or above masp_hip_options::bucket_tree_scratch_mb) — the caller
+// halves the sub-batch or leaves the proofs to the XYZZ accumulation (msm_reduce_enqueue); never returned through the C ABI
+static constexpr int MASP_HIP_E_TREE_SCRATCH = -100;
 struct MsmTreeArena {
     uint8_t* p = nullptr;
     size_t cap = 0;
+    size_t limit = 0;       // bytes this arena may take (0: whatever the device gives)
+    uint64_t refused = 0;   // reservations that did not fit
     ~MsmTreeArena() { release(); }
     void release() {
         if (p) hipFree(p);
@@ -134,8 +139,19 @@ struct MsmTreeArena {
     }
     int reserve(size_t bytes) {
         if (bytes <= cap) return MASP_HIP_OK;
+        if (limit && bytes > limit) {
+            ++refused;
+            return MASP_HIP_E_TREE_SCRATCH;
+        }
         release();  // (capacity is 0 from here on: a failed allocation must not leave it claiming memory)
-        HIP_TRY(hipMalloc(&p, bytes));
+        const hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipErrorOutOfMemory) {
+            (void)hipGetLastError();
+            p = nullptr;
+            ++refused;
+            return MASP_HIP_E_TREE_SCRATCH;
+        }
+        HIP_TRY(e);
         cap = bytes;
         return MASP_HIP_OK;
     }
@@ -176,8 +192,8 @@ struct MsmWorkspace {
     int tree_levels = 0;
     int tree_levels_shared = -1;  // levels of another workspace that reduces THIS workspace's sort (B2 over B1's): it is padded for both
     uint32_t tree_sub = 64;
+    uint64_t tree_fallbacks = 0;  // proofs whose bucket runs went to the XYZZ accumulation because the tree's scratch did not fit
     uint32_t* startT = nullptr;  // [np][nb + 1] bucket offsets of the points the tree leaves
-    size_t cap_startT = 0;
     size_t cap_nb = 0, cap_np = 0, cap_part = 0;  // cap_part: elements of `part` (np x (chunks + nb) of the largest launch)
     uint32_t *heavy = nullptr, *n_heavy = nullptr;
     Xyzz<O>*part = nullptr, *bkt = nullptr, *S[2] = {nullptr, nullptr}, *T = nullptr, *R[2] = {nullptr, nullptr};
@@ -189,7 +205,6 @@ struct MsmWorkspace {
         for (void* p : ptrs)
             if (p) hipFree(p);
         heavy = n_heavy = startT = nullptr;
-        cap_startT = 0;
         part = bkt = S[0] = S[1] = T = R[0] = R[1] = tsum = nullptr;
         cap_nb = cap_np = cap_part = 0;
     }

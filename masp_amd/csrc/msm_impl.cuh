@@ -99,14 +99,34 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
     const uint32_t tree_T = sb.pad_log >= 1 ? msm_tree_levels(B.n_eff, g, np, ws.tree_levels) : 0;
     const uint32_t* start = sb.start;
     if (tree_T) {
-        const uint32_t sub = std::max(1u, std::min(ws.tree_sub, np));
-        for (uint32_t p0 = 0; p0 < np; p0 += sub) {
-            const uint32_t q = std::min(sub, np - p0);
-            if ((rc = msm_tree_enqueue<O, BYTES>(s, B, sb, ws.tree, p0, q, tree_T))) return rc;
+        uint32_t sub = std::max(1u, std::min(ws.tree_sub, np));
+        for (uint32_t p0 = 0; p0 < np;) {
+            uint32_t q = std::min(sub, np - p0);
+            rc = msm_tree_enqueue<O, BYTES>(s, B, sb, ws.tree, p0, q, tree_T);
+            // the tree's scratch (~0.4 GB per Spend proof) does not fit — a smaller GPU, more slots, a second prover on the device:
+            // halve the sub-batch (and keep it so: the next batch does not try again), below 8 proofs leave the rest of the
+            // batch to the XYZZ accumulation over the digit list (it skips the padding entries)
+            while (rc == MASP_HIP_E_TREE_SCRATCH && sub > 8) {
+                sub = std::max(8u, sub / 2);
+                ws.tree_sub = sub;
+                q = std::min(sub, np - p0);
+                rc = msm_tree_enqueue<O, BYTES>(s, B, sb, ws.tree, p0, q, tree_T);
+            }
+            if (rc == MASP_HIP_E_TREE_SCRATCH) {
+                const uint32_t rest = np - p0;
+                ws.tree_fallbacks += rest;
+                msm_launch_accumulate<O>(s, B.tab, sb.sorted + (size_t)p0 * sb.ent_stride, sb.ent_stride, sb.start + (size_t)p0 * (nb + 1), nb, nchunks,
+                                         ws.part + (size_t)p0 * ((size_t)nchunks + nb), rest);
+                HIP_TRY(hipMemcpyAsync(ws.startT + (size_t)p0 * (nb + 1), sb.start + (size_t)p0 * (nb + 1), sizeof(uint32_t) * rest * (nb + 1),
+                                       hipMemcpyDeviceToDevice, s));
+                break;
+            }
+            if (rc) return rc;
             msm_launch_accumulate_pts<O>(s, ws.tree.points_x(), ws.tree.points_y(), ws.tree.point_stride(), ws.tree.plan_D(tree_T), nb, nchunks,
                                          ws.part + (size_t)p0 * ((size_t)nchunks + nb), q);
             // the bucket tails run over the whole batch: keep this sub-batch's offsets (the next one overwrites the plan)
             HIP_TRY(hipMemcpyAsync(ws.startT + (size_t)p0 * (nb + 1), ws.tree.plan_D(tree_T), sizeof(uint32_t) * q * (nb + 1), hipMemcpyDeviceToDevice, s));
+            p0 += q;
         }
         start = ws.startT;
     } else {

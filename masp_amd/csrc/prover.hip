@@ -43,6 +43,8 @@ static masp_hip_options resolve_options(const masp_hip_options* in) {
     o.bucket_tree_levels = o.bucket_tree_levels > 0 ? std::min<int>(o.bucket_tree_levels, 12) : o.bucket_tree_levels < 0 ? -1 : 0;  // resolved: 0 = automatic
     o.bucket_tree_sub_batch = o.bucket_tree_sub_batch > 0 ? std::min<int>(o.bucket_tree_sub_batch, 256) : 64;
     o.bucket_tree_levels_g2 = o.bucket_tree_levels_g2 > 0 ? std::min<int>(o.bucket_tree_levels_g2, 12) : o.bucket_tree_levels_g2 < 0 ? -1 : o.bucket_tree_levels;
+    o.bucket_tree_scratch_mb = std::max(o.bucket_tree_scratch_mb, 0);
+    o.bucket_tree_fallback_proofs = 0;   // output only
     return o;
 }
 // [0, n) cut into ceil(n / cap) groups whose sizes differ by at most one: (first, count) pairs
@@ -70,10 +72,9 @@ static int ensure_slots(masp_hip_ctx* ctx, size_t want) {
         ctx->slots.push_back(std::move(s));
         ctx->slot_busy.push_back(0);
     }
-    for (auto& sl : ctx->slots) {
-        sl->profiling = ctx->profiling;
-        sl->configure(ctx->opt);
-    }
+    // (a slot is configured once, when it is created: its options never change, and a busy slot's workspaces are read by the
+    // thread that owns it — the tree sub-batch may also have been halved there for lack of scratch)
+    for (auto& sl : ctx->slots) sl->profiling = ctx->profiling;
     return MASP_HIP_OK;
 }
 // Slot pool for concurrent provers.  try: a free slot, or a new one while fewer than ctx->n_slots exist.
@@ -442,7 +443,25 @@ int masp_hip_ctx_create_ex(const int* devices, int n_devices, const masp_hip_opt
 
 int masp_hip_ctx_get_options(const masp_hip_ctx* ctx, masp_hip_options* out) {
     if (!ctx || !out) return MASP_HIP_E_INVALID_ARG;
-    *out = ctx->opt;
+    const masp_hip_ctx* c = ctx->children.empty() ? ctx : ctx->children[0];
+    *out = c->opt;
+    // what lack of tree scratch has changed since the context was created: the smallest sub-batch any slot works with now, and
+    // the proofs whose bucket runs went through the XYZZ accumulation instead (all device contexts)
+    uint64_t fb = 0;
+    int sub = out->bucket_tree_sub_batch;
+    auto scan = [&](const masp_hip_ctx* d) {
+        std::lock_guard<std::mutex> g(d->slot_mu);
+        for (const auto& sl : d->slots) {
+            fb += sl->ws1.tree_fallbacks + sl->ws2.tree_fallbacks;
+            sub = std::min<int>(sub, (int)std::min(sl->ws1.tree_sub, sl->ws2.tree_sub));
+        }
+    };
+    if (ctx->children.empty())
+        scan(ctx);
+    else
+        for (const masp_hip_ctx* d : ctx->children) scan(d);
+    out->bucket_tree_sub_batch = sub;
+    out->bucket_tree_fallback_proofs = (int32_t)std::min<uint64_t>(fb, 0x7fffffff);
     return MASP_HIP_OK;
 }
 
@@ -469,6 +488,15 @@ int masp_hip_ctx_create_multi(const int* devices, int n_devices, masp_hip_ctx** 
     return MASP_HIP_OK;
 }
 
+int masp_hip_ctx_device_proofs(const masp_hip_ctx* ctx, uint64_t* counts, int cap) {
+    if (!ctx || !counts || cap < 0) return MASP_HIP_E_INVALID_ARG;
+    if (ctx->children.empty()) {
+        if (cap >= 1) counts[0] = ctx->proofs_done.load();
+        return MASP_HIP_OK;
+    }
+    for (size_t d = 0; d < ctx->children.size() && (int)d < cap; ++d) counts[d] = ctx->children[d]->proofs_done.load();
+    return MASP_HIP_OK;
+}
 int masp_hip_ctx_device_count(const masp_hip_ctx* ctx) { return !ctx ? 0 : ctx->children.empty() ? 1 : (int)ctx->children.size(); }
 
 void masp_hip_ctx_destroy(masp_hip_ctx* ctx) {
@@ -682,6 +710,7 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
         if (J.circuit >= MASP_HIP_MAX_CIRCUITS || !J.inputs || !J.aux) return MASP_HIP_E_INVALID_ARG;
         if (!ctx->circ[J.circuit]) return MASP_HIP_E_NOT_LOADED;
         if ((J.a || J.b || J.c) && !(J.a && J.b && J.c)) return MASP_HIP_E_INVALID_ARG;
+        if (J.reserved != 0) return MASP_HIP_E_INVALID_ARG;  // must be zero: a later revision of the struct can then give it a meaning
         if (J.aux_form > MASP_HIP_AUX_MONTGOMERY || (J.aux_form && J.a)) return MASP_HIP_E_INVALID_ARG;  // (a, b, c given: nothing reads aux as Montgomery)
         if (!rs_in_range(J.r) || !rs_in_range(J.s)) return MASP_HIP_E_SCALAR_RANGE;
     }
@@ -826,6 +855,7 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
         owned.push_back({si, gi});
     }
     while (!owned.empty()) slot_release(ctx, retire_oldest());
+    if (result == MASP_HIP_OK) ctx->proofs_done += n;
     // a launch the runtime refused on this thread (MASP_LAUNCH keeps the first: kernel, file:line, HIP's text)
     const int launch_rc = launch_status();
     if (launch_rc && result == MASP_HIP_OK) result = fail_shared(ctx, launch_rc);
@@ -1016,7 +1046,7 @@ int masp_hip_batch_upload(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs)
     for (size_t j = 0; j < n; ++j) {
         if (jobs[j].circuit >= MASP_HIP_MAX_CIRCUITS || !ctx->circ[jobs[j].circuit]) return -MASP_HIP_E_NOT_LOADED;
         if (!rs_in_range(jobs[j].r) || !rs_in_range(jobs[j].s)) return -MASP_HIP_E_SCALAR_RANGE;
-        if (jobs[j].aux_form != MASP_HIP_AUX_CANONICAL) return -MASP_HIP_E_INVALID_ARG;  // resident assignments are proved repeatedly: canonical only
+        if (jobs[j].aux_form > MASP_HIP_AUX_MONTGOMERY || jobs[j].reserved != 0) return -MASP_HIP_E_INVALID_ARG;
     }
     for (uint32_t c = 0; c < MASP_HIP_MAX_CIRCUITS; ++c)
         for (size_t j = 0; j < n; ++j)
@@ -1036,7 +1066,11 @@ int masp_hip_batch_upload(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs)
                   hipMemcpyAsync(B->w.p + B->w_off[k] + C.n_inputs, J.aux, 32 * (size_t)C.n_aux, hipMemcpyHostToDevice, s) == hipSuccess &&
                   hipMemcpyAsync(B->rs.p + 16 * k, J.r, 32, hipMemcpyHostToDevice, s) == hipSuccess &&
                   hipMemcpyAsync(B->rs.p + 16 * k + 8, J.s, 32, hipMemcpyHostToDevice, s) == hipSuccess;
-        if (!ok || hipStreamSynchronize(s) != hipSuccess) return -fail(ctx, MASP_HIP_E_HIP);
+        // resident assignments are proved repeatedly and proving converts a Montgomery aux part in place: the resident copy is made
+        // canonical once, here
+        if (ok && J.aux_form == MASP_HIP_AUX_MONTGOMERY && C.n_aux)
+            launch_fr_from_mont(s, B->w.p + B->w_off[k] + C.n_inputs, B->w.p + B->w_off[k] + C.n_inputs, C.n_aux);
+        if (!ok || hipStreamSynchronize(s) != hipSuccess || launch_status() != MASP_HIP_OK) return -fail(ctx, MASP_HIP_E_HIP);
     }
     for (size_t k = 0; k < ctx->batches.size(); ++k)
         if (!ctx->batches[k]) {

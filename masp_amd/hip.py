@@ -21,12 +21,12 @@ class MaspHipError(RuntimeError):
 
 
 OPTION_FIELDS = ("slots", "batch_cap", "ntt_sub_batch", "window_bits_h", "window_bits_la", "window_bits_b", "window_bits_b2_lone",
-                 "witness_nontrivial_percent", "bucket_tree_levels", "bucket_tree_sub_batch", "bucket_tree_levels_g2")
+                 "witness_nontrivial_percent", "bucket_tree_levels", "bucket_tree_sub_batch", "bucket_tree_levels_g2", "bucket_tree_scratch_mb")
 
 
 class OptionsStruct(C.Structure):
     """masp_hip_options (include/masp_hip.h): every field 0 = the default."""
-    _fields_ = [("struct_size", C.c_uint32)] + [(f, C.c_int32) for f in OPTION_FIELDS] + [("reserved", C.c_int32 * 4)]
+    _fields_ = [("struct_size", C.c_uint32)] + [(f, C.c_int32) for f in OPTION_FIELDS] + [("bucket_tree_fallback_proofs", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class JobStruct(C.Structure):
@@ -65,6 +65,7 @@ def load_library():
     L.masp_hip_options_default.argtypes = [C.POINTER(OptionsStruct)]
     L.masp_hip_options_default.restype = None
     L.masp_hip_ctx_device_count.argtypes = [vp]
+    L.masp_hip_ctx_device_proofs.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     L.masp_hip_ctx_destroy.argtypes = [vp]
     L.masp_hip_ctx_destroy.restype = None
     L.masp_hip_strerror.restype = C.c_char_p
@@ -297,9 +298,25 @@ class Context:
         self._check(self._L.masp_hip_msm_g2_multi(self._h, _p(bases), n, _p(scalars), npf, int(window_bits), _p(out)))
         return [out[i].tobytes() for i in range(npf)]
 
+    def current_options(self):
+        """masp_hip_ctx_get_options now: the options with what lack of tree scratch has changed since creation — the
+        `bucket_tree_sub_batch` in use and `bucket_tree_fallback_proofs` (proofs that went through the XYZZ accumulation)."""
+        got = OptionsStruct()
+        self._check(self._L.masp_hip_ctx_get_options(self._h, C.byref(got)))
+        d = {f: int(getattr(got, f)) for f in OPTION_FIELDS}
+        d["bucket_tree_fallback_proofs"] = int(got.bucket_tree_fallback_proofs)
+        return d
+
     @property
     def device_count(self):
         return self._L.masp_hip_ctx_device_count(self._h)
+
+    def device_proofs(self):
+        """proofs written so far by each device context of this prover (masp_hip_ctx_device_proofs)"""
+        n = self.device_count
+        counts = (C.c_uint64 * n)()
+        self._check(self._L.masp_hip_ctx_device_proofs(self._h, counts, n))
+        return list(counts)
 
     def quotient_h(self, a, b, c, logm):
         a, b, c = _u8(a, 32), _u8(b, 32), _u8(c, 32)
@@ -317,8 +334,9 @@ class Context:
         jobs = list(jobs)
         arr = (JobStruct * len(jobs))()
         keep = []
-        for i, (slot, inputs, aux, r, s) in enumerate(jobs):
-            arr[i], k = self._job(slot, inputs, aux, r, s)
+        for i, job in enumerate(jobs):          # (slot, inputs, aux, r, s[, None[, aux_form]]): as marshal_jobs
+            slot, inputs, aux, r, s = job[:5]
+            arr[i], k = self._job(slot, inputs, aux, r, s, None, job[6] if len(job) > 6 else AUX_CANONICAL)
             keep.append(k)
         h = self._L.masp_hip_batch_upload(self._h, len(jobs), arr)
         if h < 0:

@@ -42,6 +42,10 @@ def load_library():
         L.masp_host_spend_assignment.argtypes = [cp, cp, cp, cp, cp, cp, u64, cp, vp, u64, cp, C.c_int, vp, vp, cp, cp, cp]
         L.masp_host_output_assignment.argtypes = [cp, cp, cp, cp, cp, u64, cp, C.c_int, vp, vp, cp]
         L.masp_host_convert_assignment.argtypes = [cp, u64, cp, vp, u64, cp, C.c_int, vp, vp, cp]
+        L.masp_host_spend_assignments.argtypes = [C.c_size_t, vp, C.c_int]
+        L.masp_host_fr_from_montgomery.argtypes = [vp, vp, C.c_size_t]
+        L.masp_host_fr_from_montgomery.restype = None
+        L.masp_host_convert_assignments.argtypes = [C.c_size_t, vp, C.c_int]
         L.masp_host_generator.argtypes = [C.c_int, cp]
         L.masp_host_pedersen_hash.argtypes = [C.c_int, vp, C.c_size_t, cp]
         L.masp_host_asset_identifier.argtypes = [cp, C.c_size_t, cp]
@@ -174,6 +178,83 @@ def convert_assignment(generator, value, anchor, path_siblings, position, rcv, c
     _check(L.masp_host_convert_assignment(_b(generator), value, _b(anchor), p.ctypes.data, position, _b(rcv),
                                           (1 if check else 0) | (2 if montgomery else 0), inputs.ctypes.data, aux.ctypes.data, cv))
     return inputs, aux, cv.raw
+
+
+def aux_from_montgomery(aux):
+    """u8[n,32] of Montgomery residues (what the synthesizers write with montgomery=True) -> u8[n,32] canonical little-endian values."""
+    L = load_library()
+    aux = np.ascontiguousarray(aux, dtype=np.uint8)
+    out = np.zeros_like(aux)
+    L.masp_host_fr_from_montgomery(aux.ctypes.data, out.ctypes.data, aux.shape[0])
+    return out
+
+
+# ---- several witnesses per call: their Merkle blocks run in lockstep (csrc/host/circuits.h merkle_block_batch) ----
+GROUP = 16      # witnesses per call: 3 x 16 chains of affine additions share every field inversion; 256 witnesses = 16 calls
+
+
+class _SpendJob(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ak", "nsk", "diversifier", "rcm", "ar", "asset_identifier")] + [("value", C.c_uint64)] + \
+               [(n, C.c_void_p) for n in ("anchor", "path_siblings")] + [("position", C.c_uint64), ("rcv", C.c_void_p)] + \
+               [(n, C.c_void_p) for n in ("inputs", "aux", "cv_out", "rk_out", "nf_out")] + [("rc", C.c_int)]
+
+
+class _ConvertJob(C.Structure):
+    _fields_ = [("generator", C.c_void_p), ("value", C.c_uint64), ("anchor", C.c_void_p), ("path_siblings", C.c_void_p), ("position", C.c_uint64),
+                ("rcv", C.c_void_p), ("inputs", C.c_void_p), ("aux", C.c_void_p), ("cv_out", C.c_void_p), ("rc", C.c_int)]
+
+
+def _pin(keep, data, n=32):
+    buf = C.create_string_buffer(_b(data, n), n)
+    keep.append(buf)
+    return C.addressof(buf)
+
+
+def spend_assignments(items, check=False, aux_outs=None, montgomery=False):
+    """items: list of (ak, nsk, diversifier, rcm, ar, asset_identifier, value, anchor, path_siblings, position, rcv) — the arguments of
+    spend_assignment — synthesised in ONE native call (masp_host_spend_assignments: the Merkle blocks of the witnesses run side
+    by side, ~1.8x the witnesses per second of the one-by-one call).  -> list of (inputs, aux, cv, rk, nf) or HostError instances."""
+    L = load_library()
+    cs, _ = circuit("spend")
+    n = len(items)
+    jobs = (_SpendJob * n)()
+    keep, outs = [], []
+    for j, (ak, nsk, d, rcm, ar, ident, value, anchor, sib, pos, rcv) in enumerate(items):
+        inputs = np.zeros((cs.n_inputs, 32), np.uint8)
+        aux = _aux_buffer(cs, aux_outs[j] if aux_outs else None)
+        path = _path(sib)
+        keep.append(path)
+        o = C.create_string_buffer(96)
+        J = jobs[j]
+        J.ak, J.nsk, J.diversifier, J.rcm, J.ar, J.asset_identifier = (_pin(keep, ak), _pin(keep, nsk), _pin(keep, d, 11), _pin(keep, rcm),
+                                                                       _pin(keep, ar), _pin(keep, ident))
+        J.value, J.anchor, J.path_siblings, J.position, J.rcv = value, _pin(keep, anchor), path.ctypes.data, pos, _pin(keep, rcv)
+        J.inputs, J.aux = inputs.ctypes.data, aux.ctypes.data
+        J.cv_out, J.rk_out, J.nf_out = C.addressof(o), C.addressof(o) + 32, C.addressof(o) + 64
+        outs.append((inputs, aux, o))
+    L.masp_host_spend_assignments(n, jobs, (1 if check else 0) | (2 if montgomery else 0))
+    return [HostError(jobs[j].rc) if jobs[j].rc else (i, a, o.raw[:32], o.raw[32:64], o.raw[64:]) for j, (i, a, o) in enumerate(outs)]
+
+
+def convert_assignments(items, check=False, aux_outs=None, montgomery=False):
+    """items: list of (generator, value, anchor, path_siblings, position, rcv) -> list of (inputs, aux, cv) or HostError instances."""
+    L = load_library()
+    cs, _ = circuit("convert")
+    n = len(items)
+    jobs = (_ConvertJob * n)()
+    keep, outs = [], []
+    for j, (gen, value, anchor, sib, pos, rcv) in enumerate(items):
+        inputs = np.zeros((cs.n_inputs, 32), np.uint8)
+        aux = _aux_buffer(cs, aux_outs[j] if aux_outs else None)
+        path = _path(sib)
+        keep.append(path)
+        o = C.create_string_buffer(32)
+        J = jobs[j]
+        J.generator, J.value, J.anchor, J.path_siblings, J.position, J.rcv = _pin(keep, gen), value, _pin(keep, anchor), path.ctypes.data, pos, _pin(keep, rcv)
+        J.inputs, J.aux, J.cv_out = inputs.ctypes.data, aux.ctypes.data, C.addressof(o)
+        outs.append((inputs, aux, o))
+    L.masp_host_convert_assignments(n, jobs, (1 if check else 0) | (2 if montgomery else 0))
+    return [HostError(jobs[j].rc) if jobs[j].rc else (i, a, o.raw) for j, (i, a, o) in enumerate(outs)]
 
 
 class PreparedVerifyingKey:

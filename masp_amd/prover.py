@@ -81,6 +81,26 @@ class SaplingProvingContext:
         return RJS.sign(self.bsk, msg, g_rcv, **({"rng": rng} if rng else {}))
 
 
+class _Permits:
+    """A counting semaphore whose acquire(k) takes k permits at once or none (k sequential acquires of a plain semaphore from
+    several threads can each end up holding a part of what they need)."""
+
+    def __init__(self, n):
+        self._n = n
+        self._cv = threading.Condition()
+
+    def acquire(self, k=1):
+        with self._cv:
+            while self._n < k:
+                self._cv.wait()
+            self._n -= k
+
+    def release(self, k=1):
+        with self._cv:
+            self._n += k
+            self._cv.notify_all()
+
+
 class LocalTxProver:
     """An implementation of `TxProver` using the MI355X prover.  Holds the three circuits' parameters for its lifetime."""
 
@@ -216,6 +236,39 @@ class LocalTxProver:
             raise ProvingError(str(e)) from None
         return dict(slot=CONVERT, inputs=inputs, aux=aux, aux_form=1, cv=cv, rcv=rcv, _pinned=buf)
 
+    def prepare_group(self, kind, kws):
+        """prepare_<kind> for several descriptions of ONE circuit in a single native call (host.GROUP at a time): the Merkle blocks of
+        Spend / Convert witnesses are synthesised side by side (csrc/host/circuits.h merkle_block_batch), ~2x the witnesses per
+        second and thread.  -> list of job dicts, a ProvingError in the place of a description that cannot be proved."""
+        if kind == "output":
+            out = []
+            for kw in kws:
+                try:
+                    out.append(self.prepare_output(**kw))
+                except ProvingError as e:
+                    out.append(e)
+            return out
+        slot = SPEND if kind == "spend" else CONVERT
+        bufs = [self._aux_take(slot) for _ in kws]
+        if kind == "spend":
+            items = [(*kw["proof_generation_key"], kw["diversifier"], kw["rcm"], kw["ar"], kw["asset_type"], kw["value"], kw["anchor"],
+                      *kw["merkle_path"], kw["rcv"]) for kw in kws]
+            res = H.spend_assignments(items, aux_outs=bufs, montgomery=True)
+        else:
+            gens = [kw["allowed_conversion"].generator if isinstance(kw["allowed_conversion"], H.AllowedConversion) else kw["allowed_conversion"] for kw in kws]
+            items = [(g, kw["value"], kw["anchor"], *kw["merkle_path"], kw["rcv"]) for g, kw in zip(gens, kws)]
+            res = H.convert_assignments(items, aux_outs=bufs, montgomery=True)
+        out = []
+        for kw, buf, r in zip(kws, bufs, res):
+            if isinstance(r, Exception):
+                self._aux_give([dict(slot=slot, _pinned=buf)])
+                out.append(ProvingError(str(r)))              # invalid diversifier -> Err(()) (sapling/prover.rs:84)
+            elif kind == "spend":
+                out.append(dict(slot=SPEND, inputs=r[0], aux=r[1], aux_form=1, cv=r[2], rk=r[3], nf=r[4], rcv=kw["rcv"], _pinned=buf))
+            else:
+                out.append(dict(slot=CONVERT, inputs=r[0], aux=r[1], aux_form=1, cv=r[2], rcv=kw["rcv"], _pinned=buf))
+        return out
+
     def prove_batch(self, ctx, descriptions, threads=None, rs=None, chunk=None, progress=None):
         """Batched form of the serial per-description loops of `SaplingBuilder::build`
         (/root/reference/masp_primitives/src/transaction/components/sapling/builder.rs:935-1140):
@@ -250,8 +303,8 @@ class LocalTxProver:
             return list(H.point_uv(job["cv"])) + [_int(kw["anchor"])]          # convert: sapling/prover.rs:256-263
 
         # synthesis may run ahead of the GPU only so far: every job in flight owns a page-locked aux buffer (3.2 MB / Spend)
-        window = (in_flight + 1) * chunk + threads       # synthesis runs one chunk ahead (measured: two buy nothing)
-        ahead = threading.Semaphore(window)
+        window = (in_flight + 1) * chunk + threads * H.GROUP  # synthesis runs one chunk ahead (measured: two buy nothing)
+        ahead = _Permits(window)
         # ... per circuit: the most descriptions of that circuit any `window` consecutive ones hold
         most, inside = {}, {}
         for i, (kind, _) in enumerate(descriptions):
@@ -265,25 +318,43 @@ class LocalTxProver:
 
         abort = threading.Event()              # set when a chunk fails: queued synthesis tasks then return at once
 
-        def synthesize(kind, kw):
-            ahead.acquire()
+        # synthesis tasks: runs of one circuit, host.GROUP descriptions at most, never across a chunk boundary — one native call each
+        groups, i = [], 0
+        while i < n:
+            kind, j = descriptions[i][0], i + 1
+            limit = min(n, (i // chunk + 1) * chunk, i + H.GROUP)
+            while j < limit and descriptions[j][0] == kind:
+                j += 1
+            groups.append((i, j))
+            i = j
+
+        def synthesize(lo, hi):
+            ahead.acquire(hi - lo)
             if abort.is_set():
-                return None
-            return prep[kind](**kw)
+                return [None] * (hi - lo)
+            return self.prepare_group(descriptions[lo][0], [kw for _, kw in descriptions[lo:hi]])
 
         failed = None
         done_lock = threading.Lock()
         with ThreadPoolExecutor(max_workers=threads) as synth, ThreadPoolExecutor(max_workers=in_flight) as gpu:
-            futures = [synth.submit(synthesize, kind, kw) for kind, kw in descriptions]
+            group_futures = [synth.submit(synthesize, lo, hi) for lo, hi in groups]
+            where = [None] * n                        # description k -> (its group's future, its index there)
+            for f, (lo, hi) in zip(group_futures, groups):
+                for k in range(lo, hi):
+                    where[k] = (f, k - lo)
 
             def run_chunk(lo):
                 hi = min(n, lo + chunk)
                 if abort.is_set():                      # an earlier chunk failed: the transaction is lost, do not spend GPU time on it
                     raise ProvingError("batch aborted")
-                jobs = [f.result() for f in futures[lo:hi]]
-                if any(j is None for j in jobs):        # synthesis saw the abort flag
-                    self._aux_give(jobs)
-                    raise ProvingError("batch aborted")
+                jobs = [where[k][0].result()[where[k][1]] for k in range(lo, hi)]
+                errors = [j for j in jobs if isinstance(j, Exception)]
+                if errors or any(j is None for j in jobs):     # a description that cannot be proved, or synthesis saw the abort flag
+                    self._aux_give([j for j in jobs if isinstance(j, dict)])
+                    for j in jobs:
+                        if isinstance(j, dict):
+                            j["_given"] = True
+                    raise errors[0] if errors else ProvingError("batch aborted")
                 try:
                     proofs = self.prove_prepared(jobs, rs[lo:hi])
                     if self._self_verify:
@@ -297,8 +368,9 @@ class LocalTxProver:
                                 raise ProvingError("proof(s) %s failed self-verification" % bad)
                 finally:
                     self._aux_give(jobs)                   # proved and checked, or failed: the aux buffers go back to the pool
-                for _ in range(hi - lo):
-                    ahead.release()
+                    for j in jobs:
+                        j["_given"] = True
+                ahead.release(hi - lo)
                 with done_lock:
                     done[0] += hi - lo
                     so_far = done[0]
@@ -315,8 +387,7 @@ class LocalTxProver:
                         if not abort.is_set():
                             first_error.append(e)   # the cause, not the "batch aborted" of the chunks that follow it
                             abort.set()
-                            for _ in range(n):
-                                ahead.release()
+                            ahead.release(n + window)
                     raise
             try:
                 results = list(gpu.map(guarded, range(0, n, chunk)))
@@ -327,7 +398,9 @@ class LocalTxProver:
             # back (the failing chunk's earlier jobs, later chunks, tasks that ran past the abort check) returns its
             # page-locked buffer now — a service that keeps hitting bad inputs must not accumulate pinned memory.
             # The context is left untouched: the builder drops it together with the failed transaction.
-            self._aux_give([f.result() for f in futures if f.done() and not f.cancelled() and f.exception() is None and f.result() is not None])
+            left = [j for f in group_futures if f.done() and not f.cancelled() and f.exception() is None for j in f.result()
+                    if isinstance(j, dict) and not j.get("_given")]
+            self._aux_give(left)
             raise failed
         jobs = [j for js, _ in results for j in js]
         proofs = [p for _, ps in results for p in ps]

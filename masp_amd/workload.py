@@ -80,23 +80,58 @@ def public_inputs(inputs):
     return [int.from_bytes(inputs[i].tobytes(), "little") for i in range(1, inputs.shape[0])]
 
 
-def instances(kind, n, first_seed=0, threads=None, alloc=None, timing=None):
+def _spend_item(kw):
+    ak, nsk = kw["proof_generation_key"]
+    sib, pos = kw["merkle_path"]
+    return (ak, nsk, kw["diversifier"], kw["rcm"], kw["ar"], kw["asset_type"], kw["value"], kw["anchor"], sib, pos, kw["rcv"])
+
+
+def _convert_item(kw):
+    sib, pos = kw["merkle_path"]
+    return (kw["allowed_conversion"].generator, kw["value"], kw["anchor"], sib, pos, kw["rcv"])
+
+
+def assignments(kind, kws, aux_outs=None, montgomery=False):
+    """The assignments of several descriptions of one circuit in ONE native call (host.GROUP at a time is what the callers use):
+    Spend and Convert witnesses run their Merkle blocks side by side.  -> list of (inputs, aux)."""
+    if kind == "spend":
+        res = H.spend_assignments([_spend_item(kw) for kw in kws], aux_outs=aux_outs, montgomery=montgomery)
+    elif kind == "convert":
+        res = H.convert_assignments([_convert_item(kw) for kw in kws], aux_outs=aux_outs, montgomery=montgomery)
+    else:
+        return [assignment(kind, kw, aux_out=aux_outs[j] if aux_outs else None) for j, kw in enumerate(kws)]
+    for r in res:
+        if isinstance(r, Exception):
+            raise r
+    return [(r[0], r[1]) for r in res]
+
+
+def instances(kind, n, first_seed=0, threads=None, alloc=None, timing=None, montgomery=False):
     """n independent instances of circuit `kind` -> list of (inputs, aux).  alloc(kind) -> aux buffer (e.g. page-locked memory);
-    timing: dict receiving per-instance synthesis milliseconds (description + assignment, one thread each)."""
+    timing: dict receiving per-instance synthesis milliseconds (description + assignment, one thread each; the assignments of
+    host.GROUP instances are one native call, its time shared out evenly).  montgomery: aux as Montgomery residues (the in-memory form of
+    blst_fr: masp_hip_job.aux_form = 1) — the synthesizer then writes straight into the buffer."""
     threads = threads or H.effective_cpus()
 
-    def one(k):
+    def group(lo):
+        ks = range(lo, min(n, lo + H.GROUP))
         t0 = time.perf_counter()
-        _, kw = description(kind, first_seed + k)
+        kws = [description(kind, first_seed + k)[1] for k in ks]
         t1 = time.perf_counter()
-        out = assignment(kind, kw, aux_out=alloc(kind) if alloc else None)
+        if kind == "output":
+            out = [assignment(kind, kw, aux_out=alloc(kind) if alloc else None) if not montgomery else
+                   H.output_assignment(kw["esk"], *kw["payment_address"], kw["rcm"], kw["asset_type"], kw["value"], kw["rcv"],
+                                       aux_out=alloc(kind) if alloc else None, montgomery=True)[:2] for kw in kws]
+        else:
+            out = assignments(kind, kws, aux_outs=[alloc(kind) for _ in kws] if alloc else None, montgomery=montgomery)
         t2 = time.perf_counter()
-        return out, (t1 - t0) * 1e3, (t2 - t1) * 1e3
+        return out, (t1 - t0) * 1e3 / len(ks), (t2 - t1) * 1e3 / len(ks)
 
     with ThreadPoolExecutor(threads) as ex:
-        res = list(ex.map(one, range(n)))
+        res = list(ex.map(group, range(0, n, H.GROUP)))
     if timing is not None:
         timing.setdefault(kind, {"describe_ms": [], "synthesize_ms": []})
-        timing[kind]["describe_ms"] += [r[1] for r in res]
-        timing[kind]["synthesize_ms"] += [r[2] for r in res]
-    return [r[0] for r in res]
+        for out, d_ms, s_ms in res:
+            timing[kind]["describe_ms"] += [d_ms] * len(out)
+            timing[kind]["synthesize_ms"] += [s_ms] * len(out)
+    return [x for out, _, _ in res for x in out]

@@ -192,6 +192,20 @@ def test_msm_engine_batched_np16_full_size(rig, n, window_bits, shape):
     assert rig.ctx.msm_g1(bases, sc[0]) == got[0]
 
 
+def test_job_struct_reserved_field_must_be_zero(rig):
+    """masp_hip_job carries no size field: `reserved` has to be 0 so that a later revision of the struct can give it a meaning
+    (ADVICE r03).  A job with a non-zero value is refused before anything is enqueued."""
+    import masp_amd
+    from masp_amd import workload as W
+    (i, a), = W.instances("output", 1, first_seed=77)
+    arr, n, keep = rig.ctx.marshal_jobs([(KINDS.index("output"), i, a, 5, 6)])
+    assert len(rig.ctx.prove_marshalled(arr, n)) == 1
+    arr[0].reserved = 1
+    with pytest.raises(masp_amd.MaspHipError) as e:
+        rig.ctx.prove_marshalled(arr, n)
+    assert e.value.code == 1        # MASP_HIP_E_INVALID_ARG
+
+
 def test_multi_device_context_deals_batches_to_its_devices(rig):
     """masp_hip_ctx_create_multi: one prover over several device contexts (here the same GPU twice — the sharding, the
     per-device host threads and the reassembly are what is tested; with 8 GPUs the list is 0..7).  Same bytes as the

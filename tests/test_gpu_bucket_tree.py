@@ -108,3 +108,36 @@ def test_bucket_runs_of_every_length_around_the_powers_of_two(ctxs):
     want = O.g1_mul_gen_many(np.stack([_le(t) for t in totals]))
     for which in ("auto", "deep", "off"):
         assert ctxs[which].msm_g1_multi(bases, np.stack(sc), window_bits=8) == [want[p].tobytes() for p in range(np_)]
+
+
+def test_tree_scratch_that_does_not_fit_falls_back_instead_of_failing():
+    """The tree's scratch is ~0.4 GB per Spend proof.  Where it does not fit (a smaller GPU, more slots, a second prover on the
+    device — forced here with masp_hip_options::bucket_tree_scratch_mb) the sub-batch is halved, then the rest of the batch goes
+    through the XYZZ accumulation: the same bytes, no error, and masp_hip_ctx_get_options says what happened (VERDICT r03 item 7,
+    ADVICE r03)."""
+    import masp_amd
+    n, np_ = 8000, 40
+    rng = random.Random(91)
+    k_int = [rng.randrange(1, R) for _ in range(n)]
+    bases = O.g1_mul_gen_many(np.stack([_le(k) for k in k_int]))
+    sc = np.zeros((np_, n, 32), np.uint8)
+    for p in range(np_):
+        sc[p] = np.frombuffer(b"".join(rng.randrange(R).to_bytes(32, "little") for _ in range(n)), np.uint8).reshape(n, 32)
+    plain = masp_amd.Context(0, slots=1, bucket_tree_sub_batch=32)
+    try:
+        want = plain.msm_g1_multi(bases, sc, window_bits=12)
+        assert plain.current_options()["bucket_tree_fallback_proofs"] == 0
+    finally:
+        plain.close()
+    # (the scratch of this shape: ~565 / 282 / 141 MiB for sub-batches of 32 / 16 / 8 proofs)
+    # 200 MiB: 32 and 16 proofs do not fit, 8 do -> halved twice, nothing falls back
+    # 16 MiB: not even 8 proofs fit -> the whole batch through the XYZZ accumulation
+    for mb, sub_after, fell_back in ((200, 8, False), (16, 8, True)):
+        ctx = masp_amd.Context(0, slots=1, bucket_tree_sub_batch=32, bucket_tree_scratch_mb=mb)
+        try:
+            assert ctx.msm_g1_multi(bases, sc, window_bits=12) == want
+            now = ctx.current_options()
+            assert now["bucket_tree_sub_batch"] <= sub_after, now
+            assert (now["bucket_tree_fallback_proofs"] > 0) == fell_back, now
+        finally:
+            ctx.close()
