@@ -678,6 +678,19 @@ int masp_host_jubjub_add(const uint8_t p32[32], const uint8_t q32[32], int subtr
     p.add(subtract ? q.neg() : q).to_bytes(out32);
     return 0;
 }
+// acc + sum_i (+/-) points[i]  (n compressed points; subtract[i] != 0: that point is subtracted; subtract may be NULL): the value
+// commitments of a chunk of descriptions in one call (SaplingProvingContext::cv_sum, sapling/prover.rs:154,205,272)
+int masp_host_jubjub_sum(const uint8_t acc32[32], const uint8_t* points, size_t n, const uint8_t* subtract, uint8_t out32[32]) {
+    JPoint acc;
+    if (!JPoint::from_bytes(acc, acc32)) return 1;
+    for (size_t i = 0; i < n; ++i) {
+        JPoint q;
+        if (!JPoint::from_bytes(q, points + 32 * i)) return 1;
+        acc = acc.add(subtract && subtract[i] ? q.neg() : q);
+    }
+    acc.to_bytes(out32);
+    return 0;
+}
 // leaf of the commitment tree for a spendable note: derives nk, ivk, g_d, pk_d exactly as spend_proof does and
 // returns cmu (what the wallet already knows as the note commitment); also pk_d for callers that want the address
 int masp_host_spend_leaf(const uint8_t ak[32], const uint8_t nsk[32], const uint8_t diversifier[11], const uint8_t rcm[32],

@@ -257,6 +257,9 @@ struct masp_hip_ctx {
     std::vector<std::unique_ptr<ResidentBatch>> batches;
     bool profiling = false;
     std::atomic<uint64_t> proofs_done{0};   // proofs this device context has written (masp_hip_ctx_device_proofs)
+    // the building-block MSM entry points (masp_hip_msm_g1_multi ...) run on a workspace of their own: what lack of tree scratch did there
+    std::atomic<uint64_t> block_tree_fallbacks{0};
+    std::atomic<uint32_t> block_tree_sub{0xffffffffu};
     // scratch for the building-block entry points
     DevBuf<Fr> tmp_scalars;
     DevBuf<uint8_t> tmp_out;

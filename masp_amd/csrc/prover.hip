@@ -460,6 +460,8 @@ int masp_hip_ctx_get_options(const masp_hip_ctx* ctx, masp_hip_options* out) {
         scan(ctx);
     else
         for (const masp_hip_ctx* d : ctx->children) scan(d);
+    fb += c->block_tree_fallbacks.load();
+    if (c->block_tree_sub.load() != 0xffffffffu) sub = std::min<int>(sub, (int)c->block_tree_sub.load());
     out->bucket_tree_sub_batch = sub;
     out->bucket_tree_fallback_proofs = (int32_t)std::min<uint64_t>(fb, 0x7fffffff);
     return MASP_HIP_OK;
@@ -905,6 +907,16 @@ static int msm_multi(masp_hip_ctx* ctx, const uint8_t* bases, size_t n, const ui
     MsmWorkspace<O> ws;
     ws.tree_levels = ctx->opt.bucket_tree_levels;
     ws.tree_sub = (uint32_t)ctx->opt.bucket_tree_sub_batch;
+    ws.tree.own.limit = (size_t)ctx->opt.bucket_tree_scratch_mb << 20;
+    // (what lack of tree scratch does to this call's own workspace is reported like the slots': masp_hip_ctx_get_options)
+    struct Report {
+        masp_hip_ctx* c;
+        MsmWorkspace<O>& w;
+        ~Report() {
+            c->block_tree_fallbacks += w.tree_fallbacks;
+            c->block_tree_sub = std::min<uint32_t>(c->block_tree_sub, w.tree_sub);
+        }
+    } report{ctx, ws};
     DevBuf<Xyzz<O>> res;
     DevBuf<uint8_t> d_out;
     int rc;

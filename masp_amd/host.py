@@ -62,6 +62,7 @@ def load_library():
         L.masp_host_vk_verify_batch.argtypes = [vp, C.c_size_t, cp, cp, C.c_uint32, cp]
         L.masp_host_point_uv.argtypes = [cp, cp]
         L.masp_host_jubjub_add.argtypes = [cp, cp, C.c_int, cp]
+        L.masp_host_jubjub_sum.argtypes = [cp, cp, C.c_size_t, cp, cp]
         L.masp_host_spend_leaf.argtypes = [cp, cp, cp, cp, cp, u64, cp, cp]
         L.masp_host_allowed_conversion.argtypes = [C.c_size_t, cp, cp, cp]
         _lib = L
@@ -385,6 +386,16 @@ def jubjub_add(p, q, subtract=False):
 
 
 JUBJUB_IDENTITY = (1).to_bytes(32, "little")   # (u, v) = (0, 1)
+
+
+def jubjub_sum(points, subtract=None, acc=JUBJUB_IDENTITY):
+    """acc + sum of the compressed points (those with a true `subtract` flag subtracted) in one native call."""
+    pts = b"".join(_b(p) for p in points)
+    flags = bytes(1 if f else 0 for f in subtract) if subtract is not None else None
+    out = C.create_string_buffer(32)
+    if load_library().masp_host_jubjub_sum(_b(acc), pts, len(points), flags, out):
+        raise ValueError("invalid point")
+    return out.raw
 
 
 def convert_cmu(generator):

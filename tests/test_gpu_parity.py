@@ -36,7 +36,7 @@ def _rand_scalars(rng, n, bool_share=0.0):
     return out
 
 
-@pytest.mark.parametrize("logm", [1, 4, 9, 10, 11, 13, 17])
+@pytest.mark.parametrize("logm", [1, 4, 9, 10, 11, 13, 15, 16, 17])       # 15 / 16 / 17: the Output / Convert / Spend domains
 def test_ntt_matches_oracle(ctx, logm):
     rng = np.random.default_rng(logm)
     m = 1 << logm
@@ -126,7 +126,7 @@ def test_msm_g2_repeated_and_cancelling_points(ctx):
     assert ctx.msm_g2(twice, sc2) == O.msm_g2(twice, sc2)
 
 
-@pytest.mark.parametrize("n", [1, 33, 700, 9000])
+@pytest.mark.parametrize("n", [1, 33, 700, 9000, 62170])             # 62 170: the Spend circuit's b_g2 query, against the CPU multiexp itself
 def test_msm_g2_matches_oracle(ctx, n):
     rng = random.Random(n + 100)
     bases = O.g2_mul_gen_many(_rand_scalars(rng, n))
