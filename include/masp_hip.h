@@ -90,7 +90,7 @@ int masp_hip_device_count(void);
  * library reads NO environment variables; bench.py and the tools translate their MASP_HIP_* variables into this. */
 typedef struct {
     uint32_t struct_size;            /* sizeof(masp_hip_options) of the caller's header (versioning) */
-    int32_t slots;                   /* batches in flight per device, each on its own HIP stream + scratch: 1..64 (default 4) */
+    int32_t slots;                   /* batches in flight per device, each on its own HIP stream + scratch: 1..64 (default 3) */
     int32_t batch_cap;               /* proofs per launch sequence: 1..256 (default 256 = BASELINE.json configs[3]) */
     int32_t ntt_sub_batch;           /* proofs per sub-batch of the quotient's transforms (default 8: 160 MiB of work buffers
                                         stay in the Infinity Cache); -1 = the whole batch at once */
@@ -101,7 +101,7 @@ typedef struct {
     int32_t witness_nontrivial_percent; /* share of a witness that is neither 0 nor 1, for window selection (default 30) */
     int32_t bucket_tree_levels;      /* levels of shared-inversion affine additions in front of the bucket accumulation of a batch
                                         (default 4, fewer for very short bucket runs); -1 = none (XYZZ accumulation only) */
-    int32_t bucket_tree_sub_batch;   /* proofs that go through the tree at a time (default 64; its scratch is ~0.4 GB per Spend proof) */
+    int32_t bucket_tree_sub_batch;   /* proofs that go through the tree at a time (default 86: a 256-proof batch in three; its scratch is ~0.4 GB per Spend proof) */
     int32_t bucket_tree_levels_g2;   /* the same for the G2 MSM if it should differ (default: bucket_tree_levels) */
     int32_t bucket_tree_scratch_mb;  /* upper bound of the tree's scratch per slot in MiB (default 0: whatever the device gives).  If the
                                         scratch of a sub-batch does not fit — this bound, or the device is out of memory — the sub-batch

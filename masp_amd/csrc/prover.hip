@@ -32,7 +32,10 @@ static masp_hip_options resolve_options(const masp_hip_options* in) {
     memset(&o, 0, sizeof o);
     if (in) memcpy(&o, in, std::min<size_t>(in->struct_size ? in->struct_size : sizeof o, sizeof o));
     o.struct_size = sizeof o;
-    o.slots = o.slots > 0 ? std::min<int>(o.slots, (int)masp_hip_ctx::MAX_SLOTS) : 4;
+    // (round 4: with the passes of the bucket tree no longer waiting on memory, three batches in flight keep the chip as busy as
+    // four did — 1 227 vs 1 220 proofs/s — and leave their scratch to larger tree sub-batches: 3 x 86 proofs, 1 251 proofs/s, in the
+    // ~100 GB that 4 x 64 took; profiles/r04_same_box_sweep_slots_tree_sub.txt)
+    o.slots = o.slots > 0 ? std::min<int>(o.slots, (int)masp_hip_ctx::MAX_SLOTS) : 3;
     // proofs per batched launch sequence (upper bound: a list of n same-circuit jobs is cut into ceil(n / cap) equal groups);
     // scratch memory follows the batches actually formed
     o.batch_cap = o.batch_cap > 0 ? std::min<int>(o.batch_cap, 256) : 256;
@@ -41,7 +44,7 @@ static masp_hip_options resolve_options(const masp_hip_options* in) {
     // ~30 % of a MASP witness is neither 0 nor 1; measured +3..5 % throughput vs 100
     o.witness_nontrivial_percent = o.witness_nontrivial_percent > 0 ? std::min<int>(o.witness_nontrivial_percent, 100) : 30;
     o.bucket_tree_levels = o.bucket_tree_levels > 0 ? std::min<int>(o.bucket_tree_levels, 12) : o.bucket_tree_levels < 0 ? -1 : 0;  // resolved: 0 = automatic
-    o.bucket_tree_sub_batch = o.bucket_tree_sub_batch > 0 ? std::min<int>(o.bucket_tree_sub_batch, 256) : 64;
+    o.bucket_tree_sub_batch = o.bucket_tree_sub_batch > 0 ? std::min<int>(o.bucket_tree_sub_batch, 256) : 86;   // a 256-proof batch in three sub-batches
     o.bucket_tree_levels_g2 = o.bucket_tree_levels_g2 > 0 ? std::min<int>(o.bucket_tree_levels_g2, 12) : o.bucket_tree_levels_g2 < 0 ? -1 : o.bucket_tree_levels;
     o.bucket_tree_scratch_mb = std::max(o.bucket_tree_scratch_mb, 0);
     o.bucket_tree_fallback_proofs = 0;   // output only
