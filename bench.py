@@ -321,6 +321,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     acc_ms, launches, alg_bytes = ctx.profile_read()
+    split_a = ctx.profile_read_split()
     # The same launches with ONE batch in flight (one launch sequence of the first circuit's jobs, nothing else on the chip):
     # with four batches in flight the HIP events around a launch also span the time it waits for the chip behind other
     # streams' kernels, which is not kernel time (rocprofv3's begin / end of the same launches agree with THIS figure).
@@ -330,6 +331,7 @@ def main():
     ctx.batch_prove_resident(excl, n_excl)
     x_ms, x_launches, x_bytes = ctx.profile_read()          # cumulative since profile_enable
     x_ms, x_launches, x_bytes = x_ms - acc_ms, x_launches - launches, x_bytes - alg_bytes
+    x_split = {k: v - split_a[k] for k, v in ctx.profile_read_split().items()}
     ctx.batch_free(excl)
     ctx.profile_enable(False)
     # ---- region B (`value`): witnesses in page-locked host memory -> K masp_hip_prove_batch calls (one per slot
@@ -477,6 +479,8 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source, "launches": x_launches, "avg_launch_ms": x_ms / x_launches if x_launches else None,
                          "alg_bytes_per_launch": x_bytes / x_launches if x_launches else None,
+                         # the same launches by kernel group (HIP events between the groups, same stream): ms per launch
+                         "kernel_ms_per_launch": {k: round(v / x_launches, 3) for k, v in x_split.items()} if x_launches else None,
                          "timed_region": {"launches": launches, "avg_span_ms": acc_ms / launches if launches else None,
                                           "alg_bytes_per_launch": alg_bytes / launches if launches else None},
                          "note": "algorithmic bytes = n x (96 B base + 32 B scalar) per G1 MSM and proof.  avg_launch_ms / achieved: HIP events "

@@ -213,6 +213,10 @@ int masp_hip_bench_msm(masp_hip_ctx* ctx, int handle, size_t job, int which, int
  * (n x (96 + 32) per G1 MSM of n points) of all launches since enable/reset. */
 int masp_hip_profile_enable(masp_hip_ctx* ctx, int on);
 int masp_hip_profile_read(masp_hip_ctx* ctx, double* total_ms, uint64_t* launches, uint64_t* alg_bytes);
+/* The same launches by kernel group, summed milliseconds since enable / reset: ms[0] plan / records / copies of the bucket tree,
+ * ms[1] its denominators pass (k_tree_pass1), ms[2] the shared inversions (k_binv_*), ms[3] its additions pass (k_tree_pass2),
+ * ms[4] the XYZZ accumulation of what is left (k_msm_accumulate_pts, or k_msm_accumulate without a tree); ms[5..7] = 0. */
+int masp_hip_profile_read_split(masp_hip_ctx* ctx, double ms[8]);
 /* Page-locked host memory for assignments.  masp_hip_prove_batch recognises `aux` pointers that lie in page-locked
  * memory (from here or from the caller's own hipHostMalloc / hipHostRegister) and copies them to the device directly;
  * anything else goes through the library's own pinned staging buffer first (one extra host copy of ~3 MB per Spend).

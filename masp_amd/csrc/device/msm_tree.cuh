@@ -52,9 +52,15 @@ namespace masp {
 // product alone: pass 2 — the kernel that saturates the multiplier — gets the slope with ONE product instead of two, and pass 1,
 // which waits for memory three quarters of its time, does the other one (it then reads the y coordinates too: at level 0 they
 // lie in the 128-byte row it gathers anyway).  0: the round-3 form (A/B builds).
+// Level 0 only: there it takes 0.45 ms per call off the two passes together; on the deeper levels the two kernels merely swap
+// 0.21 ms and pass 1 reads 96 bytes per pair more (measured, r04c / r04m).
 #ifndef MASP_TREE_QNUM
 #define MASP_TREE_QNUM 1
 #endif
+template <bool L0>
+struct TREE_QNUM_AT {
+    static constexpr bool value = (MASP_TREE_QNUM) != 0 && L0;
+};
 __device__ __forceinline__ Fp plane_ld_fp(const uint4* __restrict__ b, size_t cap, size_t u) {
     const uint4 a = b[u], c = b[cap + u], d = b[2 * cap + u];
     Fp r;
@@ -351,7 +357,7 @@ k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
     src.tab = tab;
     src.set(xs, ys, p, np, pt_stride);
     F chain = O::one();
-#if MASP_TREE_QNUM
+    if constexpr (TREE_QNUM_AT<L0>::value) {
     // two-stage software pipeline: the record of pair j + 2 and the operands of pair j + 1 are requested before pair j is
     // multiplied in — an operand is two dependent loads away (record, then row / point) and nothing else hides that
     struct Ops {
@@ -397,7 +403,7 @@ k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
     }
     if (j) plane_st(pre, pre_cap, src.at(((size_t)(j - 1) * np + p) * NT + t), hq);
     tp[src.at((size_t)p * NT + t)] = chain;
-#else
+    } else {
     // two-stage software pipeline: the record of pair j + 2 and the operands of pair j + 1 are requested before pair j is
     // multiplied in — an operand is two dependent loads away (record, then row / point) and nothing else hides that
     Rec ra{}, rb{};
@@ -428,7 +434,7 @@ k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
     }
     if (j) plane_st(pre, pre_cap, src.at(((size_t)(j - 1) * np + p) * NT + t), chain);
     tp[src.at((size_t)p * NT + t)] = chain;
-#endif
+    }
 }
 
 // ---- pass 2: the additions --------------------------------------------------------------------------------------------
@@ -468,7 +474,7 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         }
     };
     F I = tinv[src.at((size_t)p * NT + t)];
-#if MASP_TREE_QNUM
+    if constexpr (TREE_QNUM_AT<L0>::value) {
     // two-stage software pipeline, backwards: the record of pair j - 2 and the operands of pair j - 1 are requested before pair
     // j is computed (see pass 1).  y2 is only read where a pair is exceptional: its slope's numerator came with `pre`.
     struct Ops {
@@ -531,7 +537,7 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         if (!j) break;
     }
     put(hout, hx, hy);
-#else
+    } else {
     // two-stage software pipeline, backwards: the record of pair j - 2 and the operands of pair j - 1 are requested before pair
     // j is computed (see pass 1)
     struct Ops {
@@ -597,7 +603,7 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         if (!j) break;
     }
     put(hout, hx, hy);
-#endif
+    }
 }
 
 // the last point of a bucket with an odd number of points goes to the next level as it is.  grid (nb / 256, np)

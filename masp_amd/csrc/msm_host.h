@@ -170,6 +170,7 @@ struct MsmTreeWs {
     uint32_t q = 0, nb = 0, T = 0;
     size_t stride[2] = {0, 0};
     size_t pre_cap = 0;  // elements of the plane `pre`
+    struct MsmProfile* prof = nullptr;  // set by msm_reduce_enqueue while a profiled MSM runs through the tree (MsmProfile::mark)
 
     int reserve(uint64_t E_ub, uint32_t nb, uint32_t q, uint32_t T);                 // [msm_tree_impl.cuh]
     void batch_invert(hipStream_t s, const F* in, uint32_t n, F* out);              // [msm_tree_impl.cuh]
@@ -276,9 +277,33 @@ struct MsmProfile {
     std::vector<Rec> pool;      // reusable event pairs
     double total_ms = 0;
     uint64_t launches = 0, alg_bytes = 0;
+    // the stage by kernel group: an event behind every group of launches of the bucket stage (the tree's plan / records / copies,
+    // its denominators pass, the shared inversions, its additions pass, the XYZZ accumulation of what is left); split_ms[g] = time
+    // between the event in front of group g's launches and the one behind them, summed over the profiled launches
+    enum { PH_START = -1, PH_PLAN = 0, PH_PASS1, PH_INV, PH_PASS2, PH_ACC, PH_N };
+    struct Mark {
+        hipEvent_t e;
+        int tag;
+    };
+    std::vector<Mark> marks;
+    std::vector<hipEvent_t> mark_pool;
+    double split_ms[PH_N] = {0, 0, 0, 0, 0};
+    void mark(hipStream_t s, int tag) {
+        hipEvent_t e;
+        if (!mark_pool.empty()) {
+            e = mark_pool.back();
+            mark_pool.pop_back();
+        } else if (hipEventCreate(&e) != hipSuccess) {
+            return;
+        }
+        hipEventRecord(e, s);
+        marks.push_back({e, tag});
+    }
     ~MsmProfile() {
         for (auto& r : recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
         for (auto& r : pool) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+        for (auto& m : marks) hipEventDestroy(m.e);
+        for (auto& e : mark_pool) hipEventDestroy(e);
     }
     Rec acquire() {
         if (!pool.empty()) {
@@ -304,12 +329,19 @@ struct MsmProfile {
             pool.push_back(r);
         }
         recs.clear();
+        for (size_t i = 0; i < marks.size(); ++i) {
+            float ms = 0;
+            if (i && marks[i].tag >= 0 && hipEventElapsedTime(&ms, marks[i - 1].e, marks[i].e) == hipSuccess) split_ms[marks[i].tag] += ms;
+            mark_pool.push_back(marks[i].e);
+        }
+        marks.clear();
     }
     void reset() {
         collect();
         total_ms = 0;
         launches = 0;
         alg_bytes = 0;
+        for (double& v : split_ms) v = 0;
     }
 };
 

@@ -93,6 +93,7 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
         rec = prof->acquire();
         rec.alg_bytes = (uint64_t)np * n * (BYTES + 32);  // n x (affine base + scalar) per proof
         hipEventRecord(rec.e0, s);
+        prof->mark(s, MsmProfile::PH_START);
     }
     const bool lone = np < 8;  // latency regime: short chains matter more than total work
     // the batch-affine tree in front (msm_tree_levels, msm_host.h): it needs the sort's runs padded to even lengths
@@ -100,6 +101,7 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
     const uint32_t* start = sb.start;
     if (tree_T) {
         uint32_t sub = std::max(1u, std::min(ws.tree_sub, np));
+        ws.tree.prof = prof;
         for (uint32_t p0 = 0; p0 < np;) {
             uint32_t q = std::min(sub, np - p0);
             rc = msm_tree_enqueue<O, BYTES>(s, B, sb, ws.tree, p0, q, tree_T);
@@ -124,13 +126,17 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
             if (rc) return rc;
             msm_launch_accumulate_pts<O>(s, ws.tree.points_x(), ws.tree.points_y(), ws.tree.point_stride(), ws.tree.plan_D(tree_T), nb, nchunks,
                                          ws.part + (size_t)p0 * ((size_t)nchunks + nb), q);
+            if (prof) prof->mark(s, MsmProfile::PH_ACC);
             // the bucket tails run over the whole batch: keep this sub-batch's offsets (the next one overwrites the plan)
             HIP_TRY(hipMemcpyAsync(ws.startT + (size_t)p0 * (nb + 1), ws.tree.plan_D(tree_T), sizeof(uint32_t) * q * (nb + 1), hipMemcpyDeviceToDevice, s));
+            if (prof) prof->mark(s, MsmProfile::PH_PLAN);
             p0 += q;
         }
+        ws.tree.prof = nullptr;
         start = ws.startT;
     } else {
         msm_launch_accumulate<O>(s, B.tab, sb.sorted, sb.ent_stride, sb.start, nb, nchunks, ws.part, np);
+        if (prof) prof->mark(s, MsmProfile::PH_ACC);
     }
     if (prof) {
         hipEventRecord(rec.e1, s);

@@ -113,7 +113,9 @@ int msm_tree_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSortBu
     const size_t ent_stride = E_ub;
     const uint32_t* sorted = sb.sorted + (size_t)p0 * ent_stride;
     const uint32_t* start = sb.start + (size_t)p0 * (nb + 1);
+    MsmProfile* const prof = tw.prof;
     MASP_LAUNCH(k_tree_plan, dim3(T + 1, q), dim3(1024), 0, s, start, nb, tw.D, tw.Q);
+    if (prof) prof->mark(s, MsmProfile::PH_PLAN);
     const size_t lvl = (size_t)q * (nb + 1);
     const size_t rec_stride = tree_pairs_ub(E_ub, nb, 1);
     for (uint32_t L = 0; L < T; ++L) {
@@ -138,11 +140,16 @@ int msm_tree_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSortBu
                                (F1*)tw.pre, pre_cap1, (F1*)tw.tp);
         } else {
             // (a level below the sort's pad_log has runs of even lengths only: no records, no odd points to copy)
-            if (L >= sb.pad_log) MASP_LAUNCH(k_tree_records, rgrid, block, 0, s, Dl, Dn, Ql, nb, tw.rec, rec_stride);
+            if (L >= sb.pad_log) {
+                MASP_LAUNCH(k_tree_records, rgrid, block, 0, s, Dl, Dn, Ql, nb, tw.rec, rec_stride);
+                if (prof) prof->mark(s, MsmProfile::PH_PLAN);
+            }
             MASP_LAUNCH((k_tree_pass1<O1, false>), grid1, block, 0, s, B.tab, (const F1*)xi, (const F1*)yi, si, recL, rec_stride, Ql, nb,
                                NT, (F1*)tw.pre, pre_cap1, (F1*)tw.tp);
         }
+        if (prof) prof->mark(s, MsmProfile::PH_PASS1);
         tw.batch_invert(s, tw.tp, q * NT, tw.tinv);
+        if (prof) prof->mark(s, MsmProfile::PH_INV);
         typedef typename TreeLaneOps<O, 1>::type O2;
         typedef typename O2::T F2;
         const dim3 grid2(NT * O2::LANES / 256, q);
@@ -153,9 +160,12 @@ int msm_tree_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSortBu
         else
             MASP_LAUNCH((k_tree_pass2<O2, false>), grid2, block, 0, s, B.tab, (const F2*)xi, (const F2*)yi, si, recL, rec_stride, Ql,
                                nb, NT, (const F2*)tw.pre, pre_cap2, (const F2*)tw.tinv, (F2*)xo, (F2*)yo, so, out_whole);
+        if (prof) prof->mark(s, MsmProfile::PH_PASS2);
         // (level 0 has no odd runs: a run of odd length met its padding entry as P + infinity)
-        if (L >= sb.pad_log)
+        if (L >= sb.pad_log) {
             MASP_LAUNCH((k_tree_copy<O, false>), cgrid, block, 0, s, B.tab, sorted, ent_stride, xi, yi, si, Dl, Dn, nb, xo, yo, so, out_whole);
+            if (prof) prof->mark(s, MsmProfile::PH_PLAN);
+        }
     }
     return launch_status();
 }

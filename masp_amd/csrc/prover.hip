@@ -1221,6 +1221,20 @@ int masp_hip_profile_read(masp_hip_ctx* ctx, double* total_ms, uint64_t* launche
     return MASP_HIP_OK;
 }
 
+int masp_hip_profile_read_split(masp_hip_ctx* ctx, double ms[8]) {
+    if (!ctx || !ms) return MASP_HIP_E_INVALID_ARG;
+    ctx = FIRST_DEVICE(ctx);
+    std::unique_lock<std::shared_mutex> lock(ctx->mu);
+    hipSetDevice(ctx->device);
+    hipDeviceSynchronize();
+    for (int i = 0; i < 8; ++i) ms[i] = 0;
+    for (auto& sl : ctx->slots) {
+        sl->prof.collect();
+        for (int i = 0; i < MsmProfile::PH_N; ++i) ms[i] += sl->prof.split_ms[i];
+    }
+    return MASP_HIP_OK;
+}
+
 void* masp_hip_host_alloc(masp_hip_ctx* ctx, size_t bytes) {
     if (!ctx || !bytes) return nullptr;
     hipSetDevice(ctx->device);

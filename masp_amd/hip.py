@@ -94,6 +94,7 @@ def load_library():
     L.masp_hip_bench_msm.argtypes = [vp, C.c_int, sz, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(u32)]
     L.masp_hip_profile_enable.argtypes = [vp, C.c_int]
     L.masp_hip_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.masp_hip_profile_read_split.argtypes = [vp, C.POINTER(C.c_double)]
     L.masp_hip_sync.argtypes = [vp]
     L.masp_hip_host_alloc.argtypes = [vp, sz]
     L.masp_hip_host_alloc.restype = vp
@@ -365,6 +366,12 @@ class Context:
 
     def profile_enable(self, on=True):
         self._check(self._L.masp_hip_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read_split(self):
+        """-> summed ms of the profiled bucket stages by kernel group: plan / records / copies, pass 1, shared inversions, pass 2, XYZZ accumulation"""
+        ms = (C.c_double * 8)()
+        self._check(self._L.masp_hip_profile_read_split(self._h, ms))
+        return dict(zip(("plan_records_copies", "k_tree_pass1", "k_binv", "k_tree_pass2", "k_msm_accumulate_pts"), [float(x) for x in ms[:5]]))
 
     def profile_read(self):
         """-> (summed k_msm_accumulate<G1> ms, launches, algorithmic bytes)"""
