@@ -12,7 +12,7 @@ echo "# built $out/libmasp_host.so with: g++ $FLAGS ; preloading $asan"
 # (leak checking off: CPython itself never frees everything; ASan still reports every invalid access and UBSan aborts on any UB)
 export ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
 LD_PRELOAD=$asan MASP_HOST_LIBRARY=$out/libmasp_host.so python -m pytest -q -m "not gpu" -p no:cacheprovider \
-    tests/test_circuits.py tests/test_host_api.py tests/test_binding_sig.py tests/test_subgroup_checks.py tests/test_pairing_program.py tests/test_params.py 2>&1 | tail -5
+    tests/test_circuits.py tests/test_host_api.py tests/test_host_fast_merkle.py tests/test_binding_sig.py tests/test_subgroup_checks.py tests/test_pairing_program.py tests/test_params.py 2>&1 | tail -5
 # the oracle (test infrastructure) the same way: its own build flags plus the sanitizers, into a scratch directory
 mkdir -p $out/oracle
 g++ -O1 -g -march=x86-64-v3 -std=c++17 -fPIC -pthread -shared -fsanitize=address,undefined -fno-sanitize-recover=undefined oracle/groth16_oracle.cpp -o $out/oracle/liboracle.so
