@@ -109,7 +109,10 @@ typedef struct {
                                         bytes, fewer proofs per second, never an error */
     int32_t bucket_tree_fallback_proofs; /* OUTPUT of masp_hip_ctx_get_options (ignored on input): proofs whose bucket runs went through
                                         the XYZZ accumulation for lack of tree scratch; bucket_tree_sub_batch there = the sub-batch in use now */
-    int32_t reserved[2];
+    int32_t lone_proof_graph;        /* 1: a batch of fewer than 8 proofs replays a captured HIP graph of its ~250 launches from its third
+                                        call on.  Default off: with ROCm 7.2 the replay of this five-stream graph takes 11.5 ms where the
+                                        launches enqueued one by one take 5.7 (profiles/r04_lone_proof_graph_ab.txt); the bytes are the same */
+    int32_t reserved[1];
 } masp_hip_options;
 void masp_hip_options_default(masp_hip_options* opt);
 
@@ -131,6 +134,9 @@ int masp_hip_ctx_device_count(const masp_hip_ctx* ctx);
 /* counts[d] = proofs written so far by device context d (d < min(cap, masp_hip_ctx_device_count)): lets a caller (and the
  * configs[4] test) see that a multi-device prover really deals its batches to all of its devices */
 int masp_hip_ctx_device_proofs(const masp_hip_ctx* ctx, uint64_t* counts, int cap);
+/* *out = calls of masp_hip_prove_batch groups so far that were replayed from a captured launch graph
+ * (masp_hip_options::lone_proof_graph); a caller that proves one description at a time sees it grow from its third proof on */
+int masp_hip_ctx_lone_graph_launches(const masp_hip_ctx* ctx, uint64_t* out);
 void masp_hip_ctx_destroy(masp_hip_ctx* ctx);
 const char* masp_hip_strerror(int code);
 /* last HIP runtime error text seen by this context ("" if none); the pointer belongs to the calling thread and stays
@@ -140,6 +146,13 @@ const char* masp_hip_last_error(const masp_hip_ctx* ctx);
 /* Parse `params` (bellman Parameters wire format; trailing bytes such as the MPC transcript are ignored),
  * check the length invariants against `cs`, upload the CRS and build the window tables. */
 int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* params, size_t params_len, const masp_hip_r1cs* cs);
+/* What the loader found out about the circuit in `slot` (MASP_HIP_E_NOT_LOADED if empty).  *flags:
+ *   bit 0  alpha_g1, beta_g1, delta_g1 and every a / b_g1 query point lie in the prime-order subgroup: the multiplications
+ *          s*A and r*B1 of every proof go through the curve endomorphism (half the doublings).  Clear for a CRS with a curve
+ *          point outside the subgroup — Parameters::read(_, false) does not look, lib.rs:343-347 — whose proofs then come from
+ *          the plain double-and-add, with the bytes the reference computes. */
+#define MASP_HIP_CIRCUIT_G1_ENDOMORPHISM 1u
+int masp_hip_circuit_flags(const masp_hip_ctx* ctx, uint32_t slot, uint32_t* flags);
 
 /* One proof, blocking.  proof_out: 192 bytes = A (48, G1 compressed) | B (96, G2 compressed) | C (48). */
 int masp_hip_prove(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* inputs, const uint8_t* aux, const uint8_t* a,

@@ -1109,6 +1109,7 @@ struct FpOps {
     typedef FpMulCold Cold;
     typedef FpOps Base;                     // the ops of the stored element (see Fp2PairOps)
     static constexpr uint32_t LANES = 1;    // lanes that hold one element
+    static constexpr bool REPLICATED = false;   // see FpQuadOps
     static MASP_HD T zero() { return fe_zero<FpCfg>(); }
     static MASP_HD T one() { return fe_one<FpCfg>(); }
     static MASP_HD T add(const T& a, const T& b) { return fe_add(a, b); }
@@ -1123,11 +1124,19 @@ struct FpOps {
     static MASP_HD T inv_lone(const T& a) { return fe_inv_bingcd_nc(a); }  // for single-lane serial tails
     static MASP_HD T inv_gcd(const T& a) { return fe_inv_bingcd(a); }   // for a few thousand lanes each inverting one value
 };
+// FpOps for code written over O::LANES lanes per point, with FOUR lanes per G1 point: every lane of a quad holds the whole
+// element (REPLICATED: loads read it four times, one lane stores it) and the point operations spread their independent
+// products over the quad (device/quad.cuh).  Field operations on their own are FpOps's, done redundantly by the four lanes.
+struct FpQuadOps : FpOps {
+    static constexpr uint32_t LANES = 4;
+    static constexpr bool REPLICATED = true;
+};
 struct Fp2Ops {
     typedef Fp2 T;
     typedef Fp2Ops Cold;  // already call-based
     typedef Fp2Ops Base;
     static constexpr uint32_t LANES = 1;
+    static constexpr bool REPLICATED = false;   // see FpQuadOps
     static MASP_HD T zero() { return {fe_zero<FpCfg>(), fe_zero<FpCfg>()}; }
     static MASP_HD T one() { return {fe_one<FpCfg>(), fe_zero<FpCfg>()}; }
     static MASP_HD T add(const T& a, const T& b) { return {fe_add(a.c0, b.c0), fe_add(a.c1, b.c1)}; }
@@ -1252,6 +1261,7 @@ struct Fp2PairOps {
     typedef Fp2Ops Base;
     typedef Fp2PairCold Cold;
     static constexpr uint32_t LANES = 2;
+    static constexpr bool REPLICATED = false;   // see FpQuadOps
     static __device__ __forceinline__ uint32_t half() { return Fp2PairLanes::half(); }
     static __device__ __forceinline__ T partner(const T& a) { return Fp2PairLanes::partner(a); }
     static __device__ __forceinline__ T zero() { return fe_zero<FpCfg>(); }

@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 
 #include "curve.cuh"
+#include "subgroup.cuh"
+#include "quad.cuh"
 #include "fr_io.cuh"
 #include "io.cuh"
 
@@ -39,75 +41,7 @@ __device__ __forceinline__ Xyzz<O> xyzz_fixed_mul(const Xyzz<O>* __restrict__ ta
     return acc;
 }
 
-// ---- four lanes, one point ------------------------------------------------------------------------------
-// The only long serial chain of a proof is the pair of variable-base multiplications of the assembly (252 doublings
-// each).  A lone wave spends 1.3 us per 384-bit product (its issue time: tools/ubench.hip), so the chain is cut by giving every
-// point operation to FOUR adjacent lanes: all four hold the same point, each computes a different product of the same dependency
-// level (one product site, different operands per lane), and the results are exchanged by DPP quad broadcasts.  A doubling is 3
-// levels instead of 9 products, an addition 4 instead of 14.  `lig` = lane in group (0..3).
-// lane `lig` of the group takes a_lig.  Written with lane masks (0 / ~0), not selects: the compiler turns a chain of selects
-// over twelve limbs into divergent branches of moves (550 v_mov and 50 branches per product level, more than the product)
-__device__ __forceinline__ Fp coop_pick(uint32_t lig, const Fp& a0, const Fp& a1, const Fp& a2, const Fp& a3) {
-    const uint32_t m0 = 0u - (uint32_t)(lig == 0), m1 = 0u - (uint32_t)(lig == 1), m2 = 0u - (uint32_t)(lig == 2), m3 = 0u - (uint32_t)(lig == 3);
-    Fp r;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) r.v[i] = (a0.v[i] & m0) | (a1.v[i] & m1) | (a2.v[i] & m2) | (a3.v[i] & m3);
-    return r;
-}
-// the value lane SRC of this 4-lane group holds: a DPP quad broadcast (a register move per limb; the LDS shuffle this replaced
-// cost more than the product it fed)
-template <int SRC>
-__device__ __forceinline__ Fp coop_from(const Fp& v) {
-    Fp r;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)v.v[i], SRC * 0x55 /* quad_perm [SRC, SRC, SRC, SRC] */, 0xf, 0xf, true);
-    return r;
-}
-// dbl-2008-s-1, same case analysis as xyzz_dbl
-__device__ __forceinline__ G1Xyzz xyzz_dbl_coop(const G1Xyzz& p, uint32_t lig) {
-    if (xyzz_is_inf(p)) return p;
-    Fp U = fe_dbl(p.Y);
-    if (fe_is_zero(U)) return xyzz_inf<FpOps>();
-    Fp t = fe_mul(coop_pick(lig, U, p.X, U, U), coop_pick(lig, U, p.X, U, U));  // V = U^2 | X^2
-    const Fp V = coop_from<0>(t), X2 = coop_from<1>(t);
-    const Fp M = fe_add(fe_dbl(X2), X2);
-    t = fe_mul(coop_pick(lig, U, p.X, M, V), coop_pick(lig, V, V, M, p.ZZ));      // W = U V | S = X V | M^2 | ZZ' = V ZZ
-    const Fp W = coop_from<0>(t), S = coop_from<1>(t), MM = coop_from<2>(t);
-    G1Xyzz r;
-    r.ZZ = coop_from<3>(t);
-    r.X = fe_sub(MM, fe_dbl(S));
-    t = fe_mul(coop_pick(lig, W, M, W, W), coop_pick(lig, p.Y, fe_sub(S, r.X), p.ZZZ, W));  // W Y | M (S - X') | ZZZ' = W ZZZ
-    r.Y = fe_sub(coop_from<1>(t), coop_from<0>(t));
-    r.ZZZ = coop_from<2>(t);
-    return r;
-}
-// add-2008-s, same case analysis as xyzz_add (the rare P == +-Q cases are computed redundantly by the four lanes)
-__device__ __forceinline__ void xyzz_add_coop(G1Xyzz& acc, const G1Xyzz& b, uint32_t lig) {
-    if (xyzz_is_inf(b)) return;
-    if (xyzz_is_inf(acc)) {
-        acc = b;
-        return;
-    }
-    Fp t = fe_mul(coop_pick(lig, acc.X, b.X, acc.Y, b.Y), coop_pick(lig, b.ZZ, acc.ZZ, b.ZZZ, acc.ZZZ));
-    const Fp U1 = coop_from<0>(t), U2 = coop_from<1>(t), S1 = coop_from<2>(t), S2 = coop_from<3>(t);
-    const Fp P = fe_sub(U2, U1), R = fe_sub(S2, S1);
-    if (fe_is_zero(P)) {
-        if (fe_is_zero(R))
-            acc = xyzz_dbl(acc);
-        else
-            acc = xyzz_inf<FpOps>();
-        return;
-    }
-    t = fe_mul(coop_pick(lig, P, R, acc.ZZ, acc.ZZZ), coop_pick(lig, P, R, b.ZZ, b.ZZZ));  // PP | R^2 | ZZ1 ZZ2 | ZZZ1 ZZZ2
-    const Fp PP = coop_from<0>(t), RR = coop_from<1>(t), Z12 = coop_from<2>(t), Z123 = coop_from<3>(t);
-    t = fe_mul(coop_pick(lig, P, U1, Z12, P), PP);                                       // PPP | Q | ZZ3
-    const Fp PPP = coop_from<0>(t), Q = coop_from<1>(t);
-    acc.ZZ = coop_from<2>(t);
-    acc.X = fe_sub(fe_sub(RR, PPP), fe_dbl(Q));
-    t = fe_mul(coop_pick(lig, S1, R, Z123, S1), coop_pick(lig, PPP, fe_sub(Q, acc.X), PPP, PPP));  // S1 PPP | R (Q - X3) | ZZZ3
-    acc.Y = fe_sub(coop_from<1>(t), coop_from<0>(t));
-    acc.ZZZ = coop_from<2>(t);
-}
+// four lanes per point (xyzz_dbl_coop, xyzz_add_coop): device/quad.cuh
 
 // Proof assembly:
 //   g_a = r*delta1 + alpha1 + A
@@ -185,13 +119,50 @@ __global__ void __launch_bounds__(64) k_groth16_fixed_g2(const G2Xyzz* __restric
         q[6 + h] = acc.ZZZ;
     }
 }
+// k = q u^2 + rem, rem < u^2 < 2^128 (u^2 = FpCfg::U_SQR), by binary long division; q < 2^128 for every k < 2^255 (u^2 > 2^127)
+__device__ __forceinline__ void endo_split(const uint32_t* k, uint32_t* q, uint32_t* rem) {
+    uint32_t r[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) q[i] = 0;
+    for (int i = 255; i >= 0; --i) {
+        for (int j = 4; j > 0; --j) r[j] = (r[j] << 1) | (r[j - 1] >> 31);
+        r[0] = (r[0] << 1) | ((k[i >> 5] >> (i & 31)) & 1u);
+        // r >= u^2 ?  (r < 2 u^2 < 2^129: five words)
+        bool ge = r[4] != 0;
+        if (!ge) {
+            ge = true;
+            for (int j = 3; j >= 0; --j)
+                if (r[j] != FpCfg::U_SQR[j]) {
+                    ge = r[j] > FpCfg::U_SQR[j];
+                    break;
+                }
+        }
+        if (ge) {
+            uint64_t borrow = 0;
+            for (int j = 0; j < 4; ++j) {
+                const uint64_t d = (uint64_t)r[j] - FpCfg::U_SQR[j] - borrow;
+                r[j] = (uint32_t)d;
+                borrow = (d >> 32) & 1u;
+            }
+            r[4] -= (uint32_t)borrow;
+            if (i < 128) q[i >> 5] |= 1u << (i & 31);
+        }
+    }
+    for (int i = 0; i < 4; ++i) rem[i] = r[i];
+}
 // WHICH = 0: s*A -> part[3];  1: r*B1 -> part[4].  Lanes 0..15 build the table d*P (d < 16) in LDS, then lanes 0..3 run
-// 4-bit fixed windows (252 doublings + <= 64 additions, four lanes per point; exact for any curve point: no endomorphism,
-// the CRS is read unchecked like the reference's)
+// 4-bit fixed windows, four lanes per point.
+// endo != 0 (every CRS point that A and B1 are sums of lies in the prime-order subgroup: checked once, when the circuit is
+// loaded — k_g1_subgroup_flag): k = q u^2 + rem and [u^2] P = -phi(P) = (beta x, -y) on the subgroup (subgroup.cuh), so
+// [k] P = [rem] P + [q] (beta x, -y) with two 128-bit scalars over ONE chain of 124 doublings and <= 64 additions — the
+// table of (beta x, -y) is the table of P with X scaled and Y negated.  This multiplication is the tail of the two longest
+// chains of a lone proof (2.1 ms of 252 dependent doublings; 1.3 ms this way).
+// endo == 0: 252 doublings + <= 64 additions, exact for ANY curve point — the reference reads the CRS unchecked
+// (Parameters::read(_, false), /root/reference/masp_proofs/src/lib.rs:343-347) and a point of the curve outside the
+// subgroup must give the bytes the reference's plain double-and-add gives.
 // (gridDim.y = 2 runs both: WHICH = which0 + blockIdx.y)
 __global__ void __launch_bounds__(64) k_groth16_var_mul(uint32_t which0, const G1Xyzz* __restrict__ msm_g1 /* H, L, A, B1 */,
-                                                        const uint32_t* __restrict__ rs, size_t rs_stride, G1Xyzz* __restrict__ part) {
-    __shared__ G1Xyzz wtab[16];
+                                                        const uint32_t* __restrict__ rs, size_t rs_stride, G1Xyzz* __restrict__ part, int endo) {
+    __shared__ G1Xyzz wtab[32];
     const uint32_t tid = threadIdx.x, WHICH = which0 + blockIdx.y;
     msm_g1 += (size_t)blockIdx.x * 4;
     rs += (size_t)blockIdx.x * rs_stride + (WHICH == 0 ? 8 : 0);
@@ -204,6 +175,13 @@ __global__ void __launch_bounds__(64) k_groth16_var_mul(uint32_t which0, const G
             if ((tid >> b) & 1) xyzz_add_nc(t, P);
         }
         wtab[tid] = t;
+        if (endo) {  // wtab[16 + d] = d * [u^2] P
+            Fp beta;
+            for (int i = 0; i < 12; ++i) beta.v[i] = FpCfg::ENDO_BETA[i];
+            t.X = fe_mul(t.X, beta);
+            t.Y = fe_neg(t.Y);
+            wtab[16 + tid] = t;
+        }
     }
     // same wave writes and reads the table: LDS is in order per wave, only the compiler must not reorder
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -214,14 +192,34 @@ __global__ void __launch_bounds__(64) k_groth16_var_mul(uint32_t which0, const G
         uint32_t k[8];
         for (int i = 0; i < 8; ++i) k[i] = rs[i];
         G1Xyzz acc = xyzz_inf<FpOps>();
-        for (int w = 63; w >= 0; --w) {
-            if (w != 63)
-                for (int q = 0; q < 4; ++q) acc = xyzz_dbl_coop(acc, lig);
-            const uint32_t d = (k[w >> 3] >> (4 * (w & 7))) & 15u;
-            if (d) xyzz_add_coop(acc, wtab[d], lig);
+        if (endo) {
+            uint32_t q[4], rem[4];
+            endo_split(k, q, rem);
+            for (int w = 31; w >= 0; --w) {
+                if (w != 31)
+                    for (int j = 0; j < 4; ++j) acc = xyzz_dbl_coop(acc, lig);
+                const uint32_t d0 = (rem[w >> 3] >> (4 * (w & 7))) & 15u, d1 = (q[w >> 3] >> (4 * (w & 7))) & 15u;
+                if (d0) xyzz_add_coop(acc, wtab[d0], lig);
+                if (d1) xyzz_add_coop(acc, wtab[16 + d1], lig);
+            }
+        } else {
+            for (int w = 63; w >= 0; --w) {
+                if (w != 63)
+                    for (int j = 0; j < 4; ++j) acc = xyzz_dbl_coop(acc, lig);
+                const uint32_t d = (k[w >> 3] >> (4 * (w & 7))) & 15u;
+                if (d) xyzz_add_coop(acc, wtab[d], lig);
+            }
         }
         if (lig == 0) part[3 + WHICH] = acc;
     }
+}
+// *flag |= 1 if any of the n points (affine, `stride` bytes apart, infinity skipped) lies outside the prime-order subgroup
+__global__ void __launch_bounds__(64) k_g1_subgroup_flag(const uint8_t* __restrict__ pts, size_t stride, uint32_t n, int* __restrict__ flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const G1Affine p = *reinterpret_cast<const G1Affine*>(pts + (size_t)i * stride);
+    if (fe_is_zero(p.x) && fe_is_zero(p.y)) return;
+    if (!g1_in_subgroup(p)) atomicOr(flag, 1);
 }
 // one lane: g_b = s*delta2 + beta2 + B2, normalised and encoded
 __global__ void __launch_bounds__(64) k_groth16_finish_b(const VkDevice* __restrict__ vk, const G2Xyzz* __restrict__ part2,

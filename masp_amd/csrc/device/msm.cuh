@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include "curve.cuh"
+#include "quad.cuh"
 #include "io.cuh"
 #include "msm_geom.h"
 
@@ -84,21 +85,30 @@ __global__ void __launch_bounds__(64) k_msm_precompute(TabRow<O>* __restrict__ t
 // coordinates, the odd lane the c1 halves — G2 at the register footprint of G1).  A stored point is Xyzz<O::Base>.
 template <class O>
 __device__ __forceinline__ Xyzz<O> xyzz_load(const Xyzz<typename O::Base>* __restrict__ p, uint32_t h) {
-    const typename O::T* q = reinterpret_cast<const typename O::T*>(p);
-    Xyzz<O> r;
-    r.X = q[h];
-    r.Y = q[O::LANES + h];
-    r.ZZ = q[2 * O::LANES + h];
-    r.ZZZ = q[3 * O::LANES + h];
-    return r;
+    if constexpr (O::REPLICATED) {  // every lane of the group holds the whole point
+        const Xyzz<typename O::Base> v = *p;
+        return reinterpret_cast<const Xyzz<O>&>(v);
+    } else {
+        const typename O::T* q = reinterpret_cast<const typename O::T*>(p);
+        Xyzz<O> r;
+        r.X = q[h];
+        r.Y = q[O::LANES + h];
+        r.ZZ = q[2 * O::LANES + h];
+        r.ZZZ = q[3 * O::LANES + h];
+        return r;
+    }
 }
 template <class O>
 __device__ __forceinline__ void xyzz_store(Xyzz<typename O::Base>* __restrict__ p, const Xyzz<O>& v, uint32_t h) {
-    typename O::T* q = reinterpret_cast<typename O::T*>(p);
-    q[h] = v.X;
-    q[O::LANES + h] = v.Y;
-    q[2 * O::LANES + h] = v.ZZ;
-    q[3 * O::LANES + h] = v.ZZZ;
+    if constexpr (O::REPLICATED) {
+        if (h == 0) *p = reinterpret_cast<const Xyzz<typename O::Base>&>(v);
+    } else {
+        typename O::T* q = reinterpret_cast<typename O::T*>(p);
+        q[h] = v.X;
+        q[O::LANES + h] = v.Y;
+        q[2 * O::LANES + h] = v.ZZ;
+        q[3 * O::LANES + h] = v.ZZZ;
+    }
 }
 // launch with 64 lanes per workgroup: 64 / LANES buckets
 template <class O>
@@ -264,6 +274,40 @@ __global__ void __launch_bounds__(64) k_msm_combine(const Xyzz<O>* __restrict__ 
         xyzz_add_nc(acc, tsum[l]);
     }
     *out = acc;
+}
+
+// The same two kernels over O::LANES lanes per point (a lone proof's G1 tails: FpQuadOps) — 256 points per workgroup, one point.
+template <class O>
+__global__ void __launch_bounds__(256 * O::LANES) k_xyzz_reduce_block_lanes(const Xyzz<typename O::Base>* __restrict__ in, size_t in_stride, uint32_t n,
+                                                                            Xyzz<typename O::Base>* __restrict__ out, size_t out_stride) {
+    extern __shared__ uint4 wsum_lds[];
+    Xyzz<typename O::Base>* sh = reinterpret_cast<Xyzz<typename O::Base>*>(wsum_lds);
+    const uint32_t e = threadIdx.x / O::LANES, h = threadIdx.x % O::LANES;
+    in += MSM_P * in_stride;
+    out += MSM_P * out_stride;
+    const uint32_t k = blockIdx.x * 256 + e;
+    Xyzz<O> y = k < n ? xyzz_load<O>(in + k, h) : xyzz_inf<O>();
+    for (uint32_t d = 128; d >= 1; d >>= 1) {
+        xyzz_store<O>(sh + e, y, h);
+        __syncthreads();
+        if (e < d) xyzz_add_nc(y, xyzz_load<O>(sh + e + d, h));
+        __syncthreads();
+    }
+    if (e == 0) xyzz_store<O>(out + blockIdx.x, y, h);
+}
+template <class O>
+__global__ void __launch_bounds__(64) k_msm_combine_lanes(const Xyzz<typename O::Base>* __restrict__ tsum, int levels, int cs_log,
+                                                          Xyzz<typename O::Base>* __restrict__ out, size_t out_stride) {
+    if (blockIdx.x != 0 || threadIdx.x >= O::LANES) return;
+    const uint32_t h = threadIdx.x;
+    tsum += (size_t)MSM_P * 32;
+    out += MSM_P * out_stride;
+    Xyzz<O> acc = xyzz_inf<O>();
+    for (int l = levels - 1; l >= 0; --l) {
+        for (int k = 0; k < cs_log; ++k) acc = xyzz_dbl(acc);
+        xyzz_add_nc(acc, xyzz_load<O>(tsum + l, h));
+    }
+    xyzz_store<O>(out, acc, h);
 }
 
 }  // namespace masp

@@ -30,14 +30,14 @@ struct DevBuf {
     size_t cap = 0;
     ~DevBuf() { release(); }
     void release() {
-        if (p) hipFree(p);
+        if (p) dev_free(p);
         p = nullptr;
         cap = 0;
     }
     int reserve(size_t n) {
         if (n <= cap) return MASP_HIP_OK;
         release();
-        HIP_TRY(hipMalloc(&p, sizeof(T) * std::max<size_t>(n, 1)));
+        HIP_TRY(dev_malloc(&p, sizeof(T) * std::max<size_t>(n, 1)));
         cap = n;
         return MASP_HIP_OK;
     }
@@ -121,6 +121,10 @@ struct Circuit {
     // a lone proof (every G2 addition is 40 dependent 384-bit products on one lane), and with 128 instead of 2 048 buckets
     // the gather / weighted-sum levels nearly vanish for 45 % more (chip-filling) accumulation work; n = 0: not built
     BasesG2 b2_lone;
+    // alpha_g1, beta_g1, delta_g1 and every point of the a / b_g1 queries lie in the prime-order subgroup (tested when the
+    // circuit is loaded): s*A and r*B1 may then go through the endomorphism (k_groth16_var_mul).  A CRS with a curve point
+    // outside the subgroup — the reference reads it unchecked — keeps the plain double-and-add, whose bytes are the reference's
+    bool g1_endo = false;
     NttDomain* dom = nullptr;
 };
 
@@ -151,7 +155,30 @@ struct Slot {
     uint8_t* h_proof = nullptr;  // pinned, batch_cap x 192
     size_t h_proof_cap = 0;
     int* h_flags = nullptr;      // pinned
+    // Launch graphs of lone proofs (prover.hip: enqueue_proofs_graphed; opt-in).  The ~250 launches of one proof take the
+    // host about as long to enqueue as the GPU takes to run them; captured once per (circuit, buffers, form) they replay as
+    // one hipGraphLaunch.  A graph holds raw pointers into workspaces that grow on demand: `graph_epoch` is the value of
+    // device_alloc_epoch() it was captured under, and any later allocation or release drops every graph of the slot.
+    struct LoneGraph {
+        const void *circuit, *w, *abc, *rs, *proof;
+        size_t w_stride;
+        uint32_t np;
+        bool mont;
+        int runs;                // ungraphed runs so far (the first one sizes every buffer)
+        bool dead;               // capture failed once: not tried again
+        hipGraphExec_t exec;
+    };
+    std::vector<LoneGraph> graphs;
+    uint64_t graph_epoch = 0;
+    bool lone_graph = false;     // masp_hip_options::lone_proof_graph
+    std::atomic<uint64_t> graph_launches{0};
+    void drop_graphs() {
+        for (auto& g : graphs)
+            if (g.exec) hipGraphExecDestroy(g.exec);
+        graphs.clear();
+    }
     ~Slot() {
+        drop_graphs();
         if (stream) hipStreamDestroy(stream);
         if (done) hipEventDestroy(done);
         for (int i = 0; i < N_AUX; ++i) {
@@ -174,6 +201,7 @@ struct Slot {
         ws1.tree_sub = ws2.tree_sub = (uint32_t)o.bucket_tree_sub_batch;
         ws2.tree.arena = &ws1.tree.own;   // the G1 and G2 MSMs of a batch follow each other on the slot's stream: one tree arena
         ws1.tree.own.limit = (size_t)o.bucket_tree_scratch_mb << 20;
+        lone_graph = o.lone_proof_graph > 0;
     }
     int init() {
         HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));

@@ -13,8 +13,11 @@ void launch_groth16_fixed_g2(hipStream_t s, const G2Xyzz* fb2, const uint32_t* r
     MASP_LAUNCH(k_groth16_fixed_g2, dim3(np), dim3(64), 0, s, fb2, rs, rs_stride, part2);
 }
 // which = 0: s*A, 1: r*B1, 2: both in one launch
-void launch_groth16_var_mul(hipStream_t s, int which, const G1Xyzz* msm_g1, const uint32_t* rs, size_t rs_stride, G1Xyzz* part, uint32_t np) {
-    MASP_LAUNCH(k_groth16_var_mul, dim3(np, which == 2 ? 2 : 1), dim3(64), 0, s, which == 1 ? 1u : 0u, msm_g1, rs, rs_stride, part);
+void launch_groth16_var_mul(hipStream_t s, int which, const G1Xyzz* msm_g1, const uint32_t* rs, size_t rs_stride, G1Xyzz* part, uint32_t np, bool endo) {
+    MASP_LAUNCH(k_groth16_var_mul, dim3(np, which == 2 ? 2 : 1), dim3(64), 0, s, which == 1 ? 1u : 0u, msm_g1, rs, rs_stride, part, endo ? 1 : 0);
+}
+void launch_g1_subgroup_flag(hipStream_t s, const void* pts, size_t stride_bytes, uint32_t n, int* flag) {
+    if (n) MASP_LAUNCH(k_g1_subgroup_flag, dim3((n + 63) / 64), dim3(64), 0, s, reinterpret_cast<const uint8_t*>(pts), stride_bytes, n, flag);
 }
 void launch_groth16_finish_b(hipStream_t s, const VkDevice* vk, const G2Xyzz* part2, const G2Xyzz* msm_g2, uint8_t* proof, uint32_t np) {
     MASP_LAUNCH(k_groth16_finish_b, dim3(np), dim3(64), 0, s, vk, part2, msm_g2, proof);

@@ -37,7 +37,10 @@ void launch_gather_scalars(hipStream_t s, const Fr* src, size_t src_stride, cons
 // ---- k_groth16.hip: proof assembly, point import / export, fixed-base tables (device/groth16.cuh) ----
 void launch_groth16_fixed_g1(hipStream_t s, const G1Xyzz* fb1, const uint32_t* rs, size_t rs_stride, G1Xyzz* part, uint32_t np);
 void launch_groth16_fixed_g2(hipStream_t s, const G2Xyzz* fb2, const uint32_t* rs, size_t rs_stride, G2Xyzz* part2, uint32_t np);
-void launch_groth16_var_mul(hipStream_t s, int which, const G1Xyzz* msm_g1, const uint32_t* rs, size_t rs_stride, G1Xyzz* part, uint32_t np);
+// endo: Circuit::g1_endo (the points behind A and B1 all lie in the prime-order subgroup: half as many doublings)
+void launch_groth16_var_mul(hipStream_t s, int which, const G1Xyzz* msm_g1, const uint32_t* rs, size_t rs_stride, G1Xyzz* part, uint32_t np, bool endo);
+// *flag |= 1 if one of n affine G1 points, stride_bytes apart, is outside the prime-order subgroup (infinity skipped)
+void launch_g1_subgroup_flag(hipStream_t s, const void* pts, size_t stride_bytes, uint32_t n, int* flag);
 void launch_groth16_finish_b(hipStream_t s, const VkDevice* vk, const G2Xyzz* part2, const G2Xyzz* msm_g2, uint8_t* proof, uint32_t np);
 void launch_groth16_finish_ac(hipStream_t s, const VkDevice* vk, const G1Xyzz* part, const G1Xyzz* msm_g1, uint8_t* proof, uint32_t np);
 void launch_g1_export(hipStream_t s, const G1Xyzz* p, uint8_t* out);

@@ -26,7 +26,7 @@ struct MsmBases {
 
     ~MsmBases() { release(); }
     void release() {
-        if (tab) hipFree(tab);
+        if (tab) dev_free(tab);
         tab = nullptr;
     }
     // Window width by the number of scalars expected to be neither 0 nor 1 (`n_eff`; the caller knows the witness
@@ -41,11 +41,11 @@ struct MsmBases {
     int load_host(const uint8_t* raw, uint32_t n_, hipStream_t s, uint32_t n_eff = 0xffffffffu, int force_c = 0) {
         uint8_t* d_raw = nullptr;
         if (n_) {
-            HIP_TRY(hipMalloc(&d_raw, (size_t)n_ * BYTES));
+            HIP_TRY(dev_malloc(&d_raw, (size_t)n_ * BYTES));
             HIP_TRY(hipMemcpyAsync(d_raw, raw, (size_t)n_ * BYTES, hipMemcpyHostToDevice, s));
         }
         int rc = load_device(d_raw, n_, s, n_eff, force_c);
-        if (d_raw) hipFree(d_raw);
+        if (d_raw) dev_free(d_raw);
         return rc;
     }
 };
@@ -76,7 +76,7 @@ struct MsmSortBuf {
     void release() {
         void* ptrs[] = {sorted, hist_wg, start, tmp, crel, dense};
         for (void* p : ptrs)
-            if (p) hipFree(p);
+            if (p) dev_free(p);
         sorted = hist_wg = start = tmp = crel = dense = nullptr;
         cap_ent = cap_nb = cap_np = cap_hist = cap_crel = 0;
     }
@@ -99,12 +99,12 @@ struct MsmSortBuf {
         const size_t need_crel = std::max(std::max(crel_need, cap_crel), rows * std::max<size_t>(need_nb >> 7, 1));
         release();  // (capacities are 0 from here on: a failed allocation below must not leave them claiming memory)
         auto alloc_all = [&]() -> int {
-            HIP_TRY(hipMalloc(&sorted, need_np * 4 * std::max<size_t>(need_ent, 1)));
-            HIP_TRY(hipMalloc(&hist_wg, 4 * need_hist));
-            HIP_TRY(hipMalloc(&start, need_np * 4 * (need_nb + 1)));
-            HIP_TRY(hipMalloc(&tmp, need_np * 4 * std::max<size_t>(need_ent, 1)));
-            HIP_TRY(hipMalloc(&crel, 4 * need_crel));
-            HIP_TRY(hipMalloc(&dense, need_np * 4 * (need_nb + 1)));
+            HIP_TRY(dev_malloc(&sorted, need_np * 4 * std::max<size_t>(need_ent, 1)));
+            HIP_TRY(dev_malloc(&hist_wg, 4 * need_hist));
+            HIP_TRY(dev_malloc(&start, need_np * 4 * (need_nb + 1)));
+            HIP_TRY(dev_malloc(&tmp, need_np * 4 * std::max<size_t>(need_ent, 1)));
+            HIP_TRY(dev_malloc(&crel, 4 * need_crel));
+            HIP_TRY(dev_malloc(&dense, need_np * 4 * (need_nb + 1)));
             return MASP_HIP_OK;
         };
         if (int rc = alloc_all()) {
@@ -133,7 +133,7 @@ struct MsmTreeArena {
     uint64_t refused = 0;   // reservations that did not fit
     ~MsmTreeArena() { release(); }
     void release() {
-        if (p) hipFree(p);
+        if (p) dev_free(p);
         p = nullptr;
         cap = 0;
     }
@@ -144,7 +144,7 @@ struct MsmTreeArena {
             return MASP_HIP_E_TREE_SCRATCH;
         }
         release();  // (capacity is 0 from here on: a failed allocation must not leave it claiming memory)
-        const hipError_t e = hipMalloc(&p, bytes);
+        const hipError_t e = dev_malloc(&p, bytes);
         if (e == hipErrorOutOfMemory) {
             (void)hipGetLastError();
             p = nullptr;
@@ -204,7 +204,7 @@ struct MsmWorkspace {
     void release() {
         void* ptrs[] = {heavy, n_heavy, part, bkt, S[0], S[1], T, R[0], R[1], tsum, startT};
         for (void* p : ptrs)
-            if (p) hipFree(p);
+            if (p) dev_free(p);
         heavy = n_heavy = startT = nullptr;
         part = bkt = S[0] = S[1] = T = R[0] = R[1] = tsum = nullptr;
         cap_nb = cap_np = cap_part = 0;
@@ -238,17 +238,17 @@ struct MsmWorkspace {
         const size_t P = need_np;
         size_t chunks = (need_nb + (1u << CS_LOG) - 1) >> CS_LOG;
         auto alloc_all = [&]() -> int {
-            HIP_TRY(hipMalloc(&heavy, P * 4 * need_nb));
-            HIP_TRY(hipMalloc(&n_heavy, P * 4));
-            HIP_TRY(hipMalloc(&part, sizeof(Xyzz<O>) * need_part));
-            HIP_TRY(hipMalloc(&bkt, P * sizeof(Xyzz<O>) * need_nb));
-            HIP_TRY(hipMalloc(&S[0], P * sizeof(Xyzz<O>) * chunks));
-            HIP_TRY(hipMalloc(&S[1], P * sizeof(Xyzz<O>) * chunks));
-            HIP_TRY(hipMalloc(&T, P * sizeof(Xyzz<O>) * chunks));
-            HIP_TRY(hipMalloc(&R[0], P * sizeof(Xyzz<O>) * chunks));
-            HIP_TRY(hipMalloc(&R[1], P * sizeof(Xyzz<O>) * chunks));
-            HIP_TRY(hipMalloc(&tsum, P * sizeof(Xyzz<O>) * 32));
-            HIP_TRY(hipMalloc(&startT, P * 4 * (need_nb + 1)));
+            HIP_TRY(dev_malloc(&heavy, P * 4 * need_nb));
+            HIP_TRY(dev_malloc(&n_heavy, P * 4));
+            HIP_TRY(dev_malloc(&part, sizeof(Xyzz<O>) * need_part));
+            HIP_TRY(dev_malloc(&bkt, P * sizeof(Xyzz<O>) * need_nb));
+            HIP_TRY(dev_malloc(&S[0], P * sizeof(Xyzz<O>) * chunks));
+            HIP_TRY(dev_malloc(&S[1], P * sizeof(Xyzz<O>) * chunks));
+            HIP_TRY(dev_malloc(&T, P * sizeof(Xyzz<O>) * chunks));
+            HIP_TRY(dev_malloc(&R[0], P * sizeof(Xyzz<O>) * chunks));
+            HIP_TRY(dev_malloc(&R[1], P * sizeof(Xyzz<O>) * chunks));
+            HIP_TRY(dev_malloc(&tsum, P * sizeof(Xyzz<O>) * 32));
+            HIP_TRY(dev_malloc(&startT, P * 4 * (need_nb + 1)));
             return MASP_HIP_OK;
         };
         if (int rc = alloc_all()) {
@@ -265,6 +265,9 @@ struct MsmWorkspace {
     // Workgroup tree reductions (fan-in 256, 8 dependent additions per pass).                      [msm_impl.cuh]
     void reduce_to_one(hipStream_t s, uint32_t np, const Xyzz<O>* src, size_t src_stride, uint32_t m, Xyzz<O>* dst, size_t dst_stride,
                        size_t r_stride);
+    // the same over OT::LANES lanes per point (FpQuadOps: a lone proof)
+    template <class OT>
+    void reduce_to_one_lanes(hipStream_t s, uint32_t np, const Xyzz<O>* src, size_t src_stride, uint32_t m, Xyzz<O>* dst, size_t dst_stride, size_t r_stride);
 };
 
 // Optional live timing of the dominant kernel (bucket accumulation) with HIP events on the launching stream.

@@ -16,6 +16,11 @@ struct TailLaneOps {
     typedef typename std::conditional<(MASP_G2_PAIR_TAILS) != 0 && std::is_same<O, Fp2Ops>::value, Fp2PairOps, O>::type type;
 };
 
+template <class OT>
+struct TailTag {
+    typedef OT type;
+};
+
 static inline uint32_t log2_ceil_u64(uint64_t n) {
     uint32_t k = 0;
     while ((1ull << k) < n) ++k;
@@ -29,16 +34,16 @@ int MsmBases<O, BYTES>::load_device(const uint8_t* d_raw, uint32_t n_, hipStream
         this->n_eff = std::min(n_eff, n_);
         g = force_c ? msm_geom(force_c) : pick_geom(std::min(n_eff, n_));
         if (n == 0) return MASP_HIP_OK;
-        HIP_TRY(hipMalloc(&tab, sizeof(TabRow<O>) * (size_t)g.W * n));
+        HIP_TRY(dev_malloc(&tab, sizeof(TabRow<O>) * (size_t)g.W * n));
         int* d_status;
-        HIP_TRY(hipMalloc(&d_status, sizeof(int)));
+        HIP_TRY(dev_malloc(&d_status, sizeof(int)));
         HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(int), s));
         dim3 grid((n + 63) / 64), block(64);
         MASP_LAUNCH((k_msm_import<O, BYTES>), grid, block, 0, s, d_raw, tab, n, d_status);
         MASP_LAUNCH((k_msm_precompute<O>), grid, block, 0, s, tab, n, g.c, g.W);
         HIP_TRY(hipMemcpyAsync(&import_status, d_status, sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        hipFree(d_status);
+        dev_free(d_status);
         return MASP_HIP_OK;
     }
 
@@ -53,6 +58,26 @@ void MsmWorkspace<O>::reduce_to_one(hipStream_t s, uint32_t np, const Xyzz<O>* s
             Xyzz<O>* out = outn == 1 ? dst : R[flip];
             size_t out_stride = outn == 1 ? dst_stride : r_stride;
             MASP_LAUNCH((k_xyzz_reduce_block<O>), dim3(outn, np), dim3(256), 256 * sizeof(Xyzz<O>), s, cur, cur_stride, m, out, out_stride);
+            if (outn == 1) break;
+            cur = out;
+            cur_stride = out_stride;
+            m = outn;
+            flip ^= 1;
+        }
+    }
+
+template <class O>
+template <class OT>
+void MsmWorkspace<O>::reduce_to_one_lanes(hipStream_t s, uint32_t np, const Xyzz<O>* src, size_t src_stride, uint32_t m, Xyzz<O>* dst, size_t dst_stride,
+                                          size_t r_stride) {
+        int flip = 0;
+        const Xyzz<O>* cur = src;
+        size_t cur_stride = src_stride;
+        while (true) {
+            uint32_t outn = (m + 255) / 256;
+            Xyzz<O>* out = outn == 1 ? dst : R[flip];
+            size_t out_stride = outn == 1 ? dst_stride : r_stride;
+            MASP_LAUNCH((k_xyzz_reduce_block_lanes<OT>), dim3(outn, np), dim3(256 * OT::LANES), 256 * sizeof(Xyzz<O>), s, cur, cur_stride, m, out, out_stride);
             if (outn == 1) break;
             cur = out;
             cur_stride = out_stride;
@@ -149,7 +174,8 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
     // end).  A lone proof keeps span 12 and four waves (shortest chain for its one big bucket).
     // Workgroups go to the 8 XCDs round-robin by linear id x + gridDim.x * y, so with gridDim.x a multiple of 8 every proof's
     // first working workgroup (x = 0: bucket 0) would land on the same XCD: keep gridDim.x odd.
-    typedef typename TailLaneOps<O>::type OT;
+    auto tails = [&](auto tag) {
+    typedef typename decltype(tag)::type OT;
     constexpr uint32_t LN = OT::LANES;
     MASP_LAUNCH((k_msm_bucket_gather<OT>), dim3((nb * LN + 63) / 64, np), dim3(64), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy,
                        ws.n_heavy, lone ? 12u : 8u);
@@ -187,7 +213,10 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
             MASP_WSUM_CASE(0) MASP_WSUM_CASE(2) MASP_WSUM_CASE(3) MASP_WSUM_CASE(4) MASP_WSUM_CASE(5) MASP_WSUM_CASE(6)
 #undef MASP_WSUM_CASE
         }
-        ws.reduce_to_one(s, np, ws.T, st_stride, chunks, ws.tsum + level, 32, st_stride);
+        if constexpr (OT::REPLICATED)
+            ws.template reduce_to_one_lanes<OT>(s, np, ws.T, st_stride, chunks, ws.tsum + level, 32, st_stride);
+        else
+            ws.reduce_to_one(s, np, ws.T, st_stride, chunks, ws.tsum + level, 32, st_stride);
         bk = ws.S[flip];
         bk_stride = st_stride;
         flip ^= 1;
@@ -195,7 +224,20 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
         off = 0;
         ++level;
     } while (m > 1);
-    MASP_LAUNCH((k_msm_combine<O>), dim3(1, np), dim3(64), 0, s, ws.tsum, level, (int)(g_log + WSUM_L_LOG), d_out, out_stride);
+    if constexpr (OT::REPLICATED)
+        MASP_LAUNCH((k_msm_combine_lanes<OT>), dim3(1, np), dim3(64), 0, s, ws.tsum, level, (int)(g_log + WSUM_L_LOG), d_out, out_stride);
+    else
+        MASP_LAUNCH((k_msm_combine<O>), dim3(1, np), dim3(64), 0, s, ws.tsum, level, (int)(g_log + WSUM_L_LOG), d_out, out_stride);
+    };
+    // a lone proof's G1 tails run over quads (device/quad.cuh): their chains of dependent additions are what it waits for
+    if constexpr (std::is_same<O, FpOps>::value) {
+        if (lone)
+            tails(TailTag<FpQuadOps>{});
+        else
+            tails(TailTag<FpOps>{});
+    } else {
+        tails(TailTag<typename TailLaneOps<O>::type>{});
+    }
     return launch_status();  // (a launch the runtime refused: MASP_LAUNCH, util.h)
 }
 

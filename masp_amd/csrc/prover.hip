@@ -8,6 +8,7 @@
 // MASP_HIP_E_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -48,6 +49,7 @@ static masp_hip_options resolve_options(const masp_hip_options* in) {
     o.bucket_tree_levels_g2 = o.bucket_tree_levels_g2 > 0 ? std::min<int>(o.bucket_tree_levels_g2, 12) : o.bucket_tree_levels_g2 < 0 ? -1 : o.bucket_tree_levels;
     o.bucket_tree_scratch_mb = std::max(o.bucket_tree_scratch_mb, 0);
     o.bucket_tree_fallback_proofs = 0;   // output only
+    o.lone_proof_graph = o.lone_proof_graph > 0 ? 1 : 0;   // off unless asked for: measured slower with ROCm 7.2's graph launch
     return o;
 }
 // [0, n) cut into ceil(n / cap) groups whose sizes differ by at most one: (first, count) pairs
@@ -242,7 +244,7 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
             int r;
             if (C.na) launch_gather_scalars(sl.aux[1], d_w, w_stride, C.a_var.p, C.na, sl.sa.p, np);
             if ((r = msm_enqueue(sl.aux[1], C.a, sl.ws_a, (const uint32_t*)sl.sa.p, (size_t)C.na * 8, sl.res1.p + 2, 4, np))) return r;
-            launch_groth16_var_mul(sl.aux[1], 0, sl.res1.p, d_rs, 16, sl.asm1.p, np);
+            launch_groth16_var_mul(sl.aux[1], 0, sl.res1.p, d_rs, 16, sl.asm1.p, np, C.g1_endo);
             return MASP_HIP_OK;
         };
         auto chain_b = [&]() -> int {
@@ -256,7 +258,7 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
             } else if ((r = msm_enqueue(sl.aux[2], C.b1, sl.ws_b, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res1.p + 3, 4, np))) {
                 return r;
             }
-            launch_groth16_var_mul(sl.aux[2], 1, sl.res1.p, d_rs, 16, sl.asm1.p, np);
+            launch_groth16_var_mul(sl.aux[2], 1, sl.res1.p, d_rs, 16, sl.asm1.p, np, C.g1_endo);
             HIP_TRY(hipStreamWaitEvent(sl.aux[3], sl.ev_sort_b, 0));
             if (own_b2) {
                 if ((r = msm_enqueue(sl.aux[3], C.b2_lone, sl.ws2, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res2.p, 1, np))) return r;
@@ -307,7 +309,7 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
     if (!lone) {
         launch_groth16_fixed_g1(s, C.fb1.p, d_rs, 16, sl.asm1.p, np);
         launch_groth16_fixed_g2(s, C.fb2.p, d_rs, 16, sl.asm2.p, np);
-        launch_groth16_var_mul(s, 2, sl.res1.p, d_rs, 16, sl.asm1.p, np);
+        launch_groth16_var_mul(s, 2, sl.res1.p, d_rs, 16, sl.asm1.p, np, C.g1_endo);
         launch_groth16_finish_b(s, C.vk.p, sl.asm2.p, sl.res2.p, d_proof, np);
     }
     launch_groth16_finish_ac(s, C.vk.p, sl.asm1.p, sl.res1.p, d_proof, np);
@@ -315,6 +317,63 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
         HIP_TRY(hipEventRecord(sl.ev_join[Slot::N_AUX - 1], sl.aux[Slot::N_AUX - 1]));
         HIP_TRY(hipStreamWaitEvent(s, sl.ev_join[Slot::N_AUX - 1], 0));
     }
+    return MASP_HIP_OK;
+}
+
+// enqueue_proofs for a batch of fewer than 8 proofs, replayed from a captured HIP graph once the same call has been seen
+// twice.  A lone Spend proof is ~250 launches on five streams: the host needs ~3 ms to enqueue what the GPU runs in 5 - 6 ms,
+// and the chain enqueued last starts that much late (profiles/r04z_lone_proof_timeline.txt); one hipGraphLaunch of the same
+// DAG does not.  The key is everything the launches' arguments are derived from: the circuit, the proof count, the slot's
+// buffers the caller passes and the form of the aux part; the workspaces inside (grown on demand) are covered by
+// device_alloc_epoch().  First call with a key: plain enqueue (sizes every buffer).  Second: captured (nothing runs), then
+// launched.  Any failure on the way — an allocation inside the capture, a runtime that refuses a node — marks the key dead
+// and the call is enqueued the plain way: never an error of its own.
+static int enqueue_proofs_graphed(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size_t w_stride, const Fr* const d_abc[3], const uint32_t* d_rs,
+                                  uint8_t* d_proof, bool aux_montgomery) {
+    if (np >= 8 || !sl.lone_graph || sl.profiling) return enqueue_proofs(sl, C, np, d_w, w_stride, d_abc, d_rs, d_proof, aux_montgomery);
+    const uint64_t epoch = device_alloc_epoch().load(std::memory_order_relaxed);
+    if (epoch != sl.graph_epoch) {
+        sl.drop_graphs();
+        sl.graph_epoch = epoch;
+    }
+    Slot::LoneGraph* e = nullptr;
+    for (auto& g : sl.graphs)
+        if (g.circuit == &C && g.np == np && g.w == d_w && g.w_stride == w_stride && g.abc == d_abc[0] && g.rs == d_rs && g.proof == d_proof &&
+            g.mont == aux_montgomery)
+            e = &g;
+    if (!e) {
+        if (sl.graphs.size() >= 16) sl.drop_graphs();
+        sl.graphs.push_back(Slot::LoneGraph{&C, d_w, d_abc[0], d_rs, d_proof, w_stride, np, aux_montgomery, 0, false, nullptr});
+        e = &sl.graphs.back();
+    }
+    if (e->exec) {
+        HIP_TRY(hipGraphLaunch(e->exec, sl.stream));
+        ++sl.graph_launches;
+        return MASP_HIP_OK;
+    }
+    if (e->dead || e->runs == 0) {
+        ++e->runs;
+        return enqueue_proofs(sl, C, np, d_w, w_stride, d_abc, d_rs, d_proof, aux_montgomery);
+    }
+    bool ok = hipStreamBeginCapture(sl.stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
+        const int rc = enqueue_proofs(sl, C, np, d_w, w_stride, d_abc, d_rs, d_proof, aux_montgomery);
+        hipGraph_t g = nullptr;
+        const hipError_t ce = hipStreamEndCapture(sl.stream, &g);
+        ok = rc == MASP_HIP_OK && ce == hipSuccess && g != nullptr && device_alloc_epoch().load(std::memory_order_relaxed) == epoch;
+        if (ok) ok = hipGraphInstantiate(&e->exec, g, nullptr, nullptr, 0) == hipSuccess && e->exec != nullptr;
+        if (g) hipGraphDestroy(g);
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        launch_error().clear();
+        e->exec = nullptr;
+        e->dead = true;
+        sl.graph_epoch = device_alloc_epoch().load(std::memory_order_relaxed);
+        return enqueue_proofs(sl, C, np, d_w, w_stride, d_abc, d_rs, d_proof, aux_montgomery);
+    }
+    HIP_TRY(hipGraphLaunch(e->exec, sl.stream));
+    ++sl.graph_launches;
     return MASP_HIP_OK;
 }
 
@@ -502,6 +561,21 @@ int masp_hip_ctx_device_proofs(const masp_hip_ctx* ctx, uint64_t* counts, int ca
     for (size_t d = 0; d < ctx->children.size() && (int)d < cap; ++d) counts[d] = ctx->children[d]->proofs_done.load();
     return MASP_HIP_OK;
 }
+int masp_hip_ctx_lone_graph_launches(const masp_hip_ctx* ctx, uint64_t* out) {
+    if (!ctx || !out) return MASP_HIP_E_INVALID_ARG;
+    *out = 0;
+    if (!ctx->children.empty()) {
+        for (const masp_hip_ctx* ch : ctx->children) {
+            uint64_t v = 0;
+            masp_hip_ctx_lone_graph_launches(ch, &v);
+            *out += v;
+        }
+        return MASP_HIP_OK;
+    }
+    std::lock_guard<std::mutex> g(ctx->slot_mu);
+    for (const auto& sl : ctx->slots) *out += sl->graph_launches.load();
+    return MASP_HIP_OK;
+}
 int masp_hip_ctx_device_count(const masp_hip_ctx* ctx) { return !ctx ? 0 : ctx->children.empty() ? 1 : (int)ctx->children.size(); }
 
 void masp_hip_ctx_destroy(masp_hip_ctx* ctx) {
@@ -660,8 +734,33 @@ int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* param
     }
     int st = C->h.import_status | C->l.import_status | C->a.import_status | C->b1.import_status | C->b2.import_status;
     if (st) return MASP_HIP_E_PARAMS_FORMAT;  // includes infinity inside a query vector, which bellman rejects
+    {
+        // may s*A and r*B1 use the endomorphism?  Only if everything A and B1 are sums of is in the subgroup (Circuit::g1_endo)
+        DevBuf<int> out;
+        if ((rc = out.reserve(1))) return fail(ctx, rc);
+        hipMemsetAsync(out.p, 0, sizeof(int), s);
+        launch_g1_subgroup_flag(s, C->a.tab, sizeof(*C->a.tab), C->a.n, out.p);
+        launch_g1_subgroup_flag(s, C->b1.tab, sizeof(*C->b1.tab), C->b1.n, out.p);
+        launch_g1_subgroup_flag(s, &C->vk.p->alpha_g1, 0, 1, out.p);
+        launch_g1_subgroup_flag(s, &C->vk.p->beta_g1, 0, 1, out.p);
+        launch_g1_subgroup_flag(s, &C->vk.p->delta_g1, 0, 1, out.p);
+        int outside = 1;
+        if (hipMemcpyAsync(&outside, out.p, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess ||
+            launch_status() != MASP_HIP_OK)
+            return fail(ctx, MASP_HIP_E_HIP);
+        C->g1_endo = outside == 0;
+    }
     if ((rc = get_domain(ctx, C->logm, &C->dom))) return fail(ctx, rc);
     ctx->circ[slot] = std::move(C);
+    return MASP_HIP_OK;
+}
+
+int masp_hip_circuit_flags(const masp_hip_ctx* ctx, uint32_t slot, uint32_t* flags) {
+    if (!ctx || !flags) return MASP_HIP_E_INVALID_ARG;
+    if (!ctx->children.empty()) return masp_hip_circuit_flags(ctx->children[0], slot, flags);
+    std::shared_lock<std::shared_mutex> lock(const_cast<masp_hip_ctx*>(ctx)->mu);
+    if (slot >= MASP_HIP_MAX_CIRCUITS || !ctx->circ[slot]) return MASP_HIP_E_NOT_LOADED;
+    *flags = ctx->circ[slot]->g1_endo ? MASP_HIP_CIRCUIT_G1_ENDOMORPHISM : 0u;
     return MASP_HIP_OK;
 }
 
@@ -836,9 +935,17 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
                 last_hip_error() = "memset failed";
                 result = fail_shared(ctx, MASP_HIP_E_HIP);
                 ok = false;
-            } else if ((rc = enqueue_proofs(sl, C, (uint32_t)np, sl.w.p, nv, abc, sl.rs.p, sl.proof.p, jobs[G.idx[0]].aux_form == MASP_HIP_AUX_MONTGOMERY))) {
-                result = fail_shared(ctx, rc);
-                ok = false;
+            } else {
+#ifdef MASP_ENQ_TIMING   // measurement builds only (tools/jobs): how long the host takes to enqueue one group
+                const auto tq0 = std::chrono::steady_clock::now();
+#endif
+                if ((rc = enqueue_proofs_graphed(sl, C, (uint32_t)np, sl.w.p, nv, abc, sl.rs.p, sl.proof.p, jobs[G.idx[0]].aux_form == MASP_HIP_AUX_MONTGOMERY))) {
+                    result = fail_shared(ctx, rc);
+                    ok = false;
+                }
+#ifdef MASP_ENQ_TIMING
+                fprintf(stderr, "[enq] %zu proofs: %.3f ms\n", np, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq0).count());
+#endif
             }
         }
         if (ok) {

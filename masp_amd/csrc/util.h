@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -35,6 +36,23 @@ inline int launch_status() {
     last_hip_error() = launch_error();
     launch_error().clear();
     return MASP_HIP_E_HIP;
+}
+// Every device allocation and release of the library goes through these two: they count.  A captured launch graph (the lone
+// proof's, Slot::graphs) holds raw device pointers of workspaces that grow on demand, so it is valid only as long as nothing
+// has been allocated or freed since it was captured — the count is that test (conservative: any allocation anywhere drops
+// the graphs; in steady state there are none).
+inline std::atomic<uint64_t>& device_alloc_epoch() {
+    static std::atomic<uint64_t> e{0};
+    return e;
+}
+template <class T>
+inline hipError_t dev_malloc(T** p, size_t bytes) {
+    device_alloc_epoch().fetch_add(1, std::memory_order_relaxed);
+    return hipMalloc(p, bytes);
+}
+inline hipError_t dev_free(void* p) {
+    device_alloc_epoch().fetch_add(1, std::memory_order_relaxed);
+    return hipFree(p);
 }
 // hipFuncSetAttribute applies to the CURRENT device: a process that proves on several GPUs (masp_hip_ctx_create_multi, one
 // host thread per device) has to raise a kernel's dynamic-LDS limit on each of them.  One instance per call site; `f` runs

@@ -21,12 +21,13 @@ class MaspHipError(RuntimeError):
 
 
 OPTION_FIELDS = ("slots", "batch_cap", "ntt_sub_batch", "window_bits_h", "window_bits_la", "window_bits_b", "window_bits_b2_lone",
-                 "witness_nontrivial_percent", "bucket_tree_levels", "bucket_tree_sub_batch", "bucket_tree_levels_g2", "bucket_tree_scratch_mb")
+                 "witness_nontrivial_percent", "bucket_tree_levels", "bucket_tree_sub_batch", "bucket_tree_levels_g2", "bucket_tree_scratch_mb", "lone_proof_graph")
 
 
 class OptionsStruct(C.Structure):
     """masp_hip_options (include/masp_hip.h): every field 0 = the default."""
-    _fields_ = [("struct_size", C.c_uint32)] + [(f, C.c_int32) for f in OPTION_FIELDS] + [("bucket_tree_fallback_proofs", C.c_int32), ("reserved", C.c_int32 * 2)]
+    _fields_ = ([("struct_size", C.c_uint32)] + [(f, C.c_int32) for f in OPTION_FIELDS[:-1]] +
+                [("bucket_tree_fallback_proofs", C.c_int32), ("lone_proof_graph", C.c_int32), ("reserved", C.c_int32 * 1)])
 
 
 class JobStruct(C.Structure):
@@ -66,6 +67,8 @@ def load_library():
     L.masp_hip_options_default.restype = None
     L.masp_hip_ctx_device_count.argtypes = [vp]
     L.masp_hip_ctx_device_proofs.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
+    L.masp_hip_ctx_lone_graph_launches.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.masp_hip_circuit_flags.argtypes = [vp, u32, C.POINTER(C.c_uint32)]
     L.masp_hip_ctx_destroy.argtypes = [vp]
     L.masp_hip_ctx_destroy.restype = None
     L.masp_hip_strerror.restype = C.c_char_p
@@ -311,6 +314,18 @@ class Context:
     @property
     def device_count(self):
         return self._L.masp_hip_ctx_device_count(self._h)
+
+    def circuit_uses_endomorphism(self, slot):
+        """masp_hip_circuit_flags bit 0: every CRS point behind A and B1 is in the prime-order subgroup"""
+        f = C.c_uint32(0)
+        self._check(self._L.masp_hip_circuit_flags(self._h, int(slot), C.byref(f)))
+        return bool(f.value & 1)
+
+    def lone_graph_launches(self):
+        """small batches replayed from a captured launch graph so far (masp_hip_ctx_lone_graph_launches)"""
+        v = C.c_uint64(0)
+        self._check(self._L.masp_hip_ctx_lone_graph_launches(self._h, C.byref(v)))
+        return int(v.value)
 
     def device_proofs(self):
         """proofs written so far by each device context of this prover (masp_hip_ctx_device_proofs)"""

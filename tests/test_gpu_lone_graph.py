@@ -1,0 +1,108 @@
+"""The lone proof's captured launch graph (masp_hip_options::lone_proof_graph, prover.hip: enqueue_proofs_graphed): a caller
+that proves one description at a time — what SaplingProvingContext::spend_proof does
+(/root/reference/masp_proofs/src/sapling/prover.rs:45-172) — can get its third and later proofs from one hipGraphLaunch (opt-in: with ROCm 7.2 the replay is slower than the launches,
+profiles/r04_lone_proof_graph_ab.txt).  The
+replayed graph must write the bytes the one-by-one launch sequence writes: every proof here is compared with the CPU
+restatement's for the same (r, s), the counter shows that the graph really ran, and whatever makes the captured pointers
+stale (a larger batch that grows the workspaces, a circuit loaded next to this one) is followed by correct proofs again."""
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import toy_r1cs
+from pyref import R
+
+pytestmark = pytest.mark.gpu
+
+
+def _make():
+    cs, inputs, aux, _ = toy_r1cs.make(67, 4, 80, 700, bool_share=0.6)
+    pbuf = O.generate_parameters(cs, toy_r1cs.toxic(67))
+    return cs, inputs, aux, pbuf, O.Params(pbuf)
+
+
+def test_lone_proofs_replay_a_graph_and_stay_bit_exact():
+    import masp_amd
+    cs, inputs, aux, pbuf, P = _make()
+    rng = random.Random(67)
+    ctx = masp_amd.Context(0, slots=1, lone_proof_graph=1)
+    try:
+        assert ctx.options["lone_proof_graph"] == 1
+        ctx.load_circuit(2, pbuf, cs)
+        # different auxiliary values per call (the graph replays launches, not data): perturbing aux keeps shapes and only the
+        # bytes must agree — Groth16's prover is defined for non-satisfying assignments too
+        def one(k, n=1):
+            a = aux.copy()
+            a[k % len(a)] = np.frombuffer(rng.randrange(R).to_bytes(32, "little"), np.uint8)
+            rs = [(rng.randrange(R), rng.randrange(R)) for _ in range(n)]
+            got = ctx.prove_batch([(2, inputs, a, r, s) for r, s in rs])
+            assert got == [O.create_proof(P, cs, inputs, a, r, s) for r, s in rs], (k, n)
+        for k in range(6):
+            one(k)
+        g1 = ctx.lone_graph_launches()
+        assert g1 >= 4, g1            # calls 3..6 (call 1 sizes the buffers, call 2 captures and launches)
+        for k in range(4):
+            one(k, 3)                 # another key: three proofs per call
+        g2 = ctx.lone_graph_launches()
+        assert g2 >= g1 + 2, (g1, g2)
+        one(0, 40)                    # batch mode: grows the slot's workspaces -> every graph is dropped
+        for k in range(4):
+            one(10 + k)
+        g3 = ctx.lone_graph_launches()
+        assert g3 >= g2 + 2, (g2, g3)
+        # a circuit loaded into another slot allocates: the graphs are dropped and rebuilt, proofs stay right
+        cs2, inputs2, aux2, _ = toy_r1cs.make(68, 3, 40, 300, bool_share=0.5)
+        pbuf2 = O.generate_parameters(cs2, toy_r1cs.toxic(68))
+        ctx.load_circuit(1, pbuf2, cs2)
+        P2 = O.Params(pbuf2)
+        for k in range(4):
+            one(20 + k)
+            r, s = rng.randrange(R), rng.randrange(R)
+            assert ctx.prove_batch([(1, inputs2, aux2, r, s)]) == [O.create_proof(P2, cs2, inputs2, aux2, r, s)]
+        assert ctx.lone_graph_launches() >= g3 + 4
+    finally:
+        ctx.close()
+
+
+def test_lone_graph_is_off_by_default():
+    import masp_amd
+    cs, inputs, aux, pbuf, P = _make()
+    ctx = masp_amd.Context(0, slots=1)
+    try:
+        assert ctx.options["lone_proof_graph"] == 0
+        ctx.load_circuit(2, pbuf, cs)
+        for k in range(4):
+            assert ctx.prove_batch([(2, inputs, aux, 3 + k, 4 + k)]) == [O.create_proof(P, cs, inputs, aux, 3 + k, 4 + k)]
+        assert ctx.lone_graph_launches() == 0
+    finally:
+        ctx.close()
+
+
+def test_lone_graphs_from_concurrent_threads():
+    """three host threads prove single descriptions on one context (three slots, each with its own graphs): an allocation by
+    one of them drops the graphs of all; every proof still matches"""
+    import threading
+    import masp_amd
+    cs, inputs, aux, pbuf, P = _make()
+    want = {k: O.create_proof(P, cs, inputs, aux, 100 + k, 200 + k) for k in range(24)}
+    ctx = masp_amd.Context(0, slots=3, lone_proof_graph=1)
+    bad = []
+    try:
+        ctx.load_circuit(2, pbuf, cs)
+
+        def work(t):
+            for k in range(t, 24, 3):
+                got = ctx.prove_batch([(2, inputs, aux, 100 + k, 200 + k)])
+                if got != [want[k]]:
+                    bad.append(k)
+        th = [threading.Thread(target=work, args=(t,)) for t in range(3)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not bad, bad
+        assert ctx.lone_graph_launches() >= 6
+    finally:
+        ctx.close()
