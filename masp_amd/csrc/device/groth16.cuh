@@ -153,9 +153,9 @@ __device__ __forceinline__ void endo_split(const uint32_t* k, uint32_t* q, uint3
 // 4-bit fixed windows, four lanes per point.
 // endo != 0 (every CRS point that A and B1 are sums of lies in the prime-order subgroup: checked once, when the circuit is
 // loaded — k_g1_subgroup_flag): k = q u^2 + rem and [u^2] P = -phi(P) = (beta x, -y) on the subgroup (subgroup.cuh), so
-// [k] P = [rem] P + [q] (beta x, -y) with two 128-bit scalars over ONE chain of 124 doublings and <= 64 additions — the
-// table of (beta x, -y) is the table of P with X scaled and Y negated.  This multiplication is the tail of the two longest
-// chains of a lone proof (2.1 ms of 252 dependent doublings; 1.3 ms this way).
+// [k] P = [rem] P + [q] (beta x, -y): two 128-bit scalars, 124 doublings and <= 32 additions each, on two quads of the same
+// wave — the table of (beta x, -y) is the table of P with X scaled and Y negated.  This multiplication is the tail of the
+// two longest G1 chains of a lone proof (2.1 ms of 252 dependent doublings before).
 // endo == 0: 252 doublings + <= 64 additions, exact for ANY curve point — the reference reads the CRS unchecked
 // (Parameters::read(_, false), /root/reference/masp_proofs/src/lib.rs:343-347) and a point of the curve outside the
 // subgroup must give the bytes the reference's plain double-and-add gives.
@@ -187,21 +187,26 @@ __global__ void __launch_bounds__(64) k_groth16_var_mul(uint32_t which0, const G
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (tid < 4) {  // four lanes per point (see xyzz_dbl_coop)
-        const uint32_t lig = tid;
+    // four lanes per point (quad.cuh).  endo: quad 0 runs [rem] P, quad 1 runs [q] [u^2] P — two chains of 124 doublings and
+    // <= 32 additions side by side in the same wave — and quad 0 adds the two
+    __shared__ G1Xyzz other;
+    G1Xyzz acc = xyzz_inf<FpOps>();
+    const uint32_t lig = tid & 3u, half = tid >> 2;
+    if (tid < (endo ? 8u : 4u)) {
         uint32_t k[8];
         for (int i = 0; i < 8; ++i) k[i] = rs[i];
-        G1Xyzz acc = xyzz_inf<FpOps>();
         if (endo) {
-            uint32_t q[4], rem[4];
+            uint32_t q[4], rem[4], mine[4];
             endo_split(k, q, rem);
+            for (int i = 0; i < 4; ++i) mine[i] = half ? q[i] : rem[i];
+            const G1Xyzz* tab = wtab + 16 * half;
             for (int w = 31; w >= 0; --w) {
                 if (w != 31)
                     for (int j = 0; j < 4; ++j) acc = xyzz_dbl_coop(acc, lig);
-                const uint32_t d0 = (rem[w >> 3] >> (4 * (w & 7))) & 15u, d1 = (q[w >> 3] >> (4 * (w & 7))) & 15u;
-                if (d0) xyzz_add_coop(acc, wtab[d0], lig);
-                if (d1) xyzz_add_coop(acc, wtab[16 + d1], lig);
+                const uint32_t d = (mine[w >> 3] >> (4 * (w & 7))) & 15u;
+                if (d) xyzz_add_coop(acc, tab[d], lig);
             }
+            if (tid == 4) other = acc;
         } else {
             for (int w = 63; w >= 0; --w) {
                 if (w != 63)
@@ -210,6 +215,12 @@ __global__ void __launch_bounds__(64) k_groth16_var_mul(uint32_t which0, const G
                 if (d) xyzz_add_coop(acc, wtab[d], lig);
             }
         }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (tid < 4) {
+        if (endo) xyzz_add_coop(acc, other, lig);
         if (lig == 0) part[3 + WHICH] = acc;
     }
 }

@@ -13,6 +13,10 @@
 #include "device/msm_geom.h"
 #include "util.h"
 
+// lanes of the accumulation of a lone proof's narrow-window MSM (B2 on 8-bit windows): A/B builds
+#ifndef MASP_LONE_NARROW_LANES_LOG
+#define MASP_LONE_NARROW_LANES_LOG 16
+#endif
 namespace masp {
 
 // ---- base set: T[j][i] = 2^(c j) P_i -------------------------------------------------------------
@@ -222,7 +226,7 @@ struct MsmWorkspace {
         // ... except with so few buckets (a lone proof's B2 on 8-bit windows) that every bucket goes to the heavy-bucket
         // workgroups anyway: there a lane's chunk is a chain of dependent additions on an otherwise idle chip, so the digit
         // list is cut into one full round of waves
-        if (np < 8) lanes = g.nb <= 256 ? std::max<uint64_t>((1u << 16) / np, 1u << 13) : std::min<uint64_t>(lanes, std::max<uint64_t>(8ull * g.nb, 1u << 13));
+        if (np < 8) lanes = g.nb <= 256 ? std::max<uint64_t>((1u << MASP_LONE_NARROW_LANES_LOG) / np, 1u << 13) : std::min<uint64_t>(lanes, std::max<uint64_t>(8ull * g.nb, 1u << 13));
         return (uint32_t)std::min<uint64_t>(std::min<uint64_t>(lanes, NCHUNKS), std::max<uint64_t>(ent, 1));
     }
     // room for `np` proofs of an n-point MSM with geometry g (every per-proof array is np-fold)

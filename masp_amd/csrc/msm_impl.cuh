@@ -16,11 +16,6 @@ struct TailLaneOps {
     typedef typename std::conditional<(MASP_G2_PAIR_TAILS) != 0 && std::is_same<O, Fp2Ops>::value, Fp2PairOps, O>::type type;
 };
 
-template <class OT>
-struct TailTag {
-    typedef OT type;
-};
-
 static inline uint32_t log2_ceil_u64(uint64_t n) {
     uint32_t k = 0;
     while ((1ull << k) < n) ++k;
@@ -85,6 +80,68 @@ void MsmWorkspace<O>::reduce_to_one_lanes(hipStream_t s, uint32_t np, const Xyzz
             flip ^= 1;
         }
     }
+
+// The bucket tails of an MSM — gather, heavy buckets, weighted sums by levels, block reductions, combine — over OT::LANES lanes
+// per point (OT: O itself, its lane-pair form for G2, FpQuadOps for a lone proof's G1 MSMs).
+template <class O, class OT>
+void msm_tails_enqueue(hipStream_t s, MsmWorkspace<O>& ws, const uint32_t* start, uint32_t nb, uint32_t nchunks, uint32_t np, bool lone, Xyzz<O>* d_out,
+                       size_t out_stride) {
+    constexpr uint32_t LN = OT::LANES;
+    MASP_LAUNCH((k_msm_bucket_gather<OT>), dim3((nb * LN + 63) / 64, np), dim3(64), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy,
+                       ws.n_heavy, lone ? 12u : 8u);
+    if (lone) {
+        const uint32_t heavy_blocks = std::min<uint32_t>(std::max<uint32_t>(4096u / np, 16u), nb) | 1u;
+        MASP_LAUNCH((k_msm_bucket_heavy<OT, 256>), dim3(heavy_blocks, np), dim3(256), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy,
+                           ws.n_heavy);
+    } else {
+        const uint32_t heavy_blocks = std::min<uint32_t>(64u, nb) | 1u;
+        MASP_LAUNCH((k_msm_bucket_heavy<OT, 64>), dim3(heavy_blocks, np), dim3(64), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy,
+                           ws.n_heavy);
+    }
+    // weighted sum by levels of (G x 128)-bucket workgroups.  Per lane the kernel costs 2 G additions for its buckets plus
+    // ~19 for the two lane scans: a batch takes the largest G in {8 .. 64} that still fills one workgroup (2 048 buckets: 16,
+    // the 32 768 of h+l: 64 = 2.3 instead of 3.2 additions per bucket) — with other batches in flight total work counts, not
+    // the length of the chain; a lone proof takes 4 (shortest dependent chain).
+    uint32_t g_log = nb <= WSUM_L ? 0 : WSUM_G_LOG_MIN;  // at most 128 buckets: one per lane, one workgroup, no second level
+    if (!lone) {
+        const uint32_t hi = 6u;
+        g_log = 3;
+        while (g_log < hi && (1u << (g_log + 1 + WSUM_L_LOG)) <= nb) ++g_log;
+    }
+    const uint32_t cs = 1u << (g_log + WSUM_L_LOG);
+    const size_t st_stride = (nb + cs - 1) / cs;  // level-0 chunk count bounds every later level
+    const Xyzz<O>* bk = ws.bkt;
+    size_t bk_stride = nb;
+    uint32_t m = nb, off = 1;
+    int level = 0, flip = 0;
+    do {
+        uint32_t chunks = (m + cs - 1) / cs;
+        const dim3 grid(chunks, np), block(WSUM_L * LN);
+        switch (g_log) {
+#define MASP_WSUM_CASE(GL) \
+    case GL: MASP_LAUNCH((k_msm_wsum_level<OT, GL>), grid, block, 0, s, bk, bk_stride, m, off, ws.S[flip], ws.T, st_stride); break;
+            MASP_WSUM_CASE(0) MASP_WSUM_CASE(2) MASP_WSUM_CASE(3) MASP_WSUM_CASE(4) MASP_WSUM_CASE(5) MASP_WSUM_CASE(6)
+#undef MASP_WSUM_CASE
+        }
+        if constexpr (OT::REPLICATED)
+            ws.template reduce_to_one_lanes<OT>(s, np, ws.T, st_stride, chunks, ws.tsum + level, 32, st_stride);
+        else
+            ws.reduce_to_one(s, np, ws.T, st_stride, chunks, ws.tsum + level, 32, st_stride);
+        bk = ws.S[flip];
+        bk_stride = st_stride;
+        flip ^= 1;
+        m = chunks;
+        off = 0;
+        ++level;
+    } while (m > 1);
+    if constexpr (OT::REPLICATED)
+        MASP_LAUNCH((k_msm_combine_lanes<OT>), dim3(1, np), dim3(64), 0, s, ws.tsum, level, (int)(g_log + WSUM_L_LOG), d_out, out_stride);
+    else
+        MASP_LAUNCH((k_msm_combine<O>), dim3(1, np), dim3(64), 0, s, ws.tsum, level, (int)(g_log + WSUM_L_LOG), d_out, out_stride);
+}
+#ifndef MASP_TAILS_QUAD_UNIT
+extern template void msm_tails_enqueue<FpOps, FpQuadOps>(hipStream_t, MsmWorkspace<FpOps>&, const uint32_t*, uint32_t, uint32_t, uint32_t, bool, Xyzz<FpOps>*, size_t);
+#endif
 
 template <class O, int BYTES>
 int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSortBuf& sb, MsmWorkspace<O>& ws, Xyzz<O>* d_out, size_t out_stride,
@@ -174,69 +231,15 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
     // end).  A lone proof keeps span 12 and four waves (shortest chain for its one big bucket).
     // Workgroups go to the 8 XCDs round-robin by linear id x + gridDim.x * y, so with gridDim.x a multiple of 8 every proof's
     // first working workgroup (x = 0: bucket 0) would land on the same XCD: keep gridDim.x odd.
-    auto tails = [&](auto tag) {
-    typedef typename decltype(tag)::type OT;
-    constexpr uint32_t LN = OT::LANES;
-    MASP_LAUNCH((k_msm_bucket_gather<OT>), dim3((nb * LN + 63) / 64, np), dim3(64), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy,
-                       ws.n_heavy, lone ? 12u : 8u);
-    if (lone) {
-        const uint32_t heavy_blocks = std::min<uint32_t>(std::max<uint32_t>(4096u / np, 16u), nb) | 1u;
-        MASP_LAUNCH((k_msm_bucket_heavy<OT, 256>), dim3(heavy_blocks, np), dim3(256), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy,
-                           ws.n_heavy);
-    } else {
-        const uint32_t heavy_blocks = std::min<uint32_t>(64u, nb) | 1u;
-        MASP_LAUNCH((k_msm_bucket_heavy<OT, 64>), dim3(heavy_blocks, np), dim3(64), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy,
-                           ws.n_heavy);
-    }
-    // weighted sum by levels of (G x 128)-bucket workgroups.  Per lane the kernel costs 2 G additions for its buckets plus
-    // ~19 for the two lane scans: a batch takes the largest G in {8 .. 64} that still fills one workgroup (2 048 buckets: 16,
-    // the 32 768 of h+l: 64 = 2.3 instead of 3.2 additions per bucket) — with other batches in flight total work counts, not
-    // the length of the chain; a lone proof takes 4 (shortest dependent chain).
-    uint32_t g_log = nb <= WSUM_L ? 0 : WSUM_G_LOG_MIN;  // at most 128 buckets: one per lane, one workgroup, no second level
-    if (!lone) {
-        const uint32_t hi = 6u;
-        g_log = 3;
-        while (g_log < hi && (1u << (g_log + 1 + WSUM_L_LOG)) <= nb) ++g_log;
-    }
-    const uint32_t cs = 1u << (g_log + WSUM_L_LOG);
-    const size_t st_stride = (nb + cs - 1) / cs;  // level-0 chunk count bounds every later level
-    const Xyzz<O>* bk = ws.bkt;
-    size_t bk_stride = nb;
-    uint32_t m = nb, off = 1;
-    int level = 0, flip = 0;
-    do {
-        uint32_t chunks = (m + cs - 1) / cs;
-        const dim3 grid(chunks, np), block(WSUM_L * LN);
-        switch (g_log) {
-#define MASP_WSUM_CASE(GL) \
-    case GL: MASP_LAUNCH((k_msm_wsum_level<OT, GL>), grid, block, 0, s, bk, bk_stride, m, off, ws.S[flip], ws.T, st_stride); break;
-            MASP_WSUM_CASE(0) MASP_WSUM_CASE(2) MASP_WSUM_CASE(3) MASP_WSUM_CASE(4) MASP_WSUM_CASE(5) MASP_WSUM_CASE(6)
-#undef MASP_WSUM_CASE
-        }
-        if constexpr (OT::REPLICATED)
-            ws.template reduce_to_one_lanes<OT>(s, np, ws.T, st_stride, chunks, ws.tsum + level, 32, st_stride);
-        else
-            ws.reduce_to_one(s, np, ws.T, st_stride, chunks, ws.tsum + level, 32, st_stride);
-        bk = ws.S[flip];
-        bk_stride = st_stride;
-        flip ^= 1;
-        m = chunks;
-        off = 0;
-        ++level;
-    } while (m > 1);
-    if constexpr (OT::REPLICATED)
-        MASP_LAUNCH((k_msm_combine_lanes<OT>), dim3(1, np), dim3(64), 0, s, ws.tsum, level, (int)(g_log + WSUM_L_LOG), d_out, out_stride);
-    else
-        MASP_LAUNCH((k_msm_combine<O>), dim3(1, np), dim3(64), 0, s, ws.tsum, level, (int)(g_log + WSUM_L_LOG), d_out, out_stride);
-    };
-    // a lone proof's G1 tails run over quads (device/quad.cuh): their chains of dependent additions are what it waits for
+    // a lone proof's G1 tails run over quads (device/quad.cuh): their chains of dependent additions are what it waits for.
+    // (Those kernels live in a translation unit of their own, k_msm_g1_lone.hip.)
     if constexpr (std::is_same<O, FpOps>::value) {
         if (lone)
-            tails(TailTag<FpQuadOps>{});
+            msm_tails_enqueue<O, FpQuadOps>(s, ws, start, nb, nchunks, np, lone, d_out, out_stride);
         else
-            tails(TailTag<FpOps>{});
+            msm_tails_enqueue<O, FpOps>(s, ws, start, nb, nchunks, np, lone, d_out, out_stride);
     } else {
-        tails(TailTag<typename TailLaneOps<O>::type>{});
+        msm_tails_enqueue<O, typename TailLaneOps<O>::type>(s, ws, start, nb, nchunks, np, lone, d_out, out_stride);
     }
     return launch_status();  // (a launch the runtime refused: MASP_LAUNCH, util.h)
 }

@@ -309,7 +309,7 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
     if (!lone) {
         launch_groth16_fixed_g1(s, C.fb1.p, d_rs, 16, sl.asm1.p, np);
         launch_groth16_fixed_g2(s, C.fb2.p, d_rs, 16, sl.asm2.p, np);
-        launch_groth16_var_mul(s, 2, sl.res1.p, d_rs, 16, sl.asm1.p, np, C.g1_endo);
+                launch_groth16_var_mul(s, 2, sl.res1.p, d_rs, 16, sl.asm1.p, np, C.g1_endo);
         launch_groth16_finish_b(s, C.vk.p, sl.asm2.p, sl.res2.p, d_proof, np);
     }
     launch_groth16_finish_ac(s, C.vk.p, sl.asm1.p, sl.res1.p, d_proof, np);

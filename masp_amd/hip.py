@@ -67,8 +67,11 @@ def load_library():
     L.masp_hip_options_default.restype = None
     L.masp_hip_ctx_device_count.argtypes = [vp]
     L.masp_hip_ctx_device_proofs.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
-    L.masp_hip_ctx_lone_graph_launches.argtypes = [vp, C.POINTER(C.c_uint64)]
-    L.masp_hip_circuit_flags.argtypes = [vp, u32, C.POINTER(C.c_uint32)]
+    # (introspection added in round 4: an older build passed as MASP_HIP_LIBRARY for an A/B run lacks them; calling them then raises)
+    if hasattr(L, "masp_hip_ctx_lone_graph_launches"):
+        L.masp_hip_ctx_lone_graph_launches.argtypes = [vp, C.POINTER(C.c_uint64)]
+    if hasattr(L, "masp_hip_circuit_flags"):
+        L.masp_hip_circuit_flags.argtypes = [vp, u32, C.POINTER(C.c_uint32)]
     L.masp_hip_ctx_destroy.argtypes = [vp]
     L.masp_hip_ctx_destroy.restype = None
     L.masp_hip_strerror.restype = C.c_char_p

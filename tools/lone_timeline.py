@@ -16,8 +16,8 @@ rows = list(cur.execute("select s.%s, d.start, d.end, d.queue_id, d.grid_size_x,
 last = [r for r in rows if "k_groth16_finish_ac" in r[0] and r[4] <= 128][-1]   # grid of one workgroup: a lone proof
 t1 = last[2]
 sel = [r for r in rows if r[1] >= t1 - win * 1e6 and r[2] <= t1]
-# keep only the run that belongs to this proof: starts at the last k_fr_to_mont before the assemble
-starts = [r for r in sel if "k_fr_to_mont" in r[0]]
+# keep only the run that belongs to this proof: starts at the last k_fr_to_mont / k_fr_split_forms before the assemble
+starts = [r for r in sel if "k_fr_to_mont" in r[0] or "k_fr_split_forms" in r[0]]
 t0 = starts[-1][1] if starts else sel[0][1]
 print("%-58s %9s %9s %6s %s" % ("kernel", "start_us", "dur_us", "queue", "grid"))
 for name, st, en, q, gx, gy in sel:
