@@ -63,7 +63,7 @@ import re, time
 line = [l for l in open("%s/FETCH_SIZE.log" % out).read().splitlines() if l.startswith("{")][-1]
 alg = json.loads(line)["roofline"]["alg_bytes_per_launch"]
 doc = {
- "kernel": "G1 bucket-accumulation stage per G1 MSM: k_tree_plan / k_tree_records / k_tree_pass1 / k_tree_pass2 / k_tree_copy / k_binv_* over 4 tree levels in sub-batches of 64 proofs, then k_msm_accumulate_pts",
+ "kernel": "G1 bucket-accumulation stage per G1 MSM: k_tree_plan / k_tree_records / k_tree_pass1 / k_tree_pass2 / k_tree_copy / k_binv_* over 4 tree levels in sub-batches of 86 proofs, then k_msm_accumulate_pts",
  "date": time.strftime("%Y-%m-%d"),
  "command": "tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline (256 distinct Spend witnesses per step); calibration pass on tools/_build/pmc_calib",
  "calibration": {"pattern": "one 96-byte row (6 x global_load_dwordx4) per lane at a random index, 3 GiB table, 2^24 rows per launch",
