@@ -263,66 +263,148 @@ __device__ __forceinline__ Fe<C> fe_dbl(const Fe<C>& a) {
 // (hipcc pads every asm statement with an s_nop, so the multiply-adds of a column go into as few statements
 // as possible: groups of 4, 2, 1.)
 #define MASP_MAC(A, B) "v_mad_u64_u32 %0, vcc, " A ", " B ", %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+// the first multiply-add of a column: the carry word starts from the carry alone (VOP3 form, both addends the constant 0), so
+// no instruction has to clear it between columns
+#define MASP_MAC0(A, B) "v_mad_u64_u32 %0, vcc, " A ", " B ", %0\n\tv_addc_co_u32_e64 %1, vcc, 0, 0, vcc\n\t"
+template <bool FIRST = false>
 __device__ __forceinline__ void mac_vv(uint64_t& acc, uint32_t& c2, uint32_t a, uint32_t b) {
-    asm(MASP_MAC("%2", "%3") : "+v"(acc), "+v"(c2) : "v"(a), "v"(b) : "vcc");
+    if constexpr (FIRST)
+        asm(MASP_MAC0("%2", "%3") : "+v"(acc), "=&v"(c2) : "v"(a), "v"(b) : "vcc");
+    else
+        asm(MASP_MAC("%2", "%3") : "+v"(acc), "+v"(c2) : "v"(a), "v"(b) : "vcc");
 }
+template <bool FIRST = false>
 __device__ __forceinline__ void mac_vv2(uint64_t& acc, uint32_t& c2, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1) {
-    asm(MASP_MAC("%2", "%3") MASP_MAC("%4", "%5") : "+v"(acc), "+v"(c2) : "v"(a0), "v"(b0), "v"(a1), "v"(b1) : "vcc");
+    if constexpr (FIRST)
+        asm(MASP_MAC0("%2", "%3") MASP_MAC("%4", "%5") : "+v"(acc), "=&v"(c2) : "v"(a0), "v"(b0), "v"(a1), "v"(b1) : "vcc");
+    else
+        asm(MASP_MAC("%2", "%3") MASP_MAC("%4", "%5") : "+v"(acc), "+v"(c2) : "v"(a0), "v"(b0), "v"(a1), "v"(b1) : "vcc");
 }
+template <bool FIRST = false>
 __device__ __forceinline__ void mac_vv4(uint64_t& acc, uint32_t& c2, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2,
                                         uint32_t b2, uint32_t a3, uint32_t b3) {
-    asm(MASP_MAC("%2", "%3") MASP_MAC("%4", "%5") MASP_MAC("%6", "%7") MASP_MAC("%8", "%9")
-        : "+v"(acc), "+v"(c2)
-        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3)
-        : "vcc");
+    if constexpr (FIRST)
+        asm(MASP_MAC0("%2", "%3") MASP_MAC("%4", "%5") MASP_MAC("%6", "%7") MASP_MAC("%8", "%9")
+            : "+v"(acc), "=&v"(c2)
+            : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3)
+            : "vcc");
+    else
+        asm(MASP_MAC("%2", "%3") MASP_MAC("%4", "%5") MASP_MAC("%6", "%7") MASP_MAC("%8", "%9")
+            : "+v"(acc), "+v"(c2)
+            : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3)
+            : "vcc");
 }
+template <bool FIRST = false>
 __device__ __forceinline__ void mac_vs(uint64_t& acc, uint32_t& c2, uint32_t a, uint32_t k) {
-    asm(MASP_MAC("%2", "%3") : "+v"(acc), "+v"(c2) : "v"(a), "s"(k) : "vcc");
+    if constexpr (FIRST)
+        asm(MASP_MAC0("%2", "%3") : "+v"(acc), "=&v"(c2) : "v"(a), "s"(k) : "vcc");
+    else
+        asm(MASP_MAC("%2", "%3") : "+v"(acc), "+v"(c2) : "v"(a), "s"(k) : "vcc");
 }
+template <bool FIRST = false>
 __device__ __forceinline__ void mac_vs2(uint64_t& acc, uint32_t& c2, uint32_t a0, uint32_t k0, uint32_t a1, uint32_t k1) {
-    asm(MASP_MAC("%2", "%3") MASP_MAC("%4", "%5") : "+v"(acc), "+v"(c2) : "v"(a0), "s"(k0), "v"(a1), "s"(k1) : "vcc");
+    if constexpr (FIRST)
+        asm(MASP_MAC0("%2", "%3") MASP_MAC("%4", "%5") : "+v"(acc), "=&v"(c2) : "v"(a0), "s"(k0), "v"(a1), "s"(k1) : "vcc");
+    else
+        asm(MASP_MAC("%2", "%3") MASP_MAC("%4", "%5") : "+v"(acc), "+v"(c2) : "v"(a0), "s"(k0), "v"(a1), "s"(k1) : "vcc");
 }
+template <bool FIRST = false>
 __device__ __forceinline__ void mac_vs4(uint64_t& acc, uint32_t& c2, uint32_t a0, uint32_t k0, uint32_t a1, uint32_t k1, uint32_t a2,
                                         uint32_t k2, uint32_t a3, uint32_t k3) {
-    asm(MASP_MAC("%2", "%3") MASP_MAC("%4", "%5") MASP_MAC("%6", "%7") MASP_MAC("%8", "%9")
-        : "+v"(acc), "+v"(c2)
-        : "v"(a0), "s"(k0), "v"(a1), "s"(k1), "v"(a2), "s"(k2), "v"(a3), "s"(k3)
+    if constexpr (FIRST)
+        asm(MASP_MAC0("%2", "%3") MASP_MAC("%4", "%5") MASP_MAC("%6", "%7") MASP_MAC("%8", "%9")
+            : "+v"(acc), "=&v"(c2)
+            : "v"(a0), "s"(k0), "v"(a1), "s"(k1), "v"(a2), "s"(k2), "v"(a3), "s"(k3)
+            : "vcc");
+    else
+        asm(MASP_MAC("%2", "%3") MASP_MAC("%4", "%5") MASP_MAC("%6", "%7") MASP_MAC("%8", "%9")
+            : "+v"(acc), "+v"(c2)
+            : "v"(a0), "s"(k0), "v"(a1), "s"(k1), "v"(a2), "s"(k2), "v"(a3), "s"(k3)
+            : "vcc");
+}
+// Multiply-adds that cannot carry out of the 64-bit accumulator, so that no carry word follows them: the terms of a column
+// that hold a TOP limb.  For the 381-bit modulus every operand of a product is below 2p < 2^382, its top limb below 2^30, the
+// modulus' top limb below 2^29: such a term is below 2^62, and a column starts from less than 2^39 (what the previous column
+// carried over), so the first three (four, if one of them is m x MOD[11] < 2^61) terms of a column may be of this kind.  The
+// columns 11 .. 22 of a 12-limb product have three: a[K-11] b[11], a[11] b[K-11], m[K-11] MOD[11] — 35 of 288 carry words less.
+#define MASP_MACNC(A, B) "v_mad_u64_u32 %0, vcc, " A ", " B ", %0\n\t"
+__device__ __forceinline__ void macnc_v(uint64_t& acc, uint32_t a, uint32_t b) { asm(MASP_MACNC("%1", "%2") : "+v"(acc) : "v"(a), "v"(b) : "vcc"); }
+__device__ __forceinline__ void macnc_vs(uint64_t& acc, uint32_t a, uint32_t b, uint32_t m, uint32_t k) {
+    asm(MASP_MACNC("%1", "%2") MASP_MACNC("%3", "%4") : "+v"(acc) : "v"(a), "v"(b), "v"(m), "s"(k) : "vcc");
+}
+__device__ __forceinline__ void macnc_s(uint64_t& acc, uint32_t m, uint32_t k) { asm(MASP_MACNC("%1", "%2") : "+v"(acc) : "v"(m), "s"(k) : "vcc"); }
+__device__ __forceinline__ void macnc_vvs(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t m, uint32_t k) {
+    asm(MASP_MACNC("%1", "%2") MASP_MACNC("%3", "%4") MASP_MACNC("%5", "%6") : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(m), "s"(k) : "vcc");
+}
+__device__ __forceinline__ void macnc_vvvs(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t m,
+                                           uint32_t k) {
+    asm(MASP_MACNC("%1", "%2") MASP_MACNC("%3", "%4") MASP_MACNC("%5", "%6") MASP_MACNC("%7", "%8")
+        : "+v"(acc)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(m), "s"(k)
         : "vcc");
 }
-// acc += sum_{i = I}^{END-1} x[i] * y[k - i]   (VV: both operand arrays in VGPRs; VS: y = modulus limbs)
-template <int I, int END, int K, class C>
+template <class C>
+struct TopLimbsSmall {
+    static constexpr bool value = C::N == 12;  // Fp only: Fr's top limb has one spare bit, and raw scalars reach a product unchecked
+};
+// acc += sum_{i = I}^{END-1} x[i] * y[k - i]   (VV: both operand arrays in VGPRs; VS: y = modulus limbs).  FIRST: these are the
+// first multiply-adds of their column (the range must not be empty): the carry word is written, not updated
+template <int I, int END, int K, class C, bool FIRST = false>
 __device__ __forceinline__ void macs_vv(uint64_t& acc, uint32_t& c2, const uint32_t* x, const uint32_t* y) {
+    static_assert(!FIRST || END > I, "a column cannot start with an empty range");
     if constexpr (END - I >= 4) {
-        mac_vv4(acc, c2, x[I], y[K - I], x[I + 1], y[K - I - 1], x[I + 2], y[K - I - 2], x[I + 3], y[K - I - 3]);
+        mac_vv4<FIRST>(acc, c2, x[I], y[K - I], x[I + 1], y[K - I - 1], x[I + 2], y[K - I - 2], x[I + 3], y[K - I - 3]);
         macs_vv<I + 4, END, K, C>(acc, c2, x, y);
     } else if constexpr (END - I >= 2) {
-        mac_vv2(acc, c2, x[I], y[K - I], x[I + 1], y[K - I - 1]);
+        mac_vv2<FIRST>(acc, c2, x[I], y[K - I], x[I + 1], y[K - I - 1]);
         macs_vv<I + 2, END, K, C>(acc, c2, x, y);
     } else if constexpr (END - I == 1) {
-        mac_vv(acc, c2, x[I], y[K - I]);
+        mac_vv<FIRST>(acc, c2, x[I], y[K - I]);
     }
 }
-template <int I, int END, int K, class C>
+template <int I, int END, int K, class C, bool FIRST = false>
 __device__ __forceinline__ void macs_vs(uint64_t& acc, uint32_t& c2, const uint32_t* x) {
+    static_assert(!FIRST || END > I, "a column cannot start with an empty range");
     if constexpr (END - I >= 4) {
-        mac_vs4(acc, c2, x[I], C::MOD[K - I], x[I + 1], C::MOD[K - I - 1], x[I + 2], C::MOD[K - I - 2], x[I + 3], C::MOD[K - I - 3]);
+        mac_vs4<FIRST>(acc, c2, x[I], C::MOD[K - I], x[I + 1], C::MOD[K - I - 1], x[I + 2], C::MOD[K - I - 2], x[I + 3], C::MOD[K - I - 3]);
         macs_vs<I + 4, END, K, C>(acc, c2, x);
     } else if constexpr (END - I >= 2) {
-        mac_vs2(acc, c2, x[I], C::MOD[K - I], x[I + 1], C::MOD[K - I - 1]);
+        mac_vs2<FIRST>(acc, c2, x[I], C::MOD[K - I], x[I + 1], C::MOD[K - I - 1]);
         macs_vs<I + 2, END, K, C>(acc, c2, x);
     } else if constexpr (END - I == 1) {
-        mac_vs(acc, c2, x[I], C::MOD[K - I]);
+        mac_vs<FIRST>(acc, c2, x[I], C::MOD[K - I]);
+    }
+}
+// end of a column: the low word has been consumed, the accumulator moves down one word (the carry word becomes its high word
+// and is written afresh by the next column's first multiply-add)
+__device__ __forceinline__ void mont_shift(uint64_t& acc, uint32_t c2) { acc = (acc >> 32) | ((uint64_t)c2 << 32); }
+// the multiply-adds of column K >= N - 1 with the top-limb terms first and carry-free (TopLimbsSmall); L = K - (N - 1) is the
+// lowest index of the column, VS_END the end of the range of reduction terms m[i] MOD[K - i] (K for column N - 1, else N)
+template <int K, int VS_END, class C>
+__device__ __forceinline__ void mont_top_column(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* b, const uint32_t* m) {
+    constexpr int N = C::N, L = K - (N - 1);
+    if constexpr (L == N - 1) {  // the last column: a[N-1] b[N-1] + m[N-1] MOD[N-1], nothing can carry
+        macnc_vs(acc, a[L], b[L], m[L], C::MOD[N - 1]);
+        c2 = 0;
+    } else {
+        macnc_vvs(acc, a[L], b[N - 1], a[N - 1], b[L], m[L], C::MOD[N - 1]);
+        constexpr bool VV = N - 1 > L + 1;  // terms left between the two top-limb ones
+        if constexpr (VV) macs_vv<L + 1, N - 1, K, C, true>(acc, c2, a, b);
+        macs_vs<L + 1, VS_END, K, C, !VV>(acc, c2, m);
     }
 }
 template <int K, class C>
 __device__ __forceinline__ void mont_columns_lo(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* b, uint32_t* m) {
     if constexpr (K < C::N) {
-        macs_vv<0, K + 1, K, C>(acc, c2, a, b);
-        macs_vs<0, K, K, C>(acc, c2, m);
+        if constexpr (TopLimbsSmall<C>::value && K == C::N - 1) {
+            mont_top_column<K, K, C>(acc, c2, a, b, m);
+        } else {
+            macs_vv<0, K + 1, K, C, true>(acc, c2, a, b);
+            macs_vs<0, K, K, C>(acc, c2, m);
+        }
         m[K] = (uint32_t)acc * C::INV;
         mac_vs(acc, c2, m[K], C::MOD[0]);  // low word is now 0
-        acc = (acc >> 32) | ((uint64_t)c2 << 32);
-        c2 = 0;
+        mont_shift(acc, c2);
         mont_columns_lo<K + 1, C>(acc, c2, a, b, m);
     }
 }
@@ -330,11 +412,14 @@ template <int K, class C>
 __device__ __forceinline__ void mont_columns_hi(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* b, const uint32_t* m,
                                                 uint32_t* r) {
     if constexpr (K < 2 * C::N - 1) {
-        macs_vv<K - C::N + 1, C::N, K, C>(acc, c2, a, b);
-        macs_vs<K - C::N + 1, C::N, K, C>(acc, c2, m);
+        if constexpr (TopLimbsSmall<C>::value) {
+            mont_top_column<K, C::N, C>(acc, c2, a, b, m);
+        } else {
+            macs_vv<K - C::N + 1, C::N, K, C, true>(acc, c2, a, b);
+            macs_vs<K - C::N + 1, C::N, K, C>(acc, c2, m);
+        }
         r[K - C::N] = (uint32_t)acc;
-        acc = (acc >> 32) | ((uint64_t)c2 << 32);
-        c2 = 0;
+        mont_shift(acc, c2);
         mont_columns_hi<K + 1, C>(acc, c2, a, b, m, r);
     }
 }
@@ -351,20 +436,56 @@ __device__ __forceinline__ Fe<C> fe_mul(const Fe<C>& a, const Fe<C>& b) {
     fe_reduce_once(r);
     return r;
 }
+// The same product left in [0, 2p): (a b + m p) / R < a b / R + p, so any operands with a b < p R come out below 2p — and
+// p R > 9.8 p^2 for the 381-bit modulus (R = 2^384), so operands below 2p (even 2p x 4p) qualify: a chain of products needs no
+// conditional subtraction between its links.  Only for values that are multiplied again (by fe_mul / fe_sqr / this) and never
+// compared, added or subtracted before a reducing product has made them canonical.  (Not for Fr: 4 q^2 > q 2^256.)
+template <class C>
+__device__ __forceinline__ Fe<C> fe_mul_lazy(const Fe<C>& a, const Fe<C>& b) {
+    static_assert(C::N == 12, "only the 381-bit modulus leaves the three spare bits this needs");
+    constexpr int N = C::N;
+    uint32_t m[N];
+    Fe<C> r;
+    uint64_t acc = 0;
+    uint32_t c2 = 0;
+    mont_columns_lo<0, C>(acc, c2, a.v, b.v, m);
+    mont_columns_hi<N, C>(acc, c2, a.v, b.v, m, r.v);
+    r.v[N - 1] = (uint32_t)acc;
+    return r;
+}
 // Montgomery form of a*b + z*w with ONE reduction: the two products are summed column by column before the quotient digit
 // of the column is taken (3 N^2 multiply-adds instead of 4 N^2 for two products and an addition).  Needs 2 p^2 < p R, i.e.
 // p < R / 2, to come out below 2p: true for both moduli (p < 2^381, q < 2^255).
+// (column K >= N - 1 of a b + z w: three of the four top-limb terms and the reduction's go first, carry-free)
+template <int K, int VS_END, class C>
+__device__ __forceinline__ void mont2_top_column(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* b, const uint32_t* z,
+                                                 const uint32_t* w, const uint32_t* m) {
+    constexpr int N = C::N, L = K - (N - 1);
+    if constexpr (L == N - 1) {  // the last column: three terms below 2^62
+        macnc_vvs(acc, a[L], b[L], z[L], w[L], m[L], C::MOD[N - 1]);
+        c2 = 0;
+    } else {
+        macnc_vvvs(acc, a[L], b[N - 1], a[N - 1], b[L], z[L], w[N - 1], m[L], C::MOD[N - 1]);
+        mac_vv<true>(acc, c2, z[N - 1], w[L]);
+        macs_vv<L + 1, N - 1, K, C>(acc, c2, a, b);
+        macs_vv<L + 1, N - 1, K, C>(acc, c2, z, w);
+        macs_vs<L + 1, VS_END, K, C>(acc, c2, m);
+    }
+}
 template <int K, class C>
 __device__ __forceinline__ void mont2_columns_lo(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* b, const uint32_t* z,
                                                  const uint32_t* w, uint32_t* m) {
     if constexpr (K < C::N) {
-        macs_vv<0, K + 1, K, C>(acc, c2, a, b);
-        macs_vv<0, K + 1, K, C>(acc, c2, z, w);
-        macs_vs<0, K, K, C>(acc, c2, m);
+        if constexpr (TopLimbsSmall<C>::value && K == C::N - 1) {
+            mont2_top_column<K, K, C>(acc, c2, a, b, z, w, m);
+        } else {
+            macs_vv<0, K + 1, K, C, true>(acc, c2, a, b);
+            macs_vv<0, K + 1, K, C>(acc, c2, z, w);
+            macs_vs<0, K, K, C>(acc, c2, m);
+        }
         m[K] = (uint32_t)acc * C::INV;
         mac_vs(acc, c2, m[K], C::MOD[0]);  // low word is now 0
-        acc = (acc >> 32) | ((uint64_t)c2 << 32);
-        c2 = 0;
+        mont_shift(acc, c2);
         mont2_columns_lo<K + 1, C>(acc, c2, a, b, z, w, m);
     }
 }
@@ -372,12 +493,15 @@ template <int K, class C>
 __device__ __forceinline__ void mont2_columns_hi(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* b, const uint32_t* z,
                                                  const uint32_t* w, const uint32_t* m, uint32_t* r) {
     if constexpr (K < 2 * C::N - 1) {
-        macs_vv<K - C::N + 1, C::N, K, C>(acc, c2, a, b);
-        macs_vv<K - C::N + 1, C::N, K, C>(acc, c2, z, w);
-        macs_vs<K - C::N + 1, C::N, K, C>(acc, c2, m);
+        if constexpr (TopLimbsSmall<C>::value) {
+            mont2_top_column<K, C::N, C>(acc, c2, a, b, z, w, m);
+        } else {
+            macs_vv<K - C::N + 1, C::N, K, C, true>(acc, c2, a, b);
+            macs_vv<K - C::N + 1, C::N, K, C>(acc, c2, z, w);
+            macs_vs<K - C::N + 1, C::N, K, C>(acc, c2, m);
+        }
         r[K - C::N] = (uint32_t)acc;
-        acc = (acc >> 32) | ((uint64_t)c2 << 32);
-        c2 = 0;
+        mont_shift(acc, c2);
         mont2_columns_hi<K + 1, C>(acc, c2, a, b, z, w, m, r);
     }
 }
@@ -426,38 +550,68 @@ __host__ inline Fe<C> fe_mul(const Fe<C>& a, const Fe<C>& b) {
     fe_reduce_once(r);
     return r;
 }
+template <class C>
+__host__ inline Fe<C> fe_mul_lazy(const Fe<C>& a, const Fe<C>& b) {
+    return fe_mul(a, b);
+}
 // Montgomery square.  Device form: the same product scanning with the operand doubled ONCE up front (d = 2a < 2^(32N):
 // both moduli leave spare top bits).  With B = 2^32 and P_j = a mod B^j:
 //     2 sum_{i<j} a_i a_j B^(i+j) = sum_j a_j B^j (2 P_j),      2 P_j = sum_{i<j} d_i B^i + B^j msb(a_{j-1})
 // (the limbs of d below j are those of 2 P_j except for the bit that the shift pushed out of limb j-1), so column k is
 //     sum_{i < k-i} d_i a_{k-i}  +  [k = 2j] (a_j^2 + msb(a_{j-1}) a_j)  +  the reduction terms:
 // N(N+1)/2 + (N-1) + N^2 multiply-adds instead of 2 N^2 (233 instead of 288 for N = 12).
+// (column K >= N - 1 of a square: the cross term with a[N-1] and the reduction's top-limb term first, carry-free — see MASP_MACNC)
+template <int K, int VS_END, class C>
+__device__ __forceinline__ void sqr_top_column(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* a2, const uint32_t* m) {
+    constexpr int N = C::N, L = K - (N - 1);
+    if constexpr (L == N - 1) {  // the last column: a[N-1]^2, the shifted-out bit, m[N-1] MOD[N-1]
+        macnc_vvs(acc, a[L], a[L], a[L - 1] >> 31, a[L], m[L], C::MOD[N - 1]);
+        c2 = 0;
+    } else {
+        macnc_vs(acc, a2[L], a[N - 1], m[L], C::MOD[N - 1]);
+        constexpr bool CROSS = (K + 1) / 2 > L + 1;
+        if constexpr (CROSS) macs_vv<L + 1, (K + 1) / 2, K, C, true>(acc, c2, a2, a);
+        if constexpr (K % 2 == 0) {
+            mac_vv<!CROSS>(acc, c2, a[K / 2], a[K / 2]);
+            mac_vv(acc, c2, a[K / 2 - 1] >> 31, a[K / 2]);
+        }
+        macs_vs<L + 1, VS_END, K, C, !CROSS && K % 2 != 0>(acc, c2, m);
+    }
+}
 template <int K, class C>
 __device__ __forceinline__ void sqr_columns_lo(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* a2, uint32_t* m) {
     if constexpr (K < C::N) {
-        macs_vv<0, (K + 1) / 2, K, C>(acc, c2, a2, a);
-        if constexpr (K % 2 == 0) mac_vv(acc, c2, a[K / 2], a[K / 2]);
-        if constexpr (K % 2 == 0 && K >= 2) mac_vv(acc, c2, a[K / 2 - 1] >> 31, a[K / 2]);
-        macs_vs<0, K, K, C>(acc, c2, m);
+        if constexpr (TopLimbsSmall<C>::value && K == C::N - 1) {
+            sqr_top_column<K, K, C>(acc, c2, a, a2, m);
+        } else {
+            constexpr bool CROSS = (K + 1) / 2 > 0;  // (column 0 has no cross terms: its square comes first)
+            if constexpr (CROSS) macs_vv<0, (K + 1) / 2, K, C, true>(acc, c2, a2, a);
+            if constexpr (K % 2 == 0) mac_vv<!CROSS>(acc, c2, a[K / 2], a[K / 2]);
+            if constexpr (K % 2 == 0 && K >= 2) mac_vv(acc, c2, a[K / 2 - 1] >> 31, a[K / 2]);
+            macs_vs<0, K, K, C>(acc, c2, m);
+        }
         m[K] = (uint32_t)acc * C::INV;
         mac_vs(acc, c2, m[K], C::MOD[0]);  // low word is now 0
-        acc = (acc >> 32) | ((uint64_t)c2 << 32);
-        c2 = 0;
+        mont_shift(acc, c2);
         sqr_columns_lo<K + 1, C>(acc, c2, a, a2, m);
     }
 }
 template <int K, class C>
 __device__ __forceinline__ void sqr_columns_hi(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* a2, const uint32_t* m, uint32_t* r) {
     if constexpr (K < 2 * C::N - 1) {
-        macs_vv<K - C::N + 1, (K + 1) / 2, K, C>(acc, c2, a2, a);
-        if constexpr (K % 2 == 0) {
-            mac_vv(acc, c2, a[K / 2], a[K / 2]);
-            mac_vv(acc, c2, a[K / 2 - 1] >> 31, a[K / 2]);
+        if constexpr (TopLimbsSmall<C>::value) {
+            sqr_top_column<K, C::N, C>(acc, c2, a, a2, m);
+        } else {
+            constexpr bool CROSS = (K + 1) / 2 > K - C::N + 1;  // (the last column has no cross terms)
+            if constexpr (CROSS) macs_vv<K - C::N + 1, (K + 1) / 2, K, C, true>(acc, c2, a2, a);
+            if constexpr (K % 2 == 0) {
+                mac_vv<!CROSS>(acc, c2, a[K / 2], a[K / 2]);
+                mac_vv(acc, c2, a[K / 2 - 1] >> 31, a[K / 2]);
+            }
+            macs_vs<K - C::N + 1, C::N, K, C>(acc, c2, m);
         }
-        macs_vs<K - C::N + 1, C::N, K, C>(acc, c2, m);
         r[K - C::N] = (uint32_t)acc;
-        acc = (acc >> 32) | ((uint64_t)c2 << 32);
-        c2 = 0;
+        mont_shift(acc, c2);
         sqr_columns_hi<K + 1, C>(acc, c2, a, a2, m, r);
     }
 }
@@ -1117,6 +1271,7 @@ struct FpOps {
     static MASP_HD T neg(const T& a) { return fe_neg(a); }
     static MASP_HD T dbl(const T& a) { return fe_dbl(a); }
     static MASP_HD T mul(const T& a, const T& b) { return fe_mul(a, b); }
+    static MASP_HD T mul_lazy(const T& a, const T& b) { return fe_mul_lazy(a, b); }  // result in [0, 2p): see fe_mul_lazy
     static MASP_HD T sqr(const T& a) { return fe_sqr(a); }
     static MASP_HD bool is_zero(const T& a) { return fe_is_zero(a); }
     static MASP_HD bool eq(const T& a, const T& b) { return fe_eq(a, b); }
@@ -1149,6 +1304,7 @@ struct Fp2Ops {
         Fp cc = fe_mul_nc(fe_add(a.c0, a.c1), fe_add(b.c0, b.c1));
         return {fe_sub(aa, bb), fe_sub(fe_sub(cc, aa), bb)};
     }
+    static MASP_HD T mul_lazy(const T& a, const T& b) { return mul(a, b); }
     // (a0 + a1)(a0 - a1) + 2 a0 a1 u : 2 base-field products
     static MASP_HD T sqr(const T& a) {
         Fp s = fe_add(a.c0, a.c1), d = fe_sub(a.c0, a.c1);
@@ -1271,6 +1427,7 @@ struct Fp2PairOps {
     static __device__ __forceinline__ T neg(const T& a) { return fe_neg(a); }
     static __device__ __forceinline__ T dbl(const T& a) { return fe_dbl(a); }
     static __device__ __forceinline__ T mul(const T& a, const T& b) { return Fp2PairLanes::mul(a, b); }
+    static __device__ __forceinline__ T mul_lazy(const T& a, const T& b) { return Fp2PairLanes::mul(a, b); }
     static __device__ __forceinline__ T sqr(const T& a) { return Fp2PairLanes::sqr(a); }
     static __device__ __forceinline__ bool both(bool mine) {
         const uint32_t f = mine ? 1u : 0u;

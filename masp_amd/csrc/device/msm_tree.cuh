@@ -398,8 +398,9 @@ k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
                 n = O::one();
             }
         }
-        hq = O::mul(n, chain);    // numerator x (denominators before this pair): pass 2 multiplies by 1 / (denominators up to this pair)
-        chain = O::mul(chain, d);
+        // (both left in [0, 2p) — O::mul_lazy —: they are only ever multiplied again, by pass 2 and the shared inversion)
+        hq = O::mul_lazy(n, chain);    // numerator x (denominators before this pair): pass 2 multiplies by 1 / (denominators up to this pair)
+        chain = O::mul_lazy(chain, d);
     }
     if (j) plane_st(pre, pre_cap, src.at(((size_t)(j - 1) * np + p) * NT + t), hq);
     tp[src.at((size_t)p * NT + t)] = chain;
@@ -430,7 +431,7 @@ k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
             src.load_y(cr, y1, y2);
             if (tree_classify<O>(cx1, y1, cx2, y2, d) > TREE_DBL) d = O::one();
         }
-        chain = O::mul(chain, d);
+        chain = O::mul_lazy(chain, d);  // in [0, 2p): only ever multiplied again
     }
     if (j) plane_st(pre, pre_cap, src.at(((size_t)(j - 1) * np + p) * NT + t), chain);
     tp[src.at((size_t)p * NT + t)] = chain;
@@ -514,8 +515,9 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         }
         F x3, y3;
         if (kind <= TREE_DBL) {
-            const F Inext = O::mul(I, d);
-            const F lam = O::mul(I, qn);  // (numerator x denominators before this pair) / (denominators up to this pair)
+            // (I, qn and lam stay in [0, 2p): the square and the product below make x3 and y3 canonical)
+            const F Inext = O::mul_lazy(I, d);
+            const F lam = O::mul_lazy(I, qn);  // (numerator x denominators before this pair) / (denominators up to this pair)
             I = Inext;
             const F xx = kind == TREE_ADD ? c.x2 : c.x1;
             x3 = O::sub(O::sub(O::sqr(lam), c.x1), xx);
@@ -573,8 +575,8 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         if (O::is_zero(c.x1) || O::is_zero(c.x2) || O::is_zero(d)) kind = tree_classify<O>(c.x1, c.y1, c.x2, c.y2, d);
         F x3, y3;
         if (kind <= TREE_DBL) {
-            const F Inext = O::mul(I, d);
-            const F inv = j ? O::mul(I, pp) : I;
+            const F Inext = O::mul_lazy(I, d);   // I, pp and inv in [0, 2p): lam below is a reducing product of canonical x inv
+            const F inv = j ? O::mul_lazy(I, pp) : I;
             I = Inext;
             F lam, xx = c.x2;
             if (kind == TREE_ADD) {

@@ -12,6 +12,24 @@ __global__ void k_field_ops(int op, const uint8_t* a, const uint8_t* b, uint8_t*
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     constexpr int B = 4 * C::N;
+    if (op >= 16) {
+        // RAW limbs in, raw limbs out (Fp only): the Montgomery products on operands anywhere in [0, 2p) — what the lazily
+        // reduced chains of the bucket tree feed them, and the shapes that stress the carry-free top-limb terms (field.cuh,
+        // MASP_MACNC).  16 mul, 17 mul_lazy (left in [0, 2p)), 18 sqr, 19 mul2(a, b, b, a), 20 mul_lazy(mul_lazy(a, b), b)
+        if constexpr (C::N == 12) {
+            const Fe<C> x = fe_load_le<C>(a + (size_t)B * i), y = fe_load_le<C>(b + (size_t)B * i);
+            Fe<C> r;
+            switch (op) {
+                case 16: r = fe_mul(x, y); break;
+                case 17: r = fe_mul_lazy(x, y); break;
+                case 18: r = fe_sqr(x); break;
+                case 19: r = fe_mul2(x, y, y, x); break;
+                default: r = fe_mul_lazy(fe_mul_lazy(x, y), y);
+            }
+            fe_store_le(r, out + (size_t)B * i);
+        }
+        return;
+    }
     Fe<C> x = fe_to_mont(fe_load_le<C>(a + (size_t)B * i)), y = fe_to_mont(fe_load_le<C>(b + (size_t)B * i)), r;
     switch (op) {
         case 0: r = fe_add(x, y); break;

@@ -80,6 +80,39 @@ def test_field_ops_on_the_device(mh):
             assert not bad, (which, op, hex(pairs[bad[0]][0]), hex(pairs[bad[0]][1]), hex(got[bad[0]]))
 
 
+@pytest.mark.gpu
+def test_raw_products_below_2p_on_the_device(mh):
+    """The Montgomery products on RAW operands anywhere in [0, 2p): the bucket tree keeps its chains of products in that range
+    (fe_mul_lazy: no conditional subtraction between the links), and the products skip the carry word after the terms that hold
+    a top limb (below 2^30 for any operand below 2p).  Worst shapes: 2p - 1, every limb below the top one all ones, p, p + 1,
+    2^381 + ..., against python integers."""
+    rng = random.Random(12)
+    nb, RM = 48, 1 << 384
+    rinv = pow(RM, -1, P)
+    top = (2 * P) >> 352
+    edge = [0, 1, P - 1, P, P + 1, 2 * P - 1, 2 * P - 2, (top << 352) | ((2 * P) & ((1 << 352) - 1)) - 1, ((top - 1) << 352) | ((1 << 352) - 1),
+            (1 << 381) - 1, 1 << 381, (1 << 381) | ((1 << 352) - 1), (1 << 352) - 1, ((1 << 32) - 1) << 320, (top << 352), (top << 352) | 0xffffffff,
+            sum(0xffffffff << (64 * k) for k in range(6)) % (2 * P), sum(0xffffffff << (64 * k + 32) for k in range(5)) | ((top - 1) << 352)]
+    assert all(0 <= e < 2 * P for e in edge)
+    pairs = [(a, b) for a in edge for b in edge] + [(rng.randrange(2 * P), rng.randrange(2 * P)) for _ in range(6000)] + \
+            [(rng.choice(edge), rng.randrange(2 * P)) for _ in range(500)] + [(rng.randrange(2 * P), rng.choice(edge)) for _ in range(500)]
+    n = len(pairs)
+    A = b"".join(a.to_bytes(nb, "little") for a, _ in pairs)
+    B = b"".join(b.to_bytes(nb, "little") for _, b in pairs)
+    out = C.create_string_buffer(nb * n)
+    want = {16: (lambda a, b: a * b * rinv % P, True), 17: (lambda a, b: a * b * rinv % P, False), 18: (lambda a, b: a * a * rinv % P, True),
+            19: (lambda a, b: 2 * a * b * rinv % P, True), 20: (lambda a, b: a * b * rinv * b * rinv % P, False)}
+    for op, (f, canonical) in want.items():
+        ps = pairs
+        if op == 19:   # a b + z w must stay below p R: 2 (2p)^2 < 9.8 p^2 — every pair qualifies
+            pass
+        assert mh.mh_field_ops_gpu(0, op, A, B, out, n) == 0
+        got = [int.from_bytes(out.raw[nb * i:nb * (i + 1)], "little") for i in range(n)]
+        for i in range(n):
+            g, w = got[i], f(*ps[i])
+            assert g % P == w and (g < P if canonical else g < 2 * P), (op, hex(ps[i][0]), hex(ps[i][1]), hex(g))
+
+
 def _le(x):
     return np.frombuffer(x.to_bytes(32, "little"), np.uint8)
 
