@@ -322,30 +322,45 @@ __device__ __forceinline__ void mac_vs4(uint64_t& acc, uint32_t& c2, uint32_t a0
             : "v"(a0), "s"(k0), "v"(a1), "s"(k1), "v"(a2), "s"(k2), "v"(a3), "s"(k3)
             : "vcc");
 }
-// Multiply-adds that cannot carry out of the 64-bit accumulator, so that no carry word follows them: the terms of a column
-// that hold a TOP limb.  For the 381-bit modulus every operand of a product is below 2p < 2^382, its top limb below 2^30, the
-// modulus' top limb below 2^29: such a term is below 2^62, and a column starts from less than 2^39 (what the previous column
-// carried over), so the first three (four, if one of them is m x MOD[11] < 2^61) terms of a column may be of this kind.  The
-// columns 11 .. 22 of a 12-limb product have three: a[K-11] b[11], a[11] b[K-11], m[K-11] MOD[11] — 35 of 288 carry words less.
+// Multiply-adds that cannot carry out of the 64-bit accumulator, so that no carry word follows them.  A column starts from
+// what the previous one carried over (below 2^40); a term x y with x < 2^32 and y < c is below c 2^32; so terms whose bounds c
+// sum to less than 2^32 - 2^8 may come first in their column and skip the carry word.  Two kinds of terms have small bounds:
+//  * those that hold a TOP limb — every operand of a product is below 2p, its top limb below 2 MOD[N-1] + 2 (0.203 x 2^32):
+//    a[K-11] b[11] and a[11] b[K-11] in the columns 11 .. 22 of a 12-limb product;
+//  * reduction terms m[i] MOD[j] with a small modulus limb: MOD[11] (0.10), MOD[3] (0.12), MOD[10] (0.22), MOD[8] (0.26),
+//    MOD[9] (0.29) x 2^32 ..., taken smallest first while the column's budget lasts (NcTerms::vs_mask, at compile time).
+// For a 12-limb product: 69 of 288 carry words less.  Fp only: Fr's top limb has one spare bit, and raw scalars reach a product
+// before their range check has been acted on.
 #define MASP_MACNC(A, B) "v_mad_u64_u32 %0, vcc, " A ", " B ", %0\n\t"
 __device__ __forceinline__ void macnc_v(uint64_t& acc, uint32_t a, uint32_t b) { asm(MASP_MACNC("%1", "%2") : "+v"(acc) : "v"(a), "v"(b) : "vcc"); }
-__device__ __forceinline__ void macnc_vs(uint64_t& acc, uint32_t a, uint32_t b, uint32_t m, uint32_t k) {
-    asm(MASP_MACNC("%1", "%2") MASP_MACNC("%3", "%4") : "+v"(acc) : "v"(a), "v"(b), "v"(m), "s"(k) : "vcc");
+__device__ __forceinline__ void macnc_vv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1) {
+    asm(MASP_MACNC("%1", "%2") MASP_MACNC("%3", "%4") : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1) : "vcc");
 }
 __device__ __forceinline__ void macnc_s(uint64_t& acc, uint32_t m, uint32_t k) { asm(MASP_MACNC("%1", "%2") : "+v"(acc) : "v"(m), "s"(k) : "vcc"); }
-__device__ __forceinline__ void macnc_vvs(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t m, uint32_t k) {
-    asm(MASP_MACNC("%1", "%2") MASP_MACNC("%3", "%4") MASP_MACNC("%5", "%6") : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(m), "s"(k) : "vcc");
-}
-__device__ __forceinline__ void macnc_vvvs(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t m,
-                                           uint32_t k) {
-    asm(MASP_MACNC("%1", "%2") MASP_MACNC("%3", "%4") MASP_MACNC("%5", "%6") MASP_MACNC("%7", "%8")
-        : "+v"(acc)
-        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(m), "s"(k)
-        : "vcc");
-}
 template <class C>
-struct TopLimbsSmall {
-    static constexpr bool value = C::N == 12;  // Fp only: Fr's top limb has one spare bit, and raw scalars reach a product unchecked
+struct NcTerms {
+    static constexpr bool ON = C::N == 12;
+    static constexpr uint64_t TOP = 2ull * C::MOD[C::N - 1] + 2;        // bound of an operand's top limb (operands below 2p)
+    static constexpr uint64_t LIMIT = (1ull << 32) - (1ull << 8);       // budget of a column, in units of 2^32
+    // the reduction terms m[i] MOD[K - i], i in [I0, I1), that go carry-free after terms worth `base`: bit i of the result
+    static constexpr uint32_t vs_mask(int K, int I0, int I1, uint64_t base) {
+        uint32_t mask = 0;
+        uint64_t sum = base;
+        for (;;) {
+            int best = -1;
+            for (int i = I0; i < I1; ++i)
+                if (!((mask >> i) & 1u) && (best < 0 || C::MOD[K - i] < C::MOD[K - best])) best = i;
+            if (best < 0 || sum + C::MOD[K - best] + 1 > LIMIT) break;
+            sum += C::MOD[K - best] + 1;
+            mask |= 1u << best;
+        }
+        return mask;
+    }
+    static constexpr bool any_left(int I0, int I1, uint32_t mask) {
+        for (int i = I0; i < I1; ++i)
+            if (!((mask >> i) & 1u)) return true;
+        return false;
+    }
 };
 // acc += sum_{i = I}^{END-1} x[i] * y[k - i]   (VV: both operand arrays in VGPRs; VS: y = modulus limbs).  FIRST: these are the
 // first multiply-adds of their column (the range must not be empty): the carry word is written, not updated
@@ -375,29 +390,57 @@ __device__ __forceinline__ void macs_vs(uint64_t& acc, uint32_t& c2, const uint3
         mac_vs<FIRST>(acc, c2, x[I], C::MOD[K - I]);
     }
 }
+// the reduction terms of a column: those of MASK carry-free, the others with the carry word (FIRST: written by the first)
+template <int I, int END, int K, class C, uint32_t MASK>
+__device__ __forceinline__ void macsnc_vs(uint64_t& acc, const uint32_t* x) {
+    if constexpr (I < END) {
+        if constexpr ((MASK >> I) & 1u) macnc_s(acc, x[I], C::MOD[K - I]);
+        macsnc_vs<I + 1, END, K, C, MASK>(acc, x);
+    }
+}
+template <int I, int END, int K, class C, uint32_t MASK, bool FIRST>
+__device__ __forceinline__ void macs_vs_sel(uint64_t& acc, uint32_t& c2, const uint32_t* x) {
+    if constexpr (I < END) {
+        if constexpr ((MASK >> I) & 1u) {
+            macs_vs_sel<I + 1, END, K, C, MASK, FIRST>(acc, c2, x);
+        } else if constexpr (END - I >= 4 && ((MASK >> I) & 0xfu) == 0) {
+            mac_vs4<FIRST>(acc, c2, x[I], C::MOD[K - I], x[I + 1], C::MOD[K - I - 1], x[I + 2], C::MOD[K - I - 2], x[I + 3], C::MOD[K - I - 3]);
+            macs_vs_sel<I + 4, END, K, C, MASK, false>(acc, c2, x);
+        } else if constexpr (END - I >= 2 && ((MASK >> I) & 0x3u) == 0) {
+            mac_vs2<FIRST>(acc, c2, x[I], C::MOD[K - I], x[I + 1], C::MOD[K - I - 1]);
+            macs_vs_sel<I + 2, END, K, C, MASK, false>(acc, c2, x);
+        } else {
+            mac_vs<FIRST>(acc, c2, x[I], C::MOD[K - I]);
+            macs_vs_sel<I + 1, END, K, C, MASK, false>(acc, c2, x);
+        }
+    }
+}
 // end of a column: the low word has been consumed, the accumulator moves down one word (the carry word becomes its high word
 // and is written afresh by the next column's first multiply-add)
 __device__ __forceinline__ void mont_shift(uint64_t& acc, uint32_t c2) { acc = (acc >> 32) | ((uint64_t)c2 << 32); }
-// the multiply-adds of column K >= N - 1 with the top-limb terms first and carry-free (TopLimbsSmall); L = K - (N - 1) is the
-// lowest index of the column, VS_END the end of the range of reduction terms m[i] MOD[K - i] (K for column N - 1, else N)
+// the multiply-adds of column K before its quotient digit / output word, carry-free terms first (NcTerms).  VS_END: the end of
+// the range of reduction terms m[i] MOD[K - i] (K in the low half, where m[K] is still to come, N in the high half)
 template <int K, int VS_END, class C>
-__device__ __forceinline__ void mont_top_column(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* b, const uint32_t* m) {
-    constexpr int N = C::N, L = K - (N - 1);
-    if constexpr (L == N - 1) {  // the last column: a[N-1] b[N-1] + m[N-1] MOD[N-1], nothing can carry
-        macnc_vs(acc, a[L], b[L], m[L], C::MOD[N - 1]);
-        c2 = 0;
-    } else {
-        macnc_vvs(acc, a[L], b[N - 1], a[N - 1], b[L], m[L], C::MOD[N - 1]);
-        constexpr bool VV = N - 1 > L + 1;  // terms left between the two top-limb ones
-        if constexpr (VV) macs_vv<L + 1, N - 1, K, C, true>(acc, c2, a, b);
-        macs_vs<L + 1, VS_END, K, C, !VV>(acc, c2, m);
-    }
+__device__ __forceinline__ void mont_column_nc(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* b, const uint32_t* m) {
+    constexpr int N = C::N;
+    constexpr bool TOPCOL = K >= N - 1;
+    constexpr int L = TOPCOL ? K - (N - 1) : 0;                 // lowest index of the column
+    constexpr int NTOP = !TOPCOL ? 0 : (L == N - 1 ? 1 : 2);    // terms that hold a top limb
+    constexpr uint32_t MASK = NcTerms<C>::vs_mask(K, L, VS_END, NTOP * NcTerms<C>::TOP);
+    if constexpr (NTOP == 2) macnc_vv(acc, a[L], b[N - 1], a[N - 1], b[L]);
+    if constexpr (NTOP == 1) macnc_v(acc, a[L], b[L]);
+    macsnc_vs<L, VS_END, K, C, MASK>(acc, m);
+    constexpr int V0 = TOPCOL ? L + 1 : 0, V1 = TOPCOL ? N - 1 : K + 1;
+    constexpr bool VV = V1 > V0, VS = NcTerms<C>::any_left(L, VS_END, MASK);
+    if constexpr (VV) macs_vv<V0, V1, K, C, true>(acc, c2, a, b);
+    if constexpr (VS) macs_vs_sel<L, VS_END, K, C, MASK, !VV>(acc, c2, m);
+    if constexpr (!VV && !VS) c2 = 0;
 }
 template <int K, class C>
 __device__ __forceinline__ void mont_columns_lo(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* b, uint32_t* m) {
     if constexpr (K < C::N) {
-        if constexpr (TopLimbsSmall<C>::value && K == C::N - 1) {
-            mont_top_column<K, K, C>(acc, c2, a, b, m);
+        if constexpr (NcTerms<C>::ON) {
+            mont_column_nc<K, K, C>(acc, c2, a, b, m);
         } else {
             macs_vv<0, K + 1, K, C, true>(acc, c2, a, b);
             macs_vs<0, K, K, C>(acc, c2, m);
@@ -412,8 +455,8 @@ template <int K, class C>
 __device__ __forceinline__ void mont_columns_hi(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* b, const uint32_t* m,
                                                 uint32_t* r) {
     if constexpr (K < 2 * C::N - 1) {
-        if constexpr (TopLimbsSmall<C>::value) {
-            mont_top_column<K, C::N, C>(acc, c2, a, b, m);
+        if constexpr (NcTerms<C>::ON) {
+            mont_column_nc<K, C::N, C>(acc, c2, a, b, m);
         } else {
             macs_vv<K - C::N + 1, C::N, K, C, true>(acc, c2, a, b);
             macs_vs<K - C::N + 1, C::N, K, C>(acc, c2, m);
@@ -456,28 +499,36 @@ __device__ __forceinline__ Fe<C> fe_mul_lazy(const Fe<C>& a, const Fe<C>& b) {
 // Montgomery form of a*b + z*w with ONE reduction: the two products are summed column by column before the quotient digit
 // of the column is taken (3 N^2 multiply-adds instead of 4 N^2 for two products and an addition).  Needs 2 p^2 < p R, i.e.
 // p < R / 2, to come out below 2p: true for both moduli (p < 2^381, q < 2^255).
-// (column K >= N - 1 of a b + z w: three of the four top-limb terms and the reduction's go first, carry-free)
+// (the columns of a b + z w, carry-free terms first: four top-limb terms and the reduction's with MOD[N-1] fit the budget)
 template <int K, int VS_END, class C>
-__device__ __forceinline__ void mont2_top_column(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* b, const uint32_t* z,
-                                                 const uint32_t* w, const uint32_t* m) {
-    constexpr int N = C::N, L = K - (N - 1);
-    if constexpr (L == N - 1) {  // the last column: three terms below 2^62
-        macnc_vvs(acc, a[L], b[L], z[L], w[L], m[L], C::MOD[N - 1]);
-        c2 = 0;
-    } else {
-        macnc_vvvs(acc, a[L], b[N - 1], a[N - 1], b[L], z[L], w[N - 1], m[L], C::MOD[N - 1]);
-        mac_vv<true>(acc, c2, z[N - 1], w[L]);
-        macs_vv<L + 1, N - 1, K, C>(acc, c2, a, b);
-        macs_vv<L + 1, N - 1, K, C>(acc, c2, z, w);
-        macs_vs<L + 1, VS_END, K, C>(acc, c2, m);
+__device__ __forceinline__ void mont2_column_nc(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* b, const uint32_t* z,
+                                                const uint32_t* w, const uint32_t* m) {
+    constexpr int N = C::N;
+    constexpr bool TOPCOL = K >= N - 1;
+    constexpr int L = TOPCOL ? K - (N - 1) : 0;
+    constexpr int NTOP = !TOPCOL ? 0 : (L == N - 1 ? 2 : 4);
+    constexpr uint32_t MASK = NcTerms<C>::vs_mask(K, L, VS_END, NTOP * NcTerms<C>::TOP);
+    if constexpr (NTOP == 4) {
+        macnc_vv(acc, a[L], b[N - 1], a[N - 1], b[L]);
+        macnc_vv(acc, z[L], w[N - 1], z[N - 1], w[L]);
     }
+    if constexpr (NTOP == 2) macnc_vv(acc, a[L], b[L], z[L], w[L]);
+    macsnc_vs<L, VS_END, K, C, MASK>(acc, m);
+    constexpr int V0 = TOPCOL ? L + 1 : 0, V1 = TOPCOL ? N - 1 : K + 1;
+    constexpr bool VV = V1 > V0, VS = NcTerms<C>::any_left(L, VS_END, MASK);
+    if constexpr (VV) {
+        macs_vv<V0, V1, K, C, true>(acc, c2, a, b);
+        macs_vv<V0, V1, K, C>(acc, c2, z, w);
+    }
+    if constexpr (VS) macs_vs_sel<L, VS_END, K, C, MASK, !VV>(acc, c2, m);
+    if constexpr (!VV && !VS) c2 = 0;
 }
 template <int K, class C>
 __device__ __forceinline__ void mont2_columns_lo(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* b, const uint32_t* z,
                                                  const uint32_t* w, uint32_t* m) {
     if constexpr (K < C::N) {
-        if constexpr (TopLimbsSmall<C>::value && K == C::N - 1) {
-            mont2_top_column<K, K, C>(acc, c2, a, b, z, w, m);
+        if constexpr (NcTerms<C>::ON) {
+            mont2_column_nc<K, K, C>(acc, c2, a, b, z, w, m);
         } else {
             macs_vv<0, K + 1, K, C, true>(acc, c2, a, b);
             macs_vv<0, K + 1, K, C>(acc, c2, z, w);
@@ -493,8 +544,8 @@ template <int K, class C>
 __device__ __forceinline__ void mont2_columns_hi(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* b, const uint32_t* z,
                                                  const uint32_t* w, const uint32_t* m, uint32_t* r) {
     if constexpr (K < 2 * C::N - 1) {
-        if constexpr (TopLimbsSmall<C>::value) {
-            mont2_top_column<K, C::N, C>(acc, c2, a, b, z, w, m);
+        if constexpr (NcTerms<C>::ON) {
+            mont2_column_nc<K, C::N, C>(acc, c2, a, b, z, w, m);
         } else {
             macs_vv<K - C::N + 1, C::N, K, C, true>(acc, c2, a, b);
             macs_vv<K - C::N + 1, C::N, K, C>(acc, c2, z, w);
@@ -560,29 +611,33 @@ __host__ inline Fe<C> fe_mul_lazy(const Fe<C>& a, const Fe<C>& b) {
 // (the limbs of d below j are those of 2 P_j except for the bit that the shift pushed out of limb j-1), so column k is
 //     sum_{i < k-i} d_i a_{k-i}  +  [k = 2j] (a_j^2 + msb(a_{j-1}) a_j)  +  the reduction terms:
 // N(N+1)/2 + (N-1) + N^2 multiply-adds instead of 2 N^2 (233 instead of 288 for N = 12).
-// (column K >= N - 1 of a square: the cross term with a[N-1] and the reduction's top-limb term first, carry-free — see MASP_MACNC)
+// (the columns of a square, carry-free terms first: the cross term with a[N-1], the last column's square, small reduction terms)
 template <int K, int VS_END, class C>
-__device__ __forceinline__ void sqr_top_column(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* a2, const uint32_t* m) {
-    constexpr int N = C::N, L = K - (N - 1);
-    if constexpr (L == N - 1) {  // the last column: a[N-1]^2, the shifted-out bit, m[N-1] MOD[N-1]
-        macnc_vvs(acc, a[L], a[L], a[L - 1] >> 31, a[L], m[L], C::MOD[N - 1]);
-        c2 = 0;
-    } else {
-        macnc_vs(acc, a2[L], a[N - 1], m[L], C::MOD[N - 1]);
-        constexpr bool CROSS = (K + 1) / 2 > L + 1;
-        if constexpr (CROSS) macs_vv<L + 1, (K + 1) / 2, K, C, true>(acc, c2, a2, a);
-        if constexpr (K % 2 == 0) {
-            mac_vv<!CROSS>(acc, c2, a[K / 2], a[K / 2]);
-            mac_vv(acc, c2, a[K / 2 - 1] >> 31, a[K / 2]);
-        }
-        macs_vs<L + 1, VS_END, K, C, !CROSS && K % 2 != 0>(acc, c2, m);
+__device__ __forceinline__ void sqr_column_nc(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* a2, const uint32_t* m) {
+    constexpr int N = C::N;
+    constexpr bool TOPCOL = K >= N - 1;
+    constexpr int L = TOPCOL ? K - (N - 1) : 0;
+    constexpr bool LAST = L == N - 1;                      // a[N-1]^2 + the shifted-out bit x a[N-1]: both small
+    constexpr bool XTOP = TOPCOL && !LAST;                 // the cross term a2[L] a[N-1]
+    constexpr uint32_t MASK = NcTerms<C>::vs_mask(K, L, VS_END, (XTOP ? NcTerms<C>::TOP : 0) + (LAST ? NcTerms<C>::TOP + 2 : 0));
+    if constexpr (XTOP) macnc_v(acc, a2[L], a[N - 1]);
+    if constexpr (LAST) macnc_vv(acc, a[L], a[L], a[L - 1] >> 31, a[L]);
+    macsnc_vs<L, VS_END, K, C, MASK>(acc, m);
+    constexpr int X0 = L + (XTOP ? 1 : 0), X1 = (K + 1) / 2;
+    constexpr bool CROSS = X1 > X0, SQ = K % 2 == 0 && !LAST, VS = NcTerms<C>::any_left(L, VS_END, MASK);
+    if constexpr (CROSS) macs_vv<X0, X1, K, C, true>(acc, c2, a2, a);
+    if constexpr (SQ) {
+        mac_vv<!CROSS>(acc, c2, a[K / 2], a[K / 2]);
+        if constexpr (K >= 2) mac_vv(acc, c2, a[K / 2 - 1] >> 31, a[K / 2]);
     }
+    if constexpr (VS) macs_vs_sel<L, VS_END, K, C, MASK, !CROSS && !SQ>(acc, c2, m);
+    if constexpr (!CROSS && !SQ && !VS) c2 = 0;
 }
 template <int K, class C>
 __device__ __forceinline__ void sqr_columns_lo(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* a2, uint32_t* m) {
     if constexpr (K < C::N) {
-        if constexpr (TopLimbsSmall<C>::value && K == C::N - 1) {
-            sqr_top_column<K, K, C>(acc, c2, a, a2, m);
+        if constexpr (NcTerms<C>::ON) {
+            sqr_column_nc<K, K, C>(acc, c2, a, a2, m);
         } else {
             constexpr bool CROSS = (K + 1) / 2 > 0;  // (column 0 has no cross terms: its square comes first)
             if constexpr (CROSS) macs_vv<0, (K + 1) / 2, K, C, true>(acc, c2, a2, a);
@@ -599,8 +654,8 @@ __device__ __forceinline__ void sqr_columns_lo(uint64_t& acc, uint32_t& c2, cons
 template <int K, class C>
 __device__ __forceinline__ void sqr_columns_hi(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* a2, const uint32_t* m, uint32_t* r) {
     if constexpr (K < 2 * C::N - 1) {
-        if constexpr (TopLimbsSmall<C>::value) {
-            sqr_top_column<K, C::N, C>(acc, c2, a, a2, m);
+        if constexpr (NcTerms<C>::ON) {
+            sqr_column_nc<K, C::N, C>(acc, c2, a, a2, m);
         } else {
             constexpr bool CROSS = (K + 1) / 2 > K - C::N + 1;  // (the last column has no cross terms)
             if constexpr (CROSS) macs_vv<K - C::N + 1, (K + 1) / 2, K, C, true>(acc, c2, a2, a);
