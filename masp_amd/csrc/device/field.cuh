@@ -337,9 +337,23 @@ __device__ __forceinline__ void macnc_vv(uint64_t& acc, uint32_t a0, uint32_t b0
     asm(MASP_MACNC("%1", "%2") MASP_MACNC("%3", "%4") : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1) : "vcc");
 }
 __device__ __forceinline__ void macnc_s(uint64_t& acc, uint32_t m, uint32_t k) { asm(MASP_MACNC("%1", "%2") : "+v"(acc) : "v"(m), "s"(k) : "vcc"); }
+__device__ __forceinline__ void macnc_s2(uint64_t& acc, uint32_t m0, uint32_t k0, uint32_t m1, uint32_t k1) {
+    asm(MASP_MACNC("%1", "%2") MASP_MACNC("%3", "%4") : "+v"(acc) : "v"(m0), "s"(k0), "v"(m1), "s"(k1) : "vcc");
+}
+__device__ __forceinline__ void macnc_s3(uint64_t& acc, uint32_t m0, uint32_t k0, uint32_t m1, uint32_t k1, uint32_t m2, uint32_t k2) {
+    asm(MASP_MACNC("%1", "%2") MASP_MACNC("%3", "%4") MASP_MACNC("%5", "%6") : "+v"(acc) : "v"(m0), "s"(k0), "v"(m1), "s"(k1), "v"(m2), "s"(k2) : "vcc");
+}
+__device__ __forceinline__ void macnc_s4(uint64_t& acc, uint32_t m0, uint32_t k0, uint32_t m1, uint32_t k1, uint32_t m2, uint32_t k2, uint32_t m3,
+                                         uint32_t k3) {
+    asm(MASP_MACNC("%1", "%2") MASP_MACNC("%3", "%4") MASP_MACNC("%5", "%6") MASP_MACNC("%7", "%8")
+        : "+v"(acc)
+        : "v"(m0), "s"(k0), "v"(m1), "s"(k1), "v"(m2), "s"(k2), "v"(m3), "s"(k3)
+        : "vcc");
+}
 template <class C>
 struct NcTerms {
-    static constexpr bool ON = C::N == 12;
+    static constexpr bool ON = true;
+    static constexpr bool TOPS = C::N == 12;   // top-limb terms: Fp only (Fr: one spare bit, and raw scalars reach a product unchecked)
     static constexpr uint64_t TOP = 2ull * C::MOD[C::N - 1] + 2;        // bound of an operand's top limb (operands below 2p)
     static constexpr uint64_t LIMIT = (1ull << 32) - (1ull << 8);       // budget of a column, in units of 2^32
     // the reduction terms m[i] MOD[K - i], i in [I0, I1), that go carry-free after terms worth `base`: bit i of the result
@@ -355,6 +369,19 @@ struct NcTerms {
             mask |= 1u << best;
         }
         return mask;
+    }
+    static constexpr int count(uint32_t mask) {
+        int n = 0;
+        for (; mask; mask &= mask - 1) ++n;
+        return n;
+    }
+    static constexpr int nth(uint32_t mask, int n) {  // index of the n-th set bit
+        for (int i = 0; i < 32; ++i)
+            if ((mask >> i) & 1u) {
+                if (!n) return i;
+                --n;
+            }
+        return -1;
     }
     static constexpr bool any_left(int I0, int I1, uint32_t mask) {
         for (int i = I0; i < I1; ++i)
@@ -391,11 +418,23 @@ __device__ __forceinline__ void macs_vs(uint64_t& acc, uint32_t& c2, const uint3
     }
 }
 // the reduction terms of a column: those of MASK carry-free, the others with the carry word (FIRST: written by the first)
-template <int I, int END, int K, class C, uint32_t MASK>
-__device__ __forceinline__ void macsnc_vs(uint64_t& acc, const uint32_t* x) {
-    if constexpr (I < END) {
-        if constexpr ((MASK >> I) & 1u) macnc_s(acc, x[I], C::MOD[K - I]);
-        macsnc_vs<I + 1, END, K, C, MASK>(acc, x);
+template <int I, int END, int K, class C, uint32_t MASK, int FROM = 0>
+__device__ __forceinline__ void macsnc_vs(uint64_t& acc, const uint32_t* x) {  // (the bits of MASK lie in [I, END); as few asm statements as possible)
+    typedef NcTerms<C> T;
+    constexpr int LEFT = T::count(MASK) - FROM;
+    if constexpr (LEFT >= 4) {
+        constexpr int i0 = T::nth(MASK, FROM), i1 = T::nth(MASK, FROM + 1), i2 = T::nth(MASK, FROM + 2), i3 = T::nth(MASK, FROM + 3);
+        macnc_s4(acc, x[i0], C::MOD[K - i0], x[i1], C::MOD[K - i1], x[i2], C::MOD[K - i2], x[i3], C::MOD[K - i3]);
+        macsnc_vs<I, END, K, C, MASK, FROM + 4>(acc, x);
+    } else if constexpr (LEFT == 3) {
+        constexpr int i0 = T::nth(MASK, FROM), i1 = T::nth(MASK, FROM + 1), i2 = T::nth(MASK, FROM + 2);
+        macnc_s3(acc, x[i0], C::MOD[K - i0], x[i1], C::MOD[K - i1], x[i2], C::MOD[K - i2]);
+    } else if constexpr (LEFT == 2) {
+        constexpr int i0 = T::nth(MASK, FROM), i1 = T::nth(MASK, FROM + 1);
+        macnc_s2(acc, x[i0], C::MOD[K - i0], x[i1], C::MOD[K - i1]);
+    } else if constexpr (LEFT == 1) {
+        constexpr int i0 = T::nth(MASK, FROM);
+        macnc_s(acc, x[i0], C::MOD[K - i0]);
     }
 }
 template <int I, int END, int K, class C, uint32_t MASK, bool FIRST>
@@ -425,12 +464,12 @@ __device__ __forceinline__ void mont_column_nc(uint64_t& acc, uint32_t& c2, cons
     constexpr int N = C::N;
     constexpr bool TOPCOL = K >= N - 1;
     constexpr int L = TOPCOL ? K - (N - 1) : 0;                 // lowest index of the column
-    constexpr int NTOP = !TOPCOL ? 0 : (L == N - 1 ? 1 : 2);    // terms that hold a top limb
+    constexpr int NTOP = !TOPCOL || !NcTerms<C>::TOPS ? 0 : (L == N - 1 ? 1 : 2);    // terms that hold a top limb (taken carry-free)
     constexpr uint32_t MASK = NcTerms<C>::vs_mask(K, L, VS_END, NTOP * NcTerms<C>::TOP);
     if constexpr (NTOP == 2) macnc_vv(acc, a[L], b[N - 1], a[N - 1], b[L]);
     if constexpr (NTOP == 1) macnc_v(acc, a[L], b[L]);
     macsnc_vs<L, VS_END, K, C, MASK>(acc, m);
-    constexpr int V0 = TOPCOL ? L + 1 : 0, V1 = TOPCOL ? N - 1 : K + 1;
+    constexpr int V0 = NTOP ? L + 1 : L, V1 = NTOP == 2 ? N - 1 : (NTOP == 1 ? L : (TOPCOL ? N : K + 1));
     constexpr bool VV = V1 > V0, VS = NcTerms<C>::any_left(L, VS_END, MASK);
     if constexpr (VV) macs_vv<V0, V1, K, C, true>(acc, c2, a, b);
     if constexpr (VS) macs_vs_sel<L, VS_END, K, C, MASK, !VV>(acc, c2, m);
@@ -506,7 +545,7 @@ __device__ __forceinline__ void mont2_column_nc(uint64_t& acc, uint32_t& c2, con
     constexpr int N = C::N;
     constexpr bool TOPCOL = K >= N - 1;
     constexpr int L = TOPCOL ? K - (N - 1) : 0;
-    constexpr int NTOP = !TOPCOL ? 0 : (L == N - 1 ? 2 : 4);
+    constexpr int NTOP = !TOPCOL || !NcTerms<C>::TOPS ? 0 : (L == N - 1 ? 2 : 4);
     constexpr uint32_t MASK = NcTerms<C>::vs_mask(K, L, VS_END, NTOP * NcTerms<C>::TOP);
     if constexpr (NTOP == 4) {
         macnc_vv(acc, a[L], b[N - 1], a[N - 1], b[L]);
@@ -514,7 +553,7 @@ __device__ __forceinline__ void mont2_column_nc(uint64_t& acc, uint32_t& c2, con
     }
     if constexpr (NTOP == 2) macnc_vv(acc, a[L], b[L], z[L], w[L]);
     macsnc_vs<L, VS_END, K, C, MASK>(acc, m);
-    constexpr int V0 = TOPCOL ? L + 1 : 0, V1 = TOPCOL ? N - 1 : K + 1;
+    constexpr int V0 = NTOP ? L + 1 : L, V1 = NTOP == 4 ? N - 1 : (NTOP == 2 ? L : (TOPCOL ? N : K + 1));
     constexpr bool VV = V1 > V0, VS = NcTerms<C>::any_left(L, VS_END, MASK);
     if constexpr (VV) {
         macs_vv<V0, V1, K, C, true>(acc, c2, a, b);
@@ -617,8 +656,8 @@ __device__ __forceinline__ void sqr_column_nc(uint64_t& acc, uint32_t& c2, const
     constexpr int N = C::N;
     constexpr bool TOPCOL = K >= N - 1;
     constexpr int L = TOPCOL ? K - (N - 1) : 0;
-    constexpr bool LAST = L == N - 1;                      // a[N-1]^2 + the shifted-out bit x a[N-1]: both small
-    constexpr bool XTOP = TOPCOL && !LAST;                 // the cross term a2[L] a[N-1]
+    constexpr bool LAST = NcTerms<C>::TOPS && L == N - 1;  // a[N-1]^2 + the shifted-out bit x a[N-1]: both small
+    constexpr bool XTOP = NcTerms<C>::TOPS && TOPCOL && !LAST;   // the cross term a2[L] a[N-1]
     constexpr uint32_t MASK = NcTerms<C>::vs_mask(K, L, VS_END, (XTOP ? NcTerms<C>::TOP : 0) + (LAST ? NcTerms<C>::TOP + 2 : 0));
     if constexpr (XTOP) macnc_v(acc, a2[L], a[N - 1]);
     if constexpr (LAST) macnc_vv(acc, a[L], a[L], a[L - 1] >> 31, a[L]);
