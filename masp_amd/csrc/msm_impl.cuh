@@ -81,6 +81,9 @@ void MsmWorkspace<O>::reduce_to_one_lanes(hipStream_t s, uint32_t np, const Xyzz
         }
     }
 
+#ifndef MASP_LONE_HEAVY_THREADS
+#define MASP_LONE_HEAVY_THREADS 256
+#endif
 // The bucket tails of an MSM — gather, heavy buckets, weighted sums by levels, block reductions, combine — over OT::LANES lanes
 // per point (OT: O itself, its lane-pair form for G2, FpQuadOps for a lone proof's G1 MSMs).
 template <class O, class OT>
@@ -91,8 +94,8 @@ void msm_tails_enqueue(hipStream_t s, MsmWorkspace<O>& ws, const uint32_t* start
                        ws.n_heavy, lone ? 12u : 8u);
     if (lone) {
         const uint32_t heavy_blocks = std::min<uint32_t>(std::max<uint32_t>(4096u / np, 16u), nb) | 1u;
-        MASP_LAUNCH((k_msm_bucket_heavy<OT, 256>), dim3(heavy_blocks, np), dim3(256), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy,
-                           ws.n_heavy);
+        MASP_LAUNCH((k_msm_bucket_heavy<OT, MASP_LONE_HEAVY_THREADS>), dim3(heavy_blocks, np), dim3(MASP_LONE_HEAVY_THREADS), 0, s, ws.part, start, nb,
+                    nchunks, ws.bkt, ws.heavy, ws.n_heavy);
     } else {
         const uint32_t heavy_blocks = std::min<uint32_t>(64u, nb) | 1u;
         MASP_LAUNCH((k_msm_bucket_heavy<OT, 64>), dim3(heavy_blocks, np), dim3(64), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy,

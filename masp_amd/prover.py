@@ -269,7 +269,7 @@ class LocalTxProver:
                 out.append(dict(slot=CONVERT, inputs=r[0], aux=r[1], aux_form=1, cv=r[2], rcv=kw["rcv"], _pinned=buf))
         return out
 
-    def prove_batch(self, ctx, descriptions, threads=None, rs=None, chunk=None, progress=None):
+    def prove_batch(self, ctx, descriptions, threads=None, rs=None, chunk=None, progress=None, in_flight=None):
         """Batched form of the serial per-description loops of `SaplingBuilder::build`
         (/root/reference/masp_primitives/src/transaction/components/sapling/builder.rs:935-1140):
         descriptions = [("spend", kwargs) | ("output", kwargs) | ("convert", kwargs)] with the keyword arguments of
@@ -295,7 +295,9 @@ class LocalTxProver:
         # (with the lockstep synthesizer the host is no longer what a chunk waits for: full launch sequences from 4 x 256 descriptions on)
         cap = self._ctx.options["batch_cap"]
         chunk = chunk or (cap if n >= 4 * cap else max(64, min(cap, n // 8)))
-        in_flight = max(1, self._ctx.options["slots"])    # one call per slot of the native context
+        # GPU calls in flight: one per slot of the native context and one more, so that a slot is taken again at once while the
+        # chunk that held it is being self-verified (the call waits inside the library for a free slot)
+        in_flight = in_flight or max(1, self._ctx.options["slots"]) + 1
         prep = {"spend": self.prepare_spend, "output": self.prepare_output, "convert": self.prepare_convert}
         done = [0]
 
