@@ -229,6 +229,14 @@ __device__ __forceinline__ int tree_classify(const typename O::T& x1, const type
 // the operands of a pair from its record — level 0: the two digit-list words (table row | sign << 31, or the padding entry =
 // the point at infinity), gathered from the table and negated if the digit is negative; deeper levels: (first input point,
 // output point), read from the previous level's points
+// 1: the loads of the software pipelines are unconditional (the last iteration requests its own pair once more; the padding entry
+// reads a row of zeros): a conditional load keeps the old value of its 12 destination registers alive — the compiler copied every
+// operand twice per pair (old value into the destination before the load, destination into the working set after it).
+// 0: the round-3 form (A/B builds).
+#ifndef MASP_TREE_UNCOND
+#define MASP_TREE_UNCOND 1
+#endif
+static __device__ uint4 g_tree_zero_row[16];  // 256 bytes of zeros: the row a padding entry gathers (TabRow<Fp2Ops> is the larger)
 template <bool L0>
 struct TreeRec {
     typedef uint2 type;
@@ -248,6 +256,16 @@ struct TreeSrc {
         else
             return 0u;
     }
+#if MASP_TREE_UNCOND
+    // the padding entry reads a row of zeros (= the point at infinity) that lives next to the code: the address is selected, the
+    // loads are unconditional — no exec-masked blocks, no registers cleared for the lanes that skip them
+    __device__ __forceinline__ const TabRow<typename O::Base>* row(uint32_t w) const {
+        const TabRow<typename O::Base>* z = reinterpret_cast<const TabRow<typename O::Base>*>(g_tree_zero_row);
+        return w == MSM_PAD_ENTRY ? z : tab + (w & 0x7fffffffu);
+    }
+    __device__ __forceinline__ F row_x(uint32_t w) const { return reinterpret_cast<const F*>(&row(w)->p.x)[h]; }
+    __device__ __forceinline__ F row_y(uint32_t w) const { return reinterpret_cast<const F*>(&row(w)->p.y)[h]; }
+#else
     __device__ __forceinline__ F row_x(uint32_t w) const {
         if (w == MSM_PAD_ENTRY) return O::zero();
         return reinterpret_cast<const F*>(&tab[w & 0x7fffffffu].p.x)[h];
@@ -256,6 +274,7 @@ struct TreeSrc {
         if (w == MSM_PAD_ENTRY) return O::zero();
         return reinterpret_cast<const F*>(&tab[w & 0x7fffffffu].p.y)[h];
     }
+#endif
     __device__ __forceinline__ size_t at(size_t i) const { return i * O::LANES + h; }
     // proof p of np, pt_stride points per proof (even)
     __device__ __forceinline__ void set(const F* xs_, const F* ys_, uint32_t p, uint32_t np, size_t pt_stride) {
@@ -351,8 +370,19 @@ k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
     // rec_ == nullptr: a level >= 1 whose runs all have even lengths (the sort padded to a multiple of 2^(level + 1)): pair q is
     // points 2q, 2q + 1 and lands at point q, like level 0 over the digit list
     const Rec* recs = reinterpret_cast<const Rec*>(rec_) + (size_t)p * rec_stride;
+#if MASP_TREE_UNCOND
+    // (level 0 always has its records — the digit list; on the deeper levels the load is unconditional too, from a harmless
+    // address when there are no records: a load inside a conditional block is waited for at the block's end, with vmcnt(0))
+    const bool synth = !L0 && rec_ == nullptr;
+    const Rec* recs_ld = synth ? reinterpret_cast<const Rec*>(Ql) : recs;
+    auto rec_at = [&](uint32_t q) -> Rec {
+        const Rec r = recs_ld[synth ? 0u : q];
+        return synth ? make_uint2(2u * q, q) : r;
+    };
+#else
     const bool synth = rec_ == nullptr;
     auto rec_at = [&](uint32_t q) -> Rec { return synth ? make_uint2(2u * q, q) : recs[q]; };
+#endif
     TreeSrc<O, L0> src;
     src.tab = tab;
     src.set(xs, ys, p, np, pt_stride);
@@ -384,8 +414,17 @@ k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         Ops c = nxt;
         if (j) plane_st(pre, pre_cap, src.at(((size_t)(j - 1) * np + p) * NT + t), hq);
         ra = rb;
+#if MASP_TREE_UNCOND
+        if (q + NT >= P) ra = cr;  // the last iteration asks for its own pair again: nothing reads it
+        fetch(ra, nxt);
+#else
         if (q + NT < P) fetch(ra, nxt);
+#endif
+#if MASP_TREE_UNCOND
+        rb = rec_at(q + 2 * (uint64_t)NT < P ? q + 2 * NT : q);
+#else
         if (q + 2 * (uint64_t)NT < P) rb = rec_at(q + 2 * NT);
+#endif
         TreeSrc<O, L0>::fix_y(cr, c.y1, c.y2);
         F d = O::sub(c.x2, c.x1), n = O::sub(c.y2, c.y1);
         if (O::is_zero(c.x1) || O::is_zero(c.x2) || O::is_zero(d)) {  // rare
@@ -423,8 +462,17 @@ k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         const F cx1 = x1, cx2 = x2;
         if (j) plane_st(pre, pre_cap, src.at(((size_t)(j - 1) * np + p) * NT + t), chain);
         ra = rb;
+#if MASP_TREE_UNCOND
+        if (q + NT >= P) ra = cr;
+        src.load_x(ra, x1, x2);
+#else
         if (q + NT < P) src.load_x(ra, x1, x2);
+#endif
+#if MASP_TREE_UNCOND
+        rb = rec_at(q + 2 * (uint64_t)NT < P ? q + 2 * NT : q);
+#else
         if (q + 2 * (uint64_t)NT < P) rb = rec_at(q + 2 * NT);
+#endif
         F d = O::sub(cx2, cx1);
         if (O::is_zero(cx1) || O::is_zero(cx2) || O::is_zero(d)) {  // rare: needs the y coordinates to decide
             F y1, y2;
@@ -456,8 +504,19 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
     // rec_ == nullptr: a level >= 1 whose runs all have even lengths (the sort padded to a multiple of 2^(level + 1)): pair q is
     // points 2q, 2q + 1 and lands at point q, like level 0 over the digit list
     const Rec* recs = reinterpret_cast<const Rec*>(rec_) + (size_t)p * rec_stride;
+#if MASP_TREE_UNCOND
+    // (level 0 always has its records — the digit list; on the deeper levels the load is unconditional too, from a harmless
+    // address when there are no records: a load inside a conditional block is waited for at the block's end, with vmcnt(0))
+    const bool synth = !L0 && rec_ == nullptr;
+    const Rec* recs_ld = synth ? reinterpret_cast<const Rec*>(Ql) : recs;
+    auto rec_at = [&](uint32_t q) -> Rec {
+        const Rec r = recs_ld[synth ? 0u : q];
+        return synth ? make_uint2(2u * q, q) : r;
+    };
+#else
     const bool synth = rec_ == nullptr;
     auto rec_at = [&](uint32_t q) -> Rec { return synth ? make_uint2(2u * q, q) : recs[q]; };
+#endif
     TreeSrc<O, L0> src;
     src.tab = tab;
     src.set(xs, ys, p, np, pt_stride);
@@ -501,8 +560,17 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         ra = rb;
         if (held) put(hout, hx, hy);
         const F qn = plane_ld(pre, pre_cap, src.at(((size_t)j * np + p) * NT + t));
+#if MASP_TREE_UNCOND
+        if (!j) ra = cr;  // the last iteration asks for its own pair again: nothing reads it
+        fetch(ra, nxt);
+#else
         if (j) fetch(ra, nxt);
+#endif
+#if MASP_TREE_UNCOND
+        rb = rec_at(t + (j > 1 ? j - 2 : 0u) * NT);
+#else
         if (j > 1) rb = rec_at(t + (j - 2) * NT);
+#endif
         const uint32_t out = TreeSrc<O, L0>::out_index(cr, t + j * NT);
         TreeSrc<O, L0>::fix_y1(cr, c.y1);
         F d = O::sub(c.x2, c.x1);
@@ -566,8 +634,17 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         if (held) put(hout, hx, hy);
         F pp = O::one();
         if (j) pp = plane_ld(pre, pre_cap, src.at(((size_t)(j - 1) * np + p) * NT + t));
+#if MASP_TREE_UNCOND
+        if (!j) ra = cr;  // the last iteration asks for its own pair again: nothing reads it
+        fetch(ra, nxt);
+#else
         if (j) fetch(ra, nxt);
+#endif
+#if MASP_TREE_UNCOND
+        rb = rec_at(t + (j > 1 ? j - 2 : 0u) * NT);
+#else
         if (j > 1) rb = rec_at(t + (j - 2) * NT);
+#endif
         const uint32_t out = TreeSrc<O, L0>::out_index(cr, t + j * NT);
         TreeSrc<O, L0>::fix_y(cr, c.y1, c.y2);
         F d = O::sub(c.x2, c.x1);
