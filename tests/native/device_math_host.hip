@@ -2,6 +2,7 @@
 // source the HIP kernels use can be checked on a machine without a GPU (tests/test_device_math_host.py).
 // It is never part of the product library.
 #include "../../masp_amd/csrc/device/io.cuh"
+#include "../../tools/fp28.cuh"   // (an experiment kept with its checks: see the header)
 using namespace masp;
 
 // ---- the same field functions ON THE DEVICE (their device overloads are hand-written carry chains / inline asm that the host
@@ -40,6 +41,45 @@ __global__ void k_field_ops(int op, const uint8_t* a, const uint8_t* b, uint8_t*
         default: r = fe_sqr(x);
     }
     fe_store_le(fe_from_mont(r), out + (size_t)B * i);
+}
+
+// ---- the 28-bit-limb form (device/fp28.cuh): raw limbs in and out, 56 bytes per element (an Fp operand / result uses the first
+// 48).  op: 0 mul 1 sqr 2 canon 3 sub_lazy 4 neg 5 from_fp 6 from_fp_lazy 7 to_fp 8 Ops::add 9 Ops::sub 10 Ops::dbl
+// 11 canon(sub_lazy(sub_lazy(sqr(a), b), b)) 12 is_zero(a) | eq(a, b) << 1
+MASP_HD void fp28_test_op(int op, const uint8_t* pa, const uint8_t* pb, uint8_t* po) {
+    F28 a, b, r = fp28_zero();
+    Fp fa, fr;
+    for (int i = 0; i < 14; ++i) {
+        a.v[i] = (uint32_t)pa[4 * i] | (uint32_t)pa[4 * i + 1] << 8 | (uint32_t)pa[4 * i + 2] << 16 | (uint32_t)pa[4 * i + 3] << 24;
+        b.v[i] = (uint32_t)pb[4 * i] | (uint32_t)pb[4 * i + 1] << 8 | (uint32_t)pb[4 * i + 2] << 16 | (uint32_t)pb[4 * i + 3] << 24;
+    }
+    for (int i = 0; i < 12; ++i) fa.v[i] = a.v[i];
+    bool is_fp = false;
+    switch (op) {
+        case 0: r = fp28_mul(a, b); break;
+        case 1: r = fp28_sqr(a); break;
+        case 2: r = fp28_canon(a); break;
+        case 3: r = fp28_sub_lazy(a, b); break;
+        case 4: r = fp28_neg(a); break;
+        case 5: r = fp28_from_fp(fa); break;
+        case 6: r = fp28_from_fp_lazy(fa); break;
+        case 7: fr = fp28_to_fp(a); is_fp = true; break;
+        case 8: r = Fp28Ops::add(a, b); break;
+        case 9: r = Fp28Ops::sub(a, b); break;
+        case 10: r = Fp28Ops::dbl(a); break;
+        case 11: r = fp28_canon(fp28_sub_lazy(fp28_sub_lazy(fp28_sqr(a), b), b)); break;
+        default: r.v[0] = (fp28_is_zero(a) ? 1u : 0u) | (fp28_eq(a, b) ? 2u : 0u); break;
+    }
+    if (is_fp) {
+        for (int i = 0; i < 12; ++i) r.v[i] = fr.v[i];
+        r.v[12] = r.v[13] = 0;
+    }
+    for (int i = 0; i < 14; ++i)
+        for (int k = 0; k < 4; ++k) po[4 * i + k] = (uint8_t)(r.v[i] >> (8 * k));
+}
+__global__ void k_fp28_ops(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fp28_test_op(op, a + 56 * (size_t)i, b + 56 * (size_t)i, out + 56 * (size_t)i);
 }
 
 extern "C" {
@@ -130,6 +170,24 @@ int mh_field_ops_gpu(int which, int op, const uint8_t* a, const uint8_t* b, uint
         hipLaunchKernelGGL((k_field_ops<FpCfg>), dim3((n + 63) / 64), dim3(64), 0, 0, op, da, db, dout, n);
     else
         hipLaunchKernelGGL((k_field_ops<FrCfg>), dim3((n + 63) / 64), dim3(64), 0, 0, op, da, db, dout, n);
+    e = hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);
+    hipFree(da);
+    hipFree(db);
+    hipFree(dout);
+    return (int)e;
+}
+int mh_fp28_ops(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, int n) {
+    for (int i = 0; i < n; ++i) fp28_test_op(op, a + 56 * (size_t)i, b + 56 * (size_t)i, out + 56 * (size_t)i);
+    return 0;
+}
+int mh_fp28_ops_gpu(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, int n) {
+    const size_t bytes = (size_t)56 * n;
+    uint8_t *da, *db, *dout;
+    hipError_t e;
+    if ((e = hipMalloc(&da, bytes)) || (e = hipMalloc(&db, bytes)) || (e = hipMalloc(&dout, bytes))) return (int)e;
+    hipMemcpy(da, a, bytes, hipMemcpyHostToDevice);
+    hipMemcpy(db, b, bytes, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_fp28_ops, dim3((n + 63) / 64), dim3(64), 0, 0, op, da, db, dout, n);
     e = hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);
     hipFree(da);
     hipFree(db);

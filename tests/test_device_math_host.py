@@ -20,7 +20,7 @@ SO = os.path.join(HERE, "native", "_device_math_host.so")
 
 @pytest.fixture(scope="module")
 def mh():
-    hdrs = [os.path.join(HERE, "..", "masp_amd", "csrc", "device", f) for f in ("field.cuh", "curve.cuh", "io.cuh", "consts.cuh")]
+    hdrs = [os.path.join(HERE, "..", "masp_amd", "csrc", "device", f) for f in ("field.cuh", "curve.cuh", "io.cuh", "consts.cuh")] + [os.path.join(HERE, "..", "tools", "fp28.cuh")]
     newest = max(os.path.getmtime(p) for p in hdrs + [SRC])
     if not os.path.exists(SO) or os.path.getmtime(SO) < newest:
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", SRC, "-o", SO])
@@ -167,3 +167,120 @@ def test_g2_group_law_and_encodings(mh):
     cnt[2, 0], cnt[2, 1] = 1, 1
     assert mh.mh_g2_lincomb(p3.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p), 3, 1, o192, o96) == 0
     assert o192.raw == O.g2_mul_gen(3 * ks[0] % R)[0]
+
+
+# ---- the 28-bit-limb form of Fp (tools/fp28.cuh: an experiment, measured and rejected — DESIGN.md section 6) ----------------------------------------------------------------------
+M28, R28 = (1 << 28) - 1, 1 << 392
+
+
+def _l28(limbs):
+    return b"".join(int(v).to_bytes(4, "little") for v in limbs)
+
+
+def _n28(x):  # normalised limbs of an integer < 2^392
+    return [(x >> (28 * i)) & M28 for i in range(14)]
+
+
+def _v28(raw):
+    return sum(int.from_bytes(raw[4 * i:4 * i + 4], "little") << (28 * i) for i in range(14))
+
+
+def _fp28_cases():
+    rng = random.Random(28)
+    K2 = [0x1fff5556, 0x1fdffffe, 0x17ffff72, 0x1fffd629, 0x1c483d56, 0x141ed61d, 0x1ece61a4, 0x1e70a256, 0x18ee9708, 0x19759aeb, 0x174f6c85,
+          0x1cd34962, 0x13d472fe, 0x34021]
+    assert sum(k << (28 * i) for i, k in enumerate(K2)) == 2 * P
+    canon_edge = [0, 1, 2, P - 1, P - 2, (P - 1) // 2, M28, 1 << 28, (1 << 364) - 1, 1 << 364, (0x1a011 << 364), (0x1a011 << 364) - 1, P - (1 << 28),
+                  P - (1 << 364), (1 << 380) | 5, sum(M28 << (28 * i) for i in range(13))]
+    canon_edge = [c % P for c in canon_edge]
+    canon = canon_edge + [rng.randrange(P) for _ in range(3000)]
+    return rng, canon_edge, canon
+
+
+def _run28(fn, op, A, B):
+    n = len(A)
+    out = C.create_string_buffer(56 * n)
+    assert fn(op, b"".join(A), b"".join(B), out, n) == 0
+    return [out.raw[56 * i:56 * (i + 1)] for i in range(n)]
+
+
+def _check_fp28(fn):
+    rng, canon_edge, canon = _fp28_cases()
+    rinv = pow(R28, -1, P)
+    z = _l28([0] * 14)
+    # canon: lazy limbs < 2^31 with value < 8p — built from k p + c spread over lifted limbs, and plain random lazy limbs
+    lazy = []
+    for _ in range(3000):
+        v = rng.randrange(8 * P)
+        limbs = _n28(v)
+        for i in range(13):  # move whole 2^28s down from the limb above where there are some: same value, fatter limbs
+            t = min(limbs[i + 1], rng.randrange(8))
+            limbs[i + 1] -= t
+            limbs[i] += t << 28
+        lazy.append(limbs)
+    for k in range(8):
+        for c in canon_edge:
+            if k * P + c < 8 * P:
+                lazy.append(_n28(k * P + c))
+    lazy += [_n28(k * P) for k in range(8)] + [_n28(k * P - 1) for k in range(1, 9)]
+    got = _run28(fn, 2, [_l28(l) for l in lazy], [z] * len(lazy))
+    for l, g in zip(lazy, got):
+        v = sum(x << (28 * i) for i, x in enumerate(l))
+        assert _v28(g) == v % P and all(int.from_bytes(g[4 * i:4 * i + 4], "little") <= M28 for i in range(14)), (hex(v), g.hex())
+    # products of lazy operands (limbs up to 2^30 on both sides), result N < 2p
+    ops = [(rng.choice(lazy), rng.choice(lazy)) for _ in range(3000)] + [(_n28(a), _n28(b)) for a in canon_edge for b in canon_edge]
+    fat = [[min(x * 3, (1 << 30) - 1) for x in _n28(rng.randrange(2 * P))] for _ in range(200)]   # limbs up to 2^30, any value
+    ops += [(rng.choice(fat), rng.choice(fat)) for _ in range(500)] + [(_n28(rng.randrange(2 * P)), rng.choice(lazy)) for _ in range(2000)]
+    val = lambda l: sum(x << (28 * i) for i, x in enumerate(l))
+    got = _run28(fn, 0, [_l28(a) for a, _ in ops], [_l28(b) for _, b in ops])
+    for (a, b), g in zip(ops, got):
+        if val(a) * val(b) >= P * R28 or 14 * max(a) * max(b) + 14 * (1 << 56) + (1 << 36) >= 1 << 64:   # the product's contract
+            continue
+        assert _v28(g) < 2 * P and _v28(g) % P == val(a) * val(b) * rinv % P, (a, b)
+        assert all(int.from_bytes(g[4 * i:4 * i + 4], "little") <= M28 for i in range(13))
+    sq = [l for l in lazy if max(l) < (1 << 29)] + [_n28(c) for c in canon_edge]
+    got = _run28(fn, 1, [_l28(a) for a in sq], [z] * len(sq))
+    for a, g in zip(sq, got):
+        assert _v28(g) < 2 * P and _v28(g) % P == val(a) ** 2 * rinv % P, a
+    # sub_lazy / neg / add / sub / dbl / the x3 formula on canonical operands
+    pairs = [(a, b) for a in canon_edge for b in canon_edge] + [(rng.choice(canon), rng.choice(canon)) for _ in range(3000)] + [(a, a) for a in canon_edge]
+    A, B = [_l28(_n28(a)) for a, _ in pairs], [_l28(_n28(b)) for _, b in pairs]
+    for op, f in ((3, lambda a, b: (a - b) % P), (8, lambda a, b: (a + b) % P), (9, lambda a, b: (a - b) % P), (10, lambda a, b: 2 * a % P),
+                  (4, lambda a, b: (-a) % P), (11, lambda a, b: (a * a * rinv - 2 * b) % P)):
+        got = _run28(fn, op, A, B)
+        for (a, b), g in zip(pairs, got):
+            if op == 3:
+                assert _v28(g) % P == f(a, b) and _v28(g) < 3 * P
+            else:
+                assert _v28(g) == f(a, b), (op, hex(a), hex(b), hex(_v28(g)))
+    got = _run28(fn, 12, A, B)
+    for (a, b), g in zip(pairs, got):
+        assert g[0] == (1 if a == 0 else 0) | (2 if a == b else 0)
+    # to and from the 12 x 32-bit residues: s = x 2^384 mod p  <->  x 2^392 mod p
+    fps = canon_edge + [rng.randrange(P) for _ in range(2000)]
+    F = [s.to_bytes(48, "little") + b"\0" * 8 for s in fps]
+    got = _run28(fn, 5, F, [z] * len(F))
+    for s, g in zip(fps, got):
+        assert _v28(g) == s * 256 % P
+    fps2 = fps + [rng.randrange(2 * P) for _ in range(500)]
+    F2_ = [s.to_bytes(48, "little") + b"\0" * 8 for s in fps2]
+    got = _run28(fn, 6, F2_, [z] * len(F2_))
+    for s, g in zip(fps2, got):
+        assert _v28(g) == s * 256 and all(int.from_bytes(g[4 * i:4 * i + 4], "little") <= M28 for i in range(14))
+    back = [rng.randrange(2 * P) for _ in range(2000)] + canon_edge + [P, P + 1, 2 * P - 1]
+    got = _run28(fn, 7, [_l28(_n28(v)) for v in back], [z] * len(back))
+    inv256 = pow(256, -1, P)
+    for v, g in zip(back, got):
+        assert int.from_bytes(g[:48], "little") == v * inv256 % P
+
+
+def test_fp28_ops_host(mh):
+    """The 28-bit-limb field written for the G1 bucket tree (tools/fp28.cuh; not in the product), portable build: products of lazy operands, the carry-free
+    differences, canonicalisation from every k p + c, the conversions to and from the 12 x 32-bit Montgomery residues."""
+    _check_fp28(mh.mh_fp28_ops)
+
+
+@pytest.mark.gpu
+def test_fp28_ops_on_the_device(mh):
+    """The same on the GPU: there the products are v_mad_u64_u32 chains without a carry word, the column shift a v_alignbit."""
+    _check_fp28(mh.mh_fp28_ops_gpu)
