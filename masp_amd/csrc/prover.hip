@@ -118,11 +118,15 @@ static size_t slot_acquire_blocking(masp_hip_ctx* ctx) {
     return found;
 }
 static void slot_release(masp_hip_ctx* ctx, size_t si) {
+    bool idle = true;
     {
         std::lock_guard<std::mutex> g(ctx->slot_mu);
         ctx->slot_busy[si] = 0;
+        for (char b : ctx->slot_busy) idle = idle && !b;
     }
     ctx->slot_cv.notify_one();
+    // nothing of this context is in flight: the moment to give back what its workspaces outgrew (util.h, dev_free)
+    if (idle) dev_free_drain();
 }
 static int fail_shared(masp_hip_ctx* ctx, int rc) {
     if (rc == MASP_HIP_E_HIP) {
@@ -593,6 +597,7 @@ void masp_hip_ctx_destroy(masp_hip_ctx* ctx) {
     ctx->domains.clear();
     if (ctx->main_stream) hipStreamDestroy(ctx->main_stream);
     delete ctx;
+    dev_free_drain();  // the context's buffers
 }
 
 int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* params, size_t params_len, const masp_hip_r1cs* cs) {
@@ -857,8 +862,15 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
         }
         return o.si;
     };
+#ifdef MASP_ENQ_TIMING
+    const auto tcall = std::chrono::steady_clock::now();
+    auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+#endif
     for (size_t gi = 0; gi < groups.size() && result == MASP_HIP_OK; ++gi) {
         size_t si = 0;
+#ifdef MASP_ENQ_TIMING
+        const auto tg0 = std::chrono::steady_clock::now();
+#endif
         rc = slot_try_acquire(ctx, &si);
         if (rc > 0) {
             result = fail_shared(ctx, rc);
@@ -874,6 +886,10 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
         Circuit& C = *ctx->circ[jobs[G.idx[0]].circuit];
         const size_t nv = (size_t)C.n_inputs + C.n_aux, np = G.idx.size();
         const bool has_abc = jobs[G.idx[0]].a != nullptr;
+#ifdef MASP_ENQ_TIMING
+        const double t_wait = ms_since(tg0);
+        const auto tg1 = std::chrono::steady_clock::now();
+#endif
         // staging layout: [np][nv] witness | (a | b | c each [np][nrows]) | [np][16] r,s limbs
         const size_t w_bytes = 32 * nv * np, abc_bytes = has_abc ? 3 * 32 * (size_t)C.nrows * np : 0, rs_bytes = 64 * np;
         const size_t in_bytes = 32 * (size_t)C.n_inputs * np;  // the public inputs once more, packed (see below)
@@ -965,8 +981,15 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
             break;
         }
         owned.push_back({si, gi});
+#ifdef MASP_ENQ_TIMING
+        fprintf(stderr, "[grp] call %p t=%8.2f ms group %zu circuit %u np %zu slot %zu: waited %.2f ms for the slot, staged + enqueued in %.2f ms\n", (void*)jobs,
+                ms_since(tcall), gi, jobs[G.idx[0]].circuit, np, si, t_wait, ms_since(tg1));
+#endif
     }
     while (!owned.empty()) slot_release(ctx, retire_oldest());
+#ifdef MASP_ENQ_TIMING
+    fprintf(stderr, "[call] %p done after %.2f ms (%zu jobs)\n", (void*)jobs, ms_since(tcall), n);
+#endif
     if (result == MASP_HIP_OK) ctx->proofs_done += n;
     // a launch the runtime refused on this thread (MASP_LAUNCH keeps the first: kernel, file:line, HIP's text)
     const int launch_rc = launch_status();

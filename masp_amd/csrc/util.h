@@ -45,14 +45,50 @@ inline std::atomic<uint64_t>& device_alloc_epoch() {
     static std::atomic<uint64_t> e{0};
     return e;
 }
+// hipFree waits for EVERY stream of the device to drain — a workspace that grows on one slot (a slot meets its first Spend batch
+// after Outputs: 34 GB of tree scratch instead of 3) stalled that slot's host thread for as long as the other slots kept the chip
+// busy, 1.1 - 1.8 s in a mixed job list (`profiles/r04e_mixed_calls_timing.txt`).  So a released buffer only goes on a list; the
+// list is emptied where waiting costs nothing — when the last busy slot of a context is released, when a context is destroyed —
+// and when an allocation fails for lack of memory.  What lingers in between is bounded by the buffers' earlier, smaller sizes.
+struct DevGraveyard {
+    std::mutex mu;
+    std::vector<void*> v;
+};
+inline DevGraveyard& dev_graveyard() {
+    static DevGraveyard* g = new DevGraveyard;  // (never destroyed: buffers are released from static destructors too)
+    return *g;
+}
+inline void dev_free_drain() {
+    std::vector<void*> v;
+    {
+        std::lock_guard<std::mutex> g(dev_graveyard().mu);
+        v.swap(dev_graveyard().v);
+    }
+    for (void* p : v) (void)hipFree(p);
+}
 template <class T>
 inline hipError_t dev_malloc(T** p, size_t bytes) {
     device_alloc_epoch().fetch_add(1, std::memory_order_relaxed);
-    return hipMalloc(p, bytes);
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory) {  // what was released but not yet returned to the device may be what is missing
+        bool any;
+        {
+            std::lock_guard<std::mutex> g(dev_graveyard().mu);
+            any = !dev_graveyard().v.empty();
+        }
+        if (any) {
+            (void)hipGetLastError();
+            dev_free_drain();
+            e = hipMalloc(p, bytes);
+        }
+    }
+    return e;
 }
 inline hipError_t dev_free(void* p) {
     device_alloc_epoch().fetch_add(1, std::memory_order_relaxed);
-    return hipFree(p);
+    std::lock_guard<std::mutex> g(dev_graveyard().mu);
+    dev_graveyard().v.push_back(p);
+    return hipSuccess;
 }
 // hipFuncSetAttribute applies to the CURRENT device: a process that proves on several GPUs (masp_hip_ctx_create_multi, one
 // host thread per device) has to raise a kernel's dynamic-LDS limit on each of them.  One instance per call site; `f` runs
