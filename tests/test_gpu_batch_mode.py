@@ -230,3 +230,43 @@ def test_multi_device_context_deals_batches_to_its_devices(rig):
     assert e.value.code == 7
     multi.close()
 
+
+
+def test_workspaces_growing_under_load_and_memory_returned(rig):
+    """A fresh context whose slots first see small Output batches and then, from three host threads at once, Spend batches: every
+    slot's workspaces (34 GB of tree scratch per slot at the default sub-batch; less here) grow while the other slots are busy.
+    The buffers they outgrow are not freed on the spot — `hipFree` waits for every stream of the device, which stalled a growing
+    slot's host thread for seconds behind the other slots' work (profiles/r04e_mixed_calls_timing.txt) — but put on a list that is
+    emptied when the context goes idle or is destroyed (csrc/util.h, dev_free).  Checked: the proofs (against the shared rig's
+    context, closed form and pairing) and that destroying the context returns the device's memory."""
+    import ctypes as C
+    import masp_amd
+    from masp_amd import workload as W
+    hip = C.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        free, total = C.c_size_t(0), C.c_size_t(0)
+        assert hip.hipSetDevice(0) == 0 and hip.hipDeviceSynchronize() == 0 and hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return free.value
+    ou, sp = W.instances("output", 24, first_seed=5100), W.instances("spend", 72, first_seed=5100, threads=rig.threads)
+    rs_o, rs_s = _rs(random.Random(51), 24), _rs(random.Random(52), 72)
+    jobs_o = [(1, i, a, r, s) for (i, a), (r, s) in zip(ou, rs_o)]
+    jobs_s = [(0, i, a, r, s) for (i, a), (r, s) in zip(sp, rs_s)]
+    want_o, want_s = rig.ctx.prove_batch(jobs_o), rig.ctx.prove_batch(jobs_s)   # (the shared context's own workspaces grow here: before free0)
+    free0 = free_bytes()
+    ctx = masp_amd.Context(0, batch_cap=96)
+    for slot, k in enumerate(KINDS[:2]):
+        ctx.load_circuit(slot, rig.params[k], rig.cs[k])
+    with ThreadPoolExecutor(3) as ex:                       # every slot meets Outputs first ...
+        small = list(ex.map(lambda _: ctx.prove_batch(jobs_o), range(3)))
+    with ThreadPoolExecutor(3) as ex:                       # ... then Spends, three calls in flight: the slots grow side by side
+        big = list(ex.map(lambda k: ctx.prove_batch(jobs_s[24 * k:24 * k + 24] + jobs_o[8 * k:8 * k + 8]), range(3)))
+    assert small[0] == small[1] == small[2] == want_o
+    got_s = [p for k in range(3) for p in big[k][:24]]
+    assert got_s == want_s
+    for k in range(3):
+        assert big[k][24:] == small[0][8 * k:8 * k + 8]
+    _check(rig, ["spend"] * 72, sp, rs_s, got_s, n_cpu=1)
+    ctx.close()
+    free1 = free_bytes()
+    assert free0 - free1 < (256 << 20), "a destroyed context kept %.1f GB of the device" % ((free0 - free1) / 2 ** 30)
