@@ -163,7 +163,7 @@ def main():
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
         sys.exit("bench.py: --gpus and --steps must be >= 1, --warmup >= 0")
     if args.in_library:
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
         return main_in_library(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         relaunch_under_torchrun(args)
@@ -172,7 +172,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but the launcher started %d rank(s): refusing to report a figure for a different GPU count" % (args.gpus, world))
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # let independent batches' kernels overlap (ROCm default: 4)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # let independent batches' kernels overlap (ROCm default: 4; 16: profiles/r04e_hw_queues_and_the_two_modes.txt)
     dist = dev = None
     backend = os.environ.get("MASP_BENCH_BACKEND", "nccl")      # "nccl" = RCCL on ROCm; "gloo" only for the CPU dry run
     if world > 1 or os.environ.get("MASP_BENCH_FORCE_DIST"):

@@ -54,8 +54,10 @@ def load_library():
         raise ImportError("libmasp_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "or `make -C masp_amd/csrc` (hipcc, --offload-arch=gfx950)")
     # batches in flight on different HIP streams only overlap if the runtime gives them their own hardware queues
-    # (ROCm's default is 4); read once, when the HIP runtime initialises
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # (ROCm's default is 4); read once, when the HIP runtime initialises.  16: three slots have 15 streams between them; with 8
+    # queues about one bench process in four landed in a mode 3 % slower (streams of two slots sharing a queue), with 16 none of
+    # twelve did (profiles/r04e_hw_queues_and_the_two_modes.txt)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     L = C.CDLL(path)
     vp, sz, u32 = C.c_void_p, C.c_size_t, C.c_uint32
     L.masp_hip_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]

@@ -10,7 +10,7 @@ import time
 from concurrent.futures import ThreadPoolExecutor
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 from bench import options_from_env              # noqa: E402  (MASP_HIP_* variables -> masp_hip_options; the library reads none)
 
 from masp_amd import host as H                     # noqa: E402

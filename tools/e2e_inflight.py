@@ -1,7 +1,7 @@
 import os, sys, time
 from concurrent.futures import ThreadPoolExecutor
 sys.path.insert(0, os.getcwd())
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 from bench import options_from_env
 from masp_amd import host as H
 from masp_amd import workload as W
