@@ -1,7 +1,9 @@
 #!/bin/bash
-o=gpurun_out/r04n; mkdir -p $o
-timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > $o/tests.txt; cat $o/tests.txt
-MASP_BENCH_E2E=0 bash tools/ab.sh masp_amd/libmasp_hip_B.so masp_amd/libmasp_hip.so 2 > $o/ab.txt 2>&1; cat $o/ab.txt
-PMC_STEPS=3 PMC_OUT=r04n_pmc_traffic MASP_BENCH_E2E=0 bash tools/pmc_traffic.sh > $o/pmc.log 2>&1
-python -c "
-import json; d=json.load(open('gpurun_out/r04n_pmc_traffic.json')); print('traffic GB per launch', d['hbm_bytes_per_launch']/1e9)"
+# a live torch + RCCL runtime (one-rank process group) against the plain run, at the new default of 16 hardware queues and at 8
+sel='import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print("%.1f  resident %.1f" % (d["value"], d["resident"]["value"]))'
+for r in 1 2 3; do
+  for q in 16 8; do
+    echo "plain, $q queues: $(GPU_MAX_HW_QUEUES=$q MASP_BENCH_E2E=0 python bench.py --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "$sel")"
+    echo "one-rank RCCL, $q queues: $(GPU_MAX_HW_QUEUES=$q MASP_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=2957$r MASP_BENCH_E2E=0 python bench.py --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "$sel")"
+  done
+done
