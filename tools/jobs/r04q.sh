@@ -1,8 +1,8 @@
 #!/bin/bash
-# how long does the host take to enqueue a lone proof?  (timing build of prover.hip: -DMASP_ENQ_TIMING)
-o=gpurun_out/r04q; mkdir -p $o
-MASP_HIP_LIBRARY=$PWD/masp_amd/libmasp_hip_T.so MASP_BENCH_E2E=0 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2> $o/err.txt | tail -1 > $o/bench.json
-grep "\[enq\] 1 proofs" $o/err.txt | tail -14 | tee $o/enq.txt
-python -c "
-import json; d=json.load(open('$o/bench.json')); print(d['value'], d['single_proof_latency'])" | tee -a $o/enq.txt
-timeout 600 python -m pytest tests/test_gpu_lone_graph.py -x -q 2>&1 | tail -3 | tee -a $o/enq.txt
+# 3 slots / 16 queues (default) against 4 slots / 24 queues at the driver's own flags (--steps 20 --warmup 5), end to end included: same box, two rounds
+sel='import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print("%.1f  resident %.1f  end_to_end %.1f  lat %.2f" % (d["value"], d["resident"]["value"], d["end_to_end"]["value"], d["single_proof_latency_ms"]))'
+for r in 1 2; do
+  for cfg in "MASP_HIP_SLOTS=3 GPU_MAX_HW_QUEUES=16" "MASP_HIP_SLOTS=4 GPU_MAX_HW_QUEUES=24" "MASP_HIP_SLOTS=4 GPU_MAX_HW_QUEUES=24 MASP_BENCH_H2H_CALLS=5"; do
+    echo "$cfg: $(env $cfg python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "$sel")"
+  done
+done
