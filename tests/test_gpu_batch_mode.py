@@ -269,4 +269,5 @@ def test_workspaces_growing_under_load_and_memory_returned(rig):
     _check(rig, ["spend"] * 72, sp, rs_s, got_s, n_cpu=1)
     ctx.close()
     free1 = free_bytes()
-    assert free0 - free1 < (256 << 20), "a destroyed context kept %.1f GB of the device" % ((free0 - free1) / 2 ** 30)
+    # (a slot's scratch is tens of GB; the runtime's own caches — code objects of kernels first used in between — are a few hundred MB)
+    assert free0 - free1 < (1 << 30), "a destroyed context kept %.1f GB of the device" % ((free0 - free1) / 2 ** 30)
