@@ -406,11 +406,21 @@ def main():
             k_.close()
         vk = {}
         other = [ctx.generate_parameters(H.circuit(k)[0], synthetic.toxic_waste(1 + KINDS.index(k))) for k in ("output", "convert")]
-        ctx.close()                                # the end-to-end prover owns its own context (LocalTxProver::from_bytes)
-        ctx = None
+        # the end-to-end prover works on THIS process's context (one per device: its slots' scratch is already sized).  A second
+        # context created after this one had been used and closed ran the same call 4 - 9 % slower — the resident and the host-to-host
+        # paths on it did not: profiles/r04e_second_context_in_a_process.txt —, which is not what a prover process looks like
+        for h_ in (handle, one):
+            ctx.batch_free(h_)
         from masp_amd.prover import LocalTxProver
+        if os.environ.get("MASP_BENCH_GC_FREEZE", "1") != "0":
+            # what the earlier regions left on the Python heap (job tuples, marshalled arrays, 10 000 proofs) is garbage-collected
+            # here and the survivors are frozen: a generation-2 collection in the middle of prove_batch holds the GIL of its chunk threads
+            import gc
+            del marshalled, warm_b
+            gc.collect()
+            gc.freeze()
         t_e = time.perf_counter()
-        prover = LocalTxProver(params["spend"], other[0], other[1], device=local_rank, expected=None, options=options_from_env())
+        prover = LocalTxProver(params["spend"], other[0], other[1], device=local_rank, expected=None, context=ctx)
         e2e_setup = time.perf_counter() - t_e
         with ThreadPoolExecutor(threads) as ex:
             descs = list(ex.map(lambda i: W.description("spend", 5 * 10 ** 6 + 10 ** 5 * rank + i), range(e2e_n)))
@@ -423,11 +433,13 @@ def main():
         res = prover.prove_batch(prover.new_sapling_proving_context(), descs, threads=threads)
         e2e_s = time.perf_counter() - t_e
         assert len(res) == e2e_n and len(set(r[0] for r in res)) == e2e_n
+        e2e_opt = prover._ctx.current_options()   # (what lack of tree scratch changed, if anything: sub-batch in use, proofs through the XYZZ fallback)
         prover.close()
         e2e_s = D.max_over_ranks(e2e_s, dist, dev)
         e2e = {"value": e2e_n * world / e2e_s, "unit": "proofs/s", "descriptions_per_gpu": e2e_n, "seconds": round(e2e_s, 3), "threads_per_gpu": threads,
-               "load_seconds": round(e2e_setup, 2),
-               "region": "LocalTxProver.prove_batch: Spend descriptions -> witness synthesis (libmasp_host, %d threads) -> page-locked host memory -> "
+               "load_seconds": round(e2e_setup, 2), "bucket_tree_sub_batch_in_use": e2e_opt["bucket_tree_sub_batch"],
+               "bucket_tree_fallback_proofs": e2e_opt["bucket_tree_fallback_proofs"],
+               "region": "LocalTxProver.prove_batch on this process's context: Spend descriptions -> witness synthesis (libmasp_host, %d threads) -> page-locked host memory -> "
                          "GPU batches -> GPU batch self-verification -> (zkproof, cv, rk); includes the ramp of the first synthesis chunk and the "
                          "last verification" % threads}
     if rank == 0:

@@ -104,13 +104,16 @@ class _Permits:
 class LocalTxProver:
     """An implementation of `TxProver` using the MI355X prover.  Holds the three circuits' parameters for its lifetime."""
 
-    def __init__(self, spend_params, output_params, convert_params, device=0, rng=None, self_verify=True, expected=P.EXPECTED, options=None):
+    def __init__(self, spend_params, output_params, convert_params, device=0, rng=None, self_verify=True, expected=P.EXPECTED, options=None,
+                 context=None):
         """= LocalTxProver::from_bytes (prover.rs:81-95): parameter *bytes* in the bellman wire format, digests checked
         as `parse_parameters` does (lib.rs:333-388).  Malformed or mismatching parameters raise `params.ParameterError` /
         `hip.HipError` (the reference panics, lib.rs:290-293,337,359-362).  `expected=None`: parameters that are not the
-        MPC files (benches, tests)."""
+        MPC files (benches, tests).  `context`: a `Context` the process already has for this device — the prover loads its circuits
+        into it and leaves it open when it is closed itself (a process wants ONE context per device: its slots' scratch is sized once)."""
         spend_params, output_params, convert_params = P.parse_parameters(spend_params, output_params, convert_params, expected=expected)
-        self._ctx = Context(device, **(options or {}))      # options: masp_hip_options fields (slots, batch_cap, ...)
+        self._owns_ctx = context is None
+        self._ctx = Context(device, **(options or {})) if context is None else context      # options: masp_hip_options fields (slots, batch_cap, ...)
         self._pool = {SPEND: [], OUTPUT: [], CONVERT: []}           # recycled page-locked aux buffers per circuit
         self._pool_lock = threading.Lock()
         self._rng = rng or (lambda: secrets.randbelow(FR))          # r, s <- OsRng (sapling/prover.rs:66,174,225)
@@ -163,7 +166,8 @@ class LocalTxProver:
     def close(self):
         for k in self._gpu_vk.values():
             k.close()
-        self._ctx.close()
+        if self._owns_ctx:
+            self._ctx.close()
 
     def new_sapling_proving_context(self):
         return SaplingProvingContext()

@@ -1,4 +1,8 @@
 #!/bin/bash
-o=gpurun_out/r04s; mkdir -p $o
-timeout 900 python -m pytest tests/test_gpu_endomorphism.py -x -q 2>&1 | tail -15 > $o/endo.txt; cat $o/endo.txt
-timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > $o/tests.txt; cat $o/tests.txt
+# bench.py's end_to_end region with and without the collection + freeze of the Python heap before it, 3 and 4 slots: same box
+sel='import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print("%.1f  resident %.1f  end_to_end %.1f" % (d["value"], d["resident"]["value"], d["end_to_end"]["value"]))'
+for r in 1 2; do
+  for cfg in "MASP_BENCH_GC_FREEZE=0 MASP_HIP_SLOTS=3 GPU_MAX_HW_QUEUES=16" "MASP_BENCH_GC_FREEZE=1 MASP_HIP_SLOTS=3 GPU_MAX_HW_QUEUES=16" "MASP_BENCH_GC_FREEZE=0 MASP_HIP_SLOTS=4 GPU_MAX_HW_QUEUES=24" "MASP_BENCH_GC_FREEZE=1 MASP_HIP_SLOTS=4 GPU_MAX_HW_QUEUES=24"; do
+    echo "$cfg: $(env $cfg python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "$sel")"
+  done
+done
