@@ -271,3 +271,20 @@ def test_workspaces_growing_under_load_and_memory_returned(rig):
     free1 = free_bytes()
     # (a slot's scratch is tens of GB; the runtime's own caches — code objects of kernels first used in between — are a few hundred MB)
     assert free0 - free1 < (1 << 30), "a destroyed context kept %.1f GB of the device" % ((free0 - free1) / 2 ** 30)
+
+
+def test_local_tx_prover_on_an_existing_context(rig):
+    """LocalTxProver(context=...): the prover loads its circuits into the process's context, proves through it (prove_batch with
+    self-verification) and leaves it open when closed — what bench.py's end_to_end region does."""
+    from masp_amd import workload as W
+    from masp_amd.prover import LocalTxProver
+    prover = LocalTxProver(rig.params["spend"], rig.params["output"], rig.params["convert"], expected=None, context=rig.ctx)
+    assert prover._ctx is rig.ctx
+    descs = [W.description("spend", 9000 + k) for k in range(20)] + [W.description("output", 9000 + k) for k in range(12)]
+    res = prover.prove_batch(prover.new_sapling_proving_context(), descs, threads=rig.threads, chunk=16)
+    assert len(res) == 32 and all(len(r[0]) == 192 for r in res) and len(set(r[0] for r in res)) == 32
+    for (kind, kw), r in zip(descs[20:], res[20:]):                      # Outputs are not self-checked by the prover: check them here
+        assert kind == "output" and len(r) == 2
+    prover.close()
+    (i, a), = W.instances("output", 1, first_seed=78)                    # the context is still there
+    assert len(rig.ctx.prove_batch([(1, i, a, 5, 6)])) == 1
