@@ -34,11 +34,14 @@ if os.environ.get("E2E_PRELUDE"):
 for fl in [int(a) for a in sys.argv[1:]] or [None]:
     prover = LocalTxProver.with_synthetic_parameters(seed=7, options=options_from_env())
     slots = prover._ctx.options["slots"]
+    if os.environ.get("E2E_NO_VERIFY"):
+        prover._self_verify = False
+    cpus = int(os.environ.get("E2E_THREADS", cpus))
     prover.prove_batch(prover.new_sapling_proving_context(), descs, threads=cpus, in_flight=fl)
     out = []
     for rep in range(3):
         t0 = time.perf_counter()
         prover.prove_batch(prover.new_sapling_proving_context(), descs, threads=cpus, in_flight=fl)
         out.append(n / (time.perf_counter() - t0))
-    print("slots %d in_flight %s: first timed call %.1f, then %.1f, %.1f proofs/s" % (slots, fl, out[0], out[1], out[2]), flush=True)
+    print("[verify %s threads %d prelude %s] slots %d in_flight %s: first timed call %.1f, then %.1f, %.1f proofs/s" % ("off" if os.environ.get("E2E_NO_VERIFY") else "on", cpus, os.environ.get("E2E_PRELUDE", "no"), slots, fl, out[0], out[1], out[2]), flush=True)
     prover.close()
