@@ -31,6 +31,16 @@ if os.environ.get("E2E_PRELUDE"):
         c0.batch_prove_resident_steps(h, 256, 4, rs)
     c0.close()
     print("prelude done", flush=True)
+if os.environ.get("E2E_HOST_CHURN"):
+    # host memory only: allocate, touch and free a few GB in 3 MB pieces, keeping every other one (what a process that has built
+    # witnesses, job arrays and proof lists looks like to the page allocator) - no GPU context involved
+    import numpy as np
+    keep = []
+    for _ in range(int(os.environ["E2E_HOST_CHURN"])):
+        blocks = [np.ones(3 << 20, np.uint8) for _ in range(1024)]
+        keep += blocks[::2]
+        del blocks
+    print("host churn done: %.1f GB kept" % (len(keep) * 3 / 1024), flush=True)
 for fl in [int(a) for a in sys.argv[1:]] or [None]:
     prover = LocalTxProver.with_synthetic_parameters(seed=7, options=options_from_env())
     slots = prover._ctx.options["slots"]
