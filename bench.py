@@ -194,6 +194,16 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+            if not args.dry_run:
+                # gloo with real GPU work (tests/test_gpu_bench_two_ranks.py: the N = 2 code path on a one-GPU box): ranks that outnumber the
+                # devices share them
+                from masp_amd.hip import device_count
+                n_dev = device_count()
+                if n_dev < 1:
+                    sys.exit("bench.py: no GPU visible")
+                if local_rank >= n_dev:
+                    sys.stderr.write("bench.py: rank %d shares device %d (%d device(s) visible)\n" % (rank, local_rank % n_dev, n_dev))
+                local_rank %= n_dev
         if rank == 0:
             sys.stderr.write("bench.py: %s process group up: %d rank(s), one per GPU\n" % ("RCCL" if backend == "nccl" else backend, dist.get_world_size()))
     if args.dry_run:
@@ -271,7 +281,7 @@ def main():
     assert len(set(a.tobytes() for _, a in insts)) == n, "instances are not distinct"
     rng = random.Random(0x5962be3d + rank)                            # (the reference bench's XorShift seed bytes, benches/sapling.rs:19-22)
 
-    def fresh_rs(steps):
+    def fresh_rs(steps, rng=rng):
         b = bytearray()
         for _ in range(2 * steps * n):
             b += rng.randrange(R).to_bytes(32, "little")
@@ -295,25 +305,33 @@ def main():
     warm_b = [ctx.marshal_jobs(jobs_with(rs_warm[k])) for k in range(max(Wm, 1))]
     with ThreadPoolExecutor(h2h_calls) as ex:
         list(ex.map(lambda k: ctx.prove_marshalled(warm_b[k][0], n), range(len(warm_b))))
-    # single-proof latency (not the headline value)
-    one, _ = ctx.batch_upload(jobs_with(rs_warm[0])[:1])
-    ctx.batch_prove_resident(one, 1)              # sizes the lone-proof workspace
-    lat = []
-    for _ in range(5):
-        t0 = time.perf_counter()
-        ctx.batch_prove_resident(one, 1)
-        lat.append((time.perf_counter() - t0) * 1e3)
-    latency_ms = sorted(lat)[len(lat) // 2]
-    # ... and as a caller of masp_hip_prove_batch sees it: one job, witness in page-locked host memory -> proof in host memory
-    # (MASP_HIP_LONE_GRAPH=1: replayed from a captured launch graph from the third call on — masp_hip_options::lone_proof_graph)
-    one_m = ctx.marshal_jobs(jobs_with(rs_warm[0])[:1])
-    lat_h = []
-    for _ in range(12):
-        t0 = time.perf_counter()
-        ctx.prove_marshalled(one_m[0], 1)
-        lat_h.append((time.perf_counter() - t0) * 1e3)
-    latency_host_ms = sorted(lat_h[4:])[len(lat_h[4:]) // 2]
-    lone_graphs = ctx.lone_graph_launches() if hasattr(ctx._L, "masp_hip_ctx_lone_graph_launches") else 0   # (an older build in an A/B run)
+    # single-proof latency (not the headline value; MASP_BENCH_LONE=0 skips it: the tests that compare bench lines)
+    LONE = os.environ.get("MASP_BENCH_LONE", "1") != "0"
+    one = None
+    latency_ms = latency_host_ms = None
+    lone_graphs = 0
+
+    def lone_latency(job):
+        """One job as a caller of masp_hip_prove_batch sees it: witness in page-locked host memory -> proof bytes in host memory; median of 8
+        after 4 calls (MASP_HIP_LONE_GRAPH=1: replayed from a captured launch graph from the third call on — masp_hip_options::lone_proof_graph)"""
+        one_m = ctx.marshal_jobs([job])
+        lat_h = []
+        for _ in range(12):
+            t0 = time.perf_counter()
+            ctx.prove_marshalled(one_m[0], 1)
+            lat_h.append((time.perf_counter() - t0) * 1e3)
+        return sorted(lat_h[4:])[len(lat_h[4:]) // 2]
+    if LONE:
+        one, _ = ctx.batch_upload(jobs_with(rs_warm[0])[:1])
+        ctx.batch_prove_resident(one, 1)              # sizes the lone-proof workspace
+        lat = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            ctx.batch_prove_resident(one, 1)
+            lat.append((time.perf_counter() - t0) * 1e3)
+        latency_ms = sorted(lat)[len(lat) // 2]
+        latency_host_ms = lone_latency(jobs_with(rs_warm[0])[0])
+        lone_graphs = ctx.lone_graph_launches()
 
     def barrier():
         ctx.sync()
@@ -395,9 +413,48 @@ def main():
                 sys.exit("bench.py: timed proof (step %d, job %d) differs from the oracle's closed form — no figure reported" % (st, j))
             closed_ok += 1
     verified_total = int(D.sum_over_ranks(float(verified_b), dist, dev))      # every rank verified all of its own proofs (both regions)
+    # ---- what the gather delivered: rank 0 checks EVERY gathered proof of EVERY rank (both regions) with the batch verifier against that
+    # rank's statements — instances and blinding scalars are seeded by rank, so rank 0 re-derives them — and compares two proofs per rank
+    # byte for byte with the oracle's closed form at their job positions (a gather that permuted, truncated or zero-filled a shard fails here)
+    gathered_checked = None
+    if dist is not None and rank == 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        t_g = time.perf_counter()
+        gathered_checked = {"ranks": world, "proofs_verified": 0, "closed_form_equal": 0}
+        for r in range(world):
+            if r == 0:
+                insts_r, rs_a_r, rs_b_r = [(i, H.aux_from_montgomery(a)) for i, a in (insts[0], insts[n - 1])], rs_a, rs_b
+                pub_r = pub
+            else:
+                per_r = {k: W.instances(k, job_kind.count(k), first_seed=100000 * r, threads=threads) for k in kinds}
+                it_r = {k: iter(per_r[k]) for k in kinds}
+                all_r = [next(it_r[k]) for k in job_kind]
+                pub_r = [W.public_inputs(i) for i, _ in all_r]
+                insts_r = [all_r[0], all_r[n - 1]]
+                rng_r = random.Random(0x5962be3d + r)
+                _, rs_a_r, rs_b_r = fresh_rs(max(Wm, 1), rng_r), fresh_rs(K, rng_r), fresh_rs(K, rng_r)
+            for gl in (gathered, gathered_b):
+                block = gl[r * K * n:(r + 1) * K * n]
+                for st in range(K):
+                    for kind in kinds:
+                        sel = [j for j in range(n) if job_kind[j] == kind]
+                        if not vk[kind].verify_batch([bytes(block[st * n + j]) for j in sel], [pub_r[j] for j in sel]):
+                            sys.exit("bench.py: a gathered proof of rank %d (step %d) FAILED the pairing check — no figure reported" % (r, st))
+                        gathered_checked["proofs_verified"] += len(sel)
+            for gl, rs_, st, j, (inp, aux_c) in ((gathered_b, rs_b_r, 0, 0, insts_r[0]), (gathered, rs_a_r, K - 1, n - 1, insts_r[1])):
+                kind = job_kind[j]
+                want = O.closed_form_proof(cs[kind], synthetic.toxic_waste(1 + KINDS.index(kind)), inp, aux_c,
+                                           int.from_bytes(rs_[st, j, :32].tobytes(), "little"), int.from_bytes(rs_[st, j, 32:].tobytes(), "little"))
+                if bytes(gl[r * K * n + st * n + j]) != want:
+                    sys.exit("bench.py: gathered proof (rank %d, step %d, job %d) differs from the oracle's closed form — no figure reported" % (r, st, j))
+                gathered_checked["closed_form_equal"] += 1
+        gathered_checked["seconds"] = round(time.perf_counter() - t_g, 2)
     # ---- end to end (not part of `value`): LocalTxProver.prove_batch over E2E_N Spend descriptions per GPU — synthesis on this
     # rank's share of the host cores, page-locked buffers, H2D, GPU batches, GPU batch self-verification (sapling/prover.rs:148)
     e2e = None
+    other = None            # CRS of Output and Convert (the end-to-end prover and the other circuits' short regions need them)
+    circuits_loaded = False
     # (the aux buffers are page-locked memory of `ctx`: gone once it closes; the checker wants canonical values)
     base_instance = (per[kinds[0]][0][0].copy(), H.aux_from_montgomery(per[kinds[0]][0][1]))
     e2e_n = int(os.environ.get("MASP_BENCH_E2E", str(K * n)))          # as many proofs as the timed regions of `value` / `resident`
@@ -410,7 +467,8 @@ def main():
         # context created after this one had been used and closed ran the same call 4 - 9 % slower — the resident and the host-to-host
         # paths on it did not: profiles/r04e_second_context_in_a_process.txt —, which is not what a prover process looks like
         for h_ in (handle, one):
-            ctx.batch_free(h_)
+            if h_ is not None:
+                ctx.batch_free(h_)
         from masp_amd.prover import LocalTxProver
         if os.environ.get("MASP_BENCH_GC_FREEZE", "1") != "0":
             # what the earlier regions left on the Python heap (job tuples, marshalled arrays, 10 000 proofs) is garbage-collected
@@ -435,6 +493,7 @@ def main():
         assert len(res) == e2e_n and len(set(r[0] for r in res)) == e2e_n
         e2e_opt = prover._ctx.current_options()   # (what lack of tree scratch changed, if anything: sub-batch in use, proofs through the XYZZ fallback)
         prover.close()
+        circuits_loaded = True            # (the context is ours: the three circuits stay loaded in it)
         e2e_s = D.max_over_ranks(e2e_s, dist, dev)
         e2e = {"value": e2e_n * world / e2e_s, "unit": "proofs/s", "descriptions_per_gpu": e2e_n, "seconds": round(e2e_s, 3), "threads_per_gpu": threads,
                "load_seconds": round(e2e_setup, 2), "bucket_tree_sub_batch_in_use": e2e_opt["bucket_tree_sub_batch"],
@@ -442,6 +501,51 @@ def main():
                "region": "LocalTxProver.prove_batch on this process's context: Spend descriptions -> witness synthesis (libmasp_host, %d threads) -> page-locked host memory -> "
                          "GPU batches -> GPU batch self-verification -> (zkproof, cv, rk); includes the ramp of the first synthesis chunk and the "
                          "last verification" % threads}
+    # ---- the other two circuits (BASELINE.json configs[0] / configs[2]: masp_proofs/benches/convert.rs:31-66; the reference has no Output
+    # bench): a short region shaped like `value` (OTHER_STEPS steps of 256 distinct proofs per GPU, witnesses in page-locked host memory ->
+    # proofs in host memory, every proof verified) and the lone-proof latency of each.  Not the metric; driver-timed all the same.
+    others = None
+    if WORKLOAD == "spend" and os.environ.get("MASP_BENCH_OTHER", "1") != "0":
+        others = {}
+        OTHER_STEPS = 4
+        if other is None:
+            other = [ctx.generate_parameters(H.circuit(k)[0], synthetic.toxic_waste(1 + KINDS.index(k))) for k in ("output", "convert")]
+        for oi, kind in enumerate(("output", "convert")):
+            slot_k, cs_k = KINDS.index(kind), H.circuit(kind)[0]
+            if not circuits_loaded:
+                ctx.load_circuit(slot_k, other[oi], cs_k)
+            vk_k = ctx.prepare_verifying_key(other[oi])
+            slab_k, next_k = ctx.host_alloc(cs_k.n_aux * 256, 32), iter(range(256))
+
+            def take_k(_kind, slab_k=slab_k, next_k=next_k, n_aux=cs_k.n_aux):
+                with hand_lock:
+                    j = next(next_k)
+                return slab_k[j * n_aux:(j + 1) * n_aux]
+            inst_k = W.instances(kind, 256, first_seed=100000 * rank, threads=threads, montgomery=True, alloc=take_k)
+            rs_k = fresh_rs(3 + OTHER_STEPS)[:, :256]
+            m_k = [ctx.marshal_jobs([(slot_k, i, a, bytes(rs_k[st, j, :32]), bytes(rs_k[st, j, 32:]), None, 1) for j, (i, a) in enumerate(inst_k)])
+                   for st in range(3 + OTHER_STEPS)]
+            with ThreadPoolExecutor(h2h_calls) as ex:                      # warm-up: the same call pattern
+                list(ex.map(lambda k: ctx.prove_marshalled(m_k[k][0], 256), range(3)))
+            out_k = np.zeros((OTHER_STEPS, 256, 192), np.uint8)
+            barrier()
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(h2h_calls) as ex:
+                list(ex.map(lambda k: ctx.prove_marshalled(m_k[3 + k][0], 256, out_k[k]), range(OTHER_STEPS)))
+            barrier()
+            el_k = D.max_over_ranks(time.perf_counter() - t0, dist, dev)
+            pub_k = [W.public_inputs(i) for i, _ in inst_k]
+            for st in range(OTHER_STEPS):
+                if not vk_k.verify_batch([out_k[st, j].tobytes() for j in range(256)], pub_k):
+                    sys.exit("bench.py: a timed %s proof FAILED the pairing check — no figure reported" % kind)
+            lat_k = None
+            if LONE:
+                i0, a0 = inst_k[0]
+                lat_k = lone_latency((slot_k, i0, a0, bytes(rs_k[0, 0, :32]), bytes(rs_k[0, 0, 32:]), None, 1))
+            vk_k.close()
+            others[kind] = {"value": OTHER_STEPS * 256 * world / el_k, "unit": "proofs/s", "steps": OTHER_STEPS, "proofs_per_step": 256,
+                            "ms_per_step": el_k * 1e3 / OTHER_STEPS, "verified": OTHER_STEPS * 256, "single_proof_latency_ms": lat_k,
+                            "constraints": cs_k.n_constraints}
     if rank == 0:
         total = K * n * world
         achieved = x_bytes / (x_ms * 1e-3) / 1e9 if x_ms > 0 else 0.0
@@ -476,6 +580,11 @@ def main():
                        "parallelism": "proofs sharded over %d GPU(s), no data-path collective, RCCL gather of the proofs" % world},
             "rccl_ranks": dist.get_world_size() if dist is not None else 1,
             "collectives": "rccl" if dist is not None and backend == "nccl" else backend if dist is not None else "none",
+            # what rank 0 really sent through the process group (masp_amd/distributed.py counts at the call sites; "none" = no process group:
+            # the helpers return their argument): the u8 gathers of both regions, the CRS broadcasts, the float64 reductions
+            "collective_calls": D.collective_counts() if dist is not None else None,
+            "collective_tensors": ("cuda:%d" % local_rank if dev is not None else "cpu") if dist is not None else None,
+            "gathered_checked": gathered_checked,
             "verified": verified_total, "verified_how": "every timed proof of both regions through the product's Groth16 batch verifier (masp_hip_verify_batch: Miller "
                                                         "loops on the GPU), 64 per circuit also through the host verifier; %d of rank 0 byte-equal to the oracle's "
                                                         "toxic-waste closed form" % closed_ok,
@@ -485,6 +594,8 @@ def main():
             "resident": {"value": total / elapsed, "unit": "proofs/s", "ms_per_step": elapsed * 1e3 / K, "gpu_event_ms_per_step": gpu_ms / K,
                          "region": "witnesses already resident in HBM -> proofs in host memory of rank 0 (rounds 1-2 reported this as `value`)"},
             "end_to_end": e2e,
+            # Output / Convert: `value`-shaped short regions + lone latencies (same definitions as the Spend figures of this line)
+            "other_circuits": others,
             "single_proof_latency_ms": latency_host_ms,
             "single_proof_latency": {"host_to_host_ms": latency_host_ms, "resident_witness_ms": latency_ms,
                                      "graph_replays": lone_graphs,

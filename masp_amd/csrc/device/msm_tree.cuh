@@ -44,22 +44,15 @@ namespace masp {
 // (12 words after each other) every one of the three 16-byte instructions of an access touched all 24 lines of the wave's
 // 3 KiB, a third of each: with ~30 such streams in flight per CU the lines did not survive in L2 between the three (round 3:
 // FETCH_SIZE / WRITE_SIZE of the passes ~1.6x the bytes they need).  An Fp2 (one lane per point: Fp2Ops) is two consecutive
-// elements, as in the lane-pair form.  MASP_TREE_SLICED=0 keeps the elements whole (A/B builds).
-#ifndef MASP_TREE_SLICED
-#define MASP_TREE_SLICED 1
-#endif
-// 1: pass 1 leaves, per pair, (numerator of the slope) x (product of the denominators before the pair) instead of the running
-// product alone: pass 2 — the kernel that saturates the multiplier — gets the slope with ONE product instead of two, and pass 1,
-// which waits for memory three quarters of its time, does the other one (it then reads the y coordinates too: at level 0 they
-// lie in the 128-byte row it gathers anyway).  0: the round-3 form (A/B builds).
-// Level 0 only: there it takes 0.45 ms per call off the two passes together; on the deeper levels the two kernels merely swap
-// 0.21 ms and pass 1 reads 96 bytes per pair more (measured, r04c / r04m).
-#ifndef MASP_TREE_QNUM
-#define MASP_TREE_QNUM 1
-#endif
+// elements, as in the lane-pair form.
+// At level 0 pass 1 leaves, per pair, (numerator of the slope) x (product of the denominators before the pair) instead of the running
+// product alone: pass 2 — the kernel that saturates VALU issue — gets the slope with ONE product instead of two, and pass 1 does the
+// other one (it then reads the y coordinates too: at level 0 they lie in the 128-byte row it gathers anyway).  Level 0 only: there it
+// takes 0.45 ms per call off the two passes together; on the deeper levels the two kernels merely swap 0.21 ms and pass 1 reads 96
+// bytes per pair more (measured in round 4: DESIGN.md §6).
 template <bool L0>
 struct TREE_QNUM_AT {
-    static constexpr bool value = (MASP_TREE_QNUM) != 0 && L0;
+    static constexpr bool value = L0;
 };
 __device__ __forceinline__ Fp plane_ld_fp(const uint4* __restrict__ b, size_t cap, size_t u) {
     const uint4 a = b[u], c = b[cap + u], d = b[2 * cap + u];
@@ -77,7 +70,6 @@ __device__ __forceinline__ void plane_st_fp(uint4* __restrict__ b, size_t cap, s
 // element e of a plane of `cap` elements of type F (Fp, or Fp2 = two Fp)
 template <class F>
 __device__ __forceinline__ F plane_ld(const F* __restrict__ base, size_t cap, size_t e) {
-#if MASP_TREE_SLICED
     const uint4* b = reinterpret_cast<const uint4*>(base);
     if constexpr (sizeof(F) == sizeof(Fp)) {
         return plane_ld_fp(b, cap, e);
@@ -87,13 +79,9 @@ __device__ __forceinline__ F plane_ld(const F* __restrict__ base, size_t cap, si
         r.c1 = plane_ld_fp(b, 2 * cap, 2 * e + 1);
         return r;
     }
-#else
-    return base[e];
-#endif
 }
 template <class F>
 __device__ __forceinline__ void plane_st(F* __restrict__ base, size_t cap, size_t e, const F& v) {
-#if MASP_TREE_SLICED
     uint4* b = reinterpret_cast<uint4*>(base);
     if constexpr (sizeof(F) == sizeof(Fp)) {
         plane_st_fp(b, cap, e, v);
@@ -101,9 +89,6 @@ __device__ __forceinline__ void plane_st(F* __restrict__ base, size_t cap, size_
         plane_st_fp(b, 2 * cap, 2 * e, v.c0);
         plane_st_fp(b, 2 * cap, 2 * e + 1, v.c1);
     }
-#else
-    base[e] = v;
-#endif
 }
 
 // ---- plan -------------------------------------------------------------------------------------------------------
@@ -189,22 +174,14 @@ k_tree_records(const uint32_t* __restrict__ Dl, const uint32_t* __restrict__ Dn,
 // Where point i of a proof lives in a plane of cap = np * pt_stride * LN elements (LN lanes per point, part h of it): points
 // with even and odd index in separate halves of the plane — the two operands of pair q (points 2q, 2q + 1 where the runs are
 // padded, a record's r.x, r.x + 1 elsewhere) are then each contiguous across the lanes of a wave, and so are the results
-// (point t + j NT from lane t).  pt_stride is even.  Elements whole (MASP_TREE_SLICED=0): proof after proof, point after point.
+// (point t + j NT from lane t).  pt_stride is even.
 template <uint32_t LN>
 __device__ __forceinline__ size_t tree_pt_base(uint32_t p, size_t pt_stride) {
-#if MASP_TREE_SLICED
     return (size_t)p * (pt_stride >> 1) * LN;
-#else
-    return (size_t)p * pt_stride * LN;
-#endif
 }
 template <uint32_t LN>
 __device__ __forceinline__ size_t tree_pt_slot(size_t i, uint32_t h, size_t cap) {
-#if MASP_TREE_SLICED
     return (i >> 1) * LN + h + (i & 1) * (cap >> 1);
-#else
-    return i * LN + h;
-#endif
 }
 
 // ---- the two operands of a pair ------------------------------------------------------------------------------------
@@ -229,13 +206,9 @@ __device__ __forceinline__ int tree_classify(const typename O::T& x1, const type
 // the operands of a pair from its record — level 0: the two digit-list words (table row | sign << 31, or the padding entry =
 // the point at infinity), gathered from the table and negated if the digit is negative; deeper levels: (first input point,
 // output point), read from the previous level's points
-// 1: the loads of the software pipelines are unconditional (the last iteration requests its own pair once more; the padding entry
+// The loads of the software pipelines are unconditional (the last iteration requests its own pair once more; the padding entry
 // reads a row of zeros): a conditional load keeps the old value of its 12 destination registers alive — the compiler copied every
 // operand twice per pair (old value into the destination before the load, destination into the working set after it).
-// 0: the round-3 form (A/B builds).
-#ifndef MASP_TREE_UNCOND
-#define MASP_TREE_UNCOND 1
-#endif
 static __device__ uint4 g_tree_zero_row[16];  // 256 bytes of zeros: the row a padding entry gathers (TabRow<Fp2Ops> is the larger)
 template <bool L0>
 struct TreeRec {
@@ -256,7 +229,6 @@ struct TreeSrc {
         else
             return 0u;
     }
-#if MASP_TREE_UNCOND
     // the padding entry reads a row of zeros (= the point at infinity) that lives next to the code: the address is selected, the
     // loads are unconditional — no exec-masked blocks, no registers cleared for the lanes that skip them
     __device__ __forceinline__ const TabRow<typename O::Base>* row(uint32_t w) const {
@@ -265,16 +237,6 @@ struct TreeSrc {
     }
     __device__ __forceinline__ F row_x(uint32_t w) const { return reinterpret_cast<const F*>(&row(w)->p.x)[h]; }
     __device__ __forceinline__ F row_y(uint32_t w) const { return reinterpret_cast<const F*>(&row(w)->p.y)[h]; }
-#else
-    __device__ __forceinline__ F row_x(uint32_t w) const {
-        if (w == MSM_PAD_ENTRY) return O::zero();
-        return reinterpret_cast<const F*>(&tab[w & 0x7fffffffu].p.x)[h];
-    }
-    __device__ __forceinline__ F row_y(uint32_t w) const {
-        if (w == MSM_PAD_ENTRY) return O::zero();
-        return reinterpret_cast<const F*>(&tab[w & 0x7fffffffu].p.y)[h];
-    }
-#endif
     __device__ __forceinline__ size_t at(size_t i) const { return i * O::LANES + h; }
     // proof p of np, pt_stride points per proof (even)
     __device__ __forceinline__ void set(const F* xs_, const F* ys_, uint32_t p, uint32_t np, size_t pt_stride) {
@@ -370,7 +332,6 @@ k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
     // rec_ == nullptr: a level >= 1 whose runs all have even lengths (the sort padded to a multiple of 2^(level + 1)): pair q is
     // points 2q, 2q + 1 and lands at point q, like level 0 over the digit list
     const Rec* recs = reinterpret_cast<const Rec*>(rec_) + (size_t)p * rec_stride;
-#if MASP_TREE_UNCOND
     // (level 0 always has its records — the digit list; on the deeper levels the load is unconditional too, from a harmless
     // address when there are no records: a load inside a conditional block is waited for at the block's end, with vmcnt(0))
     const bool synth = !L0 && rec_ == nullptr;
@@ -379,10 +340,6 @@ k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         const Rec r = recs_ld[synth ? 0u : q];
         return synth ? make_uint2(2u * q, q) : r;
     };
-#else
-    const bool synth = rec_ == nullptr;
-    auto rec_at = [&](uint32_t q) -> Rec { return synth ? make_uint2(2u * q, q) : recs[q]; };
-#endif
     TreeSrc<O, L0> src;
     src.tab = tab;
     src.set(xs, ys, p, np, pt_stride);
@@ -414,17 +371,9 @@ k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         Ops c = nxt;
         if (j) plane_st(pre, pre_cap, src.at(((size_t)(j - 1) * np + p) * NT + t), hq);
         ra = rb;
-#if MASP_TREE_UNCOND
         if (q + NT >= P) ra = cr;  // the last iteration asks for its own pair again: nothing reads it
         fetch(ra, nxt);
-#else
-        if (q + NT < P) fetch(ra, nxt);
-#endif
-#if MASP_TREE_UNCOND
         rb = rec_at(q + 2 * (uint64_t)NT < P ? q + 2 * NT : q);
-#else
-        if (q + 2 * (uint64_t)NT < P) rb = rec_at(q + 2 * NT);
-#endif
         TreeSrc<O, L0>::fix_y(cr, c.y1, c.y2);
         F d = O::sub(c.x2, c.x1), n = O::sub(c.y2, c.y1);
         if (O::is_zero(c.x1) || O::is_zero(c.x2) || O::is_zero(d)) {  // rare
@@ -462,17 +411,9 @@ k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         const F cx1 = x1, cx2 = x2;
         if (j) plane_st(pre, pre_cap, src.at(((size_t)(j - 1) * np + p) * NT + t), chain);
         ra = rb;
-#if MASP_TREE_UNCOND
         if (q + NT >= P) ra = cr;
         src.load_x(ra, x1, x2);
-#else
-        if (q + NT < P) src.load_x(ra, x1, x2);
-#endif
-#if MASP_TREE_UNCOND
         rb = rec_at(q + 2 * (uint64_t)NT < P ? q + 2 * NT : q);
-#else
-        if (q + 2 * (uint64_t)NT < P) rb = rec_at(q + 2 * NT);
-#endif
         F d = O::sub(cx2, cx1);
         if (O::is_zero(cx1) || O::is_zero(cx2) || O::is_zero(d)) {  // rare: needs the y coordinates to decide
             F y1, y2;
@@ -504,7 +445,6 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
     // rec_ == nullptr: a level >= 1 whose runs all have even lengths (the sort padded to a multiple of 2^(level + 1)): pair q is
     // points 2q, 2q + 1 and lands at point q, like level 0 over the digit list
     const Rec* recs = reinterpret_cast<const Rec*>(rec_) + (size_t)p * rec_stride;
-#if MASP_TREE_UNCOND
     // (level 0 always has its records — the digit list; on the deeper levels the load is unconditional too, from a harmless
     // address when there are no records: a load inside a conditional block is waited for at the block's end, with vmcnt(0))
     const bool synth = !L0 && rec_ == nullptr;
@@ -513,10 +453,6 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         const Rec r = recs_ld[synth ? 0u : q];
         return synth ? make_uint2(2u * q, q) : r;
     };
-#else
-    const bool synth = rec_ == nullptr;
-    auto rec_at = [&](uint32_t q) -> Rec { return synth ? make_uint2(2u * q, q) : recs[q]; };
-#endif
     TreeSrc<O, L0> src;
     src.tab = tab;
     src.set(xs, ys, p, np, pt_stride);
@@ -560,17 +496,9 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         ra = rb;
         if (held) put(hout, hx, hy);
         const F qn = plane_ld(pre, pre_cap, src.at(((size_t)j * np + p) * NT + t));
-#if MASP_TREE_UNCOND
         if (!j) ra = cr;  // the last iteration asks for its own pair again: nothing reads it
         fetch(ra, nxt);
-#else
-        if (j) fetch(ra, nxt);
-#endif
-#if MASP_TREE_UNCOND
         rb = rec_at(t + (j > 1 ? j - 2 : 0u) * NT);
-#else
-        if (j > 1) rb = rec_at(t + (j - 2) * NT);
-#endif
         const uint32_t out = TreeSrc<O, L0>::out_index(cr, t + j * NT);
         TreeSrc<O, L0>::fix_y1(cr, c.y1);
         F d = O::sub(c.x2, c.x1);
@@ -634,17 +562,9 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         if (held) put(hout, hx, hy);
         F pp = O::one();
         if (j) pp = plane_ld(pre, pre_cap, src.at(((size_t)(j - 1) * np + p) * NT + t));
-#if MASP_TREE_UNCOND
         if (!j) ra = cr;  // the last iteration asks for its own pair again: nothing reads it
         fetch(ra, nxt);
-#else
-        if (j) fetch(ra, nxt);
-#endif
-#if MASP_TREE_UNCOND
         rb = rec_at(t + (j > 1 ? j - 2 : 0u) * NT);
-#else
-        if (j > 1) rb = rec_at(t + (j - 2) * NT);
-#endif
         const uint32_t out = TreeSrc<O, L0>::out_index(cr, t + j * NT);
         TreeSrc<O, L0>::fix_y(cr, c.y1, c.y2);
         F d = O::sub(c.x2, c.x1);

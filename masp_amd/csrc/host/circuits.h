@@ -636,6 +636,7 @@ struct SpendState {
     AllocatedNum cur;
 };
 inline void synthesize_spend_pre(CS& cs, const SpendW& w, SpendState& st) {
+    LcRecordingScope lc_scope(cs.recording());
     EdwardsPoint ak = EdwardsPoint::witness(cs, w.ak);
     ak.assert_not_small_order(cs);
     {
@@ -693,6 +694,7 @@ inline void synthesize_spend_pre(CS& cs, const SpendW& w, SpendState& st) {
 }
 // ... then the Merkle path from st.cur (merkle_ascend, or merkle_block_batch for several witnesses at once) ...
 inline void synthesize_spend_post(CS& cs, const SpendW& w, SpendState& st) {
+    LcRecordingScope lc_scope(cs.recording());
     const EdwardsPoint& cm = st.cm;
     std::vector<Boolean>& nf_preimage = st.nf_preimage;
     const std::vector<Boolean>& position_bits = st.position_bits;
@@ -710,6 +712,7 @@ inline void synthesize_spend_post(CS& cs, const SpendW& w, SpendState& st) {
     pack_into_inputs(cs, nf);
 }
 inline void synthesize_spend(CS& cs, const SpendW& w) {
+    LcRecordingScope lc_scope(cs.recording());
     SpendState st;
     synthesize_spend_pre(cs, w, st);
     st.cur = merkle_ascend(cs, st.cur, w.path, &st.position_bits);
@@ -718,6 +721,7 @@ inline void synthesize_spend(CS& cs, const SpendW& w) {
 
 // circuit/sapling.rs:419-596
 inline void synthesize_output(CS& cs, const OutputW& w) {
+    LcRecordingScope lc_scope(cs.recording());
     std::vector<Boolean> note_contents;
     std::vector<Boolean> asset_generator_preimage;
     for (int i = 0; i < 256; ++i)
@@ -761,6 +765,7 @@ struct ConvertState {
     AllocatedNum cur;
 };
 inline void synthesize_convert_pre(CS& cs, const ConvertW& w, ConvertState& st) {
+    LcRecordingScope lc_scope(cs.recording());
     Num value_num = Num::zero();
     std::vector<Boolean> asset_generator_bits, value_bits;
     expose_value_commitment(cs, w.vc, asset_generator_bits, value_bits);
@@ -775,8 +780,12 @@ inline void synthesize_convert_pre(CS& cs, const ConvertW& w, ConvertState& st) 
     st.value_num = value_num;
     st.cur = cm.u;
 }
-inline void synthesize_convert_post(CS& cs, const ConvertW& w, ConvertState& st) { conditional_anchor(cs, st.cur, st.value_num, w.anchor); }
+inline void synthesize_convert_post(CS& cs, const ConvertW& w, ConvertState& st) {
+    LcRecordingScope lc_scope(cs.recording());
+    conditional_anchor(cs, st.cur, st.value_num, w.anchor);
+}
 inline void synthesize_convert(CS& cs, const ConvertW& w) {
+    LcRecordingScope lc_scope(cs.recording());
     ConvertState st;
     synthesize_convert_pre(cs, w, st);
     st.cur = merkle_ascend(cs, st.cur, w.path, nullptr);

@@ -41,12 +41,27 @@ static const Var ONE = 0;
             (CS_).count_constraint();              \
     } while (0)
 
-// Linear combinations exist to be recorded: while no constraint system of this thread records (proving mode), building one is
+// Linear combinations exist to be recorded: while no synthesis of this thread records (proving mode), building one is
 // a no-op — the gadgets' `Num`s carry their LC along, which cost ~17 000 small heap allocations per Spend for nothing.
+// The flag is scoped to the SYNTHESIS CALL (LcRecordingScope inside synthesize_*), not to the lifetime of a constraint system: a
+// recording CS outlives its synthesis (masp_host_circuit_setup keeps it in the handle) and may be freed on another thread than the one
+// that made it — tied to the object, that left the creating thread at +1 and took the freeing thread to -1, after which a recording
+// synthesis on the latter built empty LCs and "checked" 0 * 0 = 0.
 inline int& lc_recording_depth() {
     static thread_local int d = 0;
     return d;
 }
+struct LcRecordingScope {
+    const bool on_;
+    explicit LcRecordingScope(bool on) : on_(on) {
+        if (on_) ++lc_recording_depth();
+    }
+    ~LcRecordingScope() {
+        if (on_ && --lc_recording_depth() < 0) abort();  // cannot happen: every decrement is paired with this object's increment
+    }
+    LcRecordingScope(const LcRecordingScope&) = delete;
+    LcRecordingScope& operator=(const LcRecordingScope&) = delete;
+};
 struct LC {
     std::vector<std::pair<Var, Fr>> t;
     static bool on() { return lc_recording_depth() > 0; }
@@ -91,10 +106,6 @@ class CS {
             grow(1u << 17);  // the largest circuit (Spend) has 100 497 auxiliary variables
         }
         ext_ = ext != nullptr;
-        if (record_) ++lc_recording_depth();
-    }
-    ~CS() {
-        if (record_) --lc_recording_depth();
     }
     CS(const CS&) = delete;
     CS& operator=(const CS&) = delete;

@@ -83,17 +83,26 @@ class SaplingProvingContext:
 
 class _Permits:
     """A counting semaphore whose acquire(k) takes k permits at once or none (k sequential acquires of a plain semaphore from
-    several threads can each end up holding a part of what they need)."""
+    several threads can each end up holding a part of what they need), served in TICKET ORDER: the waiter at the head of the queue
+    blocks later acquirers even if their smaller requests could be met — a 16-permit group of the oldest chunk can then not be
+    overtaken for ever by later one-permit groups, which with all remaining permits held by later chunks left no chunk able to finish
+    and release."""
 
     def __init__(self, n):
         self._n = n
         self._cv = threading.Condition()
+        self._next_ticket = 0
+        self._serving = 0
 
     def acquire(self, k=1):
         with self._cv:
-            while self._n < k:
+            ticket = self._next_ticket
+            self._next_ticket += 1
+            while self._serving != ticket or self._n < k:
                 self._cv.wait()
             self._n -= k
+            self._serving += 1
+            self._cv.notify_all()
 
     def release(self, k=1):
         with self._cv:

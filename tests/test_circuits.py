@@ -236,3 +236,34 @@ def test_host_batch_verifier():
     assert not vk.verify_batch(proofs, [pub] * 4 + [[pub[0] + 1] + pub[1:]])   # one wrong public input
     assert not vk.verify_batch(proofs, [pub] * 4 + [pub[:-1]])                 # ragged
     assert not vk.verify_batch([bytes(192)], [pub])
+
+
+def test_recording_survives_handles_freed_on_another_thread():
+    """the 'build linear combinations' flag used to be a thread-local counter tied to the LIFETIME of a recording
+    constraint system.  A circuit handle freed on another thread than the one that made it left that thread at -1, and the next
+    recording synthesis there built empty LCs: empty matrices, a different structure hash, a satisfiability check of 0 * 0 = 0.
+    Now the flag is scoped to the synthesis call: set up on one thread, free on another (several times), set up again there."""
+    import ctypes as C
+    import threading
+    L = H.load_library()
+    exp = load("circuits.json")["output"]
+    handles, out = [], {}
+
+    def make():
+        handles.extend(L.masp_host_circuit_setup(H.KINDS["output"]) for _ in range(3))
+
+    def free_then_setup():
+        for h in handles:
+            L.masp_host_circuit_free(h)
+        h = L.masp_host_circuit_setup(H.KINDS["output"])
+        buf = C.create_string_buffer(65)
+        L.masp_host_circuit_hash(h, buf)
+        counts = (C.c_uint32 * 6)()
+        L.masp_host_circuit_counts(h, counts)
+        L.masp_host_circuit_free(h)
+        out["hash"], out["nnz"] = buf.value.decode(), list(counts)[3:]
+    for fn in (make, free_then_setup):
+        t = threading.Thread(target=fn)
+        t.start()
+        t.join()
+    assert out["hash"] == exp["hash"] and min(out["nnz"]) > 0

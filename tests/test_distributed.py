@@ -114,3 +114,43 @@ def test_bench_dress_rehearsal_eight_ranks_as_the_driver_launches_them():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and out["max_rank_seen"] == 7
     assert out["gathered"] == 8 * 2 * 256 and out["gather_ok"] is True and out["crs_broadcast_ok_ranks"] == 8
+
+
+def _one_rank_worker(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import numpy as np
+    import torch.distributed as dist
+    from masp_amd import distributed as D
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    before = D.collective_counts()
+    got = D.gather_proofs([_fake_proof(j) for j in range(5)], 5, dist)
+    crs = D.broadcast_bytes(np.arange(1000, dtype=np.uint8), dist)
+    t = D.max_over_ranks(3.5, dist) + D.sum_over_ranks(1.0, dist)
+    after = D.collective_counts()
+    dist.destroy_process_group()
+    # without a process group the helpers hand their argument back and count nothing
+    D.gather_proofs([_fake_proof(0)], 1, None)
+    D.max_over_ranks(1.0, None)
+    q.put((before, after, D.collective_counts(), got == [_fake_proof(j) for j in range(5)], crs.tobytes() == bytes(range(256)) * 3 + bytes(range(232)), t))
+
+
+def test_a_process_group_of_one_rank_still_runs_the_collectives():
+    """Round 4's helpers returned early when the group had one rank, so the one-GPU box never issued a gather / broadcast / all_reduce
+    (missing 1): with a process group the collectives run whatever its size; the call sites count them."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_worker, args=(port, q))
+    p.start()
+    before, after, final, gather_ok, crs_ok, t = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and gather_ok and crs_ok and t == 4.5
+    assert before == {k: {"calls": 0, "bytes": 0} for k in ("gather", "broadcast", "all_reduce")}
+    assert after == {"gather": {"calls": 1, "bytes": 5 * 192}, "broadcast": {"calls": 2, "bytes": 8 + 1000}, "all_reduce": {"calls": 2, "bytes": 16}}
+    assert final == after

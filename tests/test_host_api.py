@@ -96,3 +96,33 @@ def test_aux_assignment_as_montgomery_residues():
         for j in list(rng.integers(0, aux.shape[0], 300)) + [0, aux.shape[0] - 1]:
             a = int.from_bytes(aux[j].tobytes(), "little")
             assert int.from_bytes(aux2[j].tobytes(), "little") == a * (1 << 256) % R
+
+
+def test_permits_are_served_in_ticket_order():
+    """prove_batch's synthesis window (masp_amd/prover.py `_Permits`): a large request at the head of the queue must not be overtaken by
+    later small ones (with all permits then held by later chunks' groups no chunk could finish and release)."""
+    import threading
+    import time
+    from masp_amd.prover import _Permits
+    p = _Permits(4)
+    order, lock = [], threading.Lock()
+
+    def want(k, name):
+        p.acquire(k)
+        with lock:
+            order.append(name)
+    big = threading.Thread(target=want, args=(16, "big"))
+    big.start()
+    time.sleep(0.2)                                   # `big` holds ticket 0 and waits for 16 permits
+    small = [threading.Thread(target=want, args=(1, "small%d" % i)) for i in range(8)]
+    for t in small:
+        t.start()
+    time.sleep(0.3)
+    assert order == []                                # 4 permits are free, but the head of the queue wants 16
+    p.release(12)
+    big.join(timeout=10)
+    assert order == ["big"]
+    p.release(8)
+    for t in small:
+        t.join(timeout=10)
+    assert order[0] == "big" and sorted(order[1:]) == sorted("small%d" % i for i in range(8))
