@@ -57,6 +57,66 @@ def options_from_env(env=os.environ):
     return {field: int(env[name]) for name, field in ENV_OPTIONS.items() if env.get(name, "") != ""}
 
 
+class ClockWatch:
+    """Shader clock and socket power while a timed region runs: the amdgpu hwmon files of every card (freq1_input = sclk in Hz, power1_input =
+    PPT in microwatts), read every 50 ms by a thread.  A box shows all of its cards whatever this process may use; the cards whose power
+    rises with the region (>= 60 % of the busiest one's mean) are the ones it ran on.  No rocm-smi process, no HIP call."""
+
+    def __init__(self):
+        import glob
+        self.cards = []
+        for f in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input")):
+            pw = os.path.join(os.path.dirname(f), "power1_input")
+            if os.path.exists(pw):
+                self.cards.append((f, pw))
+        self.regions, self._stop, self._thread, self._cur = {}, None, None, None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as fh:
+                return float(fh.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def _run(self, stop, samples):
+        while not stop.is_set():
+            samples.append([(self._read(f), self._read(p)) for f, p in self.cards])
+            stop.wait(0.05)
+
+    def start(self, region):
+        if not self.cards:
+            return
+        self._stop, self._cur = threading.Event(), self.regions.setdefault(region, [])
+        self._thread = threading.Thread(target=self._run, args=(self._stop, self._cur), daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join()
+            self._thread = None
+
+    def summary(self, region):
+        samples = self.regions.get(region) or []
+        if not samples:
+            return None
+        per_card = []
+        for c in range(len(self.cards)):
+            fs = [s[c][0] for s in samples if s[c][0] is not None and s[c][1] is not None]
+            ps = [s[c][1] for s in samples if s[c][0] is not None and s[c][1] is not None]
+            if fs:
+                per_card.append((sum(ps) / len(ps) * 1e-6, sum(fs) / len(fs) * 1e-6, min(fs) * 1e-6, max(fs) * 1e-6, len(fs)))
+        if not per_card:
+            return None
+        top = max(w for w, *_ in per_card)
+        busy = [r for r in per_card if r[0] >= 0.6 * top]
+        return {"sclk_mhz_mean": round(sum(r[1] for r in busy) / len(busy), 1), "sclk_mhz_min": round(min(r[2] for r in busy), 1),
+                "sclk_mhz_max": round(max(r[3] for r in busy), 1), "socket_power_w_mean": round(sum(r[0] for r in busy) / len(busy), 1),
+                "samples_per_card": busy[0][4], "cards_busy": len(busy), "cards_seen": len(per_card),
+                "source": "sysfs hwmon freq1_input (sclk) / power1_input (PPT) of the busy card(s), every 50 ms during the timed region"}
+
+
 def relaunch_under_torchrun(args):
     """`python bench.py --gpus N` with N > 1 and no launcher: become N ranks (one per GPU) under torch.distributed.run."""
     with socket.socket() as s:
@@ -343,12 +403,15 @@ def main():
 
     # ---- region A (`resident`): witnesses resident in HBM -> K steps -> proofs gathered on rank 0
     ctx.profile_enable(True)
+    clocks = ClockWatch()
     barrier()
+    clocks.start("resident")
     t0 = time.perf_counter()
     proofs_a, gpu_ms = ctx.batch_prove_resident_steps(handle, n, K, rs_a)       # exactly K steps
     gathered = D.gather_proofs(proofs_a.reshape(K * n, 192), K * n * world, dist, dev) if dist is not None else proofs_a.reshape(K * n, 192)
     barrier()
     elapsed = time.perf_counter() - t0
+    clocks.stop()
     acc_ms, launches, alg_bytes = ctx.profile_read()
     split_a = ctx.profile_read_split()
     # The same launches with ONE batch in flight (one launch sequence of the first circuit's jobs, nothing else on the chip):
@@ -367,12 +430,14 @@ def main():
     # in flight) -> proofs on the host of rank 0 (H2D, D2H and the RCCL gather inside)
     out_b = np.zeros((K, n, 192), np.uint8)
     barrier()
+    clocks.start("value")
     t0 = time.perf_counter()
     with ThreadPoolExecutor(h2h_calls) as ex:
         list(ex.map(lambda k: ctx.prove_marshalled(marshalled[k][0], n, out_b[k]), range(K)))          # exactly K steps
     gathered_b = D.gather_proofs(out_b.reshape(K * n, 192), K * n * world, dist, dev) if dist is not None else out_b.reshape(K * n, 192)
     barrier()
     elapsed_b = time.perf_counter() - t0
+    clocks.stop()
     if dist is not None:
         elapsed = D.max_over_ranks(elapsed, dist, dev)
         elapsed_b = D.max_over_ranks(elapsed_b, dist, dev)
@@ -561,6 +626,34 @@ def main():
                                  "measured by this run)" % doc.get("date", "round 2")
             except Exception:
                 traffic = traffic_source = None
+        # ---- the binding roofline next to the contractual one: VALU issue.  Wave-level VALU instructions of a batch (rocprofv3 --pmc
+        # SQ_INSTS_VALU over this bench, tracked under profiles/ like the traffic figure: counter passes cannot run inside the timed bench) x
+        # their measured issue cost (cycles a wave64 instruction of each class occupies its SIMD) against 1 024 SIMDs x the shader clock
+        # SAMPLED DURING THE TIMED REGION (the chip runs this path power-limited, below its 2.4 GHz boost)
+        roofline_valu = None
+        ck_val, ck_res = clocks.summary("value"), clocks.summary("resident")
+        vm_path = os.path.join(ROOT, "profiles", "r05_valu_model.json")
+        if WORKLOAD == "spend" and os.path.exists(vm_path) and ck_val is not None:
+            try:
+                vm = json.load(open(vm_path))
+                insts, cpi = vm["valu_insts_per_batch"] * n / 256.0, vm["cycles_per_inst_weighted"]
+
+                def issue_frac(ms_step, ck):
+                    return insts * cpi / (1024 * ck["sclk_mhz_mean"] * 1e6 * ms_step * 1e-3)
+                peak = 1024 * ck_val["sclk_mhz_mean"] * 1e6 / cpi
+                roofline_valu = {"bound": "valu_issue", "achieved": insts / (elapsed_b / K) / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s per GPU",
+                                 "frac": issue_frac(elapsed_b * 1e3 / K, ck_val), "frac_resident_region": issue_frac(elapsed * 1e3 / K, ck_res) if ck_res else None,
+                                 "valu_insts_per_step_per_gpu": insts, "cycles_per_inst": cpi, "simds": 1024,
+                                 "sclk_mhz": ck_val["sclk_mhz_mean"], "sclk_boost_mhz": 2400.0, "clock_frac": ck_val["sclk_mhz_mean"] / 2400.0,
+                                 "socket_power_w": ck_val["socket_power_w_mean"],
+                                 "source": "profiles/r05_valu_model.json (tools/valu_model.sh: SQ_INSTS_VALU per kernel over this bench with one slot; "
+                                           "cycles per instruction = each kernel's static class mix, tools/valu_mix.py, priced with "
+                                           "profiles/r04e_valu_instruction_cost_classes_ubench.txt); clock: this run",
+                                 "note": "frac = issue cycles the batch's VALU instructions need / SIMD cycles the timed region had at the clock the chip "
+                                         "really ran at; clock_frac = that clock / the 2.4 GHz boost.  The HBM figure above is the contractual one and does "
+                                         "not bind: this one does"}
+            except Exception as e:
+                roofline_valu = {"error": repr(e)}
         c0 = cs[kinds[0]]
         sh = synthetic.SHAPES[kinds[0]]
         config_name = {"spend": "BASELINE.json configs[3]: batch of 256 distinct Spend proofs per step on one MI355X (throughput mode)",
@@ -593,6 +686,8 @@ def main():
                             "(BASELINE.md §4; H2D of the assignments, D2H of the proofs and the gather inside)",
             "resident": {"value": total / elapsed, "unit": "proofs/s", "ms_per_step": elapsed * 1e3 / K, "gpu_event_ms_per_step": gpu_ms / K,
                          "region": "witnesses already resident in HBM -> proofs in host memory of rank 0 (rounds 1-2 reported this as `value`)"},
+            "roofline_valu": roofline_valu,
+            "clocks": {"value_region": ck_val, "resident_region": ck_res},
             "end_to_end": e2e,
             # Output / Convert: `value`-shaped short regions + lone latencies (same definitions as the Spend figures of this line)
             "other_circuits": others,

@@ -203,6 +203,25 @@ __device__ __forceinline__ int tree_classify(const typename O::T& x1, const type
     return TREE_INF;  // P + (-P)  (or a point of order two added to itself)
 }
 
+// `a` where m, else `b`, word by word (v_cndmask on the lane mask: no branch, no exec-masked block)
+template <class F>
+__device__ __forceinline__ F tree_select(bool m, const F& a, const F& b) {
+    F r;
+    const uint32_t *pa = reinterpret_cast<const uint32_t*>(&a), *pb = reinterpret_cast<const uint32_t*>(&b);
+    uint32_t* pr = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+    for (uint32_t i = 0; i < sizeof(F) / 4; ++i) pr[i] = m ? pa[i] : pb[i];
+    return r;
+}
+// THE exceptional pair that is not rare: the second operand is the point at infinity.  The sort pads every run to a multiple of four
+// entries, so an h + l MSM (32 768 buckets of ~70 entries) has one pair in 36 with the padding entry as its second operand at level
+// 0, and as many with the point at infinity (the sum of two padding entries) at level 1: a wave of 64 lanes met one in five iterations
+// of six and ran the whole classification — ~400 instructions of exec-masked blocks and the copies that merge their results into the
+// common path's registers — for it.  Such a pair is now handled by the common path's own data flow: its denominator is replaced by 1
+// (what tree_classify's TREE_FIRST / TREE_INF meant for the shared inversion) and its result by the first operand, with word-wise
+// selects on the lane mask; the classification branch is left to the pairs that are really rare (P + P, P - P, infinity as the FIRST
+// operand only, a point with x = 0).  Same values in `pre`, `tp` and the next level as before, pair by pair.
+
 // the operands of a pair from its record — level 0: the two digit-list words (table row | sign << 31, or the padding entry =
 // the point at infinity), gathered from the table and negated if the digit is negative; deeper levels: (first input point,
 // output point), read from the previous level's points
@@ -375,8 +394,9 @@ k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         fetch(ra, nxt);
         rb = rec_at(q + 2 * (uint64_t)NT < P ? q + 2 * NT : q);
         TreeSrc<O, L0>::fix_y(cr, c.y1, c.y2);
+        const bool pad2 = cr.y == MSM_PAD_ENTRY;  // (this form is level 0's: the second operand is the padding entry)
         F d = O::sub(c.x2, c.x1), n = O::sub(c.y2, c.y1);
-        if (O::is_zero(c.x1) || O::is_zero(c.x2) || O::is_zero(d)) {  // rare
+        if (!pad2 && (O::is_zero(c.x1) || O::is_zero(c.x2) || O::is_zero(d))) {  // rare
             const int kind = tree_classify<O>(c.x1, c.y1, c.x2, c.y2, d);
             if (kind == TREE_DBL) {
                 const F s2 = O::sqr(c.x1);
@@ -386,6 +406,7 @@ k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
                 n = O::one();
             }
         }
+        d = tree_select(pad2, O::one(), d);  // nothing is divided for a pair with the padding entry; pass 2 does not use its numerator
         // (both left in [0, 2p) — O::mul_lazy —: they are only ever multiplied again, by pass 2 and the shared inversion)
         hq = O::mul_lazy(n, chain);    // numerator x (denominators before this pair): pass 2 multiplies by 1 / (denominators up to this pair)
         chain = O::mul_lazy(chain, d);
@@ -501,14 +522,16 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         rb = rec_at(t + (j > 1 ? j - 2 : 0u) * NT);
         const uint32_t out = TreeSrc<O, L0>::out_index(cr, t + j * NT);
         TreeSrc<O, L0>::fix_y1(cr, c.y1);
+        const bool pad2 = cr.y == MSM_PAD_ENTRY;  // the second operand is the padding entry: the result is the first operand (see tree_select)
         F d = O::sub(c.x2, c.x1);
         int kind = TREE_ADD;
         F y2 = O::zero();
-        if (O::is_zero(c.x1) || O::is_zero(c.x2) || O::is_zero(d)) {  // rare
+        if (!pad2 && (O::is_zero(c.x1) || O::is_zero(c.x2) || O::is_zero(d))) {  // rare
             src.load_y2_raw(cr, y2);
             TreeSrc<O, L0>::fix_y2(cr, y2);
             kind = tree_classify<O>(c.x1, c.y1, c.x2, y2, d);
         }
+        d = tree_select(pad2, O::one(), d);
         F x3, y3;
         if (kind <= TREE_DBL) {
             // (I, qn and lam stay in [0, 2p): the square and the product below make x3 and y3 canonical)
@@ -528,8 +551,8 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
             x3 = O::zero();
             y3 = O::zero();
         }
-        hx = x3;
-        hy = y3;
+        hx = tree_select(pad2, c.x1, x3);
+        hy = tree_select(pad2, c.y1, y3);
         hout = out;
         held = true;
         if (!j) break;
@@ -567,9 +590,13 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         rb = rec_at(t + (j > 1 ? j - 2 : 0u) * NT);
         const uint32_t out = TreeSrc<O, L0>::out_index(cr, t + j * NT);
         TreeSrc<O, L0>::fix_y(cr, c.y1, c.y2);
+        // the second operand is the point at infinity (level 1: what two padding entries of level 0 summed to): the result is the first
+        // operand, by selects (see tree_select)
+        const bool zx2 = O::is_zero(c.x2), inf2 = zx2 && O::is_zero(c.y2);
         F d = O::sub(c.x2, c.x1);
         int kind = TREE_ADD;
-        if (O::is_zero(c.x1) || O::is_zero(c.x2) || O::is_zero(d)) kind = tree_classify<O>(c.x1, c.y1, c.x2, c.y2, d);
+        if (!inf2 && (O::is_zero(c.x1) || zx2 || O::is_zero(d))) kind = tree_classify<O>(c.x1, c.y1, c.x2, c.y2, d);
+        d = tree_select(inf2, O::one(), d);
         F x3, y3;
         if (kind <= TREE_DBL) {
             const F Inext = O::mul_lazy(I, d);   // I, pp and inv in [0, 2p): lam below is a reducing product of canonical x inv
@@ -595,8 +622,8 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
             x3 = O::zero();
             y3 = O::zero();
         }
-        hx = x3;
-        hy = y3;
+        hx = tree_select(inf2, c.x1, x3);
+        hy = tree_select(inf2, c.y1, y3);
         hout = out;
         held = true;
         if (!j) break;

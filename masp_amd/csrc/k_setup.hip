@@ -20,6 +20,7 @@ size_t masp_hip_parameters_max_size(const masp_hip_r1cs* cs) {
 int masp_hip_generate_parameters(masp_hip_ctx* ctx, const masp_hip_r1cs* cs, const uint8_t toxic[160], uint8_t* out, size_t cap,
                                  size_t* out_len) {
     if (!ctx || !cs || !toxic || !out_len || cs->n_inputs == 0) return MASP_HIP_E_INVALID_ARG;
+    const ApiLaunchScope api_scope;
     ctx = FIRST_DEVICE(ctx);
     std::unique_lock<std::shared_mutex> lock(ctx->mu);
     hipSetDevice(ctx->device);
@@ -179,6 +180,7 @@ int masp_hip_generate_parameters(masp_hip_ctx* ctx, const masp_hip_r1cs* cs, con
     put(&h1[96 * o_b], 96 * n_b);
     put_len(n_b);
     put(&h2[192 * 3], 192 * n_b);
+    if (launch_status() != MASP_HIP_OK) return fail(ctx, MASP_HIP_E_HIP);  // a launch the runtime refused somewhere above (MASP_LAUNCH)
     return (size_t)(w - out) == total ? MASP_HIP_OK : MASP_HIP_E_INVALID_ARG;
 }
 

@@ -92,6 +92,7 @@ int masp_hip_verify_batch(masp_hip_ctx* ctx, masp_hip_vk* vk, size_t n, const ui
         *all_valid = 1;
         return MASP_HIP_OK;
     }
+    const ApiLaunchScope api_scope;
     ctx = FIRST_DEVICE(ctx);
     if (ctx->device != vk->device) return MASP_HIP_E_INVALID_ARG;
     std::shared_lock<std::shared_mutex> lock(ctx->mu);  // concurrent with provers (and with verifications under other keys)
@@ -132,6 +133,7 @@ int masp_hip_verify_batch(masp_hip_ctx* ctx, masp_hip_vk* vk, size_t n, const ui
         last_hip_error() = std::string("batch verification failed: ") + hipGetErrorString(hipGetLastError());
         return fail_shared_v(ctx, MASP_HIP_E_HIP);
     }
+    if (launch_status() != MASP_HIP_OK) return fail_shared_v(ctx, MASP_HIP_E_HIP);  // a refused launch: the buffers read back mean nothing
     for (int st : status)
         if (st & (PT_BAD_FLAGS | PT_NOT_CANONICAL | PT_NOT_IN_SUBGROUP | PT_INFINITY)) return MASP_HIP_OK;  // what Proof::read refuses (the identity included: "point at infinity"): not valid (*all_valid stays 0)
     masp_host::bls::G1A csum;

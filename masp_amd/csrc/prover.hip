@@ -601,6 +601,7 @@ void masp_hip_ctx_destroy(masp_hip_ctx* ctx) {
 }
 
 int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* params, size_t params_len, const masp_hip_r1cs* cs) {
+    const ApiLaunchScope api_scope;
     if (!ctx || !params || !cs || slot >= MASP_HIP_MAX_CIRCUITS || cs->n_inputs == 0) return MASP_HIP_E_INVALID_ARG;
     if (!ctx->children.empty()) {  // the CRS is replicated: every device builds its own window tables, side by side
         std::vector<int> rcs(ctx->children.size(), MASP_HIP_OK);
@@ -810,6 +811,7 @@ static int prove_batch_multi(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jo
 }
 
 int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, uint8_t* proofs_out) {
+    const ApiLaunchScope api_scope;
     if (!ctx || (n && (!jobs || !proofs_out))) return MASP_HIP_E_INVALID_ARG;
     if (!ctx->children.empty()) return prove_batch_multi(ctx, n, jobs, proofs_out);
     std::shared_lock<std::shared_mutex> lock(ctx->mu);  // concurrent with other provers, exclusive with circuit loads
@@ -1104,24 +1106,29 @@ extern "C" {
 #define FIRST_DEVICE(ctx) ((ctx) && !(ctx)->children.empty() ? (ctx)->children[0] : (ctx))
 
 int masp_hip_msm_g1(masp_hip_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[96]) {
+    const ApiLaunchScope api_scope;
     if (!ctx) return MASP_HIP_E_INVALID_ARG;
     ctx = FIRST_DEVICE(ctx);
     return msm_block<FpOps, 96>(ctx, bases, scalars, n, out, ctx->tmp_g1);
 }
 int masp_hip_msm_g2(masp_hip_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[192]) {
+    const ApiLaunchScope api_scope;
     if (!ctx) return MASP_HIP_E_INVALID_ARG;
     ctx = FIRST_DEVICE(ctx);
     return msm_block<Fp2Ops, 192>(ctx, bases, scalars, n, out, ctx->tmp_g2);
 }
 
 int masp_hip_msm_g1_multi(masp_hip_ctx* ctx, const uint8_t* bases, size_t n, const uint8_t* scalars, size_t np, int window_bits, uint8_t* out) {
+    const ApiLaunchScope api_scope;
     return msm_multi<FpOps, 96>(ctx, bases, n, scalars, np, window_bits, out);
 }
 int masp_hip_msm_g2_multi(masp_hip_ctx* ctx, const uint8_t* bases, size_t n, const uint8_t* scalars, size_t np, int window_bits, uint8_t* out) {
+    const ApiLaunchScope api_scope;
     return msm_multi<Fp2Ops, 192>(ctx, bases, n, scalars, np, window_bits, out);
 }
 
 int masp_hip_quotient_h(masp_hip_ctx* ctx, const uint8_t* a, const uint8_t* b, const uint8_t* c, size_t nrows, uint32_t logm, uint8_t* h_out) {
+    const ApiLaunchScope api_scope;
     if (!ctx || !a || !b || !c || !h_out || logm == 0 || logm > 20 || nrows > ((size_t)1 << logm)) return MASP_HIP_E_INVALID_ARG;
     ctx = FIRST_DEVICE(ctx);
     std::unique_lock<std::shared_mutex> lock(ctx->mu);
@@ -1149,6 +1156,7 @@ int masp_hip_quotient_h(masp_hip_ctx* ctx, const uint8_t* a, const uint8_t* b, c
 }
 
 int masp_hip_ntt(masp_hip_ctx* ctx, uint8_t* data, uint32_t logm, int inverse) {
+    const ApiLaunchScope api_scope;
     if (!ctx || !data || logm == 0 || logm > 20) return MASP_HIP_E_INVALID_ARG;
     ctx = FIRST_DEVICE(ctx);
     std::unique_lock<std::shared_mutex> lock(ctx->mu);
@@ -1181,6 +1189,7 @@ int masp_hip_ntt(masp_hip_ctx* ctx, uint8_t* data, uint32_t logm, int inverse) {
 
 // ---- measurement hooks ----------------------------------------------------------------------------
 int masp_hip_batch_upload(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs) {
+    const ApiLaunchScope api_scope;
     if (!ctx || !n || !jobs) return -MASP_HIP_E_INVALID_ARG;
     ctx = FIRST_DEVICE(ctx);
     std::unique_lock<std::shared_mutex> lock(ctx->mu);
@@ -1239,6 +1248,7 @@ int masp_hip_batch_free(masp_hip_ctx* ctx, int handle) {
 // or with the uploaded ones when rs is NULL): the whole launch sequence of all steps is enqueued on the slots' streams
 // without any host synchronisation in between.  proofs_out: steps x n x 192 bytes, job order inside every step.
 int masp_hip_batch_prove_resident_steps(masp_hip_ctx* ctx, int handle, size_t steps, const uint8_t* rs, uint8_t* proofs_out, float* elapsed_ms) {
+    const ApiLaunchScope api_scope;
     ctx = FIRST_DEVICE(ctx);
     if (!ctx || handle < 0 || (size_t)handle >= ctx->batches.size() || !ctx->batches[handle] || !proofs_out || !steps) return MASP_HIP_E_INVALID_ARG;
     std::unique_lock<std::shared_mutex> lock(ctx->mu);
@@ -1393,6 +1403,7 @@ int masp_hip_sync(masp_hip_ctx* ctx) {
 }
 
 int masp_hip_bench_msm(masp_hip_ctx* ctx, int handle, size_t job, int which, int iters, float* avg_ms, uint32_t* n_bases) {
+    const ApiLaunchScope api_scope;
     ctx = FIRST_DEVICE(ctx);
     if (!ctx || handle < 0 || (size_t)handle >= ctx->batches.size() || !ctx->batches[handle] || which < 0 || which > 3 || iters <= 0 || !avg_ms)
         return MASP_HIP_E_INVALID_ARG;

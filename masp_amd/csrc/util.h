@@ -37,6 +37,15 @@ inline int launch_status() {
     launch_error().clear();
     return MASP_HIP_E_HIP;
 }
+// First statement of every extern "C" entry point that launches kernels: whatever an earlier call of this thread left behind —
+// a latched launch failure that no launch_status() picked up, or a HIP error the embedding application (torch, RCCL ...) left on the
+// thread — must not be reported by this call as its own.  Each such entry point asks launch_status() before it reports success.
+struct ApiLaunchScope {
+    ApiLaunchScope() {
+        (void)hipGetLastError();
+        launch_error().clear();
+    }
+};
 // Every device allocation and release of the library goes through these two: they count.  A captured launch graph (the lone
 // proof's, Slot::graphs) holds raw device pointers of workspaces that grow on demand, so it is valid only as long as nothing
 // has been allocated or freed since it was captured — the count is that test (conservative: any allocation anywhere drops
