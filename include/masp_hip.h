@@ -112,9 +112,24 @@ typedef struct {
     int32_t lone_proof_graph;        /* 1: a batch of fewer than 8 proofs replays a captured HIP graph of its ~250 launches from its third
                                         call on.  Default off: with ROCm 7.2 the replay of this five-stream graph takes 11.5 ms where the
                                         launches enqueued one by one take 5.7 (profiles/r04_lone_proof_graph_ab.txt); the bytes are the same */
-    int32_t reserved[1];
+    int32_t hw_queues;               /* OUTPUT of masp_hip_ctx_get_options (ignored on input; was reserved[0]): the hardware queues the HIP
+                                        runtime of this process spreads its streams over, MEASURED when the context was created (as many
+                                        single-wave kernels as the context's slots have streams, at most 24, launched at once on streams of
+                                        their own: how many ran concurrently).  A slot owns five streams; with fewer queues than
+                                        5 x slots, independent kernels of a batch wait for each other (8 queues: -3 ... -10 % proofs/s,
+                                        profiles/r04e_hw_queues_and_the_two_modes.txt).  The runtime's default is FOUR
+                                        (profiles/r05_hw_queues_probe.txt); it reads GPU_MAX_HW_QUEUES at its first call — see
+                                        masp_hip_runtime_prepare */
 } masp_hip_options;
 void masp_hip_options_default(masp_hip_options* opt);
+/* The HIP runtime gives a process four hardware queues unless GPU_MAX_HW_QUEUES says otherwise, and reads the variable ONCE, at the
+ * process's first HIP call.  Loading this library sets GPU_MAX_HW_QUEUES=16 if the variable is not set (a constructor: the only write to
+ * the environment the library ever does, and it reads nothing else from it) — enough for a process whose first HIP call comes after the
+ * library is loaded, i.e. a Rust binary linking it.  A process that initialises HIP earlier (another HIP library's static initialisers)
+ * sets the variable itself, or calls this function before that point: hw_queues <= 0 means 16; an existing value is kept unless
+ * `overwrite`.  Returns the value now in the environment.  What the runtime really uses is reported per context:
+ * masp_hip_options::hw_queues. */
+int masp_hip_runtime_prepare(int hw_queues, int overwrite);
 
 int masp_hip_ctx_create(int device, masp_hip_ctx** out);
 /* The general constructor: n_devices == 1 gives a single-device context, more give the multi-device front described

@@ -49,6 +49,7 @@ static masp_hip_options resolve_options(const masp_hip_options* in) {
     o.bucket_tree_levels_g2 = o.bucket_tree_levels_g2 > 0 ? std::min<int>(o.bucket_tree_levels_g2, 12) : o.bucket_tree_levels_g2 < 0 ? -1 : o.bucket_tree_levels;
     o.bucket_tree_scratch_mb = std::max(o.bucket_tree_scratch_mb, 0);
     o.bucket_tree_fallback_proofs = 0;   // output only
+    o.hw_queues = 0;                     // output only (measured when a device context is created)
     o.lone_proof_graph = o.lone_proof_graph > 0 ? 1 : 0;   // off unless asked for: measured slower with ROCm 7.2's graph launch
     return o;
 }
@@ -460,10 +461,61 @@ int masp_hip_device_count(void) {
     return hipGetDeviceCount(&count) == hipSuccess && count > 0 ? count : 0;
 }
 
+int masp_hip_runtime_prepare(int hw_queues, int overwrite) {
+    char v[16];
+    snprintf(v, sizeof v, "%d", hw_queues > 0 ? std::min(hw_queues, 128) : 16);
+    setenv("GPU_MAX_HW_QUEUES", v, overwrite ? 1 : 0);
+    const char* e = getenv("GPU_MAX_HW_QUEUES");
+    return e ? atoi(e) : 0;
+}
+// (see masp_hip_runtime_prepare in include/masp_hip.h: the one thing the library does to the environment)
+__attribute__((constructor)) static void masp_hip_on_load() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 void masp_hip_options_default(masp_hip_options* opt) {
     if (!opt) return;
     memset(opt, 0, sizeof *opt);   // every field: 0 = the default (resolved when a context is created)
     opt->struct_size = sizeof *opt;
+}
+
+// ---- how many hardware queues do this process's streams really get?  (masp_hip_options::hw_queues) -------------------------------
+// One single-wave kernel per stream, all launched at once, each spinning for 2 ms of the constant 100 MHz clock and leaving its
+// [start, end): the largest number of them that overlapped = the hardware queues the streams were spread over (streams that share a
+// queue run one after the other).  Temporary streams, created and destroyed BEFORE the context creates its own.
+static __global__ void k_hwq_spin(unsigned long long* out, int idx, long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {
+    }
+    out[2 * idx] = (unsigned long long)t0;
+    out[2 * idx + 1] = (unsigned long long)wall_clock64();
+}
+static int measure_hw_queues(int streams) {
+    const int n = std::max(1, std::min(streams, 24));
+    std::vector<hipStream_t> ss;
+    unsigned long long* d = nullptr;
+    int best = 0;
+    if (hipMalloc(&d, 16 * n) != hipSuccess) return 0;
+    for (int i = 0; i < n; ++i) {
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+        ss.push_back(s);
+    }
+    if ((int)ss.size() == n) {
+        for (int r = 0; r < 2; ++r) {  // (the first round loads the code object and creates the queues)
+            for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k_hwq_spin, dim3(1), dim3(64), 0, ss[i], d, i, r ? 200000LL : 1000LL);
+            (void)hipDeviceSynchronize();
+        }
+        std::vector<unsigned long long> h(2 * n);
+        if (hipGetLastError() == hipSuccess && hipMemcpy(h.data(), d, 16 * n, hipMemcpyDeviceToHost) == hipSuccess)
+            for (int i = 0; i < n; ++i) {
+                int c = 0;
+                for (int j = 0; j < n; ++j) c += h[2 * j] <= h[2 * i] && h[2 * i] < h[2 * j + 1];
+                best = std::max(best, c);
+            }
+    }
+    for (hipStream_t s : ss) (void)hipStreamDestroy(s);
+    (void)hipFree(d);
+    (void)hipGetLastError();
+    return best;
 }
 
 static int create_single(int device, const masp_hip_options& opt, masp_hip_ctx** out) {
@@ -478,6 +530,7 @@ static int create_single(int device, const masp_hip_options& opt, masp_hip_ctx**
     ctx->batch_cap = (size_t)opt.batch_cap;
     ctx->slots.reserve(masp_hip_ctx::MAX_SLOTS);      // never reallocates: see the locking note on masp_hip_ctx
     ctx->slot_busy.reserve(masp_hip_ctx::MAX_SLOTS);
+    ctx->opt.hw_queues = measure_hw_queues(5 * opt.slots);   // (a slot owns five streams)
     if (hipStreamCreateWithFlags(&ctx->main_stream, hipStreamNonBlocking) != hipSuccess) return MASP_HIP_E_NO_DEVICE;
     *out = ctx.release();
     return MASP_HIP_OK;

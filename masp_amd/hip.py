@@ -27,7 +27,7 @@ OPTION_FIELDS = ("slots", "batch_cap", "ntt_sub_batch", "window_bits_h", "window
 class OptionsStruct(C.Structure):
     """masp_hip_options (include/masp_hip.h): every field 0 = the default."""
     _fields_ = ([("struct_size", C.c_uint32)] + [(f, C.c_int32) for f in OPTION_FIELDS[:-1]] +
-                [("bucket_tree_fallback_proofs", C.c_int32), ("lone_proof_graph", C.c_int32), ("reserved", C.c_int32 * 1)])
+                [("bucket_tree_fallback_proofs", C.c_int32), ("lone_proof_graph", C.c_int32), ("hw_queues", C.c_int32)])
 
 
 class JobStruct(C.Structure):
@@ -57,8 +57,13 @@ def load_library():
     # (ROCm's default is 4); read once, when the HIP runtime initialises.  16: three slots have 15 streams between them; with 8
     # queues about one bench process in four landed in a mode 3 % slower (streams of two slots sharing a queue), with 16 none of
     # twelve did (profiles/r04e_hw_queues_and_the_two_modes.txt)
+    # (the library's constructor does the same for a process that links it directly — masp_hip_runtime_prepare, include/masp_hip.h —;
+    # here it is said before the load because an A/B run may load an older build.  What the runtime really uses is MEASURED per context:
+    # Context.options["hw_queues"])
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     L = C.CDLL(path)
+    if hasattr(L, "masp_hip_runtime_prepare"):
+        L.masp_hip_runtime_prepare.argtypes = [C.c_int, C.c_int]
     vp, sz, u32 = C.c_void_p, C.c_size_t, C.c_uint32
     L.masp_hip_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.masp_hip_ctx_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
@@ -172,6 +177,15 @@ class Context:
         got = OptionsStruct()
         self._L.masp_hip_ctx_get_options(h, C.byref(got))
         self.options = {f: int(getattr(got, f)) for f in OPTION_FIELDS}      # defaults resolved
+        # hardware queues the runtime spreads this process's streams over, measured at creation (masp_hip_options::hw_queues): fewer than
+        # the slots have streams (five each) means independent kernels of a batch wait for each other — the HIP runtime was initialised
+        # (by whatever this process loaded first) before GPU_MAX_HW_QUEUES said 16
+        self.options["hw_queues"] = int(got.hw_queues)
+        want = min(5 * self.options["slots"], 15)
+        if 0 < self.options["hw_queues"] < want:
+            import warnings
+            warnings.warn("masp_amd: the HIP runtime gives this process %d hardware queue(s) for %d slots x 5 streams: set GPU_MAX_HW_QUEUES=16 "
+                          "before the process's first HIP call (masp_hip_runtime_prepare)" % (self.options["hw_queues"], self.options["slots"]))
         self._h = h
         self._keep = []
         self._pinned = {}
@@ -314,6 +328,7 @@ class Context:
         self._check(self._L.masp_hip_ctx_get_options(self._h, C.byref(got)))
         d = {f: int(getattr(got, f)) for f in OPTION_FIELDS}
         d["bucket_tree_fallback_proofs"] = int(got.bucket_tree_fallback_proofs)
+        d["hw_queues"] = int(got.hw_queues)
         return d
 
     @property

@@ -1,0 +1,61 @@
+"""masp_hip_options::hw_queues: the hardware queues the HIP runtime really gives this process, measured when a context is created
+(the two-mode behaviour was avoided by an environment variable the Python wrappers set, which a caller linking
+libmasp_hip.so directly never got — "nothing in the C ABI warns when the process has 8 queues for 15 streams").  Now the library sets
+GPU_MAX_HW_QUEUES=16 on load if it is unset, offers masp_hip_runtime_prepare, and reports the measured figure.  Each case is a process of
+its own: the runtime reads the variable once.  Run with `-m gpu`."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+PROBE = r"""
+import ctypes as C, os, sys, warnings
+sys.path.insert(0, %r)
+from masp_amd import hip
+mode = sys.argv[1]
+if mode == "bare":          # what a Rust binary linking the library gets: no wrapper touches the environment, the constructor does
+    os.environ.pop("GPU_MAX_HW_QUEUES", None)
+    L = C.CDLL(hip.library_path())
+    L.masp_hip_runtime_prepare.argtypes = [C.c_int, C.c_int]
+    print("prepare", L.masp_hip_runtime_prepare(0, 0))
+    h = C.c_void_p()
+    assert L.masp_hip_ctx_create(0, C.byref(h)) == 0
+    got = hip.OptionsStruct()
+    L.masp_hip_ctx_get_options.argtypes = [C.c_void_p, C.POINTER(hip.OptionsStruct)]
+    assert L.masp_hip_ctx_get_options(h, C.byref(got)) == 0
+    print("hw_queues", got.hw_queues, "slots", got.slots)
+    L.masp_hip_ctx_destroy.argtypes = [C.c_void_p]
+    L.masp_hip_ctx_destroy(h)
+else:                        # the wrapper with the variable forced by the caller
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        ctx = hip.Context(0)
+        print("hw_queues", ctx.options["hw_queues"], "slots", ctx.options["slots"])
+        print("warned", int(any("hardware queue" in str(x.message) for x in w)))
+        ctx.close()
+""" % ROOT
+
+
+def _run(mode, env_extra):
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    env.update(env_extra)
+    out = subprocess.run([sys.executable, "-c", PROBE, mode], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return dict(l.split()[:2] for l in out.stdout.splitlines() if l.strip())
+
+
+def test_a_process_that_only_links_the_library_gets_sixteen_queues():
+    got = _run("bare", {})
+    assert got["prepare"] == "16"                      # the constructor had already set it; prepare(0, 0) keeps it
+    assert int(got["hw_queues"]) >= 15                 # 3 slots x 5 streams probed, all concurrent
+
+
+def test_too_few_queues_are_measured_and_the_wrapper_warns():
+    got = _run("wrapper", {"GPU_MAX_HW_QUEUES": "4"})
+    assert int(got["hw_queues"]) == 4 and got["warned"] == "1"
+    got = _run("wrapper", {"GPU_MAX_HW_QUEUES": "16"})
+    assert int(got["hw_queues"]) >= 15 and got["warned"] == "0"
