@@ -120,6 +120,10 @@ typedef struct {
                                         profiles/r04e_hw_queues_and_the_two_modes.txt).  The runtime's default is FOUR
                                         (profiles/r05_hw_queues_probe.txt); it reads GPU_MAX_HW_QUEUES at its first call — see
                                         masp_hip_runtime_prepare */
+    int32_t window_bits_h_lone;      /* (round 5, appended: struct_size tells) window width of the h query's OWN table, which only lone
+                                        proofs use — a batch runs h and l as one MSM over the merged table on window_bits_h.  Narrower
+                                        windows mean more additions in the chip-filling accumulation and far fewer buckets in the
+                                        latency-bound tails a lone proof waits for.  Default: see resolve_options (prover.hip) */
 } masp_hip_options;
 void masp_hip_options_default(masp_hip_options* opt);
 /* The HIP runtime gives a process four hardware queues unless GPU_MAX_HW_QUEUES says otherwise, and reads the variable ONCE, at the
@@ -245,6 +249,10 @@ int masp_hip_profile_read(masp_hip_ctx* ctx, double* total_ms, uint64_t* launche
  * ms[1] its denominators pass (k_tree_pass1), ms[2] the shared inversions (k_binv_*), ms[3] its additions pass (k_tree_pass2),
  * ms[4] the XYZZ accumulation of what is left (k_msm_accumulate_pts, or k_msm_accumulate without a tree); ms[5..7] = 0. */
 int masp_hip_profile_read_split(masp_hip_ctx* ctx, double ms[8]);
+/* Where the chains of the last LONE proof (a batch of fewer than 8 proofs) proved with profiling on ended, in milliseconds of GPU time
+ * after its first kernel could start — HIP events behind the stages, no profiler in the way: ms[1] MSM a, [2] s*A, [3] MSM b_g1, [4] r*B1,
+ * [5] MSM b_g2, [6] g_b written, [7] quotient, [8] MSM h, [9] MSM l, [10] g_a / g_c written, [11] the proof complete; -1 = not recorded. */
+int masp_hip_profile_read_lone(masp_hip_ctx* ctx, double ms[12]);
 /* Page-locked host memory for assignments.  masp_hip_prove_batch recognises `aux` pointers that lie in page-locked
  * memory (from here or from the caller's own hipHostMalloc / hipHostRegister) and copies them to the device directly;
  * anything else goes through the library's own pinned staging buffer first (one extra host copy of ~3 MB per Spend).

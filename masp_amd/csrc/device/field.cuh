@@ -1369,6 +1369,7 @@ struct FpOps {
     typedef FpMulCold Cold;
     typedef FpOps Base;                     // the ops of the stored element (see Fp2PairOps)
     static constexpr uint32_t LANES = 1;    // lanes that hold one element
+    static constexpr uint32_t PARTS = 1;    // parts a STORED element is read in (one per lane of a group that shares it: see Fp2PairOps)
     static constexpr bool REPLICATED = false;   // see FpQuadOps
     static MASP_HD T zero() { return fe_zero<FpCfg>(); }
     static MASP_HD T one() { return fe_one<FpCfg>(); }
@@ -1397,6 +1398,7 @@ struct Fp2Ops {
     typedef Fp2Ops Cold;  // already call-based
     typedef Fp2Ops Base;
     static constexpr uint32_t LANES = 1;
+    static constexpr uint32_t PARTS = 1;
     static constexpr bool REPLICATED = false;   // see FpQuadOps
     static MASP_HD T zero() { return {fe_zero<FpCfg>(), fe_zero<FpCfg>()}; }
     static MASP_HD T one() { return {fe_one<FpCfg>(), fe_zero<FpCfg>()}; }
@@ -1523,6 +1525,7 @@ struct Fp2PairOps {
     typedef Fp2Ops Base;
     typedef Fp2PairCold Cold;
     static constexpr uint32_t LANES = 2;
+    static constexpr uint32_t PARTS = 2;        // lane `half` reads half of every stored Fp2
     static constexpr bool REPLICATED = false;   // see FpQuadOps
     static __device__ __forceinline__ uint32_t half() { return Fp2PairLanes::half(); }
     static __device__ __forceinline__ T partner(const T& a) { return Fp2PairLanes::partner(a); }
@@ -1547,6 +1550,13 @@ struct Fp2PairOps {
         const T r = fe_mul(a, fe_inv_bingcd(fe_mul2(a, a, ap, ap)));
         return half() ? fe_neg(r) : r;
     }
+};
+// Fp2PairOps with FOUR pairs per G2 point (device/oct.cuh): eight lanes per point, every pair holds the whole element (its lanes one half
+// each); the point operations spread their independent products over the four pairs.  Field operations on their own are Fp2PairOps's,
+// done redundantly by the four pairs.  The bucket tails of a lone proof's b_g2 MSM.
+struct Fp2OctOps : Fp2PairOps {
+    static constexpr uint32_t LANES = 8;
+    static constexpr bool REPLICATED = true;
 };
 #endif
 

@@ -27,6 +27,7 @@
 
 #include "curve.cuh"
 #include "quad.cuh"
+#include "oct.cuh"
 #include "io.cuh"
 #include "msm_geom.h"
 
@@ -83,31 +84,35 @@ __global__ void __launch_bounds__(64) k_msm_precompute(TabRow<O>* __restrict__ t
 #endif
 // The tail kernels are written over O::LANES lanes per point (1; 2 for Fp2PairOps: the even lane holds the c0 halves of the four
 // coordinates, the odd lane the c1 halves — G2 at the register footprint of G1).  A stored point is Xyzz<O::Base>.
+// (h = lane in the group of O::LANES lanes that share a point; a stored element is read in O::PARTS parts: 1 = whole — every lane of
+// a replicated group reads it —, 2 = one half of every Fp2 per lane, whichever pair of the group the lane belongs to)
 template <class O>
 __device__ __forceinline__ Xyzz<O> xyzz_load(const Xyzz<typename O::Base>* __restrict__ p, uint32_t h) {
-    if constexpr (O::REPLICATED) {  // every lane of the group holds the whole point
+    if constexpr (O::PARTS == 1) {
         const Xyzz<typename O::Base> v = *p;
         return reinterpret_cast<const Xyzz<O>&>(v);
     } else {
         const typename O::T* q = reinterpret_cast<const typename O::T*>(p);
+        const uint32_t part = h % O::PARTS;
         Xyzz<O> r;
-        r.X = q[h];
-        r.Y = q[O::LANES + h];
-        r.ZZ = q[2 * O::LANES + h];
-        r.ZZZ = q[3 * O::LANES + h];
+        r.X = q[part];
+        r.Y = q[O::PARTS + part];
+        r.ZZ = q[2 * O::PARTS + part];
+        r.ZZZ = q[3 * O::PARTS + part];
         return r;
     }
 }
 template <class O>
 __device__ __forceinline__ void xyzz_store(Xyzz<typename O::Base>* __restrict__ p, const Xyzz<O>& v, uint32_t h) {
-    if constexpr (O::REPLICATED) {
+    if constexpr (O::PARTS == 1) {
         if (h == 0) *p = reinterpret_cast<const Xyzz<typename O::Base>&>(v);
     } else {
+        if (h >= O::PARTS) return;  // (a replicated group: its first pair stores)
         typename O::T* q = reinterpret_cast<typename O::T*>(p);
         q[h] = v.X;
-        q[O::LANES + h] = v.Y;
-        q[2 * O::LANES + h] = v.ZZ;
-        q[3 * O::LANES + h] = v.ZZZ;
+        q[O::PARTS + h] = v.Y;
+        q[2 * O::PARTS + h] = v.ZZ;
+        q[3 * O::PARTS + h] = v.ZZZ;
     }
 }
 // launch with 64 lanes per workgroup: 64 / LANES buckets
@@ -151,10 +156,16 @@ __device__ __forceinline__ Xyzz<O> xyzz_shfl_down(const Xyzz<O>& p, int d) {
 // THREADS / 64 waves: strided serial sums, a shuffle tree inside each wave, the waves' values through LDS.
 // (THREADS = 256 measured faster than a single wave in both regimes: one bucket of ~650 partials per proof in a batch,
 // thousands of buckets with ~80 partials each for a lone proof.)
-template <class O, uint32_t THREADS>
+// SPLIT > 1 (a lone proof): a heavy bucket is shared by SPLIT workgroups, each summing an equal share of its partials into
+// hparts[hb * SPLIT + share]; k_msm_heavy_join adds the shares.  The unit scalars of a witness all sit in ONE bucket — 2 500 partials
+// of a lone proof's b_g2 MSM where every other bucket has 480 — and as one workgroup's 78 dependent additions that bucket alone was 0.9
+// of the 4 ms a lone Spend proof takes (profiles/r05_lone_b2_msm_kernels_in_isolation.txt).  Heavy buckets beyond MSM_HEAVY_SLOTS / SPLIT
+// (never more than a handful in practice) are summed by their first workgroup alone, as before.
+template <class O, uint32_t THREADS, uint32_t SPLIT = 1>
 __global__ void __launch_bounds__(THREADS, MASP_TAIL_MIN_WAVES)
 k_msm_bucket_heavy(const Xyzz<typename O::Base>* __restrict__ part, const uint32_t* __restrict__ start, uint32_t nb, uint32_t nchunks,
-                   Xyzz<typename O::Base>* __restrict__ bkt, const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ n_heavy) {
+                   Xyzz<typename O::Base>* __restrict__ bkt, const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ n_heavy,
+                   Xyzz<typename O::Base>* __restrict__ hparts) {
     constexpr uint32_t LN = O::LANES, WE = 64 / LN, EL = THREADS / LN;  // points per wave / per workgroup
     __shared__ Xyzz<typename O::Base> sh[THREADS / 64];
     const uint32_t tid = threadIdx.x, e = tid / LN, h = tid % LN, le = (tid & 63) / LN, wid = tid >> 6;
@@ -163,14 +174,24 @@ k_msm_bucket_heavy(const Xyzz<typename O::Base>* __restrict__ part, const uint32
     bkt += (size_t)MSM_P * nb;
     heavy += (size_t)MSM_P * nb;
     n_heavy += MSM_P;
+    if constexpr (SPLIT > 1) hparts += (size_t)MSM_P * MSM_HEAVY_SLOTS;
     const uint32_t nh = *n_heavy;
     const uint32_t K = msm_chunk_len(start[nb], nchunks);
-    for (uint32_t hb = blockIdx.x; hb < nh; hb += gridDim.x) {
+    const uint32_t share = blockIdx.x % SPLIT, nwg = gridDim.x / SPLIT;
+    for (uint32_t hb = blockIdx.x / SPLIT; hb < nh; hb += nwg) {
         const uint32_t b = heavy[hb];
-        const uint32_t c0 = start[b] / K, c1 = (start[b + 1] - 1) / K;
+        uint32_t c0 = start[b] / K, c1 = (start[b + 1] - 1) / K;
+        const bool split = SPLIT > 1 && hb < MSM_HEAVY_SLOTS / SPLIT;
+        if (split) {
+            const uint32_t len = (c1 - c0 + SPLIT) / SPLIT;  // ceil(span / SPLIT)
+            c0 += share * len;
+            c1 = c0 + len - 1 < c1 ? c0 + len - 1 : c1;
+        } else if (share != 0) {
+            continue;
+        }
         Xyzz<O> acc = xyzz_inf<O>();
-        for (uint32_t c = c0 + e; c <= c1; c += EL) xyzz_add_nc(acc, xyzz_load<O>(part + c + b, h));
-        const uint32_t span = c1 - c0 + 1;  // points >= span hold infinity: skip the tree levels that only move infinities
+        for (uint32_t c = c0 + e; c <= c1 && c1 + 1 > c0; c += EL) xyzz_add_nc(acc, xyzz_load<O>(part + c + b, h));
+        const uint32_t span = c1 + 1 > c0 ? c1 - c0 + 1 : 0;  // points >= span hold infinity: skip the tree levels that only move infinities
         for (uint32_t d = WE / 2; d >= 1; d >>= 1) {
             if (d >= span) continue;
             Xyzz<O> other = xyzz_shfl_down(acc, (int)(d * LN));
@@ -182,9 +203,30 @@ k_msm_bucket_heavy(const Xyzz<typename O::Base>* __restrict__ part, const uint32
             if (e == 0)
                 for (uint32_t w = 1; w < THREADS / 64; ++w) xyzz_add_nc(acc, xyzz_load<O>(sh + w, h));
         }
-        if (e == 0) xyzz_store<O>(bkt + b, acc, h);
+        if (e == 0) xyzz_store<O>(split ? hparts + hb * SPLIT + share : bkt + b, acc, h);
         if constexpr (THREADS > 64) __syncthreads();
     }
+}
+// bkt[heavy[hb]] = sum of the SPLIT shares of heavy bucket hb (hb < MSM_HEAVY_SLOTS / SPLIT): SPLIT groups of lanes per bucket, a
+// shuffle tree.  64 lanes per workgroup = 64 / (LANES x SPLIT) buckets.
+template <class O, uint32_t SPLIT>
+__global__ void __launch_bounds__(64, MASP_TAIL_MIN_WAVES)
+k_msm_heavy_join(const Xyzz<typename O::Base>* __restrict__ hparts, const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ n_heavy, uint32_t nb,
+                 Xyzz<typename O::Base>* __restrict__ bkt) {
+    constexpr uint32_t LN = O::LANES, PER = 64 / (LN * SPLIT);
+    static_assert(PER >= 1, "a bucket's shares fit one wave");
+    const uint32_t e = threadIdx.x / LN, h = threadIdx.x % LN, share = e % SPLIT, hb = blockIdx.x * PER + e / SPLIT;
+    hparts += (size_t)MSM_P * MSM_HEAVY_SLOTS;
+    heavy += (size_t)MSM_P * nb;
+    bkt += (size_t)MSM_P * nb;
+    const uint32_t nh = n_heavy[MSM_P], lim = nh < MSM_HEAVY_SLOTS / SPLIT ? nh : MSM_HEAVY_SLOTS / SPLIT;
+    if (hb >= lim) return;  // (all SPLIT groups of a bucket leave together)
+    Xyzz<O> acc = xyzz_load<O>(hparts + hb * SPLIT + share, h);
+    for (uint32_t d = SPLIT / 2; d >= 1; d >>= 1) {
+        Xyzz<O> other = xyzz_shfl_down(acc, (int)(d * LN));
+        if (share < d) xyzz_add_nc(acc, other);
+    }
+    if (share == 0) xyzz_store<O>(bkt + heavy[hb], acc, h);
 }
 
 // ---- (6) reductions -----------------------------------------------------------------------------
@@ -201,11 +243,18 @@ k_msm_bucket_heavy(const Xyzz<typename O::Base>* __restrict__ part, const uint32
 #ifndef MASP_WSUM_PAIR_WAVES
 #define MASP_WSUM_PAIR_WAVES 2
 #endif
+// points (groups of O::LANES lanes) per workgroup of k_msm_wsum_level: WSUM_L, or half of it where eight lanes hold a point (1 024 lanes
+// per workgroup would leave a lane 128 registers) — the chunk a workgroup owns stays (WSUM_L << G_LOG) buckets, a group takes twice as many
+template <class O>
+constexpr uint32_t wsum_points_log() {
+    return O::LANES > 4 ? WSUM_L_LOG - 1 : WSUM_L_LOG;
+}
 template <class O, uint32_t G_LOG>
-__global__ void __launch_bounds__(WSUM_L * O::LANES, (O::LANES > 1 ? MASP_WSUM_PAIR_WAVES : sizeof(Xyzz<O>) > 200 || G_LOG < 3 ? MASP_TAIL_MIN_WAVES : 2))
+__global__ void __launch_bounds__((1u << wsum_points_log<O>()) * O::LANES, (O::LANES > 1 ? MASP_WSUM_PAIR_WAVES : sizeof(Xyzz<O>) > 200 || G_LOG < 3 ? MASP_TAIL_MIN_WAVES : 2))
 k_msm_wsum_level(const Xyzz<typename O::Base>* __restrict__ B, size_t b_stride, uint32_t m, uint32_t off, Xyzz<typename O::Base>* __restrict__ S,
                  Xyzz<typename O::Base>* __restrict__ T, size_t st_stride) {
-    constexpr uint32_t G = 1u << G_LOG, CS = G * WSUM_L, LN = O::LANES, WE = 64 / LN, NW = WSUM_L / WE;  // points per wave, waves
+    constexpr uint32_t LP = 1u << wsum_points_log<O>(), GL = G_LOG + WSUM_L_LOG - wsum_points_log<O>(), G = 1u << GL, CS = G * LP, LN = O::LANES,
+                       WE = 64 / LN, NW = LP / WE;  // points per workgroup, buckets per point, points per wave, waves
     __shared__ Xyzz<typename O::Base> sh[2][NW];
     const uint32_t tid = threadIdx.x, e = tid / LN, h = tid % LN, le = (tid & 63) / LN, wid = tid >> 6;
     B += MSM_P * b_stride;
@@ -225,22 +274,46 @@ k_msm_wsum_level(const Xyzz<typename O::Base>* __restrict__ B, size_t b_stride, 
         Xyzz<O> other = xyzz_shfl_down(x, (int)(d * LN));
         if (le + d < WE) xyzz_add_nc(x, other);
     }
-    if (wid > 0 && le == 0) xyzz_store<O>(&sh[0][wid], x, h);
+    // ... across the waves: wave 0 turns the waves' totals into "sum of the totals of the waves behind" with one more shuffle scan over
+    // its first NW points (NW <= 8 <= points per wave), so that every wave adds ONE value (as a loop over the waves behind it, wave 0
+    // of a lone proof's 8-wave workgroup ran 7 dependent additions here and 7 more at the end)
+    static_assert(NW <= WE, "the waves' totals fit the points of one wave");
+    if (le == 0) xyzz_store<O>(&sh[0][wid], x, h);
     __syncthreads();
-    for (uint32_t w = wid + 1; w < NW; ++w) xyzz_add_nc(x, xyzz_load<O>(&sh[0][w], h));
+    if constexpr (NW > 1) {
+        if (wid == 0) {
+            Xyzz<O> v = le < NW ? xyzz_load<O>(&sh[0][le], h) : xyzz_inf<O>();
+            for (uint32_t d = 1; d < NW; d <<= 1) {
+                Xyzz<O> other = xyzz_shfl_down(v, (int)(d * LN));
+                if (le + d < NW) xyzz_add_nc(v, other);
+            }
+            Xyzz<O> behind = xyzz_shfl_down(v, (int)LN);  // inclusive suffix of point le + 1 = the totals of the waves behind wave le
+            if (le + 1 < NW) xyzz_store<O>(&sh[0][le], behind, h);
+        }
+        __syncthreads();
+        if (wid + 1 < NW) xyzz_add_nc(x, xyzz_load<O>(&sh[0][wid], h));
+    }
     Xyzz<O> y = e > 0 ? x : xyzz_inf<O>();
-    for (uint32_t k = 0; k < G_LOG; ++k) y = xyzz_dbl(y);
+    for (uint32_t k = 0; k < GL; ++k) y = xyzz_dbl(y);
     xyzz_add_nc(y, acc);
     for (uint32_t d = WE / 2; d >= 1; d >>= 1) {
         Xyzz<O> other = xyzz_shfl_down(y, (int)(d * LN));
         if (le < d) xyzz_add_nc(y, other);
     }
-    if (wid > 0 && le == 0) xyzz_store<O>(&sh[1][wid], y, h);
+    if (le == 0) xyzz_store<O>(&sh[1][wid], y, h);
     __syncthreads();
-    if (e == 0) {
-        for (uint32_t w = 1; w < NW; ++w) xyzz_add_nc(y, xyzz_load<O>(&sh[1][w], h));
-        xyzz_store<O>(S + blockIdx.x, x, h);
-        xyzz_store<O>(T + blockIdx.x, y, h);
+    if (wid == 0) {
+        if constexpr (NW > 1) {
+            y = le < NW ? xyzz_load<O>(&sh[1][le], h) : xyzz_inf<O>();
+            for (uint32_t d = NW / 2; d >= 1; d >>= 1) {
+                Xyzz<O> other = xyzz_shfl_down(y, (int)(d * LN));
+                if (le < d) xyzz_add_nc(y, other);
+            }
+        }
+        if (e == 0) {
+            xyzz_store<O>(S + blockIdx.x, x, h);
+            xyzz_store<O>(T + blockIdx.x, y, h);
+        }
     }
 }
 // out[b] = sum of in[b*256 .. min(n, b*256+256)) by an LDS tree (8 dependent additions)
@@ -276,18 +349,23 @@ __global__ void __launch_bounds__(64) k_msm_combine(const Xyzz<O>* __restrict__ 
     *out = acc;
 }
 
-// The same two kernels over O::LANES lanes per point (a lone proof's G1 tails: FpQuadOps) — 256 points per workgroup, one point.
+// The same two kernels over O::LANES lanes per point (a lone proof's tails: FpQuadOps, Fp2OctOps) — 256 / 64 points per workgroup, one point.
 template <class O>
-__global__ void __launch_bounds__(256 * O::LANES) k_xyzz_reduce_block_lanes(const Xyzz<typename O::Base>* __restrict__ in, size_t in_stride, uint32_t n,
+constexpr uint32_t reduce_lanes_points() {
+    return O::LANES > 4 ? 64u : 256u;  // (eight lanes per point: 512 lanes per workgroup, so that a lane keeps 256 registers)
+}
+template <class O>
+__global__ void __launch_bounds__(reduce_lanes_points<O>() * O::LANES) k_xyzz_reduce_block_lanes(const Xyzz<typename O::Base>* __restrict__ in, size_t in_stride, uint32_t n,
                                                                             Xyzz<typename O::Base>* __restrict__ out, size_t out_stride) {
     extern __shared__ uint4 wsum_lds[];
+    constexpr uint32_t PTS = reduce_lanes_points<O>();
     Xyzz<typename O::Base>* sh = reinterpret_cast<Xyzz<typename O::Base>*>(wsum_lds);
     const uint32_t e = threadIdx.x / O::LANES, h = threadIdx.x % O::LANES;
     in += MSM_P * in_stride;
     out += MSM_P * out_stride;
-    const uint32_t k = blockIdx.x * 256 + e;
+    const uint32_t k = blockIdx.x * PTS + e;
     Xyzz<O> y = k < n ? xyzz_load<O>(in + k, h) : xyzz_inf<O>();
-    for (uint32_t d = 128; d >= 1; d >>= 1) {
+    for (uint32_t d = PTS / 2; d >= 1; d >>= 1) {
         xyzz_store<O>(sh + e, y, h);
         __syncthreads();
         if (e < d) xyzz_add_nc(y, xyzz_load<O>(sh + e + d, h));

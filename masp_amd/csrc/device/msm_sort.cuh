@@ -15,7 +15,7 @@ namespace masp {
 // The scalars of one proof are cut into `ng` contiguous ranges, one workgroup each.  A workgroup keeps the whole bucket
 // histogram (2^(c-1) counters, 128 KiB for c = 16) in LDS:
 //   k_msm_hist     counts the digits of its range into LDS and stores the histogram            hist_wg[p][wg][b]
-//   k_msm_offsets  turns them into  rel[p][wg][b] = entries of bucket b in earlier ranges  and  start[p][b]
+//   k_msm_offsets_*  turn them into  rel[p][wg][b] = entries of bucket b in earlier ranges  and  start[p][b]
 //   k_msm_scatter  reloads  start[b] + rel[wg][b]  into LDS, recomputes the digits of the same range and places every
 //                  entry with one LDS atomic.
 // Scalars equal to 1 (a third of a MASP witness: booleans) all land in bucket 0 of window 0; a wave counts / places them
@@ -79,34 +79,47 @@ k_msm_hist(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32_t 
     __syncthreads();
     for (uint32_t b = tid; b < nb; b += MSM_SORT_THREADS) hist_wg[b] = msm_lds[b];
 }
-// one workgroup per proof: hist_wg[wg][b] -> rel[wg][b] (in place); dense[0..nb] = offsets of the runs packed (dense[nb] =
-// number of entries), start[0..nb] = offsets with every run starting at a multiple of 2^pad_log (start[nb] likewise rounded up)
+// hist_wg[wg][b] -> rel[wg][b] (in place); dense[0..nb] = offsets of the runs packed (dense[nb] = number of entries),
+// start[0..nb] = offsets with every run starting at a multiple of 2^pad_log (start[nb] likewise rounded up).  Two kernels (round 5:
+// as ONE workgroup per proof — which read and rewrote the 64 ranges x 32 768 buckets of a lone proof's h query, 8 MB, by itself —
+// the step took 0.22 ms of the 2.2 ms a lone proof waits for that MSM):
+//   k_msm_offsets_cols  grid (nb / 256, np): one lane per bucket walks the ranges (sixteen loads in flight), leaves the bucket's
+//                       total in dense[b]
+//   k_msm_offsets_scan  one workgroup per proof: exclusive scans of the totals and of the padded totals, 1 024 buckets at a time
+__global__ void __launch_bounds__(256)
+k_msm_offsets_cols(uint32_t* __restrict__ hist_wg, uint32_t ng, uint32_t nb, uint32_t* __restrict__ dense) {
+    hist_wg += (size_t)MSM_P * ng * nb;
+    dense += (size_t)MSM_P * (nb + 1);
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    uint32_t v = 0;
+    for (uint32_t w0 = 0; w0 < ng; w0 += 16) {
+        uint32_t h[16];
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k) h[k] = w0 + k < ng ? hist_wg[(size_t)(w0 + k) * nb + b] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k)
+            if (w0 + k < ng) {
+                hist_wg[(size_t)(w0 + k) * nb + b] = v;
+                v += h[k];
+            }
+    }
+    dense[b] = v;
+}
 __global__ void __launch_bounds__(1024)
-k_msm_offsets(uint32_t* __restrict__ hist_wg, uint32_t ng, uint32_t nb, uint32_t* __restrict__ start, uint32_t* __restrict__ dense, uint32_t pad_log) {
+k_msm_offsets_scan(uint32_t nb, uint32_t* __restrict__ start, uint32_t* __restrict__ dense, uint32_t pad_log) {
     __shared__ uint32_t wsum[2][16];
     __shared__ uint32_t base[2];
-    hist_wg += (size_t)MSM_P * ng * nb;
     start += (size_t)MSM_P * (nb + 1);
     dense += (size_t)MSM_P * (nb + 1);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, pad = (1u << pad_log) - 1u;
     if (tid == 0) base[0] = base[1] = 0;
     __syncthreads();
+    uint32_t vn = tid < nb ? dense[tid] : 0u;  // (the next iteration's total is requested before this one's scan)
     for (uint32_t b0 = 0; b0 < nb; b0 += blockDim.x) {
         const uint32_t b = b0 + tid;
-        uint32_t v = 0;
-        if (b < nb)
-            // (sixteen loads in flight at a time: one after the other, a lone proof's 64 ranges x 32 768 buckets took 0.5 ms)
-            for (uint32_t w0 = 0; w0 < ng; w0 += 16) {
-                uint32_t h[16];
-#pragma unroll
-                for (uint32_t k = 0; k < 16; ++k) h[k] = w0 + k < ng ? hist_wg[(size_t)(w0 + k) * nb + b] : 0u;
-#pragma unroll
-                for (uint32_t k = 0; k < 16; ++k)
-                    if (w0 + k < ng) {
-                        hist_wg[(size_t)(w0 + k) * nb + b] = v;
-                        v += h[k];
-                    }
-            }
+        const uint32_t v = vn;
+        vn = b + blockDim.x < nb ? dense[b + blockDim.x] : 0u;
         const uint32_t pv = (v + pad) & ~pad;
         uint32_t x = v, px = pv;
 #pragma unroll

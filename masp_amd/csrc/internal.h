@@ -149,6 +149,18 @@ struct Slot {
     DevBuf<int> flags;
     MsmProfile prof;             // live HIP-event timing of k_msm_accumulate<G1> (bench roofline leg)
     bool profiling = false;
+    // where a LONE proof's chains end, without a profiler in the way (rocprofv3 adds ~10 us per launch, which reorders five chains of
+    // ~60 launches each): timing events recorded behind the stages of the last lone proof while profiling is on
+    // (masp_hip_profile_read_lone).  Created on first use.
+    static constexpr int N_LONE_MARKS = 12;
+    hipEvent_t ev_lone[N_LONE_MARKS] = {};
+    bool lone_marked = false;
+    void lone_mark(hipStream_t st, int id) {
+        if (!profiling) return;
+        if (!ev_lone[id] && hipEventCreate(&ev_lone[id]) != hipSuccess) return;
+        (void)hipEventRecord(ev_lone[id], st);
+        if (id == N_LONE_MARKS - 1) lone_marked = true;
+    }
     uint32_t ntt_sub = 8;        // masp_hip_options::ntt_sub_batch of the owning context (0 = whole batch)
     uint8_t* h_stage = nullptr;  // pinned staging for the assignment
     size_t h_stage_cap = 0;
@@ -185,6 +197,8 @@ struct Slot {
             if (aux[i]) hipStreamDestroy(aux[i]);
             if (ev_join[i]) hipEventDestroy(ev_join[i]);
         }
+        for (hipEvent_t e : ev_lone)
+            if (e) hipEventDestroy(e);
         if (ev_fork) hipEventDestroy(ev_fork);
         if (ev_sort_b) hipEventDestroy(ev_sort_b);
         if (ev_fixed) hipEventDestroy(ev_fixed);

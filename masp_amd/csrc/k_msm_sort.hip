@@ -25,7 +25,9 @@ int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb
     sb.ent_stride = MsmSortBuf::padded_entries(n, g, pad_log);
     const uint32_t ng = MsmSortBuf::ranges_for(n, np), nb = g.nb;
     // two-pass placement (runs instead of single scattered words): the row index must leave room for the 7 low bucket bits
-    const bool two_pass = nb >= MSM_FINE && (uint64_t)n * g.W <= (1u << 24);
+    // ... and the second pass is one workgroup per (proof, coarse bin): with too few of them (a lone proof's b_g2 on 8-bit windows: ONE,
+    // 0.57 ms for 600 000 entries) the single-pass scatter over the scalar ranges is the shorter chain
+    const bool two_pass = nb >= MSM_FINE && (uint64_t)n * g.W <= (1u << 24) && (uint64_t)(nb >> MSM_FINE_LOG) * np >= 8;
     const int part_lds = 4 * (4 * 256 + 8 + (int)MSM_PART_TILE * g.W);
     static PerDeviceOnce once;
     const bool lds_ok = once([] {
@@ -40,7 +42,8 @@ int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb
         return MASP_HIP_E_HIP;
     }
     MASP_LAUNCH(k_msm_hist, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg);
-    MASP_LAUNCH(k_msm_offsets, dim3(1, np), dim3(1024), 0, s, sb.hist_wg, ng, nb, sb.start, sb.dense, pad_log);
+    MASP_LAUNCH(k_msm_offsets_cols, dim3((nb + 255) / 256, np), dim3(256), 0, s, sb.hist_wg, ng, nb, sb.dense);
+    MASP_LAUNCH(k_msm_offsets_scan, dim3(1, np), dim3(1024), 0, s, nb, sb.start, sb.dense, pad_log);
     if (two_pass && g.W <= 32) {
         const uint32_t nbins = nb >> MSM_FINE_LOG;
         MASP_LAUNCH(k_msm_coarse, dim3(nbins, np), dim3(128), 0, s, sb.hist_wg, ng, nb, sb.crel);

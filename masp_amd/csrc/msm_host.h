@@ -203,14 +203,15 @@ struct MsmWorkspace {
     uint32_t *heavy = nullptr, *n_heavy = nullptr;
     Xyzz<O>*part = nullptr, *bkt = nullptr, *S[2] = {nullptr, nullptr}, *T = nullptr, *R[2] = {nullptr, nullptr};
     Xyzz<O>* tsum = nullptr;
+    Xyzz<O>* hparts = nullptr;  // [min(np, 7)][MSM_HEAVY_SLOTS]: the shares of a lone proof's heavy buckets
 
     ~MsmWorkspace() { release(); }
     void release() {
-        void* ptrs[] = {heavy, n_heavy, part, bkt, S[0], S[1], T, R[0], R[1], tsum, startT};
+        void* ptrs[] = {heavy, n_heavy, part, bkt, S[0], S[1], T, R[0], R[1], tsum, startT, hparts};
         for (void* p : ptrs)
             if (p) dev_free(p);
         heavy = n_heavy = startT = nullptr;
-        part = bkt = S[0] = S[1] = T = R[0] = R[1] = tsum = nullptr;
+        part = bkt = S[0] = S[1] = T = R[0] = R[1] = tsum = hparts = nullptr;
         cap_nb = cap_np = cap_part = 0;
     }
     // lanes of the accumulation kernel per proof: ~2^18 across the whole batch.  Fewer, longer chunks mean fewer
@@ -253,6 +254,7 @@ struct MsmWorkspace {
             HIP_TRY(dev_malloc(&R[1], P * sizeof(Xyzz<O>) * chunks));
             HIP_TRY(dev_malloc(&tsum, P * sizeof(Xyzz<O>) * 32));
             HIP_TRY(dev_malloc(&startT, P * 4 * (need_nb + 1)));
+            HIP_TRY(dev_malloc(&hparts, std::min<size_t>(P, 7) * sizeof(Xyzz<O>) * MSM_HEAVY_SLOTS));
             return MASP_HIP_OK;
         };
         if (int rc = alloc_all()) {

@@ -11,6 +11,9 @@ namespace masp {
 #ifndef MASP_G2_PAIR_TAILS
 #define MASP_G2_PAIR_TAILS 1
 #endif
+#ifndef MASP_G2_OCT_LONE
+#define MASP_G2_OCT_LONE 1
+#endif
 template <class O>
 struct TailLaneOps {
     typedef typename std::conditional<(MASP_G2_PAIR_TAILS) != 0 && std::is_same<O, Fp2Ops>::value, Fp2PairOps, O>::type type;
@@ -68,11 +71,12 @@ void MsmWorkspace<O>::reduce_to_one_lanes(hipStream_t s, uint32_t np, const Xyzz
         int flip = 0;
         const Xyzz<O>* cur = src;
         size_t cur_stride = src_stride;
+        constexpr uint32_t PTS = reduce_lanes_points<OT>();
         while (true) {
-            uint32_t outn = (m + 255) / 256;
+            uint32_t outn = (m + PTS - 1) / PTS;
             Xyzz<O>* out = outn == 1 ? dst : R[flip];
             size_t out_stride = outn == 1 ? dst_stride : r_stride;
-            MASP_LAUNCH((k_xyzz_reduce_block_lanes<OT>), dim3(outn, np), dim3(256 * OT::LANES), 256 * sizeof(Xyzz<O>), s, cur, cur_stride, m, out, out_stride);
+            MASP_LAUNCH((k_xyzz_reduce_block_lanes<OT>), dim3(outn, np), dim3(PTS * OT::LANES), PTS * sizeof(Xyzz<O>), s, cur, cur_stride, m, out, out_stride);
             if (outn == 1) break;
             cur = out;
             cur_stride = out_stride;
@@ -94,12 +98,21 @@ void msm_tails_enqueue(hipStream_t s, MsmWorkspace<O>& ws, const uint32_t* start
                        ws.n_heavy, lone ? 12u : 8u);
     if (lone) {
         const uint32_t heavy_blocks = std::min<uint32_t>(std::max<uint32_t>(4096u / np, 16u), nb) | 1u;
-        MASP_LAUNCH((k_msm_bucket_heavy<OT, MASP_LONE_HEAVY_THREADS>), dim3(heavy_blocks, np), dim3(MASP_LONE_HEAVY_THREADS), 0, s, ws.part, start, nb,
-                    nchunks, ws.bkt, ws.heavy, ws.n_heavy);
+        if constexpr (OT::REPLICATED) {
+            // (the lone forms: every heavy bucket shared by MSM_HEAVY_SPLIT workgroups, then joined)
+            MASP_LAUNCH((k_msm_bucket_heavy<OT, MASP_LONE_HEAVY_THREADS, MSM_HEAVY_SPLIT>), dim3(heavy_blocks * MSM_HEAVY_SPLIT, np), dim3(MASP_LONE_HEAVY_THREADS), 0, s,
+                        ws.part, start, nb, nchunks, ws.bkt, ws.heavy, ws.n_heavy, ws.hparts);
+            constexpr uint32_t PER = 64 / (LN * MSM_HEAVY_SPLIT);
+            const uint32_t joinable = std::min<uint32_t>(nb, MSM_HEAVY_SLOTS / MSM_HEAVY_SPLIT);
+            MASP_LAUNCH((k_msm_heavy_join<OT, MSM_HEAVY_SPLIT>), dim3((joinable + PER - 1) / PER, np), dim3(64), 0, s, ws.hparts, ws.heavy, ws.n_heavy, nb, ws.bkt);
+        } else {
+            MASP_LAUNCH((k_msm_bucket_heavy<OT, MASP_LONE_HEAVY_THREADS>), dim3(heavy_blocks, np), dim3(MASP_LONE_HEAVY_THREADS), 0, s, ws.part, start, nb,
+                        nchunks, ws.bkt, ws.heavy, ws.n_heavy, (Xyzz<O>*)nullptr);
+        }
     } else {
         const uint32_t heavy_blocks = std::min<uint32_t>(64u, nb) | 1u;
         MASP_LAUNCH((k_msm_bucket_heavy<OT, 64>), dim3(heavy_blocks, np), dim3(64), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy,
-                           ws.n_heavy);
+                           ws.n_heavy, (Xyzz<O>*)nullptr);
     }
     // weighted sum by levels of (G x 128)-bucket workgroups.  Per lane the kernel costs 2 G additions for its buckets plus
     // ~19 for the two lane scans: a batch takes the largest G in {8 .. 64} that still fills one workgroup (2 048 buckets: 16,
@@ -119,11 +132,16 @@ void msm_tails_enqueue(hipStream_t s, MsmWorkspace<O>& ws, const uint32_t* start
     int level = 0, flip = 0;
     do {
         uint32_t chunks = (m + cs - 1) / cs;
-        const dim3 grid(chunks, np), block(WSUM_L * LN);
+        const dim3 grid(chunks, np), block((1u << wsum_points_log<OT>()) * LN);
         switch (g_log) {
 #define MASP_WSUM_CASE(GL) \
     case GL: MASP_LAUNCH((k_msm_wsum_level<OT, GL>), grid, block, 0, s, bk, bk_stride, m, off, ws.S[flip], ws.T, st_stride); break;
-            MASP_WSUM_CASE(0) MASP_WSUM_CASE(2) MASP_WSUM_CASE(3) MASP_WSUM_CASE(4) MASP_WSUM_CASE(5) MASP_WSUM_CASE(6)
+            MASP_WSUM_CASE(0) MASP_WSUM_CASE(2)
+            default:
+                if constexpr (OT::LANES <= 2) {  // (the replicated forms only serve lone proofs: g_log 0 or WSUM_G_LOG_MIN)
+                    switch (g_log) { MASP_WSUM_CASE(3) MASP_WSUM_CASE(4) MASP_WSUM_CASE(5) MASP_WSUM_CASE(6) }
+                }
+                break;
 #undef MASP_WSUM_CASE
         }
         if constexpr (OT::REPLICATED)
@@ -144,6 +162,9 @@ void msm_tails_enqueue(hipStream_t s, MsmWorkspace<O>& ws, const uint32_t* start
 }
 #ifndef MASP_TAILS_QUAD_UNIT
 extern template void msm_tails_enqueue<FpOps, FpQuadOps>(hipStream_t, MsmWorkspace<FpOps>&, const uint32_t*, uint32_t, uint32_t, uint32_t, bool, Xyzz<FpOps>*, size_t);
+#endif
+#ifndef MASP_TAILS_OCT_UNIT
+extern template void msm_tails_enqueue<Fp2Ops, Fp2OctOps>(hipStream_t, MsmWorkspace<Fp2Ops>&, const uint32_t*, uint32_t, uint32_t, uint32_t, bool, Xyzz<Fp2Ops>*, size_t);
 #endif
 
 template <class O, int BYTES>
@@ -242,7 +263,11 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
         else
             msm_tails_enqueue<O, FpOps>(s, ws, start, nb, nchunks, np, lone, d_out, out_stride);
     } else {
-        msm_tails_enqueue<O, typename TailLaneOps<O>::type>(s, ws, start, nb, nchunks, np, lone, d_out, out_stride);
+        // ... and its G2 tails over groups of four lane pairs (device/oct.cuh)
+        if (lone && (MASP_G2_OCT_LONE))
+            msm_tails_enqueue<O, Fp2OctOps>(s, ws, start, nb, nchunks, np, lone, d_out, out_stride);
+        else
+            msm_tails_enqueue<O, typename TailLaneOps<O>::type>(s, ws, start, nb, nchunks, np, lone, d_out, out_stride);
     }
     return launch_status();  // (a launch the runtime refused: MASP_LAUNCH, util.h)
 }

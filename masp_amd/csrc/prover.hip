@@ -50,6 +50,7 @@ static masp_hip_options resolve_options(const masp_hip_options* in) {
     o.bucket_tree_scratch_mb = std::max(o.bucket_tree_scratch_mb, 0);
     o.bucket_tree_fallback_proofs = 0;   // output only
     o.hw_queues = 0;                     // output only (measured when a device context is created)
+    o.window_bits_h_lone = o.window_bits_h_lone > 0 ? std::min<int>(o.window_bits_h_lone, 16) : 0;   // resolved: 0 = as window_bits_h
     o.lone_proof_graph = o.lone_proof_graph > 0 ? 1 : 0;   // off unless asked for: measured slower with ROCm 7.2's graph launch
     return o;
 }
@@ -201,6 +202,7 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
     if (lone) {
         // lone-proof mode: L, A, B1 and B2 only read the assignment (already on the device when this stream gets here), so
         // their streams fork NOW, before the range check and the SpMV are queued on the main stream
+        sl.lone_mark(s, 0);
         HIP_TRY(hipEventRecord(sl.ev_fork, s));
         for (int i = 0; i < Slot::N_AUX; ++i) HIP_TRY(hipStreamWaitEvent(sl.aux[i], sl.ev_fork, 0));
     }
@@ -249,7 +251,9 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
             int r;
             if (C.na) launch_gather_scalars(sl.aux[1], d_w, w_stride, C.a_var.p, C.na, sl.sa.p, np);
             if ((r = msm_enqueue(sl.aux[1], C.a, sl.ws_a, (const uint32_t*)sl.sa.p, (size_t)C.na * 8, sl.res1.p + 2, 4, np))) return r;
+            sl.lone_mark(sl.aux[1], 1);
             launch_groth16_var_mul(sl.aux[1], 0, sl.res1.p, d_rs, 16, sl.asm1.p, np, C.g1_endo);
+            sl.lone_mark(sl.aux[1], 2);
             return MASP_HIP_OK;
         };
         auto chain_b = [&]() -> int {
@@ -263,7 +267,9 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
             } else if ((r = msm_enqueue(sl.aux[2], C.b1, sl.ws_b, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res1.p + 3, 4, np))) {
                 return r;
             }
+            sl.lone_mark(sl.aux[2], 3);
             launch_groth16_var_mul(sl.aux[2], 1, sl.res1.p, d_rs, 16, sl.asm1.p, np, C.g1_endo);
+            sl.lone_mark(sl.aux[2], 4);
             HIP_TRY(hipStreamWaitEvent(sl.aux[3], sl.ev_sort_b, 0));
             if (own_b2) {
                 if ((r = msm_enqueue(sl.aux[3], C.b2_lone, sl.ws2, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res2.p, 1, np))) return r;
@@ -272,17 +278,25 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
             } else if ((r = msm_enqueue(sl.aux[3], C.b2, sl.ws2, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res2.p, 1, np))) {
                 return r;
             }
+            sl.lone_mark(sl.aux[3], 5);
             HIP_TRY(hipStreamWaitEvent(sl.aux[3], sl.ev_fixed, 0));
             launch_groth16_finish_b(sl.aux[3], C.vk.p, sl.asm2.p, sl.res2.p, d_proof, np);
+            sl.lone_mark(sl.aux[3], 6);
             return MASP_HIP_OK;
         };
         auto chain_l = [&]() -> int {
             return msm_enqueue(sl.aux[0], C.l, sl.ws_l, (const uint32_t*)(d_w + C.n_inputs), w_stride * 8, sl.res1.p + 1, 4, np);
         };
+        // (measured and dropped in round 5: the quotient first with the side chains' chip-filling kernels gated behind it — the quotient
+        // then ends at 0.8 instead of 1.3 ms and MSM h, which now shares the chip with four accumulations, 0.3 ms LATER: a lone proof is
+        // ~2.5 ms of chip-filling work, its chains can only trade places: profiles/r05_lone_proof_chains.txt)
         if ((rc = chain_a()) || (rc = chain_b())) return rc;
         if ((rc = enqueue_quotient(sl, *C.dom, in, C.nrows, C.nrows, mont_in, np))) return rc;
+        sl.lone_mark(s, 7);
         if ((rc = msm_enqueue(s, C.h, sl.ws1, (const uint32_t*)sl.h.p, m8, sl.res1.p + 0, 4, np, prof))) return rc;
+        sl.lone_mark(s, 8);
         if ((rc = chain_l())) return rc;
+        sl.lone_mark(sl.aux[0], 9);
         // g_a / g_c need L, s*A and r*B1 (aux[0..2]); g_b finishes on aux[3] by itself and is only joined before the proof leaves
         for (int i = 0; i < Slot::N_AUX - 1; ++i) {
             HIP_TRY(hipEventRecord(sl.ev_join[i], sl.aux[i]));
@@ -319,8 +333,10 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
     }
     launch_groth16_finish_ac(s, C.vk.p, sl.asm1.p, sl.res1.p, d_proof, np);
     if (lone) {
+        sl.lone_mark(s, 10);   // g_a / g_c written
         HIP_TRY(hipEventRecord(sl.ev_join[Slot::N_AUX - 1], sl.aux[Slot::N_AUX - 1]));
         HIP_TRY(hipStreamWaitEvent(s, sl.ev_join[Slot::N_AUX - 1], 0));
+        sl.lone_mark(s, 11);   // ... and g_b: the proof is complete
     }
     return MASP_HIP_OK;
 }
@@ -776,7 +792,9 @@ int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* param
     // h has uniform scalars: 16-bit windows from 48 k points (Spend 131 071, Convert 65 535), 15 bits below (Output 32 767)
     const uint32_t n_h = (uint32_t)(C->m - 1);
     const int c_h = ctx->opt.window_bits_h ? ctx->opt.window_bits_h : n_h >= 49152 ? 16 : n_h >= 16384 ? 15 : 0;
-    if ((rc = C->h.load_host(L.h, (uint32_t)(C->m - 1), s, 0xffffffffu, c_h)) || (rc = C->l.load_host(L.l, L.n_l, s, eff(L.n_l), c_la)) ||
+    // (h's own table serves lone proofs only: its window width is theirs to choose — masp_hip_options::window_bits_h_lone)
+    const int c_h_lone = ctx->opt.window_bits_h_lone ? ctx->opt.window_bits_h_lone : c_h;
+    if ((rc = C->h.load_host(L.h, (uint32_t)(C->m - 1), s, 0xffffffffu, c_h_lone)) || (rc = C->l.load_host(L.l, L.n_l, s, eff(L.n_l), c_la)) ||
         (rc = C->a.load_host(L.a, L.n_a, s, eff(L.n_a), c_la)) || (rc = C->b1.load_host(L.b_g1, L.n_b1, s, eff(L.n_b1), c_b)) ||
         (rc = C->b2.load_host(L.b_g2, L.n_b2, s, eff(L.n_b2), c_b)))
         return fail(ctx, rc);
@@ -789,7 +807,7 @@ int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* param
         std::vector<uint8_t> cat(96 * (nh + L.n_l));
         memcpy(cat.data(), L.h, 96 * nh);
         memcpy(cat.data() + 96 * nh, L.l, 96 * (size_t)L.n_l);
-        if ((rc = C->hl.load_host(cat.data(), (uint32_t)(nh + L.n_l), s, 0xffffffffu, C->h.g.c))) return fail(ctx, rc);
+        if ((rc = C->hl.load_host(cat.data(), (uint32_t)(nh + L.n_l), s, 0xffffffffu, c_h ? c_h : ctx->opt.window_bits_h_lone ? 0 : C->h.g.c))) return fail(ctx, rc);
     }
     int st = C->h.import_status | C->l.import_status | C->a.import_status | C->b1.import_status | C->b2.import_status;
     if (st) return MASP_HIP_E_PARAMS_FORMAT;  // includes infinity inside a query vector, which bellman rejects
@@ -1426,6 +1444,25 @@ int masp_hip_profile_read_split(masp_hip_ctx* ctx, double ms[8]) {
         for (int i = 0; i < MsmProfile::PH_N; ++i) ms[i] += sl->prof.split_ms[i];
     }
     return MASP_HIP_OK;
+}
+
+int masp_hip_profile_read_lone(masp_hip_ctx* ctx, double ms[12]) {
+    if (!ctx || !ms) return MASP_HIP_E_INVALID_ARG;
+    ctx = FIRST_DEVICE(ctx);
+    std::unique_lock<std::shared_mutex> lock(ctx->mu);
+    hipSetDevice(ctx->device);
+    hipDeviceSynchronize();
+    for (int i = 0; i < Slot::N_LONE_MARKS; ++i) ms[i] = -1.0;
+    for (auto& sl : ctx->slots) {
+        if (!sl->lone_marked || !sl->ev_lone[0]) continue;
+        for (int i = 0; i < Slot::N_LONE_MARKS; ++i) {
+            float t = 0;
+            if (sl->ev_lone[i] && hipEventElapsedTime(&t, sl->ev_lone[0], sl->ev_lone[i]) == hipSuccess) ms[i] = t;
+        }
+        (void)hipGetLastError();
+        return MASP_HIP_OK;
+    }
+    return MASP_HIP_E_INVALID_ARG;   // no lone proof has run with profiling on
 }
 
 void* masp_hip_host_alloc(masp_hip_ctx* ctx, size_t bytes) {

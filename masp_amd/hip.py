@@ -21,13 +21,13 @@ class MaspHipError(RuntimeError):
 
 
 OPTION_FIELDS = ("slots", "batch_cap", "ntt_sub_batch", "window_bits_h", "window_bits_la", "window_bits_b", "window_bits_b2_lone",
-                 "witness_nontrivial_percent", "bucket_tree_levels", "bucket_tree_sub_batch", "bucket_tree_levels_g2", "bucket_tree_scratch_mb", "lone_proof_graph")
+                 "witness_nontrivial_percent", "bucket_tree_levels", "bucket_tree_sub_batch", "bucket_tree_levels_g2", "bucket_tree_scratch_mb", "lone_proof_graph", "window_bits_h_lone")
 
 
 class OptionsStruct(C.Structure):
     """masp_hip_options (include/masp_hip.h): every field 0 = the default."""
-    _fields_ = ([("struct_size", C.c_uint32)] + [(f, C.c_int32) for f in OPTION_FIELDS[:-1]] +
-                [("bucket_tree_fallback_proofs", C.c_int32), ("lone_proof_graph", C.c_int32), ("hw_queues", C.c_int32)])
+    _fields_ = ([("struct_size", C.c_uint32)] + [(f, C.c_int32) for f in OPTION_FIELDS[:-2]] +
+                [("bucket_tree_fallback_proofs", C.c_int32), ("lone_proof_graph", C.c_int32), ("hw_queues", C.c_int32), ("window_bits_h_lone", C.c_int32)])
 
 
 class JobStruct(C.Structure):
@@ -108,6 +108,8 @@ def load_library():
     L.masp_hip_profile_enable.argtypes = [vp, C.c_int]
     L.masp_hip_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.masp_hip_profile_read_split.argtypes = [vp, C.POINTER(C.c_double)]
+    if hasattr(L, "masp_hip_profile_read_lone"):
+        L.masp_hip_profile_read_lone.argtypes = [vp, C.POINTER(C.c_double)]
     L.masp_hip_sync.argtypes = [vp]
     L.masp_hip_host_alloc.argtypes = [vp, sz]
     L.masp_hip_host_alloc.restype = vp
@@ -407,6 +409,14 @@ class Context:
         ms = (C.c_double * 8)()
         self._check(self._L.masp_hip_profile_read_split(self._h, ms))
         return dict(zip(("plan_records_copies", "k_tree_pass1", "k_binv", "k_tree_pass2", "k_msm_accumulate_pts"), [float(x) for x in ms[:5]]))
+
+    LONE_MARKS = ("start", "msm_a", "s_A", "msm_b1", "r_B1", "msm_b2", "g_b", "quotient", "msm_h", "msm_l", "g_a_g_c", "complete")
+
+    def profile_read_lone(self):
+        """masp_hip_profile_read_lone: where the chains of the last lone proof ended (ms of GPU time, HIP events) -> dict by mark"""
+        ms = (C.c_double * 12)()
+        self._check(self._L.masp_hip_profile_read_lone(self._h, ms))
+        return {k: round(float(v), 3) for k, v in zip(self.LONE_MARKS, ms)}
 
     def profile_read(self):
         """-> (summed k_msm_accumulate<G1> ms, launches, algorithmic bytes)"""
