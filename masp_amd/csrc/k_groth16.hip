@@ -25,6 +25,12 @@ void launch_groth16_finish_b(hipStream_t s, const VkDevice* vk, const G2Xyzz* pa
 void launch_groth16_finish_ac(hipStream_t s, const VkDevice* vk, const G1Xyzz* part, const G1Xyzz* msm_g1, uint8_t* proof, uint32_t np) {
     MASP_LAUNCH(k_groth16_finish_ac, dim3(np), dim3(128), 0, s, vk, part, msm_g1, proof);
 }
+void launch_groth16_finish_ac_early(hipStream_t s, const VkDevice* vk, G1Xyzz* part, const G1Xyzz* msm_g1, uint8_t* proof, uint32_t np) {
+    MASP_LAUNCH(k_groth16_finish_ac_early, dim3(np), dim3(128), 0, s, vk, part, msm_g1, proof);
+}
+void launch_groth16_finish_c_late(hipStream_t s, const G1Xyzz* part, const G1Xyzz* msm_g1, uint8_t* proof, uint32_t np) {
+    MASP_LAUNCH(k_groth16_finish_c_late, dim3(np), dim3(64), 0, s, part, msm_g1, proof);
+}
 void launch_g1_export(hipStream_t s, const G1Xyzz* p, uint8_t* out) { MASP_LAUNCH(k_g1_export, dim3(1), dim3(1), 0, s, p, out); }
 void launch_g2_export(hipStream_t s, const G2Xyzz* p, uint8_t* out) { MASP_LAUNCH(k_g2_export, dim3(1), dim3(1), 0, s, p, out); }
 void launch_g1_import_one(hipStream_t s, const uint8_t* raw, G1Affine* out, int* status) {

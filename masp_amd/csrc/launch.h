@@ -43,6 +43,8 @@ void launch_groth16_var_mul(hipStream_t s, int which, const G1Xyzz* msm_g1, cons
 void launch_g1_subgroup_flag(hipStream_t s, const void* pts, size_t stride_bytes, uint32_t n, int* flag);
 void launch_groth16_finish_b(hipStream_t s, const VkDevice* vk, const G2Xyzz* part2, const G2Xyzz* msm_g2, uint8_t* proof, uint32_t np);
 void launch_groth16_finish_ac(hipStream_t s, const VkDevice* vk, const G1Xyzz* part, const G1Xyzz* msm_g1, uint8_t* proof, uint32_t np);
+void launch_groth16_finish_ac_early(hipStream_t s, const VkDevice* vk, G1Xyzz* part, const G1Xyzz* msm_g1, uint8_t* proof, uint32_t np);
+void launch_groth16_finish_c_late(hipStream_t s, const G1Xyzz* part, const G1Xyzz* msm_g1, uint8_t* proof, uint32_t np);
 void launch_g1_export(hipStream_t s, const G1Xyzz* p, uint8_t* out);
 void launch_g2_export(hipStream_t s, const G2Xyzz* p, uint8_t* out);
 void launch_g1_import_one(hipStream_t s, const uint8_t* raw, G1Affine* out, int* status);

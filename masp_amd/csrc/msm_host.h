@@ -185,6 +185,9 @@ struct MsmTreeWs {
 };
 
 // ---- workspace of the group arithmetic ---------------------------------------------------------------
+#ifndef MASP_LONE_CHUNKS_PER_BUCKET
+#define MASP_LONE_CHUNKS_PER_BUCKET 8
+#endif
 template <class O>
 struct MsmWorkspace {
     static constexpr uint32_t CS_LOG = WSUM_G_LOG_MIN + WSUM_L_LOG;   // smallest weighted-sum chunk (buckets per workgroup): sizes S / T
@@ -227,7 +230,7 @@ struct MsmWorkspace {
         // ... except with so few buckets (a lone proof's B2 on 8-bit windows) that every bucket goes to the heavy-bucket
         // workgroups anyway: there a lane's chunk is a chain of dependent additions on an otherwise idle chip, so the digit
         // list is cut into one full round of waves
-        if (np < 8) lanes = g.nb <= 256 ? std::max<uint64_t>((1u << MASP_LONE_NARROW_LANES_LOG) / np, 1u << 13) : std::min<uint64_t>(lanes, std::max<uint64_t>(8ull * g.nb, 1u << 13));
+        if (np < 8) lanes = g.nb <= 256 ? std::max<uint64_t>((1u << MASP_LONE_NARROW_LANES_LOG) / np, 1u << 13) : std::min<uint64_t>(lanes, std::max<uint64_t>((uint64_t)(MASP_LONE_CHUNKS_PER_BUCKET) * g.nb, 1u << 13));
         return (uint32_t)std::min<uint64_t>(std::min<uint64_t>(lanes, NCHUNKS), std::max<uint64_t>(ent, 1));
     }
     // room for `np` proofs of an n-point MSM with geometry g (every per-proof array is np-fold)

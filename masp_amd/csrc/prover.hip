@@ -297,11 +297,16 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
         sl.lone_mark(s, 8);
         if ((rc = chain_l())) return rc;
         sl.lone_mark(sl.aux[0], 9);
-        // g_a / g_c need L, s*A and r*B1 (aux[0..2]); g_b finishes on aux[3] by itself and is only joined before the proof leaves
-        for (int i = 0; i < Slot::N_AUX - 1; ++i) {
+        // g_a and all of g_c but H need L, s*A and r*B1 (aux[0..2]): summed on aux[0] behind those chains, while H is still being
+        // computed (k_groth16_finish_ac_early); the main stream joins aux[0] and adds H.  g_b finishes on aux[3] by itself and is only
+        // joined before the proof leaves
+        for (int i = 1; i < Slot::N_AUX - 1; ++i) {
             HIP_TRY(hipEventRecord(sl.ev_join[i], sl.aux[i]));
-            HIP_TRY(hipStreamWaitEvent(s, sl.ev_join[i], 0));
+            HIP_TRY(hipStreamWaitEvent(sl.aux[0], sl.ev_join[i], 0));
         }
+        launch_groth16_finish_ac_early(sl.aux[0], C.vk.p, sl.asm1.p, sl.res1.p, d_proof, np);
+        HIP_TRY(hipEventRecord(sl.ev_join[0], sl.aux[0]));
+        HIP_TRY(hipStreamWaitEvent(s, sl.ev_join[0], 0));
     } else {
         // H and L as one MSM over the merged base set (Circuit::hl): the scalars of a proof are its m - 1 quotient coefficients
         // followed by its aux assignment (the quotient's m-th, unused, coefficient lands on the first aux slot and is then
@@ -331,7 +336,10 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
                 launch_groth16_var_mul(s, 2, sl.res1.p, d_rs, 16, sl.asm1.p, np, C.g1_endo);
         launch_groth16_finish_b(s, C.vk.p, sl.asm2.p, sl.res2.p, d_proof, np);
     }
-    launch_groth16_finish_ac(s, C.vk.p, sl.asm1.p, sl.res1.p, d_proof, np);
+    if (lone)
+        launch_groth16_finish_c_late(s, sl.asm1.p, sl.res1.p, d_proof, np);
+    else
+        launch_groth16_finish_ac(s, C.vk.p, sl.asm1.p, sl.res1.p, d_proof, np);
     if (lone) {
         sl.lone_mark(s, 10);   // g_a / g_c written
         HIP_TRY(hipEventRecord(sl.ev_join[Slot::N_AUX - 1], sl.aux[Slot::N_AUX - 1]));
