@@ -4,6 +4,10 @@ import sys
 
 import pytest
 
+# The HIP runtime reads GPU_MAX_HW_QUEUES once, at the process's first HIP call — which in this process may be a test-side HIP unit
+# (tests/native) loaded before libmasp_hip.so: say it here (round 5: the contexts' measured masp_hip_options::hw_queues showed the whole
+# GPU suite running on the runtime's default of four)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
