@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <mutex>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "../../include/masp_hip.h"
 
@@ -59,31 +61,51 @@ inline std::atomic<uint64_t>& device_alloc_epoch() {
 // busy, 1.1 - 1.8 s in a mixed job list (`profiles/r04e_mixed_calls_timing.txt`).  So a released buffer only goes on a list; the
 // list is emptied where waiting costs nothing — when the last busy slot of a context is released, when a context is destroyed —
 // and when an allocation fails for lack of memory.  What lingers in between is bounded by the buffers' earlier, smaller sizes.
+// One list per DEVICE (round 5): with one process-global list an idle release on one device context called hipFree — and its
+// device-wide wait — on buffers of OTHER devices that were in the middle of a batch.  A buffer goes on the list of the device that is
+// current when it is released (every library call sets its context's device first); dev_free_drain() empties the current device's list.
 struct DevGraveyard {
     std::mutex mu;
-    std::vector<void*> v;
+    std::vector<std::pair<int, void*>> v;  // (device, buffer)
 };
 inline DevGraveyard& dev_graveyard() {
     static DevGraveyard* g = new DevGraveyard;  // (never destroyed: buffers are released from static destructors too)
     return *g;
 }
+inline int dev_current() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) {
+        (void)hipGetLastError();
+        d = 0;
+    }
+    return d;
+}
 inline void dev_free_drain() {
-    std::vector<void*> v;
+    const int dev = dev_current();
+    std::vector<void*> mine;
     {
         std::lock_guard<std::mutex> g(dev_graveyard().mu);
-        v.swap(dev_graveyard().v);
+        auto& v = dev_graveyard().v;
+        size_t k = 0;
+        for (size_t i = 0; i < v.size(); ++i)
+            if (v[i].first == dev)
+                mine.push_back(v[i].second);
+            else
+                v[k++] = v[i];
+        v.resize(k);
     }
-    for (void* p : v) (void)hipFree(p);
+    for (void* p : mine) (void)hipFree(p);
 }
 template <class T>
 inline hipError_t dev_malloc(T** p, size_t bytes) {
     device_alloc_epoch().fetch_add(1, std::memory_order_relaxed);
     hipError_t e = hipMalloc(p, bytes);
     if (e == hipErrorOutOfMemory) {  // what was released but not yet returned to the device may be what is missing
-        bool any;
+        const int dev = dev_current();
+        bool any = false;
         {
             std::lock_guard<std::mutex> g(dev_graveyard().mu);
-            any = !dev_graveyard().v.empty();
+            for (auto& x : dev_graveyard().v) any = any || x.first == dev;
         }
         if (any) {
             (void)hipGetLastError();
@@ -95,8 +117,9 @@ inline hipError_t dev_malloc(T** p, size_t bytes) {
 }
 inline hipError_t dev_free(void* p) {
     device_alloc_epoch().fetch_add(1, std::memory_order_relaxed);
+    const int dev = dev_current();
     std::lock_guard<std::mutex> g(dev_graveyard().mu);
-    dev_graveyard().v.push_back(p);
+    dev_graveyard().v.push_back({dev, p});
     return hipSuccess;
 }
 // hipFuncSetAttribute applies to the CURRENT device: a process that proves on several GPUs (masp_hip_ctx_create_multi, one
