@@ -14,7 +14,24 @@ for slot, kind in enumerate(("spend", "output", "convert")):
     params = ctx.generate_parameters(cs, synthetic.toxic_waste(1 + slot))
     ctx.load_circuit(slot, params, cs)
     (inputs, aux), = W.instances(kind, 1, first_seed=3, montgomery=True, alloc=lambda k: ctx.host_alloc(cs.n_aux, 32))
-    arr, n, keep = ctx.marshal_jobs([(slot, inputs, aux, 1234567, 7654321, None, 1)])
+    arr, n, keep = ctx.marshal_jobs([(slot, inputs, aux, 0x5a3c2b1d0e0f1a2b3c4d5e6f708192a3b4c5d6e7f8091a2b3c4d5e6f70819203 if os.environ.get('LONE_SMALL_RS') is None else 1234567,
+                                     0x1f2e3d4c5b6a79880796a5b4c3d2e1f00f1e2d3c4b5a69788796a5b4c3d2e1f0 if os.environ.get('LONE_SMALL_RS') is None else 7654321, None, 1)])
+    if os.environ.get("LONE_VK"):
+        vk = ctx.prepare_verifying_key(params)
+    if os.environ.get("LONE_RESIDENT"):
+        import numpy as np
+        insts = W.instances(kind, 256, first_seed=50, montgomery=True, alloc=lambda k: ctx.host_alloc(cs.n_aux, 32))
+        jobs = [(slot, i, a, 5 + k, 6 + k, None, 1) for k, (i, a) in enumerate(insts)]
+        handle, _ = ctx.batch_upload(jobs)
+        rs = np.zeros((4, 256, 64), np.uint8); rs[:, :, 0] = 3; rs[:, :, 32] = 5
+        ctx.batch_prove_resident_steps(handle, 256, 4, rs)
+    if os.environ.get("LONE_AFTER_BATCHES"):
+        # what bench.py has done by the time it measures a lone proof: batches of 256 on every slot
+        from concurrent.futures import ThreadPoolExecutor
+        big, nb_, keep2 = ctx.marshal_jobs([(slot, inputs, aux, 1000 + k, 2000 + k, None, 1) for k in range(256)])
+        with ThreadPoolExecutor(3) as ex:
+            list(ex.map(lambda _: ctx.prove_marshalled(big, 256), range(int(os.environ["LONE_AFTER_BATCHES"]))))
+        time.sleep(float(os.environ.get("LONE_SLEEP", "0")))
     lat = []
     for _ in range(16):
         t0 = time.perf_counter()

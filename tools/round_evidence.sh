@@ -6,7 +6,7 @@ tag=${1:-evidence}
 o=gpurun_out/$tag
 mkdir -p $o
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > $o/gpu_tests.txt
-python bench.py --steps 20 --warmup 2 > $o/bench_default_20_steps.json 2> $o/bench.err
+python bench.py --steps 20 --warmup 5 > $o/bench_driver_flags_steps20_warmup5.json 2> $o/bench.err
 PROF_ARGS="--steps 2 --warmup 1 --no-cpu-baseline" bash tools/prof_run.sh ${tag}_slots1 MASP_HIP_SLOTS=1 > $o/prof_slots1.log 2>&1
 cp gpurun_out/prof_${tag}_slots1/all.txt $o/kernel_stats_one_slot_serialized_all_dispatches.txt
 db=$(find gpurun_out/prof_${tag}_slots1 -name "*.db" | head -1)
@@ -19,4 +19,4 @@ rm -rf gpurun_out/pmc_sqk
 bash tools/build_tools.sh > /dev/null 2>&1
 tools/_build/ubench > $o/instruction_rates_and_products_ubench.txt 2>&1
 tools/_build/ntt_ubench > $o/ntt_ubench.txt 2>&1
-cat $o/gpu_tests.txt; tail -c 300 $o/bench_default_20_steps.json; ls -la $o
+cat $o/gpu_tests.txt; tail -c 300 $o/bench_driver_flags_steps20_warmup5.json; ls -la $o
