@@ -124,6 +124,15 @@ typedef struct {
                                         proofs use — a batch runs h and l as one MSM over the merged table on window_bits_h.  Narrower
                                         windows mean more additions in the chip-filling accumulation and far fewer buckets in the
                                         latency-bound tails a lone proof waits for.  Default: see resolve_options (prover.hip) */
+    int32_t digit_recoding;          /* (round 5, appended) 1: the base sets a batch runs over (h + l merged, a, b_g1, b_g2) take width-(c + 1)
+                                        non-adjacent-form digits — odd, as many buckets as c-bit windows (the window_bits_* fields keep naming
+                                        the BUCKETS: 2^(bits - 1)), 14.7 instead of 16 entries per scalar of h + l, 18.6 instead of 22 per
+                                        non-trivial witness scalar — over a table of 2^t P for EVERY bit position t (256 x n rows per base
+                                        set: 16.6 GB for the Spend circuit).  Default 0: signed fixed windows, a table per window.  Measured:
+                                        random 128-byte rows arrive at 6.5 TB/s from tables of up to 3 GiB and at 1.8 TB/s from 4 GiB on (the
+                                        reach of an XCD's L2 TLB: with each XCD gathering from its own eighth of a 17 GiB table the rate is
+                                        back at 6.3 TB/s, tools/gather_tlb_ubench.hip), so the fewer additions cost more than they save where
+                                        the tables are large: Spend -8 %, Convert -2.5 %, Output (2.3 GB of tables) +2 % proofs/s */
 } masp_hip_options;
 void masp_hip_options_default(masp_hip_options* opt);
 /* The HIP runtime gives a process four hardware queues unless GPU_MAX_HW_QUEUES says otherwise, and reads the variable ONCE, at the
@@ -193,8 +202,10 @@ size_t masp_hip_parameters_max_size(const masp_hip_r1cs* cs);
 int masp_hip_msm_g1(masp_hip_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[96]);
 int masp_hip_msm_g2(masp_hip_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[192]);
 /* np MSMs over ONE set of n G1 bases, launched the way a batch of proofs launches them (one kernel sequence,
- * gridDim.y = np): scalars np x n x 32, out np x 96.  window_bits: 0 = chosen from n, else 2..16 (the prover uses 16 for
- * the h query and 12 for the witness queries).  Exists so that the batched code path can be checked on its own. */
+ * gridDim.y = np): scalars np x n x 32, out np x 96.  window_bits: 0 = chosen from n, else 2..16 (the prover's buckets: 16 for
+ * the h query and 12 for the witness queries), or MASP_HIP_MSM_NAF | w for width-w NAF digits, w = 4..17, over a table per bit position
+ * (masp_hip_options::digit_recoding; 2^(w-2) buckets).  Exists so that the batched code path can be checked on its own. */
+#define MASP_HIP_MSM_NAF 0x100
 int masp_hip_msm_g1_multi(masp_hip_ctx* ctx, const uint8_t* bases, size_t n, const uint8_t* scalars, size_t np, int window_bits,
                           uint8_t* out);
 /* the same over G2 (bases n x 192, out np x 192) */

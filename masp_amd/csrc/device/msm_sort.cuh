@@ -20,28 +20,63 @@ namespace masp {
 //                  entry with one LDS atomic.
 // Scalars equal to 1 (a third of a MASP witness: booleans) all land in bucket 0 of window 0; a wave counts / places them
 // with one ballot instead of 64 colliding atomics.  Zero scalars (38 %) produce nothing.
-// scalars: n x 8 canonical little-endian limbs.  sorted entry = table row (j*n + i) | sign << 31.
+// scalars: n x 8 canonical little-endian limbs.  sorted entry = table row (t*n + i) | sign << 31, t = the table of the digit: window j
+// (fixed windows) / bit position (NAF).
 struct MsmDigitIter {
     const uint32_t* sw;
-    uint32_t carry, mask, half;
-    int c;
-    __device__ __forceinline__ MsmDigitIter(const uint32_t* sw_, int c_) : sw(sw_), carry(0), mask((1u << c_) - 1u), half(1u << (c_ - 1)), c(c_) {}
-    // digit of window j (call with j = 0, 1, 2, ... in order); false if it is zero
-    __device__ __forceinline__ bool next(int j, uint32_t& bucket, uint32_t& neg) {
-        int bit = j * c;
-        int w = bit >> 5, off = bit & 31;
-        // (re-read from L1/L2 instead of indexing a register array dynamically)
-        uint64_t two = ((uint64_t)(w + 1 < 8 ? sw[w + 1] : 0u) << 32) | sw[w];
-        uint32_t v = ((uint32_t)(two >> off) & mask) + carry;
+    uint32_t carry, mask, half, pos, j;
+    int c, naf;
+    __device__ __forceinline__ MsmDigitIter(const uint32_t* sw_, const MsmGeom& g)
+        : sw(sw_), carry(0), mask((1u << g.c) - 1u), half(1u << (g.c - 1)), pos(0), j(0), c(g.c), naf(g.naf) {}
+    // 32 bits of the scalar from bit `bit` on, zeros beyond bit 255 (re-read from L1/L2 instead of indexing a register array dynamically)
+    __device__ __forceinline__ uint32_t bits(uint32_t bit) const {
+        const uint32_t w = bit >> 5, off = bit & 31u;
+        if (w >= 8) return 0u;
+        const uint64_t two = ((uint64_t)(w + 1 < 8 ? sw[w + 1] : 0u) << 32) | sw[w];
+        return (uint32_t)(two >> off);
+    }
+    // The next digit.  Fixed windows: call W times, window after window; false = this window's digit is zero.  NAF: false = no digit
+    // is left (every later call says so again).  table: which table of the base set the digit's row lies in.
+    __device__ __forceinline__ bool next(uint32_t& table, uint32_t& bucket, uint32_t& neg) {
+        if (!naf) {
+            uint32_t v = (bits(pos) & mask) + carry;
+            table = j++;
+            pos += (uint32_t)c;
+            neg = 0;
+            carry = 0;
+            if (v > half) {
+                v = (1u << c) - v;
+                neg = 1;
+                carry = 1;
+            }
+            bucket = v - 1;
+            return v != 0;
+        }
+        // width-c NAF from the low end: skip to the next position whose bit (with the carry of the last negative digit) is set; the c
+        // bits from there are the digit, taken negative (and carried into position + c) if they are above 2^(c-1).  The carry does not
+        // change while positions are skipped: it either still waits in front of a zero bit or has run through ones up to here.
+        while (pos < 256) {
+            const uint32_t v = bits(pos) + carry;  // (wraps: 0xffffffff + 1 = 0 — 32 more positions without a digit, the carry travels on)
+            if (v == 0) {
+                pos += 32;
+                continue;
+            }
+            pos += (uint32_t)__ffs((int)v) - 1u;
+            break;
+        }
+        if (pos >= 256) return false;
+        uint32_t u = (bits(pos) & mask) + carry;  // odd, below 2^c
+        table = pos;
+        pos += (uint32_t)c;
         neg = 0;
         carry = 0;
-        if (v > half) {
-            v = (1u << c) - v;
+        if (u > half) {
+            u = (1u << c) - u;
             neg = 1;
             carry = 1;
         }
-        bucket = v - 1;
-        return v != 0;
+        bucket = u >> 1;  // |digit| = 2 bucket + 1
+        return true;
     }
 };
 // 0: zero, 1: one, 2: anything else
@@ -69,10 +104,13 @@ k_msm_hist(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32_t 
         if (cls == 1) {
             if ((uint32_t)__ffsll((unsigned long long)ones) - 1u == (tid & 63u)) atomicAdd(&msm_lds[0], (uint32_t)__popcll(ones));
         } else if (cls == 2) {
-            MsmDigitIter it(sw, g.c);
+            MsmDigitIter it(sw, g);
             for (int j = 0; j < g.W; ++j) {
-                uint32_t bucket, neg;
-                if (it.next(j, bucket, neg)) atomicAdd(&msm_lds[bucket], 1u);
+                uint32_t table, bucket, neg;
+                if (it.next(table, bucket, neg))
+                    atomicAdd(&msm_lds[bucket], 1u);
+                else if (g.naf)
+                    break;
             }
         }
     }
@@ -182,10 +220,13 @@ k_msm_scatter(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32
             if (cls == 1) sorted[first + (uint32_t)__popcll(ones & ((1ull << (tid & 63u)) - 1ull))] = i;  // window 0: row i, positive
         }
         if (cls == 2) {
-            MsmDigitIter it(sw, g.c);
+            MsmDigitIter it(sw, g);
             for (int j = 0; j < g.W; ++j) {
-                uint32_t bucket, neg;
-                if (it.next(j, bucket, neg)) sorted[atomicAdd(&msm_lds[bucket], 1u)] = ((uint32_t)j * n + i) | (neg << 31);
+                uint32_t table, bucket, neg;
+                if (it.next(table, bucket, neg))
+                    sorted[atomicAdd(&msm_lds[bucket], 1u)] = (table * n + i) | (neg << 31);
+                else if (g.naf)
+                    break;
             }
         }
     }
@@ -200,7 +241,8 @@ k_msm_scatter(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32
 //                    sorted by bin inside LDS first (count, scan, place), then copied out bin by bin: runs of ~64 entries.
 //   k_msm_bucketize  (one workgroup per proof and bin)  the bin's entries -> their buckets, again through an LDS-sorted
 //                    tile of 4096 entries: runs of ~32 entries.
-// Between the two, an entry carries its bucket's low 7 bits:  row (24 bits) | fine << 24 | sign << 31.
+// Between the two, the low 7 bits of an entry's bucket travel in a byte array of their own (`tmpf`, next to `tmp`): a table row takes
+// up to 31 bits (a base set with a table per bit position has 256 x n rows), so the entry word has no room for them.
 static constexpr uint32_t MSM_FINE_LOG = 7, MSM_FINE = 1u << MSM_FINE_LOG;
 static constexpr uint32_t MSM_PART_TILE = 1024;   // scalars per tile of k_msm_partition (= threads)
 static constexpr uint32_t MSM_BKT_TILE = 4096;    // entries per tile of k_msm_bucketize
@@ -259,7 +301,7 @@ __device__ __forceinline__ void msm_small_scan(const uint32_t* cnt, uint32_t* of
 }
 __global__ void __launch_bounds__(1024)
 k_msm_partition(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32_t n, MsmGeom g, uint32_t ng, const uint32_t* __restrict__ crel,
-                const uint32_t* __restrict__ start /* packed offsets: MsmSortBuf::dense */, uint32_t* __restrict__ tmp) {
+                const uint32_t* __restrict__ start /* packed offsets: MsmSortBuf::dense */, uint32_t* __restrict__ tmp, uint8_t* __restrict__ tmpf) {
     extern __shared__ uint32_t msm_lds[];
     const uint32_t tid = threadIdx.x, wg = blockIdx.x, nb = (uint32_t)g.nb, nbins = nb >> MSM_FINE_LOG;
     uint32_t* cursor = msm_lds;            // [256] global position of the next entry of each bin from this workgroup
@@ -269,10 +311,12 @@ k_msm_partition(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint
     uint32_t* total = fill + 256;          // [1] (+3 pad)
     uint32_t* wsum = total + 4;            // [4]
     uint32_t* stage = wsum + 4;            // [MSM_PART_TILE * W]
+    uint8_t* stagef = reinterpret_cast<uint8_t*>(stage + MSM_PART_TILE * (uint32_t)g.W);  // [MSM_PART_TILE * W]
     scalars += MSM_P * scalar_stride;
     crel += ((size_t)MSM_P * ng + wg) * nbins;
     start += (size_t)MSM_P * (nb + 1);
     tmp += (size_t)MSM_P * n * g.W;
+    tmpf += (size_t)MSM_P * n * g.W;
     if (tid < nbins) cursor[tid] = start[tid << MSM_FINE_LOG] + crel[tid];
     const uint32_t per = (n + ng - 1) / ng, lo = wg * per, hi = lo + per < n ? lo + per : n;
     for (uint32_t base = lo; base < hi; base += MSM_PART_TILE) {
@@ -284,25 +328,25 @@ k_msm_partition(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint
         const uint64_t ones = __ballot(cls == 1);
         const int leader = ones ? __ffsll((unsigned long long)ones) - 1 : -1;
         // ONE pass over the digits of a tile: the counting atomic already hands out the entry's rank inside its bin, the entry
-        // and (bin, rank) wait in registers for the scan of the counts (the digits were extracted and counted twice before)
-        uint32_t ent[32], key[32];
+        // and (rank, bin, low bucket bits) wait in registers for the scan of the counts (the digits were extracted and counted twice before)
+        uint32_t ent[32], key[32];  // key: rank (16 bits: at most 1024 x 32 entries per tile) | bin << 16 | low bucket bits << 24
         uint32_t unit_rank = 0;
-        if (ones) {  // unit scalars: window 0, bucket 0, positive
+        if (ones) {  // unit scalars: table 0, bucket 0, positive
             if ((int)(tid & 63u) == leader) unit_rank = atomicAdd(&cnt[0], (uint32_t)__popcll(ones));
             unit_rank = __shfl(unit_rank, leader, 64) + (uint32_t)__popcll(ones & ((1ull << (tid & 63u)) - 1ull));
         }
 #pragma unroll
         for (int j = 0; j < 32; ++j) key[j] = 0xffffffffu;
         if (cls == 2) {
-            MsmDigitIter it(sw, g.c);
+            MsmDigitIter it(sw, g);
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
                 if (j < g.W) {
-                    uint32_t bucket, neg;
-                    if (it.next(j, bucket, neg)) {
+                    uint32_t table, bucket, neg;
+                    if (it.next(table, bucket, neg)) {
                         const uint32_t B = bucket >> MSM_FINE_LOG;
-                        key[j] = (B << 20) | atomicAdd(&cnt[B], 1u);
-                        ent[j] = ((uint32_t)j * n + i) | ((bucket & (MSM_FINE - 1u)) << 24) | (neg << 31);
+                        key[j] = atomicAdd(&cnt[B], 1u) | (B << 16) | ((bucket & (MSM_FINE - 1u)) << 24);
+                        ent[j] = (table * n + i) | (neg << 31);
                     }
                 }
             }
@@ -310,28 +354,38 @@ k_msm_partition(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint
         __syncthreads();
         msm_small_scan(cnt, off, fill, nbins, total, wsum);
         __syncthreads();
-        if (cls == 1) stage[off[0] + unit_rank] = i;
+        if (cls == 1) {
+            stage[off[0] + unit_rank] = i;
+            stagef[off[0] + unit_rank] = 0;
+        }
         if (cls == 2) {
 #pragma unroll
             for (int j = 0; j < 32; ++j)
-                if (key[j] != 0xffffffffu) stage[off[key[j] >> 20] + (key[j] & 0xfffffu)] = ent[j];
+                if (key[j] != 0xffffffffu) {
+                    const uint32_t at = off[(key[j] >> 16) & 0xffu] + (key[j] & 0xffffu);
+                    stage[at] = ent[j];
+                    stagef[at] = (uint8_t)(key[j] >> 24);
+                }
         }
         __syncthreads();
         const uint32_t tot = *total;
         for (uint32_t k = tid; k < tot; k += MSM_PART_TILE) {
             const uint32_t B = msm_find_run(off, nbins, k);
-            tmp[cursor[B] + (k - off[B])] = stage[k];
+            const uint32_t at = cursor[B] + (k - off[B]);
+            tmp[at] = stage[k];
+            tmpf[at] = stagef[k];
         }
         __syncthreads();
         if (tid < nbins) cursor[tid] += cnt[tid];
     }
 }
 __global__ void __launch_bounds__(1024)
-k_msm_bucketize(const uint32_t* __restrict__ tmp, size_t tmp_stride, const uint32_t* __restrict__ dense, const uint32_t* __restrict__ start, uint32_t nb,
-                uint32_t* __restrict__ sorted, size_t sorted_stride) {
+k_msm_bucketize(const uint32_t* __restrict__ tmp, const uint8_t* __restrict__ tmpf, size_t tmp_stride, const uint32_t* __restrict__ dense,
+                const uint32_t* __restrict__ start, uint32_t nb, uint32_t* __restrict__ sorted, size_t sorted_stride) {
     __shared__ uint32_t cur[MSM_FINE], cnt[MSM_FINE], off[MSM_FINE], fill[MSM_FINE], total[4], wsum[4], stage[MSM_BKT_TILE];
     const uint32_t tid = threadIdx.x, B = blockIdx.x;
     tmp += MSM_P * tmp_stride;
+    tmpf += MSM_P * tmp_stride;
     sorted += MSM_P * sorted_stride;
     start += (size_t)MSM_P * (nb + 1);
     dense += (size_t)MSM_P * (nb + 1);
@@ -340,24 +394,25 @@ k_msm_bucketize(const uint32_t* __restrict__ tmp, size_t tmp_stride, const uint3
     for (uint32_t base = lo; base < hi; base += MSM_BKT_TILE) {
         if (tid < MSM_FINE) cnt[tid] = 0;
         __syncthreads();
-        uint32_t e[MSM_BKT_TILE / 1024], rank[MSM_BKT_TILE / 1024];  // the counting atomic hands out the rank inside the bucket
+        uint32_t e[MSM_BKT_TILE / 1024], fr[MSM_BKT_TILE / 1024];  // fr: low bucket bits | rank << 8 (the counting atomic hands out the rank inside the bucket)
 #pragma unroll
         for (uint32_t q = 0; q < MSM_BKT_TILE / 1024; ++q) {
             const uint32_t k = base + q * 1024 + tid;
-            e[q] = k < hi ? tmp[k] : 0xffffffffu;
-            // (a bucket that holds most of a tile — the unit scalars' bucket 0 — is counted once per wave, not 64 times)
             const bool valid = k < hi;
-            const uint32_t f = (e[q] >> 24) & (MSM_FINE - 1u);
+            e[q] = valid ? tmp[k] : 0xffffffffu;
+            const uint32_t f = valid ? (uint32_t)tmpf[k] : 0u;
+            // (a bucket that holds most of a tile — the unit scalars' bucket 0 — is counted once per wave, not 64 times)
             const uint64_t same = __ballot(valid && f == 0);
-            rank[q] = 0;
+            uint32_t rank = 0;
             if (same) {
                 const int leader = __ffsll((unsigned long long)same) - 1;
                 uint32_t first = 0;
                 if ((int)(tid & 63u) == leader) first = atomicAdd(&cnt[0], (uint32_t)__popcll(same));
                 first = __shfl(first, leader, 64);
-                if (valid && f == 0) rank[q] = first + (uint32_t)__popcll(same & ((1ull << (tid & 63u)) - 1ull));
+                if (valid && f == 0) rank = first + (uint32_t)__popcll(same & ((1ull << (tid & 63u)) - 1ull));
             }
-            if (valid && f != 0) rank[q] = atomicAdd(&cnt[f], 1u);
+            if (valid && f != 0) rank = atomicAdd(&cnt[f], 1u);
+            fr[q] = f | (rank << 8);
         }
         __syncthreads();
         msm_small_scan(cnt, off, fill, MSM_FINE, total, wsum);
@@ -365,7 +420,7 @@ k_msm_bucketize(const uint32_t* __restrict__ tmp, size_t tmp_stride, const uint3
 #pragma unroll
         for (uint32_t q = 0; q < MSM_BKT_TILE / 1024; ++q) {
             const uint32_t k = base + q * 1024 + tid;
-            if (k < hi) stage[off[(e[q] >> 24) & (MSM_FINE - 1u)] + rank[q]] = e[q] & 0x80ffffffu;
+            if (k < hi) stage[off[fr[q] & 0xffu] + (fr[q] >> 8)] = e[q];
         }
         __syncthreads();
         const uint32_t tot = *total;

@@ -8,8 +8,12 @@ namespace masp {
 
 int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb, const uint32_t* d_scalars, size_t scalar_stride,
                                    uint32_t np, uint32_t pad_log) {
-    if (g.c < 2 || g.c > 16) {
-        last_hip_error() = "MSM window width must be 2..16 bits (the bucket histogram lives in LDS)";
+    if (g.c < 2 + 2 * g.naf || g.nb > (1 << 15)) {
+        last_hip_error() = "MSM digit width must be 2..16 bits (fixed windows) / 4..17 bits (NAF): the bucket histogram lives in LDS";
+        return MASP_HIP_E_INVALID_ARG;
+    }
+    if ((uint64_t)n * (uint32_t)g.tpos > 0x7ffffffeull) {
+        last_hip_error() = "msm_sort_enqueue: the base set has more table rows than an entry's 31 bits can name";
         return MASP_HIP_E_INVALID_ARG;
     }
     if (pad_log > 12) {
@@ -24,18 +28,19 @@ int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb
     sb.pad_log = pad_log;
     sb.ent_stride = MsmSortBuf::padded_entries(n, g, pad_log);
     const uint32_t ng = MsmSortBuf::ranges_for(n, np), nb = g.nb;
-    // two-pass placement (runs instead of single scattered words): the row index must leave room for the 7 low bucket bits
+    // two-pass placement (runs instead of single scattered words): the first pass stages a tile's entries (a word and a byte each) in LDS
     // ... and the second pass is one workgroup per (proof, coarse bin): with too few of them (a lone proof's b_g2 on 8-bit windows: ONE,
     // 0.57 ms for 600 000 entries) the single-pass scatter over the scalar ranges is the shorter chain
-    const bool two_pass = nb >= MSM_FINE && (uint64_t)n * g.W <= (1u << 24) && (uint64_t)(nb >> MSM_FINE_LOG) * np >= 8;
-    const int part_lds = 4 * (4 * 256 + 8 + (int)MSM_PART_TILE * g.W);
+    constexpr int PART_W_MAX = 30;  // 5 bytes x 1024 x 30 + the bins' counters = 154 KiB of the 160 KiB LDS
+    const bool two_pass = nb >= MSM_FINE && g.W <= PART_W_MAX && (uint64_t)(nb >> MSM_FINE_LOG) * np >= 8;
+    const int part_lds = 4 * (4 * 256 + 8) + 5 * (int)MSM_PART_TILE * g.W;
     static PerDeviceOnce once;
     const bool lds_ok = once([] {
         int bytes = 4 << 15;
         return hipFuncSetAttribute((const void*)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
                hipFuncSetAttribute((const void*)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
-               hipFuncSetAttribute((const void*)k_msm_partition, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (4 * 256 + 8 + (int)MSM_PART_TILE * 32)) ==
-                   hipSuccess;
+               hipFuncSetAttribute((const void*)k_msm_partition, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   4 * (4 * 256 + 8) + 5 * (int)MSM_PART_TILE * PART_W_MAX) == hipSuccess;
     });
     if (!lds_ok) {
         last_hip_error() = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
@@ -44,11 +49,11 @@ int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb
     MASP_LAUNCH(k_msm_hist, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg);
     MASP_LAUNCH(k_msm_offsets_cols, dim3((nb + 255) / 256, np), dim3(256), 0, s, sb.hist_wg, ng, nb, sb.dense);
     MASP_LAUNCH(k_msm_offsets_scan, dim3(1, np), dim3(1024), 0, s, nb, sb.start, sb.dense, pad_log);
-    if (two_pass && g.W <= 32) {
+    if (two_pass) {
         const uint32_t nbins = nb >> MSM_FINE_LOG;
         MASP_LAUNCH(k_msm_coarse, dim3(nbins, np), dim3(128), 0, s, sb.hist_wg, ng, nb, sb.crel);
-        MASP_LAUNCH(k_msm_partition, dim3(ng, np), dim3(MSM_PART_TILE), part_lds, s, d_scalars, scalar_stride, n, g, ng, sb.crel, sb.dense, sb.tmp);
-        MASP_LAUNCH(k_msm_bucketize, dim3(nbins, np), dim3(1024), 0, s, sb.tmp, (size_t)n * g.W, sb.dense, sb.start, nb, sb.sorted, sb.ent_stride);
+        MASP_LAUNCH(k_msm_partition, dim3(ng, np), dim3(MSM_PART_TILE), part_lds, s, d_scalars, scalar_stride, n, g, ng, sb.crel, sb.dense, sb.tmp, sb.tmpf);
+        MASP_LAUNCH(k_msm_bucketize, dim3(nbins, np), dim3(1024), 0, s, sb.tmp, sb.tmpf, (size_t)n * g.W, sb.dense, sb.start, nb, sb.sorted, sb.ent_stride);
     } else {
         // (the single-pass placement writes entries only: aligned runs get their padding from a fill first)
         if (pad_log) HIP_TRY(hipMemsetAsync(sb.sorted, 0xff, 4 * sb.ent_stride * np, s));

@@ -19,13 +19,13 @@
 #endif
 namespace masp {
 
-// ---- base set: T[j][i] = 2^(c j) P_i -------------------------------------------------------------
+// ---- base set: T[j][i] = 2^(c j) P_i (fixed windows) / T[t][i] = 2^t P_i for every bit position t (NAF digits: msm_geom.h) ------
 template <class O, int BYTES>
 struct MsmBases {
     MsmGeom g{};
     uint32_t n = 0;
     uint32_t n_eff = 0;        // scalars expected to be neither 0 nor 1 (<= n): the mean length of a bucket's run follows from it
-    TabRow<O>* tab = nullptr;  // W * n rows of 128 / 256 bytes
+    TabRow<O>* tab = nullptr;  // g.tpos * n rows of 128 / 256 bytes
     int import_status = 0;     // PT_* bits seen while decoding
 
     ~MsmBases() { release(); }
@@ -36,19 +36,21 @@ struct MsmBases {
     // Window width by the number of scalars expected to be neither 0 nor 1 (`n_eff`; the caller knows the witness
     // statistics of its circuit, a generic caller passes n): per non-trivial scalar the accumulation costs W = 256/c
     // mixed additions, per bucket the gather + weighted sum cost ~5.5 full additions.
-    static MsmGeom pick_geom(uint32_t n_eff) {
+    // naf: the same number of buckets with NAF digits of one bit more (msm_geom_naf) and a table per bit position.
+    static MsmGeom pick_geom(uint32_t n_eff, bool naf = false) {
         int c = n_eff >= (1u << 16) ? 16 : n_eff >= (1u << 12) ? 12 : n_eff >= (1u << 8) ? 10 : 7;
-        return msm_geom(c);
+        return naf ? msm_geom_naf(c + 1) : msm_geom(c);
     }
     // raw: device pointer to n uncompressed points (bellman wire format)          [msm_impl.cuh]
-    int load_device(const uint8_t* d_raw, uint32_t n_, hipStream_t s, uint32_t n_eff = 0xffffffffu, int force_c = 0);
-    int load_host(const uint8_t* raw, uint32_t n_, hipStream_t s, uint32_t n_eff = 0xffffffffu, int force_c = 0) {
+    // force_c: digit width (0: pick_geom); naf: NAF digits (force_c is then the NAF width: one more than the window with as many buckets)
+    int load_device(const uint8_t* d_raw, uint32_t n_, hipStream_t s, uint32_t n_eff = 0xffffffffu, int force_c = 0, bool naf = false);
+    int load_host(const uint8_t* raw, uint32_t n_, hipStream_t s, uint32_t n_eff = 0xffffffffu, int force_c = 0, bool naf = false) {
         uint8_t* d_raw = nullptr;
         if (n_) {
             HIP_TRY(dev_malloc(&d_raw, (size_t)n_ * BYTES));
             HIP_TRY(hipMemcpyAsync(d_raw, raw, (size_t)n_ * BYTES, hipMemcpyHostToDevice, s));
         }
-        int rc = load_device(d_raw, n_, s, n_eff, force_c);
+        int rc = load_device(d_raw, n_, s, n_eff, force_c, naf);
         if (d_raw) dev_free(d_raw);
         return rc;
     }
@@ -59,6 +61,7 @@ struct MsmSortBuf {
     size_t cap_ent = 0, cap_nb = 0, cap_np = 0, cap_hist = 0, cap_crel = 0;  // cap_hist, cap_crel: words
     uint32_t *sorted = nullptr, *hist_wg = nullptr, *start = nullptr;
     uint32_t *tmp = nullptr, *crel = nullptr;  // two-pass placement: entries grouped by coarse bin; per-range offsets of the bins
+    uint8_t* tmpf = nullptr;                   // ... and the low 7 bits of every such entry's bucket
     uint32_t* dense = nullptr;                 // [np][nb + 1] offsets without padding (where a bin lies in `tmp`)
     // what the last msm_sort_enqueue produced (consumed by msm_reduce_enqueue)
     uint32_t n = 0, np = 0;
@@ -78,10 +81,11 @@ struct MsmSortBuf {
 
     ~MsmSortBuf() { release(); }
     void release() {
-        void* ptrs[] = {sorted, hist_wg, start, tmp, crel, dense};
+        void* ptrs[] = {sorted, hist_wg, start, tmp, crel, dense, tmpf};
         for (void* p : ptrs)
             if (p) dev_free(p);
         sorted = hist_wg = start = tmp = crel = dense = nullptr;
+        tmpf = nullptr;
         cap_ent = cap_nb = cap_np = cap_hist = cap_crel = 0;
     }
     // scalar ranges (= sorting workgroups) per proof: enough to occupy the chip across the batch, not more
@@ -107,6 +111,7 @@ struct MsmSortBuf {
             HIP_TRY(dev_malloc(&hist_wg, 4 * need_hist));
             HIP_TRY(dev_malloc(&start, need_np * 4 * (need_nb + 1)));
             HIP_TRY(dev_malloc(&tmp, need_np * 4 * std::max<size_t>(need_ent, 1)));
+            HIP_TRY(dev_malloc(&tmpf, need_np * std::max<size_t>(need_ent, 1)));
             HIP_TRY(dev_malloc(&crel, 4 * need_crel));
             HIP_TRY(dev_malloc(&dense, need_np * 4 * (need_nb + 1)));
             return MASP_HIP_OK;
@@ -375,7 +380,7 @@ int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb
 inline uint32_t msm_tree_levels(uint32_t n_eff, const MsmGeom& g, uint32_t np, int opt) {
     if (np < 8 || opt < 0) return 0;  // a lone proof: latency regime, short chains matter more than total work
     if (opt > 0) return std::min<uint32_t>((uint32_t)opt, 12u);
-    const uint64_t mean = std::max<uint64_t>((uint64_t)std::max(n_eff, 1u) * g.W / g.nb, 1);
+    const uint64_t mean = std::max<uint64_t>((uint64_t)std::max(n_eff, 1u) * msm_mean_digits_x16(g) / 16 / g.nb, 1);
     uint32_t lg = 0;
     while (((uint64_t)1 << lg) < mean) ++lg;
     return std::min(4u, lg > 1 ? lg - 1 : 0u);

@@ -52,6 +52,10 @@ static masp_hip_options resolve_options(const masp_hip_options* in) {
     o.hw_queues = 0;                     // output only (measured when a device context is created)
     o.window_bits_h_lone = o.window_bits_h_lone > 0 ? std::min<int>(o.window_bits_h_lone, 16) : 0;   // resolved: 0 = as window_bits_h
     o.lone_proof_graph = o.lone_proof_graph > 0 ? 1 : 0;   // off unless asked for: measured slower with ROCm 7.2's graph launch
+    // 1 = NAF digits over per-bit tables for the base sets batches use.  Off unless asked for: 8 - 15 % fewer bucket entries, but the
+    // tables (16.6 GB for Spend) are beyond what an XCD's L2 TLB reaches (~3.5 GiB) and the gathers of the tree's level 0 then run at a
+    // quarter of their rate: -8 % Spend proofs/s, +2 % for Output, whose tables fit (profiles/r05_naf_digits_per_bit_tables_*.txt)
+    o.digit_recoding = o.digit_recoding > 0 ? 1 : 0;
     return o;
 }
 // [0, n) cut into ceil(n / cap) groups whose sizes differ by at most one: (first, count) pairs
@@ -232,7 +236,7 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
     if ((rc = sl.sa.reserve((size_t)C.na * np)) || (rc = sl.sb.reserve((size_t)C.nbq * np))) return rc;
     MsmProfile* prof = sl.profiling ? &sl.prof : nullptr;
     const size_t m8 = C.m * 8;
-    const bool share_b = C.nbq && C.b2.n == C.b1.n && C.b2.g.c == C.b1.g.c;  // B2 runs over the same scalars as B1
+    const bool share_b = C.nbq && C.b2.n == C.b1.n && C.b2.g.c == C.b1.g.c && C.b2.g.naf == C.b1.g.naf;  // B2 runs over the same scalars as B1
     if (lone) {
         // the four witness MSMs run on their own streams (forked above) while the main stream runs SpMV -> quotient -> H.
         // The pieces of the assembly start as soon as what they read exists: the fixed-base multiplications (r and s only)
@@ -802,9 +806,15 @@ int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* param
     const int c_h = ctx->opt.window_bits_h ? ctx->opt.window_bits_h : n_h >= 49152 ? 16 : n_h >= 16384 ? 15 : 0;
     // (h's own table serves lone proofs only: its window width is theirs to choose — masp_hip_options::window_bits_h_lone)
     const int c_h_lone = ctx->opt.window_bits_h_lone ? ctx->opt.window_bits_h_lone : c_h;
+    // Digits (masp_hip_options::digit_recoding = 1; default fixed windows): the base sets a BATCH runs over (h + l merged, a, b_g1, b_g2)
+    // take width-(c + 1) NAF digits over a table per bit position — as many buckets as c-bit windows, 8 % (h + l) to 15 % (the witness
+    // queries) fewer entries to add (device/msm_geom.h); the sets only lone proofs use (h, l, b_g2 on narrow windows) keep fixed windows
+    // and their compact tables.
+    const bool naf = ctx->opt.digit_recoding > 0;
+    auto nafw = [&](int c) { return c ? c + (naf ? 1 : 0) : 0; };
     if ((rc = C->h.load_host(L.h, (uint32_t)(C->m - 1), s, 0xffffffffu, c_h_lone)) || (rc = C->l.load_host(L.l, L.n_l, s, eff(L.n_l), c_la)) ||
-        (rc = C->a.load_host(L.a, L.n_a, s, eff(L.n_a), c_la)) || (rc = C->b1.load_host(L.b_g1, L.n_b1, s, eff(L.n_b1), c_b)) ||
-        (rc = C->b2.load_host(L.b_g2, L.n_b2, s, eff(L.n_b2), c_b)))
+        (rc = C->a.load_host(L.a, L.n_a, s, eff(L.n_a), nafw(c_la), naf)) || (rc = C->b1.load_host(L.b_g1, L.n_b1, s, eff(L.n_b1), nafw(c_b), naf)) ||
+        (rc = C->b2.load_host(L.b_g2, L.n_b2, s, eff(L.n_b2), nafw(c_b), naf)))
         return fail(ctx, rc);
     {
         const int c_lone = ctx->opt.window_bits_b2_lone;  // 0 = lone proofs share the batch tables (and B1's sort)
@@ -815,7 +825,8 @@ int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* param
         std::vector<uint8_t> cat(96 * (nh + L.n_l));
         memcpy(cat.data(), L.h, 96 * nh);
         memcpy(cat.data() + 96 * nh, L.l, 96 * (size_t)L.n_l);
-        if ((rc = C->hl.load_host(cat.data(), (uint32_t)(nh + L.n_l), s, 0xffffffffu, c_h ? c_h : ctx->opt.window_bits_h_lone ? 0 : C->h.g.c))) return fail(ctx, rc);
+        const int c_hl = c_h ? c_h : ctx->opt.window_bits_h_lone ? 0 : C->h.g.c;
+        if ((rc = C->hl.load_host(cat.data(), (uint32_t)(nh + L.n_l), s, 0xffffffffu, nafw(c_hl), naf))) return fail(ctx, rc);
     }
     int st = C->h.import_status | C->l.import_status | C->a.import_status | C->b1.import_status | C->b2.import_status;
     if (st) return MASP_HIP_E_PARAMS_FORMAT;  // includes infinity inside a query vector, which bellman rejects
@@ -1109,7 +1120,10 @@ int masp_hip_prove(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* inputs, cons
 // scalars np x n x 32 B, out np x BYTES uncompressed.  window_bits 0 = the engine's own choice for n.
 template <class O, int BYTES>
 static int msm_multi(masp_hip_ctx* ctx, const uint8_t* bases, size_t n, const uint8_t* scalars, size_t np, int window_bits, uint8_t* out) {
-    if (!ctx || !out || !np || np > 256 || !n || !bases || !scalars || n > (1u << 22) || window_bits < 0 || window_bits == 1 || window_bits > 16)
+    const bool naf = window_bits > 0 && (window_bits & MASP_HIP_MSM_NAF) != 0;
+    if (naf) window_bits &= ~MASP_HIP_MSM_NAF;
+    if (!ctx || !out || !np || np > 256 || !n || !bases || !scalars || n > (1u << 22) || window_bits < 0 || window_bits == 1 || window_bits > 16 + (naf ? 1 : 0) ||
+        (naf && window_bits < 4))
         return MASP_HIP_E_INVALID_ARG;
     if (!ctx->children.empty()) ctx = ctx->children[0];
     std::unique_lock<std::shared_mutex> lock(ctx->mu);
@@ -1134,7 +1148,7 @@ static int msm_multi(masp_hip_ctx* ctx, const uint8_t* bases, size_t n, const ui
     DevBuf<Xyzz<O>> res;
     DevBuf<uint8_t> d_out;
     int rc;
-    if ((rc = B.load_host(bases, (uint32_t)n, s, 0xffffffffu, window_bits))) return fail(ctx, rc);
+    if ((rc = B.load_host(bases, (uint32_t)n, s, 0xffffffffu, window_bits, naf))) return fail(ctx, rc);
     if (B.import_status & (PT_BAD_FLAGS | PT_NOT_CANONICAL)) return MASP_HIP_E_PARAMS_FORMAT;
     if ((rc = ctx->tmp_scalars.upload((const Fr*)scalars, n * np, s)) || (rc = res.reserve(np)) || (rc = d_out.reserve(BYTES * np))) return fail(ctx, rc);
     if ((rc = msm_enqueue(s, B, ws, (const uint32_t*)ctx->tmp_scalars.p, n * 8, res.p, 1, (uint32_t)np))) return fail(ctx, rc);

@@ -21,13 +21,14 @@ class MaspHipError(RuntimeError):
 
 
 OPTION_FIELDS = ("slots", "batch_cap", "ntt_sub_batch", "window_bits_h", "window_bits_la", "window_bits_b", "window_bits_b2_lone",
-                 "witness_nontrivial_percent", "bucket_tree_levels", "bucket_tree_sub_batch", "bucket_tree_levels_g2", "bucket_tree_scratch_mb", "lone_proof_graph", "window_bits_h_lone")
+                 "witness_nontrivial_percent", "bucket_tree_levels", "bucket_tree_sub_batch", "bucket_tree_levels_g2", "bucket_tree_scratch_mb", "lone_proof_graph", "window_bits_h_lone", "digit_recoding")
 
 
 class OptionsStruct(C.Structure):
     """masp_hip_options (include/masp_hip.h): every field 0 = the default."""
-    _fields_ = ([("struct_size", C.c_uint32)] + [(f, C.c_int32) for f in OPTION_FIELDS[:-2]] +
-                [("bucket_tree_fallback_proofs", C.c_int32), ("lone_proof_graph", C.c_int32), ("hw_queues", C.c_int32), ("window_bits_h_lone", C.c_int32)])
+    _fields_ = ([("struct_size", C.c_uint32)] + [(f, C.c_int32) for f in OPTION_FIELDS[:-3]] +
+                [("bucket_tree_fallback_proofs", C.c_int32), ("lone_proof_graph", C.c_int32), ("hw_queues", C.c_int32), ("window_bits_h_lone", C.c_int32),
+                 ("digit_recoding", C.c_int32)])
 
 
 class JobStruct(C.Structure):
@@ -37,6 +38,7 @@ class JobStruct(C.Structure):
 
 
 AUX_CANONICAL, AUX_MONTGOMERY = 0, 1     # masp_hip_job::aux_form
+MSM_NAF = 0x100                          # masp_hip_msm_g{1,2}_multi: window_bits = MSM_NAF | w (MASP_HIP_MSM_NAF)
 
 
 def library_path():
