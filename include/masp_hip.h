@@ -206,6 +206,7 @@ int masp_hip_msm_g2(masp_hip_ctx* ctx, const uint8_t* bases, const uint8_t* scal
  * the h query and 12 for the witness queries), or MASP_HIP_MSM_NAF | w for width-w NAF digits, w = 4..17, over a table per bit position
  * (masp_hip_options::digit_recoding; 2^(w-2) buckets).  Exists so that the batched code path can be checked on its own. */
 #define MASP_HIP_MSM_NAF 0x100
+#define MASP_HIP_MSM_REGIONS 0x200 /* with MASP_HIP_MSM_NAF: the table in one region per XCD, as the prover's batches use it */
 int masp_hip_msm_g1_multi(masp_hip_ctx* ctx, const uint8_t* bases, size_t n, const uint8_t* scalars, size_t np, int window_bits,
                           uint8_t* out);
 /* the same over G2 (bases n x 192, out np x 192) */

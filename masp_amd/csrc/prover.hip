@@ -326,11 +326,15 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
         if ((rc = msm_enqueue(s, C.hl, sl.ws1, (const uint32_t*)sl.hl.p, hl_stride * 8, sl.res1.p + 0, 4, np, prof))) return rc;
         // L is inside H + L: its slot of every proof is the point at infinity (one strided fill, not np of them)
         HIP_TRY(hipMemset2DAsync(sl.res1.p + 1, 4 * sizeof(G1Xyzz), 0, sizeof(G1Xyzz), np, s));
-        if ((rc = msm_enqueue(s, C.a, sl.ws1, (const uint32_t*)sl.sa.p, (size_t)C.na * 8, sl.res1.p + 2, 4, np, prof))) return rc;
-        if ((rc = msm_enqueue(s, C.b1, sl.ws1, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res1.p + 3, 4, np, prof))) return rc;
-        if (share_b) {
-            if ((rc = msm_reduce_enqueue(s, C.b2, sl.ws1.sort, sl.ws2, sl.res2.p, 1))) return rc;
-        } else if ((rc = msm_enqueue(s, C.b2, sl.ws2, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res2.p, 1, np))) {
+        // (masp_hip_options::digit_recoding = 1: the batch's own base sets — NAF digits, per-bit tables in regions)
+        const BasesG1 &Aq = C.a_naf.n ? C.a_naf : C.a, &B1q = C.b1_naf.n ? C.b1_naf : C.b1;
+        const BasesG2& B2q = C.b2_naf.n ? C.b2_naf : C.b2;
+        const bool share_bq = C.nbq && B2q.n == B1q.n && B2q.g.c == B1q.g.c && B2q.g.naf == B1q.g.naf && B2q.g.rg == B1q.g.rg;
+        if ((rc = msm_enqueue(s, Aq, sl.ws1, (const uint32_t*)sl.sa.p, (size_t)C.na * 8, sl.res1.p + 2, 4, np, prof))) return rc;
+        if ((rc = msm_enqueue(s, B1q, sl.ws1, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res1.p + 3, 4, np, prof))) return rc;
+        if (share_bq) {
+            if ((rc = msm_reduce_enqueue(s, B2q, sl.ws1.sort, sl.ws2, sl.res2.p, 1))) return rc;
+        } else if ((rc = msm_enqueue(s, B2q, sl.ws2, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res2.p, 1, np))) {
             return rc;
         }
     }
@@ -806,15 +810,19 @@ int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* param
     const int c_h = ctx->opt.window_bits_h ? ctx->opt.window_bits_h : n_h >= 49152 ? 16 : n_h >= 16384 ? 15 : 0;
     // (h's own table serves lone proofs only: its window width is theirs to choose — masp_hip_options::window_bits_h_lone)
     const int c_h_lone = ctx->opt.window_bits_h_lone ? ctx->opt.window_bits_h_lone : c_h;
-    // Digits (masp_hip_options::digit_recoding = 1; default fixed windows): the base sets a BATCH runs over (h + l merged, a, b_g1, b_g2)
-    // take width-(c + 1) NAF digits over a table per bit position — as many buckets as c-bit windows, 8 % (h + l) to 15 % (the witness
-    // queries) fewer entries to add (device/msm_geom.h); the sets only lone proofs use (h, l, b_g2 on narrow windows) keep fixed windows
-    // and their compact tables.
+    // Digits (masp_hip_options::digit_recoding = 1; default fixed windows): a BATCH runs its MSMs (h + l merged, a, b_g1, b_g2) on
+    // width-(c + 1) NAF digits over a table per bit position — as many buckets as c-bit windows, 8 % (h + l) to 15 % (the witness
+    // queries) fewer entries to add (device/msm_geom.h) —, the tables cut into one region per XCD; lone proofs keep fixed windows and
+    // their compact tables (h, l, a, b_g1, b_g2).
     const bool naf = ctx->opt.digit_recoding > 0;
-    auto nafw = [&](int c) { return c ? c + (naf ? 1 : 0) : 0; };
+    auto nafw = [&](int c) { return c ? c + 1 : 0; };
     if ((rc = C->h.load_host(L.h, (uint32_t)(C->m - 1), s, 0xffffffffu, c_h_lone)) || (rc = C->l.load_host(L.l, L.n_l, s, eff(L.n_l), c_la)) ||
-        (rc = C->a.load_host(L.a, L.n_a, s, eff(L.n_a), nafw(c_la), naf)) || (rc = C->b1.load_host(L.b_g1, L.n_b1, s, eff(L.n_b1), nafw(c_b), naf)) ||
-        (rc = C->b2.load_host(L.b_g2, L.n_b2, s, eff(L.n_b2), nafw(c_b), naf)))
+        (rc = C->a.load_host(L.a, L.n_a, s, eff(L.n_a), c_la)) || (rc = C->b1.load_host(L.b_g1, L.n_b1, s, eff(L.n_b1), c_b)) ||
+        (rc = C->b2.load_host(L.b_g2, L.n_b2, s, eff(L.n_b2), c_b)))
+        return fail(ctx, rc);
+    if (naf && ((rc = C->a_naf.load_host(L.a, L.n_a, s, eff(L.n_a), nafw(c_la), true, MSM_REGIONS)) ||
+                (rc = C->b1_naf.load_host(L.b_g1, L.n_b1, s, eff(L.n_b1), nafw(c_b), true, MSM_REGIONS)) ||
+                (rc = C->b2_naf.load_host(L.b_g2, L.n_b2, s, eff(L.n_b2), nafw(c_b), true, MSM_REGIONS))))
         return fail(ctx, rc);
     {
         const int c_lone = ctx->opt.window_bits_b2_lone;  // 0 = lone proofs share the batch tables (and B1's sort)
@@ -826,7 +834,7 @@ int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* param
         memcpy(cat.data(), L.h, 96 * nh);
         memcpy(cat.data() + 96 * nh, L.l, 96 * (size_t)L.n_l);
         const int c_hl = c_h ? c_h : ctx->opt.window_bits_h_lone ? 0 : C->h.g.c;
-        if ((rc = C->hl.load_host(cat.data(), (uint32_t)(nh + L.n_l), s, 0xffffffffu, nafw(c_hl), naf))) return fail(ctx, rc);
+        if ((rc = C->hl.load_host(cat.data(), (uint32_t)(nh + L.n_l), s, 0xffffffffu, naf ? nafw(c_hl) : c_hl, naf, naf ? MSM_REGIONS : 1))) return fail(ctx, rc);
     }
     int st = C->h.import_status | C->l.import_status | C->a.import_status | C->b1.import_status | C->b2.import_status;
     if (st) return MASP_HIP_E_PARAMS_FORMAT;  // includes infinity inside a query vector, which bellman rejects
@@ -1121,7 +1129,8 @@ int masp_hip_prove(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* inputs, cons
 template <class O, int BYTES>
 static int msm_multi(masp_hip_ctx* ctx, const uint8_t* bases, size_t n, const uint8_t* scalars, size_t np, int window_bits, uint8_t* out) {
     const bool naf = window_bits > 0 && (window_bits & MASP_HIP_MSM_NAF) != 0;
-    if (naf) window_bits &= ~MASP_HIP_MSM_NAF;
+    const bool regions = naf && (window_bits & MASP_HIP_MSM_REGIONS) != 0;
+    if (naf) window_bits &= ~(MASP_HIP_MSM_NAF | MASP_HIP_MSM_REGIONS);
     if (!ctx || !out || !np || np > 256 || !n || !bases || !scalars || n > (1u << 22) || window_bits < 0 || window_bits == 1 || window_bits > 16 + (naf ? 1 : 0) ||
         (naf && window_bits < 4))
         return MASP_HIP_E_INVALID_ARG;
@@ -1148,7 +1157,7 @@ static int msm_multi(masp_hip_ctx* ctx, const uint8_t* bases, size_t n, const ui
     DevBuf<Xyzz<O>> res;
     DevBuf<uint8_t> d_out;
     int rc;
-    if ((rc = B.load_host(bases, (uint32_t)n, s, 0xffffffffu, window_bits, naf))) return fail(ctx, rc);
+    if ((rc = B.load_host(bases, (uint32_t)n, s, 0xffffffffu, window_bits, naf, regions ? MSM_REGIONS : 1))) return fail(ctx, rc);
     if (B.import_status & (PT_BAD_FLAGS | PT_NOT_CANONICAL)) return MASP_HIP_E_PARAMS_FORMAT;
     if ((rc = ctx->tmp_scalars.upload((const Fr*)scalars, n * np, s)) || (rc = res.reserve(np)) || (rc = d_out.reserve(BYTES * np))) return fail(ctx, rc);
     if ((rc = msm_enqueue(s, B, ws, (const uint32_t*)ctx->tmp_scalars.p, n * 8, res.p, 1, (uint32_t)np))) return fail(ctx, rc);
