@@ -132,7 +132,10 @@ typedef struct {
                                         random 128-byte rows arrive at 6.5 TB/s from tables of up to 3 GiB and at 1.8 TB/s from 4 GiB on (the
                                         reach of an XCD's L2 TLB: with each XCD gathering from its own eighth of a 17 GiB table the rate is
                                         back at 6.3 TB/s, tools/gather_tlb_ubench.hip), so the fewer additions cost more than they save where
-                                        the tables are large: Spend -8 %, Convert -2.5 %, Output (2.3 GB of tables) +2 % proofs/s */
+                                        the tables are large: Spend -8 %, Convert -2.5 %, Output (2.3 GB of tables) +2 % proofs/s.  (Tables
+                                        cut into a region per XCD and level 0 of the bucket tree walked region by region were built and
+                                        measured too — profiles/r05_naf_digits_table_regions_per_xcd_rejected.txt, commit 5c2f854 — and
+                                        removed: the gathers recover, the stores of that level's results fragment) */
 } masp_hip_options;
 void masp_hip_options_default(masp_hip_options* opt);
 /* The HIP runtime gives a process four hardware queues unless GPU_MAX_HW_QUEUES says otherwise, and reads the variable ONCE, at the
@@ -206,7 +209,6 @@ int masp_hip_msm_g2(masp_hip_ctx* ctx, const uint8_t* bases, const uint8_t* scal
  * the h query and 12 for the witness queries), or MASP_HIP_MSM_NAF | w for width-w NAF digits, w = 4..17, over a table per bit position
  * (masp_hip_options::digit_recoding; 2^(w-2) buckets).  Exists so that the batched code path can be checked on its own. */
 #define MASP_HIP_MSM_NAF 0x100
-#define MASP_HIP_MSM_REGIONS 0x200 /* with MASP_HIP_MSM_NAF: the table in one region per XCD, as the prover's batches use it */
 int masp_hip_msm_g1_multi(masp_hip_ctx* ctx, const uint8_t* bases, size_t n, const uint8_t* scalars, size_t np, int window_bits,
                           uint8_t* out);
 /* the same over G2 (bases n x 192, out np x 192) */

@@ -42,7 +42,7 @@ namespace masp {
 // raw uncompressed bytes -> T[0][i]; status word collects PT_* bits (infinity is legal in a generic
 // MSM and contributes nothing).
 template <class O, int BYTES>
-__global__ void k_msm_import(const uint8_t* __restrict__ raw, TabRow<O>* __restrict__ tab, uint32_t n, int* __restrict__ status, MsmGeom g) {
+__global__ void k_msm_import(const uint8_t* __restrict__ raw, TabRow<O>* __restrict__ tab, uint32_t n, int* __restrict__ status) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Affine<O> p;
@@ -58,7 +58,7 @@ __global__ void k_msm_import(const uint8_t* __restrict__ raw, TabRow<O>* __restr
     } else if (st & PT_INFINITY) {
         atomicOr(status, PT_INFINITY);
     }
-    tab[msm_row(g, n, 0, i)].p = p;
+    tab[i].p = p;
 }
 // T[j][i] = 2^c * T[j-1][i]
 template <class O>
@@ -78,13 +78,12 @@ __global__ void __launch_bounds__(64) k_msm_precompute(TabRow<O>* __restrict__ t
 // XYZZ coordinates, made affine with ONE inversion (Montgomery's trick over the K values of ZZZ) — a base set of 231 568 points has
 // 59 million rows to write, an inversion per row would be 2 - 3 s of the load.
 template <class O, int K>
-__global__ void __launch_bounds__(64) k_msm_precompute_bits(TabRow<O>* __restrict__ tab, uint32_t n, MsmGeom g) {
+__global__ void __launch_bounds__(64) k_msm_precompute_bits(TabRow<O>* __restrict__ tab, uint32_t n, int tpos) {
     typedef typename O::T F;
     typedef typename O::Cold C;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int tpos = g.tpos;
-    Affine<O> p = tab[msm_row(g, n, 0, i)].p;
+    Affine<O> p = tab[i].p;
     for (int t = 1; t < tpos; t += K) {
         const int cnt = tpos - t < K ? tpos - t : K;
         Xyzz<O> q[K];
@@ -113,7 +112,7 @@ __global__ void __launch_bounds__(64) k_msm_precompute_bits(TabRow<O>* __restric
                 a.x = C::mul(q[k].X, C::sqr(zi));
                 a.y = C::mul(q[k].Y, zi3);
             }
-            if (k < cnt) tab[msm_row(g, n, (uint32_t)(t + k), i)].p = a;
+            if (k < cnt) tab[(size_t)(t + k) * n + i].p = a;
             if (k == cnt - 1) p = a;
         }
     }

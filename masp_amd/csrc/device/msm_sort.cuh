@@ -87,23 +87,6 @@ __device__ __forceinline__ int msm_scalar_class(const uint32_t* sw) {
     if (rest == 0 && lo.x <= 1) return (int)lo.x;
     return 2;
 }
-// The scalars workgroup `wg` of a proof's `ng` sorts: a contiguous range — or, for a base set whose table is cut into regions
-// (MsmGeom::rg = ng), the scalars of the points of region wg, i = wg (mod rg): entry k of it is scalar first + k * step.
-struct MsmRange {
-    uint32_t cnt, first, step;
-    __device__ __forceinline__ MsmRange(uint32_t n, uint32_t ng, uint32_t wg, int rg) {
-        if (rg > 1) {
-            step = (uint32_t)rg;
-            first = wg;
-            cnt = n > wg ? (n - wg + step - 1u) / step : 0u;
-        } else {
-            const uint32_t per = (n + ng - 1) / ng, lo = wg * per, hi = lo + per < n ? lo + per : n;
-            step = 1;
-            first = lo;
-            cnt = hi > lo ? hi - lo : 0u;
-        }
-    }
-};
 __global__ void __launch_bounds__(1024)
 k_msm_hist(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32_t n, MsmGeom g, uint32_t ng, uint32_t* __restrict__ hist_wg) {
     extern __shared__ uint32_t msm_lds[];
@@ -112,12 +95,11 @@ k_msm_hist(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32_t 
     hist_wg += ((size_t)MSM_P * ng + wg) * nb;
     for (uint32_t b = tid; b < nb; b += MSM_SORT_THREADS) msm_lds[b] = 0;
     __syncthreads();
-    const MsmRange rng(n, ng, wg, g.rg);
-    for (uint32_t base = 0; base < rng.cnt; base += MSM_SORT_THREADS) {
-        const bool valid = base + tid < rng.cnt;
-        const uint32_t i = valid ? rng.first + (base + tid) * rng.step : 0u;
+    const uint32_t per = (n + ng - 1) / ng, lo = wg * per, hi = lo + per < n ? lo + per : n;
+    for (uint32_t base = lo; base < hi; base += MSM_SORT_THREADS) {
+        const uint32_t i = base + tid;
         const uint32_t* sw = scalars + (size_t)i * 8;
-        const int cls = valid ? msm_scalar_class(sw) : 0;
+        const int cls = i < hi ? msm_scalar_class(sw) : 0;
         const uint64_t ones = __ballot(cls == 1);
         if (cls == 1) {
             if ((uint32_t)__ffsll((unsigned long long)ones) - 1u == (tid & 63u)) atomicAdd(&msm_lds[0], (uint32_t)__popcll(ones));
@@ -142,17 +124,13 @@ k_msm_hist(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32_t 
 //   k_msm_offsets_cols  grid (nb / 256, np): one lane per bucket walks the ranges (sixteen loads in flight), leaves the bucket's
 //                       total in dense[b]
 //   k_msm_offsets_scan  one workgroup per proof: exclusive scans of the totals and of the padded totals, 1 024 buckets at a time
-// rg > 1 (table regions, one scalar range per region): a bucket's run keeps its entries region by region, each region's share padded to
-// an even length — start[] counts that padding too (the total comes here in start[b], k_msm_offsets_scan rounds it up to 2^pad_log).
 __global__ void __launch_bounds__(256)
-k_msm_offsets_cols(uint32_t* __restrict__ hist_wg, uint32_t ng, uint32_t nb, uint32_t* __restrict__ dense, uint32_t* __restrict__ start, int rg) {
+k_msm_offsets_cols(uint32_t* __restrict__ hist_wg, uint32_t ng, uint32_t nb, uint32_t* __restrict__ dense) {
     hist_wg += (size_t)MSM_P * ng * nb;
     dense += (size_t)MSM_P * (nb + 1);
-    start += (size_t)MSM_P * (nb + 1);
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
-    const uint32_t sub_pad = rg > 1 ? 1u : 0u;
-    uint32_t v = 0, vp = 0;
+    uint32_t v = 0;
     for (uint32_t w0 = 0; w0 < ng; w0 += 16) {
         uint32_t h[16];
 #pragma unroll
@@ -162,11 +140,9 @@ k_msm_offsets_cols(uint32_t* __restrict__ hist_wg, uint32_t ng, uint32_t nb, uin
             if (w0 + k < ng) {
                 hist_wg[(size_t)(w0 + k) * nb + b] = v;
                 v += h[k];
-                vp += (h[k] + sub_pad) & ~sub_pad;
             }
     }
     dense[b] = v;
-    start[b] = vp;
 }
 __global__ void __launch_bounds__(1024)
 k_msm_offsets_scan(uint32_t nb, uint32_t* __restrict__ start, uint32_t* __restrict__ dense, uint32_t pad_log) {
@@ -177,12 +153,12 @@ k_msm_offsets_scan(uint32_t nb, uint32_t* __restrict__ start, uint32_t* __restri
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, pad = (1u << pad_log) - 1u;
     if (tid == 0) base[0] = base[1] = 0;
     __syncthreads();
-    uint32_t vn = tid < nb ? dense[tid] : 0u, pn = tid < nb ? start[tid] : 0u;  // (the next iteration's totals are requested before this one's scan)
+    uint32_t vn = tid < nb ? dense[tid] : 0u;  // (the next iteration's total is requested before this one's scan)
     for (uint32_t b0 = 0; b0 < nb; b0 += blockDim.x) {
         const uint32_t b = b0 + tid;
-        const uint32_t v = vn, pv = (pn + pad) & ~pad;
+        const uint32_t v = vn;
         vn = b + blockDim.x < nb ? dense[b + blockDim.x] : 0u;
-        pn = b + blockDim.x < nb ? start[b + blockDim.x] : 0u;
+        const uint32_t pv = (v + pad) & ~pad;
         uint32_t x = v, px = pv;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -221,49 +197,34 @@ k_msm_offsets_scan(uint32_t nb, uint32_t* __restrict__ start, uint32_t* __restri
 }
 __global__ void __launch_bounds__(1024)
 k_msm_scatter(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32_t n, MsmGeom g, uint32_t ng, const uint32_t* __restrict__ rel,
-              const uint32_t* __restrict__ start, const uint32_t* __restrict__ dense, uint32_t* __restrict__ sorted, size_t sorted_stride) {
+              const uint32_t* __restrict__ start, uint32_t* __restrict__ sorted, size_t sorted_stride) {
     extern __shared__ uint32_t msm_lds[];
     const uint32_t tid = threadIdx.x, wg = blockIdx.x, nb = (uint32_t)g.nb;
     scalars += MSM_P * scalar_stride;
-    rel += (size_t)MSM_P * ng * nb;
+    rel += ((size_t)MSM_P * ng + wg) * nb;
     start += (size_t)MSM_P * (nb + 1);
-    dense += (size_t)MSM_P * (nb + 1);
     sorted += (size_t)MSM_P * sorted_stride;
-    for (uint32_t b = tid; b < nb; b += MSM_SORT_THREADS) {
-        uint32_t at = rel[(size_t)wg * nb + b];
-        if (g.rg > 1) {  // the shares of the regions before this one, each padded to an even length (k_msm_offsets_cols)
-            at = 0;
-            uint32_t prev = 0;
-            for (uint32_t w = 1; w <= wg; ++w) {
-                const uint32_t r = rel[(size_t)w * nb + b];
-                at += (r - prev + 1u) & ~1u;
-                prev = r;
-            }
-        }
-        msm_lds[b] = start[b] + at;
-    }
-    (void)dense;
+    for (uint32_t b = tid; b < nb; b += MSM_SORT_THREADS) msm_lds[b] = start[b] + rel[b];
     __syncthreads();
-    const MsmRange rng(n, ng, wg, g.rg);
-    for (uint32_t base = 0; base < rng.cnt; base += MSM_SORT_THREADS) {
-        const bool valid = base + tid < rng.cnt;
-        const uint32_t i = valid ? rng.first + (base + tid) * rng.step : 0u;
+    const uint32_t per = (n + ng - 1) / ng, lo = wg * per, hi = lo + per < n ? lo + per : n;
+    for (uint32_t base = lo; base < hi; base += MSM_SORT_THREADS) {
+        const uint32_t i = base + tid;
         const uint32_t* sw = scalars + (size_t)i * 8;
-        const int cls = valid ? msm_scalar_class(sw) : 0;
+        const int cls = i < hi ? msm_scalar_class(sw) : 0;
         const uint64_t ones = __ballot(cls == 1);
         if (ones) {
             const int leader = __ffsll((unsigned long long)ones) - 1;
             uint32_t first = 0;
             if ((int)(tid & 63u) == leader) first = atomicAdd(&msm_lds[0], (uint32_t)__popcll(ones));
             first = __shfl(first, leader, 64);
-            if (cls == 1) sorted[first + (uint32_t)__popcll(ones & ((1ull << (tid & 63u)) - 1ull))] = msm_row(g, n, 0, i);  // table 0, positive
+            if (cls == 1) sorted[first + (uint32_t)__popcll(ones & ((1ull << (tid & 63u)) - 1ull))] = i;  // window 0: row i, positive
         }
         if (cls == 2) {
             MsmDigitIter it(sw, g);
             for (int j = 0; j < g.W; ++j) {
                 uint32_t table, bucket, neg;
                 if (it.next(table, bucket, neg))
-                    sorted[atomicAdd(&msm_lds[bucket], 1u)] = msm_row(g, n, table, i) | (neg << 31);
+                    sorted[atomicAdd(&msm_lds[bucket], 1u)] = (table * n + i) | (neg << 31);
                 else if (g.naf)
                     break;
             }
@@ -280,8 +241,9 @@ k_msm_scatter(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32
 //                    sorted by bin inside LDS first (count, scan, place), then copied out bin by bin: runs of ~64 entries.
 //   k_msm_bucketize  (one workgroup per proof and bin)  the bin's entries -> their buckets, again through an LDS-sorted
 //                    tile of 4096 entries: runs of ~32 entries.
-// Between the two, the low 7 bits of an entry's bucket travel in a byte array of their own (`tmpf`, next to `tmp`): a table row takes
-// up to 31 bits (a base set with a table per bit position has 256 x n rows), so the entry word has no room for them.
+// Between the two, an entry carries its bucket's low 7 bits:  row (24 bits) | fine << 24 | sign << 31 — or, where the table has more than
+// 2^24 rows (`wide`: a base set with a table per bit position has 256 x n of them), the 7 bits travel in a byte array of their own
+// (`tmpf`, next to `tmp`) and the word keeps 31 bits for the row.
 static constexpr uint32_t MSM_FINE_LOG = 7, MSM_FINE = 1u << MSM_FINE_LOG;
 static constexpr uint32_t MSM_PART_TILE = 1024;   // scalars per tile of k_msm_partition (= threads)
 static constexpr uint32_t MSM_BKT_TILE = 4096;    // entries per tile of k_msm_bucketize
@@ -340,7 +302,8 @@ __device__ __forceinline__ void msm_small_scan(const uint32_t* cnt, uint32_t* of
 }
 __global__ void __launch_bounds__(1024)
 k_msm_partition(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32_t n, MsmGeom g, uint32_t ng, const uint32_t* __restrict__ crel,
-                const uint32_t* __restrict__ start /* packed offsets: MsmSortBuf::dense */, uint32_t* __restrict__ tmp, uint8_t* __restrict__ tmpf) {
+                const uint32_t* __restrict__ start /* packed offsets: MsmSortBuf::dense */, uint32_t* __restrict__ tmp, uint8_t* __restrict__ tmpf,
+                uint32_t wide) {
     extern __shared__ uint32_t msm_lds[];
     const uint32_t tid = threadIdx.x, wg = blockIdx.x, nb = (uint32_t)g.nb, nbins = nb >> MSM_FINE_LOG;
     uint32_t* cursor = msm_lds;            // [256] global position of the next entry of each bin from this workgroup
@@ -357,14 +320,13 @@ k_msm_partition(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint
     tmp += (size_t)MSM_P * n * g.W;
     tmpf += (size_t)MSM_P * n * g.W;
     if (tid < nbins) cursor[tid] = start[tid << MSM_FINE_LOG] + crel[tid];
-    const MsmRange rng(n, ng, wg, g.rg);
-    for (uint32_t base = 0; base < rng.cnt; base += MSM_PART_TILE) {
+    const uint32_t per = (n + ng - 1) / ng, lo = wg * per, hi = lo + per < n ? lo + per : n;
+    for (uint32_t base = lo; base < hi; base += MSM_PART_TILE) {
         if (tid < nbins) cnt[tid] = 0;
         __syncthreads();
-        const bool valid = base + tid < rng.cnt;
-        const uint32_t i = valid ? rng.first + (base + tid) * rng.step : 0u;
+        const uint32_t i = base + tid;
         const uint32_t* sw = scalars + (size_t)i * 8;
-        const int cls = valid ? msm_scalar_class(sw) : 0;
+        const int cls = i < hi ? msm_scalar_class(sw) : 0;
         const uint64_t ones = __ballot(cls == 1);
         const int leader = ones ? __ffsll((unsigned long long)ones) - 1 : -1;
         // ONE pass over the digits of a tile: the counting atomic already hands out the entry's rank inside its bin, the entry
@@ -386,7 +348,7 @@ k_msm_partition(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint
                     if (it.next(table, bucket, neg)) {
                         const uint32_t B = bucket >> MSM_FINE_LOG;
                         key[j] = atomicAdd(&cnt[B], 1u) | (B << 16) | ((bucket & (MSM_FINE - 1u)) << 24);
-                        ent[j] = msm_row(g, n, table, i) | (neg << 31);
+                        ent[j] = (table * n + i) | (neg << 31) | (wide ? 0u : (bucket & (MSM_FINE - 1u)) << 24);
                     }
                 }
             }
@@ -395,8 +357,8 @@ k_msm_partition(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint
         msm_small_scan(cnt, off, fill, nbins, total, wsum);
         __syncthreads();
         if (cls == 1) {
-            stage[off[0] + unit_rank] = msm_row(g, n, 0, i);
-            stagef[off[0] + unit_rank] = 0;
+            stage[off[0] + unit_rank] = i;
+            if (wide) stagef[off[0] + unit_rank] = 0;
         }
         if (cls == 2) {
 #pragma unroll
@@ -404,7 +366,7 @@ k_msm_partition(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint
                 if (key[j] != 0xffffffffu) {
                     const uint32_t at = off[(key[j] >> 16) & 0xffu] + (key[j] & 0xffffu);
                     stage[at] = ent[j];
-                    stagef[at] = (uint8_t)(key[j] >> 24);
+                    if (wide) stagef[at] = (uint8_t)(key[j] >> 24);
                 }
         }
         __syncthreads();
@@ -413,7 +375,7 @@ k_msm_partition(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint
             const uint32_t B = msm_find_run(off, nbins, k);
             const uint32_t at = cursor[B] + (k - off[B]);
             tmp[at] = stage[k];
-            tmpf[at] = stagef[k];
+            if (wide) tmpf[at] = stagef[k];
         }
         __syncthreads();
         if (tid < nbins) cursor[tid] += cnt[tid];
@@ -421,66 +383,55 @@ k_msm_partition(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint
 }
 __global__ void __launch_bounds__(1024)
 k_msm_bucketize(const uint32_t* __restrict__ tmp, const uint8_t* __restrict__ tmpf, size_t tmp_stride, const uint32_t* __restrict__ dense,
-                const uint32_t* __restrict__ start, uint32_t nb, uint32_t* __restrict__ sorted, size_t sorted_stride, const uint32_t* __restrict__ crel,
-                uint32_t ng, int rg) {
+                const uint32_t* __restrict__ start, uint32_t nb, uint32_t* __restrict__ sorted, size_t sorted_stride, uint32_t wide) {
     __shared__ uint32_t cur[MSM_FINE], cnt[MSM_FINE], off[MSM_FINE], fill[MSM_FINE], total[4], wsum[4], stage[MSM_BKT_TILE];
-    const uint32_t tid = threadIdx.x, B = blockIdx.x, nbins = nb >> MSM_FINE_LOG;
+    const uint32_t tid = threadIdx.x, B = blockIdx.x;
     tmp += MSM_P * tmp_stride;
     tmpf += MSM_P * tmp_stride;
     sorted += MSM_P * sorted_stride;
     start += (size_t)MSM_P * (nb + 1);
     dense += (size_t)MSM_P * (nb + 1);
-    crel += (size_t)MSM_P * ng * nbins;
     const uint32_t b0 = B << MSM_FINE_LOG, lo = dense[b0], hi = dense[b0 + MSM_FINE];  // the bin in `tmp`: packed
     if (tid < MSM_FINE) cur[tid] = start[b0 + tid];                                      // its buckets in `sorted`: aligned runs
-    // table regions (rg > 1): the bin's entries lie in `tmp` region after region (k_msm_partition: one workgroup per region); they are
-    // placed region by region, and behind each region every bucket's run is brought to an even length with the padding entry — a pair
-    // of the bucket tree's level 0 (entries 2q, 2q + 1) then never mixes regions
-    const uint32_t parts = rg > 1 ? ng : 1u;
-    for (uint32_t w = 0; w < parts; ++w) {
-        const uint32_t rlo = rg > 1 ? lo + crel[(size_t)w * nbins + B] : lo, rhi = rg > 1 && w + 1 < parts ? lo + crel[(size_t)(w + 1) * nbins + B] : hi;
-        for (uint32_t base = rlo; base < rhi; base += MSM_BKT_TILE) {
-            if (tid < MSM_FINE) cnt[tid] = 0;
-            __syncthreads();
-            uint32_t e[MSM_BKT_TILE / 1024], fr[MSM_BKT_TILE / 1024];  // fr: low bucket bits | rank << 8 (the counting atomic hands out the rank inside the bucket)
+    for (uint32_t base = lo; base < hi; base += MSM_BKT_TILE) {
+        if (tid < MSM_FINE) cnt[tid] = 0;
+        __syncthreads();
+        uint32_t e[MSM_BKT_TILE / 1024], fr[MSM_BKT_TILE / 1024];  // fr: low bucket bits | rank << 8 (the counting atomic hands out the rank inside the bucket)
 #pragma unroll
-            for (uint32_t q = 0; q < MSM_BKT_TILE / 1024; ++q) {
-                const uint32_t k = base + q * 1024 + tid;
-                const bool valid = k < rhi;
-                e[q] = valid ? tmp[k] : 0xffffffffu;
-                const uint32_t f = valid ? (uint32_t)tmpf[k] : 0u;
-                // (a bucket that holds most of a tile — the unit scalars' bucket 0 — is counted once per wave, not 64 times)
-                const uint64_t same = __ballot(valid && f == 0);
-                uint32_t rank = 0;
-                if (same) {
-                    const int leader = __ffsll((unsigned long long)same) - 1;
-                    uint32_t first = 0;
-                    if ((int)(tid & 63u) == leader) first = atomicAdd(&cnt[0], (uint32_t)__popcll(same));
-                    first = __shfl(first, leader, 64);
-                    if (valid && f == 0) rank = first + (uint32_t)__popcll(same & ((1ull << (tid & 63u)) - 1ull));
-                }
-                if (valid && f != 0) rank = atomicAdd(&cnt[f], 1u);
-                fr[q] = f | (rank << 8);
+        for (uint32_t q = 0; q < MSM_BKT_TILE / 1024; ++q) {
+            const uint32_t k = base + q * 1024 + tid;
+            const bool valid = k < hi;
+            e[q] = valid ? tmp[k] : 0xffffffffu;
+            const uint32_t f = !valid ? 0u : wide ? (uint32_t)tmpf[k] : (e[q] >> 24) & (MSM_FINE - 1u);
+            // (a bucket that holds most of a tile — the unit scalars' bucket 0 — is counted once per wave, not 64 times)
+            const uint64_t same = __ballot(valid && f == 0);
+            uint32_t rank = 0;
+            if (same) {
+                const int leader = __ffsll((unsigned long long)same) - 1;
+                uint32_t first = 0;
+                if ((int)(tid & 63u) == leader) first = atomicAdd(&cnt[0], (uint32_t)__popcll(same));
+                first = __shfl(first, leader, 64);
+                if (valid && f == 0) rank = first + (uint32_t)__popcll(same & ((1ull << (tid & 63u)) - 1ull));
             }
-            __syncthreads();
-            msm_small_scan(cnt, off, fill, MSM_FINE, total, wsum);
-            __syncthreads();
-#pragma unroll
-            for (uint32_t q = 0; q < MSM_BKT_TILE / 1024; ++q) {
-                const uint32_t k = base + q * 1024 + tid;
-                if (k < rhi) stage[off[fr[q] & 0xffu] + (fr[q] >> 8)] = e[q];
-            }
-            __syncthreads();
-            const uint32_t tot = *total;
-            for (uint32_t k = tid; k < tot; k += 1024) {
-                const uint32_t f = msm_find_run(off, MSM_FINE, k);
-                sorted[cur[f] + (k - off[f])] = stage[k];
-            }
-            __syncthreads();
-            if (tid < MSM_FINE) cur[tid] += cnt[tid];
+            if (valid && f != 0) rank = atomicAdd(&cnt[f], 1u);
+            fr[q] = f | (rank << 8);
         }
-        // (start[] is even wherever regions are used: every region's share was counted as an even number of entries)
-        if (rg > 1 && tid < MSM_FINE && (cur[tid] & 1u)) sorted[cur[tid]++] = MSM_PAD_ENTRY;
+        __syncthreads();
+        msm_small_scan(cnt, off, fill, MSM_FINE, total, wsum);
+        __syncthreads();
+#pragma unroll
+        for (uint32_t q = 0; q < MSM_BKT_TILE / 1024; ++q) {
+            const uint32_t k = base + q * 1024 + tid;
+            if (k < hi) stage[off[fr[q] & 0xffu] + (fr[q] >> 8)] = wide ? e[q] : e[q] & 0x80ffffffu;
+        }
+        __syncthreads();
+        const uint32_t tot = *total;
+        for (uint32_t k = tid; k < tot; k += 1024) {
+            const uint32_t f = msm_find_run(off, MSM_FINE, k);
+            sorted[cur[f] + (k - off[f])] = stage[k];
+        }
+        __syncthreads();
+        if (tid < MSM_FINE) cur[tid] += cnt[tid];
     }
     // aligned runs: the gap between the end of a run and the start of the next holds the point at infinity
     __syncthreads();

@@ -229,24 +229,14 @@ __device__ __forceinline__ F tree_select(bool m, const F& a, const F& b) {
 // reads a row of zeros): a conditional load keeps the old value of its 12 destination registers alive — the compiler copied every
 // operand twice per pair (old value into the destination before the load, destination into the working set after it).
 static __device__ uint4 g_tree_zero_row[16];  // 256 bytes of zeros: the row a padding entry gathers (TabRow<Fp2Ops> is the larger)
-// MODE of a pass: TREE_DEEP a level >= 1 (records: first input point, output point); TREE_L0 level 0 (the "record" of pair q is the pair
-// of digit-list words 2q, 2q + 1, its output point q); TREE_L0_REGIONS level 0 of a base set whose table is cut into regions
-// (MsmGeom::rg): the pairs come from k_tree_region_records' per-region lists — (word, word, output point, -) — and workgroup x walks
-// the list of region x mod MSM_REGIONS, which is the XCD it runs on
-enum : int { TREE_DEEP = 0, TREE_L0 = 1, TREE_L0_REGIONS = 2 };
-template <int MODE>
+template <bool L0>
 struct TreeRec {
     typedef uint2 type;
 };
-template <>
-struct TreeRec<TREE_L0_REGIONS> {
-    typedef uint4 type;
-};
-template <class O, int MODE>
+template <class O, bool L0>
 struct TreeSrc {
-    static constexpr bool L0 = MODE != TREE_DEEP;
     typedef typename O::T F;
-    typedef typename TreeRec<MODE>::type Rec;
+    typedef typename TreeRec<L0>::type Rec;
     // O::LANES lanes hold one element (Fp2PairOps: 2): lane `h` of them reads part h of every stored element
     const TabRow<typename O::Base>* tab;
     const F *xs, *ys;  // the level's point planes (deeper levels): `cap` elements each
@@ -338,198 +328,38 @@ struct TreeSrc {
         fix_y(r, y1, y2);
     }
     static __device__ __forceinline__ uint32_t out_index(const Rec& r, uint32_t q) {  // level 0: pair q -> point q of level 1
-        if constexpr (MODE == TREE_L0_REGIONS)
-            return r.z;
-        else if constexpr (L0)
+        if constexpr (L0)
             return q;
         else
             return r.y;
     }
 };
 
-// ---- level 0 by table regions ------------------------------------------------------------------------------------------
-// The pairs of the digit list (entries 2q, 2q + 1: the sort has made them the same region's, device/msm_sort.cuh) are dealt to one list
-// per region, in the order of q:  rl[rbase(r) + k] = (entry, entry, q, 0).  A stable partition in three kernels over chunks of
-// TREE_RG_CHUNK pairs: count per chunk and region, scan the chunks of every region (and leave the regions' totals), place.  (With one
-// atomic per wave and region instead — 160 000 of them on eight words per proof — the placement alone took 60 ms per MSM, and the
-// results of pass 2, which leave in the order of the lists, were scattered.)  A pair of two padding entries (a run brought to a
-// multiple of four) counts for the last region.
-static constexpr uint32_t TREE_RG_CHUNK = 1024;  // pairs per workgroup of the count / place kernels: four waves x 4 x 64
-__device__ __forceinline__ uint32_t tree_pair_region(const uint2& e, uint32_t region_rows) {
-    return e.x == MSM_PAD_ENTRY ? (uint32_t)MSM_REGIONS - 1u : (e.x & 0x7fffffffu) / region_rows;
-}
-// wave `wid` of a chunk takes its pairs base + wid * 256 + i * 64 + lane, i < 4: e[i], r[i] (MSM_REGIONS = not a pair), cnt[k] = pairs of
-// region k among them (the same in every lane)
-__device__ __forceinline__ void tree_rg_load(const uint2* __restrict__ pairs, uint32_t P, uint32_t base, uint32_t region_rows, uint2 (&e)[4], uint32_t (&r)[4],
-                                             uint32_t (&cnt)[MSM_REGIONS]) {
-    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < MSM_REGIONS; ++k) cnt[k] = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < 4; ++i) {
-        const uint32_t q = base + wid * 256u + i * 64u + lane;
-        e[i] = make_uint2(MSM_PAD_ENTRY, MSM_PAD_ENTRY);
-        r[i] = MSM_REGIONS;
-        if (q < P) {
-            e[i] = pairs[q];
-            r[i] = tree_pair_region(e[i], region_rows);
-        }
-#pragma unroll
-        for (int k = 0; k < MSM_REGIONS; ++k) cnt[k] += (uint32_t)__popcll(__ballot(r[i] == (uint32_t)k));
-    }
-}
-// grid (chunks, q): rcnt[(p MSM_REGIONS + r) chunks + c] = pairs of region r in chunk c
-static __global__ void __launch_bounds__(256)
-k_tree_region_count(const uint32_t* __restrict__ sorted, size_t ent_stride, const uint32_t* __restrict__ start, uint32_t nb, uint32_t region_rows,
-                    uint32_t* __restrict__ rcnt) {
-    __shared__ uint32_t wc[4][MSM_REGIONS];
-    const uint32_t p = MSM_P, chunks = gridDim.x, c = blockIdx.x;
-    const uint2* pairs = reinterpret_cast<const uint2*>(sorted + (size_t)p * ent_stride);
-    const uint32_t P = start[(size_t)p * (nb + 1) + nb] >> 1;
-    uint2 e[4];
-    uint32_t r[4], cnt[MSM_REGIONS];
-    tree_rg_load(pairs, P, c * TREE_RG_CHUNK, region_rows, e, r, cnt);
-    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < MSM_REGIONS; ++k) wc[wid][k] = cnt[k];
-    }
-    __syncthreads();
-    if (threadIdx.x < MSM_REGIONS) rcnt[((size_t)p * MSM_REGIONS + threadIdx.x) * chunks + c] = wc[0][threadIdx.x] + wc[1][threadIdx.x] + wc[2][threadIdx.x] + wc[3][threadIdx.x];
-}
-// grid (MSM_REGIONS, q), 1024 threads: exclusive scan of a region's chunk counts in place, rtot[p MSM_REGIONS + r] = their sum
-static __global__ void __launch_bounds__(1024) k_tree_region_scan(uint32_t* __restrict__ rcnt, uint32_t chunks, uint32_t* __restrict__ rtot) {
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry;
-    const uint32_t p = MSM_P, r = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
-    uint32_t* v = rcnt + ((size_t)p * MSM_REGIONS + r) * chunks;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t c0 = 0; c0 < chunks; c0 += blockDim.x) {
-        const uint32_t c = c0 + tid, x0 = c < chunks ? v[c] : 0u;
-        uint32_t x = x0;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t y = __shfl_up(x, d, 64);
-            if ((int)lane >= d) x += y;
-        }
-        if (lane == 63) wsum[wid] = x;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (uint32_t k = 0; k < wid; ++k) woff += wsum[k];
-        const uint32_t cs = carry;
-        if (c < chunks) v[c] = cs + woff + x - x0;
-        __syncthreads();
-        if (tid == blockDim.x - 1) carry = cs + woff + x;
-        __syncthreads();
-    }
-    if (tid == 0) rtot[(size_t)p * MSM_REGIONS + r] = carry;
-}
-// grid (chunks, q): the pairs of chunk c to their places
-static __global__ void __launch_bounds__(256)
-k_tree_region_place(const uint32_t* __restrict__ sorted, size_t ent_stride, const uint32_t* __restrict__ start, uint32_t nb, uint32_t region_rows,
-                    const uint32_t* __restrict__ rcnt, const uint32_t* __restrict__ rtot, uint4* __restrict__ rl, size_t rl_stride) {
-    __shared__ uint32_t wc[4][MSM_REGIONS];
-    const uint32_t p = MSM_P, chunks = gridDim.x, c = blockIdx.x;
-    const uint2* pairs = reinterpret_cast<const uint2*>(sorted + (size_t)p * ent_stride);
-    const uint32_t P = start[(size_t)p * (nb + 1) + nb] >> 1;
-    rl += (size_t)p * rl_stride;
-    uint2 e[4];
-    uint32_t r[4], cnt[MSM_REGIONS];
-    tree_rg_load(pairs, P, c * TREE_RG_CHUNK, region_rows, e, r, cnt);
-    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < MSM_REGIONS; ++k) wc[wid][k] = cnt[k];
-    }
-    __syncthreads();
-    // next[k]: the place of this wave's next pair of region k = list base + chunks before + waves before
-    uint32_t next[MSM_REGIONS];
-    {
-        uint32_t lb = 0;
-#pragma unroll
-        for (int k = 0; k < MSM_REGIONS; ++k) {
-            uint32_t at = lb + rcnt[((size_t)p * MSM_REGIONS + k) * chunks + c];
-            for (uint32_t w = 0; w < wid; ++w) at += wc[w][k];
-            next[k] = at;
-            lb += rtot[(size_t)p * MSM_REGIONS + k];
-        }
-    }
-#pragma unroll
-    for (uint32_t i = 0; i < 4; ++i) {
-        const uint32_t q = c * TREE_RG_CHUNK + wid * 256u + i * 64u + lane;
-        uint32_t at = 0;
-#pragma unroll
-        for (int k = 0; k < MSM_REGIONS; ++k) {
-            const uint64_t m = __ballot(r[i] == (uint32_t)k);
-            if (r[i] == (uint32_t)k) at = next[k] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            next[k] += (uint32_t)__popcll(m);
-        }
-        if (r[i] < (uint32_t)MSM_REGIONS) rl[at] = make_uint4(e[i].x, e[i].y, q, 0u);
-    }
-}
-
 // ---- pass 1: denominators and their running products -----------------------------------------------------------------
 // grid (NT / 256, np).  pre[(j np + p) NT + t] = product of the denominators of lane (p, t)'s pairs 0 .. j; tp[p NT + t] = all of them.
-// TREE_L0_REGIONS: Ql = the pairs per region (rtot[p][MSM_REGIONS]), rec_ = the regions' lists; gridDim.x is a multiple of MSM_REGIONS and
-// workgroup x takes region x mod MSM_REGIONS: lane tq of its NT / MSM_REGIONS walks places tq, tq + NT / MSM_REGIONS, ... of the list, and
-// `pre` is indexed by the place itself (pre[p pre_stride + list base + place]: exact whatever the balance of the regions).
-template <uint32_t LN>
-struct TreeWalk {
-    uint32_t tq, NTq, P, rbase;   // this lane's first pair, the stride, the pairs of its list, where the list starts
-    __device__ __forceinline__ TreeWalk(int mode, uint32_t t, uint32_t NT, const uint32_t* __restrict__ Ql, uint32_t p, uint32_t nb) {
-        if (mode == TREE_L0_REGIONS) {
-            const uint32_t r = blockIdx.x % MSM_REGIONS;
-            const uint32_t* rt = Ql + (size_t)p * MSM_REGIONS;
-            rbase = 0;
-            for (uint32_t k = 0; k < r; ++k) rbase += rt[k];
-            P = rt[r];
-            NTq = NT / MSM_REGIONS;
-            tq = ((blockIdx.x / MSM_REGIONS) * blockDim.x + threadIdx.x) / LN;
-        } else {
-            rbase = 0;
-            P = Ql[(size_t)p * (nb + 1) + nb];
-            NTq = NT;
-            tq = t;
-        }
-    }
-};
-template <class O, int MODE>
+template <class O, bool L0>
 __global__ void __launch_bounds__(256)
 k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O::T* __restrict__ xs, const typename O::T* __restrict__ ys,
              size_t pt_stride, const void* __restrict__ rec_, size_t rec_stride, const uint32_t* __restrict__ Ql, uint32_t nb, uint32_t NT,
              typename O::T* __restrict__ pre, size_t pre_cap, typename O::T* __restrict__ tp) {
     typedef typename O::T F;
-    typedef typename TreeRec<MODE>::type Rec;
-    constexpr bool L0 = MODE != TREE_DEEP;
-    constexpr bool RG = MODE == TREE_L0_REGIONS;
+    typedef typename TreeRec<L0>::type Rec;
     constexpr uint32_t LN = O::LANES;  // lanes per element (see k_tree_pass2)
     const uint32_t p = MSM_P, np = gridDim.y, t = (blockIdx.x * blockDim.x + threadIdx.x) / LN;
     if (t >= NT) return;
-    const TreeWalk<LN> walk(MODE, t, NT, Ql, p, nb);
-    const uint32_t P = walk.P, tq = walk.tq, NTq = walk.NTq;
-    // where the value of this lane's j-th pair (pair tq + j NTq) lies in `pre`
-    auto pre_at = [&](uint32_t j) -> size_t {
-        if constexpr (RG)
-            return (size_t)p * rec_stride + walk.rbase + tq + (size_t)j * NTq;
-        else
-            return ((size_t)j * np + p) * NT + t;
-    };
+    const uint32_t P = Ql[(size_t)p * (nb + 1) + nb];
     // rec_ == nullptr: a level >= 1 whose runs all have even lengths (the sort padded to a multiple of 2^(level + 1)): pair q is
     // points 2q, 2q + 1 and lands at point q, like level 0 over the digit list
-    const Rec* recs = reinterpret_cast<const Rec*>(rec_) + (size_t)p * rec_stride + walk.rbase;
+    const Rec* recs = reinterpret_cast<const Rec*>(rec_) + (size_t)p * rec_stride;
     // (level 0 always has its records — the digit list; on the deeper levels the load is unconditional too, from a harmless
     // address when there are no records: a load inside a conditional block is waited for at the block's end, with vmcnt(0))
     const bool synth = !L0 && rec_ == nullptr;
     const Rec* recs_ld = synth ? reinterpret_cast<const Rec*>(Ql) : recs;
     auto rec_at = [&](uint32_t q) -> Rec {
         const Rec r = recs_ld[synth ? 0u : q];
-        if constexpr (L0)
-            return r;
-        else
-            return synth ? make_uint2(2u * q, q) : r;
+        return synth ? make_uint2(2u * q, q) : r;
     };
-    TreeSrc<O, MODE> src;
+    TreeSrc<O, L0> src;
     src.tab = tab;
     src.set(xs, ys, p, np, pt_stride);
     F chain = O::one();
@@ -545,9 +375,9 @@ k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
     };
     Rec ra{}, rb{};
     Ops nxt{O::zero(), O::zero(), O::zero(), O::zero()};
-    if (tq < P) {
-        ra = rec_at(tq);
-        if (tq + NTq < P) rb = rec_at(tq + NTq);
+    if (t < P) {
+        ra = rec_at(t);
+        if (t + NT < P) rb = rec_at(t + NT);
         fetch(ra, nxt);
     }
     // (gfx9 counts loads and stores in ONE counter and stores may complete out of order, so a wait for loaded data drains every
@@ -555,15 +385,15 @@ k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
     // iteration's wait and before its loads — by the next wait it has had a whole iteration to complete)
     F hq = O::zero();
     uint32_t j = 0;
-    for (uint32_t q = tq; q < P; q += NTq, ++j) {
+    for (uint32_t q = t; q < P; q += NT, ++j) {
         const Rec cr = ra;
         Ops c = nxt;
-        if (j) plane_st(pre, pre_cap, src.at(pre_at(j - 1)), hq);
+        if (j) plane_st(pre, pre_cap, src.at(((size_t)(j - 1) * np + p) * NT + t), hq);
         ra = rb;
-        if (q + NTq >= P) ra = cr;  // the last iteration asks for its own pair again: nothing reads it
+        if (q + NT >= P) ra = cr;  // the last iteration asks for its own pair again: nothing reads it
         fetch(ra, nxt);
-        rb = rec_at(q + 2 * (uint64_t)NTq < P ? q + 2 * NTq : q);
-        TreeSrc<O, MODE>::fix_y(cr, c.y1, c.y2);
+        rb = rec_at(q + 2 * (uint64_t)NT < P ? q + 2 * NT : q);
+        TreeSrc<O, L0>::fix_y(cr, c.y1, c.y2);
         const bool pad2 = cr.y == MSM_PAD_ENTRY;  // (this form is level 0's: the second operand is the padding entry)
         F d = O::sub(c.x2, c.x1), n = O::sub(c.y2, c.y1);
         if (!pad2 && (O::is_zero(c.x1) || O::is_zero(c.x2) || O::is_zero(d))) {  // rare
@@ -581,30 +411,30 @@ k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         hq = O::mul_lazy(n, chain);    // numerator x (denominators before this pair): pass 2 multiplies by 1 / (denominators up to this pair)
         chain = O::mul_lazy(chain, d);
     }
-    if (j) plane_st(pre, pre_cap, src.at(pre_at(j - 1)), hq);
+    if (j) plane_st(pre, pre_cap, src.at(((size_t)(j - 1) * np + p) * NT + t), hq);
     tp[src.at((size_t)p * NT + t)] = chain;
     } else {
     // two-stage software pipeline: the record of pair j + 2 and the operands of pair j + 1 are requested before pair j is
     // multiplied in — an operand is two dependent loads away (record, then row / point) and nothing else hides that
     Rec ra{}, rb{};
     F x1 = O::zero(), x2 = O::zero();
-    if (tq < P) {
-        ra = rec_at(tq);
-        if (tq + NTq < P) rb = rec_at(tq + NTq);
+    if (t < P) {
+        ra = rec_at(t);
+        if (t + NT < P) rb = rec_at(t + NT);
         src.load_x(ra, x1, x2);
     }
     // (gfx9 counts loads and stores in ONE counter and stores may complete out of order, so a wait for loaded data drains every
     // store issued before it: the prefix of pair j is therefore stored at the top of iteration j + 1, right after that
     // iteration's wait and before its loads — by the next wait it has had a whole iteration to complete)
     uint32_t j = 0;
-    for (uint32_t q = tq; q < P; q += NTq, ++j) {
+    for (uint32_t q = t; q < P; q += NT, ++j) {
         const Rec cr = ra;
         const F cx1 = x1, cx2 = x2;
-        if (j) plane_st(pre, pre_cap, src.at(pre_at(j - 1)), chain);
+        if (j) plane_st(pre, pre_cap, src.at(((size_t)(j - 1) * np + p) * NT + t), chain);
         ra = rb;
-        if (q + NTq >= P) ra = cr;
+        if (q + NT >= P) ra = cr;
         src.load_x(ra, x1, x2);
-        rb = rec_at(q + 2 * (uint64_t)NTq < P ? q + 2 * NTq : q);
+        rb = rec_at(q + 2 * (uint64_t)NT < P ? q + 2 * NT : q);
         F d = O::sub(cx2, cx1);
         if (O::is_zero(cx1) || O::is_zero(cx2) || O::is_zero(d)) {  // rare: needs the y coordinates to decide
             F y1, y2;
@@ -613,50 +443,38 @@ k_tree_pass1(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         }
         chain = O::mul_lazy(chain, d);  // in [0, 2p): only ever multiplied again
     }
-    if (j) plane_st(pre, pre_cap, src.at(pre_at(j - 1)), chain);
+    if (j) plane_st(pre, pre_cap, src.at(((size_t)(j - 1) * np + p) * NT + t), chain);
     tp[src.at((size_t)p * NT + t)] = chain;
     }
 }
 
 // ---- pass 2: the additions --------------------------------------------------------------------------------------------
 // tinv[p NT + t] = 1 / tp[p NT + t].  The lane walks its pairs backwards: 1 / d_j = (1 / (d_0 .. d_j)) (d_0 .. d_{j-1}).
-template <class O, int MODE>
+template <class O, bool L0>
 __global__ void __launch_bounds__(256, (sizeof(typename O::T) > 48 ? 1 : 2))   // two waves per SIMD (<= 256 VGPRs) where an element is 12 registers
 k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O::T* __restrict__ xs, const typename O::T* __restrict__ ys,
              size_t pt_stride, const void* __restrict__ rec_, size_t rec_stride, const uint32_t* __restrict__ Ql, uint32_t nb, uint32_t NT,
              const typename O::T* __restrict__ pre, size_t pre_cap, const typename O::T* __restrict__ tinv, typename O::T* __restrict__ ox,
              typename O::T* __restrict__ oy, size_t out_stride, uint32_t out_whole) {
     typedef typename O::T F;
-    typedef typename TreeRec<MODE>::type Rec;
-    constexpr bool L0 = MODE != TREE_DEEP;
-    constexpr bool RG = MODE == TREE_L0_REGIONS;
+    typedef typename TreeRec<L0>::type Rec;
     constexpr uint32_t LN = O::LANES;  // lanes per element; every stride and index below counts ELEMENTS (LN values of F each)
     const uint32_t p = MSM_P, np = gridDim.y, t = (blockIdx.x * blockDim.x + threadIdx.x) / LN;
     if (t >= NT) return;
-    const TreeWalk<LN> walk(MODE, t, NT, Ql, p, nb);   // (which pairs this lane takes: see k_tree_pass1)
-    const uint32_t P = walk.P, tq = walk.tq, NTq = walk.NTq;
-    if (tq >= P) return;
-    auto pre_at = [&](uint32_t j) -> size_t {
-        if constexpr (RG)
-            return (size_t)p * rec_stride + walk.rbase + tq + (size_t)j * NTq;
-        else
-            return ((size_t)j * np + p) * NT + t;
-    };
+    const uint32_t P = Ql[(size_t)p * (nb + 1) + nb];
+    if (t >= P) return;
     // rec_ == nullptr: a level >= 1 whose runs all have even lengths (the sort padded to a multiple of 2^(level + 1)): pair q is
     // points 2q, 2q + 1 and lands at point q, like level 0 over the digit list
-    const Rec* recs = reinterpret_cast<const Rec*>(rec_) + (size_t)p * rec_stride + walk.rbase;
+    const Rec* recs = reinterpret_cast<const Rec*>(rec_) + (size_t)p * rec_stride;
     // (level 0 always has its records — the digit list; on the deeper levels the load is unconditional too, from a harmless
     // address when there are no records: a load inside a conditional block is waited for at the block's end, with vmcnt(0))
     const bool synth = !L0 && rec_ == nullptr;
     const Rec* recs_ld = synth ? reinterpret_cast<const Rec*>(Ql) : recs;
     auto rec_at = [&](uint32_t q) -> Rec {
         const Rec r = recs_ld[synth ? 0u : q];
-        if constexpr (L0)
-            return r;
-        else
-            return synth ? make_uint2(2u * q, q) : r;
+        return synth ? make_uint2(2u * q, q) : r;
     };
-    TreeSrc<O, MODE> src;
+    TreeSrc<O, L0> src;
     src.tab = tab;
     src.set(xs, ys, p, np, pt_stride);
     // the results: point `out` of the next level's planes — or, from the last level (out_whole), whole elements proof after
@@ -683,9 +501,9 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         src.load_x(r, o.x1, o.x2);
         src.load_y1_raw(r, o.y1);
     };
-    uint32_t j = (P - 1 - tq) / NTq;
-    Rec ra = rec_at(tq + j * NTq), rb{};
-    if (j) rb = rec_at(tq + (j - 1) * NTq);
+    uint32_t j = (P - 1 - t) / NT;
+    Rec ra = rec_at(t + j * NT), rb{};
+    if (j) rb = rec_at(t + (j - 1) * NT);
     Ops nxt;
     fetch(ra, nxt);
     // (the result of a pair is stored at the top of the NEXT iteration, after that iteration's wait for its operands and before
@@ -698,23 +516,19 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         const Rec cr = ra;
         ra = rb;
         if (held) put(hout, hx, hy);
-        const F qn = plane_ld(pre, pre_cap, src.at(pre_at(j)));
+        const F qn = plane_ld(pre, pre_cap, src.at(((size_t)j * np + p) * NT + t));
         if (!j) ra = cr;  // the last iteration asks for its own pair again: nothing reads it
         fetch(ra, nxt);
-        rb = rec_at(tq + (j > 1 ? j - 2 : 0u) * NTq);
-#if defined(MASP_TREE_RG_DIAG) && MASP_TREE_RG_DIAG == 1
-        const uint32_t out = RG ? walk.rbase + tq + j * NTq : TreeSrc<O, MODE>::out_index(cr, tq + j * NTq);   // DIAGNOSTIC: wrong points, contiguous stores
-#else
-        const uint32_t out = TreeSrc<O, MODE>::out_index(cr, tq + j * NTq);
-#endif
-        TreeSrc<O, MODE>::fix_y1(cr, c.y1);
+        rb = rec_at(t + (j > 1 ? j - 2 : 0u) * NT);
+        const uint32_t out = TreeSrc<O, L0>::out_index(cr, t + j * NT);
+        TreeSrc<O, L0>::fix_y1(cr, c.y1);
         const bool pad2 = cr.y == MSM_PAD_ENTRY;  // the second operand is the padding entry: the result is the first operand (see tree_select)
         F d = O::sub(c.x2, c.x1);
         int kind = TREE_ADD;
         F y2 = O::zero();
         if (!pad2 && (O::is_zero(c.x1) || O::is_zero(c.x2) || O::is_zero(d))) {  // rare
             src.load_y2_raw(cr, y2);
-            TreeSrc<O, MODE>::fix_y2(cr, y2);
+            TreeSrc<O, L0>::fix_y2(cr, y2);
             kind = tree_classify<O>(c.x1, c.y1, c.x2, y2, d);
         }
         d = tree_select(pad2, O::one(), d);
@@ -754,9 +568,9 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         src.load_x(r, o.x1, o.x2);
         src.load_y_raw(r, o.y1, o.y2);
     };
-    uint32_t j = (P - 1 - tq) / NTq;
-    Rec ra = rec_at(tq + j * NTq), rb{};
-    if (j) rb = rec_at(tq + (j - 1) * NTq);
+    uint32_t j = (P - 1 - t) / NT;
+    Rec ra = rec_at(t + j * NT), rb{};
+    if (j) rb = rec_at(t + (j - 1) * NT);
     Ops nxt;
     fetch(ra, nxt);
     // (the result of a pair is stored at the top of the NEXT iteration, after that iteration's wait for its operands and before
@@ -770,12 +584,12 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
         ra = rb;
         if (held) put(hout, hx, hy);
         F pp = O::one();
-        if (j) pp = plane_ld(pre, pre_cap, src.at(pre_at(j - 1)));
+        if (j) pp = plane_ld(pre, pre_cap, src.at(((size_t)(j - 1) * np + p) * NT + t));
         if (!j) ra = cr;  // the last iteration asks for its own pair again: nothing reads it
         fetch(ra, nxt);
-        rb = rec_at(tq + (j > 1 ? j - 2 : 0u) * NTq);
-        const uint32_t out = TreeSrc<O, MODE>::out_index(cr, tq + j * NTq);
-        TreeSrc<O, MODE>::fix_y(cr, c.y1, c.y2);
+        rb = rec_at(t + (j > 1 ? j - 2 : 0u) * NT);
+        const uint32_t out = TreeSrc<O, L0>::out_index(cr, t + j * NT);
+        TreeSrc<O, L0>::fix_y(cr, c.y1, c.y2);
         // the second operand is the point at infinity (level 1: what two padding entries of level 0 summed to): the result is the first
         // operand, by selects (see tree_select)
         const bool zx2 = O::is_zero(c.x2), inf2 = zx2 && O::is_zero(c.y2);

@@ -12,16 +12,12 @@ int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb
         last_hip_error() = "MSM digit width must be 2..16 bits (fixed windows) / 4..17 bits (NAF): the bucket histogram lives in LDS";
         return MASP_HIP_E_INVALID_ARG;
     }
-    if (msm_table_rows(g, n) > 0x7ffffffeull) {
+    if ((uint64_t)n * (uint32_t)g.tpos > 0x7ffffffeull) {
         last_hip_error() = "msm_sort_enqueue: the base set has more table rows than an entry's 31 bits can name";
         return MASP_HIP_E_INVALID_ARG;
     }
     if (pad_log > 12) {
         last_hip_error() = "msm_sort_enqueue: runs can be aligned to at most 2^12 entries";
-        return MASP_HIP_E_INVALID_ARG;
-    }
-    if (g.rg > 1 && g.rg != MSM_REGIONS) {
-        last_hip_error() = "msm_sort_enqueue: a table has one region or MSM_REGIONS";
         return MASP_HIP_E_INVALID_ARG;
     }
     int rc = sb.reserve(n, g, np, pad_log);
@@ -31,12 +27,13 @@ int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb
     sb.g = g;
     sb.pad_log = pad_log;
     sb.ent_stride = MsmSortBuf::padded_entries(n, g, pad_log);
-    const uint32_t ng = MsmSortBuf::ranges_for(n, np, g.rg), nb = g.nb;
+    const uint32_t ng = MsmSortBuf::ranges_for(n, np), nb = g.nb;
     // two-pass placement (runs instead of single scattered words): the first pass stages a tile's entries (a word and a byte each) in LDS
     // ... and the second pass is one workgroup per (proof, coarse bin): with too few of them (a lone proof's b_g2 on 8-bit windows: ONE,
     // 0.57 ms for 600 000 entries) the single-pass scatter over the scalar ranges is the shorter chain
     constexpr int PART_W_MAX = 30;  // 5 bytes x 1024 x 30 + the bins' counters = 154 KiB of the 160 KiB LDS
     const bool two_pass = nb >= MSM_FINE && g.W <= PART_W_MAX && (uint64_t)(nb >> MSM_FINE_LOG) * np >= 8;
+    const uint32_t wide = (uint64_t)n * (uint32_t)g.tpos > (1u << 24) ? 1u : 0u;  // the low bucket bits of an entry in `tmpf` instead of the entry word
     const int part_lds = 4 * (4 * 256 + 8) + 5 * (int)MSM_PART_TILE * g.W;
     static PerDeviceOnce once;
     const bool lds_ok = once([] {
@@ -51,19 +48,18 @@ int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb
         return MASP_HIP_E_HIP;
     }
     MASP_LAUNCH(k_msm_hist, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg);
-    MASP_LAUNCH(k_msm_offsets_cols, dim3((nb + 255) / 256, np), dim3(256), 0, s, sb.hist_wg, ng, nb, sb.dense, sb.start, g.rg);
+    MASP_LAUNCH(k_msm_offsets_cols, dim3((nb + 255) / 256, np), dim3(256), 0, s, sb.hist_wg, ng, nb, sb.dense);
     MASP_LAUNCH(k_msm_offsets_scan, dim3(1, np), dim3(1024), 0, s, nb, sb.start, sb.dense, pad_log);
     if (two_pass) {
         const uint32_t nbins = nb >> MSM_FINE_LOG;
         MASP_LAUNCH(k_msm_coarse, dim3(nbins, np), dim3(128), 0, s, sb.hist_wg, ng, nb, sb.crel);
-        MASP_LAUNCH(k_msm_partition, dim3(ng, np), dim3(MSM_PART_TILE), part_lds, s, d_scalars, scalar_stride, n, g, ng, sb.crel, sb.dense, sb.tmp, sb.tmpf);
-        MASP_LAUNCH(k_msm_bucketize, dim3(nbins, np), dim3(1024), 0, s, sb.tmp, sb.tmpf, (size_t)n * g.W, sb.dense, sb.start, nb, sb.sorted, sb.ent_stride,
-                    sb.crel, ng, g.rg);
+        MASP_LAUNCH(k_msm_partition, dim3(ng, np), dim3(MSM_PART_TILE), part_lds, s, d_scalars, scalar_stride, n, g, ng, sb.crel, sb.dense, sb.tmp, sb.tmpf, wide);
+        MASP_LAUNCH(k_msm_bucketize, dim3(nbins, np), dim3(1024), 0, s, sb.tmp, sb.tmpf, (size_t)n * g.W, sb.dense, sb.start, nb, sb.sorted, sb.ent_stride, wide);
     } else {
         // (the single-pass placement writes entries only: aligned runs get their padding from a fill first)
-        if (pad_log || g.rg > 1) HIP_TRY(hipMemsetAsync(sb.sorted, 0xff, 4 * sb.ent_stride * np, s));
+        if (pad_log) HIP_TRY(hipMemsetAsync(sb.sorted, 0xff, 4 * sb.ent_stride * np, s));
         MASP_LAUNCH(k_msm_scatter, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg, sb.start,
-                           sb.dense, sb.sorted, sb.ent_stride);
+                           sb.sorted, sb.ent_stride);
     }
     return launch_status();
 }

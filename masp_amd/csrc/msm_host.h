@@ -43,15 +43,14 @@ struct MsmBases {
     }
     // raw: device pointer to n uncompressed points (bellman wire format)          [msm_impl.cuh]
     // force_c: digit width (0: pick_geom); naf: NAF digits (force_c is then the NAF width: one more than the window with as many buckets)
-    // regions > 1 (with naf): the table in MSM_REGIONS regions, one per XCD (device/msm_geom.h msm_row)
-    int load_device(const uint8_t* d_raw, uint32_t n_, hipStream_t s, uint32_t n_eff = 0xffffffffu, int force_c = 0, bool naf = false, int regions = 1);
-    int load_host(const uint8_t* raw, uint32_t n_, hipStream_t s, uint32_t n_eff = 0xffffffffu, int force_c = 0, bool naf = false, int regions = 1) {
+    int load_device(const uint8_t* d_raw, uint32_t n_, hipStream_t s, uint32_t n_eff = 0xffffffffu, int force_c = 0, bool naf = false);
+    int load_host(const uint8_t* raw, uint32_t n_, hipStream_t s, uint32_t n_eff = 0xffffffffu, int force_c = 0, bool naf = false) {
         uint8_t* d_raw = nullptr;
         if (n_) {
             HIP_TRY(dev_malloc(&d_raw, (size_t)n_ * BYTES));
             HIP_TRY(hipMemcpyAsync(d_raw, raw, (size_t)n_ * BYTES, hipMemcpyHostToDevice, s));
         }
-        int rc = load_device(d_raw, n_, s, n_eff, force_c, naf, regions);
+        int rc = load_device(d_raw, n_, s, n_eff, force_c, naf);
         if (d_raw) dev_free(d_raw);
         return rc;
     }
@@ -77,9 +76,7 @@ struct MsmSortBuf {
     size_t ent_stride = 0;
     static size_t padded_entries(uint32_t n_, const MsmGeom& g_, uint32_t pad_log_) {
         const size_t unit = (size_t)1 << pad_log_;
-        // (table regions: every region's share of a bucket is padded to an even length first — at most one entry per bucket and region)
-        const size_t sub = g_.rg > 1 ? (size_t)g_.nb * g_.rg : 0;
-        return ((size_t)n_ * g_.W + sub + (size_t)g_.nb * (unit - 1) + unit - 1) / unit * unit;
+        return ((size_t)n_ * g_.W + (size_t)g_.nb * (unit - 1) + unit - 1) / unit * unit;
     }
 
     ~MsmSortBuf() { release(); }
@@ -92,8 +89,7 @@ struct MsmSortBuf {
         cap_ent = cap_nb = cap_np = cap_hist = cap_crel = 0;
     }
     // scalar ranges (= sorting workgroups) per proof: enough to occupy the chip across the batch, not more
-    static uint32_t ranges_for(uint32_t n, uint32_t np, int rg = 1) {
-        if (rg > 1) return (uint32_t)rg;  // table regions: one range per region (the scalars i = r mod rg)
+    static uint32_t ranges_for(uint32_t n, uint32_t np) {
         uint32_t ng = std::max(1u, 512u / std::max(np, 1u));
         ng = std::min(ng, 64u);
         return std::max(1u, std::min(ng, (n + 1023) / 1024));
@@ -101,7 +97,7 @@ struct MsmSortBuf {
     int reserve(uint32_t n_, const MsmGeom& g_, uint32_t np_, uint32_t pad_log_ = 0) {
         // the per-workgroup histograms are addressed with the launch's own strides: np x ng x nb words, and np x ng <= 512
         // for every batch size (ranges_for) — a batch of 64 proofs (8 ranges each) fits what a batch of 256 (2 each) allocated
-        const size_t need_ent = std::max(padded_entries(n_, g_, pad_log_), cap_ent), ng = ranges_for(n_, np_, g_.rg);
+        const size_t need_ent = std::max(padded_entries(n_, g_, pad_log_), cap_ent), ng = ranges_for(n_, np_);
         const size_t bins = std::max<size_t>(g_.nb >> 7, 1);
         const size_t hist_need = (size_t)np_ * ng * g_.nb, crel_need = (size_t)np_ * ng * bins;
         if (need_ent <= cap_ent && (size_t)g_.nb <= cap_nb && np_ <= cap_np && hist_need <= cap_hist && crel_need <= cap_crel) return MASP_HIP_OK;
@@ -177,9 +173,6 @@ struct MsmTreeWs {
     MsmTreeArena* arena = &own;           // a slot points the trees of its workspaces at one arena
     uint32_t *D = nullptr, *Q = nullptr;  // [level][proof][nb + 1]
     uint2* rec = nullptr;  // pair records of the levels >= 1 (level 0 reads the digit list itself)
-    uint4* rl = nullptr;        // table regions: level 0's pairs region by region (k_tree_region_records), q x pairs_ub(0)
-    uint32_t* rcnt = nullptr;   // ... [q][MSM_REGIONS][chunks]: pairs of a region in each chunk of TREE_RG_CHUNK pairs, then their exclusive scan
-    uint32_t* rtot = nullptr;   // ... [q][MSM_REGIONS]: pairs per region
     F *pre = nullptr, *tp = nullptr, *tinv = nullptr, *bpre = nullptr, *btot = nullptr, *bitot = nullptr, *bpre2 = nullptr;
     F *px[2] = {nullptr, nullptr}, *py[2] = {nullptr, nullptr};  // points of the odd / even levels
     // what the last msm_tree_enqueue produced
@@ -188,7 +181,7 @@ struct MsmTreeWs {
     size_t pre_cap = 0;  // elements of the plane `pre`
     struct MsmProfile* prof = nullptr;  // set by msm_reduce_enqueue while a profiled MSM runs through the tree (MsmProfile::mark)
 
-    int reserve(uint64_t E_ub, uint32_t nb, uint32_t q, uint32_t T, bool regions = false);   // [msm_tree_impl.cuh]
+    int reserve(uint64_t E_ub, uint32_t nb, uint32_t q, uint32_t T);                 // [msm_tree_impl.cuh]
     void batch_invert(hipStream_t s, const F* in, uint32_t n, F* out);              // [msm_tree_impl.cuh]
     const F* points_x() const { return px[T & 1]; }
     const F* points_y() const { return py[T & 1]; }

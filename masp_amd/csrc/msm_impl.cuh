@@ -26,26 +26,24 @@ static inline uint32_t log2_ceil_u64(uint64_t n) {
 }
 
 template <class O, int BYTES>
-int MsmBases<O, BYTES>::load_device(const uint8_t* d_raw, uint32_t n_, hipStream_t s, uint32_t n_eff, int force_c, bool naf, int regions) {
+int MsmBases<O, BYTES>::load_device(const uint8_t* d_raw, uint32_t n_, hipStream_t s, uint32_t n_eff, int force_c, bool naf) {
         release();
         n = n_;
         this->n_eff = std::min(n_eff, n_);
         g = force_c ? (naf ? msm_geom_naf(force_c) : msm_geom(force_c)) : pick_geom(std::min(n_eff, n_), naf);
-        if (naf && regions > 1) g.rg = MSM_REGIONS;
         if (n == 0) return MASP_HIP_OK;
-        if (msm_table_rows(g, n) > 0x7ffffffeull) {
+        if ((uint64_t)n * (uint32_t)g.tpos > 0x7ffffffeull) {
             last_hip_error() = "MsmBases: more table rows than an entry's 31 bits can name";
             return MASP_HIP_E_INVALID_ARG;
         }
-        HIP_TRY(dev_malloc(&tab, sizeof(TabRow<O>) * (size_t)msm_table_rows(g, n)));
-        // (with regions the last rows of a region's tables may belong to no point: they are never named by an entry)
+        HIP_TRY(dev_malloc(&tab, sizeof(TabRow<O>) * (size_t)g.tpos * n));
         int* d_status;
         HIP_TRY(dev_malloc(&d_status, sizeof(int)));
         HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(int), s));
         dim3 grid((n + 63) / 64), block(64);
-        MASP_LAUNCH((k_msm_import<O, BYTES>), grid, block, 0, s, d_raw, tab, n, d_status, g);
+        MASP_LAUNCH((k_msm_import<O, BYTES>), grid, block, 0, s, d_raw, tab, n, d_status);
         if (g.naf)
-            MASP_LAUNCH((k_msm_precompute_bits<O, 4>), grid, block, 0, s, tab, n, g);
+            MASP_LAUNCH((k_msm_precompute_bits<O, 4>), grid, block, 0, s, tab, n, g.tpos);
         else
             MASP_LAUNCH((k_msm_precompute<O>), grid, block, 0, s, tab, n, g.c, g.W);
         HIP_TRY(hipMemcpyAsync(&import_status, d_status, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -183,7 +181,7 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
                        MsmProfile* prof) {
     const MsmGeom& g = B.g;
     const uint32_t n = B.n, np = sb.np;
-    if (sb.n != n || sb.g.c != g.c || sb.g.naf != g.naf || sb.g.rg != g.rg) {
+    if (sb.n != n || sb.g.c != g.c || sb.g.naf != g.naf) {
         last_hip_error() = "msm_reduce_enqueue: sort does not match the base set";
         return MASP_HIP_E_INVALID_ARG;
     }

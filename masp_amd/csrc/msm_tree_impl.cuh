@@ -26,22 +26,19 @@ struct TreeLaneOps {
 #define MASP_TREE_KP 128   // pairs per lane of the two passes (16 / 32 / 64 / 128 / 256 measured: 955 / 981 / 997 / 1007 / 1009 proofs/s)
 #endif
 static constexpr uint32_t MSM_TREE_KP = MASP_TREE_KP;
-// (2 048 lanes at a time: with table regions workgroup x of a pass takes region x mod 8, so a pass has a multiple of 8 workgroups)
 static inline uint32_t tree_lanes(uint64_t E_ub, uint32_t nb, uint32_t L) {
     const uint32_t pairs = tree_pairs_ub(E_ub, nb, L);
-    return std::max<uint32_t>(2048u, ((pairs + MSM_TREE_KP - 1) / MSM_TREE_KP + 2047u) & ~2047u);
+    return std::max<uint32_t>(256u, ((pairs + MSM_TREE_KP - 1) / MSM_TREE_KP + 255u) & ~255u);
 }
 
 template <class O>
-int MsmTreeWs<O>::reserve(uint64_t E_ub, uint32_t nb, uint32_t q, uint32_t T, bool regions) {
+int MsmTreeWs<O>::reserve(uint64_t E_ub, uint32_t nb, uint32_t q, uint32_t T) {
     const size_t plan = (size_t)(T + 1) * q * (nb + 1);
     const size_t recs = (size_t)q * tree_pairs_ub(E_ub, nb, 1);
     const size_t NT0 = tree_lanes(E_ub, nb, 0);
     const size_t lanes = (size_t)q * NT0;
     // pre[(j q + p) NT + t], j < ceil(pairs / NT) <= KP (+1 for the rounding of NT): bounded by level 0
-    // (with table regions `pre` is indexed by the pair's place in its proof's lists: q x pairs_ub(0) elements, which the bound below covers)
     const size_t pres = (size_t)((tree_pairs_ub(E_ub, nb, 0) + NT0 - 1) / NT0) * lanes;
-    const size_t rl_n = regions ? (size_t)q * tree_pairs_ub(E_ub, nb, 0) : 0;
     pre_cap = pres;
     const size_t pts1 = (size_t)q * tree_points_ub(E_ub, nb, 1), pts2 = T >= 2 ? (size_t)q * tree_points_ub(E_ub, nb, 2) : 0;
     const size_t m1 = (lanes + BINV_C - 1) / BINV_C;
@@ -55,9 +52,7 @@ int MsmTreeWs<O>::reserve(uint64_t E_ub, uint32_t nb, uint32_t q, uint32_t T, bo
     const size_t oD = take(4 * plan), oQ = take(4 * plan), oRec = take(sizeof(uint2) * recs), oPre = take(sizeof(F) * pres), oTp = take(sizeof(F) * lanes),
                  oTinv = take(sizeof(F) * lanes), oBpre = take(sizeof(F) * lanes), oBtot = take(sizeof(F) * m1), oBitot = take(sizeof(F) * m1),
                  oBpre2 = take(sizeof(F) * m1), oX1 = take(sizeof(F) * pts1), oY1 = take(sizeof(F) * pts1), oX0 = take(sizeof(F) * pts2),
-                 oY0 = take(sizeof(F) * pts2), oRl = take(sizeof(uint4) * rl_n),
-                 oRcnt = take(regions ? 4 * (size_t)q * MSM_REGIONS * ((tree_pairs_ub(E_ub, nb, 0) + TREE_RG_CHUNK - 1) / TREE_RG_CHUNK) : 0),
-                 oRtot = take(regions ? 4 * (size_t)q * MSM_REGIONS : 0);
+                 oY0 = take(sizeof(F) * pts2);
     int rc = arena->reserve(off);
     if (rc) return rc;
     uint8_t* b = arena->p;
@@ -75,9 +70,6 @@ int MsmTreeWs<O>::reserve(uint64_t E_ub, uint32_t nb, uint32_t q, uint32_t T, bo
     py[1] = (F*)(b + oY1);
     px[0] = (F*)(b + oX0);
     py[0] = (F*)(b + oY0);
-    rl = regions ? (uint4*)(b + oRl) : nullptr;
-    rcnt = regions ? (uint32_t*)(b + oRcnt) : nullptr;
-    rtot = regions ? (uint32_t*)(b + oRtot) : nullptr;
     return MASP_HIP_OK;
 }
 
@@ -111,12 +103,7 @@ int msm_tree_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSortBu
         return MASP_HIP_E_INVALID_ARG;
     }
     const uint64_t E_ub = sb.ent_stride;  // entries per proof, the padding included
-    const bool regions = B.g.rg > 1;
-    if (regions && sb.g.rg != B.g.rg) {
-        last_hip_error() = "msm_tree_enqueue: the sort was not made for this base set's table regions";
-        return MASP_HIP_E_INVALID_ARG;
-    }
-    int rc = tw.reserve(E_ub, nb, q, T, regions);
+    int rc = tw.reserve(E_ub, nb, q, T);
     if (rc) return rc;
     tw.q = q;
     tw.nb = nb;
@@ -148,19 +135,8 @@ int msm_tree_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSortBu
         const void* recL = L >= sb.pad_log ? (const void*)tw.rec : nullptr;  // levels >= 1: records, or none below pad_log
         const void* rec0 = (const void*)sorted;
         const size_t rec0_stride = ent_stride / 2;
-        // table regions: level 0's pairs by region (k_tree_region_records), workgroup x of the two passes on region x mod 8 = its XCD
-        const size_t rl_stride = tree_pairs_ub(E_ub, nb, 0);
-        const uint32_t* rtot = tw.rtot;
-        if (L == 0 && regions) {
-            const uint32_t chunks = (pairs_ub + TREE_RG_CHUNK - 1) / TREE_RG_CHUNK, region_rows = msm_region_rows(B.n, B.g.rg) * (uint32_t)B.g.tpos;
-            MASP_LAUNCH(k_tree_region_count, dim3(chunks, q), block, 0, s, sorted, ent_stride, start, nb, region_rows, tw.rcnt);
-            MASP_LAUNCH(k_tree_region_scan, dim3(MSM_REGIONS, q), dim3(1024), 0, s, tw.rcnt, chunks, tw.rtot);
-            MASP_LAUNCH(k_tree_region_place, dim3(chunks, q), block, 0, s, sorted, ent_stride, start, nb, region_rows, tw.rcnt, tw.rtot, tw.rl, rl_stride);
-            if (prof) prof->mark(s, MsmProfile::PH_PLAN);
-            MASP_LAUNCH((k_tree_pass1<O1, TREE_L0_REGIONS>), grid1, block, 0, s, B.tab, (const F1*)xi, (const F1*)yi, si, (const void*)tw.rl, rl_stride, rtot, nb,
-                               NT, (F1*)tw.pre, pre_cap1, (F1*)tw.tp);
-        } else if (L == 0) {
-            MASP_LAUNCH((k_tree_pass1<O1, TREE_L0>), grid1, block, 0, s, B.tab, (const F1*)xi, (const F1*)yi, si, rec0, rec0_stride, Ql, nb, NT,
+        if (L == 0) {
+            MASP_LAUNCH((k_tree_pass1<O1, true>), grid1, block, 0, s, B.tab, (const F1*)xi, (const F1*)yi, si, rec0, rec0_stride, Ql, nb, NT,
                                (F1*)tw.pre, pre_cap1, (F1*)tw.tp);
         } else {
             // (a level below the sort's pad_log has runs of even lengths only: no records, no odd points to copy)
@@ -168,7 +144,7 @@ int msm_tree_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSortBu
                 MASP_LAUNCH(k_tree_records, rgrid, block, 0, s, Dl, Dn, Ql, nb, tw.rec, rec_stride);
                 if (prof) prof->mark(s, MsmProfile::PH_PLAN);
             }
-            MASP_LAUNCH((k_tree_pass1<O1, TREE_DEEP>), grid1, block, 0, s, B.tab, (const F1*)xi, (const F1*)yi, si, recL, rec_stride, Ql, nb,
+            MASP_LAUNCH((k_tree_pass1<O1, false>), grid1, block, 0, s, B.tab, (const F1*)xi, (const F1*)yi, si, recL, rec_stride, Ql, nb,
                                NT, (F1*)tw.pre, pre_cap1, (F1*)tw.tp);
         }
         if (prof) prof->mark(s, MsmProfile::PH_PASS1);
@@ -178,14 +154,11 @@ int msm_tree_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSortBu
         typedef typename O2::T F2;
         const dim3 grid2(NT * O2::LANES / 256, q);
         const size_t pre_cap2 = tw.pre_cap * sizeof(F) / sizeof(F2);
-        if (L == 0 && regions)
-            MASP_LAUNCH((k_tree_pass2<O2, TREE_L0_REGIONS>), grid2, block, 0, s, B.tab, (const F2*)xi, (const F2*)yi, si, (const void*)tw.rl, rl_stride, rtot, nb,
-                               NT, (const F2*)tw.pre, pre_cap2, (const F2*)tw.tinv, (F2*)xo, (F2*)yo, so, out_whole);
-        else if (L == 0)
-            MASP_LAUNCH((k_tree_pass2<O2, TREE_L0>), grid2, block, 0, s, B.tab, (const F2*)xi, (const F2*)yi, si, rec0, rec0_stride, Ql, nb, NT,
+        if (L == 0)
+            MASP_LAUNCH((k_tree_pass2<O2, true>), grid2, block, 0, s, B.tab, (const F2*)xi, (const F2*)yi, si, rec0, rec0_stride, Ql, nb, NT,
                                (const F2*)tw.pre, pre_cap2, (const F2*)tw.tinv, (F2*)xo, (F2*)yo, so, out_whole);
         else
-            MASP_LAUNCH((k_tree_pass2<O2, TREE_DEEP>), grid2, block, 0, s, B.tab, (const F2*)xi, (const F2*)yi, si, recL, rec_stride, Ql,
+            MASP_LAUNCH((k_tree_pass2<O2, false>), grid2, block, 0, s, B.tab, (const F2*)xi, (const F2*)yi, si, recL, rec_stride, Ql,
                                nb, NT, (const F2*)tw.pre, pre_cap2, (const F2*)tw.tinv, (F2*)xo, (F2*)yo, so, out_whole);
         if (prof) prof->mark(s, MsmProfile::PH_PASS2);
         // (level 0 has no odd runs: a run of odd length met its padding entry as P + infinity)

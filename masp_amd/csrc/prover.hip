@@ -326,10 +326,10 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
         if ((rc = msm_enqueue(s, C.hl, sl.ws1, (const uint32_t*)sl.hl.p, hl_stride * 8, sl.res1.p + 0, 4, np, prof))) return rc;
         // L is inside H + L: its slot of every proof is the point at infinity (one strided fill, not np of them)
         HIP_TRY(hipMemset2DAsync(sl.res1.p + 1, 4 * sizeof(G1Xyzz), 0, sizeof(G1Xyzz), np, s));
-        // (masp_hip_options::digit_recoding = 1: the batch's own base sets — NAF digits, per-bit tables in regions)
+        // (masp_hip_options::digit_recoding = 1: the batch's own base sets — NAF digits, a table per bit position)
         const BasesG1 &Aq = C.a_naf.n ? C.a_naf : C.a, &B1q = C.b1_naf.n ? C.b1_naf : C.b1;
         const BasesG2& B2q = C.b2_naf.n ? C.b2_naf : C.b2;
-        const bool share_bq = C.nbq && B2q.n == B1q.n && B2q.g.c == B1q.g.c && B2q.g.naf == B1q.g.naf && B2q.g.rg == B1q.g.rg;
+        const bool share_bq = C.nbq && B2q.n == B1q.n && B2q.g.c == B1q.g.c && B2q.g.naf == B1q.g.naf;
         if ((rc = msm_enqueue(s, Aq, sl.ws1, (const uint32_t*)sl.sa.p, (size_t)C.na * 8, sl.res1.p + 2, 4, np, prof))) return rc;
         if ((rc = msm_enqueue(s, B1q, sl.ws1, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res1.p + 3, 4, np, prof))) return rc;
         if (share_bq) {
@@ -812,17 +812,16 @@ int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* param
     const int c_h_lone = ctx->opt.window_bits_h_lone ? ctx->opt.window_bits_h_lone : c_h;
     // Digits (masp_hip_options::digit_recoding = 1; default fixed windows): a BATCH runs its MSMs (h + l merged, a, b_g1, b_g2) on
     // width-(c + 1) NAF digits over a table per bit position — as many buckets as c-bit windows, 8 % (h + l) to 15 % (the witness
-    // queries) fewer entries to add (device/msm_geom.h) —, the tables cut into one region per XCD; lone proofs keep fixed windows and
-    // their compact tables (h, l, a, b_g1, b_g2).
+    // queries) fewer entries to add (device/msm_geom.h); lone proofs keep fixed windows and their compact tables (h, l, a, b_g1, b_g2).
     const bool naf = ctx->opt.digit_recoding > 0;
     auto nafw = [&](int c) { return c ? c + 1 : 0; };
     if ((rc = C->h.load_host(L.h, (uint32_t)(C->m - 1), s, 0xffffffffu, c_h_lone)) || (rc = C->l.load_host(L.l, L.n_l, s, eff(L.n_l), c_la)) ||
         (rc = C->a.load_host(L.a, L.n_a, s, eff(L.n_a), c_la)) || (rc = C->b1.load_host(L.b_g1, L.n_b1, s, eff(L.n_b1), c_b)) ||
         (rc = C->b2.load_host(L.b_g2, L.n_b2, s, eff(L.n_b2), c_b)))
         return fail(ctx, rc);
-    if (naf && ((rc = C->a_naf.load_host(L.a, L.n_a, s, eff(L.n_a), nafw(c_la), true, MSM_REGIONS)) ||
-                (rc = C->b1_naf.load_host(L.b_g1, L.n_b1, s, eff(L.n_b1), nafw(c_b), true, MSM_REGIONS)) ||
-                (rc = C->b2_naf.load_host(L.b_g2, L.n_b2, s, eff(L.n_b2), nafw(c_b), true, MSM_REGIONS))))
+    if (naf && ((rc = C->a_naf.load_host(L.a, L.n_a, s, eff(L.n_a), nafw(c_la), true)) ||
+                (rc = C->b1_naf.load_host(L.b_g1, L.n_b1, s, eff(L.n_b1), nafw(c_b), true)) ||
+                (rc = C->b2_naf.load_host(L.b_g2, L.n_b2, s, eff(L.n_b2), nafw(c_b), true))))
         return fail(ctx, rc);
     {
         const int c_lone = ctx->opt.window_bits_b2_lone;  // 0 = lone proofs share the batch tables (and B1's sort)
@@ -834,7 +833,7 @@ int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* param
         memcpy(cat.data(), L.h, 96 * nh);
         memcpy(cat.data() + 96 * nh, L.l, 96 * (size_t)L.n_l);
         const int c_hl = c_h ? c_h : ctx->opt.window_bits_h_lone ? 0 : C->h.g.c;
-        if ((rc = C->hl.load_host(cat.data(), (uint32_t)(nh + L.n_l), s, 0xffffffffu, naf ? nafw(c_hl) : c_hl, naf, naf ? MSM_REGIONS : 1))) return fail(ctx, rc);
+        if ((rc = C->hl.load_host(cat.data(), (uint32_t)(nh + L.n_l), s, 0xffffffffu, naf ? nafw(c_hl) : c_hl, naf))) return fail(ctx, rc);
     }
     int st = C->h.import_status | C->l.import_status | C->a.import_status | C->b1.import_status | C->b2.import_status;
     if (st) return MASP_HIP_E_PARAMS_FORMAT;  // includes infinity inside a query vector, which bellman rejects
@@ -1129,8 +1128,7 @@ int masp_hip_prove(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* inputs, cons
 template <class O, int BYTES>
 static int msm_multi(masp_hip_ctx* ctx, const uint8_t* bases, size_t n, const uint8_t* scalars, size_t np, int window_bits, uint8_t* out) {
     const bool naf = window_bits > 0 && (window_bits & MASP_HIP_MSM_NAF) != 0;
-    const bool regions = naf && (window_bits & MASP_HIP_MSM_REGIONS) != 0;
-    if (naf) window_bits &= ~(MASP_HIP_MSM_NAF | MASP_HIP_MSM_REGIONS);
+    if (naf) window_bits &= ~MASP_HIP_MSM_NAF;
     if (!ctx || !out || !np || np > 256 || !n || !bases || !scalars || n > (1u << 22) || window_bits < 0 || window_bits == 1 || window_bits > 16 + (naf ? 1 : 0) ||
         (naf && window_bits < 4))
         return MASP_HIP_E_INVALID_ARG;
@@ -1157,7 +1155,7 @@ static int msm_multi(masp_hip_ctx* ctx, const uint8_t* bases, size_t n, const ui
     DevBuf<Xyzz<O>> res;
     DevBuf<uint8_t> d_out;
     int rc;
-    if ((rc = B.load_host(bases, (uint32_t)n, s, 0xffffffffu, window_bits, naf, regions ? MSM_REGIONS : 1))) return fail(ctx, rc);
+    if ((rc = B.load_host(bases, (uint32_t)n, s, 0xffffffffu, window_bits, naf))) return fail(ctx, rc);
     if (B.import_status & (PT_BAD_FLAGS | PT_NOT_CANONICAL)) return MASP_HIP_E_PARAMS_FORMAT;
     if ((rc = ctx->tmp_scalars.upload((const Fr*)scalars, n * np, s)) || (rc = res.reserve(np)) || (rc = d_out.reserve(BYTES * np))) return fail(ctx, rc);
     if ((rc = msm_enqueue(s, B, ws, (const uint32_t*)ctx->tmp_scalars.p, n * 8, res.p, 1, (uint32_t)np))) return fail(ctx, rc);

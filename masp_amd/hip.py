@@ -39,7 +39,6 @@ class JobStruct(C.Structure):
 
 AUX_CANONICAL, AUX_MONTGOMERY = 0, 1     # masp_hip_job::aux_form
 MSM_NAF = 0x100                          # masp_hip_msm_g{1,2}_multi: window_bits = MSM_NAF | w (MASP_HIP_MSM_NAF)
-MSM_REGIONS = 0x200                      # ... | MSM_REGIONS: the table in one region per XCD (MASP_HIP_MSM_REGIONS)
 
 
 def library_path():
