@@ -33,7 +33,7 @@ int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb
     // 0.57 ms for 600 000 entries) the single-pass scatter over the scalar ranges is the shorter chain
     constexpr int PART_W_MAX = 30;  // 5 bytes x 1024 x 30 + the bins' counters = 154 KiB of the 160 KiB LDS
     const bool two_pass = nb >= MSM_FINE && g.W <= PART_W_MAX && (uint64_t)(nb >> MSM_FINE_LOG) * np >= 8;
-    const uint32_t wide = (uint64_t)n * (uint32_t)g.tpos > (1u << 24) ? 1u : 0u;  // the low bucket bits of an entry in `tmpf` instead of the entry word
+    const uint32_t wide = MsmSortBuf::msm_rows_wide(n, g) ? 1u : 0u;  // the low bucket bits of an entry in `tmpf` instead of the entry word
     const int part_lds = 4 * (4 * 256 + 8) + 5 * (int)MSM_PART_TILE * g.W;
     static PerDeviceOnce once;
     const bool lds_ok = once([] {

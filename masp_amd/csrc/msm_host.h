@@ -61,7 +61,10 @@ struct MsmSortBuf {
     size_t cap_ent = 0, cap_nb = 0, cap_np = 0, cap_hist = 0, cap_crel = 0;  // cap_hist, cap_crel: words
     uint32_t *sorted = nullptr, *hist_wg = nullptr, *start = nullptr;
     uint32_t *tmp = nullptr, *crel = nullptr;  // two-pass placement: entries grouped by coarse bin; per-range offsets of the bins
-    uint8_t* tmpf = nullptr;                   // ... and the low 7 bits of every such entry's bucket
+    uint8_t* tmpf = nullptr;                   // ... and the low 7 bits of every such entry's bucket, where the entry word has no room
+                                               // for them (msm_rows_wide: a table per bit position); not allocated otherwise
+    bool has_tmpf = false;
+    static bool msm_rows_wide(uint32_t n_, const MsmGeom& g_) { return (uint64_t)n_ * (uint32_t)g_.tpos > (1u << 24); }
     uint32_t* dense = nullptr;                 // [np][nb + 1] offsets without padding (where a bin lies in `tmp`)
     // what the last msm_sort_enqueue produced (consumed by msm_reduce_enqueue)
     uint32_t n = 0, np = 0;
@@ -86,6 +89,7 @@ struct MsmSortBuf {
             if (p) dev_free(p);
         sorted = hist_wg = start = tmp = crel = dense = nullptr;
         tmpf = nullptr;
+        has_tmpf = false;
         cap_ent = cap_nb = cap_np = cap_hist = cap_crel = 0;
     }
     // scalar ranges (= sorting workgroups) per proof: enough to occupy the chip across the batch, not more
@@ -100,7 +104,9 @@ struct MsmSortBuf {
         const size_t need_ent = std::max(padded_entries(n_, g_, pad_log_), cap_ent), ng = ranges_for(n_, np_);
         const size_t bins = std::max<size_t>(g_.nb >> 7, 1);
         const size_t hist_need = (size_t)np_ * ng * g_.nb, crel_need = (size_t)np_ * ng * bins;
-        if (need_ent <= cap_ent && (size_t)g_.nb <= cap_nb && np_ <= cap_np && hist_need <= cap_hist && crel_need <= cap_crel) return MASP_HIP_OK;
+        const bool want_tmpf = has_tmpf || msm_rows_wide(n_, g_);
+        if (need_ent <= cap_ent && (size_t)g_.nb <= cap_nb && np_ <= cap_np && hist_need <= cap_hist && crel_need <= cap_crel && want_tmpf == has_tmpf)
+            return MASP_HIP_OK;
         const size_t need_nb = std::max<size_t>(g_.nb, cap_nb), need_np = std::max<size_t>(np_, cap_np);
         const size_t rows = std::max<size_t>(need_np, 512);
         const size_t need_hist = std::max(std::max(hist_need, cap_hist), rows * need_nb);
@@ -111,7 +117,7 @@ struct MsmSortBuf {
             HIP_TRY(dev_malloc(&hist_wg, 4 * need_hist));
             HIP_TRY(dev_malloc(&start, need_np * 4 * (need_nb + 1)));
             HIP_TRY(dev_malloc(&tmp, need_np * 4 * std::max<size_t>(need_ent, 1)));
-            HIP_TRY(dev_malloc(&tmpf, need_np * std::max<size_t>(need_ent, 1)));
+            if (want_tmpf) HIP_TRY(dev_malloc(&tmpf, need_np * std::max<size_t>(need_ent, 1)));
             HIP_TRY(dev_malloc(&crel, 4 * need_crel));
             HIP_TRY(dev_malloc(&dense, need_np * 4 * (need_nb + 1)));
             return MASP_HIP_OK;
@@ -120,6 +126,7 @@ struct MsmSortBuf {
             release();
             return rc;
         }
+        has_tmpf = want_tmpf;
         cap_ent = need_ent;
         cap_nb = need_nb;
         cap_np = need_np;
