@@ -313,7 +313,8 @@ k_msm_partition(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint
     uint32_t* total = fill + 256;          // [1] (+3 pad)
     uint32_t* wsum = total + 4;            // [4]
     uint32_t* stage = wsum + 4;            // [MSM_PART_TILE * W]
-    uint8_t* stagef = reinterpret_cast<uint8_t*>(stage + MSM_PART_TILE * (uint32_t)g.W);  // [MSM_PART_TILE * W]
+    uint8_t* stageb = reinterpret_cast<uint8_t*>(stage + MSM_PART_TILE * (uint32_t)g.W);  // [MSM_PART_TILE * W] the bin of a staged entry
+    uint8_t* stagef = stageb + MSM_PART_TILE * (uint32_t)g.W;                              // [MSM_PART_TILE * W] its low bucket bits (wide only)
     scalars += MSM_P * scalar_stride;
     crel += ((size_t)MSM_P * ng + wg) * nbins;
     start += (size_t)MSM_P * (nb + 1);
@@ -358,6 +359,7 @@ k_msm_partition(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint
         __syncthreads();
         if (cls == 1) {
             stage[off[0] + unit_rank] = i;
+            stageb[off[0] + unit_rank] = 0;
             if (wide) stagef[off[0] + unit_rank] = 0;
         }
         if (cls == 2) {
@@ -366,13 +368,14 @@ k_msm_partition(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint
                 if (key[j] != 0xffffffffu) {
                     const uint32_t at = off[(key[j] >> 16) & 0xffu] + (key[j] & 0xffffu);
                     stage[at] = ent[j];
+                    stageb[at] = (uint8_t)(key[j] >> 16);
                     if (wide) stagef[at] = (uint8_t)(key[j] >> 24);
                 }
         }
         __syncthreads();
         const uint32_t tot = *total;
         for (uint32_t k = tid; k < tot; k += MSM_PART_TILE) {
-            const uint32_t B = msm_find_run(off, nbins, k);
+            const uint32_t B = stageb[k];  // (a binary search in off[] — eight dependent LDS loads per entry — found it before round 5)
             const uint32_t at = cursor[B] + (k - off[B]);
             tmp[at] = stage[k];
             if (wide) tmpf[at] = stagef[k];
@@ -385,6 +388,7 @@ __global__ void __launch_bounds__(1024)
 k_msm_bucketize(const uint32_t* __restrict__ tmp, const uint8_t* __restrict__ tmpf, size_t tmp_stride, const uint32_t* __restrict__ dense,
                 const uint32_t* __restrict__ start, uint32_t nb, uint32_t* __restrict__ sorted, size_t sorted_stride, uint32_t wide) {
     __shared__ uint32_t cur[MSM_FINE], cnt[MSM_FINE], off[MSM_FINE], fill[MSM_FINE], total[4], wsum[4], stage[MSM_BKT_TILE];
+    __shared__ uint8_t stagef[MSM_BKT_TILE];  // the low bucket bits of a staged entry (wide: the entry word does not carry them)
     const uint32_t tid = threadIdx.x, B = blockIdx.x;
     tmp += MSM_P * tmp_stride;
     tmpf += MSM_P * tmp_stride;
@@ -422,13 +426,17 @@ k_msm_bucketize(const uint32_t* __restrict__ tmp, const uint8_t* __restrict__ tm
 #pragma unroll
         for (uint32_t q = 0; q < MSM_BKT_TILE / 1024; ++q) {
             const uint32_t k = base + q * 1024 + tid;
-            if (k < hi) stage[off[fr[q] & 0xffu] + (fr[q] >> 8)] = wide ? e[q] : e[q] & 0x80ffffffu;
+            if (k < hi) {
+                const uint32_t at = off[fr[q] & 0xffu] + (fr[q] >> 8);
+                stage[at] = e[q];
+                if (wide) stagef[at] = (uint8_t)fr[q];
+            }
         }
         __syncthreads();
         const uint32_t tot = *total;
         for (uint32_t k = tid; k < tot; k += 1024) {
-            const uint32_t f = msm_find_run(off, MSM_FINE, k);
-            sorted[cur[f] + (k - off[f])] = stage[k];
+            const uint32_t v = stage[k], f = wide ? (uint32_t)stagef[k] : (v >> 24) & (MSM_FINE - 1u);  // (no search in off[]: the entry knows its bucket)
+            sorted[cur[f] + (k - off[f])] = wide ? v : v & 0x80ffffffu;
         }
         __syncthreads();
         if (tid < MSM_FINE) cur[tid] += cnt[tid];

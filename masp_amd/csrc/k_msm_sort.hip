@@ -31,17 +31,18 @@ int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb
     // two-pass placement (runs instead of single scattered words): the first pass stages a tile's entries (a word and a byte each) in LDS
     // ... and the second pass is one workgroup per (proof, coarse bin): with too few of them (a lone proof's b_g2 on 8-bit windows: ONE,
     // 0.57 ms for 600 000 entries) the single-pass scatter over the scalar ranges is the shorter chain
-    constexpr int PART_W_MAX = 30;  // 5 bytes x 1024 x 30 + the bins' counters = 154 KiB of the 160 KiB LDS
-    const bool two_pass = nb >= MSM_FINE && g.W <= PART_W_MAX && (uint64_t)(nb >> MSM_FINE_LOG) * np >= 8;
     const uint32_t wide = MsmSortBuf::msm_rows_wide(n, g) ? 1u : 0u;  // the low bucket bits of an entry in `tmpf` instead of the entry word
-    const int part_lds = 4 * (4 * 256 + 8) + 5 * (int)MSM_PART_TILE * g.W;
+    // LDS of the first pass: the bins' counters + per staged entry a word and a byte (its bin), wide: one more byte — of the 160 KiB of a CU
+    const int part_entry = wide ? 6 : 5, part_fixed = 4 * (4 * 256 + 8), part_w_max = std::min(30, (160 * 1024 - part_fixed) / ((int)MSM_PART_TILE * part_entry));
+    const bool two_pass = nb >= MSM_FINE && g.W <= part_w_max && (uint64_t)(nb >> MSM_FINE_LOG) * np >= 8;
+    const int part_lds = part_fixed + part_entry * (int)MSM_PART_TILE * g.W;
     static PerDeviceOnce once;
     const bool lds_ok = once([] {
         int bytes = 4 << 15;
         return hipFuncSetAttribute((const void*)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
                hipFuncSetAttribute((const void*)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
                hipFuncSetAttribute((const void*)k_msm_partition, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   4 * (4 * 256 + 8) + 5 * (int)MSM_PART_TILE * PART_W_MAX) == hipSuccess;
+                                   4 * (4 * 256 + 8) + 5 * (int)MSM_PART_TILE * 30) == hipSuccess;  // = the largest part_lds below (6 x 25 = 5 x 30)
     });
     if (!lds_ok) {
         last_hip_error() = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
