@@ -186,6 +186,60 @@ k_msm_bucket_gather(const Xyzz<typename O::Base>* __restrict__ part, const uint3
     }
     xyzz_store<O>(bkt + b, acc, h);
 }
+// The same for a batch, in two kinds of workgroup of ONE launch.  After the bucket tree a chunk holds ~50 points and a bucket ~5, so nine
+// buckets in ten lie inside one chunk and have ONE partial — but among the 64 buckets of a wave some always straddle a chunk boundary, and
+// the wave paid a whole group addition (exec-masked for the rest) per bucket-lane: 1.4e9 wave instructions per Spend batch for ~0.1
+// additions per bucket.  Here workgroups [0, nbw) copy the single partials (one lane per bucket: no arithmetic; heavy buckets go to their
+// list as before), workgroups [nbw, nbw + ncw) take one CHUNK BOUNDARY per lane: lane c (1 <= c < nchunks) owns the bucket that begins in
+// chunk c - 1 and runs on into chunk c, and adds its partials c - 1 .. c1 — the additions now fill their waves.  grid (nbw + ncw, np).
+template <class O>
+__global__ void __launch_bounds__(64, MASP_TAIL_MIN_WAVES)
+k_msm_bucket_gather_split(const Xyzz<typename O::Base>* __restrict__ part, const uint32_t* __restrict__ start, uint32_t nb, uint32_t nchunks,
+                          Xyzz<typename O::Base>* __restrict__ bkt, uint32_t* __restrict__ heavy, uint32_t* __restrict__ n_heavy, uint32_t heavy_span,
+                          uint32_t nbw) {
+    constexpr uint32_t LN = O::LANES;
+    const uint32_t h = threadIdx.x % LN;
+    part += (size_t)MSM_P * ((size_t)nchunks + nb);
+    start += (size_t)MSM_P * (nb + 1);
+    bkt += (size_t)MSM_P * nb;
+    heavy += (size_t)MSM_P * nb;
+    n_heavy += MSM_P;
+    const uint32_t total = start[nb];
+    const uint32_t K = msm_chunk_len(total, nchunks);
+    if (blockIdx.x < nbw) {
+        const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) / LN;
+        if (b >= nb) return;
+        const uint32_t s0 = start[b], s1 = start[b + 1];
+        if (s1 <= s0) {
+            xyzz_store<O>(bkt + b, xyzz_inf<O>(), h);
+            return;
+        }
+        const uint32_t c0 = s0 / K, c1 = (s1 - 1) / K;
+        if (c1 - c0 >= heavy_span) {
+            if (h == 0) heavy[atomicAdd(n_heavy, 1u)] = b;  // written by k_msm_bucket_heavy
+            return;
+        }
+        if (c1 == c0) xyzz_store<O>(bkt + b, xyzz_load<O>(part + c0 + b, h), h);
+        return;  // (c1 > c0: the lane of chunk boundary c0 + 1 below)
+    }
+    const uint32_t c = ((blockIdx.x - nbw) * blockDim.x + threadIdx.x) / LN + 1u;
+    if (c >= nchunks || (uint64_t)c * K >= total) return;
+    // the bucket that holds position c K - 1, the last of chunk c - 1: largest b with start[b] <= c K - 1
+    const uint32_t pos = c * K - 1u;
+    uint32_t b = 0, span = nb;
+    while (span > 1) {
+        const uint32_t half = span >> 1;
+        if (start[b + half] <= pos) b += half;
+        span -= half;
+    }
+    const uint32_t s0 = start[b], s1 = start[b + 1];
+    if (s1 <= c * K) return;                 // the bucket ends with chunk c - 1: nothing straddles this boundary
+    const uint32_t c0 = s0 / K, c1 = (s1 - 1) / K;
+    if (c0 != c - 1u || c1 - c0 >= heavy_span) return;   // it began earlier (the lane of ITS first boundary adds it up), or it is a heavy bucket
+    Xyzz<O> acc = xyzz_load<O>(part + c0 + b, h);
+    for (uint32_t k = c; k <= c1; ++k) xyzz_add_nc(acc, xyzz_load<O>(part + k + b, h));
+    xyzz_store<O>(bkt + b, acc, h);
+}
 // value of lane (lane + d) of the wave, limb by limb (a point is 36 / 96 dwords: noise next to one group addition)
 template <class O>
 __device__ __forceinline__ Xyzz<O> xyzz_shfl_down(const Xyzz<O>& p, int d) {

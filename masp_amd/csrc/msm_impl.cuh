@@ -101,8 +101,17 @@ template <class O, class OT>
 void msm_tails_enqueue(hipStream_t s, MsmWorkspace<O>& ws, const uint32_t* start, uint32_t nb, uint32_t nchunks, uint32_t np, bool lone, Xyzz<O>* d_out,
                        size_t out_stride, bool odd_weights) {
     constexpr uint32_t LN = OT::LANES;
-    MASP_LAUNCH((k_msm_bucket_gather<OT>), dim3((nb * LN + 63) / 64, np), dim3(64), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy,
-                       ws.n_heavy, lone ? 12u : 8u);
+    if constexpr (OT::LANES <= 2) {
+        if (!lone) {  // a batch: single partials copied, one lane per chunk boundary for the buckets that straddle one (k_msm_bucket_gather_split)
+            const uint32_t nbw = (nb * LN + 63) / 64, ncw = (nchunks * LN + 63) / 64;
+            MASP_LAUNCH((k_msm_bucket_gather_split<OT>), dim3(nbw + ncw, np), dim3(64), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy, ws.n_heavy, 8u, nbw);
+        } else {
+            MASP_LAUNCH((k_msm_bucket_gather<OT>), dim3((nb * LN + 63) / 64, np), dim3(64), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy, ws.n_heavy, 12u);
+        }
+    } else {
+        MASP_LAUNCH((k_msm_bucket_gather<OT>), dim3((nb * LN + 63) / 64, np), dim3(64), 0, s, ws.part, start, nb, nchunks, ws.bkt, ws.heavy,
+                           ws.n_heavy, lone ? 12u : 8u);
+    }
     if (lone) {
         const uint32_t heavy_blocks = std::min<uint32_t>(std::max<uint32_t>(4096u / np, 16u), nb) | 1u;
         if constexpr (OT::REPLICATED) {
