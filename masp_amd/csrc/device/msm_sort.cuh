@@ -22,23 +22,26 @@ namespace masp {
 // with one ballot instead of 64 colliding atomics.  Zero scalars (38 %) produce nothing.
 // scalars: n x 8 canonical little-endian limbs.  sorted entry = table row (t*n + i) | sign << 31, t = the table of the digit: window j
 // (fixed windows) / bit position (NAF).
+// (NAF is a template parameter of the iterator and of the three kernels that use it: the fixed-window form is what the prover's default
+// runs 834 million times per batch, and it costs 70 % more instructions when it shares its code with the other)
+template <bool NAF>
 struct MsmDigitIter {
     const uint32_t* sw;
     uint32_t carry, mask, half, pos, j;
-    int c, naf;
+    int c;
     __device__ __forceinline__ MsmDigitIter(const uint32_t* sw_, const MsmGeom& g)
-        : sw(sw_), carry(0), mask((1u << g.c) - 1u), half(1u << (g.c - 1)), pos(0), j(0), c(g.c), naf(g.naf) {}
+        : sw(sw_), carry(0), mask((1u << g.c) - 1u), half(1u << (g.c - 1)), pos(0), j(0), c(g.c) {}
     // 32 bits of the scalar from bit `bit` on, zeros beyond bit 255 (re-read from L1/L2 instead of indexing a register array dynamically)
     __device__ __forceinline__ uint32_t bits(uint32_t bit) const {
         const uint32_t w = bit >> 5, off = bit & 31u;
-        if (w >= 8) return 0u;
+        if (NAF && w >= 8) return 0u;   // (fixed windows: the last window starts below bit 256)
         const uint64_t two = ((uint64_t)(w + 1 < 8 ? sw[w + 1] : 0u) << 32) | sw[w];
         return (uint32_t)(two >> off);
     }
     // The next digit.  Fixed windows: call W times, window after window; false = this window's digit is zero.  NAF: false = no digit
     // is left (every later call says so again).  table: which table of the base set the digit's row lies in.
     __device__ __forceinline__ bool next(uint32_t& table, uint32_t& bucket, uint32_t& neg) {
-        if (!naf) {
+        if constexpr (!NAF) {
             uint32_t v = (bits(pos) & mask) + carry;
             table = j++;
             pos += (uint32_t)c;
@@ -87,6 +90,7 @@ __device__ __forceinline__ int msm_scalar_class(const uint32_t* sw) {
     if (rest == 0 && lo.x <= 1) return (int)lo.x;
     return 2;
 }
+template <bool NAF>
 __global__ void __launch_bounds__(1024)
 k_msm_hist(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32_t n, MsmGeom g, uint32_t ng, uint32_t* __restrict__ hist_wg) {
     extern __shared__ uint32_t msm_lds[];
@@ -104,12 +108,12 @@ k_msm_hist(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32_t 
         if (cls == 1) {
             if ((uint32_t)__ffsll((unsigned long long)ones) - 1u == (tid & 63u)) atomicAdd(&msm_lds[0], (uint32_t)__popcll(ones));
         } else if (cls == 2) {
-            MsmDigitIter it(sw, g);
+            MsmDigitIter<NAF> it(sw, g);
             for (int j = 0; j < g.W; ++j) {
                 uint32_t table, bucket, neg;
                 if (it.next(table, bucket, neg))
                     atomicAdd(&msm_lds[bucket], 1u);
-                else if (g.naf)
+                else if (NAF)
                     break;
             }
         }
@@ -195,6 +199,7 @@ k_msm_offsets_scan(uint32_t nb, uint32_t* __restrict__ start, uint32_t* __restri
         start[nb] = base[1];
     }
 }
+template <bool NAF>
 __global__ void __launch_bounds__(1024)
 k_msm_scatter(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32_t n, MsmGeom g, uint32_t ng, const uint32_t* __restrict__ rel,
               const uint32_t* __restrict__ start, uint32_t* __restrict__ sorted, size_t sorted_stride) {
@@ -220,12 +225,12 @@ k_msm_scatter(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32
             if (cls == 1) sorted[first + (uint32_t)__popcll(ones & ((1ull << (tid & 63u)) - 1ull))] = i;  // window 0: row i, positive
         }
         if (cls == 2) {
-            MsmDigitIter it(sw, g);
+            MsmDigitIter<NAF> it(sw, g);
             for (int j = 0; j < g.W; ++j) {
                 uint32_t table, bucket, neg;
                 if (it.next(table, bucket, neg))
                     sorted[atomicAdd(&msm_lds[bucket], 1u)] = (table * n + i) | (neg << 31);
-                else if (g.naf)
+                else if (NAF)
                     break;
             }
         }
@@ -300,6 +305,7 @@ __device__ __forceinline__ void msm_small_scan(const uint32_t* cnt, uint32_t* of
         if (tid == 255) *total = base + x;
     }
 }
+template <bool NAF>
 __global__ void __launch_bounds__(1024)
 k_msm_partition(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32_t n, MsmGeom g, uint32_t ng, const uint32_t* __restrict__ crel,
                 const uint32_t* __restrict__ start /* packed offsets: MsmSortBuf::dense */, uint32_t* __restrict__ tmp, uint8_t* __restrict__ tmpf,
@@ -341,7 +347,7 @@ k_msm_partition(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint
 #pragma unroll
         for (int j = 0; j < 32; ++j) key[j] = 0xffffffffu;
         if (cls == 2) {
-            MsmDigitIter it(sw, g);
+            MsmDigitIter<NAF> it(sw, g);
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
                 if (j < g.W) {

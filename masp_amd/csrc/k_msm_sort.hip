@@ -39,28 +39,42 @@ int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb
     static PerDeviceOnce once;
     const bool lds_ok = once([] {
         int bytes = 4 << 15;
-        return hipFuncSetAttribute((const void*)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
-               hipFuncSetAttribute((const void*)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
-               hipFuncSetAttribute((const void*)k_msm_partition, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   4 * (4 * 256 + 8) + 5 * (int)MSM_PART_TILE * 30) == hipSuccess;  // = the largest part_lds below (6 x 25 = 5 x 30)
+        const int part_bytes = 4 * (4 * 256 + 8) + 5 * (int)MSM_PART_TILE * 30;  // = the largest part_lds below (6 x 25 = 5 x 30)
+        return hipFuncSetAttribute((const void*)k_msm_hist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+               hipFuncSetAttribute((const void*)k_msm_hist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+               hipFuncSetAttribute((const void*)k_msm_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+               hipFuncSetAttribute((const void*)k_msm_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+               hipFuncSetAttribute((const void*)k_msm_partition<true>, hipFuncAttributeMaxDynamicSharedMemorySize, part_bytes) == hipSuccess &&
+               hipFuncSetAttribute((const void*)k_msm_partition<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   part_bytes) == hipSuccess;
     });
     if (!lds_ok) {
         last_hip_error() = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
         return MASP_HIP_E_HIP;
     }
-    MASP_LAUNCH(k_msm_hist, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg);
+    if (g.naf)
+        MASP_LAUNCH(k_msm_hist<true>, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg);
+    else
+        MASP_LAUNCH(k_msm_hist<false>, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg);
     MASP_LAUNCH(k_msm_offsets_cols, dim3((nb + 255) / 256, np), dim3(256), 0, s, sb.hist_wg, ng, nb, sb.dense);
     MASP_LAUNCH(k_msm_offsets_scan, dim3(1, np), dim3(1024), 0, s, nb, sb.start, sb.dense, pad_log);
     if (two_pass) {
         const uint32_t nbins = nb >> MSM_FINE_LOG;
         MASP_LAUNCH(k_msm_coarse, dim3(nbins, np), dim3(128), 0, s, sb.hist_wg, ng, nb, sb.crel);
-        MASP_LAUNCH(k_msm_partition, dim3(ng, np), dim3(MSM_PART_TILE), part_lds, s, d_scalars, scalar_stride, n, g, ng, sb.crel, sb.dense, sb.tmp, sb.tmpf, wide);
+        if (g.naf)
+            MASP_LAUNCH(k_msm_partition<true>, dim3(ng, np), dim3(MSM_PART_TILE), part_lds, s, d_scalars, scalar_stride, n, g, ng, sb.crel, sb.dense, sb.tmp, sb.tmpf, wide);
+        else
+            MASP_LAUNCH(k_msm_partition<false>, dim3(ng, np), dim3(MSM_PART_TILE), part_lds, s, d_scalars, scalar_stride, n, g, ng, sb.crel, sb.dense, sb.tmp, sb.tmpf, wide);
         MASP_LAUNCH(k_msm_bucketize, dim3(nbins, np), dim3(1024), 0, s, sb.tmp, sb.tmpf, (size_t)n * g.W, sb.dense, sb.start, nb, sb.sorted, sb.ent_stride, wide);
     } else {
         // (the single-pass placement writes entries only: aligned runs get their padding from a fill first)
         if (pad_log) HIP_TRY(hipMemsetAsync(sb.sorted, 0xff, 4 * sb.ent_stride * np, s));
-        MASP_LAUNCH(k_msm_scatter, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg, sb.start,
-                           sb.sorted, sb.ent_stride);
+        if (g.naf)
+            MASP_LAUNCH(k_msm_scatter<true>, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg, sb.start, sb.sorted,
+                        sb.ent_stride);
+        else
+            MASP_LAUNCH(k_msm_scatter<false>, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg, sb.start, sb.sorted,
+                        sb.ent_stride);
     }
     return launch_status();
 }
