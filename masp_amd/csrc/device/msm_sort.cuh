@@ -148,56 +148,73 @@ k_msm_offsets_cols(uint32_t* __restrict__ hist_wg, uint32_t ng, uint32_t nb, uin
     }
     dense[b] = v;
 }
+// One workgroup per proof, the totals in LDS (nb + nb / 32 words: launch with that much dynamic LDS).  Lane t owns buckets [t per, (t + 1) per),
+// per = ceil(nb / 1024): serial sums over its buckets, ONE scan over the 1 024 lanes' totals, serial prefixes — written back through LDS so
+// that every global access is coalesced.  (As 32 rounds of 1 024 buckets with a scan and three barriers each it took 49 us for the 32 768
+// buckets of a lone proof's h MSM.)  The padded lengths are recomputed from the packed offsets: v[b] = dense[b + 1] - dense[b].
+__device__ __forceinline__ uint32_t msm_scan_slot(uint32_t i) { return i + (i >> 5); }  // (a lane's 32 buckets in 32 different banks)
 __global__ void __launch_bounds__(1024)
 k_msm_offsets_scan(uint32_t nb, uint32_t* __restrict__ start, uint32_t* __restrict__ dense, uint32_t pad_log) {
+    extern __shared__ uint32_t msm_lds[];
     __shared__ uint32_t wsum[2][16];
-    __shared__ uint32_t base[2];
     start += (size_t)MSM_P * (nb + 1);
     dense += (size_t)MSM_P * (nb + 1);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, pad = (1u << pad_log) - 1u;
-    if (tid == 0) base[0] = base[1] = 0;
+    const uint32_t per = (nb + 1023u) >> 10, lo = tid * per < nb ? tid * per : nb, hi = lo + per < nb ? lo + per : nb;
+    for (uint32_t i = tid; i < nb; i += 1024) msm_lds[msm_scan_slot(i)] = dense[i];
     __syncthreads();
-    uint32_t vn = tid < nb ? dense[tid] : 0u;  // (the next iteration's total is requested before this one's scan)
-    for (uint32_t b0 = 0; b0 < nb; b0 += blockDim.x) {
-        const uint32_t b = b0 + tid;
-        const uint32_t v = vn;
-        vn = b + blockDim.x < nb ? dense[b + blockDim.x] : 0u;
-        const uint32_t pv = (v + pad) & ~pad;
-        uint32_t x = v, px = pv;
+    uint32_t sv = 0, spv = 0;
+    for (uint32_t j = lo; j < hi; ++j) {
+        const uint32_t v = msm_lds[msm_scan_slot(j)];
+        sv += v;
+        spv += (v + pad) & ~pad;
+    }
+    // exclusive scan of (sv, spv) over the workgroup's lanes
+    uint32_t x = sv, px = spv;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t y = __shfl_up(x, d, 64), py = __shfl_up(px, d, 64);
-            if ((int)lane >= d) {
-                x += y;
-                px += py;
-            }
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64), py = __shfl_up(px, d, 64);
+        if ((int)lane >= d) {
+            x += y;
+            px += py;
         }
-        if (lane == 63) {
-            wsum[0][wid] = x;
-            wsum[1][wid] = px;
-        }
-        __syncthreads();
-        uint32_t woff = 0, pwoff = 0;
-        for (uint32_t k = 0; k < wid; ++k) {
+    }
+    if (lane == 63) {
+        wsum[0][wid] = x;
+        wsum[1][wid] = px;
+    }
+    __syncthreads();
+    uint32_t woff = 0, pwoff = 0, tot = 0, ptot = 0;
+    for (uint32_t k = 0; k < 16; ++k) {
+        if (k < wid) {
             woff += wsum[0][k];
             pwoff += wsum[1][k];
         }
-        const uint32_t bs = base[0], pbs = base[1];
-        if (b < nb) {
-            dense[b] = bs + woff + x - v;
-            start[b] = pbs + pwoff + px - pv;
-        }
-        __syncthreads();
-        if (tid == blockDim.x - 1) {
-            base[0] = bs + woff + x;
-            base[1] = pbs + pwoff + px;
-        }
-        __syncthreads();
+        tot += wsum[0][k];
+        ptot += wsum[1][k];
     }
-    if (tid == 0) {
-        dense[nb] = base[0];
-        start[nb] = base[1];
+    // packed offsets, in place
+    uint32_t run = woff + x - sv;
+    for (uint32_t j = lo; j < hi; ++j) {
+        const uint32_t v = msm_lds[msm_scan_slot(j)];
+        msm_lds[msm_scan_slot(j)] = run;
+        run += v;
     }
+    __syncthreads();
+    for (uint32_t i = tid; i < nb; i += 1024) dense[i] = msm_lds[msm_scan_slot(i)];
+    if (tid == 0) dense[nb] = tot;
+    const uint32_t nxt = hi < nb ? msm_lds[msm_scan_slot(hi)] : tot;  // where the next lane's buckets begin (read before that lane overwrites it)
+    __syncthreads();
+    // aligned offsets, in place
+    uint32_t prun = pwoff + px - spv;
+    for (uint32_t j = lo; j < hi; ++j) {
+        const uint32_t cur = msm_lds[msm_scan_slot(j)], next = j + 1 < hi ? msm_lds[msm_scan_slot(j + 1)] : nxt;
+        msm_lds[msm_scan_slot(j)] = prun;
+        prun += (next - cur + pad) & ~pad;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < nb; i += 1024) start[i] = msm_lds[msm_scan_slot(i)];
+    if (tid == 0) start[nb] = ptot;
 }
 template <bool NAF>
 __global__ void __launch_bounds__(1024)
@@ -253,21 +270,17 @@ static constexpr uint32_t MSM_FINE_LOG = 7, MSM_FINE = 1u << MSM_FINE_LOG;
 static constexpr uint32_t MSM_PART_TILE = 1024;   // scalars per tile of k_msm_partition (= threads)
 static constexpr uint32_t MSM_BKT_TILE = 4096;    // entries per tile of k_msm_bucketize
 
-// crel[p][wg][B] = entries of bin B that come from earlier scalar ranges = sum over the bin's buckets of rel[p][wg][b]
-__global__ void __launch_bounds__(128) k_msm_coarse(const uint32_t* __restrict__ rel, uint32_t ng, uint32_t nb, uint32_t* __restrict__ crel) {
-    __shared__ uint32_t part[2];
-    const uint32_t B = blockIdx.x, nbins = nb >> MSM_FINE_LOG, tid = threadIdx.x;
-    rel += (size_t)MSM_P * ng * nb;
-    crel += (size_t)MSM_P * ng * nbins;
-    for (uint32_t w = 0; w < ng; ++w) {
-        uint32_t v = rel[(size_t)w * nb + (B << MSM_FINE_LOG) + tid];
+// crel[p][wg][B] = entries of bin B that come from earlier scalar ranges = sum over the bin's buckets of rel[p][wg][b].  One WAVE per
+// (bin, range): grid (bins, np, ceil(ng / waves per workgroup)) — as one workgroup per bin walking the ranges one after the other (two
+// barriers each) the kernel was 110 us of a lone proof's h MSM, whose 64 ranges it took in turn (round 5).
+__global__ void __launch_bounds__(256) k_msm_coarse(const uint32_t* __restrict__ rel, uint32_t ng, uint32_t nb, uint32_t* __restrict__ crel) {
+    const uint32_t B = blockIdx.x, nbins = nb >> MSM_FINE_LOG, lane = threadIdx.x & 63u, w = blockIdx.z * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (w >= ng) return;
+    rel += (size_t)MSM_P * ng * nb + (size_t)w * nb + (B << MSM_FINE_LOG);
+    uint32_t v = rel[lane] + rel[64 + lane];
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
-        if ((tid & 63) == 0) part[tid >> 6] = v;
-        __syncthreads();
-        if (tid == 0) crel[(size_t)w * nbins + B] = part[0] + part[1];
-        __syncthreads();
-    }
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+    if (lane == 0) crel[((size_t)MSM_P * ng + w) * nbins + B] = v;
 }
 // position of k in the exclusive offsets off[0..n): largest i with off[i] <= k
 __device__ __forceinline__ uint32_t msm_find_run(const uint32_t* off, uint32_t n, uint32_t k) {

@@ -40,7 +40,8 @@ int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb
     const bool lds_ok = once([] {
         int bytes = 4 << 15;
         const int part_bytes = 4 * (4 * 256 + 8) + 5 * (int)MSM_PART_TILE * 30;  // = the largest part_lds below (6 x 25 = 5 x 30)
-        return hipFuncSetAttribute((const void*)k_msm_hist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+        return hipFuncSetAttribute((const void*)k_msm_offsets_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ((1 << 15) + (1 << 10) + 1)) == hipSuccess &&
+               hipFuncSetAttribute((const void*)k_msm_hist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
                hipFuncSetAttribute((const void*)k_msm_hist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
                hipFuncSetAttribute((const void*)k_msm_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
                hipFuncSetAttribute((const void*)k_msm_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
@@ -57,10 +58,11 @@ int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb
     else
         MASP_LAUNCH(k_msm_hist<false>, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg);
     MASP_LAUNCH(k_msm_offsets_cols, dim3((nb + 255) / 256, np), dim3(256), 0, s, sb.hist_wg, ng, nb, sb.dense);
-    MASP_LAUNCH(k_msm_offsets_scan, dim3(1, np), dim3(1024), 0, s, nb, sb.start, sb.dense, pad_log);
+    MASP_LAUNCH(k_msm_offsets_scan, dim3(1, np), dim3(1024), 4 * (nb + (nb >> 5) + 1), s, nb, sb.start, sb.dense, pad_log);
     if (two_pass) {
         const uint32_t nbins = nb >> MSM_FINE_LOG;
-        MASP_LAUNCH(k_msm_coarse, dim3(nbins, np), dim3(128), 0, s, sb.hist_wg, ng, nb, sb.crel);
+        const uint32_t cw = std::min(ng, 4u);  // waves per workgroup of k_msm_coarse: one per scalar range
+        MASP_LAUNCH(k_msm_coarse, dim3(nbins, np, (ng + cw - 1) / cw), dim3(64 * cw), 0, s, sb.hist_wg, ng, nb, sb.crel);
         if (g.naf)
             MASP_LAUNCH(k_msm_partition<true>, dim3(ng, np), dim3(MSM_PART_TILE), part_lds, s, d_scalars, scalar_stride, n, g, ng, sb.crel, sb.dense, sb.tmp, sb.tmpf, wide);
         else
