@@ -148,28 +148,28 @@ k_msm_offsets_cols(uint32_t* __restrict__ hist_wg, uint32_t ng, uint32_t nb, uin
     }
     dense[b] = v;
 }
-// One workgroup per proof, the totals in LDS (nb + nb / 32 words: launch with that much dynamic LDS).  Lane t owns buckets [t per, (t + 1) per),
-// per = ceil(nb / 1024): serial sums over its buckets, ONE scan over the 1 024 lanes' totals, serial prefixes — written back through LDS so
-// that every global access is coalesced.  (As 32 rounds of 1 024 buckets with a scan and three barriers each it took 49 us for the 32 768
-// buckets of a lone proof's h MSM.)  The padded lengths are recomputed from the packed offsets: v[b] = dense[b + 1] - dense[b].
-__device__ __forceinline__ uint32_t msm_scan_slot(uint32_t i) { return i + (i >> 5); }  // (a lane's 32 buckets in 32 different banks)
-__global__ void __launch_bounds__(1024)
-k_msm_offsets_scan(uint32_t nb, uint32_t* __restrict__ start, uint32_t* __restrict__ dense, uint32_t pad_log) {
-    extern __shared__ uint32_t msm_lds[];
-    __shared__ uint32_t wsum[2][16];
+// Exclusive scans of the buckets' totals (packed: dense[]) and of the totals rounded up to 2^pad_log (aligned: start[]), in two kernels of
+// SMALL workgroups: grid (ceil(nb / 1024), np) x 256 lanes, four buckets per lane.
+//   k_msm_offsets_scan_a  the scan inside a block of 1 024 buckets, the block's two totals to btot[p][blk]
+//   k_msm_offsets_scan_b  every lane adds the totals of the blocks before its own; the last block leaves dense[nb], start[nb]
+// As ONE workgroup of 1 024 lanes per proof the step took a lone proof's h MSM 49 us — whatever the kernel did inside (two rewrites changed
+// nothing): a workgroup of sixteen waves waits until one CU has four free wave slots on each SIMD, and the chip is full of the other chains'
+// accumulation waves, which run for 200 - 500 us each.  Workgroups of four waves find room at once.
+static constexpr uint32_t MSM_SCAN_BLOCK = 1024;  // buckets per workgroup (256 lanes x 4)
+__global__ void __launch_bounds__(256)
+k_msm_offsets_scan_a(uint32_t nb, uint32_t* __restrict__ start, uint32_t* __restrict__ dense, uint32_t pad_log, uint2* __restrict__ btot) {
+    __shared__ uint32_t wsum[2][4];
     start += (size_t)MSM_P * (nb + 1);
     dense += (size_t)MSM_P * (nb + 1);
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, pad = (1u << pad_log) - 1u;
-    const uint32_t per = (nb + 1023u) >> 10, lo = tid * per < nb ? tid * per : nb, hi = lo + per < nb ? lo + per : nb;
-    for (uint32_t i = tid; i < nb; i += 1024) msm_lds[msm_scan_slot(i)] = dense[i];
-    __syncthreads();
-    uint32_t sv = 0, spv = 0;
-    for (uint32_t j = lo; j < hi; ++j) {
-        const uint32_t v = msm_lds[msm_scan_slot(j)];
-        sv += v;
-        spv += (v + pad) & ~pad;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, pad = (1u << pad_log) - 1u, b0 = blockIdx.x * MSM_SCAN_BLOCK + tid * 4u;
+    uint32_t v[4], pv[4], sv = 0, spv = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        v[k] = b0 + k < nb ? dense[b0 + k] : 0u;
+        pv[k] = (v[k] + pad) & ~pad;
+        sv += v[k];
+        spv += pv[k];
     }
-    // exclusive scan of (sv, spv) over the workgroup's lanes
     uint32_t x = sv, px = spv;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -184,37 +184,53 @@ k_msm_offsets_scan(uint32_t nb, uint32_t* __restrict__ start, uint32_t* __restri
         wsum[1][wid] = px;
     }
     __syncthreads();
-    uint32_t woff = 0, pwoff = 0, tot = 0, ptot = 0;
-    for (uint32_t k = 0; k < 16; ++k) {
-        if (k < wid) {
-            woff += wsum[0][k];
-            pwoff += wsum[1][k];
+    uint32_t woff = 0, pwoff = 0;
+    for (uint32_t k = 0; k < wid; ++k) {
+        woff += wsum[0][k];
+        pwoff += wsum[1][k];
+    }
+    uint32_t run = woff + x - sv, prun = pwoff + px - spv;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        if (b0 + k < nb) {
+            dense[b0 + k] = run;
+            start[b0 + k] = prun;
         }
-        tot += wsum[0][k];
-        ptot += wsum[1][k];
+        run += v[k];
+        prun += pv[k];
     }
-    // packed offsets, in place
-    uint32_t run = woff + x - sv;
-    for (uint32_t j = lo; j < hi; ++j) {
-        const uint32_t v = msm_lds[msm_scan_slot(j)];
-        msm_lds[msm_scan_slot(j)] = run;
-        run += v;
+    if (tid == 255) btot[(size_t)MSM_P * gridDim.x + blockIdx.x] = make_uint2(run, prun);
+}
+__global__ void __launch_bounds__(256)
+k_msm_offsets_scan_b(uint32_t nb, uint32_t* __restrict__ start, uint32_t* __restrict__ dense, const uint2* __restrict__ btot) {
+    start += (size_t)MSM_P * (nb + 1);
+    dense += (size_t)MSM_P * (nb + 1);
+    btot += (size_t)MSM_P * gridDim.x;
+    // (lane k of every wave fetches block k's totals — at most 32 blocks: 2^15 buckets —, one shuffle reduction: a loop over the blocks
+    // before was as many dependent round trips to L2)
+    const uint32_t lane = threadIdx.x & 63u;
+    uint2 t = make_uint2(0u, 0u);
+    if (lane < blockIdx.x) t = btot[lane];
+    uint32_t base = t.x, pbase = t.y;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        base += __shfl_xor(base, d, 64);
+        pbase += __shfl_xor(pbase, d, 64);
     }
-    __syncthreads();
-    for (uint32_t i = tid; i < nb; i += 1024) dense[i] = msm_lds[msm_scan_slot(i)];
-    if (tid == 0) dense[nb] = tot;
-    const uint32_t nxt = hi < nb ? msm_lds[msm_scan_slot(hi)] : tot;  // where the next lane's buckets begin (read before that lane overwrites it)
-    __syncthreads();
-    // aligned offsets, in place
-    uint32_t prun = pwoff + px - spv;
-    for (uint32_t j = lo; j < hi; ++j) {
-        const uint32_t cur = msm_lds[msm_scan_slot(j)], next = j + 1 < hi ? msm_lds[msm_scan_slot(j + 1)] : nxt;
-        msm_lds[msm_scan_slot(j)] = prun;
-        prun += (next - cur + pad) & ~pad;
+    const uint32_t b0 = blockIdx.x * MSM_SCAN_BLOCK + threadIdx.x * 4u;
+    if (blockIdx.x) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k)
+            if (b0 + k < nb) {
+                dense[b0 + k] += base;
+                start[b0 + k] += pbase;
+            }
     }
-    __syncthreads();
-    for (uint32_t i = tid; i < nb; i += 1024) start[i] = msm_lds[msm_scan_slot(i)];
-    if (tid == 0) start[nb] = ptot;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        const uint2 last = btot[blockIdx.x];
+        dense[nb] = base + last.x;
+        start[nb] = pbase + last.y;
+    }
 }
 template <bool NAF>
 __global__ void __launch_bounds__(1024)

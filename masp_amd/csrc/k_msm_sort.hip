@@ -8,6 +8,7 @@ namespace masp {
 
 int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb, const uint32_t* d_scalars, size_t scalar_stride,
                                    uint32_t np, uint32_t pad_log) {
+    static_assert((1u << 15) / MSM_SCAN_BLOCK <= 64, "k_msm_offsets_scan_b: a wave's lanes fetch the block totals");
     if (g.c < 2 + 2 * g.naf || g.nb > (1 << 15)) {
         last_hip_error() = "MSM digit width must be 2..16 bits (fixed windows) / 4..17 bits (NAF): the bucket histogram lives in LDS";
         return MASP_HIP_E_INVALID_ARG;
@@ -40,8 +41,7 @@ int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb
     const bool lds_ok = once([] {
         int bytes = 4 << 15;
         const int part_bytes = 4 * (4 * 256 + 8) + 5 * (int)MSM_PART_TILE * 30;  // = the largest part_lds below (6 x 25 = 5 x 30)
-        return hipFuncSetAttribute((const void*)k_msm_offsets_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ((1 << 15) + (1 << 10) + 1)) == hipSuccess &&
-               hipFuncSetAttribute((const void*)k_msm_hist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+        return hipFuncSetAttribute((const void*)k_msm_hist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
                hipFuncSetAttribute((const void*)k_msm_hist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
                hipFuncSetAttribute((const void*)k_msm_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
                hipFuncSetAttribute((const void*)k_msm_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
@@ -58,7 +58,9 @@ int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb
     else
         MASP_LAUNCH(k_msm_hist<false>, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg);
     MASP_LAUNCH(k_msm_offsets_cols, dim3((nb + 255) / 256, np), dim3(256), 0, s, sb.hist_wg, ng, nb, sb.dense);
-    MASP_LAUNCH(k_msm_offsets_scan, dim3(1, np), dim3(1024), 4 * (nb + (nb >> 5) + 1), s, nb, sb.start, sb.dense, pad_log);
+    const uint32_t scan_blocks = (nb + MSM_SCAN_BLOCK - 1) / MSM_SCAN_BLOCK;
+    MASP_LAUNCH(k_msm_offsets_scan_a, dim3(scan_blocks, np), dim3(256), 0, s, nb, sb.start, sb.dense, pad_log, sb.btot);
+    MASP_LAUNCH(k_msm_offsets_scan_b, dim3(scan_blocks, np), dim3(256), 0, s, nb, sb.start, sb.dense, sb.btot);
     if (two_pass) {
         const uint32_t nbins = nb >> MSM_FINE_LOG;
         const uint32_t cw = std::min(ng, 4u);  // waves per workgroup of k_msm_coarse: one per scalar range

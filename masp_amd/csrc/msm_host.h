@@ -66,6 +66,7 @@ struct MsmSortBuf {
     bool has_tmpf = false;
     static bool msm_rows_wide(uint32_t n_, const MsmGeom& g_) { return (uint64_t)n_ * (uint32_t)g_.tpos > (1u << 24); }
     uint32_t* dense = nullptr;                 // [np][nb + 1] offsets without padding (where a bin lies in `tmp`)
+    uint2* btot = nullptr;                     // [np][ceil(nb / 1024)] the offsets scan's block totals (packed, aligned)
     // what the last msm_sort_enqueue produced (consumed by msm_reduce_enqueue)
     uint32_t n = 0, np = 0;
     MsmGeom g{};
@@ -84,11 +85,12 @@ struct MsmSortBuf {
 
     ~MsmSortBuf() { release(); }
     void release() {
-        void* ptrs[] = {sorted, hist_wg, start, tmp, crel, dense, tmpf};
+        void* ptrs[] = {sorted, hist_wg, start, tmp, crel, dense, tmpf, btot};
         for (void* p : ptrs)
             if (p) dev_free(p);
         sorted = hist_wg = start = tmp = crel = dense = nullptr;
         tmpf = nullptr;
+        btot = nullptr;
         has_tmpf = false;
         cap_ent = cap_nb = cap_np = cap_hist = cap_crel = 0;
     }
@@ -120,6 +122,7 @@ struct MsmSortBuf {
             if (want_tmpf) HIP_TRY(dev_malloc(&tmpf, need_np * std::max<size_t>(need_ent, 1)));
             HIP_TRY(dev_malloc(&crel, 4 * need_crel));
             HIP_TRY(dev_malloc(&dense, need_np * 4 * (need_nb + 1)));
+            HIP_TRY(dev_malloc(&btot, need_np * sizeof(uint2) * ((need_nb + 1023) / 1024)));
             return MASP_HIP_OK;
         };
         if (int rc = alloc_all()) {
