@@ -46,7 +46,7 @@ PROOFS_PER_STEP = {"spend": 256, "output": 256, "convert": 256, "mixed": 512}   
 
 
 ENV_OPTIONS = {"MASP_HIP_SLOTS": "slots", "MASP_HIP_BATCH": "batch_cap", "MASP_HIP_NTT_SUB": "ntt_sub_batch", "MASP_HIP_MSM_C_H": "window_bits_h",
-               "MASP_HIP_MSM_C_LA": "window_bits_la", "MASP_HIP_MSM_C_B": "window_bits_b", "MASP_HIP_MSM_C_B2_LONE": "window_bits_b2_lone",
+               "MASP_HIP_MSM_C_LA": "window_bits_la", "MASP_HIP_MSM_C_B": "window_bits_b", "MASP_HIP_MSM_C_B2": "window_bits_b2", "MASP_HIP_MSM_C_B2_LONE": "window_bits_b2_lone",
                "MASP_HIP_WITNESS_NONTRIVIAL_PERCENT": "witness_nontrivial_percent", "MASP_HIP_TREE_LEVELS": "bucket_tree_levels",
                "MASP_HIP_TREE_SUB": "bucket_tree_sub_batch", "MASP_HIP_TREE_LEVELS_G2": "bucket_tree_levels_g2",
                "MASP_HIP_LONE_GRAPH": "lone_proof_graph", "MASP_HIP_MSM_C_H_LONE": "window_bits_h_lone", "MASP_HIP_DIGITS": "digit_recoding"}
@@ -113,8 +113,18 @@ class ClockWatch:
         busy = [r for r in per_card if r[0] >= 0.6 * top]
         return {"sclk_mhz_mean": round(sum(r[1] for r in busy) / len(busy), 1), "sclk_mhz_min": round(min(r[2] for r in busy), 1),
                 "sclk_mhz_max": round(max(r[3] for r in busy), 1), "socket_power_w_mean": round(sum(r[0] for r in busy) / len(busy), 1),
-                "samples_per_card": busy[0][4], "cards_busy": len(busy), "cards_seen": len(per_card),
-                "source": "sysfs hwmon freq1_input (sclk) / power1_input (PPT) of the busy card(s), every 50 ms during the timed region"}
+                "samples_per_card": busy[0][4], "cards_busy": len(busy), "cards_seen": len(per_card)}
+
+
+def library_sha16():
+    """sha256[:16] of the libmasp_hip.so this process loaded: tracked measurements that cannot run inside the bench (PMC passes) carry the
+    hash of the build they were taken on, and the line says whether that is this build."""
+    import hashlib
+    from masp_amd.hip import library_path
+    try:
+        return hashlib.sha256(open(library_path(), "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
 
 
 def relaunch_under_torchrun(args):
@@ -148,10 +158,10 @@ def cpu_baseline(cs, params, inputs, aux):
             for k, v in tm.items():
                 phases.setdefault(k, []).append(v)
     med = statistics.median(times)
-    return {"value": 1.0 / med, "unit": "proofs/s", "cores": O.lib().oracle_get_threads(), "kind": "port",
-            "sample": "median of 10 %s proofs after 2 warm-ups, same circuit and CRS as the GPU run, instance 0 of its batch "
-                      "(oracle/groth16_oracle.cpp, all host cores this process may use)" % (WORKLOAD if WORKLOAD != "mixed" else "spend"),
-            "median_ms_per_proof": med * 1e3, "phase_ms_per_proof": {k: round(statistics.median(v), 2) for k, v in phases.items()}}
+    return {"value": round(1.0 / med, 4), "unit": "proofs/s", "cores": O.lib().oracle_get_threads(), "kind": "port",
+            "sample": "median of 10 %s proofs after 2 warm-ups (instance 0 of the GPU batch, same CRS), oracle on all usable host cores"
+                      % (WORKLOAD if WORKLOAD != "mixed" else "spend"),
+            "median_ms_per_proof": round(med * 1e3, 2), "phase_ms_per_proof": {k: round(statistics.median(v), 2) for k, v in phases.items()}}
 
 
 def main_in_library(args):
@@ -571,15 +581,11 @@ def main():
         prover.close()
         circuits_loaded = True            # (the context is ours: the three circuits stay loaded in it)
         e2e_s = D.max_over_ranks(e2e_s, dist, dev)
-        e2e = {"value": e2e_n * world / e2e_s, "unit": "proofs/s", "descriptions_per_gpu": e2e_n, "seconds": round(e2e_s, 3), "threads_per_gpu": threads,
+        e2e = {"value": round(e2e_n * world / e2e_s, 2), "unit": "proofs/s", "descriptions_per_gpu": e2e_n, "seconds": round(e2e_s, 3), "threads_per_gpu": threads,
                "load_seconds": round(e2e_setup, 2), "warm_up_seconds": round(warm_up_s, 2),
-               "first_call": {"value": e2e_n * world / first_s, "seconds": round(first_s, 3), "of_warm": round(e2e_s / first_s, 3) if first_s else None,
-                              "note": "the first prove_batch of this LocalTxProver after warm_up() (pool + slots sized at load time); `value` is the second call"},
+               "first_call": {"value": round(e2e_n * world / first_s, 2), "seconds": round(first_s, 3), "of_warm": round(e2e_s / first_s, 3) if first_s else None},
                "bucket_tree_sub_batch_in_use": e2e_opt["bucket_tree_sub_batch"],
-               "bucket_tree_fallback_proofs": e2e_opt["bucket_tree_fallback_proofs"],
-               "region": "LocalTxProver.prove_batch on this process's context: Spend descriptions -> witness synthesis (libmasp_host, %d threads) -> page-locked host memory -> "
-                         "GPU batches -> GPU batch self-verification -> (zkproof, cv, rk); includes the ramp of the first synthesis chunk and the "
-                         "last verification" % threads}
+               "bucket_tree_fallback_proofs": e2e_opt["bucket_tree_fallback_proofs"]}
     # ---- the other two circuits (BASELINE.json configs[0] / configs[2]: masp_proofs/benches/convert.rs:31-66; the reference has no Output
     # bench): a short region shaped like `value` (OTHER_STEPS steps of 256 distinct proofs per GPU, witnesses in page-locked host memory ->
     # proofs in host memory, every proof verified) and the lone-proof latency of each.  Not the metric; driver-timed all the same.
@@ -622,32 +628,31 @@ def main():
                 i0, a0 = inst_k[0]
                 lat_k = lone_latency((slot_k, i0, a0, bytes(rs_k[0, 0, :32]), bytes(rs_k[0, 0, 32:]), None, 1))
             vk_k.close()
-            others[kind] = {"value": OTHER_STEPS * 256 * world / el_k, "unit": "proofs/s", "steps": OTHER_STEPS, "proofs_per_step": 256,
-                            "ms_per_step": el_k * 1e3 / OTHER_STEPS, "verified": OTHER_STEPS * 256, "single_proof_latency_ms": lat_k,
-                            "constraints": cs_k.n_constraints}
+            others[kind] = {"value": round(OTHER_STEPS * 256 * world / el_k, 2), "unit": "proofs/s", "steps": OTHER_STEPS, "proofs_per_step": 256,
+                            "ms_per_step": round(el_k * 1e3 / OTHER_STEPS, 3), "verified": OTHER_STEPS * 256,
+                            "single_proof_latency_ms": None if lat_k is None else round(lat_k, 3), "constraints": cs_k.n_constraints}
     if rank == 0:
         total = K * n * world
         achieved = x_bytes / (x_ms * 1e-3) / 1e9 if x_ms > 0 else 0.0
-        # HBM bytes per launch of the same kernel: NOT measured by this run (PMC counters need rocprofv3 passes of their own) —
-        # read from the builder's tracked rocprofv3 result and labelled as such
+        lib_sha = library_sha16()
+        # HBM bytes per launch of the same stage: NOT measured by this run (PMC counters need rocprofv3 passes of their own) — read from the
+        # tracked rocprofv3 result (tools/pmc_traffic.sh), with the build it was measured on next to it
         traffic = traffic_source = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 doc = json.load(open(pmc))
                 traffic = doc.get("hbm_bytes_per_launch")
-                traffic_source = "profiles/pmc_traffic.json (builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this bench, %s; not " \
-                                 "measured by this run)" % doc.get("date", "round 2")
+                traffic_source = {"file": "profiles/pmc_traffic.json", "date": doc.get("date"), "library_sha16": doc.get("library_sha16"),
+                                  "same_build": doc.get("library_sha16") == lib_sha}
             except Exception:
                 traffic = traffic_source = None
-        # ---- the binding roofline next to the contractual one: VALU issue.  Wave-level VALU instructions of a batch (rocprofv3 --pmc
-        # SQ_INSTS_VALU over this bench, tracked under profiles/ like the traffic figure: counter passes cannot run inside the timed bench) x
-        # their measured issue cost (cycles a wave64 instruction of each class occupies its SIMD) against 1 024 SIMDs x the shader clock
-        # SAMPLED DURING THE TIMED REGION (the chip runs this path power-limited, below its 2.4 GHz boost)
+        # ---- the binding roofline next to the contractual one: VALU issue (BENCH_NOTES.md#roofline_valu).  The instruction count is a tracked
+        # rocprofv3 --pmc SQ_INSTS_VALU measurement (tools/valu_model.sh) stamped with the library it was taken on; the clock is this run's
         roofline_valu = None
         ck_val, ck_res = clocks.summary("value"), clocks.summary("resident")
-        vm_path = os.path.join(ROOT, "profiles", "r05_valu_model.json")
-        if WORKLOAD == "spend" and os.path.exists(vm_path) and ck_val is not None:
+        vm_path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r06_valu_model.json", "r05_valu_model.json")) if os.path.exists(q)), None)
+        if WORKLOAD == "spend" and vm_path and ck_val is not None:
             try:
                 vm = json.load(open(vm_path))
                 insts, cpi = vm["valu_insts_per_batch"] * n / 256.0, vm["cycles_per_inst_weighted"]
@@ -655,93 +660,77 @@ def main():
                 def issue_frac(ms_step, ck):
                     return insts * cpi / (1024 * ck["sclk_mhz_mean"] * 1e6 * ms_step * 1e-3)
                 peak = 1024 * ck_val["sclk_mhz_mean"] * 1e6 / cpi
-                roofline_valu = {"bound": "valu_issue", "achieved": insts / (elapsed_b / K) / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s per GPU",
-                                 "frac": issue_frac(elapsed_b * 1e3 / K, ck_val), "frac_resident_region": issue_frac(elapsed * 1e3 / K, ck_res) if ck_res else None,
-                                 "valu_insts_per_step_per_gpu": insts, "cycles_per_inst": cpi, "simds": 1024,
-                                 "sclk_mhz": ck_val["sclk_mhz_mean"], "sclk_boost_mhz": 2400.0, "clock_frac": ck_val["sclk_mhz_mean"] / 2400.0,
-                                 "socket_power_w": ck_val["socket_power_w_mean"],
-                                 "source": "profiles/r05_valu_model.json (tools/valu_model.sh: SQ_INSTS_VALU per kernel over this bench with one slot; "
-                                           "cycles per instruction = each kernel's static class mix, tools/valu_mix.py, priced with "
-                                           "profiles/r04e_valu_instruction_cost_classes_ubench.txt); clock: this run",
-                                 "note": "frac = issue cycles the batch's VALU instructions need / SIMD cycles the timed region had at the clock the chip "
-                                         "really ran at; clock_frac = that clock / the 2.4 GHz boost.  The HBM figure above is the contractual one and does "
-                                         "not bind: this one does"}
+                roofline_valu = {"bound": "valu_issue", "achieved": round(insts / (elapsed_b / K) / 1e9, 2), "peak": round(peak / 1e9, 2),
+                                 "unit": "G wave-instructions/s per GPU", "frac": round(issue_frac(elapsed_b * 1e3 / K, ck_val), 4),
+                                 "frac_resident_region": round(issue_frac(elapsed * 1e3 / K, ck_res), 4) if ck_res else None,
+                                 "valu_insts_per_step_per_gpu": round(insts), "cycles_per_inst": round(cpi, 4), "simds": 1024,
+                                 "sclk_mhz": ck_val["sclk_mhz_mean"], "sclk_boost_mhz": 2400.0, "clock_frac": round(ck_val["sclk_mhz_mean"] / 2400.0, 4),
+                                 "socket_power_w": ck_val["socket_power_w_mean"], "model": os.path.relpath(vm_path, ROOT),
+                                 #  the count was measured on the build whose hash the model file carries: a kernel change since then
+                                 # makes it stale, and the line says so instead of presenting an old count at a new clock
+                                 "model_library_sha16": vm.get("library_sha16"), "model_stale": vm.get("library_sha16") != lib_sha}
             except Exception as e:
                 roofline_valu = {"error": repr(e)}
         c0 = cs[kinds[0]]
         sh = synthetic.SHAPES[kinds[0]]
         config_name = {"spend": "BASELINE.json configs[3]: batch of 256 distinct Spend proofs per step on one MI355X (throughput mode)",
-                       "mixed": "BASELINE.json configs[4]'s job mix: 512 jobs per GPU and step, job j of circuit j mod 3 (Spend / Output / Convert)"}.get(
+                       "mixed": "BASELINE.json configs[4]'s job mix: 512 jobs per GPU and step, job j of circuit j mod 3"}.get(
                            WORKLOAD, "batch of 256 distinct %s proofs per step" % WORKLOAD)
+
+        def r3(x):
+            return None if x is None else round(x, 3)
+        # witnesses per second THIS rank's share of the host cores synthesises, against the proofs per second its GPU proves: below 1 the
+        # end-to-end region of an N-rank run is bound by the host, not by the GPU (`value` is not: witnesses exist before timing starts)
+        syn_rate = sum(v["instances"] for v in syn.values()) / max(sum(v["synthesize_wall_s"] for v in syn.values()), 1e-9)
+        per_gpu = total / elapsed_b / world
+        host_bound = bool(syn_rate < per_gpu)
+        if e2e is not None:
+            e2e["host_bound"] = host_bound
+        # The ONE line: numbers only, in <= 4.5 KB — what each key means, how it was measured and what was verified is in BENCH_NOTES.md
+        # (the driver's record keeps the head and the tail of the line; two thirds of the 7.7 KB one were prose and its
+        # middle — lone latencies, end_to_end, other_circuits — was lost).  Contract keys first; end_to_end / other_circuits / lone last.
         out = {
-            "metric": "Spend proofs/sec" if WORKLOAD == "spend" else "%s proofs/sec" % WORKLOAD, "value": total / elapsed_b, "unit": "proofs/s",
-            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": elapsed_b * 1e3 / K, "higher_is_better": True, "scaling": "weak",
+            "metric": "Spend proofs/sec" if WORKLOAD == "spend" else "%s proofs/sec" % WORKLOAD, "value": round(total / elapsed_b, 2), "unit": "proofs/s",
+            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": r3(elapsed_b * 1e3 / K), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "%s; the real MASP circuit(s) (structure hashes pinned to the reference's KATs), %d distinct witnesses per GPU from the "
-                                   "C++ synthesizer (instances shaped like masp_proofs/benches), fresh (r, s) every step; synthetic CRS from known toxic "
-                                   "waste (first circuit: NTT 2^%d, G1 MSMs %d/%d/%d/%d, G2 MSM %d); `value`: BASELINE.md §4's region, witnesses in "
-                                   "page-locked host memory -> proofs in host memory; launch sequences of <= %d proofs on %d HIP streams"
-                                   % (config_name, n, c0.logm, (1 << c0.logm) - 1, c0.n_aux, sh[3] + c0.n_inputs, sh[4] + 1, sh[4] + 1, BATCH, SLOTS),
-                       "proofs_per_step": n, "distinct_witnesses_per_gpu": n, "proofs_per_gpu": K * n,
-                       "arithmetic": "384-bit Fp / 255-bit Fr modular integers in 32-bit limbs (v_mad_u64_u32)",
-                       "parallelism": "proofs sharded over %d GPU(s), no data-path collective, RCCL gather of the proofs" % world},
-            "rccl_ranks": dist.get_world_size() if dist is not None else 1,
-            "collectives": "rccl" if dist is not None and backend == "nccl" else backend if dist is not None else "none",
-            # what rank 0 really sent through the process group (masp_amd/distributed.py counts at the call sites; "none" = no process group:
-            # the helpers return their argument): the u8 gathers of both regions, the CRS broadcasts, the float64 reductions
-            "collective_calls": D.collective_counts() if dist is not None else None,
-            "collective_tensors": ("cuda:%d" % local_rank if dev is not None else "cpu") if dist is not None else None,
-            "gathered_checked": gathered_checked,
-            "verified": verified_total, "verified_how": "every timed proof of both regions through the product's Groth16 batch verifier (masp_hip_verify_batch: Miller "
-                                                        "loops on the GPU), 64 per circuit also through the host verifier; %d of rank 0 byte-equal to the oracle's "
-                                                        "toxic-waste closed form" % closed_ok,
-            "verify_seconds": round(verify_s, 2),
-            "value_region": "witnesses in page-locked host memory -> K masp_hip_prove_batch calls (%d in flight) -> proofs in host memory of rank 0 " % h2h_calls +
-                            "(BASELINE.md §4; H2D of the assignments, D2H of the proofs and the gather inside)",
-            "resident": {"value": total / elapsed, "unit": "proofs/s", "ms_per_step": elapsed * 1e3 / K, "gpu_event_ms_per_step": gpu_ms / K,
-                         "region": "witnesses already resident in HBM -> proofs in host memory of rank 0 (rounds 1-2 reported this as `value`)"},
-            "roofline_valu": roofline_valu,
-            "clocks": {"value_region": ck_val, "resident_region": ck_res},
-            "end_to_end": e2e,
-            # Output / Convert: `value`-shaped short regions + lone latencies (same definitions as the Spend figures of this line)
-            "other_circuits": others,
-            "single_proof_latency_ms": latency_host_ms,
-            "single_proof_latency": {"host_to_host_ms": latency_host_ms, "resident_witness_ms": latency_ms,
-                                     "graph_replays": lone_graphs,
-                                     "note": "host_to_host: one masp_hip_prove_batch call of one Spend job, witness in page-locked host memory -> proof bytes in "
-                                             "host memory, median of 8 after 4 calls; the other figure is what rounds 1-3 reported: witness resident"},
-            "setup_seconds_rank0": round(setup_s, 2),
-            # not part of `value`: libmasp_host on the host cores, before the timed regions
-            "host_synthesis": {"ms_per_proof_one_thread": {k: round(statistics.median(v["synthesize_ms"]), 2) for k, v in syn.items()},
-                               "instances_per_s_all_threads": round(sum(v["instances"] for v in syn.values()) / max(sum(v["synthesize_wall_s"] for v in syn.values()), 1e-9), 1),
-                               "threads": threads, "witnesses_per_native_call": H.GROUP,
-                               "descriptions_per_s_all_threads": round(sum(v["instances"] for v in syn.values()) / max(sum(v["describe_wall_s"] for v in syn.values()), 1e-9), 1),
-                               "note": "witnesses per second = the C++ synthesizer alone (lockstep groups, Montgomery aux written in place into page-locked "
-                                       "memory); the descriptions (keys, note, Merkle root of each synthetic instance: python + small native calls) are made "
-                                       "before and timed apart"},
-            "ms_per_proof": elapsed_b * 1e3 / (K * n),
-            "roofline": {"bound": "hbm",
-                         "kernel": "G1 bucket-accumulation stage of one G1 MSM (h+l merged, a, b_g1): shared-inversion affine tree, %s levels in sub-batches of %d "
-                                   "proofs (k_tree_pass1 / k_tree_pass2 / k_binv_* / k_tree_copy), then k_msm_accumulate_pts<G1> over what is left"
-                                   % (ctx_tree_levels, ctx_tree_sub),
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_source, "launches": x_launches, "avg_launch_ms": x_ms / x_launches if x_launches else None,
+            "config": {"workload": config_name, "proofs_per_step": n, "proofs_per_gpu": K * n, "distinct_witnesses_per_gpu": n,
+                       "ntt_log2": c0.logm, "g1_msm_points": [(1 << c0.logm) - 1, c0.n_aux, sh[3] + c0.n_inputs, sh[4] + 1], "g2_msm_points": sh[4] + 1,
+                       "batch_cap": BATCH, "slots": SLOTS, "calls_in_flight": h2h_calls, "hw_queues": ctx.options.get("hw_queues"),
+                       "parallelism": "proofs sharded over %d GPU(s), no data-path collective, gather of the proofs" % world},
+            "notes": "BENCH_NOTES.md", "library_sha16": lib_sha,
+            "roofline": {"bound": "hbm", "kernel": "G1 bucket-accumulation stage of one G1 MSM of a batch (bucket tree %s levels, sub-batches of %d, then "
+                                                   "k_msm_accumulate_pts)" % (ctx_tree_levels, ctx_tree_sub),
+                         "achieved": r3(achieved), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": traffic, "traffic_source": traffic_source, "launches": x_launches,
+                         "avg_launch_ms": r3(x_ms / x_launches) if x_launches else None,
                          "alg_bytes_per_launch": x_bytes / x_launches if x_launches else None,
-                         # the same launches by kernel group (HIP events between the groups, same stream): ms per launch
                          "kernel_ms_per_launch": {k: round(v / x_launches, 3) for k, v in x_split.items()} if x_launches else None,
-                         "timed_region": {"launches": launches, "avg_span_ms": acc_ms / launches if launches else None,
-                                          "alg_bytes_per_launch": alg_bytes / launches if launches else None},
-                         "note": "algorithmic bytes = n x (96 B base + 32 B scalar) per G1 MSM and proof.  avg_launch_ms / achieved: HIP events "
-                                 "around the stage (all its kernels, including the latency-bound shared inversions between the tree's passes) in one "
-                                 "launch sequence run right after the timed region with nothing else on the chip (rocprofv3's kernel durations of "
-                                 "the same stage: profiles/).  timed_region: the "
-                                 "same events inside the timed region, where a launch also waits for the chip behind the other three batches' "
-                                 "kernels - a wall span, not kernel time.  This path is bound by 32-bit integer multiply throughput, not HBM "
-                                 "(DESIGN.md §4)"},
+                         "timed_region": {"launches": launches, "avg_span_ms": r3(acc_ms / launches) if launches else None}},
+            "roofline_valu": roofline_valu,
         }
         if not args.no_cpu_baseline and world == 1:
             k0 = kinds[0]
             out["cpu_baseline"] = cpu_baseline(cs[k0], params[k0], base_instance[0], base_instance[1])
+        out.update({
+            "verified": verified_total, "closed_form_equal": closed_ok, "verify_seconds": round(verify_s, 2),
+            "rccl_ranks": dist.get_world_size() if dist is not None else 1,
+            "collectives": "rccl" if dist is not None and backend == "nccl" else backend if dist is not None else "none",
+            "collective_calls": D.collective_counts() if dist is not None else None,
+            "collective_tensors": ("cuda:%d" % local_rank if dev is not None else "cpu") if dist is not None else None,
+            "gathered_checked": gathered_checked,
+            "ms_per_proof": round(elapsed_b * 1e3 / (K * n), 4),
+            "setup_seconds_rank0": round(setup_s, 2),
+            "clocks": {"value_region": ck_val, "resident_region": ck_res},
+            "host_synthesis": {"ms_per_proof_one_thread": {k: round(statistics.median(v["synthesize_ms"]), 2) for k, v in syn.items()},
+                               "threads": threads, "witnesses_per_native_call": H.GROUP, "witnesses_per_s_per_rank": round(syn_rate, 1),
+                               "proofs_per_s_per_gpu": round(per_gpu, 1), "host_bound": host_bound,
+                               "descriptions_per_s_all_threads": round(sum(v["instances"] for v in syn.values()) / max(sum(v["describe_wall_s"] for v in syn.values()), 1e-9), 1)},
+            "resident": {"value": round(total / elapsed, 2), "unit": "proofs/s", "ms_per_step": r3(elapsed * 1e3 / K), "gpu_event_ms_per_step": r3(gpu_ms / K)},
+            "other_circuits": others,
+            "single_proof_latency": {"host_to_host_ms": r3(latency_host_ms), "resident_witness_ms": r3(latency_ms), "graph_replays": lone_graphs},
+            "single_proof_latency_ms": r3(latency_host_ms),
+            "end_to_end": e2e,
+        })
     else:
         out = None
     for k_ in vk.values():

@@ -77,8 +77,9 @@ typedef struct {
                                   over the Vec<Scalar> of its recording constraint system without converting 100 000 elements per
                                   Spend (libmasp_host does: 16 % of its synthesis time).  inputs, a, b, c, r, s stay canonical. */
     uint32_t reserved;         /* must be 0 (MASP_HIP_E_INVALID_ARG otherwise).  ABI note: aux_form and reserved were appended in round 3
-                                  (sizeof 88 -> 96 on LP64); the struct carries no size field, so a binding built against the older
-                                  header must be rebuilt — INTEGRATION.md "ABI revisions" */
+                                  (sizeof 112 -> 120 on LP64: 4 + 4 padding + five pointers + 64 bytes of r | s + these two words); the
+                                  struct carries no size field, so a binding built against the older header must be rebuilt —
+                                  INTEGRATION.md "ABI revisions".  The layout is asserted at the end of this header */
 } masp_hip_job;
 #define MASP_HIP_AUX_CANONICAL 0
 #define MASP_HIP_AUX_MONTGOMERY 1
@@ -136,6 +137,10 @@ typedef struct {
                                         cut into a region per XCD and level 0 of the bucket tree walked region by region were built and
                                         measured too — profiles/r05_naf_digits_table_regions_per_xcd_rejected.txt, commit 5c2f854 — and
                                         removed: the gathers recover, the stores of that level's results fragment) */
+    int32_t window_bits_b2;          /* (round 6, appended) window width of the b_g2 query's batch tables when it should differ from
+                                        window_bits_b: a G2 addition costs three G1 additions, so b_g2's optimum is wider than b_g1's —
+                                        at the price of a sort of its own (with equal widths b_g2 is reduced from b_g1's sorted digit
+                                        list).  0 = the default (resolve_options, prover.hip); -1 = as window_bits_b */
 } masp_hip_options;
 void masp_hip_options_default(masp_hip_options* opt);
 /* The HIP runtime gives a process four hardware queues unless GPU_MAX_HW_QUEUES says otherwise, and reads the variable ONCE, at the
@@ -165,6 +170,19 @@ int masp_hip_ctx_device_count(const masp_hip_ctx* ctx);
 /* counts[d] = proofs written so far by device context d (d < min(cap, masp_hip_ctx_device_count)): lets a caller (and the
  * configs[4] test) see that a multi-device prover really deals its batches to all of its devices */
 int masp_hip_ctx_device_proofs(const masp_hip_ctx* ctx, uint64_t* counts, int cap);
+/* A multi-device prover survives a device that fails: masp_hip_prove_batch deals its blocks (<= batch_cap jobs of one circuit, the most
+ * expensive first) from ONE queue that every device's host thread takes from when it is free — no static shares —; when a device's call
+ * returns MASP_HIP_E_HIP the device is taken out, its unfinished block goes back on the queue and the other devices finish the list
+ * (the reference's per-description loop fails per description, not per transaction batch:
+ * /root/reference/masp_primitives/src/transaction/components/sapling/builder.rs:955-969).  The call fails only when NO device is left
+ * (or for an error of the input, which no other device would cure).  status[d] (d < min(cap, device count)) = MASP_HIP_OK or the
+ * error code that took device context d out; a device that is out stays out for the life of the context, and masp_hip_last_error
+ * keeps its text.  requeued (may be NULL): proofs that were put back on the queue so far.  A single-device context reports status[0]
+ * = MASP_HIP_OK. */
+int masp_hip_ctx_device_status(const masp_hip_ctx* ctx, int32_t* status, int cap, uint64_t* requeued);
+/* TEST HOOK (tests/test_gpu_device_failure.py): the `nth` masp_hip_prove_batch call (1 = the next) that device context `device` of a
+ * multi-device prover receives fails with MASP_HIP_E_HIP before it touches the device, as a lost GPU would.  nth = 0 disarms. */
+int masp_hip_ctx_inject_fault(masp_hip_ctx* ctx, int device, uint32_t nth);
 /* *out = calls of masp_hip_prove_batch groups so far that were replayed from a captured launch graph
  * (masp_hip_options::lone_proof_graph); a caller that proves one description at a time sees it grow from its third proof on */
 int masp_hip_ctx_lone_graph_launches(const masp_hip_ctx* ctx, uint64_t* out);
@@ -279,5 +297,28 @@ int masp_hip_sync(masp_hip_ctx* ctx);
 
 #ifdef __cplusplus
 }
+#endif
+
+/* ---- the layout a binding relies on, checked wherever this header is compiled (LP64: the only ABI the library is built for).  A Rust
+ * `#[repr(C)]` mirror must give the same numbers; tests/native/capi_harness.c repeats them with offsetof ---- */
+#if defined(__cplusplus) && __cplusplus >= 201103L
+#define MASP_HIP_STATIC_ASSERT(c, m) static_assert(c, m)
+#elif defined(__STDC_VERSION__) && __STDC_VERSION__ >= 201112L
+#define MASP_HIP_STATIC_ASSERT(c, m) _Static_assert(c, m)
+#else
+#define MASP_HIP_SA_CAT2(a, b) a##b
+#define MASP_HIP_SA_CAT(a, b) MASP_HIP_SA_CAT2(a, b)
+#define MASP_HIP_STATIC_ASSERT(c, m) typedef char MASP_HIP_SA_CAT(masp_hip_static_assert_, __LINE__)[(c) ? 1 : -1]
+#endif
+#if defined(__LP64__) || defined(_LP64)
+MASP_HIP_STATIC_ASSERT(sizeof(masp_hip_job) == 120, "masp_hip_job: 4 + 4 pad + 5 pointers + r[32] + s[32] + aux_form + reserved");
+MASP_HIP_STATIC_ASSERT(offsetof(masp_hip_job, inputs) == 8 && offsetof(masp_hip_job, c) == 40, "masp_hip_job pointers");
+MASP_HIP_STATIC_ASSERT(offsetof(masp_hip_job, r) == 48 && offsetof(masp_hip_job, s) == 80, "masp_hip_job r | s");
+MASP_HIP_STATIC_ASSERT(offsetof(masp_hip_job, aux_form) == 112 && offsetof(masp_hip_job, reserved) == 116, "masp_hip_job tail");
+MASP_HIP_STATIC_ASSERT(sizeof(masp_hip_r1cs) == 88 && offsetof(masp_hip_r1cs, a_rowptr) == 16 && offsetof(masp_hip_r1cs, c_coef) == 80,
+                       "masp_hip_r1cs: three counts + 4 pad + nine pointers");
+MASP_HIP_STATIC_ASSERT(sizeof(masp_hip_options) == 76 && offsetof(masp_hip_options, window_bits_b2) == 72,
+                       "masp_hip_options: struct_size + 18 int32 fields (appended-only: struct_size versions it)");
+MASP_HIP_STATIC_ASSERT(offsetof(masp_hip_options, hw_queues) == 60 && offsetof(masp_hip_options, digit_recoding) == 68, "masp_hip_options tail");
 #endif
 #endif

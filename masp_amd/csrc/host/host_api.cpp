@@ -6,6 +6,7 @@
 // native primitives, so that tests can pin them against the reference's vectors.
 #include <memory>
 
+#include "../../../include/masp_host.h"   // the declarations of everything defined here: a mismatch does not compile
 #include "circuits.h"
 #include "groth16_vk.h"
 #include "pairing_prog.h"
@@ -109,7 +110,6 @@ bool load_path(MerklePathW& p, const uint8_t* siblings, uint64_t position) {
 
 extern "C" {
 
-enum { MASP_HOST_OK = 0, MASP_HOST_E_INVALID = 1, MASP_HOST_E_DIVERSIFIER = 2, MASP_HOST_E_SYNTHESIS = 3, MASP_HOST_E_UNSATISFIED = 4 };
 
 // ---- static circuits: kind 0 spend, 1 output, 2 convert --------------------------------------------
 void* masp_host_circuit_setup(int kind) {
@@ -269,24 +269,7 @@ void masp_host_fr_from_montgomery(const uint8_t* in, uint8_t* out, size_t n) {
 // One job = the arguments of masp_host_spend_assignment / masp_host_convert_assignment plus its return code.  `check` as there
 // (check & 1 records and verifies the constraints: that goes witness by witness through the generic gadgets).  Returns the number
 // of jobs whose rc is not MASP_HOST_OK.  A caller gives each of its threads a group of ~16 jobs.
-struct masp_host_spend_job {
-    const uint8_t *ak, *nsk, *diversifier, *rcm, *ar, *asset_identifier;
-    uint64_t value;
-    const uint8_t *anchor, *path_siblings;
-    uint64_t position;
-    const uint8_t* rcv;
-    uint8_t *inputs, *aux, *cv_out, *rk_out, *nf_out;
-    int rc;
-};
-struct masp_host_convert_job {
-    const uint8_t* generator;
-    uint64_t value;
-    const uint8_t *anchor, *path_siblings;
-    uint64_t position;
-    const uint8_t* rcv;
-    uint8_t *inputs, *aux, *cv_out;
-    int rc;
-};
+// (masp_host_spend_job / masp_host_convert_job: include/masp_host.h)
 int masp_host_spend_assignments(size_t n, masp_host_spend_job* jobs, int check) {
     if (check & 1) {
         int bad = 0;

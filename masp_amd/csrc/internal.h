@@ -303,6 +303,11 @@ struct masp_hip_ctx {
     std::vector<std::unique_ptr<ResidentBatch>> batches;
     bool profiling = false;
     std::atomic<uint64_t> proofs_done{0};   // proofs this device context has written (masp_hip_ctx_device_proofs)
+    // multi-device front: MASP_HIP_OK or the error that took device context d out (prove_batch_multi), and the proofs it put back on the queue
+    std::unique_ptr<std::atomic<int>[]> dev_status;
+    std::atomic<uint64_t> requeued{0};
+    // device context: the n-th masp_hip_prove_batch call from now fails before it touches the device (masp_hip_ctx_inject_fault; 0 = disarmed)
+    std::atomic<uint32_t> fault_countdown{0};
     // the building-block MSM entry points (masp_hip_msm_g1_multi ...) run on a workspace of their own: what lack of tree scratch did there
     std::atomic<uint64_t> block_tree_fallbacks{0};
     std::atomic<uint32_t> block_tree_sub{0xffffffffu};

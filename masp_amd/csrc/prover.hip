@@ -56,6 +56,8 @@ static masp_hip_options resolve_options(const masp_hip_options* in) {
     // tables (16.6 GB for Spend) are beyond what an XCD's L2 TLB reaches (~3.5 GiB) and the gathers of the tree's level 0 then run at a
     // quarter of their rate: -8 % Spend proofs/s, +2 % for Output, whose tables fit (profiles/r05_naf_digits_per_bit_tables_*.txt)
     o.digit_recoding = o.digit_recoding > 0 ? 1 : 0;
+    // b_g2's batch tables on a window width of their own (2..16); 0 / -1 resolved where the circuit is loaded (masp_hip_circuit_load)
+    o.window_bits_b2 = o.window_bits_b2 > 0 ? std::max(2, std::min<int>(o.window_bits_b2, 16)) : o.window_bits_b2 < 0 ? -1 : 0;
     return o;
 }
 // [0, n) cut into ceil(n / cap) groups whose sizes differ by at most one: (first, count) pairs
@@ -515,29 +517,40 @@ void masp_hip_options_default(masp_hip_options* opt) {
 // queue run one after the other).  Temporary streams, created and destroyed BEFORE the context creates its own.
 static __global__ void k_hwq_spin(unsigned long long* out, int idx, long long ticks) {
     const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) {
+    // (bounded: a clock that does not advance must not hang the context's creation — 2^22 polls are ~100 ms)
+    for (int it = 0; it < (1 << 22) && wall_clock64() - t0 < ticks; ++it) {
     }
     out[2 * idx] = (unsigned long long)t0;
     out[2 * idx + 1] = (unsigned long long)wall_clock64();
 }
-static int measure_hw_queues(int streams) {
+// Measured ONCE per (process, device) and remembered: the runtime fixes its queue count at the process's first HIP call, so a second
+// context has nothing new to learn — and its probe would wait behind, and share the chip with, whatever the first context is running
+// (ADVICE r05).  The probe synchronises its own streams only, and its buffer goes through dev_malloc / dev_free like every other.
+static int measure_hw_queues(int device, int streams) {
+    static std::mutex mu;
+    static std::map<int, int> known;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = known.find(device);
+    if (it != known.end()) return it->second;
     const int n = std::max(1, std::min(streams, 24));
     std::vector<hipStream_t> ss;
     unsigned long long* d = nullptr;
     int best = 0;
-    if (hipMalloc(&d, 16 * n) != hipSuccess) return 0;
+    if (dev_malloc(&d, 16 * n) != hipSuccess) return 0;
     for (int i = 0; i < n; ++i) {
         hipStream_t s = nullptr;
         if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
         ss.push_back(s);
     }
     if ((int)ss.size() == n) {
+        bool ok = true;
         for (int r = 0; r < 2; ++r) {  // (the first round loads the code object and creates the queues)
             for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k_hwq_spin, dim3(1), dim3(64), 0, ss[i], d, i, r ? 200000LL : 1000LL);
-            (void)hipDeviceSynchronize();
+            for (int i = 0; i < n; ++i) ok = hipStreamSynchronize(ss[i]) == hipSuccess && ok;
         }
         std::vector<unsigned long long> h(2 * n);
-        if (hipGetLastError() == hipSuccess && hipMemcpy(h.data(), d, 16 * n, hipMemcpyDeviceToHost) == hipSuccess)
+        if (ok && hipGetLastError() == hipSuccess && hipMemcpyAsync(h.data(), d, 16 * n, hipMemcpyDeviceToHost, ss[0]) == hipSuccess &&
+            hipStreamSynchronize(ss[0]) == hipSuccess)
             for (int i = 0; i < n; ++i) {
                 int c = 0;
                 for (int j = 0; j < n; ++j) c += h[2 * j] <= h[2 * i] && h[2 * i] < h[2 * j + 1];
@@ -545,8 +558,9 @@ static int measure_hw_queues(int streams) {
             }
     }
     for (hipStream_t s : ss) (void)hipStreamDestroy(s);
-    (void)hipFree(d);
+    (void)dev_free(d);
     (void)hipGetLastError();
+    if (best > 0) known[device] = best;
     return best;
 }
 
@@ -562,7 +576,7 @@ static int create_single(int device, const masp_hip_options& opt, masp_hip_ctx**
     ctx->batch_cap = (size_t)opt.batch_cap;
     ctx->slots.reserve(masp_hip_ctx::MAX_SLOTS);      // never reallocates: see the locking note on masp_hip_ctx
     ctx->slot_busy.reserve(masp_hip_ctx::MAX_SLOTS);
-    ctx->opt.hw_queues = measure_hw_queues(5 * opt.slots);   // (a slot owns five streams)
+    ctx->opt.hw_queues = measure_hw_queues(device, 5 * opt.slots);   // (a slot owns five streams)
     if (hipStreamCreateWithFlags(&ctx->main_stream, hipStreamNonBlocking) != hipSuccess) return MASP_HIP_E_NO_DEVICE;
     *out = ctx.release();
     return MASP_HIP_OK;
@@ -588,6 +602,8 @@ int masp_hip_ctx_create_ex(const int* devices, int n_devices, const masp_hip_opt
         }
         front->children.push_back(ch);
     }
+    front->dev_status.reset(new std::atomic<int>[n_devices]);
+    for (int i = 0; i < n_devices; ++i) front->dev_status[i] = MASP_HIP_OK;
     *out = front.release();
     return MASP_HIP_OK;
 }
@@ -595,7 +611,12 @@ int masp_hip_ctx_create_ex(const int* devices, int n_devices, const masp_hip_opt
 int masp_hip_ctx_get_options(const masp_hip_ctx* ctx, masp_hip_options* out) {
     if (!ctx || !out) return MASP_HIP_E_INVALID_ARG;
     const masp_hip_ctx* c = ctx->children.empty() ? ctx : ctx->children[0];
-    *out = c->opt;
+    // `out->struct_size` on entry = the size of the CALLER's struct (0: this header's): a binding built against an older, shorter
+    // masp_hip_options gets only the bytes its struct has room for (the plain assignment wrote sizeof(new struct) into it)
+    const size_t room = out->struct_size ? std::min<size_t>(out->struct_size, sizeof(masp_hip_options)) : sizeof(masp_hip_options);
+    if (room < 4 * sizeof(int32_t)) return MASP_HIP_E_INVALID_ARG;
+    masp_hip_options full = c->opt, *const caller_out = out;
+    out = &full;
     // what lack of tree scratch has changed since the context was created: the smallest sub-batch any slot works with now, and
     // the proofs whose bucket runs went through the XYZZ accumulation instead (all device contexts)
     uint64_t fb = 0;
@@ -615,6 +636,8 @@ int masp_hip_ctx_get_options(const masp_hip_ctx* ctx, masp_hip_options* out) {
     if (c->block_tree_sub.load() != 0xffffffffu) sub = std::min<int>(sub, (int)c->block_tree_sub.load());
     out->bucket_tree_sub_batch = sub;
     out->bucket_tree_fallback_proofs = (int32_t)std::min<uint64_t>(fb, 0x7fffffff);
+    full.struct_size = (uint32_t)room;   // the bytes written
+    memcpy(caller_out, &full, room);
     return MASP_HIP_OK;
 }
 
@@ -637,6 +660,8 @@ int masp_hip_ctx_create_multi(const int* devices, int n_devices, masp_hip_ctx** 
     int rc = create_single(devices[0], front->opt, &ch);
     if (rc) return rc;
     front->children.push_back(ch);
+    front->dev_status.reset(new std::atomic<int>[1]);
+    front->dev_status[0] = MASP_HIP_OK;
     *out = front.release();
     return MASP_HIP_OK;
 }
@@ -648,6 +673,27 @@ int masp_hip_ctx_device_proofs(const masp_hip_ctx* ctx, uint64_t* counts, int ca
         return MASP_HIP_OK;
     }
     for (size_t d = 0; d < ctx->children.size() && (int)d < cap; ++d) counts[d] = ctx->children[d]->proofs_done.load();
+    return MASP_HIP_OK;
+}
+int masp_hip_ctx_device_status(const masp_hip_ctx* ctx, int32_t* status, int cap, uint64_t* requeued) {
+    if (!ctx || !status || cap < 0) return MASP_HIP_E_INVALID_ARG;
+    if (requeued) *requeued = ctx->requeued.load();
+    if (ctx->children.empty()) {
+        if (cap >= 1) status[0] = MASP_HIP_OK;
+        return MASP_HIP_OK;
+    }
+    for (size_t d = 0; d < ctx->children.size() && (int)d < cap; ++d) status[d] = ctx->dev_status[d].load();
+    return MASP_HIP_OK;
+}
+int masp_hip_ctx_inject_fault(masp_hip_ctx* ctx, int device, uint32_t nth) {
+    if (!ctx || device < 0) return MASP_HIP_E_INVALID_ARG;
+    if (ctx->children.empty()) {
+        if (device != 0) return MASP_HIP_E_INVALID_ARG;
+        ctx->fault_countdown = nth;
+        return MASP_HIP_OK;
+    }
+    if ((size_t)device >= ctx->children.size()) return MASP_HIP_E_INVALID_ARG;
+    ctx->children[device]->fault_countdown = nth;
     return MASP_HIP_OK;
 }
 int masp_hip_ctx_lone_graph_launches(const masp_hip_ctx* ctx, uint64_t* out) {
@@ -805,6 +851,9 @@ int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* param
     const uint32_t pct = (uint32_t)ctx->opt.witness_nontrivial_percent;
     auto eff = [&](uint32_t n) { return (uint32_t)((uint64_t)n * pct / 100); };
     const int c_la = ctx->opt.window_bits_la, c_b = ctx->opt.window_bits_b;   // 0: chosen from the expected non-trivial scalars
+    // b_g2 of a batch: its own width if asked for (masp_hip_options::window_bits_b2), else b_g1's — it is then reduced from b_g1's sorted
+    // digit list instead of sorting for itself (enqueue_proofs: share_bq)
+    const int c_b2 = ctx->opt.window_bits_b2 > 0 ? ctx->opt.window_bits_b2 : c_b;
     // h has uniform scalars: 16-bit windows from 48 k points (Spend 131 071, Convert 65 535), 15 bits below (Output 32 767)
     const uint32_t n_h = (uint32_t)(C->m - 1);
     const int c_h = ctx->opt.window_bits_h ? ctx->opt.window_bits_h : n_h >= 49152 ? 16 : n_h >= 16384 ? 15 : 0;
@@ -817,7 +866,7 @@ int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* param
     auto nafw = [&](int c) { return c ? c + 1 : 0; };
     if ((rc = C->h.load_host(L.h, (uint32_t)(C->m - 1), s, 0xffffffffu, c_h_lone)) || (rc = C->l.load_host(L.l, L.n_l, s, eff(L.n_l), c_la)) ||
         (rc = C->a.load_host(L.a, L.n_a, s, eff(L.n_a), c_la)) || (rc = C->b1.load_host(L.b_g1, L.n_b1, s, eff(L.n_b1), c_b)) ||
-        (rc = C->b2.load_host(L.b_g2, L.n_b2, s, eff(L.n_b2), c_b)))
+        (rc = C->b2.load_host(L.b_g2, L.n_b2, s, eff(L.n_b2), c_b2)))
         return fail(ctx, rc);
     if (naf && ((rc = C->a_naf.load_host(L.a, L.n_a, s, eff(L.n_a), nafw(c_la), true)) ||
                 (rc = C->b1_naf.load_host(L.b_g1, L.n_b1, s, eff(L.n_b1), nafw(c_b), true)) ||
@@ -867,44 +916,118 @@ int masp_hip_circuit_flags(const masp_hip_ctx* ctx, uint32_t slot, uint32_t* fla
     return MASP_HIP_OK;
 }
 
-// Multi-device front: the jobs of every circuit are cut into blocks of up to batch_cap proofs and the blocks are dealt
-// to the devices round-robin (so every device gets full batches of every circuit in the list); one host thread per
-// device runs the ordinary single-device call on its share.  Proofs are independent: there is no data-path exchange
-// between devices, the results are copied back to the jobs' own positions.
+// What masp_hip_prove_batch refuses before it touches a device — the same tests for a single-device context and for the front of a
+// multi-device one (there they must not be mistaken for a device's failure)
+static int validate_jobs(const masp_hip_ctx* dev_ctx, size_t n, const masp_hip_job* jobs) {
+    for (size_t j = 0; j < n; ++j) {
+        const masp_hip_job& J = jobs[j];
+        if (J.circuit >= MASP_HIP_MAX_CIRCUITS || !J.inputs || !J.aux) return MASP_HIP_E_INVALID_ARG;
+        if (!dev_ctx->circ[J.circuit]) return MASP_HIP_E_NOT_LOADED;
+        if ((J.a || J.b || J.c) && !(J.a && J.b && J.c)) return MASP_HIP_E_INVALID_ARG;
+        if (J.reserved != 0) return MASP_HIP_E_INVALID_ARG;  // must be zero: a later revision of the struct can then give it a meaning
+        if (J.aux_form > MASP_HIP_AUX_MONTGOMERY || (J.aux_form && J.a)) return MASP_HIP_E_INVALID_ARG;  // (a, b, c given: nothing reads aux as Montgomery)
+        if (!rs_in_range(J.r) || !rs_in_range(J.s)) return MASP_HIP_E_SCALAR_RANGE;
+    }
+    return MASP_HIP_OK;
+}
+
+// Multi-device front (round 6: a queue instead of static shares).  The jobs of every kind (circuit, aux form, a/b/c mode) are cut into
+// blocks of up to batch_cap proofs; the blocks wait on ONE queue, the most expensive first (constraints x proofs: a Spend block costs
+// three Output blocks), and every device has `slots` host threads that each take the next block when their last one is done — a device
+// that clocks lower, or shares its GPU, simply takes fewer.  A device whose call fails with a HIP error is taken OUT (for the life of
+// the context: masp_hip_ctx_device_status), its block goes back on the queue and the other devices finish the list; the call fails only
+// when no device is left, or for an error of the input (MASP_HIP_E_SCALAR_RANGE from the device's range check of an assignment), which
+// no other device would cure.  Proofs are independent: there is no data-path exchange between devices; results are copied to the jobs'
+// own positions.  (The reference's loop fails per description: /root/reference/masp_primitives/src/transaction/components/sapling/builder.rs:955-969.)
 static int prove_batch_multi(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, uint8_t* proofs_out) {
     const size_t nd = ctx->children.size();
-    std::vector<std::vector<size_t>> share(nd);
+    auto alive = [&](size_t d) { return ctx->dev_status[d].load() == MASP_HIP_OK; };
+    size_t n_alive = 0, first_alive = nd;
+    for (size_t d = 0; d < nd; ++d)
+        if (alive(d)) {
+            ++n_alive;
+            if (first_alive == nd) first_alive = d;
+        }
+    if (!n_alive) return MASP_HIP_E_HIP;   // (masp_hip_last_error: the text of the device that failed first)
+    {
+        std::shared_lock<std::shared_mutex> lock(ctx->children[first_alive]->mu);
+        if (int rc = validate_jobs(ctx->children[first_alive], n, jobs)) return rc;
+    }
+    struct Block {
+        std::vector<size_t> idx;
+        uint64_t cost;
+    };
+    std::deque<Block> queue;
     {
         std::map<std::pair<uint32_t, bool>, std::vector<size_t>> by_kind;
         for (size_t j = 0; j < n; ++j) by_kind[{jobs[j].circuit | (jobs[j].aux_form ? 0x100u : 0u), jobs[j].a != nullptr}].push_back(j);
-        size_t next = 0;
+        std::vector<Block> blocks;
         for (auto& kv : by_kind) {
             // at least one block per device when the list is long enough to give every device a useful batch
-            size_t cap = std::min(ctx->batch_cap, std::max<size_t>((kv.second.size() + nd - 1) / nd, 8));
+            const size_t cap = std::min(ctx->batch_cap, std::max<size_t>((kv.second.size() + n_alive - 1) / n_alive, 8));
+            const Circuit& C = *ctx->children[first_alive]->circ[kv.first.first & 0xffu];
             for (auto& g : even_groups(kv.second.size(), cap)) {
-                auto& dst = share[next++ % nd];
-                dst.insert(dst.end(), kv.second.begin() + g.first, kv.second.begin() + g.first + g.second);
+                Block b;
+                b.idx.assign(kv.second.begin() + g.first, kv.second.begin() + g.first + g.second);
+                b.cost = (uint64_t)C.nrows * g.second;
+                blocks.push_back(std::move(b));
             }
         }
+        std::stable_sort(blocks.begin(), blocks.end(), [](const Block& x, const Block& y) { return x.cost > y.cost; });
+        for (auto& b : blocks) queue.push_back(std::move(b));
     }
-    std::vector<int> rcs(nd, MASP_HIP_OK);
-    std::vector<std::vector<uint8_t>> outs(nd);
+    std::mutex mu;                 // queue, pending, fatal
+    std::condition_variable cv;
+    size_t pending = queue.size();  // blocks not yet proved (queued or in some worker's hands)
+    int fatal = MASP_HIP_OK;
+    auto worker = [&](size_t d) {
+        masp_hip_ctx* ch = ctx->children[d];
+        std::vector<masp_hip_job> mine;
+        std::vector<uint8_t> out;
+        for (;;) {
+            Block b;
+            {
+                std::unique_lock<std::mutex> g(mu);
+                // (an empty queue is not the end: a block in another worker's hands may come back when its device fails)
+                cv.wait(g, [&] { return !queue.empty() || pending == 0 || fatal || !alive(d); });
+                if (pending == 0 || fatal || !alive(d)) return;
+                b = std::move(queue.front());
+                queue.pop_front();
+            }
+            mine.resize(b.idx.size());
+            for (size_t k = 0; k < mine.size(); ++k) mine[k] = jobs[b.idx[k]];
+            out.resize(192 * mine.size());
+            const int rc = masp_hip_prove_batch(ch, mine.size(), mine.data(), out.data());
+            std::unique_lock<std::mutex> g(mu);
+            if (rc == MASP_HIP_OK) {
+                for (size_t k = 0; k < b.idx.size(); ++k) memcpy(proofs_out + 192 * b.idx[k], out.data() + 192 * k, 192);
+                --pending;
+            } else if (rc == MASP_HIP_E_HIP || rc == MASP_HIP_E_NO_DEVICE) {
+                int ok = MASP_HIP_OK;
+                ctx->dev_status[d].compare_exchange_strong(ok, rc);   // the device is out; its other workers leave at their next turn
+                ctx->requeued += b.idx.size();
+                queue.push_front(std::move(b));                      // (an expensive block that has already waited: first again)
+                bool any = false;
+                for (size_t e = 0; e < nd; ++e) any = any || alive(e);
+                if (!any) fatal = rc;
+            } else {
+                fatal = rc;   // an error of the input: no other device would decide differently
+            }
+            cv.notify_all();
+            if (rc != MASP_HIP_OK) return;
+        }
+    };
     std::vector<std::thread> th;
     for (size_t d = 0; d < nd; ++d) {
-        if (share[d].empty()) continue;
-        th.emplace_back([&, d] {
-            std::vector<masp_hip_job> mine(share[d].size());
-            for (size_t k = 0; k < mine.size(); ++k) mine[k] = jobs[share[d][k]];
-            outs[d].resize(192 * mine.size());
-            rcs[d] = masp_hip_prove_batch(ctx->children[d], mine.size(), mine.data(), outs[d].data());
-        });
+        if (!alive(d)) continue;
+        // as many calls in flight per device as it has slots (masp_hip_prove_batch of a device context is re-entrant: each call's batches
+        // take slots of its pool), but not more workers than there are blocks
+        const size_t w = std::min<size_t>(std::max(ctx->children[d]->n_slots, 1), std::max<size_t>((queue.size() + n_alive - 1) / n_alive, 1));
+        for (size_t k = 0; k < w; ++k) th.emplace_back(worker, d);
     }
     for (auto& t : th) t.join();
-    for (int rc : rcs)
-        if (rc) return rc;
-    for (size_t d = 0; d < nd; ++d)
-        for (size_t k = 0; k < share[d].size(); ++k) memcpy(proofs_out + 192 * share[d][k], outs[d].data() + 192 * k, 192);
-    return MASP_HIP_OK;
+    if (fatal) return fatal;
+    return pending == 0 ? MASP_HIP_OK : MASP_HIP_E_HIP;
 }
 
 int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, uint8_t* proofs_out) {
@@ -912,16 +1035,17 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
     if (!ctx || (n && (!jobs || !proofs_out))) return MASP_HIP_E_INVALID_ARG;
     if (!ctx->children.empty()) return prove_batch_multi(ctx, n, jobs, proofs_out);
     std::shared_lock<std::shared_mutex> lock(ctx->mu);  // concurrent with other provers, exclusive with circuit loads
-    hipSetDevice(ctx->device);
-    for (size_t j = 0; j < n; ++j) {
-        const masp_hip_job& J = jobs[j];
-        if (J.circuit >= MASP_HIP_MAX_CIRCUITS || !J.inputs || !J.aux) return MASP_HIP_E_INVALID_ARG;
-        if (!ctx->circ[J.circuit]) return MASP_HIP_E_NOT_LOADED;
-        if ((J.a || J.b || J.c) && !(J.a && J.b && J.c)) return MASP_HIP_E_INVALID_ARG;
-        if (J.reserved != 0) return MASP_HIP_E_INVALID_ARG;  // must be zero: a later revision of the struct can then give it a meaning
-        if (J.aux_form > MASP_HIP_AUX_MONTGOMERY || (J.aux_form && J.a)) return MASP_HIP_E_INVALID_ARG;  // (a, b, c given: nothing reads aux as Montgomery)
-        if (!rs_in_range(J.r) || !rs_in_range(J.s)) return MASP_HIP_E_SCALAR_RANGE;
+    if (int rc = validate_jobs(ctx, n, jobs)) return rc;
+    // test hook (masp_hip_ctx_inject_fault): this call fails as a lost device's would, before anything is enqueued
+    for (uint32_t left = ctx->fault_countdown.load(); left != 0;) {
+        if (!ctx->fault_countdown.compare_exchange_weak(left, left - 1)) continue;
+        if (left == 1) {
+            last_hip_error() = "injected fault (masp_hip_ctx_inject_fault): this device context's call fails as a lost GPU's would";
+            return fail_shared(ctx, MASP_HIP_E_HIP);
+        }
+        break;
     }
+    hipSetDevice(ctx->device);
     // jobs are bucketed by (circuit, a/b/c mode) — whatever their order in the list — and every bucket is cut into
     // equal batches of at most batch_cap proofs (256 Spends with a cap of 96: 86 + 85 + 85, not 96 + 96 + 64); results go
     // back to the jobs' own positions

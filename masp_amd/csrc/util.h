@@ -62,8 +62,8 @@ inline std::atomic<uint64_t>& device_alloc_epoch() {
 // list is emptied where waiting costs nothing — when the last busy slot of a context is released, when a context is destroyed —
 // and when an allocation fails for lack of memory.  What lingers in between is bounded by the buffers' earlier, smaller sizes.
 // One list per DEVICE (round 5): with one process-global list an idle release on one device context called hipFree — and its
-// device-wide wait — on buffers of OTHER devices that were in the middle of a batch.  A buffer goes on the list of the device that is
-// current when it is released (every library call sets its context's device first); dev_free_drain() empties the current device's list.
+// device-wide wait — on buffers of OTHER devices that were in the middle of a batch.  A buffer goes on the list of the device that OWNS
+// it (asked of the runtime when it is released); dev_free_drain() empties the current device's list.
 struct DevGraveyard {
     std::mutex mu;
     std::vector<std::pair<int, void*>> v;  // (device, buffer)
@@ -117,7 +117,16 @@ inline hipError_t dev_malloc(T** p, size_t bytes) {
 }
 inline hipError_t dev_free(void* p) {
     device_alloc_epoch().fetch_add(1, std::memory_order_relaxed);
-    const int dev = dev_current();
+    // the device that OWNS the buffer, not the one that happens to be current on the releasing thread (a destructor run from static
+    // teardown, a Python GC thread, a multi-device front's other thread: ADVICE r05) — the runtime knows; if it no longer answers
+    // (process teardown), the current device is as good a guess as any
+    int dev = -1;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type == hipMemoryTypeDevice)
+        dev = attr.device;
+    else
+        (void)hipGetLastError();
+    if (dev < 0) dev = dev_current();
     std::lock_guard<std::mutex> g(dev_graveyard().mu);
     dev_graveyard().v.push_back({dev, p});
     return hipSuccess;

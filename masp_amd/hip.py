@@ -21,14 +21,18 @@ class MaspHipError(RuntimeError):
 
 
 OPTION_FIELDS = ("slots", "batch_cap", "ntt_sub_batch", "window_bits_h", "window_bits_la", "window_bits_b", "window_bits_b2_lone",
-                 "witness_nontrivial_percent", "bucket_tree_levels", "bucket_tree_sub_batch", "bucket_tree_levels_g2", "bucket_tree_scratch_mb", "lone_proof_graph", "window_bits_h_lone", "digit_recoding")
+                 "witness_nontrivial_percent", "bucket_tree_levels", "bucket_tree_sub_batch", "bucket_tree_levels_g2", "bucket_tree_scratch_mb", "lone_proof_graph", "window_bits_h_lone", "digit_recoding",
+                 "window_bits_b2")
 
 
 class OptionsStruct(C.Structure):
     """masp_hip_options (include/masp_hip.h): every field 0 = the default."""
-    _fields_ = ([("struct_size", C.c_uint32)] + [(f, C.c_int32) for f in OPTION_FIELDS[:-3]] +
+    _fields_ = ([("struct_size", C.c_uint32)] + [(f, C.c_int32) for f in OPTION_FIELDS[:OPTION_FIELDS.index("lone_proof_graph")]] +
                 [("bucket_tree_fallback_proofs", C.c_int32), ("lone_proof_graph", C.c_int32), ("hw_queues", C.c_int32), ("window_bits_h_lone", C.c_int32),
-                 ("digit_recoding", C.c_int32)])
+                 ("digit_recoding", C.c_int32), ("window_bits_b2", C.c_int32)])
+
+
+assert C.sizeof(OptionsStruct) == 76 and OptionsStruct.window_bits_b2.offset == 72        # include/masp_hip.h asserts the same
 
 
 class JobStruct(C.Structure):
@@ -37,6 +41,7 @@ class JobStruct(C.Structure):
                 ("reserved", C.c_uint32)]
 
 
+assert C.sizeof(JobStruct) == 120 and JobStruct.r.offset == 48 and JobStruct.aux_form.offset == 112   # include/masp_hip.h asserts the same
 AUX_CANONICAL, AUX_MONTGOMERY = 0, 1     # masp_hip_job::aux_form
 MSM_NAF = 0x100                          # masp_hip_msm_g{1,2}_multi: window_bits = MSM_NAF | w (MASP_HIP_MSM_NAF)
 
@@ -76,6 +81,9 @@ def load_library():
     L.masp_hip_options_default.restype = None
     L.masp_hip_ctx_device_count.argtypes = [vp]
     L.masp_hip_ctx_device_proofs.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
+    if hasattr(L, "masp_hip_ctx_device_status"):            # (round 6; an older build passed as MASP_HIP_LIBRARY lacks them)
+        L.masp_hip_ctx_device_status.argtypes = [vp, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_uint64)]
+        L.masp_hip_ctx_inject_fault.argtypes = [vp, C.c_int, C.c_uint32]
     # (introspection added in round 4: an older build passed as MASP_HIP_LIBRARY for an A/B run lacks them; calling them then raises)
     if hasattr(L, "masp_hip_ctx_lone_graph_launches"):
         L.masp_hip_ctx_lone_graph_launches.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -179,6 +187,7 @@ class Context:
         if rc:
             raise MaspHipError(rc)
         got = OptionsStruct()
+        got.struct_size = C.sizeof(OptionsStruct)           # the library writes no more than the caller's struct holds
         self._L.masp_hip_ctx_get_options(h, C.byref(got))
         self.options = {f: int(getattr(got, f)) for f in OPTION_FIELDS}      # defaults resolved
         # hardware queues the runtime spreads this process's streams over, measured at creation (masp_hip_options::hw_queues): fewer than
@@ -329,6 +338,7 @@ class Context:
         """masp_hip_ctx_get_options now: the options with what lack of tree scratch has changed since creation — the
         `bucket_tree_sub_batch` in use and `bucket_tree_fallback_proofs` (proofs that went through the XYZZ accumulation)."""
         got = OptionsStruct()
+        got.struct_size = C.sizeof(OptionsStruct)
         self._check(self._L.masp_hip_ctx_get_options(self._h, C.byref(got)))
         d = {f: int(getattr(got, f)) for f in OPTION_FIELDS}
         d["bucket_tree_fallback_proofs"] = int(got.bucket_tree_fallback_proofs)
@@ -357,6 +367,17 @@ class Context:
         counts = (C.c_uint64 * n)()
         self._check(self._L.masp_hip_ctx_device_proofs(self._h, counts, n))
         return list(counts)
+
+    def device_status(self):
+        """masp_hip_ctx_device_status -> ([0 or the error code that took device context d out], proofs put back on the queue so far)"""
+        n = self.device_count
+        st, rq = (C.c_int32 * n)(), C.c_uint64(0)
+        self._check(self._L.masp_hip_ctx_device_status(self._h, st, n, C.byref(rq)))
+        return list(st), int(rq.value)
+
+    def inject_fault(self, device, nth):
+        """TEST HOOK masp_hip_ctx_inject_fault: the nth prove_batch call device context `device` receives from now fails (0 disarms)"""
+        self._check(self._L.masp_hip_ctx_inject_fault(self._h, int(device), int(nth)))
 
     def quotient_h(self, a, b, c, logm):
         a, b, c = _u8(a, 32), _u8(b, 32), _u8(c, 32)

@@ -93,15 +93,30 @@ class _Permits:
         self._cv = threading.Condition()
         self._next_ticket = 0
         self._serving = 0
+        self._abandoned = set()
+
+    def _skip_abandoned(self):
+        while self._serving in self._abandoned:
+            self._abandoned.discard(self._serving)
+            self._serving += 1
 
     def acquire(self, k=1):
         with self._cv:
             ticket = self._next_ticket
             self._next_ticket += 1
-            while self._serving != ticket or self._n < k:
-                self._cv.wait()
+            try:
+                while self._serving != ticket or self._n < k:
+                    self._cv.wait()
+            except BaseException:
+                # a waiter interrupted in wait() (KeyboardInterrupt, an async exception) gives its ticket up: without this nobody would
+                # ever serve it and every later acquirer would wait for ever
+                self._abandoned.add(ticket)
+                self._skip_abandoned()
+                self._cv.notify_all()
+                raise
             self._n -= k
             self._serving += 1
+            self._skip_abandoned()
             self._cv.notify_all()
 
     def release(self, k=1):
@@ -442,7 +457,14 @@ class LocalTxProver:
         background=True: on a thread; the next proving call waits for it.  = what `LocalTxProver::new` (prover.rs:55-95) has no
         counterpart for: bellperson allocates per proof."""
         if background:
-            t = threading.Thread(target=self.warm_up, args=(spends, outputs, converts, threads), daemon=True)
+            self._warm_error = None
+
+            def run():
+                try:
+                    self.warm_up(spends, outputs, converts, threads)
+                except BaseException as e:      # kept for the next proving call: a daemon thread's exception is otherwise lost (ADVICE r05)
+                    self._warm_error = e
+            t = threading.Thread(target=run, daemon=True)
             self._warm = t
             t.start()
             return
@@ -472,6 +494,9 @@ class LocalTxProver:
         if t is not None and t is not threading.current_thread():
             t.join()
             self._warm = None
+            e, self._warm_error = getattr(self, "_warm_error", None), None
+            if e is not None:           # out of memory while sizing the slots, a failed launch sequence: the caller must not prove on
+                raise RuntimeError("LocalTxProver.warm_up(background=True) failed: %r" % (e,)) from e   # a context in an unknown state
 
     def prove_prepared(self, jobs, rs=None):
         """jobs: outputs of prepare_*; rs: optional explicit [(r, s)] (deterministic replay) -> list of 192-byte proofs."""

@@ -64,3 +64,16 @@ def test_libraries_export_nothing_but_their_c_abi():
     assert set(hip) == declared, (sorted(set(hip) - declared), sorted(declared - set(hip)))
     host = _dynamic_symbols("libmasp_host.so")
     assert host and all(s.startswith("masp_host_") for s in host), [s for s in host if not s.startswith("masp_host_")][:10]
+    # ... and libmasp_host.so's header (include/masp_host.h, round 6) declares exactly what the library exports; host_api.cpp includes it,
+    # so every signature is the compiler's to check
+    hhdr = open(os.path.join(ROOT, "include", "masp_host.h")).read()
+    hdecl = set(re.findall(r"\b(masp_host_[a-z0-9_]+)\s*\(", hhdr))
+    assert set(host) == hdecl, (sorted(set(host) - hdecl), sorted(hdecl - set(host)))
+    assert '#include "../../../include/masp_host.h"' in open(os.path.join(ROOT, "masp_amd", "csrc", "host", "host_api.cpp")).read()
+
+
+def test_masp_host_header_is_plain_c():
+    import subprocess
+    for std in ("c99", "c11"):
+        subprocess.check_call(["gcc", "-std=" + std, "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "masp_host.h")])
+        subprocess.check_call(["gcc", "-std=" + std, "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "masp_hip.h")])

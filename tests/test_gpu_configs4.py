@@ -54,11 +54,12 @@ def test_configs4_4096_mixed_jobs_sharded_over_the_devices_of_the_node():
         before = multi.device_proofs()
         proofs = multi.prove_batch(jobs)
         assert len(proofs) == N and all(len(p) == 192 for p in proofs) and len(set(proofs)) == N
-        # every device context took its share: 16 full batches of 256 dealt round-robin — a prover that silently ran everything
-        # on its first device would show here
+        # every device context took its share of the queue (round 6: blocks are TAKEN by whichever context is free, the most expensive
+        # first, not dealt round-robin) — a prover that silently ran everything on its first device would show here
         done = [a - b for a, b in zip(multi.device_proofs(), before)]
         assert len(done) == len(devices) and sum(done) == N, done
-        assert min(done) >= N // len(devices) - 512 and max(done) <= N // len(devices) + 512, done
+        assert min(done) >= N // len(devices) // 2, done
+        assert multi.device_status() == ([0] * len(devices), 0)
         # every proof verifies under ITS circuit's key at ITS job's statement (a proof at the wrong position would not)
         for k in KINDS:
             vk = multi.prepare_verifying_key(params[k])

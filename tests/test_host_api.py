@@ -126,3 +126,53 @@ def test_permits_are_served_in_ticket_order():
     for t in small:
         t.join(timeout=10)
     assert order[0] == "big" and sorted(order[1:]) == sorted("small%d" % i for i in range(8))
+
+
+def test_an_interrupted_waiter_gives_its_ticket_up():
+    """a waiter that leaves `_Permits.acquire` by an exception (an interrupt inside wait()) must not leave a ticket nobody
+    serves — every later acquirer would wait for ever."""
+    import ctypes
+    import threading
+    import time
+    from masp_amd.prover import _Permits
+    p = _Permits(1)
+    got, errors = [], []
+
+    def head():
+        try:
+            p.acquire(5)                              # ticket 0: can never be met before the release below
+            got.append("head")
+        except KeyboardInterrupt:
+            errors.append("interrupted")
+    t0 = threading.Thread(target=head)
+    t0.start()
+    time.sleep(0.2)
+    t1 = threading.Thread(target=lambda: (p.acquire(1), got.append("later")))   # ticket 1 queues behind ticket 0
+    t1.start()
+    time.sleep(0.2)
+    assert got == []
+    # raise KeyboardInterrupt inside the head waiter (what Ctrl-C does to the main thread), then wake it
+    assert ctypes.pythonapi.PyThreadState_SetAsyncExc(ctypes.c_ulong(t0.ident), ctypes.py_object(KeyboardInterrupt)) == 1
+    with p._cv:
+        p._cv.notify_all()
+    t0.join(timeout=10)
+    t1.join(timeout=10)
+    assert errors == ["interrupted"] and got == ["later"] and not t1.is_alive()
+
+
+def test_a_failed_background_warm_up_is_reported_by_the_next_proving_call():
+    """warm_up(background=True) runs on a daemon thread; its exception is kept and raised by `_warm_wait`, which every
+    proving call passes through first."""
+    from masp_amd.prover import LocalTxProver
+    p = LocalTxProver.__new__(LocalTxProver)            # no GPU: only the two methods under test
+    real = LocalTxProver.warm_up
+
+    def warm_up(self, spends=None, outputs=0, converts=0, threads=None, background=False):
+        if background:
+            return real(self, spends, outputs, converts, threads, True)
+        raise MemoryError("no scratch")
+    p.warm_up = warm_up.__get__(p)
+    p.warm_up(background=True)
+    with pytest.raises(RuntimeError, match="warm_up.*failed.*no scratch"):
+        p._warm_wait()
+    p._warm_wait()                                      # reported once; the prover is the caller's to discard

@@ -62,7 +62,9 @@ for k in per_kernel:
 import re, time
 line = [l for l in open("%s/FETCH_SIZE.log" % out).read().splitlines() if l.startswith("{")][-1]
 alg = json.loads(line)["roofline"]["alg_bytes_per_launch"]
+import hashlib
 doc = {
+ "library_sha16": hashlib.sha256(open("$root/masp_amd/libmasp_hip.so", "rb").read()).hexdigest()[:16],
  "kernel": "G1 bucket-accumulation stage per G1 MSM: k_tree_plan / k_tree_records / k_tree_pass1 / k_tree_pass2 / k_tree_copy / k_binv_* over 4 tree levels in sub-batches of 86 proofs, then k_msm_accumulate_pts",
  "date": time.strftime("%Y-%m-%d"),
  "command": "tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline (256 distinct Spend witnesses per step); calibration pass on tools/_build/pmc_calib",

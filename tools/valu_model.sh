@@ -1,10 +1,10 @@
 #!/bin/bash
 # VALU instructions of ONE batch of 256 Spend proofs and what they cost to issue: the numbers behind bench.py's `roofline_valu`.
-#   usage (GPU box): tools/valu_model.sh [out.json = gpurun_out/valu_model.json]      then copy to profiles/r05_valu_model.json
+#   usage (GPU box): tools/valu_model.sh [out.json = gpurun_out/valu_model.json]      then copy to profiles/r06_valu_model.json
 # One rocprofv3 --pmc pass (SQ_INSTS_VALU: wave-level VALU instructions, summed per kernel) over bench.py with ONE slot and nothing but
 # full batches in the run (no lone proofs, no other circuits, no end-to-end region); the kernels of set-up and verification are left out.
 # Batches in the run = dispatches of k_tree_pass2<FpOps, true> / 9 (three G1 MSMs per batch, each through the tree in three sub-batches).
-# Cycles per instruction: profiles/r05_static_valu_mix.json (tools/valu_mix.py: the class mix of each kernel's hot loop, priced with the
+# Cycles per instruction: profiles/r06_static_valu_mix.json (tools/valu_mix.py: the class mix of each kernel's hot loop, priced with the
 # measured issue costs), weighted with the counts.
 export TMPDIR=/tmp
 root=$PWD
@@ -24,7 +24,7 @@ for r in csv.DictReader(open(f)):
 NOT_A_BATCH = ("k_setup", "k_fixed_table", "k_msm_precompute", "k_msm_import", "k_verify", "k_miller", "k_fp12", "k_g1_sum_export", "k_fr_powers", "k_g1_subgroup",
                "k_subgroup", "k_msm_table", "k_msm_window")
 batches = disp["k_tree_pass2<FpOps, true>"] / 9.0
-mix = json.load(open("$root/profiles/r05_static_valu_mix.json"))
+mix = json.load(open("$root/profiles/${VALU_MIX:-r06_static_valu_mix.json}"))
 kern = mix["kernels"]
 rows, tot, cyc, left_out = [], 0.0, 0.0, {}
 for k, v in sorted(insts.items(), key=lambda kv: -kv[1]):
@@ -39,11 +39,13 @@ for k, v in sorted(insts.items(), key=lambda kv: -kv[1]):
     tot += v
     cyc += v * cpi
     rows.append({"kernel": k, "valu_insts_per_batch": v / batches, "dispatches_per_batch": disp[k] / batches, "cycles_per_inst": cpi})
-doc = {"what": "wave-level VALU instructions of one batch of 256 Spend proofs (rocprofv3 --pmc SQ_INSTS_VALU over bench.py, one slot) and their issue cost",
+import hashlib
+doc = {"library_sha16": hashlib.sha256(open("$root/masp_amd/libmasp_hip.so", "rb").read()).hexdigest()[:16],
+       "what": "wave-level VALU instructions of one batch of 256 Spend proofs (rocprofv3 --pmc SQ_INSTS_VALU over bench.py, one slot) and their issue cost",
        "batches_in_run": batches, "valu_insts_per_batch": tot / batches, "cycles_per_inst_weighted": cyc / tot, "simds": 1024,
        "issue_cycles_per_batch_per_simd": cyc / batches / 1024, "kernels": rows[:24],
        "left_out_not_part_of_a_batch": {k: v for k, v in sorted(left_out.items(), key=lambda kv: -kv[1])[:12]},
-       "cost_source": mix["source"], "mix_source": "profiles/r05_static_valu_mix.json"}
+       "cost_source": mix["source"], "mix_source": "profiles/${VALU_MIX:-r06_static_valu_mix.json}"}
 json.dump(doc, open("$root/${1:-gpurun_out/valu_model.json}", "w"), indent=1)
 print(json.dumps({k: doc[k] for k in ("batches_in_run", "valu_insts_per_batch", "cycles_per_inst_weighted", "issue_cycles_per_batch_per_simd")}))
 for r in rows[:12]: print(r)
