@@ -49,7 +49,7 @@ ENV_OPTIONS = {"MASP_HIP_SLOTS": "slots", "MASP_HIP_BATCH": "batch_cap", "MASP_H
                "MASP_HIP_MSM_C_LA": "window_bits_la", "MASP_HIP_MSM_C_B": "window_bits_b", "MASP_HIP_MSM_C_B2": "window_bits_b2", "MASP_HIP_MSM_C_B2_LONE": "window_bits_b2_lone",
                "MASP_HIP_WITNESS_NONTRIVIAL_PERCENT": "witness_nontrivial_percent", "MASP_HIP_TREE_LEVELS": "bucket_tree_levels",
                "MASP_HIP_TREE_SUB": "bucket_tree_sub_batch", "MASP_HIP_TREE_LEVELS_G2": "bucket_tree_levels_g2",
-               "MASP_HIP_LONE_GRAPH": "lone_proof_graph", "MASP_HIP_MSM_C_H_LONE": "window_bits_h_lone", "MASP_HIP_DIGITS": "digit_recoding"}
+               "MASP_HIP_LONE_GRAPH": "lone_proof_graph", "MASP_HIP_MSM_C_H_LONE": "window_bits_h_lone"}
 
 
 def options_from_env(env=os.environ):

@@ -125,18 +125,11 @@ typedef struct {
                                         proofs use — a batch runs h and l as one MSM over the merged table on window_bits_h.  Narrower
                                         windows mean more additions in the chip-filling accumulation and far fewer buckets in the
                                         latency-bound tails a lone proof waits for.  Default: see resolve_options (prover.hip) */
-    int32_t digit_recoding;          /* (round 5, appended) 1: the base sets a batch runs over (h + l merged, a, b_g1, b_g2) take width-(c + 1)
-                                        non-adjacent-form digits — odd, as many buckets as c-bit windows (the window_bits_* fields keep naming
-                                        the BUCKETS: 2^(bits - 1)), 14.7 instead of 16 entries per scalar of h + l, 18.6 instead of 22 per
-                                        non-trivial witness scalar — over a table of 2^t P for EVERY bit position t (256 x n rows per base
-                                        set: 16.6 GB for the Spend circuit).  Default 0: signed fixed windows, a table per window.  Measured:
-                                        random 128-byte rows arrive at 6.5 TB/s from tables of up to 3 GiB and at 1.8 TB/s from 4 GiB on (the
-                                        reach of an XCD's L2 TLB: with each XCD gathering from its own eighth of a 17 GiB table the rate is
-                                        back at 6.3 TB/s, tools/gather_tlb_ubench.hip), so the fewer additions cost more than they save where
-                                        the tables are large: Spend -8 %, Convert -2.5 %, Output (2.3 GB of tables) +2 % proofs/s.  (Tables
-                                        cut into a region per XCD and level 0 of the bucket tree walked region by region were built and
-                                        measured too — profiles/r05_naf_digits_table_regions_per_xcd_rejected.txt, commit 5c2f854 — and
-                                        removed: the gathers recover, the stores of that level's results fragment) */
+    int32_t digit_recoding;          /* RESERVED, must be 0.  (Round 5: 1 = width-(c + 1) non-adjacent-form digits over a table of 2^t P for every
+                                        bit position t — 8 - 15 % fewer bucket additions for 16.6 GB of tables per Spend circuit, which is beyond
+                                        the ~3.5 GiB of randomly gathered table an XCD's L2 TLB reaches: Spend -8 %, Output +2 % proofs/s.  Built,
+                                        bit-exact, measured, removed in round 6: EXPERIMENTS.md, profiles/r05_naf_digits_*.txt.)  A context is
+                                        created with 0 here whatever the caller passes; masp_hip_ctx_get_options returns 0 */
     int32_t window_bits_b2;          /* (round 6, appended) window width of the b_g2 query's batch tables when it should differ from
                                         window_bits_b: a G2 addition costs three G1 additions, so b_g2's optimum is wider than b_g1's —
                                         at the price of a sort of its own (with equal widths b_g2 is reduced from b_g1's sorted digit
@@ -183,6 +176,13 @@ int masp_hip_ctx_device_status(const masp_hip_ctx* ctx, int32_t* status, int cap
 /* TEST HOOK (tests/test_gpu_device_failure.py): the `nth` masp_hip_prove_batch call (1 = the next) that device context `device` of a
  * multi-device prover receives fails with MASP_HIP_E_HIP before it touches the device, as a lost GPU would.  nth = 0 disarms. */
 int masp_hip_ctx_inject_fault(masp_hip_ctx* ctx, int device, uint32_t nth);
+/* How many of THIS context's own streams (five per slot + one) run a kernel at the same time, measured now (the context must be idle; its
+ * slots are created if they do not exist yet).  *concurrent < *n_streams means two of them share a hardware queue.  The runtime hands
+ * hardware queues to streams in the order the PROCESS creates streams — other contexts', a verifying key's, torch's count — so a later
+ * context of a process can end up with two streams of one slot on one queue while another queue idles, and proves 2 - 3 % slower for its
+ * whole life (profiles/r06_second_context_root_cause.txt: the "slower second context" of round 4, seen at 4 slots / 24 queues; with the
+ * default 3 slots / 16 queues every context's 16 streams cover the 16 queues exactly once, whatever the rotation). */
+int masp_hip_ctx_stream_concurrency(masp_hip_ctx* ctx, int* n_streams, int* concurrent);
 /* *out = calls of masp_hip_prove_batch groups so far that were replayed from a captured launch graph
  * (masp_hip_options::lone_proof_graph); a caller that proves one description at a time sees it grow from its third proof on */
 int masp_hip_ctx_lone_graph_launches(const masp_hip_ctx* ctx, uint64_t* out);
@@ -224,9 +224,7 @@ int masp_hip_msm_g1(masp_hip_ctx* ctx, const uint8_t* bases, const uint8_t* scal
 int masp_hip_msm_g2(masp_hip_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[192]);
 /* np MSMs over ONE set of n G1 bases, launched the way a batch of proofs launches them (one kernel sequence,
  * gridDim.y = np): scalars np x n x 32, out np x 96.  window_bits: 0 = chosen from n, else 2..16 (the prover's buckets: 16 for
- * the h query and 12 for the witness queries), or MASP_HIP_MSM_NAF | w for width-w NAF digits, w = 4..17, over a table per bit position
- * (masp_hip_options::digit_recoding; 2^(w-2) buckets).  Exists so that the batched code path can be checked on its own. */
-#define MASP_HIP_MSM_NAF 0x100
+ * the h query and 12 for the witness queries).  Exists so that the batched code path can be checked on its own. */
 int masp_hip_msm_g1_multi(masp_hip_ctx* ctx, const uint8_t* bases, size_t n, const uint8_t* scalars, size_t np, int window_bits,
                           uint8_t* out);
 /* the same over G2 (bases n x 192, out np x 192) */

@@ -74,50 +74,6 @@ __global__ void __launch_bounds__(64) k_msm_precompute(TabRow<O>* __restrict__ t
     }
 }
 
-// T[t][i] = 2 * T[t-1][i], t = 1 .. tpos - 1 (NAF digits: a table per bit position).  One lane per point; K doublings at a time in
-// XYZZ coordinates, made affine with ONE inversion (Montgomery's trick over the K values of ZZZ) — a base set of 231 568 points has
-// 59 million rows to write, an inversion per row would be 2 - 3 s of the load.
-template <class O, int K>
-__global__ void __launch_bounds__(64) k_msm_precompute_bits(TabRow<O>* __restrict__ tab, uint32_t n, int tpos) {
-    typedef typename O::T F;
-    typedef typename O::Cold C;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Affine<O> p = tab[i].p;
-    for (int t = 1; t < tpos; t += K) {
-        const int cnt = tpos - t < K ? tpos - t : K;
-        Xyzz<O> q[K];
-        F pre[K];
-        q[0] = xyzz_dbl_affine(p);
-#pragma unroll
-        for (int k = 1; k < K; ++k) q[k] = k < cnt ? xyzz_dbl(q[k - 1]) : q[k - 1];
-        // (infinity — the point itself was, or a point that is not on the curve ran into y = 0 — stays infinity: its ZZZ counts as 1)
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const F z = xyzz_is_inf(q[k]) ? O::one() : q[k].ZZZ;
-            pre[k] = k ? C::mul(pre[k - 1], z) : z;
-        }
-        F inv = O::inv(pre[K - 1]);
-#pragma unroll
-        for (int k = K - 1; k >= 0; --k) {
-            const bool inf = xyzz_is_inf(q[k]);
-            const F zi3 = k ? C::mul(inv, pre[k - 1]) : inv;  // 1 / ZZZ_k
-            if (k) inv = C::mul(inv, inf ? O::one() : q[k].ZZZ);
-            Affine<O> a;
-            if (inf) {
-                a.x = O::zero();
-                a.y = O::zero();
-            } else {
-                const F zi = C::mul(zi3, q[k].ZZ);  // ZZ / ZZZ = 1 / Z
-                a.x = C::mul(q[k].X, C::sqr(zi));
-                a.y = C::mul(q[k].Y, zi3);
-            }
-            if (k < cnt) tab[(size_t)(t + k) * n + i].p = a;
-            if (k == cnt - 1) p = a;
-        }
-    }
-}
-
 // ---- (4) accumulate: device/msm_acc.cuh (its own translation unit) -------------------------------------
 
 // ---- (5) gather: bucket b = sum of its partials part[c + b], c over the chunks its entries touch ---------
@@ -434,11 +390,8 @@ __global__ void __launch_bounds__(256) k_xyzz_reduce_block(const Xyzz<O>* __rest
     if (tid == 0) out[blockIdx.x] = y;
 }
 // V = T0 + cs*(T1 + cs*(T2 + ...)) ;  tsum[l] holds the fully reduced T of level l.
-// total != nullptr (NAF digits: bucket b holds |digit| = 2 b + 1): the result is  sum_b (2 b + 1) B_b = 2 V - sum_b B_b,  `total` being
-// the last level's one chunk sum — the sum of all buckets.
 template <class O>
-__global__ void __launch_bounds__(64) k_msm_combine(const Xyzz<O>* __restrict__ tsum, int levels, int cs_log, Xyzz<O>* __restrict__ out, size_t out_stride,
-                                                    const Xyzz<O>* __restrict__ total, size_t total_stride) {
+__global__ void __launch_bounds__(64) k_msm_combine(const Xyzz<O>* __restrict__ tsum, int levels, int cs_log, Xyzz<O>* __restrict__ out, size_t out_stride) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     tsum += (size_t)MSM_P * 32;
     out += MSM_P * out_stride;
@@ -446,10 +399,6 @@ __global__ void __launch_bounds__(64) k_msm_combine(const Xyzz<O>* __restrict__ 
     for (int l = levels - 1; l >= 0; --l) {
         for (int k = 0; k < cs_log; ++k) acc = xyzz_dbl(acc);
         xyzz_add_nc(acc, tsum[l]);
-    }
-    if (total) {
-        acc = xyzz_dbl(acc);
-        xyzz_add_nc(acc, xyzz_neg(total[MSM_P * total_stride]));
     }
     *out = acc;
 }
@@ -480,8 +429,7 @@ __global__ void __launch_bounds__(reduce_lanes_points<O>() * O::LANES) k_xyzz_re
 }
 template <class O>
 __global__ void __launch_bounds__(64) k_msm_combine_lanes(const Xyzz<typename O::Base>* __restrict__ tsum, int levels, int cs_log,
-                                                          Xyzz<typename O::Base>* __restrict__ out, size_t out_stride,
-                                                          const Xyzz<typename O::Base>* __restrict__ total, size_t total_stride) {
+                                                          Xyzz<typename O::Base>* __restrict__ out, size_t out_stride) {
     if (blockIdx.x != 0 || threadIdx.x >= O::LANES) return;
     const uint32_t h = threadIdx.x;
     tsum += (size_t)MSM_P * 32;
@@ -490,10 +438,6 @@ __global__ void __launch_bounds__(64) k_msm_combine_lanes(const Xyzz<typename O:
     for (int l = levels - 1; l >= 0; --l) {
         for (int k = 0; k < cs_log; ++k) acc = xyzz_dbl(acc);
         xyzz_add_nc(acc, xyzz_load<O>(tsum + l, h));
-    }
-    if (total) {  // NAF digits: 2 V - (sum of all buckets), see k_msm_combine
-        acc = xyzz_dbl(acc);
-        xyzz_add_nc(acc, xyzz_neg(xyzz_load<O>(total + MSM_P * total_stride, h)));
     }
     xyzz_store<O>(out, acc, h);
 }

@@ -20,66 +20,36 @@ namespace masp {
 //                  entry with one LDS atomic.
 // Scalars equal to 1 (a third of a MASP witness: booleans) all land in bucket 0 of window 0; a wave counts / places them
 // with one ballot instead of 64 colliding atomics.  Zero scalars (38 %) produce nothing.
-// scalars: n x 8 canonical little-endian limbs.  sorted entry = table row (t*n + i) | sign << 31, t = the table of the digit: window j
-// (fixed windows) / bit position (NAF).
-// (NAF is a template parameter of the iterator and of the three kernels that use it: the fixed-window form is what the prover's default
-// runs 834 million times per batch, and it costs 70 % more instructions when it shares its code with the other)
-template <bool NAF>
+// scalars: n x 8 canonical little-endian limbs.  sorted entry = table row (j*n + i) | sign << 31, j = the window of the digit.
+// (Round 5 also had width-w NAF digits over a table per bit position here, as a template parameter of the iterator and its three kernels;
+// removed in round 6 — the tables it needs are beyond an XCD's TLB reach: EXPERIMENTS.md, profiles/r05_naf_digits_*.txt.)
 struct MsmDigitIter {
     const uint32_t* sw;
     uint32_t carry, mask, half, pos, j;
     int c;
     __device__ __forceinline__ MsmDigitIter(const uint32_t* sw_, const MsmGeom& g)
         : sw(sw_), carry(0), mask((1u << g.c) - 1u), half(1u << (g.c - 1)), pos(0), j(0), c(g.c) {}
-    // 32 bits of the scalar from bit `bit` on, zeros beyond bit 255 (re-read from L1/L2 instead of indexing a register array dynamically)
+    // 32 bits of the scalar from bit `bit` on, zeros beyond bit 255 (re-read from L1/L2 instead of indexing a register array dynamically;
+    // the last window starts below bit 256)
     __device__ __forceinline__ uint32_t bits(uint32_t bit) const {
         const uint32_t w = bit >> 5, off = bit & 31u;
-        if (NAF && w >= 8) return 0u;   // (fixed windows: the last window starts below bit 256)
         const uint64_t two = ((uint64_t)(w + 1 < 8 ? sw[w + 1] : 0u) << 32) | sw[w];
         return (uint32_t)(two >> off);
     }
-    // The next digit.  Fixed windows: call W times, window after window; false = this window's digit is zero.  NAF: false = no digit
-    // is left (every later call says so again).  table: which table of the base set the digit's row lies in.
+    // The next digit: call W times, window after window; false = this window's digit is zero.  table: the window.
     __device__ __forceinline__ bool next(uint32_t& table, uint32_t& bucket, uint32_t& neg) {
-        if constexpr (!NAF) {
-            uint32_t v = (bits(pos) & mask) + carry;
-            table = j++;
-            pos += (uint32_t)c;
-            neg = 0;
-            carry = 0;
-            if (v > half) {
-                v = (1u << c) - v;
-                neg = 1;
-                carry = 1;
-            }
-            bucket = v - 1;
-            return v != 0;
-        }
-        // width-c NAF from the low end: skip to the next position whose bit (with the carry of the last negative digit) is set; the c
-        // bits from there are the digit, taken negative (and carried into position + c) if they are above 2^(c-1).  The carry does not
-        // change while positions are skipped: it either still waits in front of a zero bit or has run through ones up to here.
-        while (pos < 256) {
-            const uint32_t v = bits(pos) + carry;  // (wraps: 0xffffffff + 1 = 0 — 32 more positions without a digit, the carry travels on)
-            if (v == 0) {
-                pos += 32;
-                continue;
-            }
-            pos += (uint32_t)__ffs((int)v) - 1u;
-            break;
-        }
-        if (pos >= 256) return false;
-        uint32_t u = (bits(pos) & mask) + carry;  // odd, below 2^c
-        table = pos;
+        uint32_t v = (bits(pos) & mask) + carry;
+        table = j++;
         pos += (uint32_t)c;
         neg = 0;
         carry = 0;
-        if (u > half) {
-            u = (1u << c) - u;
+        if (v > half) {
+            v = (1u << c) - v;
             neg = 1;
             carry = 1;
         }
-        bucket = u >> 1;  // |digit| = 2 bucket + 1
-        return true;
+        bucket = v - 1;
+        return v != 0;
     }
 };
 // 0: zero, 1: one, 2: anything else
@@ -90,7 +60,6 @@ __device__ __forceinline__ int msm_scalar_class(const uint32_t* sw) {
     if (rest == 0 && lo.x <= 1) return (int)lo.x;
     return 2;
 }
-template <bool NAF>
 __global__ void __launch_bounds__(1024)
 k_msm_hist(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32_t n, MsmGeom g, uint32_t ng, uint32_t* __restrict__ hist_wg) {
     extern __shared__ uint32_t msm_lds[];
@@ -108,13 +77,10 @@ k_msm_hist(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32_t 
         if (cls == 1) {
             if ((uint32_t)__ffsll((unsigned long long)ones) - 1u == (tid & 63u)) atomicAdd(&msm_lds[0], (uint32_t)__popcll(ones));
         } else if (cls == 2) {
-            MsmDigitIter<NAF> it(sw, g);
+            MsmDigitIter it(sw, g);
             for (int j = 0; j < g.W; ++j) {
                 uint32_t table, bucket, neg;
-                if (it.next(table, bucket, neg))
-                    atomicAdd(&msm_lds[bucket], 1u);
-                else if (NAF)
-                    break;
+                if (it.next(table, bucket, neg)) atomicAdd(&msm_lds[bucket], 1u);
             }
         }
     }
@@ -232,7 +198,6 @@ k_msm_offsets_scan_b(uint32_t nb, uint32_t* __restrict__ start, uint32_t* __rest
         start[nb] = pbase + last.y;
     }
 }
-template <bool NAF>
 __global__ void __launch_bounds__(1024)
 k_msm_scatter(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32_t n, MsmGeom g, uint32_t ng, const uint32_t* __restrict__ rel,
               const uint32_t* __restrict__ start, uint32_t* __restrict__ sorted, size_t sorted_stride) {
@@ -258,13 +223,10 @@ k_msm_scatter(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32
             if (cls == 1) sorted[first + (uint32_t)__popcll(ones & ((1ull << (tid & 63u)) - 1ull))] = i;  // window 0: row i, positive
         }
         if (cls == 2) {
-            MsmDigitIter<NAF> it(sw, g);
+            MsmDigitIter it(sw, g);
             for (int j = 0; j < g.W; ++j) {
                 uint32_t table, bucket, neg;
-                if (it.next(table, bucket, neg))
-                    sorted[atomicAdd(&msm_lds[bucket], 1u)] = (table * n + i) | (neg << 31);
-                else if (NAF)
-                    break;
+                if (it.next(table, bucket, neg)) sorted[atomicAdd(&msm_lds[bucket], 1u)] = (table * n + i) | (neg << 31);
             }
         }
     }
@@ -280,7 +242,7 @@ k_msm_scatter(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32
 //   k_msm_bucketize  (one workgroup per proof and bin)  the bin's entries -> their buckets, again through an LDS-sorted
 //                    tile of 4096 entries: runs of ~32 entries.
 // Between the two, an entry carries its bucket's low 7 bits:  row (24 bits) | fine << 24 | sign << 31 — or, where the table has more than
-// 2^24 rows (`wide`: a base set with a table per bit position has 256 x n of them), the 7 bits travel in a byte array of their own
+// 2^24 rows (`wide`: more than a million points on 16 windows), the 7 bits travel in a byte array of their own
 // (`tmpf`, next to `tmp`) and the word keeps 31 bits for the row.
 static constexpr uint32_t MSM_FINE_LOG = 7, MSM_FINE = 1u << MSM_FINE_LOG;
 static constexpr uint32_t MSM_PART_TILE = 1024;   // scalars per tile of k_msm_partition (= threads)
@@ -334,7 +296,6 @@ __device__ __forceinline__ void msm_small_scan(const uint32_t* cnt, uint32_t* of
         if (tid == 255) *total = base + x;
     }
 }
-template <bool NAF>
 __global__ void __launch_bounds__(1024)
 k_msm_partition(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint32_t n, MsmGeom g, uint32_t ng, const uint32_t* __restrict__ crel,
                 const uint32_t* __restrict__ start /* packed offsets: MsmSortBuf::dense */, uint32_t* __restrict__ tmp, uint8_t* __restrict__ tmpf,
@@ -376,7 +337,7 @@ k_msm_partition(const uint32_t* __restrict__ scalars, size_t scalar_stride, uint
 #pragma unroll
         for (int j = 0; j < 32; ++j) key[j] = 0xffffffffu;
         if (cls == 2) {
-            MsmDigitIter<NAF> it(sw, g);
+            MsmDigitIter it(sw, g);
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
                 if (j < g.W) {

@@ -508,6 +508,9 @@ k_tree_pass2(const TabRow<typename O::Base>* __restrict__ tab, const typename O:
     fetch(ra, nxt);
     // (the result of a pair is stored at the top of the NEXT iteration, after that iteration's wait for its operands and before
     // its loads: see pass 1 — a store in flight would otherwise be drained by the wait)
+    // (`c = nxt` is 36 register copies per pair.  The loop unrolled by two over two operand sets that swap roles — round 6 — keeps as
+    // many: the compiler then copies the values that merge behind the rare path instead; pass 2 25.6 -> 25.9 ms per MSM for twice the
+    // code: profiles/r06_same_box_ab_pass2_unrolled_by_two_rejected.txt)
     F hx = O::zero(), hy = O::zero();
     uint32_t hout = 0;
     bool held = false;

@@ -121,10 +121,6 @@ struct Circuit {
     // a lone proof (every G2 addition is 40 dependent 384-bit products on one lane), and with 128 instead of 2 048 buckets
     // the gather / weighted-sum levels nearly vanish for 45 % more (chip-filling) accumulation work; n = 0: not built
     BasesG2 b2_lone;
-    // masp_hip_options::digit_recoding = 1: the sets a BATCH runs a / b_g1 / b_g2 over — NAF digits over a table per bit position
-    // (device/msm_geom.h); `hl` itself is built that way then.  n = 0: batches use a / b1 / b2
-    BasesG1 a_naf, b1_naf;
-    BasesG2 b2_naf;
     // alpha_g1, beta_g1, delta_g1 and every point of the a / b_g1 queries lie in the prime-order subgroup (tested when the
     // circuit is loaded): s*A and r*B1 may then go through the endomorphism (k_groth16_var_mul).  A CRS with a curve point
     // outside the subgroup — the reference reads it unchecked — keeps the plain double-and-add, whose bytes are the reference's

@@ -4,5 +4,5 @@
 #include "msm_impl.cuh"
 
 namespace masp {
-template void msm_tails_enqueue<FpOps, FpQuadOps>(hipStream_t, MsmWorkspace<FpOps>&, const uint32_t*, uint32_t, uint32_t, uint32_t, bool, Xyzz<FpOps>*, size_t, bool);
+template void msm_tails_enqueue<FpOps, FpQuadOps>(hipStream_t, MsmWorkspace<FpOps>&, const uint32_t*, uint32_t, uint32_t, uint32_t, bool, Xyzz<FpOps>*, size_t);
 }  // namespace masp

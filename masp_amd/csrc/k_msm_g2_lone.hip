@@ -4,5 +4,5 @@
 #include "msm_impl.cuh"
 
 namespace masp {
-template void msm_tails_enqueue<Fp2Ops, Fp2OctOps>(hipStream_t, MsmWorkspace<Fp2Ops>&, const uint32_t*, uint32_t, uint32_t, uint32_t, bool, Xyzz<Fp2Ops>*, size_t, bool);
+template void msm_tails_enqueue<Fp2Ops, Fp2OctOps>(hipStream_t, MsmWorkspace<Fp2Ops>&, const uint32_t*, uint32_t, uint32_t, uint32_t, bool, Xyzz<Fp2Ops>*, size_t);
 }  // namespace masp

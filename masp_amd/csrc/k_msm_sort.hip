@@ -9,11 +9,11 @@ namespace masp {
 int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb, const uint32_t* d_scalars, size_t scalar_stride,
                                    uint32_t np, uint32_t pad_log) {
     static_assert((1u << 15) / MSM_SCAN_BLOCK <= 64, "k_msm_offsets_scan_b: a wave's lanes fetch the block totals");
-    if (g.c < 2 + 2 * g.naf || g.nb > (1 << 15)) {
-        last_hip_error() = "MSM digit width must be 2..16 bits (fixed windows) / 4..17 bits (NAF): the bucket histogram lives in LDS";
+    if (g.c < 2 || g.nb > (1 << 15)) {
+        last_hip_error() = "MSM window width must be 2..16 bits: the bucket histogram lives in LDS";
         return MASP_HIP_E_INVALID_ARG;
     }
-    if ((uint64_t)n * (uint32_t)g.tpos > 0x7ffffffeull) {
+    if ((uint64_t)n * (uint32_t)g.W > 0x7ffffffeull) {
         last_hip_error() = "msm_sort_enqueue: the base set has more table rows than an entry's 31 bits can name";
         return MASP_HIP_E_INVALID_ARG;
     }
@@ -41,22 +41,15 @@ int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb
     const bool lds_ok = once([] {
         int bytes = 4 << 15;
         const int part_bytes = 4 * (4 * 256 + 8) + 5 * (int)MSM_PART_TILE * 30;  // = the largest part_lds below (6 x 25 = 5 x 30)
-        return hipFuncSetAttribute((const void*)k_msm_hist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
-               hipFuncSetAttribute((const void*)k_msm_hist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
-               hipFuncSetAttribute((const void*)k_msm_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
-               hipFuncSetAttribute((const void*)k_msm_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
-               hipFuncSetAttribute((const void*)k_msm_partition<true>, hipFuncAttributeMaxDynamicSharedMemorySize, part_bytes) == hipSuccess &&
-               hipFuncSetAttribute((const void*)k_msm_partition<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   part_bytes) == hipSuccess;
+        return hipFuncSetAttribute((const void*)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+               hipFuncSetAttribute((const void*)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+               hipFuncSetAttribute((const void*)k_msm_partition, hipFuncAttributeMaxDynamicSharedMemorySize, part_bytes) == hipSuccess;
     });
     if (!lds_ok) {
         last_hip_error() = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
         return MASP_HIP_E_HIP;
     }
-    if (g.naf)
-        MASP_LAUNCH(k_msm_hist<true>, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg);
-    else
-        MASP_LAUNCH(k_msm_hist<false>, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg);
+    MASP_LAUNCH(k_msm_hist, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg);
     MASP_LAUNCH(k_msm_offsets_cols, dim3((nb + 255) / 256, np), dim3(256), 0, s, sb.hist_wg, ng, nb, sb.dense);
     const uint32_t scan_blocks = (nb + MSM_SCAN_BLOCK - 1) / MSM_SCAN_BLOCK;
     MASP_LAUNCH(k_msm_offsets_scan_a, dim3(scan_blocks, np), dim3(256), 0, s, nb, sb.start, sb.dense, pad_log, sb.btot);
@@ -65,19 +58,12 @@ int msm_sort_enqueue(hipStream_t s, uint32_t n, const MsmGeom& g, MsmSortBuf& sb
         const uint32_t nbins = nb >> MSM_FINE_LOG;
         const uint32_t cw = std::min(ng, 4u);  // waves per workgroup of k_msm_coarse: one per scalar range
         MASP_LAUNCH(k_msm_coarse, dim3(nbins, np, (ng + cw - 1) / cw), dim3(64 * cw), 0, s, sb.hist_wg, ng, nb, sb.crel);
-        if (g.naf)
-            MASP_LAUNCH(k_msm_partition<true>, dim3(ng, np), dim3(MSM_PART_TILE), part_lds, s, d_scalars, scalar_stride, n, g, ng, sb.crel, sb.dense, sb.tmp, sb.tmpf, wide);
-        else
-            MASP_LAUNCH(k_msm_partition<false>, dim3(ng, np), dim3(MSM_PART_TILE), part_lds, s, d_scalars, scalar_stride, n, g, ng, sb.crel, sb.dense, sb.tmp, sb.tmpf, wide);
+        MASP_LAUNCH(k_msm_partition, dim3(ng, np), dim3(MSM_PART_TILE), part_lds, s, d_scalars, scalar_stride, n, g, ng, sb.crel, sb.dense, sb.tmp, sb.tmpf, wide);
         MASP_LAUNCH(k_msm_bucketize, dim3(nbins, np), dim3(1024), 0, s, sb.tmp, sb.tmpf, (size_t)n * g.W, sb.dense, sb.start, nb, sb.sorted, sb.ent_stride, wide);
     } else {
         // (the single-pass placement writes entries only: aligned runs get their padding from a fill first)
         if (pad_log) HIP_TRY(hipMemsetAsync(sb.sorted, 0xff, 4 * sb.ent_stride * np, s));
-        if (g.naf)
-            MASP_LAUNCH(k_msm_scatter<true>, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg, sb.start, sb.sorted,
-                        sb.ent_stride);
-        else
-            MASP_LAUNCH(k_msm_scatter<false>, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg, sb.start, sb.sorted,
+        MASP_LAUNCH(k_msm_scatter, dim3(ng, np), dim3(MSM_SORT_THREADS), 4 * nb, s, d_scalars, scalar_stride, n, g, ng, sb.hist_wg, sb.start, sb.sorted,
                         sb.ent_stride);
     }
     return launch_status();

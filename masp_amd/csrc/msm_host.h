@@ -19,13 +19,13 @@
 #endif
 namespace masp {
 
-// ---- base set: T[j][i] = 2^(c j) P_i (fixed windows) / T[t][i] = 2^t P_i for every bit position t (NAF digits: msm_geom.h) ------
+// ---- base set: T[j][i] = 2^(c j) P_i -------------------------------------------------------------------------------------------
 template <class O, int BYTES>
 struct MsmBases {
     MsmGeom g{};
     uint32_t n = 0;
     uint32_t n_eff = 0;        // scalars expected to be neither 0 nor 1 (<= n): the mean length of a bucket's run follows from it
-    TabRow<O>* tab = nullptr;  // g.tpos * n rows of 128 / 256 bytes
+    TabRow<O>* tab = nullptr;  // g.W * n rows of 128 / 256 bytes
     int import_status = 0;     // PT_* bits seen while decoding
 
     ~MsmBases() { release(); }
@@ -36,21 +36,20 @@ struct MsmBases {
     // Window width by the number of scalars expected to be neither 0 nor 1 (`n_eff`; the caller knows the witness
     // statistics of its circuit, a generic caller passes n): per non-trivial scalar the accumulation costs W = 256/c
     // mixed additions, per bucket the gather + weighted sum cost ~5.5 full additions.
-    // naf: the same number of buckets with NAF digits of one bit more (msm_geom_naf) and a table per bit position.
-    static MsmGeom pick_geom(uint32_t n_eff, bool naf = false) {
+    static MsmGeom pick_geom(uint32_t n_eff) {
         int c = n_eff >= (1u << 16) ? 16 : n_eff >= (1u << 12) ? 12 : n_eff >= (1u << 8) ? 10 : 7;
-        return naf ? msm_geom_naf(c + 1) : msm_geom(c);
+        return msm_geom(c);
     }
     // raw: device pointer to n uncompressed points (bellman wire format)          [msm_impl.cuh]
-    // force_c: digit width (0: pick_geom); naf: NAF digits (force_c is then the NAF width: one more than the window with as many buckets)
-    int load_device(const uint8_t* d_raw, uint32_t n_, hipStream_t s, uint32_t n_eff = 0xffffffffu, int force_c = 0, bool naf = false);
-    int load_host(const uint8_t* raw, uint32_t n_, hipStream_t s, uint32_t n_eff = 0xffffffffu, int force_c = 0, bool naf = false) {
+    // force_c: window width (0: pick_geom)
+    int load_device(const uint8_t* d_raw, uint32_t n_, hipStream_t s, uint32_t n_eff = 0xffffffffu, int force_c = 0);
+    int load_host(const uint8_t* raw, uint32_t n_, hipStream_t s, uint32_t n_eff = 0xffffffffu, int force_c = 0) {
         uint8_t* d_raw = nullptr;
         if (n_) {
             HIP_TRY(dev_malloc(&d_raw, (size_t)n_ * BYTES));
             HIP_TRY(hipMemcpyAsync(d_raw, raw, (size_t)n_ * BYTES, hipMemcpyHostToDevice, s));
         }
-        int rc = load_device(d_raw, n_, s, n_eff, force_c, naf);
+        int rc = load_device(d_raw, n_, s, n_eff, force_c);
         if (d_raw) dev_free(d_raw);
         return rc;
     }
@@ -62,9 +61,9 @@ struct MsmSortBuf {
     uint32_t *sorted = nullptr, *hist_wg = nullptr, *start = nullptr;
     uint32_t *tmp = nullptr, *crel = nullptr;  // two-pass placement: entries grouped by coarse bin; per-range offsets of the bins
     uint8_t* tmpf = nullptr;                   // ... and the low 7 bits of every such entry's bucket, where the entry word has no room
-                                               // for them (msm_rows_wide: a table per bit position); not allocated otherwise
+                                               // for them (msm_rows_wide: more than 2^24 table rows); not allocated otherwise
     bool has_tmpf = false;
-    static bool msm_rows_wide(uint32_t n_, const MsmGeom& g_) { return (uint64_t)n_ * (uint32_t)g_.tpos > (1u << 24); }
+    static bool msm_rows_wide(uint32_t n_, const MsmGeom& g_) { return (uint64_t)n_ * (uint32_t)g_.W > (1u << 24); }
     uint32_t* dense = nullptr;                 // [np][nb + 1] offsets without padding (where a bin lies in `tmp`)
     uint2* btot = nullptr;                     // [np][ceil(nb / 1024)] the offsets scan's block totals (packed, aligned)
     // what the last msm_sort_enqueue produced (consumed by msm_reduce_enqueue)

@@ -26,26 +26,23 @@ static inline uint32_t log2_ceil_u64(uint64_t n) {
 }
 
 template <class O, int BYTES>
-int MsmBases<O, BYTES>::load_device(const uint8_t* d_raw, uint32_t n_, hipStream_t s, uint32_t n_eff, int force_c, bool naf) {
+int MsmBases<O, BYTES>::load_device(const uint8_t* d_raw, uint32_t n_, hipStream_t s, uint32_t n_eff, int force_c) {
         release();
         n = n_;
         this->n_eff = std::min(n_eff, n_);
-        g = force_c ? (naf ? msm_geom_naf(force_c) : msm_geom(force_c)) : pick_geom(std::min(n_eff, n_), naf);
+        g = force_c ? msm_geom(force_c) : pick_geom(std::min(n_eff, n_));
         if (n == 0) return MASP_HIP_OK;
-        if ((uint64_t)n * (uint32_t)g.tpos > 0x7ffffffeull) {
+        if ((uint64_t)n * (uint32_t)g.W > 0x7ffffffeull) {
             last_hip_error() = "MsmBases: more table rows than an entry's 31 bits can name";
             return MASP_HIP_E_INVALID_ARG;
         }
-        HIP_TRY(dev_malloc(&tab, sizeof(TabRow<O>) * (size_t)g.tpos * n));
+        HIP_TRY(dev_malloc(&tab, sizeof(TabRow<O>) * (size_t)g.W * n));
         int* d_status;
         HIP_TRY(dev_malloc(&d_status, sizeof(int)));
         HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(int), s));
         dim3 grid((n + 63) / 64), block(64);
         MASP_LAUNCH((k_msm_import<O, BYTES>), grid, block, 0, s, d_raw, tab, n, d_status);
-        if (g.naf)
-            MASP_LAUNCH((k_msm_precompute_bits<O, 4>), grid, block, 0, s, tab, n, g.tpos);
-        else
-            MASP_LAUNCH((k_msm_precompute<O>), grid, block, 0, s, tab, n, g.c, g.W);
+        MASP_LAUNCH((k_msm_precompute<O>), grid, block, 0, s, tab, n, g.c, g.W);
         HIP_TRY(hipMemcpyAsync(&import_status, d_status, sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         dev_free(d_status);
@@ -99,7 +96,7 @@ void MsmWorkspace<O>::reduce_to_one_lanes(hipStream_t s, uint32_t np, const Xyzz
 // per point (OT: O itself, its lane-pair form for G2, FpQuadOps for a lone proof's G1 MSMs).
 template <class O, class OT>
 void msm_tails_enqueue(hipStream_t s, MsmWorkspace<O>& ws, const uint32_t* start, uint32_t nb, uint32_t nchunks, uint32_t np, bool lone, Xyzz<O>* d_out,
-                       size_t out_stride, bool odd_weights) {
+                       size_t out_stride) {
     constexpr uint32_t LN = OT::LANES;
     if constexpr (OT::LANES <= 2) {
         if (!lone) {  // a batch: single partials copied, one lane per chunk boundary for the buckets that straddle one (k_msm_bucket_gather_split)
@@ -171,18 +168,16 @@ void msm_tails_enqueue(hipStream_t s, MsmWorkspace<O>& ws, const uint32_t* start
         off = 0;
         ++level;
     } while (m > 1);
-    // NAF digits: bucket b weighs 2 b + 1 — twice the sum above less the sum of all buckets, which is the last level's one chunk sum
-    const Xyzz<O>* total = odd_weights ? bk : nullptr;
     if constexpr (OT::REPLICATED)
-        MASP_LAUNCH((k_msm_combine_lanes<OT>), dim3(1, np), dim3(64), 0, s, ws.tsum, level, (int)(g_log + WSUM_L_LOG), d_out, out_stride, total, st_stride);
+        MASP_LAUNCH((k_msm_combine_lanes<OT>), dim3(1, np), dim3(64), 0, s, ws.tsum, level, (int)(g_log + WSUM_L_LOG), d_out, out_stride);
     else
-        MASP_LAUNCH((k_msm_combine<O>), dim3(1, np), dim3(64), 0, s, ws.tsum, level, (int)(g_log + WSUM_L_LOG), d_out, out_stride, total, st_stride);
+        MASP_LAUNCH((k_msm_combine<O>), dim3(1, np), dim3(64), 0, s, ws.tsum, level, (int)(g_log + WSUM_L_LOG), d_out, out_stride);
 }
 #ifndef MASP_TAILS_QUAD_UNIT
-extern template void msm_tails_enqueue<FpOps, FpQuadOps>(hipStream_t, MsmWorkspace<FpOps>&, const uint32_t*, uint32_t, uint32_t, uint32_t, bool, Xyzz<FpOps>*, size_t, bool);
+extern template void msm_tails_enqueue<FpOps, FpQuadOps>(hipStream_t, MsmWorkspace<FpOps>&, const uint32_t*, uint32_t, uint32_t, uint32_t, bool, Xyzz<FpOps>*, size_t);
 #endif
 #ifndef MASP_TAILS_OCT_UNIT
-extern template void msm_tails_enqueue<Fp2Ops, Fp2OctOps>(hipStream_t, MsmWorkspace<Fp2Ops>&, const uint32_t*, uint32_t, uint32_t, uint32_t, bool, Xyzz<Fp2Ops>*, size_t, bool);
+extern template void msm_tails_enqueue<Fp2Ops, Fp2OctOps>(hipStream_t, MsmWorkspace<Fp2Ops>&, const uint32_t*, uint32_t, uint32_t, uint32_t, bool, Xyzz<Fp2Ops>*, size_t);
 #endif
 
 template <class O, int BYTES>
@@ -190,7 +185,7 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
                        MsmProfile* prof) {
     const MsmGeom& g = B.g;
     const uint32_t n = B.n, np = sb.np;
-    if (sb.n != n || sb.g.c != g.c || sb.g.naf != g.naf) {
+    if (sb.n != n || sb.g.c != g.c) {
         last_hip_error() = "msm_reduce_enqueue: sort does not match the base set";
         return MASP_HIP_E_INVALID_ARG;
     }
@@ -277,15 +272,15 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
     // (Those kernels live in a translation unit of their own, k_msm_g1_lone.hip.)
     if constexpr (std::is_same<O, FpOps>::value) {
         if (lone)
-            msm_tails_enqueue<O, FpQuadOps>(s, ws, start, nb, nchunks, np, lone, d_out, out_stride, g.naf != 0);
+            msm_tails_enqueue<O, FpQuadOps>(s, ws, start, nb, nchunks, np, lone, d_out, out_stride);
         else
-            msm_tails_enqueue<O, FpOps>(s, ws, start, nb, nchunks, np, lone, d_out, out_stride, g.naf != 0);
+            msm_tails_enqueue<O, FpOps>(s, ws, start, nb, nchunks, np, lone, d_out, out_stride);
     } else {
         // ... and its G2 tails over groups of four lane pairs (device/oct.cuh)
         if (lone && (MASP_G2_OCT_LONE))
-            msm_tails_enqueue<O, Fp2OctOps>(s, ws, start, nb, nchunks, np, lone, d_out, out_stride, g.naf != 0);
+            msm_tails_enqueue<O, Fp2OctOps>(s, ws, start, nb, nchunks, np, lone, d_out, out_stride);
         else
-            msm_tails_enqueue<O, typename TailLaneOps<O>::type>(s, ws, start, nb, nchunks, np, lone, d_out, out_stride, g.naf != 0);
+            msm_tails_enqueue<O, typename TailLaneOps<O>::type>(s, ws, start, nb, nchunks, np, lone, d_out, out_stride);
     }
     return launch_status();  // (a launch the runtime refused: MASP_LAUNCH, util.h)
 }

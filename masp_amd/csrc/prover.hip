@@ -52,10 +52,7 @@ static masp_hip_options resolve_options(const masp_hip_options* in) {
     o.hw_queues = 0;                     // output only (measured when a device context is created)
     o.window_bits_h_lone = o.window_bits_h_lone > 0 ? std::min<int>(o.window_bits_h_lone, 16) : 0;   // resolved: 0 = as window_bits_h
     o.lone_proof_graph = o.lone_proof_graph > 0 ? 1 : 0;   // off unless asked for: measured slower with ROCm 7.2's graph launch
-    // 1 = NAF digits over per-bit tables for the base sets batches use.  Off unless asked for: 8 - 15 % fewer bucket entries, but the
-    // tables (16.6 GB for Spend) are beyond what an XCD's L2 TLB reaches (~3.5 GiB) and the gathers of the tree's level 0 then run at a
-    // quarter of their rate: -8 % Spend proofs/s, +2 % for Output, whose tables fit (profiles/r05_naf_digits_per_bit_tables_*.txt)
-    o.digit_recoding = o.digit_recoding > 0 ? 1 : 0;
+    o.digit_recoding = 0;   // (round 5's NAF digits over per-bit tables were removed in round 6: the field is reserved, must be 0 on input)
     // b_g2's batch tables on a window width of their own (2..16); 0 / -1 resolved where the circuit is loaded (masp_hip_circuit_load)
     o.window_bits_b2 = o.window_bits_b2 > 0 ? std::max(2, std::min<int>(o.window_bits_b2, 16)) : o.window_bits_b2 < 0 ? -1 : 0;
     return o;
@@ -238,7 +235,7 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
     if ((rc = sl.sa.reserve((size_t)C.na * np)) || (rc = sl.sb.reserve((size_t)C.nbq * np))) return rc;
     MsmProfile* prof = sl.profiling ? &sl.prof : nullptr;
     const size_t m8 = C.m * 8;
-    const bool share_b = C.nbq && C.b2.n == C.b1.n && C.b2.g.c == C.b1.g.c && C.b2.g.naf == C.b1.g.naf;  // B2 runs over the same scalars as B1
+    const bool share_b = C.nbq && C.b2.n == C.b1.n && C.b2.g.c == C.b1.g.c;  // B2 runs over the same scalars as B1
     if (lone) {
         // the four witness MSMs run on their own streams (forked above) while the main stream runs SpMV -> quotient -> H.
         // The pieces of the assembly start as soon as what they read exists: the fixed-base multiplications (r and s only)
@@ -328,10 +325,10 @@ static int enqueue_proofs(Slot& sl, Circuit& C, uint32_t np, const Fr* d_w, size
         if ((rc = msm_enqueue(s, C.hl, sl.ws1, (const uint32_t*)sl.hl.p, hl_stride * 8, sl.res1.p + 0, 4, np, prof))) return rc;
         // L is inside H + L: its slot of every proof is the point at infinity (one strided fill, not np of them)
         HIP_TRY(hipMemset2DAsync(sl.res1.p + 1, 4 * sizeof(G1Xyzz), 0, sizeof(G1Xyzz), np, s));
-        // (masp_hip_options::digit_recoding = 1: the batch's own base sets — NAF digits, a table per bit position)
-        const BasesG1 &Aq = C.a_naf.n ? C.a_naf : C.a, &B1q = C.b1_naf.n ? C.b1_naf : C.b1;
-        const BasesG2& B2q = C.b2_naf.n ? C.b2_naf : C.b2;
-        const bool share_bq = C.nbq && B2q.n == B1q.n && B2q.g.c == B1q.g.c && B2q.g.naf == B1q.g.naf;
+        // (b_g2 on b_g1's window width is reduced from b_g1's sorted digit list; on a width of its own — masp_hip_options::window_bits_b2 — it sorts for itself)
+        const BasesG1 &Aq = C.a, &B1q = C.b1;
+        const BasesG2& B2q = C.b2;
+        const bool share_bq = share_b;
         if ((rc = msm_enqueue(s, Aq, sl.ws1, (const uint32_t*)sl.sa.p, (size_t)C.na * 8, sl.res1.p + 2, 4, np, prof))) return rc;
         if ((rc = msm_enqueue(s, B1q, sl.ws1, (const uint32_t*)sl.sb.p, (size_t)C.nbq * 8, sl.res1.p + 3, 4, np, prof))) return rc;
         if (share_bq) {
@@ -564,6 +561,41 @@ static int measure_hw_queues(int device, int streams) {
     return best;
 }
 
+// The same measurement on a context's OWN streams (every slot's five + the main stream): how many of them run a kernel at the same time.
+// Fewer than there are streams = two of them share a hardware queue, and kernels of one batch that could overlap wait for each other.
+static int measure_own_streams(masp_hip_ctx* ctx, int* n_streams, int* concurrent) {
+    std::vector<hipStream_t> ss;
+    ss.push_back(ctx->main_stream);
+    for (auto& sl : ctx->slots) {
+        ss.push_back(sl->stream);
+        for (int i = 0; i < Slot::N_AUX; ++i) ss.push_back(sl->aux[i]);
+    }
+    const int n = (int)ss.size();
+    unsigned long long* d = nullptr;
+    HIP_TRY(dev_malloc(&d, 16 * n));
+    int best = 0;
+    bool ok = true;
+    for (int r = 0; r < 2; ++r) {
+        for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k_hwq_spin, dim3(1), dim3(64), 0, ss[i], d, i, r ? 200000LL : 1000LL);
+        for (int i = 0; i < n; ++i) ok = hipStreamSynchronize(ss[i]) == hipSuccess && ok;
+    }
+    std::vector<unsigned long long> h(2 * n);
+    ok = ok && hipMemcpy(h.data(), d, 16 * n, hipMemcpyDeviceToHost) == hipSuccess;
+    (void)dev_free(d);
+    if (!ok) {
+        last_hip_error() = "stream concurrency probe failed";
+        return MASP_HIP_E_HIP;
+    }
+    for (int i = 0; i < n; ++i) {
+        int c = 0;
+        for (int j = 0; j < n; ++j) c += h[2 * j] <= h[2 * i] && h[2 * i] < h[2 * j + 1];
+        best = std::max(best, c);
+    }
+    *n_streams = n;
+    *concurrent = best;
+    return MASP_HIP_OK;
+}
+
 static int create_single(int device, const masp_hip_options& opt, masp_hip_ctx** out) {
     *out = nullptr;
     int count = 0;
@@ -696,6 +728,15 @@ int masp_hip_ctx_inject_fault(masp_hip_ctx* ctx, int device, uint32_t nth) {
     ctx->children[device]->fault_countdown = nth;
     return MASP_HIP_OK;
 }
+int masp_hip_ctx_stream_concurrency(masp_hip_ctx* ctx, int* n_streams, int* concurrent) {
+    if (!ctx || !n_streams || !concurrent) return MASP_HIP_E_INVALID_ARG;
+    if (!ctx->children.empty()) ctx = ctx->children[0];
+    std::unique_lock<std::shared_mutex> lock(ctx->mu);
+    hipSetDevice(ctx->device);
+    if (int rc = ensure_slots(ctx, (size_t)ctx->n_slots)) return fail(ctx, rc);
+    if (hipDeviceSynchronize() != hipSuccess) return fail(ctx, MASP_HIP_E_HIP);
+    return fail(ctx, measure_own_streams(ctx, n_streams, concurrent));
+}
 int masp_hip_ctx_lone_graph_launches(const masp_hip_ctx* ctx, uint64_t* out) {
     if (!ctx || !out) return MASP_HIP_E_INVALID_ARG;
     *out = 0;
@@ -728,7 +769,7 @@ void masp_hip_ctx_destroy(masp_hip_ctx* ctx) {
     ctx->domains.clear();
     if (ctx->main_stream) hipStreamDestroy(ctx->main_stream);
     delete ctx;
-    dev_free_drain();  // the context's buffers
+    if (!(MASP_KEEP_RELEASED_BUFFERS)) dev_free_drain();  // the context's buffers
 }
 
 int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* params, size_t params_len, const masp_hip_r1cs* cs) {
@@ -859,18 +900,9 @@ int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* param
     const int c_h = ctx->opt.window_bits_h ? ctx->opt.window_bits_h : n_h >= 49152 ? 16 : n_h >= 16384 ? 15 : 0;
     // (h's own table serves lone proofs only: its window width is theirs to choose — masp_hip_options::window_bits_h_lone)
     const int c_h_lone = ctx->opt.window_bits_h_lone ? ctx->opt.window_bits_h_lone : c_h;
-    // Digits (masp_hip_options::digit_recoding = 1; default fixed windows): a BATCH runs its MSMs (h + l merged, a, b_g1, b_g2) on
-    // width-(c + 1) NAF digits over a table per bit position — as many buckets as c-bit windows, 8 % (h + l) to 15 % (the witness
-    // queries) fewer entries to add (device/msm_geom.h); lone proofs keep fixed windows and their compact tables (h, l, a, b_g1, b_g2).
-    const bool naf = ctx->opt.digit_recoding > 0;
-    auto nafw = [&](int c) { return c ? c + 1 : 0; };
     if ((rc = C->h.load_host(L.h, (uint32_t)(C->m - 1), s, 0xffffffffu, c_h_lone)) || (rc = C->l.load_host(L.l, L.n_l, s, eff(L.n_l), c_la)) ||
         (rc = C->a.load_host(L.a, L.n_a, s, eff(L.n_a), c_la)) || (rc = C->b1.load_host(L.b_g1, L.n_b1, s, eff(L.n_b1), c_b)) ||
         (rc = C->b2.load_host(L.b_g2, L.n_b2, s, eff(L.n_b2), c_b2)))
-        return fail(ctx, rc);
-    if (naf && ((rc = C->a_naf.load_host(L.a, L.n_a, s, eff(L.n_a), nafw(c_la), true)) ||
-                (rc = C->b1_naf.load_host(L.b_g1, L.n_b1, s, eff(L.n_b1), nafw(c_b), true)) ||
-                (rc = C->b2_naf.load_host(L.b_g2, L.n_b2, s, eff(L.n_b2), nafw(c_b), true))))
         return fail(ctx, rc);
     {
         const int c_lone = ctx->opt.window_bits_b2_lone;  // 0 = lone proofs share the batch tables (and B1's sort)
@@ -882,7 +914,7 @@ int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* param
         memcpy(cat.data(), L.h, 96 * nh);
         memcpy(cat.data() + 96 * nh, L.l, 96 * (size_t)L.n_l);
         const int c_hl = c_h ? c_h : ctx->opt.window_bits_h_lone ? 0 : C->h.g.c;
-        if ((rc = C->hl.load_host(cat.data(), (uint32_t)(nh + L.n_l), s, 0xffffffffu, naf ? nafw(c_hl) : c_hl, naf))) return fail(ctx, rc);
+        if ((rc = C->hl.load_host(cat.data(), (uint32_t)(nh + L.n_l), s, 0xffffffffu, c_hl))) return fail(ctx, rc);
     }
     int st = C->h.import_status | C->l.import_status | C->a.import_status | C->b1.import_status | C->b2.import_status;
     if (st) return MASP_HIP_E_PARAMS_FORMAT;  // includes infinity inside a query vector, which bellman rejects
@@ -1251,10 +1283,7 @@ int masp_hip_prove(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* inputs, cons
 // scalars np x n x 32 B, out np x BYTES uncompressed.  window_bits 0 = the engine's own choice for n.
 template <class O, int BYTES>
 static int msm_multi(masp_hip_ctx* ctx, const uint8_t* bases, size_t n, const uint8_t* scalars, size_t np, int window_bits, uint8_t* out) {
-    const bool naf = window_bits > 0 && (window_bits & MASP_HIP_MSM_NAF) != 0;
-    if (naf) window_bits &= ~MASP_HIP_MSM_NAF;
-    if (!ctx || !out || !np || np > 256 || !n || !bases || !scalars || n > (1u << 22) || window_bits < 0 || window_bits == 1 || window_bits > 16 + (naf ? 1 : 0) ||
-        (naf && window_bits < 4))
+    if (!ctx || !out || !np || np > 256 || !n || !bases || !scalars || n > (1u << 22) || window_bits < 0 || window_bits == 1 || window_bits > 16)
         return MASP_HIP_E_INVALID_ARG;
     if (!ctx->children.empty()) ctx = ctx->children[0];
     std::unique_lock<std::shared_mutex> lock(ctx->mu);
@@ -1279,7 +1308,7 @@ static int msm_multi(masp_hip_ctx* ctx, const uint8_t* bases, size_t n, const ui
     DevBuf<Xyzz<O>> res;
     DevBuf<uint8_t> d_out;
     int rc;
-    if ((rc = B.load_host(bases, (uint32_t)n, s, 0xffffffffu, window_bits, naf))) return fail(ctx, rc);
+    if ((rc = B.load_host(bases, (uint32_t)n, s, 0xffffffffu, window_bits))) return fail(ctx, rc);
     if (B.import_status & (PT_BAD_FLAGS | PT_NOT_CANONICAL)) return MASP_HIP_E_PARAMS_FORMAT;
     if ((rc = ctx->tmp_scalars.upload((const Fr*)scalars, n * np, s)) || (rc = res.reserve(np)) || (rc = d_out.reserve(BYTES * np))) return fail(ctx, rc);
     if ((rc = msm_enqueue(s, B, ws, (const uint32_t*)ctx->tmp_scalars.p, n * 8, res.p, 1, (uint32_t)np))) return fail(ctx, rc);

@@ -21,7 +21,7 @@ class MaspHipError(RuntimeError):
 
 
 OPTION_FIELDS = ("slots", "batch_cap", "ntt_sub_batch", "window_bits_h", "window_bits_la", "window_bits_b", "window_bits_b2_lone",
-                 "witness_nontrivial_percent", "bucket_tree_levels", "bucket_tree_sub_batch", "bucket_tree_levels_g2", "bucket_tree_scratch_mb", "lone_proof_graph", "window_bits_h_lone", "digit_recoding",
+                 "witness_nontrivial_percent", "bucket_tree_levels", "bucket_tree_sub_batch", "bucket_tree_levels_g2", "bucket_tree_scratch_mb", "lone_proof_graph", "window_bits_h_lone",
                  "window_bits_b2")
 
 
@@ -29,7 +29,8 @@ class OptionsStruct(C.Structure):
     """masp_hip_options (include/masp_hip.h): every field 0 = the default."""
     _fields_ = ([("struct_size", C.c_uint32)] + [(f, C.c_int32) for f in OPTION_FIELDS[:OPTION_FIELDS.index("lone_proof_graph")]] +
                 [("bucket_tree_fallback_proofs", C.c_int32), ("lone_proof_graph", C.c_int32), ("hw_queues", C.c_int32), ("window_bits_h_lone", C.c_int32),
-                 ("digit_recoding", C.c_int32), ("window_bits_b2", C.c_int32)])
+                 ("digit_recoding", C.c_int32),     # reserved since round 6 (was: NAF digits over per-bit tables), must be 0
+                 ("window_bits_b2", C.c_int32)])
 
 
 assert C.sizeof(OptionsStruct) == 76 and OptionsStruct.window_bits_b2.offset == 72        # include/masp_hip.h asserts the same
@@ -43,7 +44,6 @@ class JobStruct(C.Structure):
 
 assert C.sizeof(JobStruct) == 120 and JobStruct.r.offset == 48 and JobStruct.aux_form.offset == 112   # include/masp_hip.h asserts the same
 AUX_CANONICAL, AUX_MONTGOMERY = 0, 1     # masp_hip_job::aux_form
-MSM_NAF = 0x100                          # masp_hip_msm_g{1,2}_multi: window_bits = MSM_NAF | w (MASP_HIP_MSM_NAF)
 
 
 def library_path():
@@ -81,6 +81,8 @@ def load_library():
     L.masp_hip_options_default.restype = None
     L.masp_hip_ctx_device_count.argtypes = [vp]
     L.masp_hip_ctx_device_proofs.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
+    if hasattr(L, "masp_hip_ctx_stream_concurrency"):
+        L.masp_hip_ctx_stream_concurrency.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     if hasattr(L, "masp_hip_ctx_device_status"):            # (round 6; an older build passed as MASP_HIP_LIBRARY lacks them)
         L.masp_hip_ctx_device_status.argtypes = [vp, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_uint64)]
         L.masp_hip_ctx_inject_fault.argtypes = [vp, C.c_int, C.c_uint32]
@@ -367,6 +369,12 @@ class Context:
         counts = (C.c_uint64 * n)()
         self._check(self._L.masp_hip_ctx_device_proofs(self._h, counts, n))
         return list(counts)
+
+    def stream_concurrency(self):
+        """masp_hip_ctx_stream_concurrency -> (streams of this context, how many of them ran a kernel at the same time)"""
+        n, c = C.c_int(0), C.c_int(0)
+        self._check(self._L.masp_hip_ctx_stream_concurrency(self._h, C.byref(n), C.byref(c)))
+        return int(n.value), int(c.value)
 
     def device_status(self):
         """masp_hip_ctx_device_status -> ([0 or the error code that took device context d out], proofs put back on the queue so far)"""

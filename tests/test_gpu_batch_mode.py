@@ -162,13 +162,11 @@ def _le(x):
     return np.frombuffer((x % R).to_bytes(32, "little"), np.uint8)
 
 
-@pytest.mark.parametrize("n,window_bits,shape", [(131071, 16, "uniform"), (100497, 12, "witness"), (131071, 0x100 | 17, "uniform"), (100497, 0x100 | 13, "witness")])
+@pytest.mark.parametrize("n,window_bits,shape", [(131071, 16, "uniform"), (100497, 12, "witness")])
 def test_msm_engine_batched_np16_full_size(rig, n, window_bits, shape):
     """The MSM engine alone in batch mode: 16 scalar vectors over one base set in one launch sequence (gridDim.y = 16), at
     the Spend sizes and window widths the prover uses (h: 131 071 uniform scalars, 16-bit windows; l: 100 497
-    witness-shaped scalars — 38 % zeros, 33 % ones, the rest full width — 12-bit windows; and both again with the NAF digits of the same
-    bucket counts over a table per bit position — MASP_HIP_MSM_NAF | 17 / 13: what masp_hip_options::digit_recoding = 1 makes the
-    prover's batches run),
+    witness-shaped scalars — 38 % zeros, 33 % ones, the rest full width — 12-bit windows),
     checked by the discrete-log identity: with bases P_i = k_i G,  sum_i s_i P_i = (sum_i s_i k_i mod r) G."""
     rng = random.Random(n)
     np_ = 16
