@@ -117,8 +117,9 @@ typedef struct {
                                         runtime of this process spreads its streams over, MEASURED when the context was created (as many
                                         single-wave kernels as the context's slots have streams, at most 24, launched at once on streams of
                                         their own: how many ran concurrently).  A slot owns five streams; with fewer queues than
-                                        5 x slots, independent kernels of a batch wait for each other (8 queues: -3 ... -10 % proofs/s,
-                                        profiles/r04e_hw_queues_and_the_two_modes.txt).  The runtime's default is FOUR
+                                        streams, independent kernels wait for each other (round 4, 8 queues: -3 ... -10 % proofs/s) — and
+                                        with MORE than
+                                        MASP_HIP_MAX_USEFUL_HW_QUEUES in the process every dispatch is slower (see there).  The runtime's default is FOUR
                                         (profiles/r05_hw_queues_probe.txt); it reads GPU_MAX_HW_QUEUES at its first call — see
                                         masp_hip_runtime_prepare */
     int32_t window_bits_h_lone;      /* (round 5, appended: struct_size tells) window width of the h query's OWN table, which only lone
@@ -136,12 +137,17 @@ typedef struct {
                                         list).  0 = the default (resolve_options, prover.hip); -1 = as window_bits_b */
 } masp_hip_options;
 void masp_hip_options_default(masp_hip_options* opt);
+/* More hardware queues than this make a process SLOWER (round 6, profiles/r06_second_context_root_cause.txt): the runtime creates a
+ * hardware queue for every new stream until GPU_MAX_HW_QUEUES exist and never gives one back, and once a process holds 24 / 32 of them
+ * every kernel dispatch — also of a lone launch sequence on an idle chip — is 7 / 21 % slower (up to 20: nothing).  A context owns
+ * 5 x slots + 1 streams (a slot's four side streams only work during lone proofs). */
+#define MASP_HIP_MAX_USEFUL_HW_QUEUES 20
 /* The HIP runtime gives a process four hardware queues unless GPU_MAX_HW_QUEUES says otherwise, and reads the variable ONCE, at the
  * process's first HIP call.  Loading this library sets GPU_MAX_HW_QUEUES=16 if the variable is not set (a constructor: the only write to
  * the environment the library ever does, and it reads nothing else from it) — enough for a process whose first HIP call comes after the
  * library is loaded, i.e. a Rust binary linking it.  A process that initialises HIP earlier (another HIP library's static initialisers)
- * sets the variable itself, or calls this function before that point: hw_queues <= 0 means 16; an existing value is kept unless
- * `overwrite`.  Returns the value now in the environment.  What the runtime really uses is reported per context:
+ * sets the variable itself, or calls this function before that point: hw_queues <= 0 means 16, more than
+ * MASP_HIP_MAX_USEFUL_HW_QUEUES is cut to it; an existing value is kept unless `overwrite`.  Returns the value now in the environment.  What the runtime really uses is reported per context:
  * masp_hip_options::hw_queues. */
 int masp_hip_runtime_prepare(int hw_queues, int overwrite);
 

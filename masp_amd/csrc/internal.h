@@ -223,6 +223,10 @@ struct Slot {
         HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ev_sort_b, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ev_fixed, hipEventDisableTiming));
+        // (the four side streams are created WITH the slot.  Creating them at the slot's first lone proof instead — so that a batch prover
+        // holds one stream per slot — was measured in round 6: batch throughput equal, lone proofs 4.1 - 4.2 instead of 3.6 - 3.7 ms inside
+        // bench.py, equal in the standalone tool; not understood, not kept: profiles/r06_second_context_root_cause.txt.  With the default
+        // 3 slots a context's 16 streams cover the default 16 hardware queues exactly once.)
         for (int i = 0; i < N_AUX; ++i) {
             HIP_TRY(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));

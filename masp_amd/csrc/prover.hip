@@ -494,7 +494,9 @@ int masp_hip_device_count(void) {
 
 int masp_hip_runtime_prepare(int hw_queues, int overwrite) {
     char v[16];
-    snprintf(v, sizeof v, "%d", hw_queues > 0 ? std::min(hw_queues, 128) : 16);
+    // (never more than 20: the runtime creates a hardware queue per new stream up to this number and never gives one back, and a process
+    // that holds 24 / 32 of them dispatches every kernel 7 / 21 % slower — profiles/r06_second_context_root_cause.txt)
+    snprintf(v, sizeof v, "%d", hw_queues > 0 ? std::min(hw_queues, (int)MASP_HIP_MAX_USEFUL_HW_QUEUES) : 16);
     setenv("GPU_MAX_HW_QUEUES", v, overwrite ? 1 : 0);
     const char* e = getenv("GPU_MAX_HW_QUEUES");
     return e ? atoi(e) : 0;
@@ -529,7 +531,9 @@ static int measure_hw_queues(int device, int streams) {
     std::lock_guard<std::mutex> lock(mu);
     auto it = known.find(device);
     if (it != known.end()) return it->second;
-    const int n = std::max(1, std::min(streams, 24));
+    // (at most one more than MASP_HIP_MAX_USEFUL_HW_QUEUES: every stream created here makes the runtime create a hardware queue that it
+    // keeps for the life of the process — the probe must not itself walk the pool into the slow regime; 21 says "more than 20")
+    const int n = std::max(1, std::min(streams, (int)MASP_HIP_MAX_USEFUL_HW_QUEUES + 1));
     std::vector<hipStream_t> ss;
     unsigned long long* d = nullptr;
     int best = 0;
@@ -608,7 +612,7 @@ static int create_single(int device, const masp_hip_options& opt, masp_hip_ctx**
     ctx->batch_cap = (size_t)opt.batch_cap;
     ctx->slots.reserve(masp_hip_ctx::MAX_SLOTS);      // never reallocates: see the locking note on masp_hip_ctx
     ctx->slot_busy.reserve(masp_hip_ctx::MAX_SLOTS);
-    ctx->opt.hw_queues = measure_hw_queues(device, 5 * opt.slots);   // (a slot owns five streams)
+    ctx->opt.hw_queues = measure_hw_queues(device, 5 * opt.slots);   // (a slot owns up to five streams)
     if (hipStreamCreateWithFlags(&ctx->main_stream, hipStreamNonBlocking) != hipSuccess) return MASP_HIP_E_NO_DEVICE;
     *out = ctx.release();
     return MASP_HIP_OK;
@@ -769,7 +773,7 @@ void masp_hip_ctx_destroy(masp_hip_ctx* ctx) {
     ctx->domains.clear();
     if (ctx->main_stream) hipStreamDestroy(ctx->main_stream);
     delete ctx;
-    if (!(MASP_KEEP_RELEASED_BUFFERS)) dev_free_drain();  // the context's buffers
+    dev_free_drain();  // the context's buffers
 }
 
 int masp_hip_circuit_load(masp_hip_ctx* ctx, uint32_t slot, const uint8_t* params, size_t params_len, const masp_hip_r1cs* cs) {

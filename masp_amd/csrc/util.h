@@ -6,7 +6,6 @@
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
-#include <map>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -14,9 +13,6 @@
 
 #include "../../include/masp_hip.h"
 
-#ifndef MASP_KEEP_RELEASED_BUFFERS
-#define MASP_KEEP_RELEASED_BUFFERS 0
-#endif
 namespace masp {
 // thread-local text of the last HIP error, surfaced through masp_hip_last_error()
 inline std::string& last_hip_error() {
@@ -71,7 +67,6 @@ inline std::atomic<uint64_t>& device_alloc_epoch() {
 struct DevGraveyard {
     std::mutex mu;
     std::vector<std::pair<int, void*>> v;  // (device, buffer)
-    std::map<void*, size_t> bytes;         // every live or listed buffer of the library -> its size (for the reuse below)
 };
 inline DevGraveyard& dev_graveyard() {
     static DevGraveyard* g = new DevGraveyard;  // (never destroyed: buffers are released from static destructors too)
@@ -100,29 +95,10 @@ inline void dev_free_drain() {
         v.resize(k);
     }
     for (void* p : mine) (void)hipFree(p);
-    if (MASP_KEEP_RELEASED_BUFFERS) {
-        std::lock_guard<std::mutex> g(dev_graveyard().mu);
-        for (void* p : mine) dev_graveyard().bytes.erase(p);
-    }
 }
-// A buffer on the list whose size is exactly what is asked for is handed out again instead of a fresh hipMalloc (see dev_free_drain's
-// callers: masp_hip_ctx_destroy keeps the list when MASP_KEEP_RELEASED_BUFFERS is set).
 template <class T>
 inline hipError_t dev_malloc(T** p, size_t bytes) {
     device_alloc_epoch().fetch_add(1, std::memory_order_relaxed);
-    if (MASP_KEEP_RELEASED_BUFFERS) {
-        const int dev = dev_current();
-        std::lock_guard<std::mutex> g(dev_graveyard().mu);
-        auto& v = dev_graveyard().v;
-        for (size_t i = 0; i < v.size(); ++i) {
-            auto it = dev_graveyard().bytes.find(v[i].second);
-            if (v[i].first == dev && it != dev_graveyard().bytes.end() && it->second == bytes) {
-                *p = (T*)v[i].second;
-                v.erase(v.begin() + i);
-                return hipSuccess;
-            }
-        }
-    }
     hipError_t e = hipMalloc(p, bytes);
     if (e == hipErrorOutOfMemory) {  // what was released but not yet returned to the device may be what is missing
         const int dev = dev_current();
@@ -136,10 +112,6 @@ inline hipError_t dev_malloc(T** p, size_t bytes) {
             dev_free_drain();
             e = hipMalloc(p, bytes);
         }
-    }
-    if (e == hipSuccess && MASP_KEEP_RELEASED_BUFFERS) {
-        std::lock_guard<std::mutex> g(dev_graveyard().mu);
-        dev_graveyard().bytes[(void*)*p] = bytes;
     }
     return e;
 }

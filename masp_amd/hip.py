@@ -71,6 +71,13 @@ def load_library():
     L = C.CDLL(path)
     if hasattr(L, "masp_hip_runtime_prepare"):
         L.masp_hip_runtime_prepare.argtypes = [C.c_int, C.c_int]
+        # more than 20 hardware queues make a process SLOWER once its runtime has created them (the cap is what counts: the pool only
+        # grows) — masp_hip_runtime_prepare(0, 0) changes nothing and returns what the environment says
+        q = L.masp_hip_runtime_prepare(0, 0)
+        if q > 20:
+            import warnings
+            warnings.warn("masp_amd: GPU_MAX_HW_QUEUES=%d: once this process holds more than 20 hardware queues every kernel dispatch gets "
+                          "slower (24: -7 %%, 32: -21 %% proofs/s; profiles/r06_second_context_root_cause.txt) — use 16" % q)
     vp, sz, u32 = C.c_void_p, C.c_size_t, C.c_uint32
     L.masp_hip_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.masp_hip_ctx_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
@@ -201,6 +208,7 @@ class Context:
             import warnings
             warnings.warn("masp_amd: the HIP runtime gives this process %d hardware queue(s) for %d slots x 5 streams: set GPU_MAX_HW_QUEUES=16 "
                           "before the process's first HIP call (masp_hip_runtime_prepare)" % (self.options["hw_queues"], self.options["slots"]))
+
         self._h = h
         self._keep = []
         self._pinned = {}

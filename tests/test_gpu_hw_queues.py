@@ -59,3 +59,28 @@ def test_too_few_queues_are_measured_and_the_wrapper_warns():
     assert int(got["hw_queues"]) == 4 and got["warned"] == "1"
     got = _run("wrapper", {"GPU_MAX_HW_QUEUES": "16"})
     assert int(got["hw_queues"]) >= 15 and got["warned"] == "0"
+
+
+def test_too_many_queues_warn_and_runtime_prepare_never_writes_more_than_twenty():
+    """Round 6 (profiles/r06_second_context_root_cause.txt): a process that holds 24 / 32 hardware queues dispatches every kernel 7 / 21 % slower,
+    and the runtime's pool only grows — the cap is what counts.  The wrapper warns when the environment allows more than 20;
+    masp_hip_runtime_prepare cuts what it writes to MASP_HIP_MAX_USEFUL_HW_QUEUES."""
+    got = _run("wrapper", {"GPU_MAX_HW_QUEUES": "32"})
+    assert got["warned"] == "1" and int(got["hw_queues"]) <= 21          # (the probe itself stops at 21 streams: it must not grow the pool further)
+    code = ("import ctypes as C, os, sys; sys.path.insert(0, %r); from masp_amd import hip; os.environ.pop('GPU_MAX_HW_QUEUES', None); "
+            "L = C.CDLL(hip.library_path()); L.masp_hip_runtime_prepare.argtypes = [C.c_int, C.c_int]; "
+            "print(L.masp_hip_runtime_prepare(64, 1), L.masp_hip_runtime_prepare(0, 0))" % ROOT)      # (setenv from C: os.environ does not see it)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.split() == ["20", "20"], out.stdout + out.stderr
+
+
+def test_a_contexts_own_streams_each_get_a_hardware_queue():
+    """masp_hip_ctx_stream_concurrency: with the default 16 hardware queues the 5 x slots + 1 streams of a default context run kernels at the
+    same time (the probe behind round 6's root cause of the "slower second context": profiles/r06_second_context_root_cause.txt)."""
+    import masp_amd
+    ctx = masp_amd.Context(0, slots=2)
+    try:
+        n, c = ctx.stream_concurrency()
+        assert n == 11 and c >= 10, (n, c)
+    finally:
+        ctx.close()

@@ -56,8 +56,36 @@ class Timers:
         setattr(obj, name, g)
 
 
+SLOTS_SEQ = [int(x) for x in os.environ.get("SCP_SLOTS", "").split(",") if x]
+
+
+def pre_streams(n):
+    """create, use and destroy n HIP streams before any context exists: the process's stream history without any prover in it"""
+    import ctypes as C
+    L = C.CDLL("libamdhip64.so")
+    ss = [C.c_void_p() for _ in range(n)]
+    buf = C.c_void_p()
+    assert L.hipMalloc(C.byref(buf), 4096) == 0
+    for h in ss:
+        assert L.hipStreamCreateWithFlags(C.byref(h), 1) == 0
+        assert L.hipMemsetAsync(buf, 0, 4096, h) == 0
+    for h in ss:
+        assert L.hipStreamSynchronize(h) == 0
+    if not os.environ.get("SCP_PRE_STREAMS_KEEP"):
+        for h in ss:
+            assert L.hipStreamDestroy(h) == 0
+    print("%d streams created, used%s before the first context" % (n, "" if os.environ.get("SCP_PRE_STREAMS_KEEP") else ", destroyed"), flush=True)
+
+
+if os.environ.get("SCP_PRE_STREAMS"):
+    pre_streams(int(os.environ["SCP_PRE_STREAMS"]))
+
+
 def run(tag):
-    prover = LocalTxProver(*params, expected=None, options=options_from_env())
+    opts = options_from_env()
+    if SLOTS_SEQ:
+        opts["slots"] = SLOTS_SEQ.pop(0)
+    prover = LocalTxProver(*params, expected=None, options=opts)
     if os.environ.get("SCP_NO_VERIFY"):
         prover._self_verify = False
     prover.warm_up(spends=N, threads=cpus)
@@ -87,12 +115,32 @@ def run(tag):
         t0 = time.perf_counter()
         list(ex.map(lambda _: prover._ctx.prove_marshalled(arr, n), range(12)))
     print("    host to host on this context: %.1f proofs/s" % (12 * 256 / (time.perf_counter() - t0)), flush=True)
+    # ... and the kernels themselves: the G1 bucket stage of one 256-proof launch sequence alone on the chip (HIP events), resident steps
+    import numpy as np
+    ctx = prover._ctx
+    h, nn = ctx.batch_upload([(j["slot"], j["inputs"], j["aux"], 5 + i, 6 + i, None, 1) for i, j in enumerate(jobs)])
+    ctx.batch_prove_resident(h, nn)
+    ctx.profile_enable(True)
+    ctx.batch_prove_resident(h, nn)
+    ms, launches, _ = ctx.profile_read()
+    ctx.profile_enable(False)
+    rs = np.zeros((6, nn, 64), np.uint8)
+    rs[:, :, 0] = 3
+    rs[:, :, 32] = 5
+    ctx.batch_prove_resident_steps(h, nn, 2, rs[:2])
+    t0 = time.perf_counter()
+    ctx.batch_prove_resident_steps(h, nn, 6, rs)
+    print("    slots %d: isolated G1 stage %.2f ms per MSM; resident %.1f proofs/s" % (S, ms / max(launches, 1), 6 * nn / (time.perf_counter() - t0)), flush=True)
+    ctx.batch_free(h)
     if hasattr(prover._ctx._L, "masp_hip_ctx_stream_concurrency"):
         print("    own streams running at the same time: %d of %d   (hardware queues of the process: %s)" % (prover._ctx.stream_concurrency()[::-1] + (os.environ.get("GPU_MAX_HW_QUEUES"),)), flush=True)
     return prover
 
 
 first = run("context A (first used)")
+if os.environ.get("SCP_CONTEXTS") == "1":
+    first.close()
+    sys.exit(0)
 if not os.environ.get("SCP_KEEP_FIRST"):
     first.close()
 second = run("context B (second)")
