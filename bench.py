@@ -62,13 +62,24 @@ class ClockWatch:
     PPT in microwatts), read every 50 ms by a thread.  A box shows all of its cards whatever this process may use; the cards whose power
     rises with the region (>= 60 % of the busiest one's mean) are the ones it ran on.  No rocm-smi process, no HIP call."""
 
-    def __init__(self):
+    def __init__(self, device=None):
         import glob
         self.cards = []
+        # the card THIS process proves on, by PCI address (masp_hip_device_pci_bus_id against the sysfs device links):
+        # a box shows all eight cards and another tenant's may be busy at the same time (round 6: a line averaged two cards' clocks)
+        mine = None
+        if device is not None:
+            from masp_amd.hip import device_pci_bus_id
+            mine = device_pci_bus_id(device)
         for f in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input")):
             pw = os.path.join(os.path.dirname(f), "power1_input")
             if os.path.exists(pw):
-                self.cards.append((f, pw))
+                pci = os.path.basename(os.path.realpath(f.split("/hwmon/")[0])).lower()
+                if mine is None or pci == mine:
+                    self.cards.append((f, pw))
+        self.by_pci = mine is not None and len(self.cards) == 1
+        if mine is not None and not self.cards:      # (no such link: fall back to every card and the power heuristic)
+            self.__init__(None)
         self.regions, self._stop, self._thread, self._cur = {}, None, None, None
 
     @staticmethod
@@ -113,7 +124,7 @@ class ClockWatch:
         busy = [r for r in per_card if r[0] >= 0.6 * top]
         return {"sclk_mhz_mean": round(sum(r[1] for r in busy) / len(busy), 1), "sclk_mhz_min": round(min(r[2] for r in busy), 1),
                 "sclk_mhz_max": round(max(r[3] for r in busy), 1), "socket_power_w_mean": round(sum(r[0] for r in busy) / len(busy), 1),
-                "samples_per_card": busy[0][4], "cards_busy": len(busy), "cards_seen": len(per_card)}
+                "samples_per_card": busy[0][4], "cards_busy": len(busy), "cards_seen": len(per_card), "card_by_pci_address": bool(getattr(self, "by_pci", False))}
 
 
 def library_sha16():
@@ -413,7 +424,7 @@ def main():
 
     # ---- region A (`resident`): witnesses resident in HBM -> K steps -> proofs gathered on rank 0
     ctx.profile_enable(True)
-    clocks = ClockWatch()
+    clocks = ClockWatch(local_rank)
     barrier()
     clocks.start("resident")
     t0 = time.perf_counter()

@@ -86,6 +86,9 @@ typedef struct {
 
 /* Number of HIP devices this process can see (0 if the runtime is unusable). */
 int masp_hip_device_count(void);
+/* PCI address of device `device` as "0000:c1:00.0" (cap >= 13): which card of the box a context proves on — its clock and power are
+ * the files under /sys/bus/pci/devices/<address>/hwmon (bench.py's clock watch reads them during the timed regions). */
+int masp_hip_device_pci_bus_id(int device, char* out, size_t cap);
 
 /* Tuning of a prover, fixed when the context is created (masp_hip_ctx_create_ex).  Every field: 0 = the default.  The
  * library reads NO environment variables; bench.py and the tools translate their MASP_HIP_* variables into this. */
@@ -115,13 +118,12 @@ typedef struct {
                                         launches enqueued one by one take 5.7 (profiles/r04_lone_proof_graph_ab.txt); the bytes are the same */
     int32_t hw_queues;               /* OUTPUT of masp_hip_ctx_get_options (ignored on input; was reserved[0]): the hardware queues the HIP
                                         runtime of this process spreads its streams over, MEASURED when the context was created (as many
-                                        single-wave kernels as the context's slots have streams, at most 24, launched at once on streams of
-                                        their own: how many ran concurrently).  A slot owns five streams; with fewer queues than
-                                        streams, independent kernels wait for each other (round 4, 8 queues: -3 ... -10 % proofs/s) — and
-                                        with MORE than
-                                        MASP_HIP_MAX_USEFUL_HW_QUEUES in the process every dispatch is slower (see there).  The runtime's default is FOUR
-                                        (profiles/r05_hw_queues_probe.txt); it reads GPU_MAX_HW_QUEUES at its first call — see
-                                        masp_hip_runtime_prepare */
+                                        single-wave kernels as the context's slots have streams, at most 21, launched at once on streams of
+                                        their own, once per process and device: how many ran concurrently).  A slot owns five streams; with
+                                        fewer queues than streams, independent kernels wait for each other (round 4, 8 queues: -3 ... -10 %
+                                        proofs/s) — and with MORE than MASP_HIP_MAX_USEFUL_HW_QUEUES in the process every dispatch is slower
+                                        (see there).  The runtime's default is FOUR (profiles/r05_hw_queues_probe.txt); it reads
+                                        GPU_MAX_HW_QUEUES at its first call — see masp_hip_runtime_prepare */
     int32_t window_bits_h_lone;      /* (round 5, appended: struct_size tells) window width of the h query's OWN table, which only lone
                                         proofs use — a batch runs h and l as one MSM over the merged table on window_bits_h.  Narrower
                                         windows mean more additions in the chip-filling accumulation and far fewer buckets in the

@@ -492,6 +492,13 @@ int masp_hip_device_count(void) {
     return hipGetDeviceCount(&count) == hipSuccess && count > 0 ? count : 0;
 }
 
+int masp_hip_device_pci_bus_id(int device, char* out, size_t cap) {
+    if (!out || cap < 13) return MASP_HIP_E_INVALID_ARG;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return MASP_HIP_E_NO_DEVICE;
+    return hipDeviceGetPCIBusId(out, (int)std::min<size_t>(cap, 64), device) == hipSuccess ? MASP_HIP_OK : MASP_HIP_E_HIP;
+}
+
 int masp_hip_runtime_prepare(int hw_queues, int overwrite) {
     char v[16];
     // (never more than 20: the runtime creates a hardware queue per new stream up to this number and never gives one back, and a process

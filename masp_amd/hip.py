@@ -138,6 +138,16 @@ def load_library():
     return L
 
 
+def device_pci_bus_id(device=0):
+    """masp_hip_device_pci_bus_id -> "0000:c1:00.0" (lower case), or None"""
+    L = load_library()
+    if not hasattr(L, "masp_hip_device_pci_bus_id"):
+        return None
+    buf = C.create_string_buffer(64)
+    L.masp_hip_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+    return buf.value.decode().lower() if L.masp_hip_device_pci_bus_id(int(device), buf, 64) == 0 else None
+
+
 def device_count():
     """HIP devices visible to this process (masp_hip_device_count)."""
     return int(load_library().masp_hip_device_count())

@@ -56,7 +56,14 @@ static int abi(void) {
     CHECK(masp_hip_last_error((const masp_hip_ctx*)0)[0] == 0, "masp_hip_last_error(NULL)");
     n = masp_hip_device_count();
     printf("devices %d\n", n);
-    rc = masp_hip_ctx_create(n > 0 ? 0 : 0, &ctx);
+    {
+        char pci[64];
+        rc = masp_hip_device_pci_bus_id(0, pci, sizeof pci);
+        CHECK(n > 0 ? rc == MASP_HIP_OK && strlen(pci) >= 12 : rc == MASP_HIP_E_NO_DEVICE, "masp_hip_device_pci_bus_id: %d", rc);
+        CHECK(masp_hip_device_pci_bus_id(0, pci, 4) == MASP_HIP_E_INVALID_ARG, "a buffer too short for a PCI address must be refused");
+        if (n > 0) printf("pci %s\n", pci);
+    }
+    rc = masp_hip_ctx_create(0, &ctx);
     printf("ctx_create %d\n", rc);
     if (n == 0) CHECK(rc == MASP_HIP_E_NO_DEVICE && ctx == (masp_hip_ctx*)0, "without a device masp_hip_ctx_create must fail with MASP_HIP_E_NO_DEVICE");
     CHECK(masp_hip_ctx_get_options((const masp_hip_ctx*)0, &o) == MASP_HIP_E_INVALID_ARG, "get_options(NULL)");

@@ -3,7 +3,8 @@
 # PMC slots) prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 passes (they do not fit one), --pmc combined with
 # nothing but --kernel-trace, and FETCH_SIZE calibrated on a known byte count in THIS access pattern (tools/pmc_calib.hip:
 # one 96-byte row gathered per lane at a 128-byte stride from a 3 GiB table) instead of assuming the x2 of wide streams.
-# The bench runs its default workload: 256 DISTINCT Spend witnesses per step.  Writes profiles/pmc_traffic.json.
+# The bench runs its default workload: 256 DISTINCT Spend witnesses per step — and nothing but Spend batches (MASP_BENCH_OTHER=0: since round 5 the bench also
+# proves Output / Convert batches of 256, whose G1 MSMs would be counted as stages and dilute the per-MSM figure; the end-to-end region proves Spend batches).  Writes profiles/pmc_traffic.json.
 # usage (on the GPU box): tools/pmc_traffic.sh
 export TMPDIR=/tmp
 root=$PWD
@@ -12,7 +13,7 @@ rm -rf $out; mkdir -p $out
 [ -x $root/tools/_build/pmc_calib ] || { mkdir -p $root/tools/_build; /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $root/tools/pmc_calib.hip -o $root/tools/_build/pmc_calib; }
 (cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/calib -o run -- $root/tools/_build/pmc_calib > $out/calib.log 2>&1)
 for c in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/$c -o run -- python $root/bench.py --steps ${PMC_STEPS:-4} --warmup 1 --no-cpu-baseline > $out/$c.log 2>&1)
+  (cd /tmp && MASP_BENCH_OTHER=0 MASP_BENCH_LONE=0 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/$c -o run -- python $root/bench.py --steps ${PMC_STEPS:-4} --warmup 1 --no-cpu-baseline > $out/$c.log 2>&1)
 done
 python - <<PY
 import csv, glob, json, os, re

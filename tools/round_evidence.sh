@@ -18,7 +18,7 @@ PROF_ARGS="--steps 4 --warmup 1 --no-cpu-baseline" bash tools/prof_run.sh ${tag}
 db=$(find gpurun_out/prof_${tag}_spend_only -name "*.db" | head -1)
 python tools/g1_stage_stats.py $db > $o/g1_stage_per_spend_msm.txt 2>&1
 cp gpurun_out/prof_${tag}_spend_only/batch.txt $o/kernel_stats_spend_batches_only_grid_y_256.txt
-tail -1 gpurun_out/prof_${tag}_spend_only/bench.log > $o/g1_stage_per_spend_msm_bench_line_of_the_same_run.json
+grep '^{' gpurun_out/prof_${tag}_spend_only/bench.log | tail -1 > $o/g1_stage_per_spend_msm_bench_line_of_the_same_run.json
 PROF_ARGS="--steps 3 --warmup 1 --no-cpu-baseline" bash tools/prof_run.sh ${tag}_default > $o/prof_default.log 2>&1
 cp gpurun_out/prof_${tag}_default/all.txt $o/kernel_stats_default_bench_all_dispatches.txt
 rm -rf gpurun_out/prof_${tag}_slots1 gpurun_out/prof_${tag}_default gpurun_out/prof_${tag}_spend_only

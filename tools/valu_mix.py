@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Static VALU instruction mix of every kernel of libmasp_hip.so, priced with the measured issue costs per class
-(profiles/r04e_valu_instruction_cost_classes_ubench.txt: a wave64 instruction occupies its SIMD for ~2.45 cycles if it is a plain
+(profiles/r06_valu_instruction_cost_classes_ubench.txt, first measured in round 4: a wave64 instruction occupies its SIMD for ~2.45 cycles if it is a plain
 VOP1 / VOP2, ~4.5 if it is VOP3-encoded, reads or writes a carry, ~4.8 for v_mad_u64_u32, ~12 for v_mul_lo/hi_u32 and 64-bit shifts).
 
-    make -C masp_amd/csrc asm && tools/valu_mix.py masp_amd/csrc/_build/*.s > profiles/r05_static_valu_mix.json
+    make -C masp_amd/csrc asm && tools/valu_mix.py masp_amd/csrc/_build/*.s > profiles/r06_static_valu_mix.json
 
 Per kernel: the class histogram of its hottest loop (the longest backward-branch span; the whole body if it has no loop) and the
 cycles per VALU instruction that follow.  tools/valu_model.sh weights these with the SQ_INSTS_VALU counts of a bench run."""
@@ -62,7 +62,7 @@ def main():
         short = re.sub(r"\(.*", "", d).replace("void ", "").replace("masp::", "")
         rec["mangled"] = name
         res[short] = rec
-    json.dump({"cost_cycles_per_class": COST, "source": "profiles/r04e_valu_instruction_cost_classes_ubench.txt", "kernels": res}, sys.stdout, indent=1)
+    json.dump({"cost_cycles_per_class": COST, "source": "profiles/r06_valu_instruction_cost_classes_ubench.txt (tools/valu_rate_ubench.hip on the round's final box; the classes' costs are those of round 4's measurement)", "kernels": res}, sys.stdout, indent=1)
 
 
 if __name__ == "__main__":
