@@ -8,7 +8,7 @@
 // (nam-blstrs / nam-blst, /root/reference/Cargo.lock:1385-1411).  Curve: y^2 = x^3 + 4 over Fp,
 // y^2 = x^3 + 4(1+u) over Fp2; a = 0 in both, which is all the formulas need.
 #pragma once
-#include "field.cuh"
+#include "field.hpp"
 
 namespace masp {
 
@@ -63,7 +63,7 @@ MASP_HD Xyzz<O> xyzz_neg(const Xyzz<O>& p) {
 }
 
 // dbl-2008-s-1 for XYZZ.  Reached from the rare P == Q branch of the additions and from serial tails: its products go
-// through the Cold multiplier policy (register-argument calls, field.cuh), so inlining it costs ~1.5 KiB per site while
+// through the Cold multiplier policy (register-argument calls, field.hpp), so inlining it costs ~1.5 KiB per site while
 // the point itself never leaves the VGPRs.
 template <class O>
 MASP_HD Xyzz<O> xyzz_dbl(const Xyzz<O>& p) {

@@ -13,7 +13,7 @@
 
 #include <cstdint>
 
-#include "consts.cuh"
+#include "consts.hpp"
 
 #define MASP_HD __host__ __device__ __forceinline__
 // Out-of-line variant.  NOTE (ROCm 7.2 / LLVM 22, gfx950): a non-kernel device function larger than the
@@ -1054,7 +1054,7 @@ MASP_NOINLINE Fe<C> fe_inv(const Fe<C>& a) {
     return fe_mul_nc(fe_mul_nc(r, r2), r2);  // (aR)^-1 R^2 R^-1 = a^-1, once more: a^-1 R
 }
 // Inverse (inv(0) = 0) by the binary extended Euclid in 32-bit limbs, the form for a lane that inverts ONE value while its
-// neighbours do the same (the shared inversions of the batch-affine bucket trees, device/msm_tree.cuh): ~1.45 log2 p rounds of
+// neighbours do the same (the shared inversions of the batch-affine bucket trees, device/msm_tree.hpp): ~1.45 log2 p rounds of
 // ~150 full-rate integer instructions and not a single multiplication — on a lone wave ~6x sooner than the Fermat power
 // (570 dependent 384-bit products), and free of the 64/128-bit arithmetic the divsteps above are written in.
 // Invariants: a = u y, b = v y (mod p), b odd; a reaches 0 with b = gcd = 1 and v = 1 / y.  Branch-free inside a round
@@ -1388,7 +1388,7 @@ struct FpOps {
 };
 // FpOps for code written over O::LANES lanes per point, with FOUR lanes per G1 point: every lane of a quad holds the whole
 // element (REPLICATED: loads read it four times, one lane stores it) and the point operations spread their independent
-// products over the quad (device/quad.cuh).  Field operations on their own are FpOps's, done redundantly by the four lanes.
+// products over the quad (device/quad.hpp).  Field operations on their own are FpOps's, done redundantly by the four lanes.
 struct FpQuadOps : FpOps {
     static constexpr uint32_t LANES = 4;
     static constexpr bool REPLICATED = true;
@@ -1551,7 +1551,7 @@ struct Fp2PairOps {
         return half() ? fe_neg(r) : r;
     }
 };
-// Fp2PairOps with FOUR pairs per G2 point (device/oct.cuh): eight lanes per point, every pair holds the whole element (its lanes one half
+// Fp2PairOps with FOUR pairs per G2 point (device/oct.hpp): eight lanes per point, every pair holds the whole element (its lanes one half
 // each); the point operations spread their independent products over the four pairs.  Field operations on their own are Fp2PairOps's,
 // done redundantly by the four pairs.  The bucket tails of a lone proof's b_g2 MSM.
 struct Fp2OctOps : Fp2PairOps {

@@ -2,7 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "field.cuh"
+#include "field.hpp"
 
 namespace masp {
 

@@ -6,11 +6,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "curve.cuh"
-#include "subgroup.cuh"
-#include "quad.cuh"
-#include "fr_io.cuh"
-#include "io.cuh"
+#include "curve.hpp"
+#include "subgroup.hpp"
+#include "quad.hpp"
+#include "fr_io.hpp"
+#include "io.hpp"
 
 namespace masp {
 
@@ -41,7 +41,7 @@ __device__ __forceinline__ Xyzz<O> xyzz_fixed_mul(const Xyzz<O>* __restrict__ ta
     return acc;
 }
 
-// four lanes per point (xyzz_dbl_coop, xyzz_add_coop): device/quad.cuh
+// four lanes per point (xyzz_dbl_coop, xyzz_add_coop): device/quad.hpp
 
 // Proof assembly:
 //   g_a = r*delta1 + alpha1 + A
@@ -152,7 +152,7 @@ __device__ __forceinline__ void endo_split(const uint32_t* k, uint32_t* q, uint3
 // WHICH = 0: s*A -> part[3];  1: r*B1 -> part[4].  Lanes 0..15 build the table d*P (d < 16) in LDS, then lanes 0..3 run
 // 4-bit fixed windows, four lanes per point.
 // endo != 0 (every CRS point that A and B1 are sums of lies in the prime-order subgroup: checked once, when the circuit is
-// loaded — k_g1_subgroup_flag): k = q u^2 + rem and [u^2] P = -phi(P) = (beta x, -y) on the subgroup (subgroup.cuh), so
+// loaded — k_g1_subgroup_flag): k = q u^2 + rem and [u^2] P = -phi(P) = (beta x, -y) on the subgroup (subgroup.hpp), so
 // [k] P = [rem] P + [q] (beta x, -y): two 128-bit scalars, 124 doublings and <= 32 additions each, on two quads of the same
 // wave — the table of (beta x, -y) is the table of P with X scaled and Y negated.  This multiplication is the tail of the
 // two longest G1 chains of a lone proof (2.1 ms of 252 dependent doublings before).
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(64) k_groth16_var_mul(uint32_t which0, const G
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // four lanes per point (quad.cuh).  endo: quad 0 runs [rem] P, quad 1 runs [q] [u^2] P — two chains of 124 doublings and
+    // four lanes per point (quad.hpp).  endo: quad 0 runs [rem] P, quad 1 runs [q] [u^2] P — two chains of 124 doublings and
     // <= 32 additions side by side in the same wave — and quad 0 adds the two
     __shared__ G1Xyzz other;
     G1Xyzz acc = xyzz_inf<FpOps>();

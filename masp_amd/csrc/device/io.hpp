@@ -4,7 +4,7 @@
 //   * compressed points as written by `Proof::write` (/root/reference/masp_proofs/src/prover.rs:190-193);
 //   * Fr as 32-byte little-endian canonical (`to_repr()`).
 #pragma once
-#include "curve.cuh"
+#include "curve.hpp"
 
 namespace masp {
 

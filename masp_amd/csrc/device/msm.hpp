@@ -25,10 +25,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "curve.cuh"
-#include "quad.cuh"
-#include "oct.cuh"
-#include "io.cuh"
+#include "curve.hpp"
+#include "quad.hpp"
+#include "oct.hpp"
+#include "io.hpp"
 #include "msm_geom.h"
 
 namespace masp {
@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(64) k_msm_precompute(TabRow<O>* __restrict__ t
     }
 }
 
-// ---- (4) accumulate: device/msm_acc.cuh (its own translation unit) -------------------------------------
+// ---- (4) accumulate: device/msm_acc.hpp (its own translation unit) -------------------------------------
 
 // ---- (5) gather: bucket b = sum of its partials part[c + b], c over the chunks its entries touch ---------
 // heavy_span: a bucket with at least this many partials is left to k_msm_bucket_heavy (24 in a batch, where work

@@ -1,8 +1,8 @@
-// Stage (4) of the MSM (see device/msm.cuh for the plan): bucket accumulation, the dominant kernel of the whole prover.
+// Stage (4) of the MSM (see device/msm.hpp for the plan): bucket accumulation, the dominant kernel of the whole prover.
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "curve.cuh"
+#include "curve.hpp"
 #include "msm_geom.h"
 
 namespace masp {

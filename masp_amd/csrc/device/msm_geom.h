@@ -30,7 +30,7 @@ __host__ __device__ static inline uint32_t msm_chunk_len(uint32_t total, uint32_
 // weighted-sum geometry (k_msm_wsum_level): 128 lanes per workgroup, 2^G_LOG buckets per lane
 static constexpr unsigned WSUM_L_LOG = 7, WSUM_L = 1u << WSUM_L_LOG;
 static constexpr unsigned WSUM_G_LOG_MIN = 2;
-// a lone proof's heavy buckets are shared by MSM_HEAVY_SPLIT workgroups each (device/msm.cuh k_msm_bucket_heavy): slots for their shares
+// a lone proof's heavy buckets are shared by MSM_HEAVY_SPLIT workgroups each (device/msm.hpp k_msm_bucket_heavy): slots for their shares
 static constexpr unsigned MSM_HEAVY_SPLIT = 8, MSM_HEAVY_SLOTS = 2048;
 static constexpr unsigned MSM_SORT_THREADS = 1024;
 // the entry that fills the gap behind a bucket's run when runs are aligned (MsmSortBuf::pad_log): the point at infinity

@@ -1,4 +1,4 @@
-// Counting sort of the signed window digits of an MSM by bucket (stages 1-3 of device/msm.cuh's plan): curve-independent,
+// Counting sort of the signed window digits of an MSM by bucket (stages 1-3 of device/msm.hpp's plan): curve-independent,
 // compiled once (k_msm_sort.hip).
 #pragma once
 #include <hip/hip_runtime.h>

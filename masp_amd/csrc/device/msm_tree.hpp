@@ -1,4 +1,4 @@
-// Shared-inversion ("batch-affine") pre-reduction of the bucket runs of an MSM: stage (3b) of device/msm.cuh's plan, between
+// Shared-inversion ("batch-affine") pre-reduction of the bucket runs of an MSM: stage (3b) of device/msm.hpp's plan, between
 // the counting sort and the XYZZ accumulation.
 //
 // The sorted digit list holds, bucket after bucket, the window-table rows a bucket has to sum.  k_msm_accumulate adds them
@@ -22,13 +22,13 @@
 // The price is memory: a level reads its points twice and keeps 48 bytes per pair in between; level 0 gathers every table row
 // twice (measured: random 128-byte rows arrive at 6.5 TB/s, tools/batch_affine_ubench.hip).
 // Exceptional pairs (P + P, P - P, the point at infinity as an operand) are handled exactly, like everywhere else: proof bytes
-// must equal the CPU prover's for any CRS.  Infinity is x = y = 0 (curve.cuh).
+// must equal the CPU prover's for any CRS.  Infinity is x = y = 0 (curve.hpp).
 // Replaces nothing the reference has by name: bellperson's multiexp (call sites
 // /root/reference/masp_proofs/src/sapling/prover.rs:117,202,252) sums buckets in projective coordinates on the CPU.
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "curve.cuh"
+#include "curve.hpp"
 #include "msm_geom.h"
 
 namespace masp {

@@ -18,8 +18,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "field.cuh"
-#include "fr_io.cuh"
+#include "field.hpp"
+#include "fr_io.hpp"
 #include "ntt_geom.h"
 
 namespace masp {

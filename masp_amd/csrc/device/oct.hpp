@@ -1,4 +1,4 @@
-// Eight lanes, one G2 point: the G2 twin of device/quad.cuh for the bucket tails of a lone proof's b_g2 MSM.
+// Eight lanes, one G2 point: the G2 twin of device/quad.hpp for the bucket tails of a lone proof's b_g2 MSM.
 //
 // What a lone proof waits for at the end is B2's chain of dependent G2 additions on waves that have a SIMD to themselves: over lane
 // pairs (Fp2PairOps: one Fp2 per pair of lanes) an XYZZ addition is ~14 dependent Fp2 products of ~2.4 us each, and the heavy-bucket
@@ -10,8 +10,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "curve.cuh"
-#include "quad.cuh"
+#include "curve.hpp"
+#include "quad.hpp"
 
 namespace masp {
 

@@ -10,9 +10,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "curve.cuh"
-#include "subgroup.cuh"
-#include "io.cuh"
+#include "curve.hpp"
+#include "subgroup.hpp"
+#include "io.hpp"
 
 namespace masp {
 
@@ -61,7 +61,7 @@ __device__ inline bool fp2_sqrt(const Fp2& v, Fp2& out) {  // host/pairing.h Fp2
     out = {x0, x1};
     return Fp2Ops::eq(Fp2Ops::sqr(out), v);
 }
-// subgroup membership of G1 / G2 points (g1_in_subgroup, g2_in_subgroup): device/subgroup.cuh
+// subgroup membership of G1 / G2 points (g1_in_subgroup, g2_in_subgroup): device/subgroup.hpp
 // the encoding of the point at infinity: compression and infinity flags, nothing else (bellman rejects stray bits)
 __device__ inline bool infinity_encoding_is_clean(const uint8_t* in, int len) {
     if ((in[0] & 0x3f) != 0) return false;

@@ -5,7 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "curve.cuh"
+#include "curve.hpp"
 
 namespace masp {
 
@@ -79,8 +79,8 @@ __device__ __forceinline__ void xyzz_add_coop(G1Xyzz& acc, const G1Xyzz& b, uint
     acc.ZZZ = coop_from<2>(t);
 }
 
-// FpOps over quads (field.cuh: FpQuadOps — O::LANES = 4, every lane of a quad holds the whole point): the bucket tails of a
-// lone proof's G1 MSMs (device/msm.cuh) call these through the names they use for every other O
+// FpOps over quads (field.hpp: FpQuadOps — O::LANES = 4, every lane of a quad holds the whole point): the bucket tails of a
+// lone proof's G1 MSMs (device/msm.hpp) call these through the names they use for every other O
 __device__ __forceinline__ uint32_t quad_lane() { return __lane_id() & 3u; }
 __device__ __forceinline__ Xyzz<FpQuadOps> xyzz_dbl(const Xyzz<FpQuadOps>& p) {
     const G1Xyzz r = xyzz_dbl_coop(reinterpret_cast<const G1Xyzz&>(p), quad_lane());

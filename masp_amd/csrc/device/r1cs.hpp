@@ -5,7 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../launch.h"
-#include "fr_io.cuh"
+#include "fr_io.hpp"
 
 namespace masp {
 

@@ -10,9 +10,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "curve.cuh"
-#include "fr_io.cuh"
-#include "io.cuh"
+#include "curve.hpp"
+#include "fr_io.hpp"
+#include "io.hpp"
 
 namespace masp {
 

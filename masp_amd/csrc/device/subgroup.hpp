@@ -1,7 +1,7 @@
 // Membership of a curve point in the prime-order subgroups of BLS12-381 (used by the verifier for proof points and, when a
-// circuit is loaded, for the CRS points whose multiples the prover takes through the endomorphism: device/groth16.cuh).
+// circuit is loaded, for the CRS points whose multiples the prover takes through the endomorphism: device/groth16.hpp).
 #pragma once
-#include "curve.cuh"
+#include "curve.hpp"
 
 namespace masp {
 

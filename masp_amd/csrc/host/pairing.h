@@ -13,7 +13,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../device/consts.cuh"
+#include "../device/consts.hpp"
 #include "mont.h"
 
 namespace masp_host {
@@ -348,7 +348,7 @@ inline bool g2_uncompressed(G2A& p, const uint8_t* in) {
     p.inf = false;
     return Fp::from_be(p.x.b, in) && Fp::from_be(p.x.a, in + 48) && Fp::from_be(p.y.b, in + 96) && Fp::from_be(p.y.a, in + 144);
 }
-// ---- subgroup membership (same tests and constants as the device verifier, device/pairing.cuh) ------------------------
+// ---- subgroup membership (same tests and constants as the device verifier, device/pairing.hpp) ------------------------
 // `groth16::Proof::read` refuses points outside the prime-order subgroups (/root/reference/masp_proofs/src/sapling/verifier/
 // batch.rs:85,125,154 parse with it); the pairing cannot see the cofactor part of a point, so a verifier without this test
 // accepts malleated proofs.  G1: (beta x, y) = -[u^2] P.  G2: psi(Q) = [u] Q.  (M. Scott's membership tests.)

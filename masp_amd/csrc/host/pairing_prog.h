@@ -7,7 +7,7 @@
 // the twist, sparse line (c0, c1 v, c2 v w), Karatsuba tower) are written ONCE below as templates over the base field,
 // instantiated with a symbolic type that records every Fp operation into a DAG, and the DAG is levelled (ASAP) into
 // steps of mutually independent operations with values living in numbered 48-byte slots.  The device kernel
-// (device/pairing.cuh) is then a tiny interpreter: one WAVE per pair, slots in LDS, lane k of the wave executes the k-th
+// (device/pairing.hpp) is then a tiny interpreter: one WAVE per pair, slots in LDS, lane k of the wave executes the k-th
 // operation of the current step — a doubling iteration is ~6 steps that contain products instead of ~135 products in a row.
 // The same program runs on the host interpreter below, which is how it is checked against host/pairing.h without a GPU
 // (masp_host_pairing_program_selftest, tests/test_pairing_program.py).

@@ -15,7 +15,7 @@
 #include <thread>
 #include <vector>
 
-#include "device/io.cuh"
+#include "device/io.hpp"
 #include "device/ntt_geom.h"
 #include "launch.h"
 #include "msm_host.h"

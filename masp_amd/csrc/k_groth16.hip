@@ -1,6 +1,6 @@
 // Proof assembly + zcash encoding, point import / export and the per-circuit fixed-base tables, with their launch
 // wrappers (launch.h).
-#include "device/groth16.cuh"
+#include "device/groth16.hpp"
 #include "launch.h"
 #include "util.h"
 

@@ -1,5 +1,5 @@
 // G1 instantiation of the MSM driver (window-table import / precomputation, bucket gather, heavy buckets, weighted sums).
-#include "msm_impl.cuh"
+#include "msm_impl.hpp"
 
 namespace masp {
 template struct MsmBases<FpOps, 96>;

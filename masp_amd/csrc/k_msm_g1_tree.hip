@@ -1,5 +1,5 @@
-// G1 instantiation of the batch-affine pre-reduction of the bucket runs (device/msm_tree.cuh, msm_tree_impl.cuh).
-#include "msm_tree_impl.cuh"
+// G1 instantiation of the batch-affine pre-reduction of the bucket runs (device/msm_tree.hpp, msm_tree_impl.hpp).
+#include "msm_tree_impl.hpp"
 
 namespace masp {
 template struct MsmTreeWs<FpOps>;

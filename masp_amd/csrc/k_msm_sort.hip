@@ -1,7 +1,7 @@
-// Counting sort of the MSM digits: kernels (device/msm_sort.cuh) + their host-side enqueue.
+// Counting sort of the MSM digits: kernels (device/msm_sort.hpp) + their host-side enqueue.
 #include <cstring>
 
-#include "device/msm_sort.cuh"
+#include "device/msm_sort.hpp"
 #include "msm_host.h"
 
 namespace masp {

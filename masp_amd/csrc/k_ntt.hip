@@ -1,7 +1,7 @@
 // Fr NTT / quotient kernels and the static-R1CS kernels with their launch wrappers (launch.h).
 #include <algorithm>
-#include "device/ntt.cuh"
-#include "device/r1cs.cuh"
+#include "device/ntt.hpp"
+#include "device/r1cs.hpp"
 #include "launch.h"
 #include "util.h"
 

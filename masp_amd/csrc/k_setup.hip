@@ -1,6 +1,6 @@
-// Groth16 parameter generation from explicit toxic waste (kernels: device/setup.cuh) — mirrors bellperson's
+// Groth16 parameter generation from explicit toxic waste (kernels: device/setup.hpp) — mirrors bellperson's
 // `generate_random_parameters`, which the reference's benches call (/root/reference/masp_proofs/benches/sapling.rs:24-36).
-#include "device/setup.cuh"
+#include "device/setup.hpp"
 #include "internal.h"
 
 using namespace masp;

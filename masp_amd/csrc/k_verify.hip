@@ -1,11 +1,11 @@
 // GPU Groth16 batch verification: the C ABI entry points masp_hip_vk_prepare / masp_hip_verify_batch (include/masp_hip.h),
-// the kernels of device/pairing.cuh, and the host-side remainder (host/groth16_vk.h: public-input combination, two pairs,
+// the kernels of device/pairing.hpp, and the host-side remainder (host/groth16_vk.h: public-input combination, two pairs,
 // final exponentiation — work that does not grow with the batch).
 // Replaces bellman `verify_proofs_batch` as reached from /root/reference/masp_proofs/src/sapling/verifier/batch.rs:24-31,201-239
 // and the per-proof `verify_proof` self-checks of the prover (sapling/prover.rs:148,266) when they are batched.
 #include <mutex>
 
-#include "device/pairing.cuh"
+#include "device/pairing.hpp"
 #include "host/groth16_vk.h"
 #include "host/pairing_prog.h"
 #include "internal.h"

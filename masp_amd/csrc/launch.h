@@ -4,11 +4,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "device/curve.cuh"
+#include "device/curve.hpp"
 
 namespace masp {
 
-// ---- k_ntt.hip: Fr NTT / quotient kernels (device/ntt.cuh) and the R1CS kernels (device/r1cs.cuh) ----
+// ---- k_ntt.hip: Fr NTT / quotient kernels (device/ntt.hpp) and the R1CS kernels (device/r1cs.hpp) ----
 void launch_fr_powers(hipStream_t s, Fr* table, uint32_t n, const Fr& base, const Fr& scale, int plain);
 // stages [s0, s0 + nst) of np transforms of 2^logm points at data + p * 2^logm
 void launch_ntt_pass(hipStream_t s, Fr* data, const Fr* tw, uint32_t logm, uint32_t s0, uint32_t nst, uint32_t np);
@@ -34,7 +34,7 @@ static constexpr uint32_t R1CS_LONG_ROW = 64;
 void launch_r1cs_eval(hipStream_t s, const R1csMatrices& M, const Fr* w, uint32_t n_vars, uint32_t n_constraints, uint32_t n_inputs, uint32_t np);
 void launch_gather_scalars(hipStream_t s, const Fr* src, size_t src_stride, const uint32_t* idx, uint32_t n, Fr* dst, uint32_t np);
 
-// ---- k_groth16.hip: proof assembly, point import / export, fixed-base tables (device/groth16.cuh) ----
+// ---- k_groth16.hip: proof assembly, point import / export, fixed-base tables (device/groth16.hpp) ----
 void launch_groth16_fixed_g1(hipStream_t s, const G1Xyzz* fb1, const uint32_t* rs, size_t rs_stride, G1Xyzz* part, uint32_t np);
 void launch_groth16_fixed_g2(hipStream_t s, const G2Xyzz* fb2, const uint32_t* rs, size_t rs_stride, G2Xyzz* part2, uint32_t np);
 // endo: Circuit::g1_endo (the points behind A and B1 all lie in the prime-order subgroup: half as many doublings)

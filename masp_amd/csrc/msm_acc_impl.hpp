@@ -1,7 +1,7 @@
 // The launch of the dominant kernel, k_msm_accumulate<O>, on its own: one translation unit per curve (k_msm_g1_acc.hip,
 // k_msm_g2_acc.hip) so that the hot kernel can be rebuilt in seconds.
 #pragma once
-#include "device/msm_acc.cuh"
+#include "device/msm_acc.hpp"
 #include "msm_host.h"
 
 namespace masp {

@@ -1,6 +1,6 @@
 // Host-side driver of the MSM kernels: owns the precomputed window tables of one base set and a reusable workspace, and
 // enqueues one MSM on a HIP stream without any host sync.  This header holds types and declarations only; the functions
-// that launch kernels are defined in msm_impl.cuh / msm_acc_impl.cuh and instantiated in their own translation units
+// that launch kernels are defined in msm_impl.hpp / msm_acc_impl.hpp and instantiated in their own translation units
 // (k_msm_g1.hip, k_msm_g2.hip, k_msm_g1_acc.hip, k_msm_g2_acc.hip, k_msm_sort.hip), so that the kernel families compile side
 // by side and a change to one kernel recompiles one unit.
 #pragma once
@@ -9,7 +9,7 @@
 #include <cstdio>
 #include <vector>
 
-#include "device/curve.cuh"
+#include "device/curve.hpp"
 #include "device/msm_geom.h"
 #include "util.h"
 
@@ -40,7 +40,7 @@ struct MsmBases {
         int c = n_eff >= (1u << 16) ? 16 : n_eff >= (1u << 12) ? 12 : n_eff >= (1u << 8) ? 10 : 7;
         return msm_geom(c);
     }
-    // raw: device pointer to n uncompressed points (bellman wire format)          [msm_impl.cuh]
+    // raw: device pointer to n uncompressed points (bellman wire format)          [msm_impl.hpp]
     // force_c: window width (0: pick_geom)
     int load_device(const uint8_t* d_raw, uint32_t n_, hipStream_t s, uint32_t n_eff = 0xffffffffu, int force_c = 0);
     int load_host(const uint8_t* raw, uint32_t n_, hipStream_t s, uint32_t n_eff = 0xffffffffu, int force_c = 0) {
@@ -70,7 +70,7 @@ struct MsmSortBuf {
     uint32_t n = 0, np = 0;
     MsmGeom g{};
     // Every bucket's run in `sorted` starts at a multiple of 2^pad_log entries; the gap behind a run holds MSM_PAD_ENTRY (the
-    // point at infinity).  The batch-affine tree (device/msm_tree.cuh) asks for pad_log = 2 (MASP_TREE_PAD_LOG): every run's
+    // point at infinity).  The batch-affine tree (device/msm_tree.hpp) asks for pad_log = 2 (MASP_TREE_PAD_LOG): every run's
     // length is a multiple of four, so pair q of level 0 is simply entries 2q, 2q + 1 and lands at point q of level 1, and the
     // same again for level 1 — no per-pair records for the two levels that hold three quarters of all pairs (1 / 2 / 3
     // measured: stage 54.1 / 52.7 / 54.2 ms per G1 MSM; padding to 2^levels costs more pair slots than records: DESIGN.md §6).
@@ -138,7 +138,7 @@ struct MsmSortBuf {
     }
 };
 
-// ---- scratch of the batch-affine pre-reduction (device/msm_tree.cuh) for up to q proofs at a time ---------------------
+// ---- scratch of the batch-affine pre-reduction (device/msm_tree.hpp) for up to q proofs at a time ---------------------
 // One byte arena serves every tree of a slot (its G1 and G2 MSMs run one after the other on the slot's stream): the views below
 // are carved out of it anew by every msm_tree_enqueue.
 // internal: the tree's scratch does not fit (device out of memory, or above masp_hip_options::bucket_tree_scratch_mb) — the caller
@@ -190,8 +190,8 @@ struct MsmTreeWs {
     size_t pre_cap = 0;  // elements of the plane `pre`
     struct MsmProfile* prof = nullptr;  // set by msm_reduce_enqueue while a profiled MSM runs through the tree (MsmProfile::mark)
 
-    int reserve(uint64_t E_ub, uint32_t nb, uint32_t q, uint32_t T);                 // [msm_tree_impl.cuh]
-    void batch_invert(hipStream_t s, const F* in, uint32_t n, F* out);              // [msm_tree_impl.cuh]
+    int reserve(uint64_t E_ub, uint32_t nb, uint32_t q, uint32_t T);                 // [msm_tree_impl.hpp]
+    void batch_invert(hipStream_t s, const F* in, uint32_t n, F* out);              // [msm_tree_impl.hpp]
     const F* points_x() const { return px[T & 1]; }
     const F* points_y() const { return py[T & 1]; }
     size_t point_stride() const { return stride[T & 1]; }
@@ -285,7 +285,7 @@ struct MsmWorkspace {
     }
 
     // per proof: reduce the `m` points at `src + p*src_stride` to one at `dst + p*dst_stride` (src must not be R[]).
-    // Workgroup tree reductions (fan-in 256, 8 dependent additions per pass).                      [msm_impl.cuh]
+    // Workgroup tree reductions (fan-in 256, 8 dependent additions per pass).                      [msm_impl.hpp]
     void reduce_to_one(hipStream_t s, uint32_t np, const Xyzz<O>* src, size_t src_stride, uint32_t m, Xyzz<O>* dst, size_t dst_stride,
                        size_t r_stride);
     // the same over OT::LANES lanes per point (FpQuadOps: a lone proof)
@@ -395,21 +395,21 @@ inline uint32_t msm_tree_levels(uint32_t n_eff, const MsmGeom& g, uint32_t np, i
     return std::min(4u, lg > 1 ? lg - 1 : 0u);
 }
 
-// The dominant kernel on its own: bucket accumulation of the sorted digit list (k_msm_accumulate<O>).   [msm_acc_impl.cuh]
+// The dominant kernel on its own: bucket accumulation of the sorted digit list (k_msm_accumulate<O>).   [msm_acc_impl.hpp]
 template <class O>
 void msm_launch_accumulate(hipStream_t s, const TabRow<O>* tab, const uint32_t* sorted, size_t ent_stride, const uint32_t* start, uint32_t nb,
                            uint32_t nchunks, Xyzz<O>* part, uint32_t np);
 
-// Batch-affine pre-reduction (device/msm_tree.cuh) of proofs [p0, p0 + q) of the sort `sb`: T levels.   [msm_tree_impl.cuh]
+// Batch-affine pre-reduction (device/msm_tree.hpp) of proofs [p0, p0 + q) of the sort `sb`: T levels.   [msm_tree_impl.hpp]
 template <class O, int BYTES>
 int msm_tree_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSortBuf& sb, MsmTreeWs<O>& tw, uint32_t p0, uint32_t q, uint32_t T);
-// k_msm_accumulate over explicit points instead of gathered table rows                                   [msm_tree_impl.cuh]
+// k_msm_accumulate over explicit points instead of gathered table rows                                   [msm_tree_impl.hpp]
 template <class O>
 void msm_launch_accumulate_pts(hipStream_t s, const typename O::T* xs, const typename O::T* ys, size_t pt_stride, const uint32_t* start, uint32_t nb,
                                uint32_t nchunks, Xyzz<O>* part, uint32_t np);
 
 // Bucket accumulation + reduction of the MSM whose digits were sorted into `sb` (same n, geometry and batch size):
-// result p at d_out + p * out_stride.  No host synchronisation.                                    [msm_impl.cuh]
+// result p at d_out + p * out_stride.  No host synchronisation.                                    [msm_impl.hpp]
 template <class O, int BYTES>
 int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSortBuf& sb, MsmWorkspace<O>& ws, Xyzz<O>* d_out, size_t out_stride,
                        MsmProfile* prof = nullptr);

@@ -1,13 +1,13 @@
 // Definitions of the MSM driver functions that launch kernels (everything but the accumulation): included only by the
 // translation units that instantiate them for one curve (k_msm_g1.hip, k_msm_g2.hip).
 #pragma once
-#include "device/msm.cuh"
+#include "device/msm.hpp"
 #include "msm_host.h"
 #include <type_traits>
 
 namespace masp {
 
-// the G2 bucket tails (gather, heavy buckets, weighted sums) run over lane pairs (Fp2PairOps, field.cuh); 0: one lane per point
+// the G2 bucket tails (gather, heavy buckets, weighted sums) run over lane pairs (Fp2PairOps, field.hpp); 0: one lane per point
 #ifndef MASP_G2_PAIR_TAILS
 #define MASP_G2_PAIR_TAILS 1
 #endif
@@ -268,7 +268,7 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
     // end).  A lone proof keeps span 12 and four waves (shortest chain for its one big bucket).
     // Workgroups go to the 8 XCDs round-robin by linear id x + gridDim.x * y, so with gridDim.x a multiple of 8 every proof's
     // first working workgroup (x = 0: bucket 0) would land on the same XCD: keep gridDim.x odd.
-    // a lone proof's G1 tails run over quads (device/quad.cuh): their chains of dependent additions are what it waits for.
+    // a lone proof's G1 tails run over quads (device/quad.hpp): their chains of dependent additions are what it waits for.
     // (Those kernels live in a translation unit of their own, k_msm_g1_lone.hip.)
     if constexpr (std::is_same<O, FpOps>::value) {
         if (lone)
@@ -276,7 +276,7 @@ int msm_reduce_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSort
         else
             msm_tails_enqueue<O, FpOps>(s, ws, start, nb, nchunks, np, lone, d_out, out_stride);
     } else {
-        // ... and its G2 tails over groups of four lane pairs (device/oct.cuh)
+        // ... and its G2 tails over groups of four lane pairs (device/oct.hpp)
         if (lone && (MASP_G2_OCT_LONE))
             msm_tails_enqueue<O, Fp2OctOps>(s, ws, start, nb, nchunks, np, lone, d_out, out_stride);
         else

@@ -1,7 +1,7 @@
-// Host driver of the batch-affine pre-reduction (device/msm_tree.cuh): instantiated per curve in k_msm_g1_tree.hip /
+// Host driver of the batch-affine pre-reduction (device/msm_tree.hpp): instantiated per curve in k_msm_g1_tree.hip /
 // k_msm_g2_tree.hip.
 #pragma once
-#include "device/msm_tree.cuh"
+#include "device/msm_tree.hpp"
 #include "msm_host.h"
 #include <type_traits>
 
@@ -9,11 +9,11 @@ namespace masp {
 
 // ---- geometry of a level (host side; the device works with the exact counts of D / Q) -----------------------------------
 // E_ub: upper bound of a proof's digit-list length.  Points of level L <= E / 2^L + nb, pairs <= E / 2^(L+1) + nb / 2 + 1.
-// (even: the planes keep points of even and odd index in separate halves, device/msm_tree.cuh)
+// (even: the planes keep points of even and odd index in separate halves, device/msm_tree.hpp)
 static inline uint32_t tree_points_ub(uint64_t E_ub, uint32_t nb, uint32_t L) { return (uint32_t)(((E_ub >> L) + nb + 2) & ~(uint64_t)1); }
 static inline uint32_t tree_pairs_ub(uint64_t E_ub, uint32_t nb, uint32_t L) { return (uint32_t)((E_ub >> (L + 1)) + nb / 2 + 1); }
 // lanes per proof of the two passes: ~MSM_TREE_KP pairs per lane, whole workgroups
-// G2 kernels that run over lane pairs (Fp2PairOps, field.cuh: half an Fp2 per lane, two waves per SIMD where the Fp2Ops form
+// G2 kernels that run over lane pairs (Fp2PairOps, field.hpp: half an Fp2 per lane, two waves per SIMD where the Fp2Ops form
 // gets one).  Bits: 1 pass 2, 2 pass 1, 4 the shared inversions, 8 the accumulation of the level-T points.
 #ifndef MASP_TREE_G2_PAIR
 #define MASP_TREE_G2_PAIR 15
@@ -128,7 +128,7 @@ int msm_tree_enqueue(hipStream_t s, const MsmBases<O, BYTES>& B, const MsmSortBu
         typedef typename TreeLaneOps<O, 2>::type O1;
         typedef typename O1::T F1;
         const dim3 grid1(NT * O1::LANES / 256, q);
-        // `pre` is a plane of tw.pre_cap curve elements (device/msm_tree.cuh): its capacity in the kernels' element types
+        // `pre` is a plane of tw.pre_cap curve elements (device/msm_tree.hpp): its capacity in the kernels' element types
         const size_t pre_cap1 = tw.pre_cap * sizeof(F) / sizeof(F1);
         const uint32_t out_whole = L + 1 == T;  // the last level's points as whole elements: what k_msm_accumulate_pts reads
         // level 0: the "records" are the digit list itself, two entries at a time (runs of even length: pair q = entries 2q, 2q + 1)

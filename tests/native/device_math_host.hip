@@ -1,8 +1,8 @@
-// TEST-ONLY shim: compiles masp_amd/csrc/device/{field,curve,io}.cuh for the *host* so the exact
+// TEST-ONLY shim: compiles masp_amd/csrc/device/{field,curve,io}.hpp for the *host* so the exact
 // source the HIP kernels use can be checked on a machine without a GPU (tests/test_device_math_host.py).
 // It is never part of the product library.
-#include "../../masp_amd/csrc/device/io.cuh"
-#include "../../tools/fp28.cuh"   // (an experiment kept with its checks: see the header)
+#include "../../masp_amd/csrc/device/io.hpp"
+#include "../../tools/fp28.hpp"   // (an experiment kept with its checks: see the header)
 using namespace masp;
 
 // ---- the same field functions ON THE DEVICE (their device overloads are hand-written carry chains / inline asm that the host
@@ -15,7 +15,7 @@ __global__ void k_field_ops(int op, const uint8_t* a, const uint8_t* b, uint8_t*
     constexpr int B = 4 * C::N;
     if (op >= 16) {
         // RAW limbs in, raw limbs out (Fp only): the Montgomery products on operands anywhere in [0, 2p) — what the lazily
-        // reduced chains of the bucket tree feed them, and the shapes that stress the carry-free top-limb terms (field.cuh,
+        // reduced chains of the bucket tree feed them, and the shapes that stress the carry-free top-limb terms (field.hpp,
         // MASP_MACNC).  16 mul, 17 mul_lazy (left in [0, 2p)), 18 sqr, 19 mul2(a, b, b, a), 20 mul_lazy(mul_lazy(a, b), b)
         if constexpr (C::N == 12) {
             const Fe<C> x = fe_load_le<C>(a + (size_t)B * i), y = fe_load_le<C>(b + (size_t)B * i);
@@ -43,7 +43,7 @@ __global__ void k_field_ops(int op, const uint8_t* a, const uint8_t* b, uint8_t*
     fe_store_le(fe_from_mont(r), out + (size_t)B * i);
 }
 
-// ---- the 28-bit-limb form (device/fp28.cuh): raw limbs in and out, 56 bytes per element (an Fp operand / result uses the first
+// ---- the 28-bit-limb form (device/fp28.hpp): raw limbs in and out, 56 bytes per element (an Fp operand / result uses the first
 // 48).  op: 0 mul 1 sqr 2 canon 3 sub_lazy 4 neg 5 from_fp 6 from_fp_lazy 7 to_fp 8 Ops::add 9 Ops::sub 10 Ops::dbl
 // 11 canon(sub_lazy(sub_lazy(sqr(a), b), b)) 12 is_zero(a) | eq(a, b) << 1
 MASP_HD void fp28_test_op(int op, const uint8_t* pa, const uint8_t* pb, uint8_t* po) {

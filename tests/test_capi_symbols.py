@@ -32,7 +32,7 @@ def test_product_never_references_the_oracle():
     bad = []
     for base, _, files in os.walk(os.path.join(ROOT, "masp_amd")):
         for f in files:
-            if f.endswith((".py", ".h", ".cuh", ".hip", ".cpp")) or f == "Makefile":
+            if f.endswith((".py", ".h", ".hpp", ".hip", ".cpp")) or f == "Makefile":
                 text = open(os.path.join(base, f), errors="replace").read()
                 for line in text.splitlines():
                     code = line.split("//")[0].split("#")[0] if not f.endswith(".py") else line.split("#")[0]

@@ -1,4 +1,4 @@
-"""The HIP kernels' field/curve/encoding source (masp_amd/csrc/device/*.cuh, 32-bit limbs) compiled for
+"""The HIP kernels' field/curve/encoding source (masp_amd/csrc/device/*.hpp, 32-bit limbs) compiled for
 the host and checked against python big integers and the oracle.  Runs without a GPU; the same
 functions run on the device in the -m gpu tests."""
 import ctypes as C
@@ -20,7 +20,7 @@ SO = os.path.join(HERE, "native", "_device_math_host.so")
 
 @pytest.fixture(scope="module")
 def mh():
-    hdrs = [os.path.join(HERE, "..", "masp_amd", "csrc", "device", f) for f in ("field.cuh", "curve.cuh", "io.cuh", "consts.cuh")] + [os.path.join(HERE, "..", "tools", "fp28.cuh")]
+    hdrs = [os.path.join(HERE, "..", "masp_amd", "csrc", "device", f) for f in ("field.hpp", "curve.hpp", "io.hpp", "consts.hpp")] + [os.path.join(HERE, "..", "tools", "fp28.hpp")]
     newest = max(os.path.getmtime(p) for p in hdrs + [SRC])
     if not os.path.exists(SO) or os.path.getmtime(SO) < newest:
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", SRC, "-o", SO])
@@ -59,7 +59,7 @@ def test_field_ops(mh):
 @pytest.mark.gpu
 def test_field_ops_on_the_device(mh):
     """The DEVICE overloads of add / sub / neg / dbl / the conditional subtraction behind every product are hand-written carry
-    chains (field.cuh) that the host build never compiles: the same operations on the GPU, against python integers — the
+    chains (field.hpp) that the host build never compiles: the same operations on the GPU, against python integers — the
     edge values against each other (sums and differences that land exactly on 0, p - 1, p, 2p - 2) and random pairs."""
     rng = random.Random(11)
     for which, mod, nb in ((0, P, 48), (1, R, 32)):
@@ -169,7 +169,7 @@ def test_g2_group_law_and_encodings(mh):
     assert o192.raw == O.g2_mul_gen(3 * ks[0] % R)[0]
 
 
-# ---- the 28-bit-limb form of Fp (tools/fp28.cuh: an experiment, measured and rejected — DESIGN.md section 6) ----------------------------------------------------------------------
+# ---- the 28-bit-limb form of Fp (tools/fp28.hpp: an experiment, measured and rejected — DESIGN.md section 6) ----------------------------------------------------------------------
 M28, R28 = (1 << 28) - 1, 1 << 392
 
 
@@ -275,7 +275,7 @@ def _check_fp28(fn):
 
 
 def test_fp28_ops_host(mh):
-    """The 28-bit-limb field written for the G1 bucket tree (tools/fp28.cuh; not in the product), portable build: products of lazy operands, the carry-free
+    """The 28-bit-limb field written for the G1 bucket tree (tools/fp28.hpp; not in the product), portable build: products of lazy operands, the carry-free
     differences, canonicalisation from every k p + c, the conversions to and from the 12 x 32-bit Montgomery residues."""
     _check_fp28(mh.mh_fp28_ops)
 

@@ -1,4 +1,4 @@
-"""The batch-affine pre-reduction of the bucket runs (masp_amd/csrc/device/msm_tree.cuh: pairwise affine additions whose
+"""The batch-affine pre-reduction of the bucket runs (masp_amd/csrc/device/msm_tree.hpp: pairwise affine additions whose
 inversions are shared across the grid) through the C ABI, in the regime that uses it (np >= 8 MSMs per launch sequence):
 against the CPU restatement's multiexp on every exceptional case of the affine group law — P + P (a doubling inside the
 shared inversion), P + (-P) (the point at infinity as a RESULT that later levels meet as an operand), bases at infinity,

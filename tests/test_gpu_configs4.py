@@ -51,6 +51,7 @@ def test_configs4_4096_mixed_jobs_sharded_over_the_devices_of_the_node():
         insts = [next(it[k]) for k in kinds]
         rs = _rs(random.Random(44), N)
         jobs = [(KINDS.index(k), i, a, r, s) for k, (i, a), (r, s) in zip(kinds, insts, rs)]
+        assert multi.prove_batch([]) == []                  # an empty list through the multi-device front: no block, no worker waits for one
         before = multi.device_proofs()
         proofs = multi.prove_batch(jobs)
         assert len(proofs) == N and all(len(p) == 192 for p in proofs) and len(set(proofs)) == N

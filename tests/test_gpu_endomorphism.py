@@ -1,4 +1,4 @@
-"""s*A and r*B1 through the curve endomorphism (device/groth16.cuh: k_groth16_var_mul, endo): [k] P = [rem] P + [q] (beta x, -y)
+"""s*A and r*B1 through the curve endomorphism (device/groth16.hpp: k_groth16_var_mul, endo): [k] P = [rem] P + [q] (beta x, -y)
 with k = q u^2 + rem holds on the prime-order subgroup only.  A CRS whose points behind A and B1 are all in the subgroup takes
 that path (every other proof test of the suite runs it); the reference reads its parameters unchecked
 (/root/reference/masp_proofs/src/lib.rs:343-347, Parameters::read(_, false)), so a CRS with a curve point OUTSIDE the subgroup

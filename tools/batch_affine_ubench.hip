@@ -24,7 +24,7 @@
 #include <random>
 #include <vector>
 
-#include "../masp_amd/csrc/device/msm_acc.cuh"
+#include "../masp_amd/csrc/device/msm_acc.hpp"
 using namespace masp;
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)

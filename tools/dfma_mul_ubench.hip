@@ -17,7 +17,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "../masp_amd/csrc/device/field.cuh"
+#include "../masp_amd/csrc/device/field.hpp"
 using namespace masp;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
@@ -120,7 +120,7 @@ int main() {
     float ms2 = time_ms([&] { hipLaunchKernelGGL(k_femul, dim3(blocks), dim3(threads), 0, 0, df, it); });
     const double imad = (double)n * it * 2 / ms2 / 1e6;
     printf("device %s, %d CUs\n", p.name, p.multiProcessorCount);
-    printf("Fp product on v_mad_u64_u32 (device/field.cuh fe_mul, 12 x 32-bit limbs):  %8.3f ms  %7.2f G products/s\n", ms2, imad);
+    printf("Fp product on v_mad_u64_u32 (device/field.hpp fe_mul, 12 x 32-bit limbs):  %8.3f ms  %7.2f G products/s\n", ms2, imad);
     printf("Fp product on v_fma_f64     (8 x 52-bit limbs, result converted back):     %8.3f ms  %7.2f G products/s\n", ms, dfma);
     printf("verdict: %s (go needs >= 15 %% more products/s than the integer path: %.2f)\n", dfma >= 1.15 * imad ? "GO" : "NO-GO", 1.15 * imad);
     return 0;

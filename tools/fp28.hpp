@@ -5,7 +5,7 @@
 //
 // Why a second representation (measured, tools/valu_rate_ubench.hip / tools/carry_ubench.hip, profiles/r04e_*): on gfx950 every
 // VOP3 instruction and every instruction that reads or writes a carry costs a wave ~4.5 SIMD cycles — a v_addc_co_u32 as much
-// as a v_mad_u64_u32 — and only plain VOP2 add / and / shift / mov cost 2.45.  The 12 x 32-bit product (field.cuh) is 300
+// as a v_mad_u64_u32 — and only plain VOP2 add / and / shift / mov cost 2.45.  The 12 x 32-bit product (field.hpp) is 300
 // multiply-adds + 219 carry words + a 36-instruction conditional subtraction: 555 slow instructions.  With 28-bit limbs a
 // column of 28 limb products (< 2^56 each) cannot overflow the 64-bit accumulator: 406 multiply-adds + one v_alignbit per
 // column, no carry word (433 slow instructions), the square 342 instead of 471; additions and subtractions need no carry
@@ -17,13 +17,13 @@
 //                                                        comparisons are limb-wise
 //   N < 2p      limbs < 2^28, v < 2p                     what a product returns
 //   lazy        limbs < 2^31, v < 8p                     sums / differences; fp28_canon brings them back
-// Montgomery residues are x R' mod p.  A 12 x 32-bit residue s = x 2^384 (field.cuh) becomes one by reading it at an
+// Montgomery residues are x R' mod p.  A 12 x 32-bit residue s = x 2^384 (field.hpp) becomes one by reading it at an
 // 8-bit offset: the integer s 2^8 < 2^392 is congruent to x R' (fp28_from_fp_lazy: no arithmetic); the way back costs a product
 // by 2^384 (fp28_to_fp).
 // Replaces nothing the reference has by name: it is the arithmetic under bellperson's multiexp (call
 // sites /root/reference/masp_proofs/src/sapling/prover.rs:117,202,252).
 #pragma once
-#include "../masp_amd/csrc/device/field.cuh"
+#include "../masp_amd/csrc/device/field.hpp"
 
 namespace masp {
 
@@ -289,7 +289,7 @@ MASP_HD F28 fp28_neg(const F28& a) {  // p - a, and 0 for 0
     return r;
 }
 
-// ---- to and from the 12 x 32-bit residues of field.cuh ----------------------------------------------------------------
+// ---- to and from the 12 x 32-bit residues of field.hpp ----------------------------------------------------------------
 // the integer s 2^8 in 28-bit limbs: congruent to x R' when s = x 2^384 — a lazy operand (limbs < 2^28, value < 2^392: a
 // product with anything below 4p comes out below 2p)
 MASP_HD F28 fp28_from_fp_lazy(const Fp& s) {
@@ -329,7 +329,7 @@ MASP_HD Fp fp28_to_fp(const F28& a) {
     return r;
 }
 
-// ---- the ops policy of the tree's passes (device/msm_tree.cuh): elements are F28, what crosses into the rest of the MSM
+// ---- the ops policy of the tree's passes (device/msm_tree.hpp): elements are F28, what crosses into the rest of the MSM
 // (lane totals for the shared inversion, the last level's points) is Fp --------------------------------------------------
 struct Fp28Ops {
     typedef F28 T;

@@ -1,9 +1,9 @@
-// The 28-bit-limb field as built (masp_amd/csrc/device/fp28.cuh) against field.cuh's 12 x 32-bit one: chains of products,
+// The 28-bit-limb field as built (masp_amd/csrc/device/fp28.hpp) against field.hpp's 12 x 32-bit one: chains of products,
 // squares, and the additions pass's arithmetic per pair (3 products + 1 square + differences + two canonicalisations), whole chip.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
-#include "fp28.cuh"
+#include "fp28.hpp"
 using namespace masp;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Emits masp_amd/csrc/device/consts.cuh: 32-bit-limb Montgomery constants for BLS12-381 Fp / Fr.
+"""Emits masp_amd/csrc/device/consts.hpp: 32-bit-limb Montgomery constants for BLS12-381 Fp / Fr.
 
 Montgomery radix is R = 2^(32*N) — N = 12 for Fp (R = 2^384), N = 8 for Fr (R = 2^256) — i.e. the
 same in-memory form as blst's 64-bit-limb `blst_fp` / `blst_fr` on a little-endian host
@@ -135,6 +135,6 @@ namespace masp {
 %s
 }  // namespace masp
 """ % (block("FpCfg", P, 12, fp_extra), block("FrCfg", R, 8, fr_extra))
-path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "masp_amd", "csrc", "device", "consts.cuh")
+path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "masp_amd", "csrc", "device", "consts.hpp")
 open(path, "w").write(text)
 print("wrote", os.path.normpath(path))

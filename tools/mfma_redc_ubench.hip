@@ -12,7 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
-#include "../masp_amd/csrc/device/field.cuh"
+#include "../masp_amd/csrc/device/field.hpp"
 using namespace masp;
 typedef int v4i __attribute__((ext_vector_type(4)));
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
