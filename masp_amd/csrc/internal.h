@@ -140,6 +140,7 @@ struct Slot {
     static constexpr int N_AUX = 4;
     hipStream_t aux[N_AUX] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_sort_b = nullptr, ev_fixed = nullptr, ev_join[N_AUX] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_uploaded = nullptr;   // behind the host-to-device copies of this slot's batch (masp_hip_ctx::upload_tail)
     MsmWorkspace<FpOps> ws_l, ws_a, ws_b;
     DevBuf<Fr> w, inp, abc, wm, ev[3], x0, x1, h, hl, sa, sb;
     DevBuf<G1Xyzz> res1, asm1;  // asm1: the six G1 pieces of the assembly per proof, asm2: s*delta2
@@ -200,6 +201,7 @@ struct Slot {
         for (hipEvent_t e : ev_lone)
             if (e) hipEventDestroy(e);
         if (ev_fork) hipEventDestroy(ev_fork);
+        if (ev_uploaded) hipEventDestroy(ev_uploaded);
         if (ev_sort_b) hipEventDestroy(ev_sort_b);
         if (ev_fixed) hipEventDestroy(ev_fixed);
         if (h_stage) hipHostFree(h_stage);
@@ -221,6 +223,7 @@ struct Slot {
         HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_uploaded, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ev_sort_b, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ev_fixed, hipEventDisableTiming));
         // (the four side streams are created WITH the slot.  Creating them at the slot's first lone proof instead — so that a batch prover
@@ -308,6 +311,11 @@ struct masp_hip_ctx {
     std::atomic<uint64_t> requeued{0};
     // device context: the n-th masp_hip_prove_batch call from now fails before it touches the device (masp_hip_ctx_inject_fault; 0 = disarmed)
     std::atomic<uint32_t> fault_countdown{0};
+    // Host-to-device copies of concurrent masp_hip_prove_batch calls go ONE BATCH AFTER THE OTHER: a batch's copies wait for the event
+    // behind the previous batch's copies (whatever slot that was).  Three calls that start together (the beginning of a job list, of a
+    // timed region) otherwise share the link, and none of them can start computing before all 3 x 820 MB have crossed it.
+    std::mutex upload_mu;
+    hipEvent_t upload_tail = nullptr;   // an event of some slot of this context (slots live as long as the context)
     // the building-block MSM entry points (masp_hip_msm_g1_multi ...) run on a workspace of their own: what lack of tree scratch did there
     std::atomic<uint64_t> block_tree_fallbacks{0};
     std::atomic<uint32_t> block_tree_sub{0xffffffffu};

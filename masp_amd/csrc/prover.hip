@@ -25,6 +25,11 @@
 
 using namespace masp;
 
+// host-to-device copies of concurrent calls one batch after the other (masp_hip_ctx::upload_tail); 0: as they come (A/B builds)
+#ifndef MASP_UPLOAD_CHAIN
+#define MASP_UPLOAD_CHAIN 1
+#endif
+
 namespace {
 
 // options of a context (include/masp_hip.h: masp_hip_options) with every "0 = default" resolved; no environment is read
@@ -1189,7 +1194,13 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
                 memcpy(hs + w_bytes + abc_bytes + 64 * p + 32, J.s, 32);
             }
             hipStream_t s = sl.stream;
-            if (any_staged) {
+#if MASP_UPLOAD_CHAIN
+            // (see masp_hip_ctx::upload_tail; the lock covers wait + enqueue + record so that the chain has one order)
+            std::lock_guard<std::mutex> upload_turn(ctx->upload_mu);
+            if (ctx->upload_tail && ctx->upload_tail != sl.ev_uploaded) ok = hipStreamWaitEvent(s, ctx->upload_tail, 0) == hipSuccess;
+#endif
+            if (!ok) {
+            } else if (any_staged) {
                 ok = hipMemcpyAsync(sl.w.p, hs, w_bytes, hipMemcpyHostToDevice, s) == hipSuccess;
             } else {
                 // only the public inputs of each proof come from staging: ONE packed copy to the device and a strided copy on the
@@ -1204,6 +1215,9 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
                          hipSuccess;
             ok = ok && (!has_abc || hipMemcpyAsync(sl.abc.p, hs + w_bytes, abc_bytes, hipMemcpyHostToDevice, s) == hipSuccess) &&
                  hipMemcpyAsync(sl.rs.p, hs + w_bytes + abc_bytes, rs_bytes, hipMemcpyHostToDevice, s) == hipSuccess;
+#if MASP_UPLOAD_CHAIN
+            if (ok && hipEventRecord(sl.ev_uploaded, s) == hipSuccess) ctx->upload_tail = sl.ev_uploaded;
+#endif
             if (!ok) {
                 last_hip_error() = "H2D copy failed";
                 result = fail_shared(ctx, MASP_HIP_E_HIP);
