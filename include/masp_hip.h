@@ -94,7 +94,9 @@ int masp_hip_device_pci_bus_id(int device, char* out, size_t cap);
  * library reads NO environment variables; bench.py and the tools translate their MASP_HIP_* variables into this. */
 typedef struct {
     uint32_t struct_size;            /* sizeof(masp_hip_options) of the caller's header (versioning) */
-    int32_t slots;                   /* batches in flight per device, each on its own HIP stream + scratch: 1..64 (default 3) */
+    int32_t slots;                   /* batches in flight per device, each on its own HIP streams + scratch: 1..64 (default 4 since round 6: +1.7 % host to
+                                        host over 3 at 16 hardware queues — a batch uploads while three compute; 42 GB of scratch per slot
+                                        for Spend batches; profiles/r06_slots_3_4_5_at_16_hardware_queues.txt) */
     int32_t batch_cap;               /* proofs per launch sequence: 1..256 (default 256 = BASELINE.json configs[3]) */
     int32_t ntt_sub_batch;           /* proofs per sub-batch of the quotient's transforms (default 8: 160 MiB of work buffers
                                         stay in the Infinity Cache); -1 = the whole batch at once */
@@ -184,13 +186,15 @@ int masp_hip_ctx_device_status(const masp_hip_ctx* ctx, int32_t* status, int cap
 /* TEST HOOK (tests/test_gpu_device_failure.py): the `nth` masp_hip_prove_batch call (1 = the next) that device context `device` of a
  * multi-device prover receives fails with MASP_HIP_E_HIP before it touches the device, as a lost GPU would.  nth = 0 disarms. */
 int masp_hip_ctx_inject_fault(masp_hip_ctx* ctx, int device, uint32_t nth);
-/* How many of THIS context's own streams (five per slot + one) run a kernel at the same time, measured now (the context must be idle; its
- * slots are created if they do not exist yet).  *concurrent < *n_streams means two of them share a hardware queue.  The runtime hands
+/* How many of THIS context's own streams (five per slot + one; mains_only: the slots' main streams + one, the streams that carry batches)
+ * run a kernel at the same time, measured now (the context must be idle).  *concurrent < *n_streams means two of them share a hardware queue.  The runtime hands
  * hardware queues to streams in the order the PROCESS creates streams — other contexts', a verifying key's, torch's count — so a later
  * context of a process can end up with two streams of one slot on one queue while another queue idles, and proves 2 - 3 % slower for its
  * whole life (profiles/r06_second_context_root_cause.txt: the "slower second context" of round 4, seen at 4 slots / 24 queues; with the
- * default 3 slots / 16 queues every context's 16 streams cover the 16 queues exactly once, whatever the rotation). */
-int masp_hip_ctx_stream_concurrency(masp_hip_ctx* ctx, int* n_streams, int* concurrent);
+ * default 16 queues a process never holds more; since round 6 a context creates all of its slots' streams when it is created — slot 0's
+ * five, then the other slots' main streams, then their side streams — so that the streams that carry batches get queues of their own
+ * whatever the process created before: first, second and third context prove at the same rate, at 3 and at 4 slots). */
+int masp_hip_ctx_stream_concurrency(masp_hip_ctx* ctx, int mains_only, int* n_streams, int* concurrent);
 /* *out = calls of masp_hip_prove_batch groups so far that were replayed from a captured launch graph
  * (masp_hip_options::lone_proof_graph); a caller that proves one description at a time sees it grow from its third proof on */
 int masp_hip_ctx_lone_graph_launches(const masp_hip_ctx* ctx, uint64_t* out);
@@ -254,8 +258,8 @@ int masp_hip_ntt(masp_hip_ctx* ctx, uint8_t* data, uint32_t logm, int inverse);
  * n x 16 B of caller-supplied randomness z (one random linear combination, as bellman does).  Proof decompression, the
  * z_i-multiples and the n Miller loops (one wavefront per pairing) run on the device; the public-input combination, two
  * pairings and the single final exponentiation on the host.  *all_valid = 1 iff every proof verifies (up to 2^-127);
- * 0 says at least one does not, not which.  Re-entrant: runs on the key's own stream next to proving calls (one verification
- * at a time per key). */
+ * 0 says at least one does not, not which.  Re-entrant: runs next to proving calls on one of the context's two verifier streams (one
+ * verification at a time per key; keys beyond two share a stream).  A key must be freed before its context is destroyed. */
 typedef struct masp_hip_vk masp_hip_vk;
 int masp_hip_vk_prepare(masp_hip_ctx* ctx, const uint8_t* params, size_t params_len, masp_hip_vk** out);
 void masp_hip_vk_free(masp_hip_vk* vk);

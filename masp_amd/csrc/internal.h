@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -139,6 +140,7 @@ struct Slot {
     // with its own workspace, next to the quotient pipeline on the main stream
     static constexpr int N_AUX = 4;
     hipStream_t aux[N_AUX] = {nullptr, nullptr, nullptr, nullptr};
+    bool owns_aux = true;   // false: the side streams are slot 1's (masp_hip_ctx::slot_streams)
     hipEvent_t ev_fork = nullptr, ev_sort_b = nullptr, ev_fixed = nullptr, ev_join[N_AUX] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_uploaded = nullptr;   // behind the host-to-device copies of this slot's batch (masp_hip_ctx::upload_tail)
     MsmWorkspace<FpOps> ws_l, ws_a, ws_b;
@@ -195,7 +197,7 @@ struct Slot {
         if (stream) hipStreamDestroy(stream);
         if (done) hipEventDestroy(done);
         for (int i = 0; i < N_AUX; ++i) {
-            if (aux[i]) hipStreamDestroy(aux[i]);
+            if (aux[i] && owns_aux) hipStreamDestroy(aux[i]);
             if (ev_join[i]) hipEventDestroy(ev_join[i]);
         }
         for (hipEvent_t e : ev_lone)
@@ -219,8 +221,16 @@ struct Slot {
         ws1.tree.own.limit = (size_t)o.bucket_tree_scratch_mb << 20;
         lone_graph = o.lone_proof_graph > 0;
     }
-    int init() {
-        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    // `streams`: this slot's five streams (main, then the four side streams), created by the context when IT was created (see
+    // masp_hip_ctx::slot_streams); nullptr: the slot creates its own
+    int init(const hipStream_t* streams = nullptr, bool side_streams_are_mine = true) {
+        owns_aux = side_streams_are_mine;
+        if (streams) {
+            stream = streams[0];
+            for (int i = 0; i < N_AUX; ++i) aux[i] = streams[1 + i];
+        } else {
+            HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        }
         HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ev_uploaded, hipEventDisableTiming));
@@ -231,7 +241,7 @@ struct Slot {
         // bench.py, equal in the standalone tool; not understood, not kept: profiles/r06_second_context_root_cause.txt.  With the default
         // 3 slots a context's 16 streams cover the default 16 hardware queues exactly once.)
         for (int i = 0; i < N_AUX; ++i) {
-            HIP_TRY(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking));
+            if (!aux[i]) HIP_TRY(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
         }
         HIP_TRY(hipHostMalloc(&h_flags, sizeof(int)));
@@ -314,6 +324,22 @@ struct masp_hip_ctx {
     // Host-to-device copies of concurrent masp_hip_prove_batch calls go ONE BATCH AFTER THE OTHER: a batch's copies wait for the event
     // behind the previous batch's copies (whatever slot that was).  Three calls that start together (the beginning of a job list, of a
     // timed region) otherwise share the link, and none of them can start computing before all 3 x 820 MB have crossed it.
+    // The streams of ALL slots are created with the context, slot by slot (create_single), and the main streams are then MEASURED and, where
+    // two share a hardware queue, replaced (separate_main_streams): the runtime hands hardware queues to streams in creation order, so the main streams — the ones that carry batches — get
+    // queues of their own whatever the process created before (round 6: with 21 streams created slot by slot over 16 queues, a later
+    // context of a process could find two of its main streams on one queue: -3.5 % at 4 slots).  [slot][0] main, [slot][1..4] side streams;
+    // a slot takes its five when it is created and owns them from then on (taken[slot]).
+    // Slots 0 and 1 have side streams of their own; from slot 2 on a slot uses slot 1's (a lone proof takes the first free slot, so three lone
+    // proofs must be in flight at once before two of them share side streams — they then interleave on them, each behind its own events).  A
+    // default context so has 1 + 4 + 8 + 2 = 15 streams: one hardware queue each of the default 16, nothing shares.  (With
+    // masp_hip_options::lone_proof_graph every slot keeps its own: a stream that is being captured cannot take another thread's launches.)
+    std::vector<std::array<hipStream_t, 5>> slot_streams;
+    // ... and two streams for the batch verifier's keys (masp_hip_vk_prepare hands them out in turn; a key does not own its stream): a
+    // verification that shared a hardware queue with a slot's main stream waited behind a 185 ms batch (end to end -10 %)
+    hipStream_t vk_streams[2] = {nullptr, nullptr};
+    std::atomic<unsigned> vk_next{0};
+    int main_streams_concurrent = 0;   // of the 1 + slots streams that carry batches, how many ran at once when the context was created
+    std::vector<char> slot_streams_taken;
     std::mutex upload_mu;
     hipEvent_t upload_tail = nullptr;   // an event of some slot of this context (slots live as long as the context)
     // the building-block MSM entry points (masp_hip_msm_g1_multi ...) run on a workspace of their own: what lack of tree scratch did there

@@ -26,11 +26,9 @@ struct masp_hip_vk {
     DevBuf<G1Xyzz> d_zc;
     DevBuf<int> d_status;
     DevBuf<Fp> d_f;
-    hipStream_t stream = nullptr;  // verification runs on its own stream, next to the provers' batches
+    hipStream_t stream = nullptr;  // verification runs next to the provers' batches, on one of the context's two verifier streams (not owned:
+                                   // masp_hip_ctx::vk_streams — created and kept off the batch streams' hardware queues with the context)
     std::mutex mu;                 // one verification at a time per key
-    ~masp_hip_vk() {
-        if (stream) hipStreamDestroy(stream);
-    }
 };
 
 // (fail() takes slot_mu for the error text: fine under the shared context lock too)
@@ -72,7 +70,7 @@ int masp_hip_vk_prepare(masp_hip_ctx* ctx, const uint8_t* params, size_t params_
     v->n_slots = pp.n_slots;
     v->lds_ok = hipFuncSetAttribute((const void*)k_miller_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess &&
                 hipFuncSetAttribute((const void*)k_fp12_product, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess;
-    if (hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking) != hipSuccess) return fail(ctx, MASP_HIP_E_HIP);
+    v->stream = ctx->vk_streams[ctx->vk_next.fetch_add(1) % 2];
     *out = v.release();
     return MASP_HIP_OK;
 }

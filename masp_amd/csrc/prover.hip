@@ -26,6 +26,9 @@
 using namespace masp;
 
 // host-to-device copies of concurrent calls one batch after the other (masp_hip_ctx::upload_tail); 0: as they come (A/B builds)
+#ifndef MASP_STREAM_ORDER
+#define MASP_STREAM_ORDER 2   // slot by slot (see create_single); separate_main_streams then makes sure the main streams do not share queues
+#endif
 #ifndef MASP_UPLOAD_CHAIN
 #define MASP_UPLOAD_CHAIN 1
 #endif
@@ -41,7 +44,10 @@ static masp_hip_options resolve_options(const masp_hip_options* in) {
     // (round 4: with the passes of the bucket tree no longer waiting on memory, three batches in flight keep the chip as busy as
     // four did — 1 227 vs 1 220 proofs/s — and leave their scratch to larger tree sub-batches: 3 x 86 proofs, 1 251 proofs/s, in the
     // ~100 GB that 4 x 64 took; profiles/r04_same_box_sweep_slots_tree_sub.txt)
-    o.slots = o.slots > 0 ? std::min<int>(o.slots, (int)masp_hip_ctx::MAX_SLOTS) : 3;
+    // (round 6: FOUR — +1.5 ... 1.7 % host to host over three at the default 16 hardware queues: a batch uploads while three compute;
+    // five are not faster, and the measurements of round 5 that made four look no better were taken at 24 queues, in the runtime's
+    // oversubscribed regime: profiles/r06_slots_3_4_5_at_16_hardware_queues.txt)
+    o.slots = o.slots > 0 ? std::min<int>(o.slots, (int)masp_hip_ctx::MAX_SLOTS) : 4;
     // proofs per batched launch sequence (upper bound: a list of n same-circuit jobs is cut into ceil(n / cap) equal groups);
     // scratch memory follows the batches actually formed
     o.batch_cap = o.batch_cap > 0 ? std::min<int>(o.batch_cap, 256) : 256;
@@ -76,12 +82,25 @@ static std::vector<std::pair<size_t, size_t>> even_groups(size_t n, size_t cap) 
     return out;
 }
 
+// slots 0 and 1 — and every slot when lone proofs are replayed from captured graphs — have side streams of their own (masp_hip_ctx::slot_streams)
+static bool slot_owns_side_streams(const masp_hip_ctx* ctx, size_t si) { return si < 2 || ctx->opt.lone_proof_graph > 0; }
+// the five streams the context created for its next slot (slot_mu held), or nullptr if it has none left
+static const hipStream_t* take_slot_streams(masp_hip_ctx* ctx, bool* side_streams_are_its_own) {
+    const size_t i = ctx->slots.size();
+    *side_streams_are_its_own = true;
+    if (i >= ctx->slot_streams.size() || ctx->slot_streams_taken[i]) return nullptr;
+    ctx->slot_streams_taken[i] = 1;
+    *side_streams_are_its_own = slot_owns_side_streams(ctx, i);
+    return ctx->slot_streams[i].data();
+}
 static int ensure_slots(masp_hip_ctx* ctx, size_t want) {
     std::lock_guard<std::mutex> g(ctx->slot_mu);
     want = std::min(want, masp_hip_ctx::MAX_SLOTS);
     while (ctx->slots.size() < want) {
         std::unique_ptr<Slot> s(new Slot);
-        int rc = s->init();
+        bool own = true;
+        const hipStream_t* st = take_slot_streams(ctx, &own);
+        int rc = s->init(st, own);
         if (rc) return rc;
         s->configure(ctx->opt);
         ctx->slots.push_back(std::move(s));
@@ -104,7 +123,9 @@ static int slot_try_acquire(masp_hip_ctx* ctx, size_t* si) {
         }
     if (ctx->slots.size() >= (size_t)ctx->n_slots) return -1;
     std::unique_ptr<Slot> s(new Slot);
-    int rc = s->init();
+    bool own = true;
+    const hipStream_t* st = take_slot_streams(ctx, &own);
+    int rc = s->init(st, own);
     if (rc) return rc;
     s->profiling = ctx->profiling;
     s->configure(ctx->opt);
@@ -579,13 +600,20 @@ static int measure_hw_queues(int device, int streams) {
 
 // The same measurement on a context's OWN streams (every slot's five + the main stream): how many of them run a kernel at the same time.
 // Fewer than there are streams = two of them share a hardware queue, and kernels of one batch that could overlap wait for each other.
-static int measure_own_streams(masp_hip_ctx* ctx, int* n_streams, int* concurrent) {
+static int measure_streams(const std::vector<hipStream_t>& ss, int* n_streams, int* concurrent, std::vector<unsigned long long>* intervals = nullptr);
+// mains_only: the context's own stream, the slots' main streams (the ones that carry batches) and the verifier's two
+static int measure_own_streams(masp_hip_ctx* ctx, bool mains_only, int* n_streams, int* concurrent) {
     std::vector<hipStream_t> ss;
     ss.push_back(ctx->main_stream);
-    for (auto& sl : ctx->slots) {
-        ss.push_back(sl->stream);
-        for (int i = 0; i < Slot::N_AUX; ++i) ss.push_back(sl->aux[i]);
+    for (size_t i = 0; i < ctx->slot_streams.size(); ++i) {
+        ss.push_back(ctx->slot_streams[i][0]);
+        if (!mains_only && slot_owns_side_streams(ctx, i))
+            for (int j = 1; j < 5; ++j) ss.push_back(ctx->slot_streams[i][j]);
     }
+    for (hipStream_t v : ctx->vk_streams) ss.push_back(v);
+    return measure_streams(ss, n_streams, concurrent);
+}
+static int measure_streams(const std::vector<hipStream_t>& ss, int* n_streams, int* concurrent, std::vector<unsigned long long>* intervals) {
     const int n = (int)ss.size();
     unsigned long long* d = nullptr;
     HIP_TRY(dev_malloc(&d, 16 * n));
@@ -609,7 +637,54 @@ static int measure_own_streams(masp_hip_ctx* ctx, int* n_streams, int* concurren
     }
     *n_streams = n;
     *concurrent = best;
+    if (intervals) *intervals = h;
     return MASP_HIP_OK;
+}
+
+// The streams that carry batches — the context's own and every slot's main stream — must each sit on a hardware queue of its own: two
+// of them on one queue run their batches one after the other (a later context of a process at 4 slots: -6 %, profiles/
+// r06_second_context_root_cause.txt).  Which queue the runtime gives a new stream depends on everything the process has created before and
+// cannot be asked, so it is MEASURED: a 2 ms single-wave kernel on each of them at once; a stream that starts a millisecond late shares its
+// queue with the one that ended when it started.  Such a stream is replaced — the new one is created BEFORE the old one is destroyed, so
+// that it cannot get the same queue back — and the measurement repeated, a few times at most.  Nothing has been launched on these streams
+// yet.  Slot 0's main stream is never the one replaced (a lone proof runs 0.4 ms longer when its main stream was not created right in
+// front of its side streams: profiles/r06_slot_streams_creation_order.txt).
+static int separate_main_streams(masp_hip_ctx* ctx) {
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        std::vector<hipStream_t*> at;
+        at.push_back(&ctx->main_stream);
+        for (auto& a : ctx->slot_streams) at.push_back(&a[0]);
+        for (hipStream_t& v : ctx->vk_streams) at.push_back(&v);   // (the verifier's streams work next to the batches: the same rule)
+        std::vector<hipStream_t> ss;
+        for (hipStream_t* p : at) ss.push_back(*p);
+        int n = 0, conc = 0;
+        std::vector<unsigned long long> h;
+        if (int rc = measure_streams(ss, &n, &conc, &h)) return rc;
+        ctx->main_streams_concurrent = conc;
+        if (conc >= n) return MASP_HIP_OK;
+        unsigned long long t0 = ~0ull;
+        for (int i = 0; i < n; ++i) t0 = std::min(t0, h[2 * i]);
+        bool replaced = false;
+        for (int i = 0; i < n; ++i) {
+            if (h[2 * i] - t0 < 100000ull) continue;          // started with the others (100 MHz clock: 1 ms)
+            int partner = -1;                                  // the stream whose kernel ended when this one's began
+            unsigned long long bestd = ~0ull;
+            for (int j = 0; j < n; ++j) {
+                if (j == i) continue;
+                const unsigned long long d = h[2 * j + 1] > h[2 * i] ? h[2 * j + 1] - h[2 * i] : h[2 * i] - h[2 * j + 1];
+                if (d < bestd) bestd = d, partner = j;
+            }
+            const int victim = i == 1 && partner >= 0 ? partner : i;   // (index 1 = slot 0's main stream)
+            if (victim == 1) continue;
+            hipStream_t fresh = nullptr;
+            if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) return MASP_HIP_E_HIP;
+            (void)hipStreamDestroy(*at[victim]);
+            *at[victim] = fresh;
+            replaced = true;
+        }
+        if (!replaced) return MASP_HIP_OK;
+    }
+    return MASP_HIP_OK;   // (still shared after eight rounds: a process with fewer queues than main streams — reported, not an error)
 }
 
 static int create_single(int device, const masp_hip_options& opt, masp_hip_ctx** out) {
@@ -626,6 +701,49 @@ static int create_single(int device, const masp_hip_options& opt, masp_hip_ctx**
     ctx->slot_busy.reserve(masp_hip_ctx::MAX_SLOTS);
     ctx->opt.hw_queues = measure_hw_queues(device, 5 * opt.slots);   // (a slot owns up to five streams)
     if (hipStreamCreateWithFlags(&ctx->main_stream, hipStreamNonBlocking) != hipSuccess) return MASP_HIP_E_NO_DEVICE;
+    // every slot's streams now, main streams first (masp_hip_ctx::slot_streams)
+    ctx->slot_streams.assign((size_t)opt.slots, std::array<hipStream_t, 5>{});
+    ctx->slot_streams_taken.assign((size_t)opt.slots, 0);
+    bool streams_ok = true;
+    // order: slot by slot, a slot's main stream right in front of its side streams (a lone proof takes the first free slot, i.e. slot 0, and
+    // runs 0.3 - 0.4 ms longer when its side streams were not created right behind its main stream — measured three ways, not understood:
+    // profiles/r06_slot_streams_creation_order.txt); that the main streams then do not share hardware queues is measured and repaired:
+    // separate_main_streams
+    auto make = [&](int si, int j) {
+        if (j > 0 && !slot_owns_side_streams(ctx.get(), (size_t)si))
+            ctx->slot_streams[si][j] = ctx->slot_streams[1][j];   // (slot 1's: created before, in every order below)
+        else
+            streams_ok = streams_ok && hipStreamCreateWithFlags(&ctx->slot_streams[si][j], hipStreamNonBlocking) == hipSuccess;
+    };
+#if MASP_STREAM_ORDER == 1      // (A/B builds) every main stream first
+    for (int si = 0; si < opt.slots; ++si) make(si, 0);
+    for (int si = 0; si < opt.slots; ++si)
+        for (int j = 1; j < 5; ++j) make(si, j);
+#elif MASP_STREAM_ORDER == 2    // (A/B builds) slot by slot, as the slots created them before round 6
+    for (int si = 0; si < opt.slots; ++si)
+        for (int j = 0; j < 5; ++j) make(si, j);
+#elif MASP_STREAM_ORDER == 3    // slot 0's side streams, then every main stream (slot 0's first), then the other side streams
+    for (int j = 1; j < 5; ++j) make(0, j);
+    for (int si = 0; si < opt.slots; ++si) make(si, 0);
+    for (int si = 1; si < opt.slots; ++si)
+        for (int j = 1; j < 5; ++j) make(si, j);
+#else                           // slot 0's five, the other slots' main streams, their side streams
+    for (int j = 0; j < 5; ++j) make(0, j);
+    for (int si = 1; si < opt.slots; ++si) make(si, 0);
+    for (int si = 1; si < opt.slots; ++si)
+        for (int j = 1; j < 5; ++j) make(si, j);
+#endif
+    for (hipStream_t& v : ctx->vk_streams) streams_ok = streams_ok && hipStreamCreateWithFlags(&v, hipStreamNonBlocking) == hipSuccess;
+    if (streams_ok && separate_main_streams(ctx.get()) != MASP_HIP_OK) streams_ok = false;
+    if (!streams_ok) {
+        for (size_t si = 0; si < ctx->slot_streams.size(); ++si)
+            for (int j = 0; j < 5; ++j)
+                if (ctx->slot_streams[si][j] && (j == 0 || slot_owns_side_streams(ctx.get(), si))) hipStreamDestroy(ctx->slot_streams[si][j]);
+        for (hipStream_t v : ctx->vk_streams)
+            if (v) hipStreamDestroy(v);
+        hipStreamDestroy(ctx->main_stream);
+        return MASP_HIP_E_NO_DEVICE;
+    }
     *out = ctx.release();
     return MASP_HIP_OK;
 }
@@ -744,14 +862,13 @@ int masp_hip_ctx_inject_fault(masp_hip_ctx* ctx, int device, uint32_t nth) {
     ctx->children[device]->fault_countdown = nth;
     return MASP_HIP_OK;
 }
-int masp_hip_ctx_stream_concurrency(masp_hip_ctx* ctx, int* n_streams, int* concurrent) {
+int masp_hip_ctx_stream_concurrency(masp_hip_ctx* ctx, int mains_only, int* n_streams, int* concurrent) {
     if (!ctx || !n_streams || !concurrent) return MASP_HIP_E_INVALID_ARG;
     if (!ctx->children.empty()) ctx = ctx->children[0];
     std::unique_lock<std::shared_mutex> lock(ctx->mu);
     hipSetDevice(ctx->device);
-    if (int rc = ensure_slots(ctx, (size_t)ctx->n_slots)) return fail(ctx, rc);
     if (hipDeviceSynchronize() != hipSuccess) return fail(ctx, MASP_HIP_E_HIP);
-    return fail(ctx, measure_own_streams(ctx, n_streams, concurrent));
+    return fail(ctx, measure_own_streams(ctx, mains_only != 0, n_streams, concurrent));
 }
 int masp_hip_ctx_lone_graph_launches(const masp_hip_ctx* ctx, uint64_t* out) {
     if (!ctx || !out) return MASP_HIP_E_INVALID_ARG;
@@ -783,6 +900,12 @@ void masp_hip_ctx_destroy(masp_hip_ctx* ctx) {
     ctx->slots.clear();
     for (auto& c : ctx->circ) c.reset();
     ctx->domains.clear();
+    for (size_t i = 0; i < ctx->slot_streams.size(); ++i)    // (streams of slots that were never created)
+        if (!ctx->slot_streams_taken[i])
+            for (int j = 0; j < 5; ++j)
+                if (ctx->slot_streams[i][j] && (j == 0 || slot_owns_side_streams(ctx, i))) hipStreamDestroy(ctx->slot_streams[i][j]);
+    for (hipStream_t v : ctx->vk_streams)
+        if (v) hipStreamDestroy(v);
     if (ctx->main_stream) hipStreamDestroy(ctx->main_stream);
     delete ctx;
     dev_free_drain();  // the context's buffers

@@ -61,7 +61,7 @@ def load_library():
         raise ImportError("libmasp_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "or `make -C masp_amd/csrc` (hipcc, --offload-arch=gfx950)")
     # batches in flight on different HIP streams only overlap if the runtime gives them their own hardware queues
-    # (ROCm's default is 4); read once, when the HIP runtime initialises.  16: three slots have 15 streams between them; with 8
+    # (ROCm's default is 4); read once, when the HIP runtime initialises.  16: the slots' main streams and the context's own need a queue each; with 8
     # queues about one bench process in four landed in a mode 3 % slower (streams of two slots sharing a queue), with 16 none of
     # twelve did (profiles/r04e_hw_queues_and_the_two_modes.txt)
     # (the library's constructor does the same for a process that links it directly — masp_hip_runtime_prepare, include/masp_hip.h —;
@@ -89,7 +89,7 @@ def load_library():
     L.masp_hip_ctx_device_count.argtypes = [vp]
     L.masp_hip_ctx_device_proofs.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     if hasattr(L, "masp_hip_ctx_stream_concurrency"):
-        L.masp_hip_ctx_stream_concurrency.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.masp_hip_ctx_stream_concurrency.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     if hasattr(L, "masp_hip_ctx_device_status"):            # (round 6; an older build passed as MASP_HIP_LIBRARY lacks them)
         L.masp_hip_ctx_device_status.argtypes = [vp, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_uint64)]
         L.masp_hip_ctx_inject_fault.argtypes = [vp, C.c_int, C.c_uint32]
@@ -388,10 +388,11 @@ class Context:
         self._check(self._L.masp_hip_ctx_device_proofs(self._h, counts, n))
         return list(counts)
 
-    def stream_concurrency(self):
-        """masp_hip_ctx_stream_concurrency -> (streams of this context, how many of them ran a kernel at the same time)"""
+    def stream_concurrency(self, mains_only=False):
+        """masp_hip_ctx_stream_concurrency -> (streams of this context — or only the ones that carry batches —, how many of them ran a kernel at
+        the same time)"""
         n, c = C.c_int(0), C.c_int(0)
-        self._check(self._L.masp_hip_ctx_stream_concurrency(self._h, C.byref(n), C.byref(c)))
+        self._check(self._L.masp_hip_ctx_stream_concurrency(self._h, 1 if mains_only else 0, C.byref(n), C.byref(c)))
         return int(n.value), int(c.value)
 
     def device_status(self):

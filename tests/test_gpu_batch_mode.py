@@ -31,7 +31,7 @@ class Rig:
         from masp_amd import host as H
         from masp_amd.synthetic import toxic_waste
         self.ctx = masp_amd.Context(device, batch_cap=cap)
-        assert self.ctx.options["batch_cap"] == cap and self.ctx.options["slots"] == 3
+        assert self.ctx.options["batch_cap"] == cap and self.ctx.options["slots"] == 4
         self.cs = {k: H.circuit(k)[0] for k in kinds}
         self.toxic = {k: toxic_waste(40 + KINDS.index(k)) for k in kinds}
         self.params = {}

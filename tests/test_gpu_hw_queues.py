@@ -81,6 +81,7 @@ def test_a_contexts_own_streams_each_get_a_hardware_queue():
     ctx = masp_amd.Context(0, slots=2)
     try:
         n, c = ctx.stream_concurrency()
-        assert n == 11 and c >= 10, (n, c)
+        assert n == 13 and c >= 12, (n, c)
+        assert ctx.stream_concurrency(mains_only=True) == (5, 5)          # the streams that work next to each other (context, slots, verifier): a queue each
     finally:
         ctx.close()

@@ -133,7 +133,7 @@ def run(tag):
     print("    slots %d: isolated G1 stage %.2f ms per MSM; resident %.1f proofs/s" % (S, ms / max(launches, 1), 6 * nn / (time.perf_counter() - t0)), flush=True)
     ctx.batch_free(h)
     if hasattr(prover._ctx._L, "masp_hip_ctx_stream_concurrency"):
-        print("    own streams running at the same time: %d of %d   (hardware queues of the process: %s)" % (prover._ctx.stream_concurrency()[::-1] + (os.environ.get("GPU_MAX_HW_QUEUES"),)), flush=True)
+        print("    own streams running at the same time: %d of %d; main streams: %d of %d   (hardware queues of the process: %s)" % (prover._ctx.stream_concurrency()[::-1] + prover._ctx.stream_concurrency(True)[::-1] + (os.environ.get("GPU_MAX_HW_QUEUES"),)), flush=True)
     return prover
 
 
