@@ -186,14 +186,13 @@ int masp_hip_ctx_device_status(const masp_hip_ctx* ctx, int32_t* status, int cap
 /* TEST HOOK (tests/test_gpu_device_failure.py): the `nth` masp_hip_prove_batch call (1 = the next) that device context `device` of a
  * multi-device prover receives fails with MASP_HIP_E_HIP before it touches the device, as a lost GPU would.  nth = 0 disarms. */
 int masp_hip_ctx_inject_fault(masp_hip_ctx* ctx, int device, uint32_t nth);
-/* How many of THIS context's own streams (five per slot + one; mains_only: the slots' main streams + one, the streams that carry batches)
- * run a kernel at the same time, measured now (the context must be idle).  *concurrent < *n_streams means two of them share a hardware queue.  The runtime hands
- * hardware queues to streams in the order the PROCESS creates streams — other contexts', a verifying key's, torch's count — so a later
- * context of a process can end up with two streams of one slot on one queue while another queue idles, and proves 2 - 3 % slower for its
- * whole life (profiles/r06_second_context_root_cause.txt: the "slower second context" of round 4, seen at 4 slots / 24 queues; with the
- * default 16 queues a process never holds more; since round 6 a context creates all of its slots' streams when it is created — slot 0's
- * five, then the other slots' main streams, then their side streams — so that the streams that carry batches get queues of their own
- * whatever the process created before: first, second and third context prove at the same rate, at 3 and at 4 slots). */
+/* How many of THIS context's own streams (mains_only: only the ones that work side by side — the context's, the slots' main streams, the
+ * verifier's two) run a kernel at the same time, measured now (the context must be idle).  *concurrent < *n_streams means two of them
+ * share a hardware queue and run their work one after the other.  Which queue the runtime gives a stream depends on everything the PROCESS
+ * created before, so a context creates all of its streams when it is created — 15 with the default four slots (slots 2 and up use slot 1's
+ * side streams), one queue each of the default 16 —, measures the ones that work side by side and replaces any that share a queue:
+ * a first, second and third context of a process prove at the same rate (profiles/r06_slot_streams_creation_order.txt,
+ * profiles/r06_second_context_root_cause.txt). */
 int masp_hip_ctx_stream_concurrency(masp_hip_ctx* ctx, int mains_only, int* n_streams, int* concurrent);
 /* *out = calls of masp_hip_prove_batch groups so far that were replayed from a captured launch graph
  * (masp_hip_options::lone_proof_graph); a caller that proves one description at a time sees it grow from its third proof on */

@@ -58,3 +58,35 @@ def test_warm_up_sizes_pool_and_slots_then_the_first_call_is_like_any_other():
     opt = warm._ctx.current_options()
     assert opt["bucket_tree_fallback_proofs"] == 0 and opt["hw_queues"] >= 15
     warm.close()
+
+
+def test_six_lone_proofs_at_once_share_side_streams_and_keep_their_bytes():
+    """Round 6: slots 0 and 1 have side streams of their own, slots 2 and 3 use slot 1's (a default context so has 15 streams, one hardware
+    queue each).  Six host threads prove lone Output proofs of the real circuit at the same time — four in flight, two of them interleaving
+    with slot 1 on one set of side streams, each behind its own events —: every proof is the closed form's."""
+    from concurrent.futures import ThreadPoolExecutor
+    import masp_amd
+    from masp_amd import host as H, synthetic, workload as W
+    ctx = masp_amd.Context(0)
+    try:
+        assert ctx.options["slots"] == 4 and ctx.stream_concurrency()[0] == 15
+        cs = H.circuit("output")[0]
+        tw = synthetic.toxic_waste(3)
+        ctx.load_circuit(1, ctx.generate_parameters(cs, tw), cs)
+        insts = W.instances("output", 6, first_seed=21)
+
+        def caller(t):
+            inputs, aux = insts[t]
+            return [ctx.prove(1, inputs, aux, 1000 * t + k + 1, 7 + 1000 * t + k) for k in range(12)]
+        with ThreadPoolExecutor(6) as ex:
+            got = list(ex.map(caller, range(6)))
+        for t in range(6):
+            inputs, aux = insts[t]
+            for k in (0, 5, 11):
+                assert got[t][k] == O.closed_form_proof(cs, tw, inputs, aux, 1000 * t + k + 1, 7 + 1000 * t + k), (t, k)
+            assert len(set(got[t])) == 12
+        vk = ctx.prepare_verifying_key(ctx.generate_parameters(cs, tw))
+        assert vk.verify_batch([p for t in range(6) for p in got[t]], [W.public_inputs(insts[t][0]) for t in range(6) for _ in range(12)])
+        vk.close()
+    finally:
+        ctx.close()
