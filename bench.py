@@ -24,6 +24,7 @@ Ranks shard the proofs with no data-path collective (weak scaling).  Prints ONE 
 """
 import argparse
 import json
+import math
 import os
 import random
 import socket
@@ -69,8 +70,11 @@ class ClockWatch:
         # a box shows all eight cards and another tenant's may be busy at the same time (round 6: a line averaged two cards' clocks)
         mine = None
         if device is not None:
-            from masp_amd.hip import device_pci_bus_id
-            mine = device_pci_bus_id(device)
+            try:
+                from masp_amd.hip import device_pci_bus_id
+                mine = device_pci_bus_id(device)
+            except Exception:                        # (a watch that cannot find its card watches them all; it never stops the bench)
+                mine = None
         for f in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input")):
             pw = os.path.join(os.path.dirname(f), "power1_input")
             if os.path.exists(pw):
@@ -373,9 +377,13 @@ def main():
 
     rs_warm, rs_a, rs_b = fresh_rs(max(Wm, 1)), fresh_rs(K), fresh_rs(K)
     handle, _ = ctx.batch_upload(jobs_with(rs_a[0]))
-    # set-up, not warm-up: every slot's workspace (hipMalloc on first use) gets its final size — enough steps to reach every slot
+    # set-up, not warm-up: every slot's workspace (hipMalloc on first use) gets its final size.  The library deals a call's groups
+    # (<= batch_cap proofs of one circuit) to the slots round robin, starting at slot 0 in every call: group g of step s goes to slot
+    # (s x groups_per_step + g) mod SLOTS, a pattern that repeats after SLOTS / gcd steps — so that many steps show every slot every
+    # circuit it will ever get (three circuits on four slots: 4 steps, not 2 — with 2, two slots met their first Spend batch, and the
+    # 40 GB hipMalloc that goes with it, inside the timed region: `resident` of the mixed workload read 1 522 instead of ~ 2 000)
     groups_per_step = sum(-(-job_kind.count(k) // BATCH) for k in kinds)
-    sizing_steps = max(2, -(-SLOTS // groups_per_step))
+    sizing_steps = max(2, SLOTS // math.gcd(groups_per_step, SLOTS))
     ctx.batch_prove_resident_steps(handle, n, sizing_steps, fresh_rs(sizing_steps))
     if Wm > 0:
         ctx.batch_prove_resident_steps(handle, n, Wm, rs_warm)
