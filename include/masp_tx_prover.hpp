@@ -1,0 +1,721 @@
+// masp_tx_prover.hpp — the host side of the drop-in in C++17, above the two C ABIs (masp_hip.h: the Groth16 prover on the GPU;
+// masp_host.h: witness synthesis, native primitives, host verification).  Header-only; link -lmasp_hip -lmasp_host.
+//
+// Mirrors, name for name, what a user of the reference holds (citations relative to /root/reference):
+//   masp::LocalTxProver            = masp_proofs::prover::LocalTxProver               masp_proofs/src/prover.rs:27-33,55-95,156-261
+//     ::from_bytes / ::from_paths  = LocalTxProver::from_bytes / ::new                prover.rs:81-95 / :55-64
+//     ::new_sapling_proving_context, ::spend_proof, ::output_proof, ::convert_proof
+//                                  = trait TxProver                                   masp_primitives/src/sapling/prover.rs:17-83
+//   masp::SaplingProvingContext    = masp_proofs::sapling::SaplingProvingContext (bsk, cv_sum)   masp_proofs/src/sapling/prover.rs:26-47
+// with the argument order and the error behaviour of the reference:
+//   Result<_, ()>  ->  std::optional<_>: empty iff the diversifier is invalid (sapling/prover.rs:84) or the proof fails its
+//                      self-verification (:148, :266); the context then holds the new bsk and the old cv_sum, as in the reference (:69-75 vs :154)
+//   panic          ->  masp::Panic (a std::runtime_error): parameters that do not load (lib.rs:290-293,337,359-362), proving that fails
+//                      ("proving should not fail", sapling/prover.rs:117,202,252), output_proof on a statement that cannot be synthesised
+// and one extension the reference does not have: spend_proofs / output_proofs / convert_proofs take the
+// descriptions of a whole transaction (the serial loops of SaplingBuilder::build, masp_primitives/src/transaction/components/sapling/
+// builder.rs:955-969,1007-1016) and prove them in batches of masp_hip_options::batch_cap — witnesses synthesised on host threads while
+// earlier batches prove, the Spend / Convert self-checks as one GPU batch verification per batch — with the context accumulated in
+// description order, so that the proofs, cv, rk, bsk and cv_sum are those of the serial loop.
+// binding_sig (sapling/prover.rs:279-326) is RedJubjub over the context's bsk / cv_sum and does not touch the prover (SURVEY.md §8b
+// "Not touched by the build"): SaplingProvingContext exposes both, the caller's RedJubjub signs (this repository's: masp_amd/redjubjub.py).
+// The parameter digests (lib.rs:351-388) stay with the caller as SURVEY.md §8b has it ("No hashing here").
+//
+// Thread-safe like the reference's `&self` methods: one LocalTxProver may be shared by several threads, each with its own context.
+#ifndef MASP_TX_PROVER_HPP
+#define MASP_TX_PROVER_HPP
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <fstream>
+#include <future>
+#include <memory>
+#include <mutex>
+#include <optional>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#ifdef __linux__
+#include <sched.h>
+#include <sys/random.h>
+#include <sys/types.h>
+#endif
+
+#include "masp_hip.h"
+#include "masp_host.h"
+
+namespace masp {
+
+constexpr size_t GROTH_PROOF_SIZE = 192;  // masp_primitives/src/transaction/components.rs:15
+using Bytes32 = std::array<uint8_t, 32>;
+using GrothProofBytes = std::array<uint8_t, GROTH_PROOF_SIZE>;
+
+struct Panic : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+// ---- the argument types of the trait, as the bytes the reference's types serialise to ----
+struct ProofGenerationKey {  // masp_primitives/src/sapling.rs: ak (a Jubjub point), nsk (jubjub::Fr)
+    Bytes32 ak, nsk;
+};
+struct Diversifier {
+    std::array<uint8_t, 11> bytes;
+};
+struct PaymentAddress {
+    Diversifier diversifier;
+    Bytes32 pk_d;
+};
+struct AssetType {
+    Bytes32 identifier;
+    static std::optional<AssetType> from_name(const std::string& name) {  // AssetType::new (asset_type.rs)
+        AssetType a;
+        if (masp_host_asset_identifier(reinterpret_cast<const uint8_t*>(name.data()), name.size(), a.identifier.data()) != MASP_HOST_OK) return std::nullopt;
+        return a;
+    }
+};
+struct MerklePath {                        // MerklePath<Node>: the authentication path, leaf level first, and the leaf's position
+    std::array<Bytes32, 32> auth_path;
+    uint64_t position;
+};
+struct AllowedConversion {                 // masp_primitives/src/convert.rs:22-29: the circuit sees its asset generator only
+    Bytes32 generator;
+    // AllowedConversion::from(I128Sum) (convert.rs:86-118): (asset, signed 128-bit amount as 16 little-endian two's-complement bytes)
+    static std::optional<AllowedConversion> from(const std::vector<std::pair<AssetType, std::array<uint8_t, 16>>>& assets) {
+        std::vector<uint8_t> ids(32 * assets.size()), vals(16 * assets.size());
+        for (size_t i = 0; i < assets.size(); ++i) {
+            std::memcpy(&ids[32 * i], assets[i].first.identifier.data(), 32);
+            std::memcpy(&vals[16 * i], assets[i].second.data(), 16);
+        }
+        AllowedConversion c;
+        if (masp_host_allowed_conversion(assets.size(), ids.data(), vals.data(), c.generator.data()) != MASP_HOST_OK) return std::nullopt;
+        return c;
+    }
+};
+
+namespace detail {
+// little-endian 256-bit helpers for the two scalar fields that cross this interface
+struct U256 {
+    uint64_t w[4];
+};
+inline U256 load(const uint8_t* b) {
+    U256 x;
+    for (int i = 0; i < 4; ++i) {
+        x.w[i] = 0;
+        for (int j = 7; j >= 0; --j) x.w[i] = (x.w[i] << 8) | b[8 * i + j];
+    }
+    return x;
+}
+inline void store(const U256& x, uint8_t* b) {
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 8; ++j) b[8 * i + j] = (uint8_t)(x.w[i] >> (8 * j));
+}
+inline bool geq(const U256& a, const U256& b) {
+    for (int i = 3; i >= 0; --i)
+        if (a.w[i] != b.w[i]) return a.w[i] > b.w[i];
+    return true;
+}
+inline uint64_t add_in_place(U256& a, const U256& b) {
+    uint64_t carry = 0;
+    for (int i = 0; i < 4; ++i) {
+        const uint64_t t = a.w[i] + carry;
+        carry = t < carry;
+        a.w[i] = t + b.w[i];
+        carry += a.w[i] < t;
+    }
+    return carry;
+}
+inline void sub_in_place(U256& a, const U256& b) {
+    uint64_t borrow = 0;
+    for (int i = 0; i < 4; ++i) {
+        const uint64_t t = a.w[i] - borrow;
+        borrow = a.w[i] < borrow;
+        a.w[i] = t - b.w[i];
+        borrow += t < b.w[i];
+    }
+}
+// the order of the Jubjub prime-order subgroup (jubjub::Fr) and the BLS12-381 scalar field (bls12_381::Scalar)
+constexpr U256 JUBJUB_ORDER = {{0xd0970e5ed6f72cb7ULL, 0xa6682093ccc81082ULL, 0x06673b0101343b00ULL, 0x0e7db4ea6533afa9ULL}};
+constexpr U256 FR_MODULUS = {{0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL}};
+// (a +/- b) mod the Jubjub order, both canonical
+inline Bytes32 fs_add(const Bytes32& a, const Bytes32& b, bool subtract) {
+    U256 x = load(a.data()), y = load(b.data());
+    if (subtract) {
+        if (!geq(x, y)) add_in_place(x, JUBJUB_ORDER);  // (< 2^253: no carry out)
+        sub_in_place(x, y);
+    } else {
+        add_in_place(x, y);
+        if (geq(x, JUBJUB_ORDER)) sub_in_place(x, JUBJUB_ORDER);
+    }
+    Bytes32 r;
+    store(x, r.data());
+    return r;
+}
+inline bool fs_canonical(const Bytes32& a) { return !geq(load(a.data()), JUBJUB_ORDER); }
+inline bool fr_canonical(const uint8_t* a) { return !geq(load(a), FR_MODULUS); }
+// bellman multipack::compute_multipacking(bytes_to_bits_le(data)) for 32 bytes: two scalars of 254 and 2 bits (sapling/prover.rs:138-139)
+inline void multipack32(const uint8_t data[32], uint8_t out[64]) {
+    std::memcpy(out, data, 32);
+    out[31] &= 0x3f;                    // bits 0..253
+    std::memset(out + 32, 0, 32);
+    out[32] = (uint8_t)(data[31] >> 6);  // bits 254, 255
+}
+// host threads worth starting: what the scheduler lets this process run on, capped by a cgroup CPU quota when one is set (a container
+// that sees 256 logical CPUs may be entitled to 16 of them; oversubscribing it only adds contention)
+inline unsigned effective_cpus() {
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+#ifdef __linux__
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) n = (unsigned)CPU_COUNT(&set);
+#endif
+    std::ifstream f("/sys/fs/cgroup/cpu.max");
+    std::string quota;
+    unsigned long long period = 0;
+    if (f >> quota >> period && quota != "max" && period > 0) {
+        const unsigned long long q = std::strtoull(quota.c_str(), nullptr, 10) / period;
+        n = (unsigned)std::min<unsigned long long>(n, std::max<unsigned long long>(1, q));
+    } else {
+        std::ifstream fq("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), fp("/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+        long long q = 0, p = 0;
+        if (fq >> q && fp >> p && q > 0 && p > 0) n = (unsigned)std::min<long long>(n, std::max<long long>(1, q / p));
+    }
+    return n;
+}
+// `n` permits handed out in ticket order: the batches of a transaction enter the context's slots in the order they were synthesised
+// (their results are committed in that order: a later batch that overtook an earlier one for a slot would finish first and then wait,
+// holding its buffers, while the pipeline behind it stands still)
+class FifoPermits {
+  public:
+    explicit FifoPermits(size_t n = 1) : free_(n) {}
+    void resize(size_t n) { free_ = n; }
+    size_t ticket() {
+        std::lock_guard<std::mutex> g(mu_);
+        return issued_++;
+    }
+    void acquire(size_t ticket) {
+        std::unique_lock<std::mutex> l(mu_);
+        cv_.wait(l, [&] { return serving_ == ticket && free_ > 0; });
+        --free_;
+        ++serving_;
+        cv_.notify_all();
+    }
+    void release() {
+        std::lock_guard<std::mutex> g(mu_);
+        ++free_;
+        cv_.notify_all();
+    }
+
+  private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    size_t free_, issued_ = 0, serving_ = 0;
+};
+// bytes from the operating system's generator: getrandom(2) where there is one (one system call per request), std::random_device otherwise
+inline void os_random(uint8_t* out, size_t n) {
+#ifdef __linux__
+    size_t got = 0;
+    while (got < n) {
+        const ssize_t k = getrandom(out + got, n - got, 0);
+        if (k <= 0) break;
+        got += (size_t)k;
+    }
+    if (got == n) return;
+#endif
+    static thread_local std::random_device rd;
+    for (size_t i = 0; i < n; i += 4) {
+        const uint32_t w = rd();
+        std::memcpy(out + i, &w, std::min<size_t>(4, n - i));
+    }
+}
+inline std::string hip_error(masp_hip_ctx* ctx, int rc, const char* what) {
+    std::string s = std::string(what) + ": " + masp_hip_strerror(rc);
+    const char* more = ctx ? masp_hip_last_error(ctx) : nullptr;
+    if (more && *more) s += std::string(" (") + more + ")";
+    return s;
+}
+}  // namespace detail
+
+// bsk / cv_sum of one transaction (sapling/prover.rs:26-47).  Independent of the proof bytes: the proofs of a transaction may be
+// produced in any order or in one batch as long as the accumulations happen.
+class SaplingProvingContext {
+  public:
+    SaplingProvingContext() {
+        bsk_.fill(0);        // jubjub::Fr::zero()
+        cv_sum_.fill(0);     // jubjub::ExtendedPoint::identity(): (u, v) = (0, 1)
+        cv_sum_[0] = 1;
+    }
+    const Bytes32& bsk() const { return bsk_; }        // for binding_sig: PrivateKey(bsk)
+    const Bytes32& cv_sum() const { return cv_sum_; }  // for binding_sig: bvk = cv_sum - value_balance (sapling/prover.rs:291-318)
+
+  private:
+    friend class LocalTxProver;
+    void bsk_add(const Bytes32& rcv, bool subtract) { bsk_ = detail::fs_add(bsk_, rcv, subtract); }  // "Outputs subtract from the total."
+    void cv_add(const Bytes32& cv, bool subtract) {
+        Bytes32 out;
+        if (masp_host_jubjub_add(cv_sum_.data(), cv.data(), subtract ? 1 : 0, out.data()) != MASP_HOST_OK) throw Panic("cv_sum: not a Jubjub point");
+        cv_sum_ = out;
+    }
+    Bytes32 bsk_, cv_sum_;
+};
+
+// what one description of a transaction hands the prover: the arguments of the trait's methods after `ctx`
+struct SpendInfo {
+    ProofGenerationKey proof_generation_key;
+    Diversifier diversifier;
+    Bytes32 rcm;  // Rseed as note.rcm()
+    Bytes32 ar;
+    AssetType asset_type;
+    uint64_t value;
+    Bytes32 anchor;
+    MerklePath merkle_path;
+    Bytes32 rcv;
+};
+struct OutputInfo {
+    Bytes32 esk;
+    PaymentAddress payment_address;
+    Bytes32 rcm;
+    AssetType asset_type;
+    uint64_t value;
+    Bytes32 rcv;
+};
+struct ConvertInfo {
+    AllowedConversion allowed_conversion;
+    uint64_t value;
+    Bytes32 anchor;
+    MerklePath merkle_path;
+    Bytes32 rcv;
+};
+struct SpendProof {
+    GrothProofBytes zkproof;
+    Bytes32 cv;  // jubjub::ExtendedPoint
+    Bytes32 rk;  // redjubjub::PublicKey
+};
+struct ValueProof {  // what output_proof / convert_proof return
+    GrothProofBytes zkproof;
+    Bytes32 cv;
+};
+// explicit Groth16 blinding scalars (deterministic replay, tests); the reference draws them from OsRng (sapling/prover.rs:66,174,225)
+struct BlindingScalars {
+    Bytes32 r, s;
+};
+
+struct LocalTxProverConfig {
+    int device = 0;
+    bool self_verify = true;                    // sapling/prover.rs:148,266 (tests of the failure paths switch it off)
+    const masp_hip_options* options = nullptr;  // slots, batch_cap, ... (nullptr: the library's defaults)
+    unsigned threads = 0;                       // synthesis threads of the *_proofs batch methods (0: the CPUs this process may use)
+    bool trace = false;                         // one line per batch on stderr: when it was synthesised, got a slot, was proved, verified, committed
+};
+
+class LocalTxProver {
+  public:
+    using Config = LocalTxProverConfig;
+
+    // = LocalTxProver::from_bytes (prover.rs:81-95): the three parameter files' bytes in the bellman wire format
+    static std::unique_ptr<LocalTxProver> from_bytes(const uint8_t* spend, size_t spend_len, const uint8_t* output, size_t output_len,
+                                                     const uint8_t* convert, size_t convert_len, const Config& cfg = Config()) {
+        return std::unique_ptr<LocalTxProver>(new LocalTxProver(spend, spend_len, output, output_len, convert, convert_len, cfg));
+    }
+    // = LocalTxProver::new (prover.rs:55-64): parameter files on disk
+    static std::unique_ptr<LocalTxProver> from_paths(const std::string& spend_path, const std::string& output_path, const std::string& convert_path,
+                                                     const Config& cfg = Config()) {
+        std::vector<uint8_t> b[3];
+        const std::string* p[3] = {&spend_path, &output_path, &convert_path};
+        for (int i = 0; i < 3; ++i) {
+            std::ifstream f(*p[i], std::ios::binary);
+            if (!f) throw Panic("cannot open " + *p[i]);  // (the reference: File::open(..).expect(..), lib.rs:284-288)
+            b[i].assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+        }
+        return from_bytes(b[0].data(), b[0].size(), b[1].data(), b[1].size(), b[2].data(), b[2].size(), cfg);
+    }
+    ~LocalTxProver() { release(); }
+    LocalTxProver(const LocalTxProver&) = delete;
+    LocalTxProver& operator=(const LocalTxProver&) = delete;
+
+    SaplingProvingContext new_sapling_proving_context() const { return SaplingProvingContext(); }
+    masp_hip_ctx* context() const { return ctx_; }
+    size_t batch_cap() const { return batch_cap_; }
+
+    // ---- trait TxProver ----
+    std::optional<SpendProof> spend_proof(SaplingProvingContext& ctx, const ProofGenerationKey& proof_generation_key, const Diversifier& diversifier,
+                                          const Bytes32& rseed, const Bytes32& ar, const AssetType& asset_type, uint64_t value, const Bytes32& anchor,
+                                          const MerklePath& merkle_path, const Bytes32& rcv, const BlindingScalars* rs = nullptr) {
+        const SpendInfo d{proof_generation_key, diversifier, rseed, ar, asset_type, value, anchor, merkle_path, rcv};
+        auto out = spend_proofs(ctx, &d, 1, rs);
+        return out[0];
+    }
+    ValueProof output_proof(SaplingProvingContext& ctx, const Bytes32& esk, const PaymentAddress& payment_address, const Bytes32& rcm,
+                            const AssetType& asset_type, uint64_t value, const Bytes32& rcv, const BlindingScalars* rs = nullptr) {
+        const OutputInfo d{esk, payment_address, rcm, asset_type, value, rcv};
+        auto out = output_proofs(ctx, &d, 1, rs);
+        if (!out[0]) throw Panic("output_proof: the statement cannot be synthesised (invalid diversifier or pk_d)");  // the reference unwraps here (:189-196)
+        return *out[0];
+    }
+    std::optional<ValueProof> convert_proof(SaplingProvingContext& ctx, const AllowedConversion& allowed_conversion, uint64_t value, const Bytes32& anchor,
+                                            const MerklePath& merkle_path, const Bytes32& rcv, const BlindingScalars* rs = nullptr) {
+        const ConvertInfo d{allowed_conversion, value, anchor, merkle_path, rcv};
+        auto out = convert_proofs(ctx, &d, 1, rs);
+        return out[0];
+    }
+
+    // ---- the descriptions of a whole transaction at once (see the head of this file).  Element i of the result is what the trait's
+    // method returns for description i; `rs`: n explicit (r, s) pairs or nullptr ----
+    std::vector<std::optional<SpendProof>> spend_proofs(SaplingProvingContext& ctx, const SpendInfo* d, size_t n, const BlindingScalars* rs = nullptr) {
+        std::vector<std::optional<SpendProof>> out(n);
+        for (size_t i = 0; i < n; ++i) ctx.bsk_add(d[i].rcv, false);  // sapling/prover.rs:69-75, before anything can fail
+        std::vector<Bytes32> rk(n), nf(n);
+        run<SpendInfo>(MASP_HIP_SPEND, ctx, false, d, n, rs,
+                       [&](size_t lo, size_t cnt, uint8_t* inputs, uint8_t* aux, Bytes32* cv, int* rc) {
+                           std::vector<masp_host_spend_job> jobs(cnt);
+                           for (size_t k = 0; k < cnt; ++k) {
+                               const SpendInfo& x = d[lo + k];
+                               jobs[k] = masp_host_spend_job{x.proof_generation_key.ak.data(), x.proof_generation_key.nsk.data(), x.diversifier.bytes.data(),
+                                                             x.rcm.data(), x.ar.data(), x.asset_type.identifier.data(), x.value, x.anchor.data(),
+                                                             x.merkle_path.auth_path[0].data(), x.merkle_path.position, x.rcv.data(),
+                                                             inputs + k * 32 * n_inputs_[MASP_HIP_SPEND], aux + k * 32 * (size_t)n_aux_[MASP_HIP_SPEND],
+                                                             cv[k].data(), rk[lo + k].data(), nf[lo + k].data(), 0};
+                           }
+                           masp_host_spend_assignments(cnt, jobs.data(), 2);
+                           for (size_t k = 0; k < cnt; ++k) rc[k] = jobs[k].rc;
+                       },
+                       // public input of the self-check (sapling/prover.rs:121-145): rk, cv, anchor, the nullifier packed into two scalars
+                       [&](size_t i, const Bytes32& cv, uint8_t* pub) {
+                           if (masp_host_point_uv(rk[i].data(), pub) != MASP_HOST_OK || masp_host_point_uv(cv.data(), pub + 64) != MASP_HOST_OK) throw Panic("rk / cv: not a Jubjub point");
+                           std::memcpy(pub + 128, d[i].anchor.data(), 32);
+                           detail::multipack32(nf[i].data(), pub + 160);
+                       },
+                       7,
+                       [&](size_t i, const GrothProofBytes& zk, const Bytes32& cv) { out[i] = SpendProof{zk, cv, rk[i]}; });  // (cv_sum += cv, :154: by `run`)
+        return out;
+    }
+    std::vector<std::optional<ValueProof>> output_proofs(SaplingProvingContext& ctx, const OutputInfo* d, size_t n, const BlindingScalars* rs = nullptr) {
+        std::vector<std::optional<ValueProof>> out(n);
+        for (size_t i = 0; i < n; ++i) ctx.bsk_add(d[i].rcv, true);  // :177-183
+        run<OutputInfo>(MASP_HIP_OUTPUT, ctx, true, d, n, rs,
+                        [&](size_t lo, size_t cnt, uint8_t* inputs, uint8_t* aux, Bytes32* cv, int* rc) {
+                            for (size_t k = 0; k < cnt; ++k) {
+                                const OutputInfo& x = d[lo + k];
+                                rc[k] = masp_host_output_assignment(x.esk.data(), x.payment_address.diversifier.bytes.data(), x.payment_address.pk_d.data(),
+                                                                    x.rcm.data(), x.asset_type.identifier.data(), x.value, x.rcv.data(), 2,
+                                                                    inputs + k * 32 * n_inputs_[MASP_HIP_OUTPUT], aux + k * 32 * (size_t)n_aux_[MASP_HIP_OUTPUT],
+                                                                    cv[k].data());
+                            }
+                        },
+                        nullptr, 0,  // "Output proofs are not self-checked" (the reference verifies Spend and Convert only)
+                        [&](size_t i, const GrothProofBytes& zk, const Bytes32& cv) { out[i] = ValueProof{zk, cv}; });  // (cv_sum -= cv, :205: by `run`)
+        return out;
+    }
+    std::vector<std::optional<ValueProof>> convert_proofs(SaplingProvingContext& ctx, const ConvertInfo* d, size_t n, const BlindingScalars* rs = nullptr) {
+        std::vector<std::optional<ValueProof>> out(n);
+        for (size_t i = 0; i < n; ++i) ctx.bsk_add(d[i].rcv, false);  // :228-234
+        run<ConvertInfo>(MASP_HIP_CONVERT, ctx, false, d, n, rs,
+                         [&](size_t lo, size_t cnt, uint8_t* inputs, uint8_t* aux, Bytes32* cv, int* rc) {
+                             std::vector<masp_host_convert_job> jobs(cnt);
+                             for (size_t k = 0; k < cnt; ++k) {
+                                 const ConvertInfo& x = d[lo + k];
+                                 jobs[k] = masp_host_convert_job{x.allowed_conversion.generator.data(), x.value, x.anchor.data(), x.merkle_path.auth_path[0].data(),
+                                                                 x.merkle_path.position, x.rcv.data(), inputs + k * 32 * n_inputs_[MASP_HIP_CONVERT],
+                                                                 aux + k * 32 * (size_t)n_aux_[MASP_HIP_CONVERT], cv[k].data(), 0};
+                             }
+                             masp_host_convert_assignments(cnt, jobs.data(), 2);
+                             for (size_t k = 0; k < cnt; ++k) rc[k] = jobs[k].rc;
+                         },
+                         [&](size_t i, const Bytes32& cv, uint8_t* pub) {  // sapling/prover.rs:256-263: cv, anchor
+                             if (masp_host_point_uv(cv.data(), pub) != MASP_HOST_OK) throw Panic("cv: not a Jubjub point");
+                             std::memcpy(pub + 64, d[i].anchor.data(), 32);
+                         },
+                         3,
+                         [&](size_t i, const GrothProofBytes& zk, const Bytes32& cv) { out[i] = ValueProof{zk, cv}; });  // (cv_sum += cv, :272: by `run`)
+        return out;
+    }
+
+    // a uniform bls12_381::Scalar as 32 canonical bytes from the operating system's generator (the reference: OsRng, sapling/prover.rs:66)
+    static Bytes32 random_scalar() {
+        for (;;) {
+            Bytes32 b;
+            detail::os_random(b.data(), b.size());
+            b[31] &= 0x7f;
+            if (detail::fr_canonical(b.data())) return b;
+        }
+    }
+
+  private:
+    LocalTxProver(const uint8_t* spend, size_t spend_len, const uint8_t* output, size_t output_len, const uint8_t* convert, size_t convert_len, const Config& cfg)
+        : cfg_(cfg) {
+        masp_hip_options opt;
+        if (cfg.options) {
+            opt = *cfg.options;
+        } else {
+            std::memset(&opt, 0, sizeof opt);  // every field: 0 = the default
+        }
+        opt.struct_size = sizeof(masp_hip_options);
+        const int dev = cfg.device;
+        int rc = masp_hip_ctx_create_ex(&dev, 1, &opt, &ctx_);
+        if (rc != MASP_HIP_OK) throw Panic(detail::hip_error(nullptr, rc, "masp_hip_ctx_create_ex"));
+        try {
+            masp_hip_options got;
+            std::memset(&got, 0, sizeof got);
+            got.struct_size = sizeof got;
+            if ((rc = masp_hip_ctx_get_options(ctx_, &got)) != MASP_HIP_OK) throw Panic(detail::hip_error(ctx_, rc, "masp_hip_ctx_get_options"));
+            batch_cap_ = (size_t)got.batch_cap;
+            slots_ = (size_t)got.slots;
+            permits_.resize(slots_);
+            const uint8_t* params[3] = {spend, output, convert};
+            const size_t lens[3] = {spend_len, output_len, convert_len};
+            for (int k = 0; k < 3; ++k) load_circuit(k, params[k], lens[k]);
+            // spend_vk / convert_vk: PreparedVerifyingKey (prover.rs:27-33, lib.rs:391-393); on the host for single proofs and for finding the
+            // culprit of a failing batch, on the GPU for the batches
+            for (int k : {MASP_HIP_SPEND, MASP_HIP_CONVERT}) {
+                host_vk_[k] = masp_host_vk_prepare(params[k], lens[k]);
+                if (!host_vk_[k]) throw Panic("verifying key does not parse");
+                if ((rc = masp_hip_vk_prepare(ctx_, params[k], lens[k], &gpu_vk_[k])) != MASP_HIP_OK) throw Panic(detail::hip_error(ctx_, rc, "masp_hip_vk_prepare"));
+            }
+        } catch (...) {
+            release();
+            throw;
+        }
+    }
+    void release() {  // (a verifying key goes before its context: masp_hip.h)
+        for (int k = 0; k < 3; ++k) {
+            for (uint8_t* p : pool_[k]) masp_hip_host_free(ctx_, p);
+            pool_[k].clear();
+            if (gpu_vk_[k]) masp_hip_vk_free(gpu_vk_[k]);
+            if (host_vk_[k]) masp_host_vk_free(host_vk_[k]);
+            gpu_vk_[k] = nullptr;
+            host_vk_[k] = nullptr;
+        }
+        if (ctx_) masp_hip_ctx_destroy(ctx_);
+        ctx_ = nullptr;
+    }
+
+    // the circuit's static R1CS (what bellperson's KeypairAssembly collects) from libmasp_host, the CRS from the caller's bytes
+    void load_circuit(int kind, const uint8_t* params, size_t len) {
+        void* h = masp_host_circuit_setup(kind);
+        if (!h) throw Panic("masp_host_circuit_setup failed");
+        uint32_t counts[6];
+        masp_host_circuit_counts(h, counts);
+        n_inputs_[kind] = counts[0];
+        n_aux_[kind] = counts[1];
+        std::vector<uint32_t> rowptr[3], col[3];
+        std::vector<uint8_t> coef[3];
+        for (int m = 0; m < 3; ++m) {
+            rowptr[m].resize((size_t)counts[2] + 1);
+            col[m].resize(counts[3 + m]);
+            coef[m].resize((size_t)32 * counts[3 + m]);
+            masp_host_circuit_matrix(h, m, rowptr[m].data(), col[m].data(), coef[m].data());
+        }
+        masp_host_circuit_free(h);
+        masp_hip_r1cs cs;
+        cs.n_inputs = counts[0];
+        cs.n_aux = counts[1];
+        cs.n_constraints = counts[2];
+        cs.a_rowptr = rowptr[0].data(); cs.a_col = col[0].data(); cs.a_coef = coef[0].data();
+        cs.b_rowptr = rowptr[1].data(); cs.b_col = col[1].data(); cs.b_coef = coef[1].data();
+        cs.c_rowptr = rowptr[2].data(); cs.c_col = col[2].data(); cs.c_coef = coef[2].data();
+        const int rc = masp_hip_circuit_load(ctx_, (uint32_t)kind, params, len, &cs);
+        if (rc != MASP_HIP_OK) throw Panic(detail::hip_error(ctx_, rc, "masp_hip_circuit_load"));  // the reference panics on undecodable parameters (lib.rs:337)
+    }
+
+    // page-locked slabs of batch_cap aux assignments per circuit: the synthesizer writes where the DMA engine reads
+    uint8_t* slab_take(int kind) {
+        {
+            std::lock_guard<std::mutex> g(pool_mu_);
+            if (!pool_[kind].empty()) {
+                uint8_t* p = pool_[kind].back();
+                pool_[kind].pop_back();
+                return p;
+            }
+        }
+        void* p = masp_hip_host_alloc(ctx_, batch_cap_ * 32 * (size_t)n_aux_[kind]);
+        if (!p) throw Panic("masp_hip_host_alloc failed");
+        return static_cast<uint8_t*>(p);
+    }
+    void slab_give(int kind, uint8_t* p) {
+        std::lock_guard<std::mutex> g(pool_mu_);
+        pool_[kind].push_back(p);
+    }
+
+    // One circuit's descriptions in batches of batch_cap: the host threads synthesise batch k + 1 while batches <= k prove — up to
+    // slots + 2 batches handed over at a time: `slots` of them on a slot of the context each, two waiting for one, so that a slot
+    // that finishes never waits for a synthesis (each waiting batch holds its page-locked slab: 0.8 GB for 256 Spends); results
+    // committed in description order.
+    //   synth(lo, cnt, inputs, aux, cv, rc): witnesses of descriptions [lo, lo + cnt) — called from several threads on disjoint ranges
+    //   public_input(i, cv, pub) / n_public: the statement of description i (nullptr: no self-check)
+    //   commit(i, zkproof, cv): description i proved (and verified); called in order of i, from the calling thread; the context's
+    //   cv_sum takes the batch's commitments right after (+ or -: subtract_cv)
+    template <class Info, class Synth, class PublicInput, class Commit>
+    void run(int kind, SaplingProvingContext& ctx, bool subtract_cv, const Info*, size_t n, const BlindingScalars* rs, Synth synth, PublicInput public_input,
+             uint32_t n_public, Commit commit) {
+        struct Batch {
+            size_t lo = 0, cnt = 0;
+            uint8_t* aux = nullptr;
+            std::vector<uint8_t> inputs, proofs;
+            std::vector<Bytes32> cv;
+            std::vector<int> rc;        // synthesis: MASP_HOST_OK or why the description cannot be proved
+            std::vector<char> valid;    // after proving: the proof exists and passed its self-check
+            Bytes32 cv_partial{};       // the sum of the value commitments of its valid proofs (one point addition per batch on the caller's thread)
+            bool any_valid = false;
+            size_t ticket = 0;          // its place in the queue for a slot of the context
+            bool ticketed = false;
+            double t[6] = {0, 0, 0, 0, 0, 0};  // (trace) seconds since the call began: synthesis from / to, slot taken, proved, verified, committed
+            std::future<void> proving;
+        };
+        const size_t cap = batch_cap_, nin = n_inputs_[kind], naux = n_aux_[kind];
+        const auto t_begin = std::chrono::steady_clock::now();
+        auto now = [t_begin]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
+        const unsigned threads = cfg_.threads ? cfg_.threads : detail::effective_cpus();
+        std::deque<std::unique_ptr<Batch>> flying;
+        auto land = [&]() {  // the oldest batch: wait, commit in order, recycle its slab
+            std::unique_ptr<Batch> b = std::move(flying.front());
+            flying.pop_front();
+            struct Give {
+                LocalTxProver* p; int kind; uint8_t* s;
+                ~Give() { p->slab_give(kind, s); }
+            } give{this, kind, b->aux};
+            b->proving.get();  // (rethrows a Panic of the proving thread)
+            for (size_t k = 0; k < b->cnt; ++k)
+                if (b->valid[k]) {
+                    GrothProofBytes zk;
+                    std::memcpy(zk.data(), &b->proofs[GROTH_PROOF_SIZE * k], GROTH_PROOF_SIZE);
+                    commit(b->lo + k, zk, b->cv[k]);
+                }
+            if (b->any_valid) ctx.cv_add(b->cv_partial, subtract_cv);  // cv_sum after the self-check (sapling/prover.rs:154,205,272)
+            b->t[5] = now();
+            if (cfg_.trace)
+                std::fprintf(stderr, "batch at %zu (%zu): synthesis %.3f - %.3f, slot %.3f, proved %.3f, verified %.3f, committed %.3f\n", b->lo, b->cnt, b->t[0], b->t[1], b->t[2],
+                             b->t[3], b->t[4], b->t[5]);
+        };
+        try {
+            for (size_t lo = 0; lo < n; lo += cap) {
+                std::unique_ptr<Batch> b(new Batch);
+                b->lo = lo;
+                b->cnt = std::min(cap, n - lo);
+                b->aux = slab_take(kind);
+                b->inputs.resize(b->cnt * 32 * nin);
+                b->proofs.resize(b->cnt * GROTH_PROOF_SIZE);
+                b->cv.resize(b->cnt);
+                b->rc.assign(b->cnt, MASP_HOST_OK);
+                b->valid.assign(b->cnt, 0);
+                b->ticket = permits_.ticket();
+                b->ticketed = true;
+                Batch* B = b.get();
+                flying.push_back(std::move(b));
+                // ---- synthesis: groups of 16 witnesses per native call (their Merkle blocks side by side), dealt to the threads
+                B->t[0] = now();
+                {
+                    constexpr size_t GROUP = 16;
+                    const size_t groups = (B->cnt + GROUP - 1) / GROUP;
+                    std::atomic<size_t> next{0};
+                    auto worker = [&]() {
+                        for (size_t g; (g = next.fetch_add(1)) < groups;) {
+                            const size_t k0 = g * GROUP, c = std::min(GROUP, B->cnt - k0);
+                            synth(B->lo + k0, c, B->inputs.data() + k0 * 32 * nin, B->aux + k0 * 32 * naux, B->cv.data() + k0, B->rc.data() + k0);
+                        }
+                    };
+                    std::vector<std::thread> ts;
+                    for (unsigned t = 1; t < std::min<size_t>(threads, groups); ++t) ts.emplace_back(worker);
+                    worker();
+                    for (auto& t : ts) t.join();
+                }
+                B->t[1] = now();
+                // ---- proving + self-check of this batch on a thread of its own
+                B->proving = std::async(std::launch::async, [this, B, kind, nin, naux, rs, public_input, n_public, now]() {
+                    std::vector<masp_hip_job> jobs;
+                    std::vector<size_t> idx;
+                    for (size_t k = 0; k < B->cnt; ++k) {
+                        if (B->rc[k] != MASP_HOST_OK) continue;  // Err(()): invalid diversifier (sapling/prover.rs:84) — nothing to prove
+                        masp_hip_job j;
+                        std::memset(&j, 0, sizeof j);
+                        j.circuit = (uint32_t)kind;
+                        j.inputs = B->inputs.data() + k * 32 * nin;
+                        j.aux = B->aux + k * 32 * naux;
+                        j.aux_form = MASP_HIP_AUX_MONTGOMERY;
+                        const Bytes32 r = rs ? rs[B->lo + k].r : random_scalar(), s = rs ? rs[B->lo + k].s : random_scalar();
+                        std::memcpy(j.r, r.data(), 32);
+                        std::memcpy(j.s, s.data(), 32);
+                        jobs.push_back(j);
+                        idx.push_back(k);
+                    }
+                    std::vector<uint8_t> proofs(GROTH_PROOF_SIZE * jobs.size());
+                    int rc = MASP_HIP_OK;
+                    permits_.acquire(B->ticket);   // (a batch with nothing to prove takes its turn too: the tickets are consecutive)
+                    B->t[2] = now();
+                    if (!jobs.empty()) rc = masp_hip_prove_batch(ctx_, jobs.size(), jobs.data(), proofs.data());
+                    permits_.release();
+                    B->t[3] = now();
+                    if (jobs.empty()) return;
+                    if (rc != MASP_HIP_OK) throw Panic(detail::hip_error(ctx_, rc, "proving should not fail"));  // .expect(..) at sapling/prover.rs:117,202,252
+                    std::vector<char> ok(jobs.size(), 1);
+                    if constexpr (!std::is_same<PublicInput, std::nullptr_t>::value) {
+                        if (cfg_.self_verify) {
+                            std::vector<uint8_t> pub(jobs.size() * 32 * n_public);
+                            for (size_t q = 0; q < jobs.size(); ++q) public_input(B->lo + idx[q], B->cv[idx[q]], &pub[q * 32 * n_public]);
+                            bool all = false;
+                            if (jobs.size() > 1) {  // one random linear combination on the GPU (bellman's verify_proofs_batch, sapling/verifier/batch.rs:201-239)
+                                std::vector<uint8_t> z(16 * jobs.size());
+                                detail::os_random(z.data(), z.size());
+                                int valid = 0;
+                                rc = masp_hip_verify_batch(ctx_, gpu_vk_[kind], jobs.size(), proofs.data(), pub.data(), n_public, z.data(), &valid);
+                                if (rc != MASP_HIP_OK) throw Panic(detail::hip_error(ctx_, rc, "masp_hip_verify_batch"));
+                                all = valid == 1;
+                            }
+                            if (!all)  // a lone proof, or the batch holds a proof that does not verify: each one on the host (verify_proof, :148 / :266)
+                                for (size_t q = 0; q < jobs.size(); ++q)
+                                    ok[q] = masp_host_vk_verify(host_vk_[kind], &proofs[GROTH_PROOF_SIZE * q], &pub[q * 32 * n_public], n_public) == 1;
+                        }
+                    }
+                    B->t[4] = now();
+                    std::vector<uint8_t> cvs;
+                    for (size_t q = 0; q < jobs.size(); ++q) {
+                        std::memcpy(&B->proofs[GROTH_PROOF_SIZE * idx[q]], &proofs[GROTH_PROOF_SIZE * q], GROTH_PROOF_SIZE);
+                        B->valid[idx[q]] = ok[q];
+                        if (ok[q]) cvs.insert(cvs.end(), B->cv[idx[q]].begin(), B->cv[idx[q]].end());
+                    }
+                    if (!cvs.empty()) {  // one native call for the batch's commitments (a point addition per proof on the caller's thread: 30 ms per 256)
+                        Bytes32 identity{};
+                        identity[0] = 1;
+                        if (masp_host_jubjub_sum(identity.data(), cvs.data(), cvs.size() / 32, nullptr, B->cv_partial.data()) != MASP_HOST_OK) throw Panic("cv: not a Jubjub point");
+                        B->any_valid = true;
+                    }
+                });
+                while (flying.size() > slots_ + 2) land();
+            }
+            while (!flying.empty()) land();
+        } catch (...) {
+            for (auto& b : flying) {  // let the proving threads finish with their buffers before those go away
+                if (b->proving.valid()) {
+                    b->proving.wait();
+                } else if (b->ticketed) {  // never handed over: its turn must still pass, or every later batch of this prover waits for it
+                    permits_.acquire(b->ticket);
+                    permits_.release();
+                }
+                slab_give(kind, b->aux);
+            }
+            throw;
+        }
+    }
+
+    Config cfg_;
+    masp_hip_ctx* ctx_ = nullptr;
+    size_t batch_cap_ = 256, slots_ = 4;
+    uint32_t n_inputs_[3] = {0, 0, 0}, n_aux_[3] = {0, 0, 0};
+    void* host_vk_[3] = {nullptr, nullptr, nullptr};
+    masp_hip_vk* gpu_vk_[3] = {nullptr, nullptr, nullptr};
+    std::mutex pool_mu_;
+    std::vector<uint8_t*> pool_[3];
+    detail::FifoPermits permits_;
+};
+
+}  // namespace masp
+#endif

@@ -1,0 +1,287 @@
+// A compiled C++ user of include/masp_tx_prover.hpp: what a C++ wallet that held the reference's LocalTxProver would write.
+// No Python in its call path: tests/test_tx_prover_cpp.py writes the case file (parameter bytes + descriptions), runs this program
+// and compares what it wrote with the Python mirror's results and the oracle's proofs.
+//
+//   tx_prover_harness --selftest <file>      CPU only: the header's scalar helpers on the vectors of <file>, results as hex lines
+//   tx_prover_harness <case.bin> <out.bin>   one MI355X: see the format below
+//
+// case.bin (little-endian):  "MTP1" | 3 x (u64 length, Parameters bytes: spend, output, convert) | u32 self_verify | u32 threads |
+//   u32 batch_cap (0: default) | u32 mode (0: the trait's methods one description at a time, in file order; 1: spend_proofs /
+//   output_proofs / convert_proofs over all descriptions of a kind; 2: as 1, then the Spend descriptions again, timed) | u32 n | n records:
+//     u32 kind (0 spend, 1 output, 2 convert), then
+//     spend:   ak nsk diversifier[11] rcm ar asset value:u64 anchor path[32][32] position:u64 rcv r s
+//     output:  esk diversifier[11] pk_d rcm asset value:u64 rcv r s
+//     convert: generator value:u64 anchor path[32][32] position:u64 rcv r s
+// out.bin: n x (u32 status (1 Some / 0 None = Err(()) / 2 Panic) | zkproof[192] | cv[32] | rk[32]) | bsk[32] | cv_sum[32]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "masp_tx_prover.hpp"
+
+using namespace masp;
+
+struct Reader {
+    std::vector<uint8_t> b;
+    size_t at = 0;
+    void need(size_t n) const {
+        if (at + n > b.size()) {
+            std::fprintf(stderr, "case file truncated at %zu (+%zu of %zu)\n", at, n, b.size());
+            std::exit(2);
+        }
+    }
+    template <class T>
+    T num() {
+        need(sizeof(T));
+        T v = 0;
+        for (size_t i = 0; i < sizeof(T); ++i) v |= (T)b[at + i] << (8 * i);
+        at += sizeof(T);
+        return v;
+    }
+    template <size_t N>
+    std::array<uint8_t, N> bytes() {
+        need(N);
+        std::array<uint8_t, N> a;
+        std::memcpy(a.data(), &b[at], N);
+        at += N;
+        return a;
+    }
+    std::vector<uint8_t> blob() {
+        const uint64_t n = num<uint64_t>();
+        need(n);
+        std::vector<uint8_t> v(b.begin() + at, b.begin() + at + n);
+        at += n;
+        return v;
+    }
+    MerklePath path() {
+        MerklePath p;
+        for (auto& node : p.auth_path) node = bytes<32>();
+        p.position = num<uint64_t>();
+        return p;
+    }
+};
+
+static std::string hex(const uint8_t* p, size_t n) {
+    static const char* d = "0123456789abcdef";
+    std::string s;
+    for (size_t i = 0; i < n; ++i) {
+        s += d[p[i] >> 4];
+        s += d[p[i] & 15];
+    }
+    return s;
+}
+static Bytes32 unhex32(const std::string& s) {
+    Bytes32 b;
+    for (int i = 0; i < 32; ++i) b[i] = (uint8_t)std::stoul(s.substr(2 * i, 2), nullptr, 16);
+    return b;
+}
+
+// lines "add <a> <b>", "sub <a> <b>" (jubjub::Fr, 64 hex digits each, little-endian bytes), "pack <32 bytes>", "random <count>"
+static int selftest(const char* path) {
+    std::ifstream f(path);
+    std::string line;
+    while (std::getline(f, line)) {
+        std::istringstream in(line);
+        std::string op, a, b;
+        in >> op;
+        if (op == "add" || op == "sub") {
+            in >> a >> b;
+            const Bytes32 r = detail::fs_add(unhex32(a), unhex32(b), op == "sub");
+            std::printf("%s %s\n", op.c_str(), hex(r.data(), 32).c_str());
+        } else if (op == "pack") {
+            in >> a;
+            uint8_t out[64];
+            detail::multipack32(unhex32(a).data(), out);
+            std::printf("pack %s %s\n", hex(out, 32).c_str(), hex(out + 32, 32).c_str());
+        } else if (op == "random") {
+            int n = 0, bad = 0, distinct = 1;
+            in >> n;
+            Bytes32 prev = LocalTxProver::random_scalar();
+            for (int i = 1; i < n; ++i) {
+                const Bytes32 x = LocalTxProver::random_scalar();
+                bad += !detail::fr_canonical(x.data());
+                distinct += x != prev;
+                prev = x;
+            }
+            std::printf("random %d canonical %d distinct %d\n", n, n - bad, distinct);
+        }
+    }
+    SaplingProvingContext ctx;  // zero and the identity
+    std::printf("context %s %s\n", hex(ctx.bsk().data(), 32).c_str(), hex(ctx.cv_sum().data(), 32).c_str());
+    std::printf("selftest ok\n");
+    return 0;
+}
+
+struct Record {
+    uint32_t kind;
+    SpendInfo spend;
+    OutputInfo output;
+    ConvertInfo convert;
+    BlindingScalars rs;
+    // result
+    uint32_t status = 0;
+    GrothProofBytes zk{};
+    Bytes32 cv{}, rk{};
+};
+
+int main(int argc, char** argv) {
+    if (argc == 3 && std::string(argv[1]) == "--selftest") return selftest(argv[2]);
+    if (argc != 3) {
+        std::fprintf(stderr, "usage: %s <case.bin> <out.bin> | --selftest <file>\n", argv[0]);
+        return 2;
+    }
+    Reader rd;
+    {
+        std::ifstream f(argv[1], std::ios::binary);
+        rd.b.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+    }
+    if (rd.b.size() < 4 || std::memcmp(rd.b.data(), "MTP1", 4) != 0) {
+        std::fprintf(stderr, "not a case file\n");
+        return 2;
+    }
+    rd.at = 4;
+    std::vector<uint8_t> params[3] = {rd.blob(), rd.blob(), rd.blob()};
+    LocalTxProver::Config cfg;
+    cfg.self_verify = rd.num<uint32_t>() != 0;
+    cfg.threads = rd.num<uint32_t>();
+    masp_hip_options opt;
+    std::memset(&opt, 0, sizeof opt);
+    opt.struct_size = sizeof opt;
+    opt.batch_cap = (int32_t)rd.num<uint32_t>();
+    cfg.options = &opt;
+    cfg.trace = std::getenv("MASP_TXP_TRACE") != nullptr;
+    const uint32_t mode = rd.num<uint32_t>(), n = rd.num<uint32_t>();
+    std::vector<Record> recs(n);
+    for (Record& r : recs) {
+        r.kind = rd.num<uint32_t>();
+        if (r.kind == MASP_HIP_SPEND) {
+            SpendInfo& s = r.spend;
+            s.proof_generation_key.ak = rd.bytes<32>();
+            s.proof_generation_key.nsk = rd.bytes<32>();
+            s.diversifier.bytes = rd.bytes<11>();
+            s.rcm = rd.bytes<32>();
+            s.ar = rd.bytes<32>();
+            s.asset_type.identifier = rd.bytes<32>();
+            s.value = rd.num<uint64_t>();
+            s.anchor = rd.bytes<32>();
+            s.merkle_path = rd.path();
+            s.rcv = rd.bytes<32>();
+        } else if (r.kind == MASP_HIP_OUTPUT) {
+            OutputInfo& o = r.output;
+            o.esk = rd.bytes<32>();
+            o.payment_address.diversifier.bytes = rd.bytes<11>();
+            o.payment_address.pk_d = rd.bytes<32>();
+            o.rcm = rd.bytes<32>();
+            o.asset_type.identifier = rd.bytes<32>();
+            o.value = rd.num<uint64_t>();
+            o.rcv = rd.bytes<32>();
+        } else if (r.kind == MASP_HIP_CONVERT) {
+            ConvertInfo& c = r.convert;
+            c.allowed_conversion.generator = rd.bytes<32>();
+            c.value = rd.num<uint64_t>();
+            c.anchor = rd.bytes<32>();
+            c.merkle_path = rd.path();
+            c.rcv = rd.bytes<32>();
+        } else {
+            std::fprintf(stderr, "bad kind %u\n", r.kind);
+            return 2;
+        }
+        r.rs.r = rd.bytes<32>();
+        r.rs.s = rd.bytes<32>();
+    }
+    std::unique_ptr<LocalTxProver> prover;
+    try {
+        prover = LocalTxProver::from_bytes(params[0].data(), params[0].size(), params[1].data(), params[1].size(), params[2].data(), params[2].size(), cfg);
+    } catch (const Panic& e) {
+        std::printf("panic at load: %s\n", e.what());
+        return 3;
+    }
+    std::printf("loaded: batch_cap %zu, host threads %u\n", prover->batch_cap(), cfg.threads ? cfg.threads : detail::effective_cpus());
+    SaplingProvingContext ctx = prover->new_sapling_proving_context();
+    size_t some = 0, none = 0, panics = 0;
+    if (mode == 0) {
+        for (Record& r : recs) {
+            try {
+                if (r.kind == MASP_HIP_SPEND) {
+                    const SpendInfo& s = r.spend;
+                    auto got = prover->spend_proof(ctx, s.proof_generation_key, s.diversifier, s.rcm, s.ar, s.asset_type, s.value, s.anchor, s.merkle_path, s.rcv, &r.rs);
+                    if (got) r.status = 1, r.zk = got->zkproof, r.cv = got->cv, r.rk = got->rk;
+                } else if (r.kind == MASP_HIP_OUTPUT) {
+                    const OutputInfo& o = r.output;
+                    const ValueProof got = prover->output_proof(ctx, o.esk, o.payment_address, o.rcm, o.asset_type, o.value, o.rcv, &r.rs);
+                    r.status = 1, r.zk = got.zkproof, r.cv = got.cv;
+                } else {
+                    const ConvertInfo& c = r.convert;
+                    auto got = prover->convert_proof(ctx, c.allowed_conversion, c.value, c.anchor, c.merkle_path, c.rcv, &r.rs);
+                    if (got) r.status = 1, r.zk = got->zkproof, r.cv = got->cv;
+                }
+            } catch (const Panic& e) {
+                r.status = 2;
+                std::printf("panic: %s\n", e.what());
+            }
+        }
+    } else {   // modes 1 and 2
+        std::vector<size_t> at[3];
+        for (size_t i = 0; i < recs.size(); ++i) at[recs[i].kind].push_back(i);
+        std::vector<SpendInfo> sp;
+        std::vector<OutputInfo> ou;
+        std::vector<ConvertInfo> co;
+        std::vector<BlindingScalars> rs[3];
+        for (int k = 0; k < 3; ++k)
+            for (size_t i : at[k]) {
+                rs[k].push_back(recs[i].rs);
+                if (k == 0) sp.push_back(recs[i].spend);
+                if (k == 1) ou.push_back(recs[i].output);
+                if (k == 2) co.push_back(recs[i].convert);
+            }
+        try {
+            const auto a = prover->spend_proofs(ctx, sp.data(), sp.size(), rs[0].data());
+            for (size_t q = 0; q < a.size(); ++q)
+                if (a[q]) recs[at[0][q]].status = 1, recs[at[0][q]].zk = a[q]->zkproof, recs[at[0][q]].cv = a[q]->cv, recs[at[0][q]].rk = a[q]->rk;
+            const auto b = prover->output_proofs(ctx, ou.data(), ou.size(), rs[1].data());
+            for (size_t q = 0; q < b.size(); ++q)
+                if (b[q]) recs[at[1][q]].status = 1, recs[at[1][q]].zk = b[q]->zkproof, recs[at[1][q]].cv = b[q]->cv;
+            const auto c = prover->convert_proofs(ctx, co.data(), co.size(), rs[2].data());
+            for (size_t q = 0; q < c.size(); ++q)
+                if (c[q]) recs[at[2][q]].status = 1, recs[at[2][q]].zk = c[q]->zkproof, recs[at[2][q]].cv = c[q]->cv;
+        } catch (const Panic& e) {
+            std::printf("panic: %s\n", e.what());
+            return 3;
+        }
+    }
+    if (mode == 2) {
+        // the Spend descriptions once more, twice, with blinding scalars from the system's generator: the first pass sizes whatever the
+        // pass above left unsized (every slot's scratch), the second is timed — host to host, synthesis and self-checks included
+        std::vector<SpendInfo> sp;
+        for (const Record& r : recs)
+            if (r.kind == MASP_HIP_SPEND) sp.push_back(r.spend);
+        for (int pass = 0; pass < 2; ++pass) {
+            SaplingProvingContext c2 = prover->new_sapling_proving_context();
+            const auto t0 = std::chrono::steady_clock::now();
+            const auto got = prover->spend_proofs(c2, sp.data(), sp.size());
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            size_t ok = 0;
+            for (const auto& g : got) ok += g.has_value();
+            std::printf("%s: %zu Spend descriptions, %zu proofs in %.3f s = %.1f proofs/s\n", pass ? "timed" : "warm-up", sp.size(), ok, dt, ok / dt);
+        }
+    }
+    std::ofstream out(argv[2], std::ios::binary);
+    for (const Record& r : recs) {
+        some += r.status == 1;
+        none += r.status == 0;
+        panics += r.status == 2;
+        const uint8_t st[4] = {(uint8_t)r.status, 0, 0, 0};
+        out.write(reinterpret_cast<const char*>(st), 4);
+        out.write(reinterpret_cast<const char*>(r.zk.data()), 192);
+        out.write(reinterpret_cast<const char*>(r.cv.data()), 32);
+        out.write(reinterpret_cast<const char*>(r.rk.data()), 32);
+    }
+    out.write(reinterpret_cast<const char*>(ctx.bsk().data()), 32);
+    out.write(reinterpret_cast<const char*>(ctx.cv_sum().data()), 32);
+    out.close();
+    std::printf("descriptions %u: Some %zu, None %zu, Panic %zu\n", n, some, none, panics);
+    return 0;
+}

@@ -77,3 +77,18 @@ def test_masp_host_header_is_plain_c():
     for std in ("c99", "c11"):
         subprocess.check_call(["gcc", "-std=" + std, "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "masp_host.h")])
         subprocess.check_call(["gcc", "-std=" + std, "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "masp_hip.h")])
+
+
+def test_the_cxx_host_mirror_reaches_the_libraries_through_their_headers_only():
+    """include/masp_tx_prover.hpp (masp::LocalTxProver above the two C ABIs) calls nothing the C headers do not declare, includes nothing
+    of the product's internals and nothing of the oracle: what it needs IS the boundary."""
+    text = open(os.path.join(ROOT, "include", "masp_tx_prover.hpp")).read()
+    code = "\n".join(line.split("//")[0] for line in text.splitlines())
+    hdr = open(os.path.join(ROOT, "include", "masp_hip.h")).read() + open(os.path.join(ROOT, "include", "masp_host.h")).read()
+    declared = set(re.findall(r"\b(masp_h(?:ip|ost)_[a-z0-9_]+)\s*\(", hdr)) | set(re.findall(r"\b(masp_h(?:ip|ost)_[a-z0-9_]+)\b(?=;|\s*\{)", hdr))
+    types = {"masp_hip_ctx", "masp_hip_vk", "masp_hip_job", "masp_hip_r1cs", "masp_hip_options", "masp_host_spend_job", "masp_host_convert_job"}
+    used = set(re.findall(r"\b(masp_h(?:ip|ost)_[a-z0-9_]+)\b", code))
+    assert used - declared - types == set(), sorted(used - declared - types)
+    assert {"masp_hip_prove_batch", "masp_hip_verify_batch", "masp_hip_circuit_load", "masp_host_spend_assignments", "masp_host_vk_verify"} <= used
+    own = re.findall(r'#include\s+"([^"]+)"', text)                 # (the <...> ones are the standard library's and the system's)
+    assert sorted(own) == ["masp_hip.h", "masp_host.h"], own

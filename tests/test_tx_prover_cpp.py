@@ -1,0 +1,200 @@
+"""The host side of the drop-in in C++: include/masp_tx_prover.hpp (masp::LocalTxProver / masp::SaplingProvingContext above the two C
+ABIs) used by a compiled program, tests/native/tx_prover_harness.cpp — the stand-in this image allows for a Rust crate that implemented
+`trait TxProver` (/root/reference/masp_primitives/src/sapling/prover.rs:17-83) the way masp_proofs::prover::LocalTxProver does
+(/root/reference/masp_proofs/src/prover.rs:156-261).  No Python is in the harness's call path: this file writes the case (parameter
+bytes, descriptions, explicit blinding scalars), runs the program and compares what it wrote — proofs, cv, rk, and the context's bsk and
+cv_sum — with the Python mirror (masp_amd/prover.py) on the same descriptions and with the oracle's proof bytes.
+
+CPU part: the header compiles as strict C++17 (-pedantic -Wall -Wextra -Werror) with every template instantiated, and its scalar
+helpers (jubjub::Fr addition of bsk, the nullifier's multipacking, the blinding-scalar sampler) agree with Python integers."""
+import os
+import random
+import struct
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "native", "tx_prover_harness.cpp")
+EXE = os.path.join(HERE, "native", "_tx_prover_harness")
+LIBDIR = os.path.join(ROOT, "masp_amd")
+
+
+def _build(out=EXE):
+    deps = [SRC] + [os.path.join(ROOT, "include", h) for h in ("masp_tx_prover.hpp", "masp_hip.h", "masp_host.h")] + \
+           [os.path.join(LIBDIR, l) for l in ("libmasp_hip.so", "libmasp_host.so")]
+    if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(p) for p in deps):
+        return out
+    subprocess.check_call(["g++", "-std=c++17", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O1", "-I", os.path.join(ROOT, "include"), SRC,
+                           "-L", LIBDIR, "-lmasp_hip", "-lmasp_host", "-pthread", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath-link,/opt/rocm/lib",
+                           "-Wl,--allow-shlib-undefined", "-o", out])
+    return out
+
+
+def _b32(x):
+    return x.to_bytes(32, "little") if isinstance(x, int) else bytes(x)
+
+
+def test_the_header_compiles_as_strict_cxx17_and_its_scalar_helpers_agree_with_python(tmp_path):
+    from masp_amd import host as H
+    exe = _build(str(tmp_path / "harness"))
+    RJ = H.JUBJUB_ORDER
+    rng = random.Random(5)
+    pairs = [(RJ - 1, RJ - 1), (0, 0), (0, RJ - 1), (5, 7), (RJ - 1, 1)] + [(rng.randrange(RJ), rng.randrange(RJ)) for _ in range(40)]
+    packs = [bytes(range(224, 256)), b"\xff" * 32, b"\x00" * 32] + [bytes(rng.getrandbits(8) for _ in range(32)) for _ in range(8)]
+    lines = []
+    for a, b in pairs:
+        lines += ["add %s %s" % (_b32(a).hex(), _b32(b).hex()), "sub %s %s" % (_b32(a).hex(), _b32(b).hex())]
+    lines += ["pack " + p.hex() for p in packs] + ["random 2000"]
+    vec = tmp_path / "vectors.txt"
+    vec.write_text("\n".join(lines) + "\n")
+    out = subprocess.run([exe, "--selftest", str(vec)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "selftest ok" in out.stdout, out.stdout + out.stderr
+    got = out.stdout.splitlines()
+    k = 0
+    for a, b in pairs:                                        # SaplingProvingContext::bsk: "Outputs subtract from the total."
+        assert got[k] == "add " + _b32((a + b) % RJ).hex() and got[k + 1] == "sub " + _b32((a - b) % RJ).hex(), (a, b)
+        k += 2
+    for p in packs:                                           # multipack::compute_multipacking(bytes_to_bits_le(nf)) (sapling/prover.rs:138-139)
+        want = H.multipack(p)
+        assert got[k] == "pack %s %s" % (_b32(want[0]).hex(), _b32(want[1]).hex()), p.hex()
+        k += 1
+    assert got[k] == "random 2000 canonical 2000 distinct 2000"
+    assert got[k + 1] == "context %s %s" % (_b32(0).hex(), H.JUBJUB_IDENTITY.hex())
+
+
+def _record(kind, kw, r, s):
+    """one description in the harness's case format (tests/native/tx_prover_harness.cpp)"""
+    from masp_amd import host as H
+    if kind == "spend":
+        ak, nsk = kw["proof_generation_key"]
+        sib, pos = kw["merkle_path"]
+        body = _b32(ak) + _b32(nsk) + bytes(kw["diversifier"]) + _b32(kw["rcm"]) + _b32(kw["ar"]) + _b32(kw["asset_type"]) + \
+            struct.pack("<Q", kw["value"]) + _b32(kw["anchor"]) + b"".join(_b32(x) for x in sib) + struct.pack("<Q", pos) + _b32(kw["rcv"])
+        k = 0
+    elif kind == "output":
+        d, pk = kw["payment_address"]
+        body = _b32(kw["esk"]) + bytes(d) + _b32(pk) + _b32(kw["rcm"]) + _b32(kw["asset_type"]) + struct.pack("<Q", kw["value"]) + _b32(kw["rcv"])
+        k = 1
+    else:
+        sib, pos = kw["merkle_path"]
+        ac = kw["allowed_conversion"]
+        gen = ac.generator if isinstance(ac, H.AllowedConversion) else ac
+        body = _b32(gen) + struct.pack("<Q", kw["value"]) + _b32(kw["anchor"]) + b"".join(_b32(x) for x in sib) + struct.pack("<Q", pos) + _b32(kw["rcv"])
+        k = 2
+    return struct.pack("<I", k) + body + _b32(r) + _b32(s)
+
+
+def _python_results(lp, descs, rs):
+    """the Python mirror, one description at a time -> [(status, zkproof, cv, rk)], bsk, cv_sum"""
+    from masp_amd import prover as P
+    pc = lp.new_sapling_proving_context()
+    out = []
+    for (kind, kw), (r, s) in zip(descs, rs):
+        try:
+            if kind == "spend":
+                zk, cv, rk = lp.spend_proof(pc, kw["proof_generation_key"], kw["diversifier"], kw["rcm"], kw["ar"], kw["asset_type"], kw["value"],
+                                            kw["anchor"], kw["merkle_path"], kw["rcv"], rs=(r, s))
+            elif kind == "output":
+                zk, cv = lp.output_proof(pc, kw["esk"], kw["payment_address"], kw["rcm"], kw["asset_type"], kw["value"], kw["rcv"], rs=(r, s))
+                rk = bytes(32)
+            else:
+                zk, cv = lp.convert_proof(pc, kw["allowed_conversion"], kw["value"], kw["anchor"], kw["merkle_path"], kw["rcv"], rs=(r, s))
+                rk = bytes(32)
+            out.append((1, bytes(zk), bytes(cv), bytes(rk)))
+        except P.ProvingError:
+            out.append((0, bytes(192), bytes(32), bytes(32)))
+    return out, _b32(pc.bsk), bytes(pc.cv_sum)
+
+
+def _descriptions(n_spend, n_output, n_convert, seed):
+    """valid descriptions of the three kinds, interleaved, plus the reference's two Err(()) cases for a Spend: a diversifier without a
+    group hash (sapling/prover.rs:84) and a statement that does not hold (wrong anchor: the proof fails its self-check, :148) — and
+    a Convert whose anchor is wrong (:266)"""
+    from masp_amd import host as H
+    from masp_amd import workload as W
+    descs = []
+    for k in range(max(n_spend, n_output, n_convert)):
+        if k < n_spend:
+            descs.append(W.description("spend", seed + k))
+        if k < n_output:
+            descs.append(W.description("output", seed + k))
+        if k < n_convert:
+            descs.append(W.description("convert", seed + k))
+    kind, kw = W.description("spend", seed + 1000)
+    bad = None
+    for b in range(256):
+        try:
+            H.spend_leaf(*kw["proof_generation_key"], bytes([b]) * 11, kw["rcm"], kw["asset_type"], 1)
+        except H.HostError:
+            bad = bytes([b]) * 11
+            break
+    assert bad is not None
+    descs.insert(2, ("spend", dict(kw, diversifier=bad)))
+    wrong = (int.from_bytes(_b32(kw["anchor"]), "little") + 1) % H.FR_MODULUS
+    descs.insert(5, ("spend", dict(kw, anchor=wrong)))
+    kind, kw = W.description("convert", seed + 1001)
+    descs.append(("convert", dict(kw, anchor=(int.from_bytes(_b32(kw["anchor"]), "little") + 1) % H.FR_MODULUS)))
+    return descs
+
+
+def _run_case(tmp_path, lp, descs, rs, mode, batch_cap, threads):
+    blob = bytearray(b"MTP1")
+    for k in ("spend", "output", "convert"):
+        p = lp.parameters[k]
+        blob += struct.pack("<Q", p.size) + p.tobytes()
+    blob += struct.pack("<IIIII", 1, threads, batch_cap, mode, len(descs))
+    for (kind, kw), (r, s) in zip(descs, rs):
+        blob += _record(kind, kw, r, s)
+    case, out = tmp_path / ("case%d.bin" % mode), tmp_path / ("out%d.bin" % mode)
+    case.write_bytes(bytes(blob))
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    run = subprocess.run([_build(), str(case), str(out)], capture_output=True, text=True, timeout=900, env=env)
+    assert run.returncode == 0, run.stdout + run.stderr
+    got = out.read_bytes()
+    assert len(got) == 260 * len(descs) + 64, run.stdout
+    recs = [(got[260 * i], got[260 * i + 4:260 * i + 196], got[260 * i + 196:260 * i + 228], got[260 * i + 228:260 * i + 260]) for i in range(len(descs))]
+    return recs, got[-64:-32], got[-32:], run.stdout
+
+
+@pytest.mark.gpu
+def test_a_cxx_program_holds_a_local_tx_prover_and_gets_the_python_mirrors_bytes(tmp_path):
+    """trait TxProver, one description at a time (mode 0), then the same descriptions through the batch methods in batches of 8 on four
+    synthesis threads (mode 1): proofs, cv, rk, Err(()) cases, bsk and cv_sum are those of the Python mirror; a proof of each kind is the
+    oracle's."""
+    import oracle_lib as O
+    from masp_amd import host as H
+    from masp_amd import prover as P
+    lp = P.LocalTxProver.with_synthetic_parameters(seed=8)
+    descs = _descriptions(19, 5, 4, seed=700)
+    rng = random.Random(99)
+    rs = [(rng.randrange(H.FR_MODULUS), rng.randrange(H.FR_MODULUS)) for _ in descs]
+    want, bsk, cv_sum = _python_results(lp, descs, rs)
+    assert [w[0] for w in want].count(0) == 3 and want[2][0] == 0 and want[5][0] == 0 and want[-1][0] == 0
+    # the oracle's bytes for the first valid description of every kind (the Python mirror is itself tested against it: test_gpu_parity.py)
+    seen = set()
+    for (kind, kw), (r, s), w in zip(descs, rs, want):
+        if kind in seen or not w[0]:
+            continue
+        seen.add(kind)
+        cs, _ = H.circuit(kind)
+        if kind == "spend":
+            inputs, aux = H.spend_assignment(*kw["proof_generation_key"], kw["diversifier"], kw["rcm"], kw["ar"], kw["asset_type"], kw["value"], kw["anchor"],
+                                             *kw["merkle_path"], kw["rcv"])[:2]
+        elif kind == "output":
+            inputs, aux = H.output_assignment(kw["esk"], *kw["payment_address"], kw["rcm"], kw["asset_type"], kw["value"], kw["rcv"])[:2]
+        else:
+            inputs, aux = H.convert_assignment(kw["allowed_conversion"].generator, kw["value"], kw["anchor"], *kw["merkle_path"], kw["rcv"])[:2]
+        assert w[1] == O.create_proof(O.Params(lp.parameters[kind]), cs, inputs, aux, r, s), kind
+    assert seen == {"spend", "output", "convert"}
+    lp.close()                                               # (its parameter bytes stay: the harness loads them into a context of its own)
+    for mode, cap, threads in ((0, 0, 1), (1, 8, 4)):
+        recs, got_bsk, got_cv_sum, log = _run_case(tmp_path, lp, descs, rs, mode, cap, threads)
+        for i, (g, w) in enumerate(zip(recs, want)):
+            assert g[0] == w[0], "description %d (%s): status %d, the Python mirror says %d\n%s" % (i, descs[i][0], g[0], w[0], log)
+            assert g[1:] == w[1:], "description %d (%s), mode %d: bytes differ from the Python mirror" % (i, descs[i][0], mode)
+        assert got_bsk == bsk and got_cv_sum == cv_sum, "mode %d: the context differs" % mode
+        assert "Some %d, None 3, Panic 0" % (len(descs) - 3) in log
+        if mode == 1:
+            assert "batch_cap 8" in log
