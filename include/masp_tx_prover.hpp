@@ -4,7 +4,7 @@
 // Mirrors, name for name, what a user of the reference holds (citations relative to /root/reference):
 //   masp::LocalTxProver            = masp_proofs::prover::LocalTxProver               masp_proofs/src/prover.rs:27-33,55-95,156-261
 //     ::from_bytes / ::from_paths  = LocalTxProver::from_bytes / ::new                prover.rs:81-95 / :55-64
-//     ::new_sapling_proving_context, ::spend_proof, ::output_proof, ::convert_proof
+//     ::new_sapling_proving_context, ::spend_proof, ::output_proof, ::convert_proof, ::binding_sig
 //                                  = trait TxProver                                   masp_primitives/src/sapling/prover.rs:17-83
 //   masp::SaplingProvingContext    = masp_proofs::sapling::SaplingProvingContext (bsk, cv_sum)   masp_proofs/src/sapling/prover.rs:26-47
 // with the argument order and the error behaviour of the reference:
@@ -17,8 +17,9 @@
 // builder.rs:955-969,1007-1016) and prove them in batches of masp_hip_options::batch_cap — witnesses synthesised on host threads while
 // earlier batches prove, the Spend / Convert self-checks as one GPU batch verification per batch — with the context accumulated in
 // description order, so that the proofs, cv, rk, bsk and cv_sum are those of the serial loop.
-// binding_sig (sapling/prover.rs:279-326) is RedJubjub over the context's bsk / cv_sum and does not touch the prover (SURVEY.md §8b
-// "Not touched by the build"): SaplingProvingContext exposes both, the caller's RedJubjub signs (this repository's: masp_amd/redjubjub.py).
+// binding_sig (sapling/prover.rs:279-326) — RedJubjub over the context's bsk / cv_sum; it does not touch the GPU prover (SURVEY.md §8b
+// "Not touched by the build") and is here so that the trait is whole: BLAKE2b-512 and jubjub::Fr arithmetic in this header, the curve
+// through libmasp_host.
 // The parameter digests (lib.rs:351-388) stay with the caller as SURVEY.md §8b has it ("No hashing here").
 //
 // Thread-safe like the reference's `&self` methods: one LocalTxProver may be shared by several threads, each with its own context.
@@ -85,6 +86,30 @@ struct AssetType {
         return a;
     }
 };
+struct I128 {                              // a signed 128-bit amount: 16 little-endian two's-complement bytes (the values of an I128Sum)
+    std::array<uint8_t, 16> le;
+    static I128 from_i64(int64_t v) {
+        I128 x;
+        for (int i = 0; i < 16; ++i) x.le[i] = i < 8 ? (uint8_t)((uint64_t)v >> (8 * i)) : (v < 0 ? 0xff : 0);
+        return x;
+    }
+    bool negative() const { return (le[15] & 0x80) != 0; }
+    bool is_min() const {                  // i128::MIN has no absolute value (checked_abs, sapling/mod.rs:14-20)
+        for (int i = 0; i < 15; ++i)
+            if (le[i]) return false;
+        return le[15] == 0x80;
+    }
+    Bytes32 magnitude() const {            // |v| as a jubjub::Fr
+        Bytes32 m{};
+        unsigned carry = negative() ? 1 : 0;
+        for (int i = 0; i < 16; ++i) {
+            const unsigned b = negative() ? (uint8_t)~le[i] + carry : le[i];
+            m[i] = (uint8_t)b;
+            carry = negative() ? b >> 8 : 0;
+        }
+        return m;
+    }
+};
 struct MerklePath {                        // MerklePath<Node>: the authentication path, leaf level first, and the leaf's position
     std::array<Bytes32, 32> auth_path;
     uint64_t position;
@@ -92,11 +117,11 @@ struct MerklePath {                        // MerklePath<Node>: the authenticati
 struct AllowedConversion {                 // masp_primitives/src/convert.rs:22-29: the circuit sees its asset generator only
     Bytes32 generator;
     // AllowedConversion::from(I128Sum) (convert.rs:86-118): (asset, signed 128-bit amount as 16 little-endian two's-complement bytes)
-    static std::optional<AllowedConversion> from(const std::vector<std::pair<AssetType, std::array<uint8_t, 16>>>& assets) {
+    static std::optional<AllowedConversion> from(const std::vector<std::pair<AssetType, I128>>& assets) {
         std::vector<uint8_t> ids(32 * assets.size()), vals(16 * assets.size());
         for (size_t i = 0; i < assets.size(); ++i) {
             std::memcpy(&ids[32 * i], assets[i].first.identifier.data(), 32);
-            std::memcpy(&vals[16 * i], assets[i].second.data(), 16);
+            std::memcpy(&vals[16 * i], assets[i].second.le.data(), 16);
         }
         AllowedConversion c;
         if (masp_host_allowed_conversion(assets.size(), ids.data(), vals.data(), c.generator.data()) != MASP_HOST_OK) return std::nullopt;
@@ -163,6 +188,125 @@ inline Bytes32 fs_add(const Bytes32& a, const Bytes32& b, bool subtract) {
     return r;
 }
 inline bool fs_canonical(const Bytes32& a) { return !geq(load(a.data()), JUBJUB_ORDER); }
+// a 512-bit little-endian integer (8 x u64) mod the Jubjub order: jubjub::Fr::from_bytes_wide.  One bit at a time — this runs twice per
+// binding signature, not in any loop over proofs
+inline U256 fs_reduce_wide(const uint64_t x[8]) {
+    U256 r = {{0, 0, 0, 0}};
+    for (int bit = 511; bit >= 0; --bit) {
+        for (int i = 3; i > 0; --i) r.w[i] = (r.w[i] << 1) | (r.w[i - 1] >> 63);  // r < 2^252: nothing falls off the top
+        r.w[0] = (r.w[0] << 1) | ((x[bit >> 6] >> (bit & 63)) & 1);
+        if (geq(r, JUBJUB_ORDER)) sub_in_place(r, JUBJUB_ORDER);
+    }
+    return r;
+}
+// a * b mod the Jubjub order
+inline U256 fs_mul(const U256& a, const U256& b) {
+    uint64_t p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) {
+        uint64_t carry = 0;
+        for (int j = 0; j < 4; ++j) {  // 64 x 64 -> 128 by halves (no __int128: the header stays ISO C++)
+            const uint64_t al = a.w[i] & 0xffffffffu, ah = a.w[i] >> 32, bl = b.w[j] & 0xffffffffu, bh = b.w[j] >> 32;
+            const uint64_t ll = al * bl, lh = al * bh, hl = ah * bl, hh = ah * bh;
+            const uint64_t mid = (ll >> 32) + (lh & 0xffffffffu) + (hl & 0xffffffffu);
+            uint64_t lo = (ll & 0xffffffffu) | (mid << 32), hi = hh + (lh >> 32) + (hl >> 32) + (mid >> 32);
+            lo += carry;
+            hi += lo < carry;
+            const uint64_t t = p[i + j] + lo;
+            hi += t < lo;
+            p[i + j] = t;
+            carry = hi;
+        }
+        p[i + 4] = carry;
+    }
+    return fs_reduce_wide(p);
+}
+// BLAKE2b-512 (RFC 7693), unkeyed, with a 16-byte personalization: what RedJubjub's H* needs (masp_primitives/src/sapling/util.rs:9-15)
+class Blake2b512 {
+  public:
+    explicit Blake2b512(const char personal[16]) {
+        static const uint64_t iv[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
+                                       0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+        for (int i = 0; i < 8; ++i) h_[i] = iv[i];
+        h_[0] ^= 0x01010000ULL ^ 64;  // digest length 64, no key, fanout 1, depth 1
+        uint64_t p[2] = {0, 0};
+        for (int i = 0; i < 16; ++i) p[i >> 3] |= (uint64_t)(uint8_t)personal[i] << (8 * (i & 7));
+        h_[6] ^= p[0];
+        h_[7] ^= p[1];
+    }
+    void update(const uint8_t* in, size_t n) {
+        while (n) {
+            if (fill_ == 128) {  // (the last block is only compressed by finish: it carries the final flag)
+                t_ += 128;
+                compress(false);
+                fill_ = 0;
+            }
+            const size_t k = std::min<size_t>(n, 128 - fill_);
+            std::memcpy(buf_ + fill_, in, k);
+            fill_ += k;
+            in += k;
+            n -= k;
+        }
+    }
+    void finish(uint8_t out[64]) {
+        t_ += fill_;
+        std::memset(buf_ + fill_, 0, 128 - fill_);
+        compress(true);
+        for (int i = 0; i < 64; ++i) out[i] = (uint8_t)(h_[i >> 3] >> (8 * (i & 7)));
+    }
+
+  private:
+    static uint64_t rotr(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+    void compress(bool last) {
+        static const uint8_t sigma[12][16] = {
+            {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+            {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+            {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+            {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+            {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0},
+            {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3}};
+        static const uint64_t iv[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
+                                       0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+        uint64_t m[16], v[16];
+        for (int i = 0; i < 16; ++i) {
+            m[i] = 0;
+            for (int j = 7; j >= 0; --j) m[i] = (m[i] << 8) | buf_[8 * i + j];
+        }
+        for (int i = 0; i < 8; ++i) v[i] = h_[i], v[i + 8] = iv[i];
+        v[12] ^= t_;  // (messages here are far below 2^64 bytes: the high counter word stays 0)
+        if (last) v[14] = ~v[14];
+        auto G = [&](int a, int b, int c, int d, uint64_t x, uint64_t y) {
+            v[a] = v[a] + v[b] + x; v[d] = rotr(v[d] ^ v[a], 32);
+            v[c] = v[c] + v[d];     v[b] = rotr(v[b] ^ v[c], 24);
+            v[a] = v[a] + v[b] + y; v[d] = rotr(v[d] ^ v[a], 16);
+            v[c] = v[c] + v[d];     v[b] = rotr(v[b] ^ v[c], 63);
+        };
+        for (int r = 0; r < 12; ++r) {
+            const uint8_t* s = sigma[r];
+            G(0, 4, 8, 12, m[s[0]], m[s[1]]);   G(1, 5, 9, 13, m[s[2]], m[s[3]]);
+            G(2, 6, 10, 14, m[s[4]], m[s[5]]);  G(3, 7, 11, 15, m[s[6]], m[s[7]]);
+            G(0, 5, 10, 15, m[s[8]], m[s[9]]);  G(1, 6, 11, 12, m[s[10]], m[s[11]]);
+            G(2, 7, 8, 13, m[s[12]], m[s[13]]); G(3, 4, 9, 14, m[s[14]], m[s[15]]);
+        }
+        for (int i = 0; i < 8; ++i) h_[i] ^= v[i] ^ v[i + 8];
+    }
+    uint64_t h_[8], t_ = 0;
+    uint8_t buf_[128];
+    size_t fill_ = 0;
+};
+// RedJubjub's H*(a || b): BLAKE2b-512 personalised "MASP__RedJubjubH", reduced into jubjub::Fr (redjubjub.rs:36-38, util.rs:9-15)
+inline U256 h_star(const uint8_t* a, size_t na, const uint8_t* b, size_t nb) {
+    Blake2b512 h("MASP__RedJubjubH");
+    h.update(a, na);
+    h.update(b, nb);
+    uint8_t d[64];
+    h.finish(d);
+    uint64_t x[8];
+    for (int i = 0; i < 8; ++i) {
+        x[i] = 0;
+        for (int j = 7; j >= 0; --j) x[i] = (x[i] << 8) | d[8 * i + j];
+    }
+    return fs_reduce_wide(x);
+}
 inline bool fr_canonical(const uint8_t* a) { return !geq(load(a), FR_MODULUS); }
 // bellman multipack::compute_multipacking(bytes_to_bits_le(data)) for 32 bytes: two scalars of 254 and 2 bits (sapling/prover.rs:138-139)
 inline void multipack32(const uint8_t data[32], uint8_t out[64]) {
@@ -255,8 +399,22 @@ class SaplingProvingContext {
         cv_sum_.fill(0);     // jubjub::ExtendedPoint::identity(): (u, v) = (0, 1)
         cv_sum_[0] = 1;
     }
-    const Bytes32& bsk() const { return bsk_; }        // for binding_sig: PrivateKey(bsk)
-    const Bytes32& cv_sum() const { return cv_sum_; }  // for binding_sig: bvk = cv_sum - value_balance (sapling/prover.rs:291-318)
+    const Bytes32& bsk() const { return bsk_; }
+    const Bytes32& cv_sum() const { return cv_sum_; }
+    // a context with the accumulations of another one (a transaction built in several processes; tests)
+    static SaplingProvingContext from_parts(const Bytes32& bsk, const Bytes32& cv_sum) {
+        SaplingProvingContext c;
+        c.bsk_ = bsk;
+        c.cv_sum_ = cv_sum;
+        return c;
+    }
+
+    // = SaplingProvingContext::binding_sig (sapling/prover.rs:279-326): the RedJubjub signature (Rbar || Sbar, 64 bytes) over
+    // bvk || sighash under bsk, after checking — as the verifier will — that bvk = [bsk] G_rcv equals cv_sum minus the value balances.
+    // amount: the components of the reference's I128Sum.  Empty (`Err(())`) when the balances do not match the accumulated commitments
+    // or a balance is i128::MIN.  Host only; `nonce`: the signature's 80 random bytes T (nullptr: from the operating system, as OsRng).
+    std::optional<std::array<uint8_t, 64>> binding_sig(const std::vector<std::pair<AssetType, I128>>& amount, const uint8_t sighash[32],
+                                                       const uint8_t* nonce = nullptr) const;
 
   private:
     friend class LocalTxProver;
@@ -268,6 +426,52 @@ class SaplingProvingContext {
     }
     Bytes32 bsk_, cv_sum_;
 };
+
+inline std::optional<std::array<uint8_t, 64>> SaplingProvingContext::binding_sig(const std::vector<std::pair<AssetType, I128>>& amount, const uint8_t sighash[32],
+                                                                                 const uint8_t* nonce) const {
+    // value_commitment_randomness_generator() as point bytes: v with the sign of u in the top bit
+    uint8_t uv[64];
+    masp_host_generator(3, uv);
+    Bytes32 g;
+    std::memcpy(g.data(), uv + 32, 32);
+    g[31] |= (uint8_t)((uv[0] & 1) << 7);
+    Bytes32 bvk;  // PublicKey::from_private(&bsk, G_rcv)
+    if (masp_host_jubjub_mul(g.data(), bsk_.data(), bvk.data()) != MASP_HOST_OK) return std::nullopt;
+    Bytes32 final_bvk = cv_sum_;
+    for (const auto& [asset, value] : amount) {
+        if (value.is_min()) return std::nullopt;
+        // masp_compute_value_balance: the asset's value commitment generator (its generator with the cofactor cleared) times |value|
+        Bytes32 gen, eight{}, vcg, vb, next;
+        eight[0] = 8;
+        const Bytes32 mag = value.magnitude();
+        if (masp_host_asset_generator(asset.identifier.data(), gen.data()) != MASP_HOST_OK || masp_host_jubjub_mul(gen.data(), eight.data(), vcg.data()) != MASP_HOST_OK ||
+            masp_host_jubjub_mul(vcg.data(), mag.data(), vb.data()) != MASP_HOST_OK ||
+            masp_host_jubjub_add(final_bvk.data(), vb.data(), value.negative() ? 0 : 1, next.data()) != MASP_HOST_OK)
+            return std::nullopt;
+        final_bvk = next;  // cv_sum minus the value balance (a negative balance: minus its negation)
+    }
+    if (bvk != final_bvk) return std::nullopt;  // "unless the provided valueBalance is wrong" (:313-316)
+    uint8_t msg[64];
+    std::memcpy(msg, bvk.data(), 32);
+    std::memcpy(msg + 32, sighash, 32);
+    // PrivateKey::sign (redjubjub.rs:138-160): T = 80 random bytes, r = H*(T || M), R = [r] G, S = r + H*(Rbar || M) bsk
+    uint8_t t[80];
+    if (nonce)
+        std::memcpy(t, nonce, 80);
+    else
+        detail::os_random(t, 80);
+    const detail::U256 r = detail::h_star(t, 80, msg, 64);
+    Bytes32 rb, rbar;
+    detail::store(r, rb.data());
+    if (masp_host_jubjub_mul(g.data(), rb.data(), rbar.data()) != MASP_HOST_OK) return std::nullopt;
+    detail::U256 sv = detail::fs_mul(detail::h_star(rbar.data(), 32, msg, 64), detail::load(bsk_.data()));
+    detail::add_in_place(sv, r);
+    if (detail::geq(sv, detail::JUBJUB_ORDER)) detail::sub_in_place(sv, detail::JUBJUB_ORDER);
+    std::array<uint8_t, 64> sig;
+    std::memcpy(sig.data(), rbar.data(), 32);
+    detail::store(sv, sig.data() + 32);
+    return sig;
+}
 
 // what one description of a transaction hands the prover: the arguments of the trait's methods after `ctx`
 struct SpendInfo {
@@ -367,6 +571,12 @@ class LocalTxProver {
         const ConvertInfo d{allowed_conversion, value, anchor, merkle_path, rcv};
         auto out = convert_proofs(ctx, &d, 1, rs);
         return out[0];
+    }
+
+    // = TxProver::binding_sig: all of it is the context's (sapling/prover.rs:279-326); no GPU work
+    std::optional<std::array<uint8_t, 64>> binding_sig(const SaplingProvingContext& ctx, const std::vector<std::pair<AssetType, I128>>& amount,
+                                                       const uint8_t sighash[32]) const {
+        return ctx.binding_sig(amount, sighash);
     }
 
     // ---- the descriptions of a whole transaction at once (see the head of this file).  Element i of the result is what the trait's

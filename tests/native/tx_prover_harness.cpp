@@ -79,7 +79,8 @@ static Bytes32 unhex32(const std::string& s) {
     return b;
 }
 
-// lines "add <a> <b>", "sub <a> <b>" (jubjub::Fr, 64 hex digits each, little-endian bytes), "pack <32 bytes>", "random <count>"
+// lines "add <a> <b>", "sub <a> <b>", "mul <a> <b>" (jubjub::Fr, 64 hex digits each, little-endian bytes), "pack <32 bytes>", "hstar <a> <b>",
+// "sig ..." (a binding signature with a given nonce), "random <count>"
 static int selftest(const char* path) {
     std::ifstream f(path);
     std::string line;
@@ -96,6 +97,40 @@ static int selftest(const char* path) {
             uint8_t out[64];
             detail::multipack32(unhex32(a).data(), out);
             std::printf("pack %s %s\n", hex(out, 32).c_str(), hex(out + 32, 32).c_str());
+        } else if (op == "hstar") {  // H*(a || b) of RedJubjub: two byte strings of any length as hex ("-" = empty)
+            in >> a >> b;
+            auto bytes = [](const std::string& x) {
+                std::vector<uint8_t> v;
+                if (x != "-")
+                    for (size_t i = 0; i + 1 < x.size(); i += 2) v.push_back((uint8_t)std::stoul(x.substr(i, 2), nullptr, 16));
+                return v;
+            };
+            const std::vector<uint8_t> va = bytes(a), vb = bytes(b);
+            Bytes32 r;
+            detail::store(detail::h_star(va.data(), va.size(), vb.data(), vb.size()), r.data());
+            std::printf("hstar %s\n", hex(r.data(), 32).c_str());
+        } else if (op == "mul") {
+            in >> a >> b;
+            Bytes32 r;
+            detail::store(detail::fs_mul(detail::load(unhex32(a).data()), detail::load(unhex32(b).data())), r.data());
+            std::printf("mul %s\n", hex(r.data(), 32).c_str());
+        } else if (op == "sig") {  // sig <bsk> <cv_sum> <sighash> <nonce: 80 bytes> <n> n x (<asset identifier> <value: 16 bytes>)
+            std::string cv, sh, nonce;
+            int n = 0;
+            in >> a >> cv >> sh >> nonce >> n;
+            std::vector<std::pair<AssetType, I128>> amount;
+            for (int i = 0; i < n; ++i) {
+                std::string id, val;
+                in >> id >> val;
+                I128 v;
+                for (int k = 0; k < 16; ++k) v.le[k] = (uint8_t)std::stoul(val.substr(2 * k, 2), nullptr, 16);
+                amount.push_back({AssetType{unhex32(id)}, v});
+            }
+            uint8_t t[80];
+            for (int k = 0; k < 80; ++k) t[k] = (uint8_t)std::stoul(nonce.substr(2 * k, 2), nullptr, 16);
+            const SaplingProvingContext ctx = SaplingProvingContext::from_parts(unhex32(a), unhex32(cv));
+            const auto sig = ctx.binding_sig(amount, unhex32(sh).data(), t);
+            std::printf("sig %s\n", sig ? hex(sig->data(), 64).c_str() : "None");
         } else if (op == "random") {
             int n = 0, bad = 0, distinct = 1;
             in >> n;

@@ -158,6 +158,60 @@ def _run_case(tmp_path, lp, descs, rs, mode, batch_cap, threads):
     return recs, got[-64:-32], got[-32:], run.stdout
 
 
+def test_binding_sig_in_cxx_is_the_python_mirrors_signature_and_verifies(tmp_path):
+    """masp::SaplingProvingContext::binding_sig (= sapling/prover.rs:279-326; RedJubjub of masp_primitives/src/sapling/redjubjub.rs:138-160
+    with BLAKE2b-512 and jubjub::Fr arithmetic inside the header): with the same 80-byte nonce it is byte for byte the Python mirror's
+    signature, it verifies under the key the verifier reconstructs, and the reference's three Err(()) cases come back empty.  H* and the
+    multiplication mod the Jubjub order are also compared on their own (message lengths around BLAKE2b's 128-byte block)."""
+    from masp_amd import host as H
+    from masp_amd import redjubjub as RJS
+    from masp_amd.prover import SaplingProvingContext
+    exe = _build(str(tmp_path / "harness"))
+    RJ = H.JUBJUB_ORDER
+    rng = random.Random(4)
+    lines, want = [], []
+    for la, lb in ((0, 0), (80, 64), (32, 64), (127, 1), (128, 0), (129, 300), (256, 5), (1, 127), (64, 64)):
+        a, b = bytes(rng.getrandbits(8) for _ in range(la)), bytes(rng.getrandbits(8) for _ in range(lb))
+        lines.append("hstar %s %s" % (a.hex() or "-", b.hex() or "-"))
+        want.append("hstar " + _b32(RJS.h_star(a, b)).hex())
+    for a, b in [(RJ - 1, RJ - 1), (0, 5), (1, RJ - 1)] + [(rng.randrange(RJ), rng.randrange(RJ)) for _ in range(20)]:
+        lines.append("mul %s %s" % (_b32(a).hex(), _b32(b).hex()))
+        want.append("mul " + _b32(a * b % RJ).hex())
+    A, B = H.asset_identifier(b"asset A"), H.asset_identifier(b"asset B")
+    v1, v2, v3 = 1000, 250, 7
+    rcv = [rng.randrange(1, RJ) for _ in range(3)]
+    ctx = SaplingProvingContext()                            # spend(v1, A) + spend(v3, B) - output(v2, A), as tests/test_binding_sig.py
+    ctx._spend_like(rcv[0], H.value_commitment(A, v1, rcv[0])[0])
+    ctx._output(rcv[1], H.value_commitment(A, v2, rcv[1])[0])
+    ctx._spend_like(rcv[2], H.value_commitment(B, v3, rcv[2])[0])
+    ctx2 = SaplingProvingContext()                           # outputs only: a negative balance
+    ctx2._output(rcv[1], H.value_commitment(A, v2, rcv[1])[0])
+    sighash, T = bytes(rng.getrandbits(8) for _ in range(32)), bytes(rng.getrandbits(8) for _ in range(80))
+
+    def line(c, amount):
+        return "sig %s %s %s %s %d %s" % (_b32(c.bsk).hex(), bytes(c.cv_sum).hex(), sighash.hex(), T.hex(), len(amount),
+                                          " ".join("%s %s" % (bytes(a).hex(), (v % (1 << 128)).to_bytes(16, "little").hex()) for a, v in amount))
+    sigs = []
+    for c, amount in ((ctx, [(A, v1 - v2), (B, v3)]), (ctx2, [(A, -v2)])):
+        lines.append(line(c, amount))
+        sigs.append((c, c.binding_sig(amount, sighash, rng=lambda n: T)))
+        want.append("sig " + sigs[-1][1].hex())
+    for amount in ([(A, v1 - v2 + 1), (B, v3)], [(A, v1 - v2)], [(A, -(1 << 127))]):      # wrong balance, a missing asset, i128::MIN
+        lines.append(line(ctx, amount))
+        want.append("sig None")
+    vec = tmp_path / "vectors.txt"
+    vec.write_text("\n".join(lines) + "\n")
+    out = subprocess.run([exe, "--selftest", str(vec)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "selftest ok" in out.stdout, out.stdout + out.stderr
+    got = out.stdout.splitlines()
+    for g, w, l in zip(got, want, lines):
+        assert g == w, l[:80]
+    g_rcv = H.point_bytes(*H.generator_uv(3))
+    for (c, sig), g in zip(sigs, [x for x in got if x.startswith("sig ") and x != "sig None"]):
+        bvk = RJS.public_key(c.bsk, g_rcv)
+        assert RJS.verify(bvk, bvk + sighash, bytes.fromhex(g[4:]), g_rcv)
+
+
 @pytest.mark.gpu
 def test_a_cxx_program_holds_a_local_tx_prover_and_gets_the_python_mirrors_bytes(tmp_path):
     """trait TxProver, one description at a time (mode 0), then the same descriptions through the batch methods in batches of 8 on four
