@@ -4,6 +4,7 @@
 // Mirrors, name for name, what a user of the reference holds (citations relative to /root/reference):
 //   masp::LocalTxProver            = masp_proofs::prover::LocalTxProver               masp_proofs/src/prover.rs:27-33,55-95,156-261
 //     ::from_bytes / ::from_paths  = LocalTxProver::from_bytes / ::new                prover.rs:81-95 / :55-64
+//     ::with_default_location      = LocalTxProver::with_default_location             prover.rs:120-136
 //     ::new_sapling_proving_context, ::spend_proof, ::output_proof, ::convert_proof, ::binding_sig
 //                                  = trait TxProver                                   masp_primitives/src/sapling/prover.rs:17-83
 //   masp::SaplingProvingContext    = masp_proofs::sapling::SaplingProvingContext (bsk, cv_sum)   masp_proofs/src/sapling/prover.rs:26-47
@@ -20,7 +21,8 @@
 // binding_sig (sapling/prover.rs:279-326) — RedJubjub over the context's bsk / cv_sum; it does not touch the GPU prover (SURVEY.md §8b
 // "Not touched by the build") and is here so that the trait is whole: BLAKE2b-512 and jubjub::Fr arithmetic in this header, the curve
 // through libmasp_host.
-// The parameter digests (lib.rs:351-388) stay with the caller as SURVEY.md §8b has it ("No hashing here").
+// The C ABI does no hashing; this layer does what `load_parameters` / `parse_parameters` do (lib.rs:278-388): file sizes before
+// any large read, the BLAKE2b-512 digest of every file against LocalTxProverConfig::expected (default: the pinned MPC files).
 //
 // Thread-safe like the reference's `&self` methods: one LocalTxProver may be shared by several threads, each with its own context.
 #ifndef MASP_TX_PROVER_HPP
@@ -514,11 +516,30 @@ struct BlindingScalars {
     Bytes32 r, s;
 };
 
+// What `load_parameters` / `parse_parameters` hold a parameter file against (masp_proofs/src/lib.rs:278-328, :333-388): its size, checked
+// before anything is read, and the BLAKE2b-512 digest of the whole file (body + MPC transcript).
+struct ExpectedParameters {
+    size_t bytes;
+    const char* blake2b_hex;  // 128 hex digits
+};
+struct ExpectedParameterSet {
+    ExpectedParameters spend, output, convert;
+};
+// the MPC parameters the reference pins: MASP_{SPEND,OUTPUT,CONVERT}_{HASH,BYTES} (lib.rs:60-76)
+inline const ExpectedParameterSet& masp_mpc_parameters() {
+    static const ExpectedParameterSet set = {
+        {49848572, "196e7c717f25e16653431559ce2c8816e750a4490f98696e3c031efca37e25e0647182b7b013660806db11eb2b1e365fb2d6a0f24dbbd9a4a8314fef10a7cba2"},
+        {16398620, "eafc3b1746cccc8b9eed2b69395692c5892f6aca83552a07dceb2dcbaa64dcd0e22434260b3aa3b049b633a08b008988cbe0d31effc77e2bc09bfab690a23724"},
+        {22570940, "dc4aaf3c3ce056ab448b6c4a7f43c1d68502c2902ea89ab8769b1524a2e8ace9a5369621a73ee1daa52aec826907a19974a37874391cf8f11bbe0b0420de1ab7"}};
+    return set;
+}
+
 struct LocalTxProverConfig {
     int device = 0;
     bool self_verify = true;                    // sapling/prover.rs:148,266 (tests of the failure paths switch it off)
     const masp_hip_options* options = nullptr;  // slots, batch_cap, ... (nullptr: the library's defaults)
     unsigned threads = 0;                       // synthesis threads of the *_proofs batch methods (0: the CPUs this process may use)
+    const ExpectedParameterSet* expected = &masp_mpc_parameters();  // nullptr: parameters that are not the MPC files (benches, tests)
     bool trace = false;                         // one line per batch on stderr: when it was synthesised, got a slot, was proved, verified, committed
 };
 
@@ -536,12 +557,33 @@ class LocalTxProver {
                                                      const Config& cfg = Config()) {
         std::vector<uint8_t> b[3];
         const std::string* p[3] = {&spend_path, &output_path, &convert_path};
+        static const char* names[3] = {"masp spend", "masp output", "masp convert"};
         for (int i = 0; i < 3; ++i) {
-            std::ifstream f(*p[i], std::ios::binary);
+            std::ifstream f(*p[i], std::ios::binary | std::ios::ate);
             if (!f) throw Panic("cannot open " + *p[i]);  // (the reference: File::open(..).expect(..), lib.rs:284-288)
-            b[i].assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+            const std::streamoff size = f.tellg();
+            if (cfg.expected) {  // verify_file_size (lib.rs:409-430): the file system's word, before any large read
+                const ExpectedParameters& e = i == 0 ? cfg.expected->spend : i == 1 ? cfg.expected->output : cfg.expected->convert;
+                if ((size_t)size != e.bytes)
+                    throw Panic(std::string(names[i]) + " parameters " + *p[i] + ": " + std::to_string((long long)size) + " bytes on disk, expected " + std::to_string(e.bytes));
+            }
+            f.seekg(0);
+            b[i].resize((size_t)size);
+            f.read(reinterpret_cast<char*>(b[i].data()), size);
+            if (!f) throw Panic("cannot read " + *p[i]);
         }
         return from_bytes(b[0].data(), b[0].size(), b[1].data(), b[1].size(), b[2].data(), b[2].size(), cfg);
+    }
+    // = LocalTxProver::with_default_location (prover.rs:120-136): the three files in default_params_folder() (lib.rs:100-108; this image's
+    // platform: ~/.masp-params), or nullptr when the folder or one of them is missing
+    static std::unique_ptr<LocalTxProver> with_default_location(const Config& cfg = Config()) {
+        const char* home = std::getenv("HOME");
+        if (!home || !*home) return nullptr;
+        const std::string dir = std::string(home) + "/.masp-params/";
+        const std::string p[3] = {dir + "masp-spend.params", dir + "masp-output.params", dir + "masp-convert.params"};
+        for (const std::string& x : p)
+            if (!std::ifstream(x, std::ios::binary)) return nullptr;
+        return from_paths(p[0], p[1], p[2], cfg);
     }
     ~LocalTxProver() { release(); }
     LocalTxProver(const LocalTxProver&) = delete;
@@ -663,6 +705,27 @@ class LocalTxProver {
   private:
     LocalTxProver(const uint8_t* spend, size_t spend_len, const uint8_t* output, size_t output_len, const uint8_t* convert, size_t convert_len, const Config& cfg)
         : cfg_(cfg) {
+        if (cfg.expected) {  // verify_hash (lib.rs:439-487): size and BLAKE2b-512 of the whole stream; the reference panics on a mismatch
+            const uint8_t* blob[3] = {spend, output, convert};
+            const size_t len[3] = {spend_len, output_len, convert_len};
+            const ExpectedParameters* e[3] = {&cfg.expected->spend, &cfg.expected->output, &cfg.expected->convert};
+            static const char* names[3] = {"masp spend", "masp output", "masp convert"};
+            for (int k = 0; k < 3; ++k) {
+                if (len[k] != e[k]->bytes) throw Panic(std::string(names[k]) + " parameters: " + std::to_string(len[k]) + " bytes, expected " + std::to_string(e[k]->bytes));
+                const char zero[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                detail::Blake2b512 h(zero);
+                h.update(blob[k], len[k]);
+                uint8_t d[64];
+                h.finish(d);
+                static const char* hexd = "0123456789abcdef";
+                std::string got;
+                for (uint8_t x : d) {
+                    got += hexd[x >> 4];
+                    got += hexd[x & 15];
+                }
+                if (got != e[k]->blake2b_hex) throw Panic(std::string(names[k]) + " parameters: BLAKE2b-512 digest " + got + ", expected " + e[k]->blake2b_hex);
+            }
+        }
         masp_hip_options opt;
         if (cfg.options) {
             opt = *cfg.options;

@@ -3,6 +3,7 @@
 // and compares what it wrote with the Python mirror's results and the oracle's proofs.
 //
 //   tx_prover_harness --selftest <file>      CPU only: the header's scalar helpers on the vectors of <file>, results as hex lines
+//   tx_prover_harness --load <3 paths> 3 x (<bytes> <digest>)   LocalTxProver::from_paths against expected sizes and digests ("mpc": the pinned ones)
 //   tx_prover_harness <case.bin> <out.bin>   one MI355X: see the format below
 //
 // case.bin (little-endian):  "MTP1" | 3 x (u64 length, Parameters bytes: spend, output, convert) | u32 self_verify | u32 threads |
@@ -144,6 +145,13 @@ static int selftest(const char* path) {
             std::printf("random %d canonical %d distinct %d\n", n, n - bad, distinct);
         }
     }
+    {   // with_default_location: no folder, no prover (and no panic)
+        const char* home = std::getenv("HOME");
+        const std::string keep = home ? home : "";
+        setenv("HOME", "/nonexistent-masp-home", 1);
+        std::printf("default location %s\n", LocalTxProver::with_default_location() ? "found" : "none");
+        setenv("HOME", keep.c_str(), 1);
+    }
     SaplingProvingContext ctx;  // zero and the identity
     std::printf("context %s %s\n", hex(ctx.bsk().data(), 32).c_str(), hex(ctx.cv_sum().data(), 32).c_str());
     std::printf("selftest ok\n");
@@ -164,6 +172,20 @@ struct Record {
 
 int main(int argc, char** argv) {
     if (argc == 3 && std::string(argv[1]) == "--selftest") return selftest(argv[2]);
+    if (argc == 11 && std::string(argv[1]) == "--load") {  // --load <spend> <output> <convert> 3 x (<bytes> <blake2b hex>): LocalTxProver::from_paths
+        ExpectedParameterSet e;
+        ExpectedParameters* slot[3] = {&e.spend, &e.output, &e.convert};
+        for (int k = 0; k < 3; ++k) *slot[k] = ExpectedParameters{(size_t)std::strtoull(argv[5 + 2 * k], nullptr, 10), argv[6 + 2 * k]};
+        LocalTxProver::Config cfg;
+        cfg.expected = std::string(argv[5]) == "mpc" ? &masp_mpc_parameters() : &e;
+        try {
+            auto p = LocalTxProver::from_paths(argv[2], argv[3], argv[4], cfg);
+            std::printf("loaded\n");
+        } catch (const Panic& x) {
+            std::printf("panic at load: %s\n", x.what());
+        }
+        return 0;
+    }
     if (argc != 3) {
         std::fprintf(stderr, "usage: %s <case.bin> <out.bin> | --selftest <file>\n", argv[0]);
         return 2;
@@ -187,6 +209,7 @@ int main(int argc, char** argv) {
     opt.struct_size = sizeof opt;
     opt.batch_cap = (int32_t)rd.num<uint32_t>();
     cfg.options = &opt;
+    cfg.expected = nullptr;  // the case's parameters are synthetic
     cfg.trace = std::getenv("MASP_TXP_TRACE") != nullptr;
     const uint32_t mode = rd.num<uint32_t>(), n = rd.num<uint32_t>();
     std::vector<Record> recs(n);

@@ -61,7 +61,8 @@ def test_the_header_compiles_as_strict_cxx17_and_its_scalar_helpers_agree_with_p
         assert got[k] == "pack %s %s" % (_b32(want[0]).hex(), _b32(want[1]).hex()), p.hex()
         k += 1
     assert got[k] == "random 2000 canonical 2000 distinct 2000"
-    assert got[k + 1] == "context %s %s" % (_b32(0).hex(), H.JUBJUB_IDENTITY.hex())
+    assert got[k + 1] == "default location none"              # with_default_location (prover.rs:120-136): None without the folder
+    assert got[k + 2] == "context %s %s" % (_b32(0).hex(), H.JUBJUB_IDENTITY.hex())
 
 
 def _record(kind, kw, r, s):
@@ -212,6 +213,39 @@ def test_binding_sig_in_cxx_is_the_python_mirrors_signature_and_verifies(tmp_pat
         assert RJS.verify(bvk, bvk + sighash, bytes.fromhex(g[4:]), g_rcv)
 
 
+def _load(exe, paths, expected):
+    args = [exe, "--load"] + [str(p) for p in paths]
+    for n, hx in expected:
+        args += [str(n), hx]
+    return subprocess.run(args, capture_output=True, text=True, timeout=600).stdout.strip()
+
+
+def test_from_paths_checks_sizes_then_digests_before_it_touches_a_device(tmp_path):
+    """masp::LocalTxProver::from_paths = LocalTxProver::new = load_parameters (lib.rs:278-328): the file sizes first, from the file system,
+    then the BLAKE2b-512 digest of every whole file (parse_parameters, lib.rs:351-388); the reference panics on a mismatch, this throws
+    masp::Panic — before any device is touched (here, without a GPU, correct files get as far as "no usable HIP device")."""
+    import hashlib
+    exe = _build(str(tmp_path / "harness"))
+    rng = random.Random(6)
+    blobs = [bytes(rng.getrandbits(8) for _ in range(5000 + 300 * i)) for i in range(3)]
+    paths = []
+    for i, b in enumerate(blobs):
+        paths.append(tmp_path / ("p%d.params" % i))
+        paths[-1].write_bytes(b)
+    good = [(len(b), hashlib.blake2b(b, digest_size=64).hexdigest()) for b in blobs]
+    out = _load(exe, paths, good)
+    assert out == "loaded" or "no usable HIP device" in out or "masp_hip_circuit_load" in out, out     # (random bytes are no Parameters on a GPU box)
+    out = _load(exe, paths, [good[0], (good[1][0] + 1, good[1][1]), good[2]])
+    assert out.startswith("panic at load: masp output parameters") and "5300 bytes on disk, expected 5301" in out, out
+    out = _load(exe, paths, [good[0], good[1], (good[2][0], good[0][1])])
+    assert out.startswith("panic at load: masp convert parameters: BLAKE2b-512 digest " + good[2][1] + ", expected " + good[0][1]), out
+    out = _load(exe, paths, [("mpc", "-")] + good[1:])           # the default: the pinned MPC files (MASP_SPEND_BYTES, lib.rs:60-76)
+    assert "5000 bytes on disk, expected 49848572" in out, out
+    from masp_amd import params as P
+    from masp_tx_prover_constants import constants                # the header's pinned sizes and digests are the Python mirror's
+    assert constants() == [(P.EXPECTED[k].bytes, P.EXPECTED[k].hash) for k in P.KINDS]
+
+
 @pytest.mark.gpu
 def test_a_cxx_program_holds_a_local_tx_prover_and_gets_the_python_mirrors_bytes(tmp_path):
     """trait TxProver, one description at a time (mode 0), then the same descriptions through the batch methods in batches of 8 on four
@@ -243,6 +277,14 @@ def test_a_cxx_program_holds_a_local_tx_prover_and_gets_the_python_mirrors_bytes
         assert w[1] == O.create_proof(O.Params(lp.parameters[kind]), cs, inputs, aux, r, s), kind
     assert seen == {"spend", "output", "convert"}
     lp.close()                                               # (its parameter bytes stay: the harness loads them into a context of its own)
+    import hashlib
+    paths = []
+    for k in ("spend", "output", "convert"):                  # LocalTxProver::new on files with the right sizes and digests, then with a wrong one
+        paths.append(tmp_path / (k + ".params"))
+        paths[-1].write_bytes(lp.parameters[k].tobytes())
+    good = [(lp.parameters[k].size, hashlib.blake2b(lp.parameters[k].tobytes(), digest_size=64).hexdigest()) for k in ("spend", "output", "convert")]
+    assert _load(_build(), paths, good) == "loaded"
+    assert "BLAKE2b-512 digest" in _load(_build(), paths, [good[0], (good[1][0], good[0][1]), good[2]])
     for mode, cap, threads in ((0, 0, 1), (1, 8, 4)):
         recs, got_bsk, got_cv_sum, log = _run_case(tmp_path, lp, descs, rs, mode, cap, threads)
         for i, (g, w) in enumerate(zip(recs, want)):
