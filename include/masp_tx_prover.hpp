@@ -38,6 +38,7 @@
 #include <cstring>
 #include <deque>
 #include <fstream>
+#include <functional>
 #include <future>
 #include <memory>
 #include <mutex>
@@ -534,6 +535,9 @@ inline const ExpectedParameterSet& masp_mpc_parameters() {
     return set;
 }
 
+// the builder's `Progress` notifications (builder.rs:946-952): descriptions of the call done so far, of how many
+using Progress = std::function<void(size_t done, size_t total)>;
+
 struct LocalTxProverConfig {
     int device = 0;
     bool self_verify = true;                    // sapling/prover.rs:148,266 (tests of the failure paths switch it off)
@@ -623,11 +627,12 @@ class LocalTxProver {
 
     // ---- the descriptions of a whole transaction at once (see the head of this file).  Element i of the result is what the trait's
     // method returns for description i; `rs`: n explicit (r, s) pairs or nullptr ----
-    std::vector<std::optional<SpendProof>> spend_proofs(SaplingProvingContext& ctx, const SpendInfo* d, size_t n, const BlindingScalars* rs = nullptr) {
+    std::vector<std::optional<SpendProof>> spend_proofs(SaplingProvingContext& ctx, const SpendInfo* d, size_t n, const BlindingScalars* rs = nullptr,
+                                                        const Progress& progress = nullptr) {
         std::vector<std::optional<SpendProof>> out(n);
         for (size_t i = 0; i < n; ++i) ctx.bsk_add(d[i].rcv, false);  // sapling/prover.rs:69-75, before anything can fail
         std::vector<Bytes32> rk(n), nf(n);
-        run<SpendInfo>(MASP_HIP_SPEND, ctx, false, d, n, rs,
+        run<SpendInfo>(MASP_HIP_SPEND, ctx, false, d, n, rs, progress,
                        [&](size_t lo, size_t cnt, uint8_t* inputs, uint8_t* aux, Bytes32* cv, int* rc) {
                            std::vector<masp_host_spend_job> jobs(cnt);
                            for (size_t k = 0; k < cnt; ++k) {
@@ -651,10 +656,11 @@ class LocalTxProver {
                        [&](size_t i, const GrothProofBytes& zk, const Bytes32& cv) { out[i] = SpendProof{zk, cv, rk[i]}; });  // (cv_sum += cv, :154: by `run`)
         return out;
     }
-    std::vector<std::optional<ValueProof>> output_proofs(SaplingProvingContext& ctx, const OutputInfo* d, size_t n, const BlindingScalars* rs = nullptr) {
+    std::vector<std::optional<ValueProof>> output_proofs(SaplingProvingContext& ctx, const OutputInfo* d, size_t n, const BlindingScalars* rs = nullptr,
+                                                         const Progress& progress = nullptr) {
         std::vector<std::optional<ValueProof>> out(n);
         for (size_t i = 0; i < n; ++i) ctx.bsk_add(d[i].rcv, true);  // :177-183
-        run<OutputInfo>(MASP_HIP_OUTPUT, ctx, true, d, n, rs,
+        run<OutputInfo>(MASP_HIP_OUTPUT, ctx, true, d, n, rs, progress,
                         [&](size_t lo, size_t cnt, uint8_t* inputs, uint8_t* aux, Bytes32* cv, int* rc) {
                             for (size_t k = 0; k < cnt; ++k) {
                                 const OutputInfo& x = d[lo + k];
@@ -668,10 +674,11 @@ class LocalTxProver {
                         [&](size_t i, const GrothProofBytes& zk, const Bytes32& cv) { out[i] = ValueProof{zk, cv}; });  // (cv_sum -= cv, :205: by `run`)
         return out;
     }
-    std::vector<std::optional<ValueProof>> convert_proofs(SaplingProvingContext& ctx, const ConvertInfo* d, size_t n, const BlindingScalars* rs = nullptr) {
+    std::vector<std::optional<ValueProof>> convert_proofs(SaplingProvingContext& ctx, const ConvertInfo* d, size_t n, const BlindingScalars* rs = nullptr,
+                                                          const Progress& progress = nullptr) {
         std::vector<std::optional<ValueProof>> out(n);
         for (size_t i = 0; i < n; ++i) ctx.bsk_add(d[i].rcv, false);  // :228-234
-        run<ConvertInfo>(MASP_HIP_CONVERT, ctx, false, d, n, rs,
+        run<ConvertInfo>(MASP_HIP_CONVERT, ctx, false, d, n, rs, progress,
                          [&](size_t lo, size_t cnt, uint8_t* inputs, uint8_t* aux, Bytes32* cv, int* rc) {
                              std::vector<masp_host_convert_job> jobs(cnt);
                              for (size_t k = 0; k < cnt; ++k) {
@@ -690,6 +697,47 @@ class LocalTxProver {
                          3,
                          [&](size_t i, const GrothProofBytes& zk, const Bytes32& cv) { out[i] = ValueProof{zk, cv}; });  // (cv_sum += cv, :272: by `run`)
         return out;
+    }
+
+    // Pay at load time what the first batches otherwise pay in their own latency: every slot's device scratch at its final size (one
+    // launch sequence of batch_cap proofs per slot over a witness of zeros: the scratch does not depend on the witness) and the
+    // page-locked slabs a call over that many descriptions keeps in flight.  No counterpart in the reference (bellperson allocates per
+    // proof); = masp_amd/prover.py LocalTxProver.warm_up.
+    void warm_up(size_t spends, size_t outputs = 0, size_t converts = 0) {
+        const size_t want[3] = {spends, outputs, converts};
+        for (int kind = 0; kind < 3; ++kind) {
+            if (!want[kind]) continue;
+            const size_t batches = (want[kind] + batch_cap_ - 1) / batch_cap_, slabs = std::min(batches, slots_ + 3);
+            std::vector<uint8_t*> held;
+            for (size_t i = 0; i < slabs; ++i) held.push_back(slab_take(kind));  // (page-locks what the pool does not hold yet)
+            const size_t np = std::min(batch_cap_, want[kind]);
+            std::memset(held[0], 0, np * 32 * (size_t)n_aux_[kind]);  // Montgomery zero = canonical zero
+            std::vector<uint8_t> inputs(32 * (size_t)n_inputs_[kind], 0);
+            inputs[0] = 1;  // ONE
+            std::vector<masp_hip_job> jobs(np);
+            for (size_t k = 0; k < np; ++k) {
+                std::memset(&jobs[k], 0, sizeof jobs[k]);
+                jobs[k].circuit = (uint32_t)kind;
+                jobs[k].inputs = inputs.data();
+                jobs[k].aux = held[0] + k * 32 * (size_t)n_aux_[kind];
+                jobs[k].aux_form = MASP_HIP_AUX_MONTGOMERY;
+                jobs[k].r[0] = 1;
+                jobs[k].s[0] = 2;
+            }
+            std::vector<std::future<int>> calls;  // `slots` calls side by side: each lands on a slot of its own
+            for (size_t c = 0; c < std::min(slots_, batches); ++c)
+                calls.push_back(std::async(std::launch::async, [this, &jobs]() {
+                    std::vector<uint8_t> proofs(GROTH_PROOF_SIZE * jobs.size());
+                    return masp_hip_prove_batch(ctx_, jobs.size(), jobs.data(), proofs.data());
+                }));
+            int rc = MASP_HIP_OK;
+            for (auto& c : calls) {
+                const int r = c.get();
+                if (r != MASP_HIP_OK) rc = r;
+            }
+            for (uint8_t* p : held) slab_give(kind, p);
+            if (rc != MASP_HIP_OK) throw Panic(detail::hip_error(ctx_, rc, "warm_up"));
+        }
     }
 
     // a uniform bls12_381::Scalar as 32 canonical bytes from the operating system's generator (the reference: OsRng, sapling/prover.rs:66)
@@ -828,7 +876,8 @@ class LocalTxProver {
     //   commit(i, zkproof, cv): description i proved (and verified); called in order of i, from the calling thread; the context's
     //   cv_sum takes the batch's commitments right after (+ or -: subtract_cv)
     template <class Info, class Synth, class PublicInput, class Commit>
-    void run(int kind, SaplingProvingContext& ctx, bool subtract_cv, const Info*, size_t n, const BlindingScalars* rs, Synth synth, PublicInput public_input,
+    void run(int kind, SaplingProvingContext& ctx, bool subtract_cv, const Info*, size_t n, const BlindingScalars* rs, const Progress& progress, Synth synth,
+             PublicInput public_input,
              uint32_t n_public, Commit commit) {
         struct Batch {
             size_t lo = 0, cnt = 0;
@@ -864,6 +913,7 @@ class LocalTxProver {
                     commit(b->lo + k, zk, b->cv[k]);
                 }
             if (b->any_valid) ctx.cv_add(b->cv_partial, subtract_cv);  // cv_sum after the self-check (sapling/prover.rs:154,205,272)
+            if (progress) progress(b->lo + b->cnt, n);
             b->t[5] = now();
             if (cfg_.trace)
                 std::fprintf(stderr, "batch at %zu (%zu): synthesis %.3f - %.3f, slot %.3f, proved %.3f, verified %.3f, committed %.3f\n", b->lo, b->cnt, b->t[0], b->t[1], b->t[2],

@@ -8,7 +8,7 @@
 //
 // case.bin (little-endian):  "MTP1" | 3 x (u64 length, Parameters bytes: spend, output, convert) | u32 self_verify | u32 threads |
 //   u32 batch_cap (0: default) | u32 mode (0: the trait's methods one description at a time, in file order; 1: spend_proofs /
-//   output_proofs / convert_proofs over all descriptions of a kind; 2: as 1, then the Spend descriptions again, timed) | u32 n | n records:
+//   output_proofs / convert_proofs over all descriptions of a kind; 2: warm_up, then all Spend descriptions through spend_proofs twice, timed) | u32 n | n records:
 //     u32 kind (0 spend, 1 output, 2 convert), then
 //     spend:   ak nsk diversifier[11] rcm ar asset value:u64 anchor path[32][32] position:u64 rcv r s
 //     output:  esk diversifier[11] pk_d rcm asset value:u64 rcv r s
@@ -281,7 +281,7 @@ int main(int argc, char** argv) {
                 std::printf("panic: %s\n", e.what());
             }
         }
-    } else {   // modes 1 and 2
+    } else if (mode == 1) {
         std::vector<size_t> at[3];
         for (size_t i = 0; i < recs.size(); ++i) at[recs[i].kind].push_back(i);
         std::vector<SpendInfo> sp;
@@ -296,7 +296,14 @@ int main(int argc, char** argv) {
                 if (k == 2) co.push_back(recs[i].convert);
             }
         try {
-            const auto a = prover->spend_proofs(ctx, sp.data(), sp.size(), rs[0].data());
+            prover->warm_up(sp.size(), ou.size(), co.size());  // every slot's scratch and the page-locked slabs, before the first real call
+            size_t calls = 0, last = 0;
+            const auto a = prover->spend_proofs(ctx, sp.data(), sp.size(), rs[0].data(), [&](size_t done, size_t total) {
+                ++calls;
+                last = done;
+                (void)total;
+            });
+            std::printf("progress: %zu calls, last %zu of %zu\n", calls, last, sp.size());
             for (size_t q = 0; q < a.size(); ++q)
                 if (a[q]) recs[at[0][q]].status = 1, recs[at[0][q]].zk = a[q]->zkproof, recs[at[0][q]].cv = a[q]->cv, recs[at[0][q]].rk = a[q]->rk;
             const auto b = prover->output_proofs(ctx, ou.data(), ou.size(), rs[1].data());
@@ -311,19 +318,27 @@ int main(int argc, char** argv) {
         }
     }
     if (mode == 2) {
-        // the Spend descriptions once more, twice, with blinding scalars from the system's generator: the first pass sizes whatever the
-        // pass above left unsized (every slot's scratch), the second is timed — host to host, synthesis and self-checks included
+        // all Spend descriptions of the case through spend_proofs, blinding scalars from the system's generator, timed host to host
+        // (synthesis and self-checks included): the first call of the prover after warm_up(), then a second one
         std::vector<SpendInfo> sp;
         for (const Record& r : recs)
             if (r.kind == MASP_HIP_SPEND) sp.push_back(r.spend);
+        auto t0 = std::chrono::steady_clock::now();
+        prover->warm_up(sp.size());
+        std::printf("warm_up: %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         for (int pass = 0; pass < 2; ++pass) {
             SaplingProvingContext c2 = prover->new_sapling_proving_context();
-            const auto t0 = std::chrono::steady_clock::now();
-            const auto got = prover->spend_proofs(c2, sp.data(), sp.size());
+            size_t calls = 0, last = 0;
+            t0 = std::chrono::steady_clock::now();
+            const auto got = prover->spend_proofs(c2, sp.data(), sp.size(), nullptr, [&](size_t done, size_t total) {
+                ++calls;
+                last = done == total ? done : last;
+            });
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             size_t ok = 0;
             for (const auto& g : got) ok += g.has_value();
-            std::printf("%s: %zu Spend descriptions, %zu proofs in %.3f s = %.1f proofs/s\n", pass ? "timed" : "warm-up", sp.size(), ok, dt, ok / dt);
+            std::printf("%s: %zu Spend descriptions, %zu proofs in %.3f s = %.1f proofs/s (progress called %zu times, last %zu)\n", pass ? "timed" : "first call",
+                        sp.size(), ok, dt, ok / dt, calls, last);
         }
     }
     std::ofstream out(argv[2], std::ios::binary);
@@ -340,6 +355,6 @@ int main(int argc, char** argv) {
     out.write(reinterpret_cast<const char*>(ctx.bsk().data()), 32);
     out.write(reinterpret_cast<const char*>(ctx.cv_sum().data()), 32);
     out.close();
-    std::printf("descriptions %u: Some %zu, None %zu, Panic %zu\n", n, some, none, panics);
+    if (mode != 2) std::printf("descriptions %u: Some %zu, None %zu, Panic %zu\n", n, some, none, panics);  // (mode 2 keeps no results)
     return 0;
 }

@@ -292,5 +292,5 @@ def test_a_cxx_program_holds_a_local_tx_prover_and_gets_the_python_mirrors_bytes
             assert g[1:] == w[1:], "description %d (%s), mode %d: bytes differ from the Python mirror" % (i, descs[i][0], mode)
         assert got_bsk == bsk and got_cv_sum == cv_sum, "mode %d: the context differs" % mode
         assert "Some %d, None 3, Panic 0" % (len(descs) - 3) in log
-        if mode == 1:
-            assert "batch_cap 8" in log
+        if mode == 1:                                            # 21 Spend descriptions in batches of 8: the builder's Progress after each
+            assert "batch_cap 8" in log and "progress: 3 calls, last 21 of 21" in log, log
