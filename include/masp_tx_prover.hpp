@@ -393,6 +393,33 @@ inline std::string hip_error(masp_hip_ctx* ctx, int rc, const char* what) {
 }
 }  // namespace detail
 
+// Rseed (masp_primitives/src/sapling.rs:643-647) and Note::rcm (:856-864): the note commitment randomness itself (BeforeZip212), or 32
+// seed bytes from which it is derived as jubjub::Fr::from_bytes_wide(PRF^expand(rseed, [0x04])), PRF^expand = BLAKE2b-512 personalised
+// "MASP__ExpandSeed" (masp_primitives/src/keys.rs:5-20)
+struct Rseed {
+    enum Kind { BeforeZip212, AfterZip212 } kind;
+    Bytes32 bytes;
+    static Rseed before_zip212(const Bytes32& rcm) { return Rseed{BeforeZip212, rcm}; }
+    static Rseed after_zip212(const Bytes32& rseed) { return Rseed{AfterZip212, rseed}; }
+    Bytes32 rcm() const {
+        if (kind == BeforeZip212) return bytes;
+        detail::Blake2b512 h("MASP__ExpandSeed");
+        h.update(bytes.data(), 32);
+        const uint8_t t = 0x04;
+        h.update(&t, 1);
+        uint8_t d[64];
+        h.finish(d);
+        uint64_t x[8];
+        for (int i = 0; i < 8; ++i) {
+            x[i] = 0;
+            for (int j = 7; j >= 0; --j) x[i] = (x[i] << 8) | d[8 * i + j];
+        }
+        Bytes32 out;
+        detail::store(detail::fs_reduce_wide(x), out.data());
+        return out;
+    }
+};
+
 // bsk / cv_sum of one transaction (sapling/prover.rs:26-47).  Independent of the proof bytes: the proofs of a transaction may be
 // produced in any order or in one batch as long as the accumulations happen.
 class SaplingProvingContext {
@@ -480,7 +507,7 @@ inline std::optional<std::array<uint8_t, 64>> SaplingProvingContext::binding_sig
 struct SpendInfo {
     ProofGenerationKey proof_generation_key;
     Diversifier diversifier;
-    Bytes32 rcm;  // Rseed as note.rcm()
+    Bytes32 rcm;  // note.rcm() = Rseed::rcm()
     Bytes32 ar;
     AssetType asset_type;
     uint64_t value;
@@ -599,9 +626,9 @@ class LocalTxProver {
 
     // ---- trait TxProver ----
     std::optional<SpendProof> spend_proof(SaplingProvingContext& ctx, const ProofGenerationKey& proof_generation_key, const Diversifier& diversifier,
-                                          const Bytes32& rseed, const Bytes32& ar, const AssetType& asset_type, uint64_t value, const Bytes32& anchor,
+                                          const Rseed& rseed, const Bytes32& ar, const AssetType& asset_type, uint64_t value, const Bytes32& anchor,
                                           const MerklePath& merkle_path, const Bytes32& rcv, const BlindingScalars* rs = nullptr) {
-        const SpendInfo d{proof_generation_key, diversifier, rseed, ar, asset_type, value, anchor, merkle_path, rcv};
+        const SpendInfo d{proof_generation_key, diversifier, rseed.rcm(), ar, asset_type, value, anchor, merkle_path, rcv};
         auto out = spend_proofs(ctx, &d, 1, rs);
         return out[0];
     }

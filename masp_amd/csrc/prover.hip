@@ -1318,9 +1318,14 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
             }
             hipStream_t s = sl.stream;
 #if MASP_UPLOAD_CHAIN
-            // (see masp_hip_ctx::upload_tail; the lock covers wait + enqueue + record so that the chain has one order)
-            std::lock_guard<std::mutex> upload_turn(ctx->upload_mu);
-            if (ctx->upload_tail && ctx->upload_tail != sl.ev_uploaded) ok = hipStreamWaitEvent(s, ctx->upload_tail, 0) == hipSuccess;
+            // (see masp_hip_ctx::upload_tail; the lock covers wait + enqueue + record so that the chain has one order.)  Not with
+            // lone_proof_graph: the tail is an event on ANOTHER slot's stream, and while that stream is being captured into a launch graph the
+            // runtime refuses the wait ("dependency created on uncaptured work in another stream") although the event was recorded before the
+            // capture began — 38 of 960 calls of three threads failed that way (profiles/r06_lone_graph_upload_chain_capture_isolation.txt)
+            const bool chain = ctx->opt.lone_proof_graph == 0;
+            std::unique_lock<std::mutex> upload_turn(ctx->upload_mu, std::defer_lock);
+            if (chain) upload_turn.lock();
+            if (chain && ctx->upload_tail && ctx->upload_tail != sl.ev_uploaded) ok = hipStreamWaitEvent(s, ctx->upload_tail, 0) == hipSuccess;
 #endif
             if (!ok) {
             } else if (any_staged) {
@@ -1339,10 +1344,10 @@ int masp_hip_prove_batch(masp_hip_ctx* ctx, size_t n, const masp_hip_job* jobs, 
             ok = ok && (!has_abc || hipMemcpyAsync(sl.abc.p, hs + w_bytes, abc_bytes, hipMemcpyHostToDevice, s) == hipSuccess) &&
                  hipMemcpyAsync(sl.rs.p, hs + w_bytes + abc_bytes, rs_bytes, hipMemcpyHostToDevice, s) == hipSuccess;
 #if MASP_UPLOAD_CHAIN
-            if (ok && hipEventRecord(sl.ev_uploaded, s) == hipSuccess) ctx->upload_tail = sl.ev_uploaded;
+            if (chain && ok && hipEventRecord(sl.ev_uploaded, s) == hipSuccess) ctx->upload_tail = sl.ev_uploaded;
 #endif
             if (!ok) {
-                last_hip_error() = "H2D copy failed";
+                last_hip_error() = std::string("H2D copy failed: ") + hipGetErrorString(hipGetLastError());
                 result = fail_shared(ctx, MASP_HIP_E_HIP);
             }
         }

@@ -34,6 +34,34 @@ def _int(x):
     return x if isinstance(x, int) else int.from_bytes(bytes(x), "little")
 
 
+class Rseed:
+    """`Rseed` (masp_primitives/src/sapling.rs:643-647) with `Note::rcm` (:856-864): BeforeZip212 holds the note commitment randomness itself,
+    AfterZip212 32 seed bytes from which it is derived — jubjub::Fr::from_bytes_wide(PRF^expand(rseed, [0x04])), PRF^expand = BLAKE2b-512
+    personalised "MASP__ExpandSeed" (masp_primitives/src/keys.rs:5-20).  `spend_proof` takes one of these, or rcm as an int / 32 bytes."""
+
+    def __init__(self, kind, value):
+        assert kind in ("BeforeZip212", "AfterZip212")
+        self.kind, self.value = kind, value
+
+    @classmethod
+    def before_zip212(cls, rcm):
+        return cls("BeforeZip212", rcm)
+
+    @classmethod
+    def after_zip212(cls, rseed):
+        assert len(bytes(rseed)) == 32
+        return cls("AfterZip212", bytes(rseed))
+
+    def rcm(self):
+        if self.kind == "BeforeZip212":
+            return self.value
+        import hashlib
+        h = hashlib.blake2b(digest_size=64, person=b"MASP__ExpandSeed")
+        h.update(self.value)
+        h.update(b"\x04")
+        return int.from_bytes(h.digest(), "little") % RJ
+
+
 class SaplingProvingContext:
     """bsk / cv_sum bookkeeping of one transaction (sapling/prover.rs:26-47, :69-75, :154, :177-183, :205, :228-234, :272).
 
@@ -508,7 +536,9 @@ class LocalTxProver:
 
     # ---- the TxProver methods ----
     def spend_proof(self, ctx, proof_generation_key, diversifier, rseed, ar, asset_type, value, anchor, merkle_path, rcv, rs=None):
-        """-> (zkproof[192], cv, rk).  `rseed` is the note commitment randomness rcm = note.rcm() (Rseed::BeforeZip212 form)."""
+        """-> (zkproof[192], cv, rk).  `rseed`: an `Rseed`, or the note commitment randomness rcm = note.rcm() itself (the BeforeZip212 form)."""
+        if isinstance(rseed, Rseed):
+            rseed = rseed.rcm()                                                # note.rcm() (sapling/prover.rs:95-101 builds the note from rseed)
         ctx._bsk_add(rcv)                                                      # :69-75, before anything can fail
         job = self.prepare_spend(proof_generation_key, diversifier, rseed, ar, asset_type, value, anchor, merkle_path, rcv)
         try:

@@ -132,6 +132,10 @@ static int selftest(const char* path) {
             const SaplingProvingContext ctx = SaplingProvingContext::from_parts(unhex32(a), unhex32(cv));
             const auto sig = ctx.binding_sig(amount, unhex32(sh).data(), t);
             std::printf("sig %s\n", sig ? hex(sig->data(), 64).c_str() : "None");
+        } else if (op == "rcm") {  // Note::rcm of Rseed::AfterZip212(<32 bytes>)
+            in >> a;
+            const Bytes32 r = Rseed::after_zip212(unhex32(a)).rcm();
+            std::printf("rcm %s\n", hex(r.data(), 32).c_str());
         } else if (op == "random") {
             int n = 0, bad = 0, distinct = 1;
             in >> n;
@@ -265,7 +269,7 @@ int main(int argc, char** argv) {
             try {
                 if (r.kind == MASP_HIP_SPEND) {
                     const SpendInfo& s = r.spend;
-                    auto got = prover->spend_proof(ctx, s.proof_generation_key, s.diversifier, s.rcm, s.ar, s.asset_type, s.value, s.anchor, s.merkle_path, s.rcv, &r.rs);
+                    auto got = prover->spend_proof(ctx, s.proof_generation_key, s.diversifier, Rseed::before_zip212(s.rcm), s.ar, s.asset_type, s.value, s.anchor, s.merkle_path, s.rcv, &r.rs);
                     if (got) r.status = 1, r.zk = got->zkproof, r.cv = got->cv, r.rk = got->rk;
                 } else if (r.kind == MASP_HIP_OUTPUT) {
                     const OutputInfo& o = r.output;

@@ -94,7 +94,11 @@ def test_lone_graphs_from_concurrent_threads():
 
         def work(t):
             for k in range(t, 24, 3):
-                got = ctx.prove_batch([(2, inputs, aux, 100 + k, 200 + k)])
+                try:                                           # (an exception in a thread is no test failure by itself: round 6 had a call fail here
+                    got = ctx.prove_batch([(2, inputs, aux, 100 + k, 200 + k)])   # now and then — the upload chain's wait on a stream under capture — unnoticed)
+                except Exception as e:                         # noqa: BLE001
+                    bad.append((k, str(e)))
+                    continue
                 if got != [want[k]]:
                     bad.append(k)
         th = [threading.Thread(target=work, args=(t,)) for t in range(3)]

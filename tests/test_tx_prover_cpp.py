@@ -46,7 +46,9 @@ def test_the_header_compiles_as_strict_cxx17_and_its_scalar_helpers_agree_with_p
     lines = []
     for a, b in pairs:
         lines += ["add %s %s" % (_b32(a).hex(), _b32(b).hex()), "sub %s %s" % (_b32(a).hex(), _b32(b).hex())]
-    lines += ["pack " + p.hex() for p in packs] + ["random 2000"]
+    lines += ["pack " + p.hex() for p in packs]
+    seeds = [bytes(32), b"\xff" * 32] + [bytes(rng.getrandbits(8) for _ in range(32)) for _ in range(6)]
+    lines += ["rcm " + x.hex() for x in seeds] + ["random 2000"]
     vec = tmp_path / "vectors.txt"
     vec.write_text("\n".join(lines) + "\n")
     out = subprocess.run([exe, "--selftest", str(vec)], capture_output=True, text=True, timeout=120)
@@ -60,6 +62,11 @@ def test_the_header_compiles_as_strict_cxx17_and_its_scalar_helpers_agree_with_p
         want = H.multipack(p)
         assert got[k] == "pack %s %s" % (_b32(want[0]).hex(), _b32(want[1]).hex()), p.hex()
         k += 1
+    from masp_amd.prover import Rseed
+    for x in seeds:                                           # Note::rcm of Rseed::AfterZip212 (sapling.rs:856-864): the two mirrors agree (the reference holds no vector for it)
+        assert got[k] == "rcm " + _b32(Rseed.after_zip212(x).rcm()).hex(), x.hex()
+        k += 1
+    assert Rseed.before_zip212(7).rcm() == 7
     assert got[k] == "random 2000 canonical 2000 distinct 2000"
     assert got[k + 1] == "default location none"              # with_default_location (prover.rs:120-136): None without the folder
     assert got[k + 2] == "context %s %s" % (_b32(0).hex(), H.JUBJUB_IDENTITY.hex())
@@ -95,7 +102,7 @@ def _python_results(lp, descs, rs):
     for (kind, kw), (r, s) in zip(descs, rs):
         try:
             if kind == "spend":
-                zk, cv, rk = lp.spend_proof(pc, kw["proof_generation_key"], kw["diversifier"], kw["rcm"], kw["ar"], kw["asset_type"], kw["value"],
+                zk, cv, rk = lp.spend_proof(pc, kw["proof_generation_key"], kw["diversifier"], P.Rseed.before_zip212(kw["rcm"]), kw["ar"], kw["asset_type"], kw["value"],
                                             kw["anchor"], kw["merkle_path"], kw["rcv"], rs=(r, s))
             elif kind == "output":
                 zk, cv = lp.output_proof(pc, kw["esk"], kw["payment_address"], kw["rcm"], kw["asset_type"], kw["value"], kw["rcv"], rs=(r, s))
