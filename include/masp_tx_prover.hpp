@@ -571,6 +571,8 @@ struct LocalTxProverConfig {
     const masp_hip_options* options = nullptr;  // slots, batch_cap, ... (nullptr: the library's defaults)
     unsigned threads = 0;                       // synthesis threads of the *_proofs batch methods (0: the CPUs this process may use)
     const ExpectedParameterSet* expected = &masp_mpc_parameters();  // nullptr: parameters that are not the MPC files (benches, tests)
+    unsigned calls_in_flight = 0;               // masp_hip_prove_batch calls of the *_proofs methods at a time (0: slots + 1 — one waits inside the
+                                                // library for the slot that frees next)
     bool trace = false;                         // one line per batch on stderr: when it was synthesised, got a slot, was proved, verified, committed
 };
 
@@ -818,7 +820,7 @@ class LocalTxProver {
             if ((rc = masp_hip_ctx_get_options(ctx_, &got)) != MASP_HIP_OK) throw Panic(detail::hip_error(ctx_, rc, "masp_hip_ctx_get_options"));
             batch_cap_ = (size_t)got.batch_cap;
             slots_ = (size_t)got.slots;
-            permits_.resize(slots_);
+            permits_.resize(cfg_.calls_in_flight ? cfg_.calls_in_flight : slots_ + 1);
             const uint8_t* params[3] = {spend, output, convert};
             const size_t lens[3] = {spend_len, output_len, convert_len};
             for (int k = 0; k < 3; ++k) load_circuit(k, params[k], lens[k]);
@@ -895,7 +897,8 @@ class LocalTxProver {
     }
 
     // One circuit's descriptions in batches of batch_cap: the host threads synthesise batch k + 1 while batches <= k prove — up to
-    // slots + 2 batches handed over at a time: `slots` of them on a slot of the context each, two waiting for one, so that a slot
+    // slots + 3 batches handed over at a time: `slots` of them on a slot of the context each, one inside the library waiting for the next
+    // free slot, two behind it, so that a slot
     // that finishes never waits for a synthesis (each waiting batch holds its page-locked slab: 0.8 GB for 256 Spends); results
     // committed in description order.
     //   synth(lo, cnt, inputs, aux, cv, rc): witnesses of descriptions [lo, lo + cnt) — called from several threads on disjoint ranges
@@ -1039,7 +1042,7 @@ class LocalTxProver {
                         B->any_valid = true;
                     }
                 });
-                while (flying.size() > slots_ + 2) land();
+                while (flying.size() > slots_ + 3) land();
             }
             while (!flying.empty()) land();
         } catch (...) {

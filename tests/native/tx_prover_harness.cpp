@@ -215,6 +215,7 @@ int main(int argc, char** argv) {
     cfg.options = &opt;
     cfg.expected = nullptr;  // the case's parameters are synthetic
     cfg.trace = std::getenv("MASP_TXP_TRACE") != nullptr;
+    if (const char* v = std::getenv("MASP_TXP_CALLS")) cfg.calls_in_flight = (unsigned)std::atoi(v);
     const uint32_t mode = rd.num<uint32_t>(), n = rd.num<uint32_t>();
     std::vector<Record> recs(n);
     for (Record& r : recs) {
