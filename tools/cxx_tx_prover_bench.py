@@ -29,7 +29,7 @@ rng = random.Random(3)
 blob = bytearray(b"MTP1")
 for p in params:
     blob += struct.pack("<Q", p.size) + p.tobytes()
-blob += struct.pack("<IIIII", 1, int(os.environ.get("MASP_TXP_THREADS", "0")), 0, 2, len(descs))
+blob += struct.pack("<IIIII", int(os.environ.get("MASP_TXP_SELF_VERIFY", "1")), int(os.environ.get("MASP_TXP_THREADS", "0")), 0, 2, len(descs))
 for kind, kw in descs:
     blob += T._record(kind, kw, rng.randrange(H.FR_MODULUS), rng.randrange(H.FR_MODULUS))
 with tempfile.TemporaryDirectory() as d:
