@@ -839,7 +839,9 @@ class LocalTxProver {
     void release() {  // (a verifying key goes before its context: masp_hip.h)
         for (int k = 0; k < 3; ++k) {
             for (uint8_t* p : pool_[k]) masp_hip_host_free(ctx_, p);
+            for (uint8_t* p : pool_one_[k]) masp_hip_host_free(ctx_, p);
             pool_[k].clear();
+            pool_one_[k].clear();
             if (gpu_vk_[k]) masp_hip_vk_free(gpu_vk_[k]);
             if (host_vk_[k]) masp_host_vk_free(host_vk_[k]);
             gpu_vk_[k] = nullptr;
@@ -877,23 +879,25 @@ class LocalTxProver {
         if (rc != MASP_HIP_OK) throw Panic(detail::hip_error(ctx_, rc, "masp_hip_circuit_load"));  // the reference panics on undecodable parameters (lib.rs:337)
     }
 
-    // page-locked slabs of batch_cap aux assignments per circuit: the synthesizer writes where the DMA engine reads
-    uint8_t* slab_take(int kind) {
+    // page-locked slabs of aux assignments per circuit — room for batch_cap of them, or for one (the trait's single-description methods
+    // must not page-lock 0.8 GB for one Spend): the synthesizer writes where the DMA engine reads
+    uint8_t* slab_take(int kind, bool single = false) {
+        std::vector<uint8_t*>& pool = single ? pool_one_[kind] : pool_[kind];
         {
             std::lock_guard<std::mutex> g(pool_mu_);
-            if (!pool_[kind].empty()) {
-                uint8_t* p = pool_[kind].back();
-                pool_[kind].pop_back();
+            if (!pool.empty()) {
+                uint8_t* p = pool.back();
+                pool.pop_back();
                 return p;
             }
         }
-        void* p = masp_hip_host_alloc(ctx_, batch_cap_ * 32 * (size_t)n_aux_[kind]);
+        void* p = masp_hip_host_alloc(ctx_, (single ? 1 : batch_cap_) * 32 * (size_t)n_aux_[kind]);
         if (!p) throw Panic("masp_hip_host_alloc failed");
         return static_cast<uint8_t*>(p);
     }
-    void slab_give(int kind, uint8_t* p) {
+    void slab_give(int kind, uint8_t* p, bool single = false) {
         std::lock_guard<std::mutex> g(pool_mu_);
-        pool_[kind].push_back(p);
+        (single ? pool_one_[kind] : pool_[kind]).push_back(p);
     }
 
     // One circuit's descriptions in batches of batch_cap: the host threads synthesise batch k + 1 while batches <= k prove — up to
@@ -924,6 +928,7 @@ class LocalTxProver {
             std::future<void> proving;
         };
         const size_t cap = batch_cap_, nin = n_inputs_[kind], naux = n_aux_[kind];
+        const bool single = n == 1;
         const auto t_begin = std::chrono::steady_clock::now();
         auto now = [t_begin]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
         const unsigned threads = cfg_.threads ? cfg_.threads : detail::effective_cpus();
@@ -932,9 +937,9 @@ class LocalTxProver {
             std::unique_ptr<Batch> b = std::move(flying.front());
             flying.pop_front();
             struct Give {
-                LocalTxProver* p; int kind; uint8_t* s;
-                ~Give() { p->slab_give(kind, s); }
-            } give{this, kind, b->aux};
+                LocalTxProver* p; int kind; uint8_t* s; bool single;
+                ~Give() { p->slab_give(kind, s, single); }
+            } give{this, kind, b->aux, single};
             b->proving.get();  // (rethrows a Panic of the proving thread)
             for (size_t k = 0; k < b->cnt; ++k)
                 if (b->valid[k]) {
@@ -954,7 +959,7 @@ class LocalTxProver {
                 std::unique_ptr<Batch> b(new Batch);
                 b->lo = lo;
                 b->cnt = std::min(cap, n - lo);
-                b->aux = slab_take(kind);
+                b->aux = slab_take(kind, single);
                 b->inputs.resize(b->cnt * 32 * nin);
                 b->proofs.resize(b->cnt * GROTH_PROOF_SIZE);
                 b->cv.resize(b->cnt);
@@ -1053,7 +1058,7 @@ class LocalTxProver {
                     permits_.acquire(b->ticket);
                     permits_.release();
                 }
-                slab_give(kind, b->aux);
+                slab_give(kind, b->aux, single);
             }
             throw;
         }
@@ -1066,7 +1071,7 @@ class LocalTxProver {
     void* host_vk_[3] = {nullptr, nullptr, nullptr};
     masp_hip_vk* gpu_vk_[3] = {nullptr, nullptr, nullptr};
     std::mutex pool_mu_;
-    std::vector<uint8_t*> pool_[3];
+    std::vector<uint8_t*> pool_[3], pool_one_[3];
     detail::FifoPermits permits_;
 };
 
