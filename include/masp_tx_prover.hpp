@@ -567,6 +567,7 @@ using Progress = std::function<void(size_t done, size_t total)>;
 
 struct LocalTxProverConfig {
     int device = 0;
+    std::vector<int> devices;                   // more than one GPU: the HIP devices of one multi-device context (empty: `device` alone)
     bool self_verify = true;                    // sapling/prover.rs:148,266 (tests of the failure paths switch it off)
     const masp_hip_options* options = nullptr;  // slots, batch_cap, ... (nullptr: the library's defaults)
     unsigned threads = 0;                       // synthesis threads of the *_proofs batch methods (0: the CPUs this process may use)
@@ -810,8 +811,10 @@ class LocalTxProver {
             std::memset(&opt, 0, sizeof opt);  // every field: 0 = the default
         }
         opt.struct_size = sizeof(masp_hip_options);
-        const int dev = cfg.device;
-        int rc = masp_hip_ctx_create_ex(&dev, 1, &opt, &ctx_);
+        // one context over one GPU, or over every GPU listed: the library then deals the batches of a call to the devices from one queue and
+        // finishes on the others when one fails (masp_hip.h: masp_hip_ctx_create_ex)
+        std::vector<int> devs = cfg.devices.empty() ? std::vector<int>{cfg.device} : cfg.devices;
+        int rc = masp_hip_ctx_create_ex(devs.data(), (int)devs.size(), &opt, &ctx_);
         if (rc != MASP_HIP_OK) throw Panic(detail::hip_error(nullptr, rc, "masp_hip_ctx_create_ex"));
         try {
             masp_hip_options got;
@@ -819,7 +822,7 @@ class LocalTxProver {
             got.struct_size = sizeof got;
             if ((rc = masp_hip_ctx_get_options(ctx_, &got)) != MASP_HIP_OK) throw Panic(detail::hip_error(ctx_, rc, "masp_hip_ctx_get_options"));
             batch_cap_ = (size_t)got.batch_cap;
-            slots_ = (size_t)got.slots;
+            slots_ = (size_t)got.slots * devs.size();   // batches that prove side by side: `slots` per device
             permits_.resize(cfg_.calls_in_flight ? cfg_.calls_in_flight : slots_ + 1);
             const uint8_t* params[3] = {spend, output, convert};
             const size_t lens[3] = {spend_len, output_len, convert_len};

@@ -215,6 +215,14 @@ int main(int argc, char** argv) {
     cfg.options = &opt;
     cfg.expected = nullptr;  // the case's parameters are synthetic
     cfg.trace = std::getenv("MASP_TXP_TRACE") != nullptr;
+    if (const char* v = std::getenv("MASP_TXP_DEVICES")) {  // "0,1,...": one prover over several GPUs (the same one twice on a one-GPU box)
+        for (const char* p = v; *p;) {
+            cfg.devices.push_back(std::atoi(p));
+            while (*p && *p != ',') ++p;
+            if (*p) ++p;
+        }
+        if (cfg.devices.size() > 1) opt.slots = 1, opt.bucket_tree_sub_batch = 32;  // (two contexts' scratch on one device in the test)
+    }
     if (const char* v = std::getenv("MASP_TXP_CALLS")) cfg.calls_in_flight = (unsigned)std::atoi(v);
     const uint32_t mode = rd.num<uint32_t>(), n = rd.num<uint32_t>();
     std::vector<Record> recs(n);
@@ -262,7 +270,8 @@ int main(int argc, char** argv) {
         std::printf("panic at load: %s\n", e.what());
         return 3;
     }
-    std::printf("loaded: batch_cap %zu, host threads %u\n", prover->batch_cap(), cfg.threads ? cfg.threads : detail::effective_cpus());
+    std::printf("loaded: batch_cap %zu, host threads %u, devices %d\n", prover->batch_cap(), cfg.threads ? cfg.threads : detail::effective_cpus(),
+                masp_hip_ctx_device_count(prover->context()));
     SaplingProvingContext ctx = prover->new_sapling_proving_context();
     size_t some = 0, none = 0, panics = 0;
     if (mode == 0) {

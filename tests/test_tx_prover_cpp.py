@@ -147,7 +147,7 @@ def _descriptions(n_spend, n_output, n_convert, seed):
     return descs
 
 
-def _run_case(tmp_path, lp, descs, rs, mode, batch_cap, threads):
+def _run_case(tmp_path, lp, descs, rs, mode, batch_cap, threads, devices=None):
     blob = bytearray(b"MTP1")
     for k in ("spend", "output", "convert"):
         p = lp.parameters[k]
@@ -158,6 +158,8 @@ def _run_case(tmp_path, lp, descs, rs, mode, batch_cap, threads):
     case, out = tmp_path / ("case%d.bin" % mode), tmp_path / ("out%d.bin" % mode)
     case.write_bytes(bytes(blob))
     env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    if devices:
+        env["MASP_TXP_DEVICES"] = devices
     run = subprocess.run([_build(), str(case), str(out)], capture_output=True, text=True, timeout=900, env=env)
     assert run.returncode == 0, run.stdout + run.stderr
     got = out.read_bytes()
@@ -292,8 +294,11 @@ def test_a_cxx_program_holds_a_local_tx_prover_and_gets_the_python_mirrors_bytes
     good = [(lp.parameters[k].size, hashlib.blake2b(lp.parameters[k].tobytes(), digest_size=64).hexdigest()) for k in ("spend", "output", "convert")]
     assert _load(_build(), paths, good) == "loaded"
     assert "BLAKE2b-512 digest" in _load(_build(), paths, [good[0], (good[1][0], good[0][1]), good[2]])
-    for mode, cap, threads in ((0, 0, 1), (1, 8, 4)):
-        recs, got_bsk, got_cv_sum, log = _run_case(tmp_path, lp, descs, rs, mode, cap, threads)
+    # ... one description at a time; the batch methods; the batch methods on a prover over two device contexts (this GPU listed twice: the
+    # library deals the batches to them from one queue)
+    for mode, cap, threads, devices in ((0, 0, 1, None), (1, 8, 4, None), (1, 8, 4, "0,0")):
+        recs, got_bsk, got_cv_sum, log = _run_case(tmp_path, lp, descs, rs, mode, cap, threads, devices)
+        assert ("devices 2" if devices else "devices 1") in log, log
         for i, (g, w) in enumerate(zip(recs, want)):
             assert g[0] == w[0], "description %d (%s): status %d, the Python mirror says %d\n%s" % (i, descs[i][0], g[0], w[0], log)
             assert g[1:] == w[1:], "description %d (%s), mode %d: bytes differ from the Python mirror" % (i, descs[i][0], mode)
