@@ -326,6 +326,39 @@ int main(int argc, char** argv) {
             const auto c = prover->convert_proofs(ctx, co.data(), co.size(), rs[2].data());
             for (size_t q = 0; q < c.size(); ++q)
                 if (c[q]) recs[at[2][q]].status = 1, recs[at[2][q]].zk = c[q]->zkproof, recs[at[2][q]].cv = c[q]->cv;
+            // ... and the same prover shared by three threads, each with a context of its own (the reference's `&self` methods): four rounds of
+            // the three calls per thread, in different orders — every result and every context must equal the ones above
+            std::atomic<size_t> calls3{0}, diffs{0};
+            auto same_sp = [](const std::optional<SpendProof>& x, const std::optional<SpendProof>& y) {
+                return x.has_value() == y.has_value() && (!x || (x->zkproof == y->zkproof && x->cv == y->cv && x->rk == y->rk));
+            };
+            auto same_vp = [](const std::optional<ValueProof>& x, const std::optional<ValueProof>& y) {
+                return x.has_value() == y.has_value() && (!x || (x->zkproof == y->zkproof && x->cv == y->cv));
+            };
+            auto user = [&](int t) {
+                for (int round = 0; round < 4; ++round) {
+                    SaplingProvingContext mine = prover->new_sapling_proving_context();
+                    for (int step = 0; step < 3; ++step) {
+                        const int k = (step + t + round) % 3;
+                        if (k == 0) {
+                            const auto x = prover->spend_proofs(mine, sp.data(), sp.size(), rs[0].data());
+                            for (size_t q = 0; q < x.size(); ++q) diffs += !same_sp(x[q], a[q]);
+                        } else if (k == 1) {
+                            const auto x = prover->output_proofs(mine, ou.data(), ou.size(), rs[1].data());
+                            for (size_t q = 0; q < x.size(); ++q) diffs += !same_vp(x[q], b[q]);
+                        } else {
+                            const auto x = prover->convert_proofs(mine, co.data(), co.size(), rs[2].data());
+                            for (size_t q = 0; q < x.size(); ++q) diffs += !same_vp(x[q], c[q]);
+                        }
+                        ++calls3;
+                    }
+                    diffs += mine.bsk() != ctx.bsk() || mine.cv_sum() != ctx.cv_sum();
+                }
+            };
+            std::vector<std::future<void>> users;
+            for (int t = 0; t < 3; ++t) users.push_back(std::async(std::launch::async, user, t));
+            for (auto& u : users) u.get();
+            std::printf("shared by 3 threads: %zu calls, %zu differences\n", calls3.load(), diffs.load());
         } catch (const Panic& e) {
             std::printf("panic: %s\n", e.what());
             return 3;

@@ -306,3 +306,4 @@ def test_a_cxx_program_holds_a_local_tx_prover_and_gets_the_python_mirrors_bytes
         assert "Some %d, None 3, Panic 0" % (len(descs) - 3) in log
         if mode == 1:                                            # 21 Spend descriptions in batches of 8: the builder's Progress after each
             assert "batch_cap 8" in log and "progress: 3 calls, last 21 of 21" in log, log
+            assert "shared by 3 threads: 36 calls, 0 differences" in log, log       # one prover, three threads, a context each
